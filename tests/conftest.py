@@ -1,0 +1,46 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False))
+
+
+@pytest.fixture(scope='session')
+def golden():
+    return load_golden
+
+
+# kwargs of every tiny fixture written by tools/gen_golden.py
+TINY_BASE = dict(n_classes=7, depth=3, wf=2, batch_norm=True, padding=True, do_res=True, block_depth=2)
+TINY_CFGS = {
+    'tiny_sc_l14': dict(TINY_BASE, max_pool=False, num_lands=14),
+    'tiny_mp_l0': dict(TINY_BASE, max_pool=True, num_lands=0),
+    'tiny_mp_l14': dict(TINY_BASE, max_pool=True, num_lands=14),
+    'tiny_valid_nores': dict(n_classes=7, depth=2, wf=2, batch_norm=True, padding=False, do_res=False,
+                             block_depth=2, max_pool=True, num_lands=0),
+    'tiny_nobn_d1': dict(n_classes=3, depth=2, wf=3, batch_norm=False, padding=True, do_res=True,
+                         block_depth=1, max_pool=False, num_lands=14),
+    'tiny_nobn_nores': dict(n_classes=3, depth=2, wf=3, batch_norm=False, padding=True, do_res=False,
+                            block_depth=2, max_pool=False, num_lands=0),
+    'tiny_bd3_nosm': dict(n_classes=5, depth=2, wf=3, batch_norm=True, padding=True, do_res=True,
+                          block_depth=3, max_pool=True, num_lands=0, do_soft_max=False),
+}
+PAPER_CFGS = {
+    'paper_sc_l14': (1234, dict(n_classes=7, depth=6, wf=5, batch_norm=True, padding=True, max_pool=False,
+                                num_lands=14, do_res=True, block_depth=2)),
+    'paper_mp_l0': (1235, dict(n_classes=7, depth=6, wf=5, batch_norm=True, padding=True, max_pool=True,
+                               num_lands=0, do_res=True, block_depth=2)),
+}

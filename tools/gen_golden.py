@@ -1,0 +1,462 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures under tests/golden/ by RUNNING THE REFERENCE in this container.
+
+Dev-only: needs /root/reference (absent on the GPU box).  It imports the reference's own modules
+(unet, dice, ncc, util, warm_restarts_lr, dataset) from /root/reference/train_test_code with stub
+h5py/torchvision modules (neither is installed; recipe: SURVEY.md Appendix G) and stores inputs and
+expected outputs only -- no reference source text is stored.
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py
+"""
+import hashlib
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = '/root/reference/train_test_code'
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden')
+sys.dont_write_bytecode = True
+
+
+# ----------------------------------------------------------------------------- stubs
+class _FakeDS:
+    def __init__(self, arr):
+        self._a = arr
+
+    def __getitem__(self, k):
+        return self._a[k] if not (isinstance(k, tuple) and len(k) == 0) else self._a
+
+    @property
+    def shape(self):
+        return self._a.shape
+
+
+class _FakeGroup(dict):
+    def __getitem__(self, k):
+        if '/' in k:
+            head, rest = k.split('/', 1)
+            return dict.__getitem__(self, head)[rest]
+        return dict.__getitem__(self, k)
+
+
+FAKE_FILES = {}
+
+
+class _FakeFile(_FakeGroup):
+    def __init__(self, path, mode='r'):
+        super().__init__(FAKE_FILES[path])
+
+    def close(self):
+        pass
+
+
+def install_stubs():
+    h5 = types.ModuleType('h5py')
+    h5.File = _FakeFile
+    sys.modules['h5py'] = h5
+    tv = types.ModuleType('torchvision')
+    tvt = types.ModuleType('torchvision.transforms')
+    tvf = types.ModuleType('torchvision.transforms.functional')
+    tvt.InterpolationMode = object
+    tvt.functional = tvf
+    tv.transforms = tvt
+    sys.modules['torchvision'] = tv
+    sys.modules['torchvision.transforms'] = tvt
+    sys.modules['torchvision.transforms.functional'] = tvf
+
+
+def sha(t):
+    return hashlib.sha256(t.detach().cpu().contiguous().numpy().tobytes()).hexdigest()
+
+
+def np32(t):
+    return t.detach().cpu().numpy()
+
+
+# ----------------------------------------------------------------------------- synthetic data
+def toy_ellipses(n, H, W, seed, num_lands=14):
+    """Seeded synthetic 'fluoro' images: background noise + 6 axis-aligned ellipses (labels 1..6).
+    Returns projs [n,H,W] f32, segs [n,H,W] u8, lands [n,2,L] f32 (row 0 = col, row 1 = row)."""
+    g = torch.Generator().manual_seed(seed)
+    projs = 0.1 * torch.randn(n, H, W, generator=g)
+    segs = torch.zeros(n, H, W, dtype=torch.uint8)
+    lands = torch.zeros(n, 2, num_lands)
+    Y, X = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing='ij')
+    for i in range(n):
+        for c in range(1, 7):
+            cx = float(torch.rand(1, generator=g)) * (W * 0.6) + W * 0.2
+            cy = float(torch.rand(1, generator=g)) * (H * 0.6) + H * 0.2
+            rx = float(torch.rand(1, generator=g)) * (W * 0.10) + W * 0.05
+            ry = float(torch.rand(1, generator=g)) * (H * 0.10) + H * 0.05
+            m = ((X - cx) / rx) ** 2 + ((Y - cy) / ry) ** 2 <= 1.0
+            segs[i][m] = c
+            projs[i][m] += 0.3 * c
+            lands[i, 0, c - 1] = cx
+            lands[i, 1, c - 1] = cy
+            lands[i, 0, 6 + c - 1] = cx
+            lands[i, 1, 6 + c - 1] = cy - ry
+        lands[i, 0, 12], lands[i, 1, 12] = W * 0.25, H * 0.25
+        lands[i, 0, 13], lands[i, 1, 13] = -5.0, H * 0.5        # out of bounds on purpose
+    return projs, segs, lands
+
+
+# ----------------------------------------------------------------------------- fixtures
+def fixture_tiny(unet, dice, util, name, seed, hp=24, bwd=True, **kw):
+    """Tiny preset: full state_dict, input, every block output, outputs, losses, all grads."""
+    torch.manual_seed(seed)
+    net = unet.UNet(**kw)
+    num_lands = kw.get('num_lands', 0)
+    ncls = kw['n_classes']
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.randn(2, 1, hp, hp, generator=g)
+    net.train()
+    # perturb BN affine + running stats so they are not the trivial 1/0
+    with torch.no_grad():
+        for n_, p in net.named_parameters():
+            if p.dim() == 1 and ('block.2' in n_ or 'block.5' in n_):
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+    acts = {}
+    hooks = []
+    for i, m in enumerate(net.down_path):
+        hooks.append(m.register_forward_hook(lambda mod, inp, out, k='down%d' % i: acts.__setitem__(k, out.detach().clone())))
+    for i, m in enumerate(net.up_path):
+        hooks.append(m.register_forward_hook(lambda mod, inp, out, k='up%d' % i: acts.__setitem__(k, out.detach().clone())))
+    sd0 = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    out = net(x)
+    for h in hooks:
+        h.remove()
+    seg = out[0] if num_lands > 0 else out
+    Ho, Wo = seg.shape[-2], seg.shape[-1]
+    Ht, Wt = Ho - 4, Wo - 4           # targets smaller than the output => exercises center_crop
+    lab = torch.randint(0, ncls, (2, Ht, Wt), generator=g)
+    tseg = torch.stack([(lab == c) for c in range(ncls)], 1).float()
+    res = {'x': np32(x), 'tseg': np32(tseg), 'seg': np32(seg)}
+    if num_lands > 0:
+        theat = torch.rand(2, num_lands, Ht, Wt, generator=g) * 0.02
+        crit = dice.DiceAndHeatMapLoss2D(skip_bg=False, heatmap_wgt=0.5)
+        loss = crit((util.center_crop(seg, tseg.shape), util.center_crop(out[1], theat.shape)), (tseg, theat))
+        res['theat'] = np32(theat)
+        res['heat'] = np32(out[1])
+    else:
+        crit = dice.DiceLoss2D(skip_bg=False)
+        loss = crit(util.center_crop(seg, tseg.shape), tseg)
+    if bwd:
+        loss.backward()   # (the reference cannot back-propagate without BN when do_res=True: in-place add on a ReLU output)
+    res['loss'] = np.array(loss.item(), dtype=np.float64)
+    for k, v in sd0.items():
+        res['sd0/' + k] = np32(v)
+    for k, v in net.state_dict().items():
+        if 'running' in k or 'num_batches' in k:
+            res['sd1/' + k] = np32(v)       # BN buffers after one training forward
+    keep = ('down0', 'down%d' % (kw['depth'] - 1), 'up%d' % (kw['depth'] - 2))
+    for k, v in acts.items():
+        if k in keep:
+            res['act/' + k] = np32(v)
+    if bwd:
+        for k, p in net.named_parameters():
+            res['grad/' + k] = np32(p.grad) if p.grad is not None else np.zeros(0, dtype=np.float32)
+    # eval-mode forward with the updated running stats
+    net.eval()
+    with torch.no_grad():
+        oe = net(x)
+    res['seg_eval'] = np32(oe[0] if num_lands > 0 else oe)
+    if num_lands > 0:
+        res['heat_eval'] = np32(oe[1])
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **res)
+    print(name, 'loss', loss.item(), 'keys', len(res))
+
+
+def fixture_paper(unet, dice, util, name, seed, max_pool, num_lands):
+    """Paper preset: init hashes, strided output samples, argmax map, loss, grad norms (fp32 + fp64)."""
+    kw = dict(n_classes=7, depth=6, wf=5, batch_norm=True, padding=True, max_pool=max_pool,
+              num_lands=num_lands, do_res=True, block_depth=2)
+    torch.manual_seed(seed)
+    net = unet.UNet(**kw)
+    res = {}
+    names = list(net.state_dict().keys())
+    res['sd_names'] = np.array(names)
+    res['sd_sha'] = np.array([sha(v) for v in net.state_dict().values()])
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.randn(2, 1, 192, 192, generator=g)
+    lab = torch.randint(0, 7, (2, 184, 184), generator=g)
+    tseg = torch.stack([(lab == c) for c in range(7)], 1).float()
+    theat = torch.rand(2, 14, 184, 184, generator=g) * 0.02
+    res['x_sha'] = np.array(sha(x))
+    res['lab'] = lab.to(torch.uint8).numpy()
+    res['theat_sha'] = np.array(sha(theat))
+
+    def run(net_, dt):
+        net_.train()
+        for p in net_.parameters():
+            p.grad = None
+        out = net_(x.to(dt))
+        seg = out[0] if num_lands > 0 else out
+        if num_lands > 0:
+            crit = dice.DiceAndHeatMapLoss2D(skip_bg=False, heatmap_wgt=0.5)
+            loss = crit((util.center_crop(seg, tseg.shape), util.center_crop(out[1], theat.shape)),
+                        (tseg.to(dt), theat.to(dt)))
+        else:
+            loss = dice.DiceLoss2D(skip_bg=False)(util.center_crop(seg, tseg.shape), tseg.to(dt))
+        loss.backward()
+        return out, loss
+
+    out32, loss32 = run(net, torch.float32)
+    seg32 = out32[0] if num_lands > 0 else out32
+    gn32 = {k: p.grad.double().norm().item() if p.grad is not None else -1.0 for k, p in net.named_parameters()}
+    import copy
+    net64 = copy.deepcopy(net).double()
+    # deepcopy after a training forward has updated running stats; harmless for a train-mode forward
+    out64, loss64 = run(net64, torch.float64)
+    seg64 = out64[0] if num_lands > 0 else out64
+    gn64 = {k: p.grad.norm().item() if p.grad is not None else -1.0 for k, p in net64.named_parameters()}
+    res['seg_s16'] = np32(seg32[:, :, ::16, ::16])
+    res['seg64_s16'] = seg64[:, :, ::16, ::16].detach().numpy()
+    top2 = torch.topk(seg64, 2, dim=1)[0]
+    res['argmax64'] = torch.max(seg64, dim=1)[1].to(torch.uint8).numpy()
+    res['argmax32'] = torch.max(seg32, dim=1)[1].to(torch.uint8).numpy()
+    res['margin_lt_1e5'] = np.packbits(((top2[:, 0] - top2[:, 1]) < 1e-5).numpy())
+    if num_lands > 0:
+        res['heat_s16'] = np32(out32[1][:, :, ::16, ::16])
+        res['heat64_s16'] = out64[1][:, :, ::16, ::16].detach().numpy()
+    res['loss32'] = np.array(loss32.item())
+    res['loss64'] = np.array(loss64.item())
+    pn = [k for k, _ in net.named_parameters()]
+    res['param_names'] = np.array(pn)
+    res['gradnorm32'] = np.array([gn32[k] for k in pn])
+    res['gradnorm64'] = np.array([gn64[k] for k in pn])
+    # a few full small gradients from the fp64 run (heads + deepest BN) for direct comparison
+    for k, p in net64.named_parameters():
+        if p.grad is not None and p.numel() <= 4096:
+            res['g64/' + k] = p.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **res)
+    print(name, 'loss32', loss32.item(), 'loss64', loss64.item())
+
+
+def fixture_losses(dice, ncc):
+    g = torch.Generator().manual_seed(7)
+    res = {}
+    s = torch.softmax(torch.randn(2, 7, 10, 12, generator=g), 1).double().requires_grad_(True)
+    lab = torch.randint(0, 7, (2, 10, 12), generator=g)
+    lab[0][lab[0] == 6] = 5           # class 6 empty in the target of image 0
+    t = torch.stack([(lab == c) for c in range(7)], 1).double()
+    for sb in (True, False):
+        s.grad = None
+        l = dice.DiceLoss2D(skip_bg=sb)(s, t)
+        l.backward()
+        res['dice_sb%d' % int(sb)] = np.array(l.item())
+        res['dice_sb%d_grad' % int(sb)] = s.grad.numpy().copy()
+    res['dice_in'] = s.detach().numpy()
+    res['dice_tgt'] = t.numpy()
+    perfect = dice.DiceLoss2D(skip_bg=False)(t, t)
+    res['dice_perfect'] = np.array(perfect.item())
+    X = torch.randn(2, 14, 10, 12, generator=g).double().requires_grad_(True)
+    Y = (torch.rand(2, 14, 10, 12, generator=g) * 0.02).double()
+    n = ncc.ncc_2d(X, Y)
+    n.sum().backward()
+    res['ncc_x'] = X.detach().numpy()
+    res['ncc_y'] = Y.numpy()
+    res['ncc'] = n.detach().numpy()
+    res['ncc_grad_of_sum'] = X.grad.numpy().copy()
+    res['ncc_self'] = ncc.ncc_2d(Y, Y).numpy()
+    X.grad = None
+    s.grad = None
+    l = dice.DiceAndHeatMapLoss2D(skip_bg=False, heatmap_wgt=0.3)((s, X), (t, Y))
+    l.backward()
+    res['dh_loss'] = np.array(l.item())
+    res['dh_gseg'] = s.grad.numpy().copy()
+    res['dh_gheat'] = X.grad.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, 'losses.npz'), **res)
+    print('losses', {k: float(v) for k, v in res.items() if v.ndim == 0})
+
+
+def fixture_sched(wr):
+    import torch.optim as optim
+    res = {}
+    for tag, (period, growth) in {'p2g2': (2, 2), 'p3g1': (3, 1)}.items():
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = optim.SGD([p], lr=0.1)
+        import io
+        import contextlib
+        with contextlib.redirect_stdout(io.StringIO()):
+            s = wr.WarmRestartLR(opt, init_run_period_epochs=period, growth_factor=growth)
+            trace = []
+            restarts = []
+            for ep in range(9):
+                for k in range(4):
+                    s.intra_epoch_step((k + 1) / 4)
+                    trace.append(opt.param_groups[0]['lr'])
+                s.step()
+                trace.append(opt.param_groups[0]['lr'])
+                restarts.append(int(s.just_restarted))
+        res[tag] = np.array(trace)
+        res[tag + '_restarts'] = np.array(restarts)
+    np.savez_compressed(os.path.join(OUT, 'sched.npz'), **res)
+    print('sched', res['p2g2'][:6])
+
+
+def fixture_dataset(dataset):
+    projs, segs, lands = toy_ellipses(3, 46, 46, seed=11)
+    FAKE_FILES['fake.h5'] = {
+        '01': {'projs': _FakeDS(projs[:2].numpy()), 'segs': _FakeDS(segs[:2].numpy()), 'lands': _FakeDS(lands[:2].numpy())},
+        '02': {'projs': _FakeDS(projs[2:].numpy()), 'segs': _FakeDS(segs[2:].numpy()), 'lands': _FakeDS(lands[2:].numpy())},
+        'land-names': {'num-lands': _FakeDS(np.array(14)),
+                       **{'land-%02d' % l: _FakeDS(np.bytes_(('L%02d' % l).encode())) for l in range(14)}},
+    }
+    ds = dataset.get_dataset('fake.h5', [1, 2], num_classes=7, pad_img_dim=48)
+    res = {'projs': projs.numpy(), 'segs': segs.numpy(), 'lands': lands.numpy(),
+           'num_lands': np.array(dataset.get_num_lands_from_dataset('fake.h5')),
+           'pad_48_46': np.array(dataset.calc_pad_amount(48, 46)),
+           'pad_192_184': np.array(dataset.calc_pad_amount(192, 184)),
+           'pad_193_180': np.array(dataset.calc_pad_amount(193, 180)),
+           'orig_shape': np.array(ds.rob_orig_img_shape), 'len': np.array(len(ds))}
+    for i in range(3):
+        p, s, l, h = ds[i]
+        res['item%d_p' % i] = p.numpy()
+        res['item%d_s' % i] = s.numpy()
+        res['item%d_l' % i] = l.numpy()
+        res['item%d_h' % i] = h.numpy()
+    np.savez_compressed(os.path.join(OUT, 'dataset.npz'), **res)
+    print('dataset item shapes', [tuple(t.shape) for t in ds[0]])
+
+
+def fixture_ensemble(unet, util):
+    """seg_dataset_ensemble (util.py:293-377) with 3 tiny reference nets on 2 images."""
+    kw = dict(n_classes=7, depth=3, wf=2, batch_norm=True, padding=True, max_pool=False,
+              num_lands=14, do_res=True, block_depth=2)
+    nets = []
+    sds = []
+    for s in (21, 22, 23):
+        torch.manual_seed(s)
+        n = unet.UNet(**kw)
+        g = torch.Generator().manual_seed(s)
+        with torch.no_grad():
+            for b in n.buffers():
+                if b.dtype.is_floating_point:
+                    b.add_(0.2 * torch.rand(b.shape, generator=g))
+        nets.append(n)
+        sds.append({k: v.clone() for k, v in n.state_dict().items()})
+    g = torch.Generator().manual_seed(5)
+    imgs = torch.randn(2, 1, 32, 32, generator=g)
+
+    class DS(torch.utils.data.Dataset):
+        rob_orig_img_shape = (28, 28)
+
+        def __len__(self):
+            return 2
+
+        def __getitem__(self, i):
+            return (imgs[i], torch.zeros(1), torch.zeros(1), torch.zeros(1))
+
+    class FakeH5DS:
+        def __init__(self, shape, dtype):
+            self.a = np.zeros(shape, dtype=dtype)
+
+        def __setitem__(self, k, v):
+            self.a[k] = v
+
+    class FakeH5:
+        def __init__(self):
+            self.d = {}
+
+        def create_dataset(self, name, shape, dtype='f4', **kw_):
+            self.d[name] = FakeH5DS(shape, dtype)
+            return self.d[name]
+
+    f = FakeH5()
+    util.seg_dataset_ensemble(DS(), nets, f, dev=None, num_lands=14, times=[])
+    res = {'imgs': imgs.numpy(), 'nn_segs': f.d['nn-segs'].a, 'nn_heats': f.d['nn-heats'].a}
+    for i, sd in enumerate(sds):
+        for k, v in sd.items():
+            res['net%d/%s' % (i, k)] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, 'ensemble.npz'), **res)
+    print('ensemble labels hist', np.bincount(res['nn_segs'].ravel(), minlength=7))
+
+
+def fixture_trajectory(unet, dice, util):
+    """Short SGD trajectory (train.py:405-430 wiring) on the toy-ellipses set, tiny-ish net."""
+    import torch.optim as optim
+    projs, segs, lands = toy_ellipses(8, 40, 40, seed=3)
+    kw = dict(n_classes=7, depth=3, wf=3, batch_norm=True, padding=True, max_pool=False,
+              num_lands=14, do_res=True, block_depth=2)
+    torch.manual_seed(99)
+    net = unet.UNet(**kw)
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    opt = optim.SGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4, nesterov=True)
+    crit = dice.DiceAndHeatMapLoss2D(skip_bg=False, heatmap_wgt=0.5)
+    # loader math restated inline from the reference's own functions is avoided: use its dataset class
+    import dataset
+    FAKE_FILES['traj.h5'] = {'01': {'projs': _FakeDS(projs.numpy()), 'segs': _FakeDS(segs.numpy()),
+                                    'lands': _FakeDS(lands.numpy())},
+                             'land-names': {'num-lands': _FakeDS(np.array(14))}}
+    ds = dataset.get_dataset('traj.h5', [1], num_classes=7, pad_img_dim=48)
+    items = [ds[i] for i in range(8)]
+    P = torch.stack([it[0] for it in items])
+    S = torch.stack([it[1] for it in items])
+    Hm = torch.stack([it[3] for it in items]).view(8, 14, 40, 40)
+    losses = []
+    net.train()
+    for step in range(30):
+        idx = [(step * 4 + j) % 8 for j in range(4)]
+        opt.zero_grad()
+        out = net(P[idx])
+        loss = crit((util.center_crop(out[0], S[idx].shape), util.center_crop(out[1], Hm[idx].shape)),
+                    (S[idx], Hm[idx]))
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    net.eval()
+    with torch.no_grad():
+        out = net(P)
+    labels = torch.max(util.center_crop(out[0], S.shape), dim=1)[1]
+    d = []
+    for c in range(1, 7):
+        a, b = labels == c, segs.long() == c
+        den = int(a.sum()) + int(b.sum())
+        d.append(2.0 * int((a & b).sum()) / den if den > 0 else 1.0)
+    res = {'projs': projs.numpy(), 'segs': segs.numpy(), 'lands': lands.numpy(),
+           'losses': np.array(losses), 'hard_dice': np.array(d)}
+    for k, v in sd0.items():
+        res['sd0/' + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, 'trajectory.npz'), **res)
+    print('trajectory losses', losses[0], losses[-1], 'dice', np.mean(d))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    install_stubs()
+    sys.path.insert(0, REF)
+    import ncc
+    import dice
+    import util
+    import unet
+    import warm_restarts_lr as wr
+    import dataset
+    torch.set_num_threads(8)
+    base = dict(n_classes=7, depth=3, wf=2, batch_norm=True, padding=True, do_res=True, block_depth=2)
+    fixture_tiny(unet, dice, util, 'tiny_sc_l14', 101, max_pool=False, num_lands=14, **base)
+    fixture_tiny(unet, dice, util, 'tiny_mp_l0', 102, max_pool=True, num_lands=0, **base)
+    fixture_tiny(unet, dice, util, 'tiny_mp_l14', 103, max_pool=True, num_lands=14, **base)
+    fixture_tiny(unet, dice, util, 'tiny_valid_nores', 104, hp=32, max_pool=True, num_lands=0,
+                 n_classes=7, depth=2, wf=2, batch_norm=True, padding=False, do_res=False, block_depth=2)
+    fixture_tiny(unet, dice, util, 'tiny_nobn_d1', 105, bwd=False, max_pool=False, num_lands=14,
+                 n_classes=3, depth=2, wf=3, batch_norm=False, padding=True, do_res=True, block_depth=1)
+    fixture_tiny(unet, dice, util, 'tiny_nobn_nores', 107, max_pool=False, num_lands=0,
+                 n_classes=3, depth=2, wf=3, batch_norm=False, padding=True, do_res=False, block_depth=2)
+    fixture_tiny(unet, dice, util, 'tiny_bd3_nosm', 106, max_pool=True, num_lands=0,
+                 n_classes=5, depth=2, wf=3, batch_norm=True, padding=True, do_res=True, block_depth=3,
+                 do_soft_max=False)
+    fixture_losses(dice, ncc)
+    fixture_sched(wr)
+    fixture_dataset(dataset)
+    fixture_ensemble(unet, util)
+    fixture_trajectory(unet, dice, util)
+    fixture_paper(unet, dice, util, 'paper_sc_l14', 1234, max_pool=False, num_lands=14)
+    fixture_paper(unet, dice, util, 'paper_mp_l0', 1235, max_pool=True, num_lands=0)
+
+
+if __name__ == '__main__':
+    main()
