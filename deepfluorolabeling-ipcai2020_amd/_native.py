@@ -1,0 +1,248 @@
+"""ctypes binding of libdfl_hip.so (C ABI declared in include/dfl_hip.h).
+
+The library is the product: there is no CPU or PyTorch fallback.  If it is missing, loading fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libdfl_hip.so')
+
+i32, i64, f32 = C.c_int32, C.c_int64, C.c_float
+fp = C.c_void_p   # every device pointer is passed as a plain address
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [('x', fp), ('w', fp), ('bias', fp), ('in_scale', fp), ('in_shift', fp), ('add', fp),
+                ('add_scale', fp), ('add_shift', fp), ('stat_other', fp), ('y', fp), ('stat_partials', fp),
+                ('N', i32), ('Hin', i32), ('Win', i32), ('Cin', i32), ('ldx', i32),
+                ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32),
+                ('Hout', i32), ('Wout', i32), ('Ntot', i32), ('ldy', i32),
+                ('ldadd', i32), ('ldso', i32), ('relu', i32), ('accumulate', i32), ('scatter2x2', i32),
+                ('reserved', i32)]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [('g', fp), ('d', fp), ('in_scale', fp), ('in_shift', fp), ('dw', fp), ('partial', fp),
+                ('N', i32), ('Hin', i32), ('Win', i32), ('Cg', i32), ('ldg', i32),
+                ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32),
+                ('Hout', i32), ('Wout', i32), ('Cm', i32), ('ldd', i32), ('splits', i32), ('reserved', i32)]
+
+
+class PackJob(C.Structure):
+    _fields_ = [('src', fp), ('dst', fp), ('off', i64), ('D0', i32), ('D1', i32), ('D2', i32),
+                ('s0', i32), ('s1', i32), ('s2', i32)]
+
+
+class BnFinalizeArgs(C.Structure):
+    _fields_ = [('partials', fp), ('gamma', fp), ('beta', fp), ('running_mean', fp), ('running_var', fp),
+                ('num_batches_tracked', fp), ('scale', fp), ('shift', fp), ('save_mean', fp), ('save_invstd', fp),
+                ('count', i64), ('nblocks', i32), ('C', i32), ('eps', f32), ('momentum', f32)]
+
+
+class ColstatsArgs(C.Structure):
+    _fields_ = [('a', fp), ('b', fp), ('partials', fp), ('M', i64), ('C', i32), ('lda', i32), ('ldb', i32),
+                ('nblocks', i32)]
+
+
+class BnBwdFinalizeArgs(C.Structure):
+    _fields_ = [('partials', fp), ('gamma', fp), ('save_mean', fp), ('save_invstd', fp), ('dgamma', fp),
+                ('dbeta', fp), ('coef', fp), ('count', i64), ('nblocks', i32), ('C', i32)]
+
+
+class BnReluBwdArgs(C.Structure):
+    _fields_ = [('dy', fp), ('r', fp), ('coef', fp), ('dpre', fp), ('partials', fp), ('M', i64), ('C', i32),
+                ('lddy', i32), ('ldr', i32), ('ldo', i32), ('nblocks', i32)]
+
+
+class AffineCopyArgs(C.Structure):
+    _fields_ = [('x', fp), ('y', fp), ('scale', fp), ('shift', fp),
+                ('N', i32), ('H', i32), ('W', i32), ('C', i32),
+                ('ldx', i32), ('xH', i32), ('xW', i32), ('xoy', i32), ('xox', i32),
+                ('ldy', i32), ('yH', i32), ('yW', i32), ('yoy', i32), ('yox', i32),
+                ('accumulate', i32), ('reserved', i32)]
+
+
+class PoolArgs(C.Structure):
+    _fields_ = [('x', fp), ('y', fp), ('dx', fp), ('N', i32), ('H', i32), ('W', i32), ('C', i32),
+                ('ldx', i32), ('ldy', i32), ('lddx', i32), ('reserved', i32)]
+
+
+class HeadFwdArgs(C.Structure):
+    _fields_ = [('x', fp), ('w_seg', fp), ('w_l1', fp), ('w_l2', fp), ('seg', fp), ('heat', fp),
+                ('N', i32), ('H', i32), ('W', i32), ('F', i32), ('ldx', i32),
+                ('NC', i32), ('NM', i32), ('L', i32), ('softmax', i32), ('reserved', i32)]
+
+
+class HeadBwdArgs(C.Structure):
+    _fields_ = [('x', fp), ('seg', fp), ('dseg', fp), ('dheat', fp), ('w_seg', fp), ('w_l1', fp), ('w_l2', fp),
+                ('dx', fp), ('scratch', fp),
+                ('N', i32), ('H', i32), ('W', i32), ('F', i32), ('ldx', i32), ('lddx', i32),
+                ('NC', i32), ('NM', i32), ('L', i32), ('softmax', i32), ('scratch_ld', i32), ('reserved', i32)]
+
+
+class LossArgs(C.Structure):
+    _fields_ = [('seg', fp), ('tseg', fp), ('heat', fp), ('theat', fp), ('loss', fp), ('dseg', fp), ('dheat', fp),
+                ('ncc_vals', fp), ('sums', fp),
+                ('seg_sN', i64), ('seg_sC', i64), ('seg_sH', i64), ('tseg_sN', i64), ('tseg_sC', i64), ('tseg_sH', i64),
+                ('heat_sN', i64), ('heat_sC', i64), ('heat_sH', i64), ('theat_sN', i64), ('theat_sC', i64),
+                ('theat_sH', i64),
+                ('B', i32), ('C', i32), ('L', i32), ('h', i32), ('w', i32), ('skip_bg', i32),
+                ('dice_wgt', f32), ('heat_wgt', f32)]
+
+
+class EnsembleArgs(C.Structure):
+    _fields_ = [('seg_ptrs', fp), ('heat_ptrs', fp), ('labels', fp), ('avg_seg', fp), ('heat_out', fp),
+                ('minmax', fp),
+                ('nnets', i32), ('C', i32), ('L', i32), ('Hp', i32), ('Wp', i32), ('h', i32), ('w', i32),
+                ('oy', i32), ('ox', i32), ('raw_heat', i32)]
+
+
+class SumPartialsArgs(C.Structure):
+    _fields_ = [('src', fp), ('dst', fp), ('n', i64), ('splits', i32), ('reserved', i32)]
+
+
+class PackArgs(C.Structure):
+    _fields_ = [('jobs_dev', fp), ('max_elems', i64), ('njobs', i32), ('reserved', i32)]
+
+
+class BnEvalArgs(C.Structure):
+    _fields_ = [('gamma', fp), ('beta', fp), ('running_mean', fp), ('running_var', fp), ('scale', fp),
+                ('shift', fp), ('C', i32), ('eps', f32)]
+
+
+class ReducePartialsArgs(C.Structure):
+    _fields_ = [('partials', fp), ('out', fp), ('nblocks', i32), ('stride', i32), ('C', i32), ('reserved', i32)]
+
+
+class MemsetArgs(C.Structure):
+    _fields_ = [('ptr', fp), ('bytes', i64)]
+
+
+class Op(C.Structure):
+    _fields_ = [('kind', i32), ('reserved', i32), ('args', fp)]
+
+
+OP_CONV, OP_WGRAD, OP_SUM_PARTIALS, OP_PACK, OP_BN_FINALIZE, OP_BN_EVAL, OP_COLSTATS, OP_BN_BWD_FINALIZE, \
+    OP_BN_RELU_BWD, OP_REDUCE_PARTIALS, OP_AFFINE_COPY, OP_POOL_FWD, OP_POOL_BWD, OP_HEAD_FWD, OP_HEAD_BWD, \
+    OP_MEMSET = range(1, 17)
+
+_KIND_OF = {ConvArgs: OP_CONV, WgradArgs: OP_WGRAD, SumPartialsArgs: OP_SUM_PARTIALS, PackArgs: OP_PACK,
+            BnFinalizeArgs: OP_BN_FINALIZE, BnEvalArgs: OP_BN_EVAL, ColstatsArgs: OP_COLSTATS,
+            BnBwdFinalizeArgs: OP_BN_BWD_FINALIZE, BnReluBwdArgs: OP_BN_RELU_BWD,
+            ReducePartialsArgs: OP_REDUCE_PARTIALS, AffineCopyArgs: OP_AFFINE_COPY, HeadFwdArgs: OP_HEAD_FWD,
+            HeadBwdArgs: OP_HEAD_BWD, MemsetArgs: OP_MEMSET}
+
+_SIZEOF_ORDER = [ConvArgs, WgradArgs, PackJob, BnFinalizeArgs, ColstatsArgs, BnBwdFinalizeArgs, BnReluBwdArgs,
+                 AffineCopyArgs, PoolArgs, HeadFwdArgs, HeadBwdArgs, LossArgs, EnsembleArgs, Op]
+
+EXPORTS = ['dfl_version', 'dfl_last_error', 'dfl_sizeof', 'dfl_conv2d', 'dfl_conv_grid_m', 'dfl_conv2d_wgrad',
+           'dfl_wgrad_suggest_splits', 'dfl_sum_partials', 'dfl_pack_weights', 'dfl_bn_finalize',
+           'dfl_bn_eval_prepare', 'dfl_rowblock_count', 'dfl_colstats', 'dfl_bn_bwd_finalize',
+           'dfl_bn_relu_bwd_apply', 'dfl_reduce_partials', 'dfl_affine_copy', 'dfl_maxpool2x2_fwd',
+           'dfl_maxpool2x2_bwd', 'dfl_head_fwd', 'dfl_head_bwd', 'dfl_head_scratch_ld', 'dfl_head_scratch_off',
+           'dfl_dice_ncc_loss', 'dfl_loss_scratch_doubles', 'dfl_ensemble_reduce', 'dfl_sgd_step', 'dfl_exec']
+
+
+class DflError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DflError('libdfl_hip.so not found at %s -- build it with __graft_entry__.build() '
+                       '(csrc/build.sh); there is no fallback path' % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(L, name):
+            raise DflError('libdfl_hip.so does not export %s' % name)
+    L.dfl_last_error.restype = C.c_char_p
+    L.dfl_loss_scratch_doubles.restype = i64
+    L.dfl_loss_scratch_doubles.argtypes = [i32, i32, i32]
+    L.dfl_rowblock_count.argtypes = [i64, i32]
+    L.dfl_sum_partials.argtypes = [fp, fp, i64, i32, fp]
+    L.dfl_pack_weights.argtypes = [fp, i32, i64, fp]
+    L.dfl_bn_eval_prepare.argtypes = [fp, fp, fp, fp, fp, fp, i32, f32, fp]
+    L.dfl_reduce_partials.argtypes = [fp, fp, i32, i32, i32, fp]
+    L.dfl_sgd_step.argtypes = [fp, fp, fp, i64, f32, f32, f32, f32, i32, i32, fp]
+    L.dfl_exec.argtypes = [fp, i32, fp]
+    for fn in ('dfl_conv2d', 'dfl_conv2d_wgrad', 'dfl_bn_finalize', 'dfl_colstats', 'dfl_bn_bwd_finalize',
+               'dfl_bn_relu_bwd_apply', 'dfl_affine_copy', 'dfl_maxpool2x2_fwd', 'dfl_maxpool2x2_bwd',
+               'dfl_head_fwd', 'dfl_head_bwd', 'dfl_dice_ncc_loss', 'dfl_ensemble_reduce'):
+        getattr(L, fn).argtypes = [fp, fp]
+    for fn in ('dfl_conv_grid_m', 'dfl_wgrad_suggest_splits'):
+        getattr(L, fn).argtypes = [fp]
+    for k, cls in enumerate(_SIZEOF_ORDER):
+        if L.dfl_sizeof(k) != C.sizeof(cls):
+            raise DflError('struct mirror %s has size %d, library says %d' % (cls.__name__, C.sizeof(cls), L.dfl_sizeof(k)))
+    _lib = L
+    return L
+
+
+def check(rc, what=''):
+    if rc < 0:
+        raise DflError('%s failed (%d): %s' % (what or 'libdfl_hip call', rc, lib().dfl_last_error().decode()))
+    return rc
+
+
+def ptr(t):
+    """Device address of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def byref(s):
+    return C.addressof(s)
+
+
+def call(fn_name, args_struct, stream):
+    return check(getattr(lib(), fn_name)(C.addressof(args_struct), stream), fn_name)
+
+
+class Program:
+    """A recorded list of library calls replayed by dfl_exec (one ctypes transition per replay)."""
+
+    def __init__(self):
+        self.structs = []      # keeps the argument structs alive
+        self.kinds = []
+        self._ops = None
+        self.keep = []         # tensors referenced by raw pointers
+
+    def add(self, args_struct, kind=None):
+        self.structs.append(args_struct)
+        self.kinds.append(kind if kind is not None else _KIND_OF[type(args_struct)])
+        self._ops = None
+        return args_struct
+
+    def add_pool(self, args_struct, backward):
+        return self.add(args_struct, OP_POOL_BWD if backward else OP_POOL_FWD)
+
+    def extend(self, other):
+        for s, k in zip(other.structs, other.kinds):
+            self.add(s, k)
+        self.keep.extend(other.keep)
+
+    def __len__(self):
+        return len(self.structs)
+
+    def _build(self):
+        arr = (Op * len(self.structs))()
+        for i, (s, k) in enumerate(zip(self.structs, self.kinds)):
+            arr[i].kind = k
+            arr[i].args = C.addressof(s)
+        self._ops = arr
+
+    def run(self, stream, start=0, count=None):
+        if not self.structs:
+            return
+        if self._ops is None:
+            self._build()
+        n = len(self.structs) - start if count is None else count
+        base = C.addressof(self._ops) + start * C.sizeof(Op)
+        check(lib().dfl_exec(base, n, stream), 'dfl_exec')

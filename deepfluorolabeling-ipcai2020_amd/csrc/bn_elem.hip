@@ -1,0 +1,539 @@
+// Streaming (HBM-bound) kernels around the convolutions: BatchNorm finalize / backward, per-channel reductions,
+// affine copy, 2x2 max-pool, weight re-layout, SGD.  All operate on NHWC rows [M][C] with float4 (= 4 channels)
+// accesses when C, ld and the pointers allow it, 4-byte accesses otherwise.
+// Reference behaviour: nn.BatchNorm2d (train_test_code/unet.py:215,222), nn.ReLU (:213,220), F.max_pool2d (:169),
+// torch.optim.SGD (train.py:333-334).  Contracts: include/dfl_hip.h.
+#include "common.h"
+
+namespace dfl {
+
+// ------------------------------------------------------------------------------------------------ helpers
+struct RowGeom {
+  int vec;    // 1: float4 units
+  int units;  // units per row (C/4 or C)
+  int UX;     // threads along the row (power of two <= 256)
+  int RY;     // rows per pass = 256 / UX
+  int gy;     // grid.y = ceil(units / UX)
+};
+
+static RowGeom row_geom(int C, bool vec_ok) {
+  RowGeom g;
+  g.vec = (vec_ok && C % 4 == 0) ? 1 : 0;
+  g.units = g.vec ? C / 4 : C;
+  int ux = 1;
+  while (ux * 2 <= g.units && ux * 2 <= 256) ux *= 2;
+  g.UX = ux;
+  g.RY = 256 / ux;
+  g.gy = (int)ceil_div(g.units, ux);
+  return g;
+}
+
+static int rowblocks(int64_t M, int C) {
+  int64_t nb = ceil_div(M * (int64_t)C, 8192);
+  if (nb > 2048) nb = 2048;
+  if (nb > M) nb = M;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p, bool vec, int c, int C) {
+  if (vec) return *reinterpret_cast<const float4*>(p);
+  (void)c; (void)C;
+  return make_float4(p[0], 0.f, 0.f, 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------ colstats
+// partials[blk][0][c] = sum a, partials[blk][1][c] = sum a*b over the block's rows.
+template <int VEC>
+__global__ void __launch_bounds__(256) colstats_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                      float* __restrict__ partials, int64_t M, int C, int lda, int ldb,
+                                                      int UX, int rows_per_block) {
+  __shared__ float red[2][256][VEC ? 4 : 1];
+  const int RY = 256 / UX;
+  const int ux = threadIdx.x % UX, uy = threadIdx.x / UX;
+  const int unit = blockIdx.y * UX + ux;
+  const int c = VEC ? unit * 4 : unit;
+  const bool cok = c < C;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > M) r1 = M;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (cok) {
+    for (int64_t r = r0 + uy; r < r1; r += RY) {
+      if constexpr (VEC) {
+        const float4 va = *reinterpret_cast<const float4*>(a + r * lda + c);
+        const float4 vb = b ? *reinterpret_cast<const float4*>(b + r * ldb + c) : va;
+        s1[0] += va.x; s1[1] += va.y; s1[2] += va.z; s1[3] += va.w;
+        s2[0] = fmaf(va.x, vb.x, s2[0]); s2[1] = fmaf(va.y, vb.y, s2[1]);
+        s2[2] = fmaf(va.z, vb.z, s2[2]); s2[3] = fmaf(va.w, vb.w, s2[3]);
+      } else {
+        const float va = a[r * lda + c];
+        const float vb = b ? b[r * ldb + c] : va;
+        s1[0] += va;
+        s2[0] = fmaf(va, vb, s2[0]);
+      }
+    }
+  }
+  constexpr int W = VEC ? 4 : 1;
+#pragma unroll
+  for (int j = 0; j < W; ++j) {
+    red[0][threadIdx.x][j] = s1[j];
+    red[1][threadIdx.x][j] = s2[j];
+  }
+  __syncthreads();
+  if (uy == 0 && cok) {
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      float t1 = 0.f, t2 = 0.f;
+      for (int y = 0; y < RY; ++y) {
+        t1 += red[0][y * UX + ux][j];
+        t2 += red[1][y * UX + ux][j];
+      }
+      if (c + j < C) {
+        partials[((int64_t)blockIdx.x * 2 + 0) * C + c + j] = t1;
+        partials[((int64_t)blockIdx.x * 2 + 1) * C + c + j] = t2;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ BN finalize
+// One workgroup per 8 channels: 32 lanes walk the partial rows, fp64 tree over them.
+__device__ __forceinline__ void sum_partials_f64(const float* __restrict__ partials, int nblocks, int C, int c,
+                                                 double* out1, double* out2, double (*red)[256]) {
+  const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C) {
+    for (int r = rl; r < nblocks; r += 32) {
+      s1 += (double)partials[((int64_t)r * 2 + 0) * C + c];
+      s2 += (double)partials[((int64_t)r * 2 + 1) * C + c];
+    }
+  }
+  red[0][threadIdx.x] = s1;
+  red[1][threadIdx.x] = s2;
+  __syncthreads();
+  for (int off = 16; off >= 1; off >>= 1) {
+    if (rl < off) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + off * 8];
+      red[1][threadIdx.x] += red[1][threadIdx.x + off * 8];
+    }
+    __syncthreads();
+  }
+  *out1 = red[0][cl];
+  *out2 = red[1][cl];
+}
+
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const dfl_bn_finalize_args a) {
+  __shared__ double red[2][256];
+  const int c = blockIdx.x * 8 + (threadIdx.x & 7);
+  double s1, s2;
+  sum_partials_f64(a.partials, a.nblocks, a.C, c, &s1, &s2, red);
+  if (threadIdx.x < 8 && c < a.C) {
+    const double cnt = (double)a.count;
+    const double mean = s1 / cnt;
+    double var = s2 / cnt - mean * mean;  // biased variance used for normalisation
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)a.eps);
+    const float scale = (float)((double)a.gamma[c] * invstd);
+    a.scale[c] = scale;
+    a.shift[c] = (float)((double)a.beta[c] - mean * (double)a.gamma[c] * invstd);
+    a.save_mean[c] = (float)mean;
+    a.save_invstd[c] = (float)invstd;
+    if (a.running_mean != nullptr) {
+      const double mom = (double)a.momentum;
+      const double unbiased = (cnt > 1.0) ? var * cnt / (cnt - 1.0) : var;
+      a.running_mean[c] = (float)((1.0 - mom) * (double)a.running_mean[c] + mom * mean);
+      a.running_var[c] = (float)((1.0 - mom) * (double)a.running_var[c] + mom * unbiased);
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && a.num_batches_tracked != nullptr) *a.num_batches_tracked += 1;
+}
+
+__global__ void bn_eval_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ rm, const float* __restrict__ rv, float* __restrict__ scale,
+                               float* __restrict__ shift, int C, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    const float invstd = 1.0f / sqrtf(rv[c] + eps);
+    const float s = gamma[c] * invstd;
+    scale[c] = s;
+    shift[c] = beta[c] - rm[c] * s;
+  }
+}
+
+// dy-side finalize: dgamma, dbeta and the affine form of BatchNorm+ReLU backward.
+__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const dfl_bn_bwd_finalize_args a) {
+  __shared__ double red[2][256];
+  const int c = blockIdx.x * 8 + (threadIdx.x & 7);
+  double sdy, sdyr;
+  sum_partials_f64(a.partials, a.nblocks, a.C, c, &sdy, &sdyr, red);
+  if (threadIdx.x < 8 && c < a.C) {
+    const double cnt = (double)a.count;
+    const double mean = (double)a.save_mean[c], invstd = (double)a.save_invstd[c], g = (double)a.gamma[c];
+    const double sdyx = invstd * (sdyr - mean * sdy);  // sum dy * xhat
+    a.dgamma[c] = (float)sdyx;
+    a.dbeta[c] = (float)sdy;
+    const double s = g * invstd;
+    const double c1 = sdy / cnt, c2 = sdyx / cnt;
+    // dr = s*(dy - c1 - xhat*c2),  xhat = (r - mean)*invstd
+    a.coef[0 * a.C + c] = (float)s;
+    a.coef[1 * a.C + c] = (float)(-s * c2 * invstd);
+    a.coef[2 * a.C + c] = (float)(-s * c1 + s * c2 * invstd * mean);
+  }
+}
+
+// dpre = [r > 0] * (A*dy + B*r + C); partials[blk][c] = column sums of dpre.
+template <int VEC>
+__global__ void __launch_bounds__(256) bn_relu_bwd_kernel(const dfl_bn_relu_bwd_args a, int UX, int rows_per_block) {
+  __shared__ float red[256][VEC ? 4 : 1];
+  const int RY = 256 / UX;
+  const int ux = threadIdx.x % UX, uy = threadIdx.x / UX;
+  const int unit = blockIdx.y * UX + ux;
+  const int c = VEC ? unit * 4 : unit;
+  const int C = a.C;
+  const bool cok = c < C;
+  constexpr int W = VEC ? 4 : 1;
+  float cA[W], cB[W], cC[W], s[W];
+#pragma unroll
+  for (int j = 0; j < W; ++j) {
+    cA[j] = 1.f; cB[j] = 0.f; cC[j] = 0.f; s[j] = 0.f;
+    if (a.coef != nullptr && cok && c + j < C) {
+      cA[j] = a.coef[c + j];
+      cB[j] = a.coef[C + c + j];
+      cC[j] = a.coef[2 * C + c + j];
+    }
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > a.M) r1 = a.M;
+  if (cok) {
+    for (int64_t r = r0 + uy; r < r1; r += RY) {
+      if constexpr (VEC) {
+        const float4 dy = *reinterpret_cast<const float4*>(a.dy + r * a.lddy + c);
+        const float4 rv = *reinterpret_cast<const float4*>(a.r + r * a.ldr + c);
+        float4 o;
+        o.x = rv.x > 0.f ? fmaf(cA[0], dy.x, fmaf(cB[0], rv.x, cC[0])) : 0.f;
+        o.y = rv.y > 0.f ? fmaf(cA[1], dy.y, fmaf(cB[1], rv.y, cC[1])) : 0.f;
+        o.z = rv.z > 0.f ? fmaf(cA[2], dy.z, fmaf(cB[2], rv.z, cC[2])) : 0.f;
+        o.w = rv.w > 0.f ? fmaf(cA[3], dy.w, fmaf(cB[3], rv.w, cC[3])) : 0.f;
+        *reinterpret_cast<float4*>(a.dpre + r * a.ldo + c) = o;
+        s[0] += o.x; s[1] += o.y; s[2] += o.z; s[3] += o.w;
+      } else {
+        const float dy = a.dy[r * a.lddy + c], rv = a.r[r * a.ldr + c];
+        const float o = rv > 0.f ? fmaf(cA[0], dy, fmaf(cB[0], rv, cC[0])) : 0.f;
+        a.dpre[r * a.ldo + c] = o;
+        s[0] += o;
+      }
+    }
+  }
+  if (a.partials == nullptr) return;
+#pragma unroll
+  for (int j = 0; j < W; ++j) red[threadIdx.x][j] = s[j];
+  __syncthreads();
+  if (uy == 0 && cok) {
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      float t = 0.f;
+      for (int y = 0; y < RY; ++y) t += red[y * UX + ux][j];
+      if (c + j < C) a.partials[(int64_t)blockIdx.x * C + c + j] = t;
+    }
+  }
+}
+
+// out[c] = sum_b partials[b*stride + c] in fp64
+__global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __restrict__ partials, float* __restrict__ out,
+                                                             int nblocks, int stride, int C) {
+  __shared__ double red[256];
+  const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
+  double s = 0.0;
+  if (c < C)
+    for (int r = rl; r < nblocks; r += 32) s += (double)partials[(int64_t)r * stride + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 16; off >= 1; off >>= 1) {
+    if (rl < off) red[threadIdx.x] += red[threadIdx.x + off * 8];
+    __syncthreads();
+  }
+  if (threadIdx.x < 8 && c < C) out[c] = (float)red[threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------------------ affine copy
+template <int VEC>
+__global__ void __launch_bounds__(256) affine_copy_kernel(const dfl_affine_copy_args a, int64_t total_units, int cq) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_units; i += stride) {
+    const int u = (int)(i % cq);
+    int64_t pix = i / cq;
+    const int xw = (int)(pix % a.W);
+    pix /= a.W;
+    const int yh = (int)(pix % a.H);
+    const int n = (int)(pix / a.H);
+    const int c = VEC ? u * 4 : u;
+    const float* src = a.x + (((int64_t)n * a.xH + a.xoy + yh) * a.xW + a.xox + xw) * a.ldx + c;
+    float* dst = a.y + (((int64_t)n * a.yH + a.yoy + yh) * a.yW + a.yox + xw) * a.ldy + c;
+    if constexpr (VEC) {
+      float4 v = *reinterpret_cast<const float4*>(src);
+      if (a.scale != nullptr) {
+        const float4 sc = *reinterpret_cast<const float4*>(a.scale + c);
+        const float4 sh = *reinterpret_cast<const float4*>(a.shift + c);
+        v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
+        v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+      }
+      if (a.accumulate) {
+        const float4 o = *reinterpret_cast<const float4*>(dst);
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+      }
+      *reinterpret_cast<float4*>(dst) = v;
+    } else {
+      float v = *src;
+      if (a.scale != nullptr) v = fmaf(v, a.scale[c], a.shift[c]);
+      if (a.accumulate) v += *dst;
+      *dst = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ max pool
+template <int VEC>
+__global__ void __launch_bounds__(256) maxpool_fwd_kernel(const dfl_pool_args a, int64_t total_units, int cq) {
+  const int Ho = a.H / 2, Wo = a.W / 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_units; i += stride) {
+    const int u = (int)(i % cq);
+    int64_t pix = i / cq;
+    const int ox = (int)(pix % Wo);
+    pix /= Wo;
+    const int oy = (int)(pix % Ho);
+    const int n = (int)(pix / Ho);
+    const int c = VEC ? u * 4 : u;
+    const float* s00 = a.x + (((int64_t)n * a.H + 2 * oy) * a.W + 2 * ox) * a.ldx + c;
+    const float* s10 = s00 + (int64_t)a.W * a.ldx;
+    float* dst = a.y + (((int64_t)n * Ho + oy) * Wo + ox) * a.ldy + c;
+    if constexpr (VEC) {
+      const float4 v0 = *reinterpret_cast<const float4*>(s00), v1 = *reinterpret_cast<const float4*>(s00 + a.ldx);
+      const float4 v2 = *reinterpret_cast<const float4*>(s10), v3 = *reinterpret_cast<const float4*>(s10 + a.ldx);
+      float4 m;
+      m.x = fmaxf(fmaxf(v0.x, v1.x), fmaxf(v2.x, v3.x));
+      m.y = fmaxf(fmaxf(v0.y, v1.y), fmaxf(v2.y, v3.y));
+      m.z = fmaxf(fmaxf(v0.z, v1.z), fmaxf(v2.z, v3.z));
+      m.w = fmaxf(fmaxf(v0.w, v1.w), fmaxf(v2.w, v3.w));
+      *reinterpret_cast<float4*>(dst) = m;
+    } else {
+      *dst = fmaxf(fmaxf(s00[0], s00[a.ldx]), fmaxf(s10[0], s10[a.ldx]));
+    }
+  }
+}
+
+__device__ __forceinline__ int first_max4(float v0, float v1, float v2, float v3) {
+  int k = 0;
+  float m = v0;
+  if (v1 > m) { m = v1; k = 1; }
+  if (v2 > m) { m = v2; k = 2; }
+  if (v3 > m) { k = 3; }
+  return k;
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const dfl_pool_args a, int64_t total_units, int cq) {
+  const int Ho = a.H / 2, Wo = a.W / 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_units; i += stride) {
+    const int u = (int)(i % cq);
+    int64_t pix = i / cq;
+    const int ox = (int)(pix % Wo);
+    pix /= Wo;
+    const int oy = (int)(pix % Ho);
+    const int n = (int)(pix / Ho);
+    const int c = VEC ? u * 4 : u;
+    const int64_t ipix = ((int64_t)n * a.H + 2 * oy) * a.W + 2 * ox;
+    const float* s00 = a.x + ipix * a.ldx + c;
+    const float* s10 = s00 + (int64_t)a.W * a.ldx;
+    float* d00 = a.dx + ipix * a.lddx + c;
+    float* d10 = d00 + (int64_t)a.W * a.lddx;
+    const float* g = a.y + (((int64_t)n * Ho + oy) * Wo + ox) * a.ldy + c;
+    constexpr int W = VEC ? 4 : 1;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      const int k = first_max4(s00[j], s00[a.ldx + j], s10[j], s10[a.ldx + j]);
+      float* d = (k == 0) ? d00 + j : (k == 1) ? d00 + a.lddx + j : (k == 2) ? d10 + j : d10 + a.lddx + j;
+      *d += g[j];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ weight pack
+__global__ void __launch_bounds__(256) pack_kernel(const dfl_pack_job* __restrict__ jobs) {
+  const dfl_pack_job j = jobs[blockIdx.y];
+  const int64_t total = (int64_t)j.D0 * j.D1 * j.D2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int i2 = (int)(i % j.D2);
+    const int64_t t = i / j.D2;
+    const int i1 = (int)(t % j.D1);
+    const int i0 = (int)(t / j.D1);
+    j.dst[i] = j.src[j.off + (int64_t)i0 * j.s0 + (int64_t)i1 * j.s1 + (int64_t)i2 * j.s2];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ SGD
+__global__ void __launch_bounds__(256) sgd_kernel(float* __restrict__ p, const float* __restrict__ grad,
+                                                 float* __restrict__ buf, int64_t n, float lr, float mom, float wd,
+                                                 float gscale, int nesterov, int first) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float w = p[i];
+    float g = fmaf(wd, w, grad[i] * gscale);
+    if (mom != 0.f) {
+      const float b = first ? g : fmaf(mom, buf[i], g);
+      buf[i] = b;
+      g = nesterov ? fmaf(mom, b, g) : b;
+    }
+    p[i] = fmaf(-lr, g, w);
+  }
+}
+
+static unsigned stream_grid(int64_t units) {
+  int64_t b = ceil_div(units, 256);
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace dfl
+
+using namespace dfl;
+
+extern "C" int dfl_rowblock_count(int64_t M, int32_t C) { return rowblocks(M, C); }
+
+extern "C" int dfl_colstats(const dfl_colstats_args* a, dfl_stream_t stream) {
+  DFL_REQUIRE(a && a->a && a->partials && a->M > 0 && a->C > 0, "dfl_colstats: bad args");
+  DFL_REQUIRE(a->nblocks == rowblocks(a->M, a->C), "dfl_colstats: nblocks must be dfl_rowblock_count(M, C)");
+  const bool vec_ok = a->lda % 4 == 0 && aligned16(a->a) && (a->b == nullptr || (a->ldb % 4 == 0 && aligned16(a->b)));
+  const RowGeom g = row_geom(a->C, vec_ok);
+  const int rpb = (int)ceil_div(a->M, a->nblocks);
+  dim3 grid((unsigned)a->nblocks, (unsigned)g.gy);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (g.vec)
+    hipLaunchKernelGGL(colstats_kernel<1>, grid, dim3(256), 0, s, a->a, a->b, a->partials, a->M, a->C, a->lda, a->ldb, g.UX, rpb);
+  else
+    hipLaunchKernelGGL(colstats_kernel<0>, grid, dim3(256), 0, s, a->a, a->b, a->partials, a->M, a->C, a->lda, a->ldb, g.UX, rpb);
+  return check_launch("dfl_colstats");
+}
+
+extern "C" int dfl_bn_finalize(const dfl_bn_finalize_args* a, dfl_stream_t stream) {
+  DFL_REQUIRE(a && a->partials && a->gamma && a->beta && a->scale && a->shift && a->save_mean && a->save_invstd,
+              "dfl_bn_finalize: missing pointer");
+  DFL_REQUIRE(a->C > 0 && a->nblocks > 0 && a->count > 0, "dfl_bn_finalize: bad sizes");
+  DFL_REQUIRE((a->running_mean == nullptr) == (a->running_var == nullptr), "dfl_bn_finalize: running stats go together");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(a->C, 8)), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  return check_launch("dfl_bn_finalize");
+}
+
+extern "C" int dfl_bn_eval_prepare(const float* gamma, const float* beta, const float* running_mean,
+                                   const float* running_var, float* scale, float* shift, int32_t C, float eps,
+                                   dfl_stream_t stream) {
+  DFL_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && C > 0, "dfl_bn_eval_prepare: bad args");
+  hipLaunchKernelGGL(bn_eval_kernel, dim3((unsigned)ceil_div(C, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     gamma, beta, running_mean, running_var, scale, shift, (int)C, eps);
+  return check_launch("dfl_bn_eval_prepare");
+}
+
+extern "C" int dfl_bn_bwd_finalize(const dfl_bn_bwd_finalize_args* a, dfl_stream_t stream) {
+  DFL_REQUIRE(a && a->partials && a->gamma && a->save_mean && a->save_invstd && a->dgamma && a->dbeta && a->coef,
+              "dfl_bn_bwd_finalize: missing pointer");
+  DFL_REQUIRE(a->C > 0 && a->nblocks > 0 && a->count > 0, "dfl_bn_bwd_finalize: bad sizes");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(a->C, 8)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), *a);
+  return check_launch("dfl_bn_bwd_finalize");
+}
+
+extern "C" int dfl_bn_relu_bwd_apply(const dfl_bn_relu_bwd_args* a, dfl_stream_t stream) {
+  DFL_REQUIRE(a && a->dy && a->r && a->dpre && a->M > 0 && a->C > 0, "dfl_bn_relu_bwd_apply: bad args");
+  DFL_REQUIRE(a->nblocks == rowblocks(a->M, a->C), "dfl_bn_relu_bwd_apply: nblocks must be dfl_rowblock_count(M, C)");
+  const bool vec_ok = a->lddy % 4 == 0 && a->ldr % 4 == 0 && a->ldo % 4 == 0 && aligned16(a->dy) && aligned16(a->r) &&
+                      aligned16(a->dpre);
+  const RowGeom g = row_geom(a->C, vec_ok);
+  const int rpb = (int)ceil_div(a->M, a->nblocks);
+  dim3 grid((unsigned)a->nblocks, (unsigned)g.gy);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (g.vec)
+    hipLaunchKernelGGL(bn_relu_bwd_kernel<1>, grid, dim3(256), 0, s, *a, g.UX, rpb);
+  else
+    hipLaunchKernelGGL(bn_relu_bwd_kernel<0>, grid, dim3(256), 0, s, *a, g.UX, rpb);
+  return check_launch("dfl_bn_relu_bwd_apply");
+}
+
+extern "C" int dfl_reduce_partials(const float* partials, float* out, int32_t nblocks, int32_t stride, int32_t C,
+                                   dfl_stream_t stream) {
+  DFL_REQUIRE(partials && out && nblocks > 0 && C > 0 && stride >= C, "dfl_reduce_partials: bad args");
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(C, 8)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     partials, out, (int)nblocks, (int)stride, (int)C);
+  return check_launch("dfl_reduce_partials");
+}
+
+extern "C" int dfl_affine_copy(const dfl_affine_copy_args* a, dfl_stream_t stream) {
+  DFL_REQUIRE(a && a->x && a->y && a->N > 0 && a->H > 0 && a->W > 0 && a->C > 0, "dfl_affine_copy: bad args");
+  DFL_REQUIRE(a->xoy >= 0 && a->xox >= 0 && a->xoy + a->H <= a->xH && a->xox + a->W <= a->xW, "dfl_affine_copy: source window");
+  DFL_REQUIRE(a->yoy >= 0 && a->yox >= 0 && a->yoy + a->H <= a->yH && a->yox + a->W <= a->yW, "dfl_affine_copy: dest window");
+  DFL_REQUIRE((a->scale == nullptr) == (a->shift == nullptr), "dfl_affine_copy: scale/shift go together");
+  const bool vec = a->C % 4 == 0 && a->ldx % 4 == 0 && a->ldy % 4 == 0 && aligned16(a->x) && aligned16(a->y) &&
+                   (a->scale == nullptr || (aligned16(a->scale) && aligned16(a->shift)));
+  const int cq = vec ? a->C / 4 : a->C;
+  const int64_t total = (int64_t)a->N * a->H * a->W * cq;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (vec)
+    hipLaunchKernelGGL(affine_copy_kernel<1>, dim3(stream_grid(total)), dim3(256), 0, s, *a, total, cq);
+  else
+    hipLaunchKernelGGL(affine_copy_kernel<0>, dim3(stream_grid(total)), dim3(256), 0, s, *a, total, cq);
+  return check_launch("dfl_affine_copy");
+}
+
+static int pool_common(const dfl_pool_args* a, bool bwd, bool* vec, int* cq, int64_t* total) {
+  DFL_REQUIRE(a && a->x && a->y && a->N > 0 && a->H >= 2 && a->W >= 2 && a->C > 0, "dfl_maxpool2x2: bad args");
+  DFL_REQUIRE(!bwd || a->dx != nullptr, "dfl_maxpool2x2_bwd: dx required");
+  *vec = a->C % 4 == 0 && a->ldx % 4 == 0 && a->ldy % 4 == 0 && aligned16(a->x) && aligned16(a->y) &&
+         (!bwd || (a->lddx % 4 == 0 && aligned16(a->dx)));
+  *cq = *vec ? a->C / 4 : a->C;
+  *total = (int64_t)a->N * (a->H / 2) * (a->W / 2) * *cq;
+  return DFL_OK;
+}
+
+extern "C" int dfl_maxpool2x2_fwd(const dfl_pool_args* a, dfl_stream_t stream) {
+  bool vec; int cq; int64_t total;
+  int rc = pool_common(a, false, &vec, &cq, &total);
+  if (rc != DFL_OK) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (vec) hipLaunchKernelGGL(maxpool_fwd_kernel<1>, dim3(stream_grid(total)), dim3(256), 0, s, *a, total, cq);
+  else hipLaunchKernelGGL(maxpool_fwd_kernel<0>, dim3(stream_grid(total)), dim3(256), 0, s, *a, total, cq);
+  return check_launch("dfl_maxpool2x2_fwd");
+}
+
+extern "C" int dfl_maxpool2x2_bwd(const dfl_pool_args* a, dfl_stream_t stream) {
+  bool vec; int cq; int64_t total;
+  int rc = pool_common(a, true, &vec, &cq, &total);
+  if (rc != DFL_OK) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (vec) hipLaunchKernelGGL(maxpool_bwd_kernel<1>, dim3(stream_grid(total)), dim3(256), 0, s, *a, total, cq);
+  else hipLaunchKernelGGL(maxpool_bwd_kernel<0>, dim3(stream_grid(total)), dim3(256), 0, s, *a, total, cq);
+  return check_launch("dfl_maxpool2x2_bwd");
+}
+
+extern "C" int dfl_pack_weights(const dfl_pack_job* jobs_dev, int32_t njobs, int64_t max_elems, dfl_stream_t stream) {
+  DFL_REQUIRE(jobs_dev && njobs > 0 && max_elems > 0, "dfl_pack_weights: bad args");
+  int64_t bx = ceil_div(max_elems, 256 * 8);
+  if (bx > 1024) bx = 1024;
+  if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)bx, (unsigned)njobs), dim3(256), 0, static_cast<hipStream_t>(stream), jobs_dev);
+  return check_launch("dfl_pack_weights");
+}
+
+extern "C" int dfl_sgd_step(float* p, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
+                            float weight_decay, float grad_scale, int32_t nesterov, int32_t first_step,
+                            dfl_stream_t stream) {
+  DFL_REQUIRE(p && grad && n > 0, "dfl_sgd_step: bad args");
+  DFL_REQUIRE(momentum == 0.f || momentum_buf != nullptr, "dfl_sgd_step: momentum buffer required");
+  hipLaunchKernelGGL(sgd_kernel, dim3(stream_grid(n)), dim3(256), 0, static_cast<hipStream_t>(stream), p, grad,
+                     momentum_buf, n, lr, momentum, weight_decay, grad_scale, (int)nesterov, (int)first_step);
+  return check_launch("dfl_sgd_step");
+}

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Builds libdfl_hip.so for gfx950 (cross-compiles without a GPU).  Usage: csrc/build.sh [extra hipcc flags]
+set -euo pipefail
+here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+out="$here/../lib"
+mkdir -p "$out"
+srcs=(api.hip conv_gemm.hip wgrad_gemm.hip bn_elem.hip head.hip loss.hip)
+objs=()
+pids=()
+for s in "${srcs[@]}"; do
+  o="$out/${s%.hip}.o"
+  objs+=("$o")
+  if [ ! -f "$o" ] || [ "$here/$s" -nt "$o" ] || [ "$here/common.h" -nt "$o" ] || [ "$here/../../include/dfl_hip.h" -nt "$o" ]; then
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -c "$here/$s" -o "$o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$out/libdfl_hip.so" "${objs[@]}"
+echo "built $out/libdfl_hip.so"

@@ -1,0 +1,398 @@
+// Gather-GEMM convolution on the gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// One kernel family serves nn.Conv2d 3x3 / 1x1 / 2x2-stride-2, nn.ConvTranspose2d(k2,s2) (scatter epilogue)
+// and, with re-packed weights, the data gradient of each of them (reference: train_test_code/unet.py:93,207,
+// 211,218,240 and torch autograd at train.py:422).  See include/dfl_hip.h (dfl_conv2d) for the contract.
+//
+// Structure per workgroup (WM x WN waves, each wave TM x TN tiles of 32x32):
+//   K is walked in chunks of KC = 16 (k = tap*Cin + channel).  For each chunk every thread gathers its share
+//   of the [BM pixels][16] input slab straight from the NHWC activation (float4 = 4 channels of one pixel, zero
+//   outside the image, BatchNorm scale/shift applied on load) and of the [16][BN] weight slab into registers,
+//   the wave computes the previous chunk out of LDS meanwhile, then the registers are written to the other LDS
+//   buffer: one barrier per chunk.  LDS images are k-major (A: [16][BM+4], B: [16][BN+4]) so that the MFMA
+//   operand reads (lane = row/col index, lane>>5 = k parity) are unit-stride ds_read_b32, conflict free.
+//   f32 MFMA issues one 32x32x2 per 64 cycles per SIMD, so operand traffic (2 x 256 B per MFMA) is far below
+//   what LDS and L2 deliver; the kernel is bound by the matrix pipe (roofline "mfma", peak 157.3 TFLOP/s).
+// Epilogue: bias, ReLU, "+ BN(other)" (residual sum), accumulate, NHWC or 2x2-scatter store, and per-channel
+//   partial sums (v, v*u) reduced lane -> half-wave (one xor-32 shuffle) -> workgroup (LDS) -> one row of
+//   stat_partials per row block; dfl_bn_finalize adds the rows in fp64.
+#include "common.h"
+
+namespace dfl {
+
+constexpr int KC = 16;
+
+struct ConvK {
+  dfl_conv_args a;
+  int Mtot, Ktot, Hg, Wg, Cout;
+  int vecA, vecB;
+};
+
+template <int WM, int WN, int TM, int TN>
+__global__ void __launch_bounds__(WM* WN * 64) conv_gemm_kernel(const ConvK p) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int LDA = BM + 4, LDB = BN + 4;
+  constexpr int RPP = NT / 4;  // pixel rows covered per pass of the A gather
+  constexpr int QA = BM / RPP;
+  static_assert(BM % RPP == 0, "A tile must divide evenly");
+  constexpr int NQB = KC * BN / 4;
+  constexpr int QB = (NQB + NT - 1) / NT;
+  constexpr int BQ = BN / 4;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                  // [2][KC][LDA]
+  float* Bs = smem + 2 * KC * LDA;   // [2][KC][LDB]
+
+  const dfl_conv_args& a = p.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int Hin = a.Hin, Win = a.Win, Cin = a.Cin, KW = a.KW;
+  const int Ktot = p.Ktot, Ntot = a.Ntot;
+
+  // ---- per-thread gather rows ------------------------------------------------------------------
+  const int aq = tid & 3;
+  int a_iy0[QA], a_ix0[QA], a_base[QA];
+#pragma unroll
+  for (int r = 0; r < QA; ++r) {
+    const int m = m0 + (tid >> 2) + r * RPP;
+    if (m < p.Mtot) {
+      const int ox = m % p.Wg;
+      const int t = m / p.Wg;
+      const int oy = t % p.Hg;
+      const int n = t / p.Hg;
+      a_iy0[r] = oy * a.stride - a.pad;
+      a_ix0[r] = ox * a.stride - a.pad;
+      a_base[r] = n * Hin * Win;
+    } else {
+      a_iy0[r] = -(1 << 28);  // every tap lands outside the image => zeros
+      a_ix0[r] = 0;
+      a_base[r] = 0;
+    }
+  }
+
+  float4 ra[QA];
+  float4 rb[QB];
+
+  auto load_A = [&](int kc0) {
+    const int k = kc0 + 4 * aq;
+    if (p.vecA) {
+      const bool kvalid = k < Ktot;
+      const int t = kvalid ? k / Cin : 0;
+      const int c = kvalid ? k - t * Cin : 0;
+      const int dy = t / KW, dx = t - dy * KW;
+      float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a.in_scale != nullptr && kvalid) {
+        sc = *reinterpret_cast<const float4*>(a.in_scale + c);
+        sh = *reinterpret_cast<const float4*>(a.in_shift + c);
+      }
+#pragma unroll
+      for (int r = 0; r < QA; ++r) {
+        const int iy = a_iy0[r] + dy, ix = a_ix0[r] + dx;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kvalid && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win) {
+          const int64_t pix = (int64_t)a_base[r] + (int64_t)iy * Win + ix;
+          v = *reinterpret_cast<const float4*>(a.x + pix * a.ldx + c);
+          v.x = fmaf(v.x, sc.x, sh.x);
+          v.y = fmaf(v.y, sc.y, sh.y);
+          v.z = fmaf(v.z, sc.z, sh.z);
+          v.w = fmaf(v.w, sc.w, sh.w);
+        }
+        ra[r] = v;
+      }
+    } else {
+      float vals[QA][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kj = k + j;
+        const bool kvalid = kj < Ktot;
+        const int t = kvalid ? kj / Cin : 0;
+        const int c = kvalid ? kj - t * Cin : 0;
+        const int dy = t / KW, dx = t - dy * KW;
+        float sc = 1.f, sh = 0.f;
+        if (a.in_scale != nullptr && kvalid) {
+          sc = a.in_scale[c];
+          sh = a.in_shift[c];
+        }
+#pragma unroll
+        for (int r = 0; r < QA; ++r) {
+          const int iy = a_iy0[r] + dy, ix = a_ix0[r] + dx;
+          float v = 0.f;
+          if (kvalid && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win) {
+            const int64_t pix = (int64_t)a_base[r] + (int64_t)iy * Win + ix;
+            v = fmaf(a.x[pix * a.ldx + c], sc, sh);
+          }
+          vals[r][j] = v;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < QA; ++r) ra[r] = make_float4(vals[r][0], vals[r][1], vals[r][2], vals[r][3]);
+    }
+  };
+
+  auto load_B = [&](int kc0) {
+#pragma unroll
+    for (int r = 0; r < QB; ++r) {
+      const int idx = tid + r * NT;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < NQB) {
+        const int krow = idx / BQ, nq = idx - krow * BQ;
+        const int k = kc0 + krow, n = n0 + 4 * nq;
+        if (k < Ktot) {
+          const float* src = a.w + (int64_t)k * Ntot + n;
+          if (p.vecB) {
+            if (n < Ntot) v = *reinterpret_cast<const float4*>(src);
+          } else {
+            if (n + 0 < Ntot) v.x = src[0];
+            if (n + 1 < Ntot) v.y = src[1];
+            if (n + 2 < Ntot) v.z = src[2];
+            if (n + 3 < Ntot) v.w = src[3];
+          }
+        }
+      }
+      rb[r] = v;
+    }
+  };
+
+  auto store_AB = [&](int buf) {
+    float* Ab = As + buf * KC * LDA;
+#pragma unroll
+    for (int r = 0; r < QA; ++r) {
+      const int row = (tid >> 2) + r * RPP;
+      Ab[(4 * aq + 0) * LDA + row] = ra[r].x;
+      Ab[(4 * aq + 1) * LDA + row] = ra[r].y;
+      Ab[(4 * aq + 2) * LDA + row] = ra[r].z;
+      Ab[(4 * aq + 3) * LDA + row] = ra[r].w;
+    }
+    float* Bb = Bs + buf * KC * LDB;
+#pragma unroll
+    for (int r = 0; r < QB; ++r) {
+      const int idx = tid + r * NT;
+      if (idx < NQB) {
+        const int krow = idx / BQ, nq = idx - krow * BQ;
+        *reinterpret_cast<float4*>(Bb + krow * LDB + 4 * nq) = rb[r];
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nchunks = (Ktot + KC - 1) / KC;
+  load_A(0);
+  load_B(0);
+  store_AB(0);
+  __syncthreads();
+
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int buf = ch & 1;
+    const bool more = (ch + 1) < nchunks;
+    if (more) {
+      load_A((ch + 1) * KC);
+      load_B((ch + 1) * KC);
+    }
+    const float* Ab = As + buf * KC * LDA + wm * (TM * 32) + li;
+    const float* Bb = Bs + buf * KC * LDB + wn * (TN * 32) + li;
+#pragma unroll
+    for (int kk = 0; kk < KC / 2; ++kk) {
+      float av[TM], bv[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[i] = Ab[(2 * kk + lh) * LDA + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[j] = Bb[(2 * kk + lh) * LDB + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_AB(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------------
+  const bool do_stats = a.stat_partials != nullptr;
+  float s1[TN], s2[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    s1[j] = 0.f;
+    s2[j] = 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * (TN * 32) + j * 32 + li;
+    const bool nok = n < Ntot;
+    int co = n, ab = 0;
+    if (a.scatter2x2) {
+      ab = n / p.Cout;
+      co = n - ab * p.Cout;
+    }
+    const float bias = (a.bias != nullptr && nok) ? a.bias[co] : 0.f;
+    float asc = 1.f, ash = 0.f;
+    if (a.add != nullptr && a.add_scale != nullptr && nok) {
+      asc = a.add_scale[n];
+      ash = a.add_shift[n];
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * (TM * 32) + i * 32 + mfma32_row(r, lane);
+        if (nok && m < p.Mtot) {
+          float v = acc[i][j][r] + bias;
+          if (a.relu) v = fmaxf(v, 0.f);
+          if (a.add != nullptr) v += fmaf(a.add[(int64_t)m * a.ldadd + n], asc, ash);
+          float* dst;
+          if (a.scatter2x2) {
+            const int jx = m % p.Wg;
+            const int t = m / p.Wg;
+            const int iy = t % p.Hg;
+            const int ni = t / p.Hg;
+            const int64_t opix = ((int64_t)ni * a.Hout + 2 * iy + (ab >> 1)) * a.Wout + 2 * jx + (ab & 1);
+            dst = a.y + opix * a.ldy + co;
+          } else {
+            dst = a.y + (int64_t)m * a.ldy + n;
+          }
+          if (a.accumulate) v += *dst;
+          *dst = v;
+          if (do_stats) {
+            const float u = (a.stat_other != nullptr) ? a.stat_other[(int64_t)m * a.ldso + n] : v;
+            s1[j] += v;
+            s2[j] = fmaf(v, u, s2[j]);
+          }
+        }
+      }
+    }
+  }
+
+  if (do_stats) {
+    // all MFMA reads of As/Bs are behind the last loop barrier: reuse the LDS for the cross-wave sums
+    float* red = smem;  // [WM][2][BN]
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const float t1 = s1[j] + xor32(s1[j]);
+      const float t2 = s2[j] + xor32(s2[j]);
+      if (lh == 0) {
+        const int col = wn * (TN * 32) + j * 32 + li;
+        red[(wm * 2 + 0) * BN + col] = t1;
+        red[(wm * 2 + 1) * BN + col] = t2;
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 2 * BN; idx += NT) {
+      const int which = idx / BN, col = idx - which * BN;
+      const int n = n0 + col;
+      if (n < Ntot) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) s += red[(w * 2 + which) * BN + col];
+        a.stat_partials[((int64_t)blockIdx.x * 2 + which) * Ntot + n] = s;
+      }
+    }
+  }
+}
+
+// ---- host side -------------------------------------------------------------------------------------
+
+enum ConvCfg { CFG_128x128 = 0, CFG_128x64, CFG_256x32, CFG_64x64, CFG_32x64 };
+
+static void cfg_tile(ConvCfg c, int* bm, int* bn) {
+  switch (c) {
+    case CFG_128x128: *bm = 128; *bn = 128; break;
+    case CFG_128x64: *bm = 128; *bn = 64; break;
+    case CFG_256x32: *bm = 256; *bn = 32; break;
+    case CFG_64x64: *bm = 64; *bn = 64; break;
+    default: *bm = 32; *bn = 64; break;
+  }
+}
+
+// Largest tile that still gives the 256 CUs a few workgroups each; small problems take the small tiles.
+static ConvCfg pick_cfg(int64_t M, int Ntot) {
+  const int64_t want = 1024;
+  if (Ntot <= 32) {
+    if (ceil_div(M, 256) >= want / 2) return CFG_256x32;
+    return (ceil_div(M, 64) >= 256) ? CFG_64x64 : CFG_32x64;
+  }
+  if (Ntot >= 128 && ceil_div(M, 128) * ceil_div(Ntot, 128) >= want) return CFG_128x128;
+  if (ceil_div(M, 128) * ceil_div(Ntot, 64) >= want) return CFG_128x64;
+  if (ceil_div(M, 64) * ceil_div(Ntot, 64) >= want) return CFG_64x64;
+  return CFG_32x64;
+}
+
+template <int WM, int WN, int TM, int TN>
+static int launch(const ConvK& k, hipStream_t s) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  const size_t lds = (size_t)(2 * KC * (BM + 4) + 2 * KC * (BN + 4)) * sizeof(float);
+  dim3 grid((unsigned)ceil_div(k.Mtot, BM), (unsigned)ceil_div(k.a.Ntot, BN));
+  hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, TM, TN>), grid, dim3(WM * WN * 64), lds, s, k);
+  return check_launch("dfl_conv2d");
+}
+
+static int prepare(const dfl_conv_args* a, ConvK* k) {
+  DFL_REQUIRE(a != nullptr, "dfl_conv2d: null args");
+  DFL_REQUIRE(a->x && a->w && a->y, "dfl_conv2d: x, w and y are required");
+  DFL_REQUIRE(a->N > 0 && a->Hin > 0 && a->Win > 0 && a->Cin > 0 && a->Ntot > 0, "dfl_conv2d: bad sizes");
+  DFL_REQUIRE(a->KH > 0 && a->KW > 0 && a->stride > 0 && a->pad >= 0, "dfl_conv2d: bad window");
+  DFL_REQUIRE(a->ldx >= a->Cin, "dfl_conv2d: ldx < Cin");
+  DFL_REQUIRE((a->in_scale == nullptr) == (a->in_shift == nullptr), "dfl_conv2d: in_scale/in_shift go together");
+  DFL_REQUIRE((a->add_scale == nullptr) == (a->add_shift == nullptr), "dfl_conv2d: add_scale/add_shift go together");
+  k->a = *a;
+  if (a->scatter2x2) {
+    DFL_REQUIRE(a->KH == 1 && a->KW == 1 && a->stride == 1 && a->pad == 0, "dfl_conv2d: scatter2x2 needs a 1x1 gather");
+    DFL_REQUIRE(a->Ntot % 4 == 0, "dfl_conv2d: scatter2x2 needs Ntot = 4*Cout");
+    DFL_REQUIRE(a->Hout >= 2 * a->Hin && a->Wout >= 2 * a->Win, "dfl_conv2d: scatter target too small");
+    DFL_REQUIRE(a->add == nullptr && a->stat_partials == nullptr, "dfl_conv2d: scatter2x2 has no add/stats epilogue");
+    k->Hg = a->Hin;
+    k->Wg = a->Win;
+    k->Cout = a->Ntot / 4;
+  } else {
+    const int ho = (a->Hin + 2 * a->pad - a->KH) / a->stride + 1;
+    const int wo = (a->Win + 2 * a->pad - a->KW) / a->stride + 1;
+    DFL_REQUIRE(ho == a->Hout && wo == a->Wout, "dfl_conv2d: Hout/Wout (%d,%d) do not match the window (%d,%d)",
+                a->Hout, a->Wout, ho, wo);
+    k->Hg = a->Hout;
+    k->Wg = a->Wout;
+    k->Cout = a->Ntot;
+  }
+  DFL_REQUIRE(a->ldy >= k->Cout, "dfl_conv2d: ldy < Cout");
+  const int64_t M = (int64_t)a->N * k->Hg * k->Wg;
+  DFL_REQUIRE(M < (1ll << 31) && (int64_t)a->N * a->Hin * a->Win < (1ll << 31), "dfl_conv2d: too many pixels");
+  k->Mtot = (int)M;
+  k->Ktot = a->KH * a->KW * a->Cin;
+  k->vecA = (a->Cin % 4 == 0) && (a->ldx % 4 == 0) && aligned16(a->x) &&
+            (a->in_scale == nullptr || (aligned16(a->in_scale) && aligned16(a->in_shift)));
+  k->vecB = (a->Ntot % 4 == 0) && aligned16(a->w);
+  return DFL_OK;
+}
+
+}  // namespace dfl
+
+extern "C" int dfl_conv_grid_m(const dfl_conv_args* a) {
+  dfl::ConvK k;
+  int rc = dfl::prepare(a, &k);
+  if (rc != DFL_OK) return rc;
+  int bm, bn;
+  dfl::cfg_tile(dfl::pick_cfg(k.Mtot, a->Ntot), &bm, &bn);
+  return (int)dfl::ceil_div(k.Mtot, bm);
+}
+
+extern "C" int dfl_conv2d(const dfl_conv_args* a, dfl_stream_t stream) {
+  dfl::ConvK k;
+  int rc = dfl::prepare(a, &k);
+  if (rc != DFL_OK) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (dfl::pick_cfg(k.Mtot, a->Ntot)) {
+    case dfl::CFG_128x128: return dfl::launch<2, 2, 2, 2>(k, s);
+    case dfl::CFG_128x64: return dfl::launch<2, 2, 2, 1>(k, s);
+    case dfl::CFG_256x32: return dfl::launch<4, 1, 2, 1>(k, s);
+    case dfl::CFG_64x64: return dfl::launch<2, 2, 1, 1>(k, s);
+    default: return dfl::launch<1, 2, 1, 1>(k, s);
+  }
+}

@@ -1,0 +1,301 @@
+// Soft-Dice + NCC heat-map loss with closed-form gradients, and the ensemble reduction of test_ensemble.py.
+// Reference: train_test_code/dice.py:14-86, train_test_code/ncc.py:12-38, train_test_code/util.py:326-373.
+// Gradient formulas: SURVEY.md Appendix F (checked there against the reference's autograd in fp64).
+// All three loss kernels are HBM-bound streams over the [B,C,h,w] windows; the per-(image,channel) sums are
+// accumulated in fp64 (the reference sums in fp32 pairwise; fp64 is the tighter of the two).
+#include "common.h"
+
+namespace dfl {
+
+constexpr double DICE_EPS = 1.0e-4;  // dice.py:24
+constexpr double NCC_EPS = 1.0e-8;   // ncc.py:38
+
+__device__ __forceinline__ void block_sum5(double* v, int nv, double (*red)[256]) {
+  for (int k = 0; k < nv; ++k) red[k][threadIdx.x] = v[k];
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off)
+      for (int k = 0; k < nv; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + off];
+    __syncthreads();
+  }
+  for (int k = 0; k < nv; ++k) v[k] = red[k][0];
+}
+
+// blocks [0, B*C): Dice sums (sum t*s, sum t*t, sum s*s); blocks [B*C, B*C + B*L): NCC sums (x, y, xx, yy, xy).
+__global__ void __launch_bounds__(256) loss_sums_kernel(const dfl_loss_args a) {
+  __shared__ double red[5][256];
+  const int BC = a.B * a.C;
+  const int hw = a.h * a.w;
+  double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  if ((int)blockIdx.x < BC) {
+    const int n = blockIdx.x / a.C, c = blockIdx.x % a.C;
+    const float* s = a.seg + n * a.seg_sN + c * a.seg_sC;
+    const float* t = a.tseg + n * a.tseg_sN + c * a.tseg_sC;
+    for (int i = threadIdx.x; i < hw; i += 256) {
+      const int y = i / a.w, x = i - y * a.w;
+      const double sv = (double)s[y * a.seg_sH + x], tv = (double)t[y * a.tseg_sH + x];
+      v[0] += tv * sv;
+      v[1] += tv * tv;
+      v[2] += sv * sv;
+    }
+    block_sum5(v, 3, red);
+    if (threadIdx.x == 0) {
+      double* o = a.sums + (int64_t)blockIdx.x * 3;
+      o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+    }
+  } else {
+    const int b = blockIdx.x - BC;
+    const int n = b / a.L, l = b % a.L;
+    const float* xp = a.heat + n * a.heat_sN + l * a.heat_sC;
+    const float* yp = a.theat + n * a.theat_sN + l * a.theat_sC;
+    for (int i = threadIdx.x; i < hw; i += 256) {
+      const int y = i / a.w, x = i - y * a.w;
+      const double xv = (double)xp[y * a.heat_sH + x], yv = (double)yp[y * a.theat_sH + x];
+      v[0] += xv; v[1] += yv; v[2] += xv * xv; v[3] += yv * yv; v[4] += xv * yv;
+    }
+    block_sum5(v, 5, red);
+    if (threadIdx.x == 0) {
+      double* o = a.sums + (int64_t)BC * 3 + (int64_t)b * 5;
+      for (int k = 0; k < 5; ++k) o[k] = v[k];
+    }
+  }
+}
+
+// Single workgroup: loss value + per-(image,channel) gradient coefficients.
+__global__ void __launch_bounds__(256) loss_finalize_kernel(const dfl_loss_args a) {
+  __shared__ double red[2][256];
+  const int BC = a.B * a.C, BL = a.B * a.L;
+  const double* dsum = a.sums;
+  const double* nsum = a.sums + (int64_t)BC * 3;
+  double* dcoef = a.sums + (int64_t)BC * 3 + (int64_t)BL * 5;  // [BC][2]
+  double* ncoef = dcoef + (int64_t)BC * 2;                      // [BL][3]
+  const int ceff = a.C - (a.skip_bg ? 1 : 0);
+  double dice_acc = 0.0, ncc_acc = 0.0;
+  if (a.dice_wgt != 0.f && a.C > 0) {
+    const double g = (double)a.dice_wgt / ((double)a.B * (double)ceff);
+    for (int i = threadIdx.x; i < BC; i += 256) {
+      const int c = i % a.C;
+      double a1 = 0.0, a2 = 0.0;
+      if (!(a.skip_bg && c == 0)) {
+        const double I = dsum[i * 3 + 0], T = dsum[i * 3 + 1], S = dsum[i * 3 + 2];
+        const double num = -2.0 * I + DICE_EPS, den = T + S + DICE_EPS;
+        dice_acc += num / den;
+        a1 = -2.0 / den * g;
+        a2 = -2.0 * num / (den * den) * g;
+      }
+      dcoef[i * 2 + 0] = a1;
+      dcoef[i * 2 + 1] = a2;
+    }
+  }
+  if (a.L > 0 && (a.heat_wgt != 0.f || a.ncc_vals != nullptr)) {
+    const double N = (double)a.h * (double)a.w;
+    const double q = -0.5 * (double)a.heat_wgt / (double)BL;
+    for (int i = threadIdx.x; i < BL; i += 256) {
+      const double sx = nsum[i * 5 + 0], sy = nsum[i * 5 + 1], sxx = nsum[i * 5 + 2], syy = nsum[i * 5 + 3],
+                   sxy = nsum[i * 5 + 4];
+      const double mx = sx / N, my = sy / N;
+      double va = sxx - sx * mx, vb = syy - sy * my;  // sum of squared deviations
+      if (va < 0.0) va = 0.0;
+      if (vb < 0.0) vb = 0.0;
+      const double cxy = sxy - sx * my;
+      const double sdx = sqrt(va / (N - 1.0)), sdy = sqrt(vb / (N - 1.0));
+      const double D = N * sdx * sdy + NCC_EPS;
+      const double ncc = cxy / D;
+      if (a.ncc_vals != nullptr) a.ncc_vals[i] = (float)ncc;
+      ncc_acc += -(ncc + 1.0) * 0.5;
+      const double E = cxy * N * sdy / (D * D * (N - 1.0) * sdx);
+      const double k1 = q / D, k2 = -q * E;
+      ncoef[i * 3 + 0] = k1;
+      ncoef[i * 3 + 1] = k2;
+      ncoef[i * 3 + 2] = -k1 * my - k2 * mx;
+    }
+  }
+  red[0][threadIdx.x] = dice_acc;
+  red[1][threadIdx.x] = ncc_acc;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + off];
+      red[1][threadIdx.x] += red[1][threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    double loss = 0.0;
+    if (a.dice_wgt != 0.f && a.C > 0) loss += (double)a.dice_wgt * red[0][0] / ((double)a.B * (double)ceff);
+    if (a.L > 0 && a.heat_wgt != 0.f) loss += (double)a.heat_wgt * red[1][0] / (double)BL;
+    *a.loss = (float)loss;
+  }
+}
+
+__global__ void __launch_bounds__(256) loss_grad_kernel(const dfl_loss_args a) {
+  const int BC = a.B * a.C, BL = a.B * a.L;
+  const int64_t hw = (int64_t)a.h * a.w;
+  const double* dcoef = a.sums + (int64_t)BC * 3 + (int64_t)BL * 5;
+  const double* ncoef = dcoef + (int64_t)BC * 2;
+  const int64_t nseg = (a.dseg != nullptr) ? (int64_t)BC * hw : 0;
+  const int64_t nheat = (a.dheat != nullptr && a.L > 0) ? (int64_t)BL * hw : 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nseg + nheat; i += stride) {
+    if (i < nseg) {
+      const int64_t pc = i / hw;
+      const int64_t rem = i - pc * hw;
+      const int y = (int)(rem / a.w), x = (int)(rem - (int64_t)y * a.w);
+      const int n = (int)(pc / a.C), c = (int)(pc % a.C);
+      const float a1 = (float)dcoef[pc * 2 + 0], a2 = (float)dcoef[pc * 2 + 1];
+      const float sv = a.seg[n * a.seg_sN + c * a.seg_sC + y * a.seg_sH + x];
+      const float tv = a.tseg[n * a.tseg_sN + c * a.tseg_sC + y * a.tseg_sH + x];
+      a.dseg[i] = fmaf(a1, tv, a2 * sv);
+    } else {
+      const int64_t j = i - nseg;
+      const int64_t pc = j / hw;
+      const int64_t rem = j - pc * hw;
+      const int y = (int)(rem / a.w), x = (int)(rem - (int64_t)y * a.w);
+      const int n = (int)(pc / a.L), l = (int)(pc % a.L);
+      const float k1 = (float)ncoef[pc * 3 + 0], k2 = (float)ncoef[pc * 3 + 1], k0 = (float)ncoef[pc * 3 + 2];
+      const float xv = a.heat[n * a.heat_sN + l * a.heat_sC + y * a.heat_sH + x];
+      const float yv = a.theat[n * a.theat_sN + l * a.theat_sC + y * a.theat_sH + x];
+      a.dheat[j] = fmaf(k1, yv, fmaf(k2, xv, k0));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ ensemble
+__global__ void __launch_bounds__(256) ens_minmax_partial(const dfl_ensemble_args a, float* part, int nblk) {
+  __shared__ float rmin[256], rmax[256];
+  const int net = blockIdx.y;
+  const float* hp = a.heat_ptrs[net];
+  const int64_t hw = (int64_t)a.h * a.w, total = (int64_t)a.L * hw;
+  float mn = INFINITY, mx = -INFINITY;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)nblk * 256) {
+    const int l = (int)(i / hw);
+    const int64_t rem = i - (int64_t)l * hw;
+    const int y = (int)(rem / a.w), x = (int)(rem - (int64_t)y * a.w);
+    const float v = hp[((int64_t)l * a.Hp + a.oy + y) * a.Wp + a.ox + x];
+    mn = fminf(mn, v);
+    mx = fmaxf(mx, v);
+  }
+  rmin[threadIdx.x] = mn;
+  rmax[threadIdx.x] = mx;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      rmin[threadIdx.x] = fminf(rmin[threadIdx.x], rmin[threadIdx.x + off]);
+      rmax[threadIdx.x] = fmaxf(rmax[threadIdx.x], rmax[threadIdx.x + off]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    part[((int64_t)net * nblk + blockIdx.x) * 2 + 0] = rmin[0];
+    part[((int64_t)net * nblk + blockIdx.x) * 2 + 1] = rmax[0];
+  }
+}
+
+__global__ void __launch_bounds__(256) ens_minmax_final(const float* part, float* minmax, int nblk) {
+  __shared__ float rmin[256], rmax[256];
+  const int net = blockIdx.x;
+  float mn = INFINITY, mx = -INFINITY;
+  for (int i = threadIdx.x; i < nblk; i += 256) {
+    mn = fminf(mn, part[((int64_t)net * nblk + i) * 2 + 0]);
+    mx = fmaxf(mx, part[((int64_t)net * nblk + i) * 2 + 1]);
+  }
+  rmin[threadIdx.x] = mn;
+  rmax[threadIdx.x] = mx;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      rmin[threadIdx.x] = fminf(rmin[threadIdx.x], rmin[threadIdx.x + off]);
+      rmax[threadIdx.x] = fmaxf(rmax[threadIdx.x], rmax[threadIdx.x + off]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    minmax[net * 2 + 0] = rmin[0];
+    minmax[net * 2 + 1] = rmax[0];
+  }
+}
+
+// One thread per output pixel: mean over nets (summed in net order, then one division, as util.py:340-343,359),
+// first-maximum argmax (torch.max(dim=1), util.py:361), min-max normalised heat maps (util.py:348-356,370).
+__global__ void __launch_bounds__(256) ens_final(const dfl_ensemble_args a) {
+  const int64_t hw = (int64_t)a.h * a.w;
+  const int64_t pHW = (int64_t)a.Hp * a.Wp;
+  const float fn = (float)a.nnets;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += (int64_t)gridDim.x * blockDim.x) {
+    const int y = (int)(i / a.w), x = (int)(i - (int64_t)y * a.w);
+    const int64_t po = (int64_t)(a.oy + y) * a.Wp + a.ox + x;
+    float best = 0.f;
+    int arg = 0;
+    for (int c = 0; c < a.C; ++c) {
+      float s = a.seg_ptrs[0][c * pHW + po];
+      for (int k = 1; k < a.nnets; ++k) s += a.seg_ptrs[k][c * pHW + po];
+      s = s / fn;
+      if (a.avg_seg != nullptr) a.avg_seg[c * hw + i] = s;
+      if (c == 0 || s > best) {
+        best = s;
+        arg = c;
+      }
+    }
+    a.labels[i] = (uint8_t)arg;
+    if (a.heat_out != nullptr) {
+      for (int l = 0; l < a.L; ++l) {
+        float s = 0.f;
+        for (int k = 0; k < a.nnets; ++k) {
+          float v = a.heat_ptrs[k][l * pHW + po];
+          if (!a.raw_heat) {
+            const float mn = a.minmax[k * 2 + 0], mx = a.minmax[k * 2 + 1];
+            v = (v - mn) / (mx - mn);
+          }
+          s = (k == 0) ? v : s + v;
+        }
+        a.heat_out[l * hw + i] = s / fn;
+      }
+    }
+  }
+}
+
+}  // namespace dfl
+
+using namespace dfl;
+
+extern "C" int64_t dfl_loss_scratch_doubles(int32_t B, int32_t C, int32_t L) {
+  return (int64_t)B * C * 5 + (int64_t)B * L * 8 + 8;
+}
+
+extern "C" int dfl_dice_ncc_loss(const dfl_loss_args* a, dfl_stream_t stream) {
+  DFL_REQUIRE(a && a->loss && a->sums, "dfl_dice_ncc_loss: loss and sums are required");
+  DFL_REQUIRE(a->B > 0 && a->C >= 0 && a->L >= 0 && a->C + a->L > 0 && a->h > 0 && a->w > 0, "dfl_dice_ncc_loss: bad sizes");
+  DFL_REQUIRE(a->C == 0 || (a->seg && a->tseg), "dfl_dice_ncc_loss: seg and tseg are required when C > 0");
+  DFL_REQUIRE(a->L == 0 || (a->heat && a->theat), "dfl_dice_ncc_loss: heat and theat are required when L > 0");
+  DFL_REQUIRE(a->L == 0 || (int64_t)a->h * a->w > 1, "dfl_dice_ncc_loss: NCC needs more than one pixel");
+  DFL_REQUIRE(!(a->skip_bg && a->C < 2), "dfl_dice_ncc_loss: skip_bg needs at least 2 classes");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(loss_sums_kernel, dim3((unsigned)(a->B * (a->C + a->L))), dim3(256), 0, s, *a);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, *a);
+  if (a->dseg != nullptr || (a->dheat != nullptr && a->L > 0)) {
+    const int64_t total = (int64_t)a->B * (a->C + a->L) * a->h * a->w;
+    int64_t blocks = ceil_div(total, 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(loss_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, s, *a);
+  }
+  return check_launch("dfl_dice_ncc_loss");
+}
+
+extern "C" int dfl_ensemble_reduce(const dfl_ensemble_args* a, dfl_stream_t stream) {
+  DFL_REQUIRE(a && a->seg_ptrs && a->labels, "dfl_ensemble_reduce: missing pointer");
+  DFL_REQUIRE(a->nnets > 0 && a->C > 0 && a->C <= 255 && a->h > 0 && a->w > 0, "dfl_ensemble_reduce: bad sizes");
+  DFL_REQUIRE(a->oy >= 0 && a->ox >= 0 && a->oy + a->h <= a->Hp && a->ox + a->w <= a->Wp, "dfl_ensemble_reduce: crop window");
+  DFL_REQUIRE(a->heat_out == nullptr || (a->heat_ptrs && (a->minmax || a->raw_heat) && a->L > 0), "dfl_ensemble_reduce: heat inputs");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (a->heat_out != nullptr && !a->raw_heat) {
+    // the partial min/max rows live behind the final [nnets][2] table in the same scratch
+    const int nblk = 64;
+    float* part = a->minmax + 2 * a->nnets;
+    hipLaunchKernelGGL(ens_minmax_partial, dim3(nblk, (unsigned)a->nnets), dim3(256), 0, s, *a, part, nblk);
+    hipLaunchKernelGGL(ens_minmax_final, dim3((unsigned)a->nnets), dim3(256), 0, s, part, a->minmax, nblk);
+  }
+  int64_t blocks = ceil_div((int64_t)a->h * a->w, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(ens_final, dim3((unsigned)blocks), dim3(256), 0, s, *a);
+  return check_launch("dfl_ensemble_reduce");
+}

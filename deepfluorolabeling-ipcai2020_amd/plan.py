@@ -1,0 +1,543 @@
+"""Execution plans for the U-Net: the graph builder that turns one (architecture, input shape, mode) into recorded
+lists of libdfl_hip.so calls (forward, backward, weight re-layout) plus the HBM buffers they run on.
+
+Reference being restated: UNet.forward / UNetConvBlock.forward / UNetUpBlock.forward
+(train_test_code/unet.py:161-193, 226-233, 254-260) and their autograd.  Data layout: every internal activation
+is NHWC fp32; torch.cat([up, bridge], 1) (unet.py:257) is free because both producers write straight into the two
+channel halves of one buffer (pixel stride 2C); BatchNorm is never applied as a separate pass -- its scale/shift
+ride on the next consumer's loads (see include/dfl_hip.h).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native as nat
+from ._native import (ConvArgs, WgradArgs, PackJob, BnFinalizeArgs, ColstatsArgs, BnBwdFinalizeArgs, BnReluBwdArgs,
+                      AffineCopyArgs, PoolArgs, HeadFwdArgs, HeadBwdArgs, SumPartialsArgs, PackArgs, BnEvalArgs,
+                      ReducePartialsArgs, MemsetArgs, Program)
+
+BN_EPS = 1.0e-5
+BN_MOMENTUM = 0.1
+
+
+class Act:
+    """An NHWC activation window: channels [0, C) of rows with pixel stride ld starting at ptr."""
+    __slots__ = ('t', 'ptr', 'ld', 'N', 'H', 'W', 'C')
+
+    def __init__(self, t, ptr, ld, N, H, W, C):
+        self.t, self.ptr, self.ld, self.N, self.H, self.W, self.C = t, ptr, ld, N, H, W, C
+
+    @property
+    def M(self):
+        return self.N * self.H * self.W
+
+    def chan_slice(self, c0, c):
+        return Act(self.t, self.ptr + 4 * c0, self.ld, self.N, self.H, self.W, c)
+
+
+class PlanError(RuntimeError):
+    pass
+
+
+class UNetPlan:
+    def __init__(self, cfg, params, buffers, N, H, W, training, need_grad, device):
+        """cfg: dict of the UNet constructor flags; params / buffers: name -> tensor (module state)."""
+        self.cfg = cfg
+        self.P = params
+        self.Bf = buffers
+        self.N, self.H, self.W = N, H, W
+        self.training = training
+        self.need_grad = need_grad
+        self.dev = device
+        self.lib = nat.lib()
+        self._keep = []
+        self.fwd = Program()
+        self.bwd = Program() if need_grad else None
+        self._pack_jobs = []
+        self._pack_dsts = []
+        self.busy = False
+        self.generation = 0
+        self._scratch = {}
+        self._build()
+
+    # ------------------------------------------------------------------------------------------ memory
+    def _new(self, nelem, dtype=torch.float32):
+        t = torch.empty(max(int(nelem), 1), dtype=dtype, device=self.dev)
+        self._keep.append(t)
+        return t
+
+    def _act(self, N, H, W, C):
+        t = self._new(N * H * W * C)
+        return Act(t, t.data_ptr(), C, N, H, W, C)
+
+    def _scratch_act(self, key, N, H, W, C):
+        """Backward scratch shared by all blocks (stream order makes reuse safe)."""
+        need = N * H * W * C
+        t = self._scratch.get(key)
+        if t is None or t.numel() < need:
+            raise PlanError('scratch %s not sized' % key)
+        return Act(t, t.data_ptr(), C, N, H, W, C)
+
+    # ------------------------------------------------------------------------------------------ weights
+    def _pack(self, src, D, s, off=0):
+        """Register a re-layout job; returns the destination tensor [D0][D1][D2]."""
+        dst = self._new(D[0] * D[1] * D[2])
+        self._pack_jobs.append((src, dst, off, D, s))
+        return dst
+
+    def _pack_conv_fwd(self, w):      # [Co][Ci][KH][KW] -> [T][Ci][Co]
+        Co, Ci, KH, KW = w.shape
+        T = KH * KW
+        return self._pack(w, (T, Ci, Co), (1, T, Ci * T))
+
+    def _pack_conv_dgrad(self, w):    # stride-1 conv: [Co][Ci][T] -> [T flipped][Co][Ci]
+        Co, Ci, KH, KW = w.shape
+        T = KH * KW
+        return self._pack(w, (T, Co, Ci), (-1, Ci * T, T), off=T - 1)
+
+    def _pack_down_dgrad(self, w):    # conv2x2 s2: [Co][Ci][ab] -> [Co][ab][Ci] (scatter form)
+        Co, Ci, KH, KW = w.shape
+        T = KH * KW
+        return self._pack(w, (Co, T, Ci), (Ci * T, 1, T))
+
+    def _pack_convT_fwd(self, w):     # [Ci][Co][ab] -> [Ci][ab][Co] (scatter form)
+        Ci, Co, KH, KW = w.shape
+        T = KH * KW
+        return self._pack(w, (Ci, T, Co), (Co * T, 1, T))
+
+    def _pack_convT_dgrad(self, w):   # [Ci][Co][ab] -> [ab][Co][Ci]
+        Ci, Co, KH, KW = w.shape
+        T = KH * KW
+        return self._pack(w, (T, Co, Ci), (1, T, Co * T))
+
+    def _finish_pack(self):
+        n = len(self._pack_jobs)
+        self.pack = Program()
+        if n == 0:
+            return
+        arr = (PackJob * n)()
+        mx = 0
+        for i, (src, dst, off, D, s) in enumerate(self._pack_jobs):
+            arr[i].src, arr[i].dst, arr[i].off = src.data_ptr(), dst.data_ptr(), off
+            arr[i].D0, arr[i].D1, arr[i].D2 = D
+            arr[i].s0, arr[i].s1, arr[i].s2 = s
+            mx = max(mx, D[0] * D[1] * D[2])
+        raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+        self._jobs_dev = torch.from_numpy(raw).to(self.dev)
+        self._keep.append(self._jobs_dev)
+        self.pack.add(PackArgs(jobs_dev=self._jobs_dev.data_ptr(), max_elems=mx, njobs=n))
+
+    # ------------------------------------------------------------------------------------------ op helpers
+    def _conv(self, prog, x, w, y, KH, KW, stride, pad, Ntot, bias=None, in_aff=None, relu=0, add=None,
+              add_aff=None, accumulate=0, scatter=0, stats=False, stat_other=None, Hout=None, Wout=None):
+        a = ConvArgs()
+        a.x, a.w, a.y = x.ptr, w.data_ptr(), y.ptr
+        a.bias = nat.ptr(bias)
+        if in_aff is not None:
+            a.in_scale, a.in_shift = in_aff[0].data_ptr(), in_aff[1].data_ptr()
+        if add is not None:
+            a.add, a.ldadd = add.ptr, add.ld
+            if add_aff is not None:
+                a.add_scale, a.add_shift = add_aff[0].data_ptr(), add_aff[1].data_ptr()
+        a.N, a.Hin, a.Win, a.Cin, a.ldx = x.N, x.H, x.W, x.C, x.ld
+        a.KH, a.KW, a.stride, a.pad = KH, KW, stride, pad
+        a.Hout, a.Wout = (y.H, y.W) if Hout is None else (Hout, Wout)
+        a.Ntot, a.ldy = Ntot, y.ld
+        a.relu, a.accumulate, a.scatter2x2 = relu, accumulate, scatter
+        partials = None
+        if stats:
+            gm = nat.check(self.lib.dfl_conv_grid_m(C.addressof(a)), 'dfl_conv_grid_m')
+            partials = self._new(gm * 2 * Ntot)
+            a.stat_partials = partials.data_ptr()
+            if stat_other is not None:
+                a.stat_other, a.ldso = stat_other.ptr, stat_other.ld
+            partials = (partials, gm)
+        prog.add(a)
+        return partials
+
+    def _wgrad(self, prog, g, d, dw, KH, KW, stride, pad, Hout, Wout, in_aff=None):
+        a = WgradArgs()
+        a.g, a.d, a.dw = g.ptr, d.ptr, dw.data_ptr()
+        if in_aff is not None:
+            a.in_scale, a.in_shift = in_aff[0].data_ptr(), in_aff[1].data_ptr()
+        a.N, a.Hin, a.Win, a.Cg, a.ldg = g.N, g.H, g.W, g.C, g.ld
+        a.KH, a.KW, a.stride, a.pad = KH, KW, stride, pad
+        a.Hout, a.Wout, a.Cm, a.ldd = Hout, Wout, d.C, d.ld
+        a.splits = 1
+        s = nat.check(self.lib.dfl_wgrad_suggest_splits(C.addressof(a)), 'dfl_wgrad_suggest_splits')
+        a.splits = s
+        if s > 1:
+            n = d.C * g.C * KH * KW
+            part = self._wg_partial(s * n)
+            a.partial = part.data_ptr()
+            prog.add(a)
+            prog.add(SumPartialsArgs(src=part.data_ptr(), dst=dw.data_ptr(), n=n, splits=s))
+        else:
+            prog.add(a)
+
+    def _wg_partial(self, nelem):
+        t = self._scratch.get('wg_partial')
+        if t is None or t.numel() < nelem:
+            t = self._new(nelem)
+            self._scratch['wg_partial'] = t
+        return t
+
+    def _colsum(self, prog, a, out):
+        """out[c] = sum over pixels of a[:, c]."""
+        nb = self.lib.dfl_rowblock_count(a.M, a.C)
+        part = self._new(nb * 2 * a.C)
+        prog.add(ColstatsArgs(a=a.ptr, b=None, partials=part.data_ptr(), M=a.M, C=a.C, lda=a.ld, ldb=0, nblocks=nb))
+        prog.add(ReducePartialsArgs(partials=part.data_ptr(), out=out.data_ptr(), nblocks=nb, stride=2 * a.C, C=a.C))
+
+    # ------------------------------------------------------------------------------------------ build
+    def _build(self):
+        cfg = self.cfg
+        depth, wf = cfg['depth'], cfg['wf']
+        pad = 1 if cfg['padding'] else 0
+        bd = cfg['block_depth']
+        bn = cfg['batch_norm']
+        do_res = cfg['do_res']
+        N = self.N
+        chans = [2 ** (wf + i) for i in range(depth)]
+        for c in chans:
+            if c % 4 != 0:
+                raise PlanError('channel counts must be multiples of 4 (wf >= 2)')
+        shrink = 0 if pad else 2 * bd
+        # spatial size of every level (input / output of the block), down then up
+        hin, win = [self.H], [self.W]
+        hout, wout = [], []
+        for i in range(depth):
+            ho, wo = hin[i] - shrink, win[i] - shrink
+            if ho < 1 or wo < 1:
+                raise PlanError('input %dx%d too small for this architecture' % (self.H, self.W))
+            hout.append(ho)
+            wout.append(wo)
+            if i != depth - 1:
+                if ho < 2 or wo < 2:
+                    raise PlanError('input %dx%d too small for this architecture' % (self.H, self.W))
+                hin.append(ho // 2)
+                win.append(wo // 2)
+        if do_res and shrink != 0:
+            raise PlanError('do_res=True needs padding=True: the 1x1 residual and the unpadded 3x3 stack differ in '
+                            'size (the reference fails at unet.py:231 for the same reason)')
+
+        # backward scratch: sized for the largest [M][C] any block produces
+        if self.need_grad:
+            mx = 0
+            h, w = self.H, self.W
+            sizes = []
+            for i in range(depth):
+                sizes.append((N * hin[i] * win[i], chans[i]))
+            uh, uw = hout[depth - 1], wout[depth - 1]
+            for i in reversed(range(depth - 1)):
+                uh, uw = 2 * uh, 2 * uw
+                sizes.append((N * uh * uw, chans[i]))
+                uh, uw = uh - shrink, uw - shrink
+            mx = max(m * c for m, c in sizes)
+            self._scratch['dpre'] = self._new(mx)
+            self._scratch['dz'] = self._new(mx)
+
+        fwd, bwd = self.fwd, self.bwd
+        Cin0 = cfg['in_channels']
+        self.x_in = self._new(N * self.H * self.W * Cin0)
+        x0 = Act(self.x_in, self.x_in.data_ptr(), Cin0, N, self.H, self.W, Cin0)
+
+        # cat buffers for the up path are allocated up front so that down blocks can write their bridge half directly
+        up_hw = []           # size of the up-sampled tensor at level i (i = depth-2 .. 0)
+        uh, uw = hout[depth - 1], wout[depth - 1]
+        for i in reversed(range(depth - 1)):
+            uh, uw = 2 * uh, 2 * uw
+            up_hw.append((uh, uw))
+            uh, uw = uh - shrink, uw - shrink
+        self.last_hw = (uh, uw)
+        cat = {}
+        dcat = {}
+        direct_bridge = {}
+        for j, i in enumerate(reversed(range(depth - 1))):
+            ch, cw = up_hw[j]
+            cat[i] = self._act(N, ch, cw, 2 * chans[i])
+            direct_bridge[i] = (ch == hout[i] and cw == wout[i])
+            if self.need_grad:
+                dcat[i] = self._act(N, ch, cw, 2 * chans[i])
+
+        bwd_stages = []      # closures appended in forward order, executed reversed
+
+        # ------------------------------------------------------------------ one residual conv block
+        def block(prefix, xin, out, first=False):
+            """Forward ops of UNetConvBlock `prefix` reading xin, writing out; returns a backward emitter."""
+            P = self.P
+            Cout = out.C
+            Hb, Wb = xin.H - shrink, xin.W - shrink
+            convs = []
+            cur, cur_aff = xin, None
+            step = 3 if bn else 2
+            for d in range(bd):
+                wname = '%s.block.%d' % (prefix, d * step)
+                w, b = P[wname + '.weight'], P[wname + '.bias']
+                wp = self._pack_conv_fwd(w)
+                Ho, Wo = cur.H - (0 if pad else 2), cur.W - (0 if pad else 2)
+                r = self._act(N, Ho, Wo, Cout)
+                part = self._conv(fwd, cur, wp, r, 3, 3, 1, pad, Cout, bias=b, in_aff=cur_aff, relu=1,
+                                   stats=bn and self.training)
+                aff = None
+                bnrec = None
+                if bn:
+                    bname = '%s.block.%d' % (prefix, d * step + 2)
+                    gamma, beta = P[bname + '.weight'], P[bname + '.bias']
+                    scale, shift = self._new(Cout), self._new(Cout)
+                    mean, invstd = self._new(Cout), self._new(Cout)
+                    if self.training:
+                        fa = BnFinalizeArgs(partials=part[0].data_ptr(), gamma=gamma.data_ptr(), beta=beta.data_ptr(),
+                                            running_mean=self.Bf[bname + '.running_mean'].data_ptr(),
+                                            running_var=self.Bf[bname + '.running_var'].data_ptr(),
+                                            num_batches_tracked=self.Bf[bname + '.num_batches_tracked'].data_ptr(),
+                                            scale=scale.data_ptr(), shift=shift.data_ptr(),
+                                            save_mean=mean.data_ptr(), save_invstd=invstd.data_ptr(),
+                                            count=N * Ho * Wo, nblocks=part[1], C=Cout, eps=BN_EPS, momentum=BN_MOMENTUM)
+                        fwd.add(fa)
+                    else:
+                        fwd.add(BnEvalArgs(gamma=gamma.data_ptr(), beta=beta.data_ptr(),
+                                           running_mean=self.Bf[bname + '.running_mean'].data_ptr(),
+                                           running_var=self.Bf[bname + '.running_var'].data_ptr(),
+                                           scale=scale.data_ptr(), shift=shift.data_ptr(), C=Cout, eps=BN_EPS))
+                    aff = (scale, shift)
+                    bnrec = (gamma, mean, invstd, bname)
+                convs.append(dict(w=w, wname=wname, inp=cur, inp_aff=cur_aff, r=r, bn=bnrec))
+                cur, cur_aff = r, aff
+            assert cur.H == Hb and cur.W == Wb
+            if do_res:
+                rw, rb = P[prefix + '.res_conv1x1.weight'], P[prefix + '.res_conv1x1.bias']
+                rwp = self._pack_conv_fwd(rw)
+                self._conv(fwd, xin, rwp, out, 1, 1, 1, 0, Cout, bias=rb, add=cur, add_aff=cur_aff)
+            else:
+                a = AffineCopyArgs(x=cur.ptr, y=out.ptr, N=N, H=Hb, W=Wb, C=Cout, ldx=cur.ld, xH=Hb, xW=Wb,
+                                   ldy=out.ld, yH=out.H, yW=out.W)
+                if cur_aff is not None:
+                    a.scale, a.shift = cur_aff[0].data_ptr(), cur_aff[1].data_ptr()
+                fwd.add(a)
+
+            def backward(dout, dxin):
+                """dout: Act with d(loss)/d(block output); dxin: Act to receive d/d(xin) (None for the net input)."""
+                G = self.G
+                wrote_dxin = False
+                if do_res:
+                    self._wgrad(bwd, xin, dout, G[prefix + '.res_conv1x1.weight'], 1, 1, 1, 0, xin.H, xin.W)
+                    if dxin is not None:
+                        # 1x1 data gradient: B[k=co][n=ci] is the weight tensor itself
+                        self._conv(bwd, dout, rw, dxin, 1, 1, 1, 0, xin.C)
+                        wrote_dxin = True
+                g = dout
+                for d in reversed(range(bd)):
+                    cv = convs[d]
+                    r = cv['r']
+                    dpre = self._scratch_act('dpre', N, r.H, r.W, Cout)
+                    nb = self.lib.dfl_rowblock_count(r.M, Cout)
+                    coef = None
+                    if cv['bn'] is not None:
+                        gamma, mean, invstd, bname = cv['bn']
+                        part = self._new(nb * 2 * Cout)
+                        bwd.add(ColstatsArgs(a=g.ptr, b=r.ptr, partials=part.data_ptr(), M=r.M, C=Cout, lda=g.ld,
+                                             ldb=r.ld, nblocks=nb))
+                        coef = self._new(3 * Cout)
+                        bwd.add(BnBwdFinalizeArgs(partials=part.data_ptr(), gamma=gamma.data_ptr(),
+                                                  save_mean=mean.data_ptr(), save_invstd=invstd.data_ptr(),
+                                                  dgamma=G[bname + '.weight'].data_ptr(),
+                                                  dbeta=G[bname + '.bias'].data_ptr(), coef=coef.data_ptr(),
+                                                  count=r.M, nblocks=nb, C=Cout))
+                        if do_res and d == bd - 1:
+                            # residual bias gradient = column sums of dout, already in the same partials
+                            bwd.add(ReducePartialsArgs(partials=part.data_ptr(),
+                                                       out=G[prefix + '.res_conv1x1.bias'].data_ptr(), nblocks=nb,
+                                                       stride=2 * Cout, C=Cout))
+                    elif do_res and d == bd - 1:
+                        self._colsum(bwd, g, G[prefix + '.res_conv1x1.bias'])
+                    bpart = self._new(nb * Cout)
+                    bwd.add(BnReluBwdArgs(dy=g.ptr, r=r.ptr, coef=nat.ptr(coef), dpre=dpre.ptr,
+                                          partials=bpart.data_ptr(), M=r.M, C=Cout, lddy=g.ld, ldr=r.ld, ldo=dpre.ld,
+                                          nblocks=nb))
+                    bwd.add(ReducePartialsArgs(partials=bpart.data_ptr(), out=G[cv['wname'] + '.bias'].data_ptr(),
+                                               nblocks=nb, stride=Cout, C=Cout))
+                    inp = cv['inp']
+                    self._wgrad(bwd, inp, dpre, G[cv['wname'] + '.weight'], 3, 3, 1, pad, r.H, r.W,
+                                in_aff=cv['inp_aff'])
+                    if d > 0:
+                        wd = self._pack_conv_dgrad(cv['w'])
+                        dz = self._scratch_act('dz', N, inp.H, inp.W, Cout)
+                        self._conv(bwd, dpre, wd, dz, 3, 3, 1, 2 - pad, Cout)
+                        g = dz
+                    elif dxin is not None:
+                        wd = self._pack_conv_dgrad(cv['w'])
+                        self._conv(bwd, dpre, wd, dxin, 3, 3, 1, 2 - pad, xin.C, accumulate=1 if wrote_dxin else 0)
+            return backward
+
+        # ------------------------------------------------------------------ down path
+        x = x0
+        dx_in = None        # gradient Act of the current block input (None for the network input)
+        pending = []        # (kind, data) records consumed when emitting backward
+        down_out = []
+        for i in range(depth):
+            Ci = chans[i]
+            if i != depth - 1 and direct_bridge[i]:
+                out = cat[i].chan_slice(Ci, Ci)
+            else:
+                out = self._act(N, hout[i], wout[i], Ci)
+            bw = block('down_path.%d' % i, x, out, first=(i == 0))
+            down_out.append(out)
+            rec = dict(block_bw=bw, out=out, xin=x, level=i)
+            if i != depth - 1:
+                if not direct_bridge[i]:
+                    ch, cw = up_hw[depth - 2 - i]
+                    oy, ox = (hout[i] - ch) // 2, (wout[i] - cw) // 2
+                    dst = cat[i].chan_slice(Ci, Ci)
+                    fwd.add(AffineCopyArgs(x=out.ptr, y=dst.ptr, N=N, H=ch, W=cw, C=Ci, ldx=out.ld, xH=out.H, xW=out.W,
+                                           xoy=oy, xox=ox, ldy=dst.ld, yH=ch, yW=cw))
+                    rec['crop'] = (oy, ox, ch, cw)
+                nxt = self._act(N, hin[i + 1], win[i + 1], Ci)
+                if cfg['max_pool']:
+                    fwd.add_pool(PoolArgs(x=out.ptr, y=nxt.ptr, N=N, H=out.H, W=out.W, C=Ci, ldx=out.ld, ldy=nxt.ld),
+                                 backward=False)
+                else:
+                    dw_, db_ = self.P['downsample_convs.%d.weight' % i], self.P['downsample_convs.%d.bias' % i]
+                    wp = self._pack_conv_fwd(dw_)
+                    self._conv(fwd, out, wp, nxt, 2, 2, 2, 0, Ci, bias=db_)
+                rec['nxt'] = nxt
+                x = nxt
+            pending.append(rec)
+
+        # ------------------------------------------------------------------ up path
+        up_recs = []
+        u = down_out[depth - 1]
+        for j, i in enumerate(reversed(range(depth - 1))):
+            Ci = chans[i]
+            name = 'up_path.%d' % j
+            uw_, ub_ = self.P[name + '.up.weight'], self.P[name + '.up.bias']
+            wp = self._pack_convT_fwd(uw_)
+            ch, cw = up_hw[j]
+            up_half = cat[i].chan_slice(0, Ci)
+            self._conv(fwd, u, wp, up_half, 1, 1, 1, 0, 4 * Ci, bias=ub_, scatter=1, Hout=ch, Wout=cw)
+            out = self._act(N, ch - shrink, cw - shrink, Ci)
+            bw = block(name + '.conv_block', cat[i], out)
+            up_recs.append(dict(block_bw=bw, out=out, u=u, level=i, name=name, w=uw_))
+            u = out
+        self.feat = u
+
+        # ------------------------------------------------------------------ heads
+        NC, L = cfg['n_classes'], cfg['num_lands']
+        F = u.C
+        self.NC, self.L = NC, L
+        w_seg = self.P['seg_conv.weight']
+        w_l1 = self.P['lands_1x1.0.weight'] if L > 0 else None
+        w_l2 = self.P.get('lands_1x1.1.weight') if L > 0 else None
+        NM = w_l1.shape[0] if L > 0 else 0
+        self.head_fwd = HeadFwdArgs(x=u.ptr, w_seg=w_seg.data_ptr(), w_l1=nat.ptr(w_l1), w_l2=nat.ptr(w_l2),
+                                    N=N, H=u.H, W=u.W, F=F, ldx=u.ld, NC=NC, NM=NM, L=L,
+                                    softmax=1 if cfg['do_soft_max'] else 0)
+        fwd.add(self.head_fwd)
+        self.out_hw = (u.H, u.W)
+
+        self._n_fwd_pack = len(self._pack_jobs)
+        if not self.need_grad:
+            self._finish_pack()
+            return
+
+        # ================================================================== backward program
+        # flat gradient arena in parameters() order
+        self.grad_names = [k for k in self.P.keys()]
+        offs, tot = {}, 0
+        for k in self.grad_names:
+            offs[k] = tot
+            tot += (self.P[k].numel() + 3) // 4 * 4          # keep every slice 16-byte aligned
+        self.grad_flat = self._new(tot)
+        self.G = {k: self.grad_flat[offs[k]:offs[k] + self.P[k].numel()].view(self.P[k].shape) for k in self.grad_names}
+        self.grad_offsets = offs
+        self.dead_params = set()
+        if not cfg['max_pool']:
+            self.dead_params.add('downsample_convs.%d.weight' % (depth - 1))    # never used in forward
+            self.dead_params.add('downsample_convs.%d.bias' % (depth - 1))
+
+        # heads
+        sld = self.lib.dfl_head_scratch_ld(F)
+        M = u.M
+        scratch = self._new(M * sld)
+        dfeat = self._act(N, u.H, u.W, F)
+        self.head_bwd = HeadBwdArgs(x=u.ptr, w_seg=w_seg.data_ptr(), w_l1=nat.ptr(w_l1), w_l2=nat.ptr(w_l2),
+                                    dx=dfeat.ptr, scratch=scratch.data_ptr(), N=N, H=u.H, W=u.W, F=F, ldx=u.ld,
+                                    lddx=dfeat.ld, NC=NC, NM=NM, L=L, softmax=1 if cfg['do_soft_max'] else 0,
+                                    scratch_ld=sld)
+        bwd.add(self.head_bwd)
+        off = [self.lib.dfl_head_scratch_off(F, k) for k in range(5)]
+
+        def sact(o, c):
+            return Act(scratch, scratch.data_ptr() + 4 * o, sld, N, u.H, u.W, c)
+        self._wgrad(bwd, sact(off[0], F), sact(off[1], NC), self.G['seg_conv.weight'], 1, 1, 1, 0, u.H, u.W)
+        if L > 0:
+            self._wgrad(bwd, sact(off[0], F + NC), sact(off[2], NM), self.G['lands_1x1.0.weight'], 1, 1, 1, 0, u.H, u.W)
+            if w_l2 is not None:
+                self._wgrad(bwd, sact(off[3], NM), sact(off[4], L), self.G['lands_1x1.1.weight'], 1, 1, 1, 0, u.H, u.W)
+
+        # up path, last block first
+        dout = dfeat
+        for j in reversed(range(len(up_recs))):
+            rec = up_recs[j]
+            i = rec['level']
+            Ci = chans[i]
+            rec['block_bw'](dout, dcat[i])
+            dy = dcat[i].chan_slice(0, Ci)                    # gradient of the transposed-conv output
+            uin = rec['u']
+            self._colsum(bwd, dy, self.G[rec['name'] + '.up.bias'])
+            # dW[ci][co][ab] = sum x[i,j][ci] * dy[2i+a,2j+b][co]
+            self._wgrad(bwd, dy, uin, self.G[rec['name'] + '.up.weight'], 2, 2, 2, 0, uin.H, uin.W)
+            wd = self._pack_convT_dgrad(rec['w'])
+            du = self._act(N, uin.H, uin.W, uin.C)
+            self._conv(bwd, dy, wd, du, 2, 2, 2, 0, uin.C)
+            dout = du
+        # down path, deepest block first
+        for i in reversed(range(depth)):
+            rec = pending[i]
+            out = rec['out']
+            Ci = chans[i]
+            if i != depth - 1:
+                # dout = bridge gradient (+ crop padding) + down-sampling gradient
+                if direct_bridge[i]:
+                    dout = dcat[i].chan_slice(Ci, Ci)
+                else:
+                    dout = self._act(N, out.H, out.W, Ci)
+                    oy, ox, ch, cw = rec['crop']
+                    src = dcat[i].chan_slice(Ci, Ci)
+                    bwd.add(MemsetArgs(ptr=dout.ptr, bytes=4 * dout.M * Ci))
+                    bwd.add(AffineCopyArgs(x=src.ptr, y=dout.ptr, N=N, H=ch, W=cw, C=Ci, ldx=src.ld, xH=ch, xW=cw,
+                                           ldy=dout.ld, yH=out.H, yW=out.W, yoy=oy, yox=ox))
+                dnxt = rec['dnxt']
+                nxt = rec['nxt']
+                if cfg['max_pool']:
+                    bwd.add_pool(PoolArgs(x=out.ptr, y=dnxt.ptr, dx=dout.ptr, N=N, H=out.H, W=out.W, C=Ci, ldx=out.ld,
+                                          ldy=dnxt.ld, lddx=dout.ld), backward=True)
+                else:
+                    wname = 'downsample_convs.%d' % i
+                    self._colsum(bwd, dnxt, self.G[wname + '.bias'])
+                    self._wgrad(bwd, out, dnxt, self.G[wname + '.weight'], 2, 2, 2, 0, nxt.H, nxt.W)
+                    wd = self._pack_down_dgrad(self.P[wname + '.weight'])
+                    self._conv(bwd, dnxt, wd, dout, 1, 1, 1, 0, 4 * Ci, accumulate=1, scatter=1,
+                               Hout=out.H, Wout=out.W)
+            if i > 0:
+                dxin = self._act(N, rec['xin'].H, rec['xin'].W, rec['xin'].C)
+                pending[i - 1]['dnxt'] = dxin
+            else:
+                dxin = None
+            rec['block_bw'](dout, dxin)
+        self._finish_pack()
+
+    # ------------------------------------------------------------------------------------------ run
+    def run_pack(self, stream, forward_only=False):
+        self.pack.run(stream)
+
+    def new_outputs(self):
+        N = self.N
+        h, w = self.out_hw
+        seg = torch.empty((N, self.NC, h, w), dtype=torch.float32, device=self.dev)
+        heat = torch.empty((N, self.L, h, w), dtype=torch.float32, device=self.dev) if self.L > 0 else None
+        return seg, heat
+
+    def grads(self):
+        return [None if k in self.dead_params else self.G[k] for k in self.grad_names]

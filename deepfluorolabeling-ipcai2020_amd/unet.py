@@ -1,0 +1,237 @@
+"""U-Net with residual Conv3x3 -> ReLU -> BatchNorm blocks, two heads -- MI355X (gfx950) implementation.
+
+Drop-in for the reference's ``train_test_code/unet.py``: same constructor (unet.py:41-45), same module tree, hence the
+same ``state_dict`` keys / parameter order / seeded initialisation, same forward
+contract (``seg`` or ``(seg, heat_maps)``, unet.py:183-193) and ordinary autograd outputs (``loss.backward()`` fills
+``.grad`` for ``torch.optim``).  What differs is everything underneath: ``forward`` does not call ``torch.nn`` -- it
+replays a recorded program of hand-written HIP kernels from ``libdfl_hip.so`` (see ``plan.py``, ``include/dfl_hip.h``);
+the sub-modules below only own the parameters.  There is no CPU or eager fallback: tensors must live on the GPU.
+"""
+import torch
+from torch import nn
+
+from . import _native as nat
+from .plan import UNetPlan, PlanError
+
+__all__ = ['UNet', 'UNetConvBlock', 'UNetUpBlock']
+
+
+def _no_forward(name):
+    def forward(self, *a, **k):
+        raise RuntimeError('%s is a parameter container; the computation runs in UNet.forward (HIP program)' % name)
+    return forward
+
+
+class UNetConvBlock(nn.Module):
+    """Parameters of one block (reference: unet.py:196-224): optional 1x1 residual conv, then block_depth x
+    [Conv3x3, ReLU, (BatchNorm)] kept in a Sequential so the state_dict indices match (0,2,3,5 / 0,2)."""
+
+    def __init__(self, in_size, out_size, padding, batch_norm, pad_mode, do_res, block_depth):
+        super().__init__()
+        if block_depth <= 0:
+            raise AssertionError('block_depth must be positive')
+        self.do_res = do_res
+        if do_res:                                   # created first: RNG order of the reference
+            self.res_conv1x1 = nn.Conv2d(in_size, out_size, kernel_size=1, padding=0)
+        mods = []
+        cin = in_size
+        for _ in range(block_depth):
+            mods += [nn.Conv2d(cin, out_size, kernel_size=3, padding=int(padding), padding_mode=pad_mode), nn.ReLU()]
+            if batch_norm:
+                mods.append(nn.BatchNorm2d(out_size))
+            cin = out_size
+        self.block = nn.Sequential(*mods)
+
+    forward = _no_forward('UNetConvBlock')
+
+
+class UNetUpBlock(nn.Module):
+    """Parameters of one decoder stage (reference: unet.py:236-246)."""
+
+    def __init__(self, in_size, out_size, up_mode, padding, batch_norm, pad_mode, do_res, block_depth):
+        super().__init__()
+        if up_mode != 'upconv':
+            raise NotImplementedError("up_mode='upsample' is not implemented in the HIP path (no reference CLI selects it)")
+        self.up = nn.ConvTranspose2d(in_size, out_size, kernel_size=2, stride=2)
+        self.conv_block = UNetConvBlock(in_size, out_size, padding, batch_norm, pad_mode, do_res, block_depth)
+
+    forward = _no_forward('UNetUpBlock')
+
+
+class _UNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, plan, x, *params):
+        seg, heat = net._run_forward(plan, x)
+        ctx.net, ctx.plan, ctx.gen = net, plan, plan.generation
+        ctx.save_for_backward(seg)
+        ctx.n_params = len(params)
+        return (seg, heat) if heat is not None else seg
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        plan, net = ctx.plan, ctx.net
+        if plan.generation != ctx.gen or not plan.busy:
+            raise RuntimeError('the activations of this forward pass were overwritten by a later forward of the same '
+                               'network; run backward before the next-but-one forward')
+        (seg,) = ctx.saved_tensors
+        dseg = gouts[0]
+        dheat = gouts[1] if len(gouts) > 1 else None
+        if dseg is None:
+            dseg = torch.zeros_like(seg)
+        dseg = dseg.contiguous()
+        hb = plan.head_bwd
+        hb.seg, hb.dseg = seg.data_ptr(), dseg.data_ptr()
+        if dheat is not None:
+            dheat = dheat.contiguous()
+        hb.dheat = nat.ptr(dheat)
+        stream = torch.cuda.current_stream().cuda_stream
+        net._backward_runner(plan, stream)
+        plan.busy = False
+        grads = plan.grads()
+        # the gradients are views of the plan's flat arena; if .grad already holds such a view (no zero_grad since
+        # the previous backward) autograd would add a buffer to itself, so hand out copies in that case
+        if any(p.grad is not None for p in net._param_list):
+            grads = [None if g is None else g.clone() for g in grads]
+        out = []
+        for g, p in zip(grads, net._param_list):
+            out.append(g if p.requires_grad else None)
+        return (None, None, None) + tuple(out)
+
+
+class UNet(nn.Module):
+    def __init__(self, in_channels=1, n_classes=2, depth=5, wf=6, padding=False, pad_mode='zeros', batch_norm=False,
+                 up_mode='upconv', max_pool=True, num_lands=0, do_res=True, block_depth=2, lands_block_depth=0,
+                 lands_num_1x1=2, do_soft_max=True):
+        super().__init__()
+        if up_mode not in ('upconv', 'upsample'):
+            raise AssertionError("up_mode must be 'upconv' or 'upsample'")
+        if pad_mode != 'zeros':
+            raise NotImplementedError("pad_mode='%s' is not implemented in the HIP path (no reference CLI selects it)" % pad_mode)
+        if num_lands > 0 and lands_block_depth > 0:
+            raise NotImplementedError('lands_block_depth > 0 is not implemented in the HIP path (no reference CLI selects it)')
+        if num_lands > 0 and lands_num_1x1 not in (1, 2):
+            raise NotImplementedError('lands_num_1x1 must be 1 or 2 in the HIP path')
+        self.padding, self.pad_mode, self.depth = padding, pad_mode, depth
+        self.do_max_pool, self.num_lands, self.do_soft_max = max_pool, num_lands, do_soft_max
+        self._cfg = dict(in_channels=in_channels, n_classes=n_classes, depth=depth, wf=wf, padding=bool(padding),
+                         batch_norm=bool(batch_norm), max_pool=bool(max_pool), num_lands=num_lands, do_res=bool(do_res),
+                         block_depth=block_depth, lands_num_1x1=lands_num_1x1, do_soft_max=bool(do_soft_max))
+
+        # registration order: downsample_convs is assigned before down_path (reference unet.py:80-85)
+        self.downsample_convs = None if max_pool else nn.ModuleList()
+        self.down_path = nn.ModuleList()
+        ch = in_channels
+        for lvl in range(depth):
+            width = 2 ** (wf + lvl)
+            self.down_path.append(UNetConvBlock(ch, width, padding, batch_norm, pad_mode, do_res, block_depth))
+            ch = width
+            if not max_pool:
+                # one per level, including the unused last one (kept for checkpoint compatibility)
+                self.downsample_convs.append(nn.Conv2d(ch, ch, kernel_size=2, stride=2))
+        self.up_path = nn.ModuleList()
+        for lvl in reversed(range(depth - 1)):
+            width = 2 ** (wf + lvl)
+            self.up_path.append(UNetUpBlock(ch, width, up_mode, padding, batch_norm, pad_mode, do_res, block_depth))
+            ch = width
+        self.seg_conv = nn.Conv2d(ch, n_classes, kernel_size=1, bias=False)
+        if do_soft_max:
+            self.soft_max = nn.Softmax2d()           # stateless; present so attribute access matches the reference
+        if num_lands > 0:
+            self.lands_block = None
+            mid = num_lands + n_classes if lands_num_1x1 > 1 else num_lands
+            heads = [nn.Conv2d(ch + n_classes, mid, kernel_size=1, bias=False)]
+            if lands_num_1x1 > 1:
+                heads.append(nn.Conv2d(mid, num_lands, kernel_size=1, bias=False))
+            self.lands_1x1 = nn.Sequential(*heads)
+
+        self._plans = {}
+        self._param_list = None
+        self._pack_version = None
+        self._backward_runner = self._run_backward
+        self.dp = None                                # set by parallel.DataParallel
+
+    # ---------------------------------------------------------------------------------------------- plumbing
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self.invalidate_plans()
+        return out
+
+    def invalidate_plans(self):
+        """Forget recorded programs (they hold raw parameter addresses)."""
+        self._plans = {}
+        self._param_list = None
+        self._pack_version = None
+
+    def _state(self):
+        if self._param_list is None:
+            self._param_names = [k for k, _ in self.named_parameters()]
+            self._param_list = [p for _, p in self.named_parameters()]
+            self._param_dict = dict(zip(self._param_names, self._param_list))
+            self._buffer_dict = dict(self.named_buffers())
+            self._weight_params = [p for p in self._param_list if p.dim() == 4]
+        return self._param_dict, self._buffer_dict
+
+    def _get_plan(self, x, need_grad):
+        P, B = self._state()
+        N, _, H, W = x.shape
+        key = (N, H, W, self.training, need_grad)
+        plans = self._plans.setdefault(key, [])
+        for p in plans:
+            if not p.busy:
+                return p
+        if len(plans) >= 2:                          # both in flight: recycle the older one
+            p = plans.pop(0)
+            p.busy = False
+            p.generation += 1
+            plans.append(p)
+            return p
+        for p_ in self._param_list:
+            if p_.device != x.device or p_.dtype != torch.float32 or not p_.is_contiguous():
+                raise RuntimeError('UNet parameters must be contiguous float32 tensors on %s' % x.device)
+        try:
+            plan = UNetPlan(self._cfg, P, B, N, H, W, self.training, need_grad, x.device)
+        except PlanError as e:
+            raise RuntimeError(str(e))
+        plans.append(plan)
+        return plan
+
+    def _run_forward(self, plan, x):
+        stream = torch.cuda.current_stream().cuda_stream
+        ver = sum(p._version for p in self._weight_params)
+        if self._pack_version != (id(plan), ver):
+            plan.pack.run(stream)                    # weight re-layout for this plan's kernels
+            self._pack_version = (id(plan), ver)
+        cin = self._cfg['in_channels']
+        if cin == 1:
+            plan.x_in.copy_(x.reshape(-1))
+        else:
+            plan.x_in.copy_(x.permute(0, 2, 3, 1).reshape(-1))
+        seg, heat = plan.new_outputs()
+        plan.head_fwd.seg = seg.data_ptr()
+        plan.head_fwd.heat = nat.ptr(heat)
+        plan.fwd.run(stream)
+        return seg, heat
+
+    def _run_backward(self, plan, stream):
+        plan.bwd.run(stream)
+
+    # ---------------------------------------------------------------------------------------------- forward
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError('deepfluorolabeling-ipcai2020_amd.UNet runs on the GPU only (HIP kernels, no CPU '
+                               'fallback); move the network and its input to the device')
+        if x.dim() != 4 or x.shape[1] != self._cfg['in_channels']:
+            raise RuntimeError('expected input of shape [B, %d, H, W]' % self._cfg['in_channels'])
+        x = x.detach().to(torch.float32).contiguous()
+        self._state()
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list)
+        if need_grad and self._cfg['batch_norm'] and not self.training:
+            raise NotImplementedError('gradients through eval-mode BatchNorm are not implemented in the HIP path; '
+                                      'call net.train() or wrap the call in torch.no_grad()')
+        plan = self._get_plan(x, need_grad)
+        if not need_grad:
+            seg, heat = self._run_forward(plan, x)
+            return (seg, heat) if heat is not None else seg
+        plan.busy = True
+        plan.generation += 1
+        return _UNetFn.apply(self, plan, x, *self._param_list)

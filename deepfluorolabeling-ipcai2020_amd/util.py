@@ -1,0 +1,230 @@
+"""Utility layer: centre crop, device pick, loss logs, validation and (ensemble) inference loops.
+
+Counterpart of the reference's train_test_code/util.py.  ``center_crop`` (util.py:92-114) is index math and stays a view;
+the loops (``test_dataset`` :116-165, ``test_dataset_ensemble`` :167-241, ``seg_dataset`` :243-290,
+``seg_dataset_ensemble`` :293-377) keep their signatures and file outputs but run the network through the HIP
+programs and do the per-image ensemble arithmetic (mean over nets, first-max argmax, per-net min-max normalised heat
+maps) in one ``dfl_ensemble_reduce`` call instead of a chain of torch ops.
+"""
+import ctypes as C
+import time
+
+import torch
+from torch.utils.data import DataLoader
+
+from . import _native as nat
+from .dice import DiceLoss2D, DiceAndHeatMapLoss2D
+
+__all__ = ['get_device', 'center_crop', 'RunningFloatWriter', 'write_floats_to_txt', 'read_floats_from_txt',
+           'test_dataset', 'test_dataset_ensemble', 'seg_dataset', 'seg_dataset_ensemble', 'ensemble_reduce']
+
+
+def get_device(no_gpu=False):
+    """Reference: util.py:17-36.  The HIP path needs the GPU; asking for the CPU is an error here, not a fallback."""
+    if no_gpu:
+        raise RuntimeError('--no-gpu: this build has no CPU path (the hot path is HIP kernels for MI355X)')
+    if not torch.cuda.is_available():
+        raise RuntimeError('no GPU visible: this build has no CPU path (the hot path is HIP kernels for MI355X)')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def center_crop(img, dst_shape):
+    """Centre window of the last two dims as a view; ``img`` itself when the sizes already match (util.py:92-114)."""
+    rows, cols = img.shape[-2], img.shape[-1]
+    want_r, want_c = dst_shape[-2], dst_shape[-1]
+    if rows == want_r and cols == want_c:
+        return img
+    assert img.dim() in (2, 3, 4)
+    r0 = int((rows - want_r) / 2)
+    c0 = int((cols - want_c) / 2)
+    return img[..., r0:r0 + want_r, c0:c0 + want_c]
+
+
+def write_floats_to_txt(file_path, floats):
+    with open(file_path, 'w') as out:
+        out.writelines('{:.6f}\n'.format(f) for f in floats)
+
+
+def read_floats_from_txt(file_path):
+    with open(file_path) as f:
+        return torch.Tensor([float(line.strip()) for line in f])
+
+
+class RunningFloatWriter:
+    """One '%.6f' line per value, flushed per write; append mode when resuming (util.py:62-89)."""
+
+    def __init__(self, file_path, new_file=True):
+        self.out = open(file_path, 'w' if new_file else 'a')
+
+    def write(self, x):
+        self.out.write('{:.6f}\n'.format(x))
+        self.out.flush()
+
+    def close(self):
+        if self.out:
+            self.out.flush()
+            self.out.close()
+            self.out = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        self.close()
+
+
+# ------------------------------------------------------------------------------------------------ ensemble kernel
+def ensemble_reduce(seg_list, heat_list, orig_shape, raw_heat=False, want_avg_seg=False):
+    """One image: list of per-net outputs [1,C,Hp,Wp] / [1,L,Hp,Wp] -> (labels uint8 [h,w], heats [L,h,w] or None,
+    avg_seg [C,h,w] or None).  Arithmetic of util.py:326-373 (or :204-229 with raw_heat) in one library call."""
+    lib = nat.lib()
+    n = len(seg_list)
+    s0 = seg_list[0]
+    dev = s0.device
+    Cc, Hp, Wp = s0.shape[1], s0.shape[2], s0.shape[3]
+    h, w = orig_shape[-2], orig_shape[-1]
+    segs = [s.detach().float().contiguous() for s in seg_list]
+    a = nat.EnsembleArgs()
+    seg_ptrs = torch.tensor([s.data_ptr() for s in segs], dtype=torch.int64).to(dev)
+    a.seg_ptrs = seg_ptrs.data_ptr()
+    labels = torch.empty((h, w), dtype=torch.uint8, device=dev)
+    a.labels = labels.data_ptr()
+    avg = torch.empty((Cc, h, w), dtype=torch.float32, device=dev) if want_avg_seg else None
+    a.avg_seg = nat.ptr(avg)
+    heats_out = None
+    L = 0
+    keep = [segs, seg_ptrs]
+    if heat_list:
+        heats = [t.detach().float().contiguous() for t in heat_list]
+        L = heats[0].shape[1]
+        heat_ptrs = torch.tensor([t.data_ptr() for t in heats], dtype=torch.int64).to(dev)
+        heats_out = torch.empty((L, h, w), dtype=torch.float32, device=dev)
+        minmax = torch.empty(2 * n * 65, dtype=torch.float32, device=dev)
+        a.heat_ptrs, a.heat_out, a.minmax = heat_ptrs.data_ptr(), heats_out.data_ptr(), minmax.data_ptr()
+        keep += [heats, heat_ptrs, minmax]
+    a.nnets, a.C, a.L, a.Hp, a.Wp, a.h, a.w = n, Cc, L, Hp, Wp, h, w
+    a.oy, a.ox = int((Hp - h) / 2), int((Wp - w) / 2)
+    a.raw_heat = 1 if raw_heat else 0
+    nat.check(lib.dfl_ensemble_reduce(C.addressof(a), torch.cuda.current_stream().cuda_stream), 'dfl_ensemble_reduce')
+    return labels, heats_out, avg
+
+
+def _split_out(net_out, num_lands):
+    if num_lands > 0 or type(net_out) is tuple:
+        return net_out[0], net_out[1]
+    return net_out, None
+
+
+def _squeeze_heats(heats):
+    if heats.dim() > 4:
+        assert heats.dim() == 5 and heats.shape[2] == 1
+        heats = heats.view(heats.shape[0], heats.shape[1], heats.shape[3], heats.shape[4])
+    return heats
+
+
+# ------------------------------------------------------------------------------------------------ validation loops
+def test_dataset(ds, net, dev=None, num_lands=0):
+    """Eval-mode per-image loss; returns (mean, std) over the data set (util.py:116-165).  Leaves the net in eval mode."""
+    dev = dev if dev is not None else next(net.parameters()).device
+    crit = DiceAndHeatMapLoss2D(skip_bg=False) if num_lands > 0 else DiceLoss2D(skip_bg=False)
+    losses = torch.zeros(len(ds))
+    count = 0
+    with torch.no_grad():
+        net.eval()
+        for i, (projs, masks, lands, heats) in enumerate(DataLoader(ds, batch_size=1, shuffle=False)):
+            projs, masks = projs.to(dev), masks.to(dev)
+            seg, heat = _split_out(net(projs), num_lands)
+            seg = center_crop(seg, masks.shape)
+            if num_lands > 0:
+                heats = _squeeze_heats(heats).to(dev)
+                loss = crit((seg, center_crop(heat, heats.shape)), (masks, heats))
+            else:
+                loss = crit(seg, masks)
+            losses[i] = loss.item()
+            count += 1
+    assert count == len(ds)
+    return torch.mean(losses), torch.std(losses)
+
+
+def test_dataset_ensemble(ds, nets, dev=None, num_lands=0, dice_only=False):
+    """Loss of the averaged (un-normalised) ensemble output per image (util.py:167-241)."""
+    dev = dev if dev is not None else next(nets[0].parameters()).device
+    use_heat = (not dice_only) and num_lands > 0
+    crit = DiceAndHeatMapLoss2D(skip_bg=False) if use_heat else DiceLoss2D(skip_bg=False)
+    losses = torch.zeros(len(ds))
+    count = 0
+    with torch.no_grad():
+        for n_ in nets:
+            n_.eval()
+        for i, (projs, masks, lands, heats) in enumerate(DataLoader(ds, batch_size=1, shuffle=False)):
+            projs, masks = projs.to(dev), masks.to(dev)
+            outs = [_split_out(n_(projs), num_lands) for n_ in nets]
+            hl = [o[1] for o in outs] if num_lands > 0 else None
+            _, avg_heat, avg_seg = ensemble_reduce([o[0] for o in outs], hl, masks.shape, raw_heat=True,
+                                                   want_avg_seg=True)
+            if use_heat:
+                heats = _squeeze_heats(heats).to(dev)
+                loss = crit((avg_seg.unsqueeze(0), avg_heat.unsqueeze(0)), (masks, heats))
+            else:
+                loss = crit(avg_seg.unsqueeze(0), masks)
+            losses[i] = loss.item()
+            count += 1
+    assert count == len(ds)
+    return torch.mean(losses), torch.std(losses)
+
+
+def _create_outputs(h5_f, n_items, orig_shape, num_lands):
+    seg_ds = h5_f.create_dataset('nn-segs', (n_items, *orig_shape), dtype='u1', chunks=(1, *orig_shape),
+                                 compression='gzip', compression_opts=9)
+    heat_ds = None
+    if num_lands > 0:
+        heat_ds = h5_f.create_dataset('nn-heats', (n_items, num_lands, *orig_shape), chunks=(1, 1, *orig_shape),
+                                      compression='gzip', compression_opts=9)
+    return seg_ds, heat_ds
+
+
+def seg_dataset(ds, net, h5_f, dev=None, num_lands=0):
+    """Single-net labels ('nn-segs', u1) and raw cropped heat maps ('nn-heats') per image (util.py:243-290)."""
+    dev = dev if dev is not None else next(net.parameters()).device
+    shape = ds.rob_orig_img_shape
+    seg_ds, heat_ds = _create_outputs(h5_f, len(ds), shape, num_lands)
+    count = 0
+    with torch.no_grad():
+        net.eval()
+        for i, data in enumerate(DataLoader(ds, batch_size=1, shuffle=False)):
+            seg, heat = _split_out(net(data[0].to(dev)), num_lands)
+            labels, _, _ = ensemble_reduce([seg], None, shape)
+            seg_ds[i, :, :] = labels.cpu().numpy()
+            if heat_ds is not None:
+                heat_ds[i, :, :, :] = center_crop(heat, shape)[0].cpu().numpy()
+            count += 1
+    assert count == len(ds)
+
+
+def seg_dataset_ensemble(ds, nets, h5_f, dev=None, num_lands=0, times=None):
+    """Ensemble labels + averaged min-max-normalised heat maps per image; per-image seconds appended to ``times``
+    (timed region as util.py:321-366: H2D copy, all forwards, reduction; excludes the D2H copy and file write)."""
+    dev = dev if dev is not None else next(nets[0].parameters()).device
+    shape = ds.rob_orig_img_shape
+    seg_ds, heat_ds = _create_outputs(h5_f, len(ds), shape, num_lands)
+    count = 0
+    with torch.no_grad():
+        for n_ in nets:
+            n_.eval()
+        for i, data in enumerate(DataLoader(ds, batch_size=1, shuffle=False)):
+            t0 = time.time()
+            projs = data[0].to(dev)
+            outs = [_split_out(n_(projs), num_lands) for n_ in nets]
+            hl = [o[1] for o in outs] if heat_ds is not None else None
+            labels, heats, _ = ensemble_reduce([o[0] for o in outs], hl, shape)
+            torch.cuda.synchronize(dev)
+            if times is not None:
+                times.append(time.time() - t0)
+            seg_ds[i, :, :] = labels.cpu().numpy()
+            if heat_ds is not None:
+                heat_ds[i, :, :, :] = heats.cpu().numpy()
+            count += 1
+    assert count == len(ds)

@@ -1,0 +1,353 @@
+/*
+ * dfl_hip.h -- C ABI of libdfl_hip.so: the MI355X (gfx950) implementation of the U-Net hot path of
+ * rg2/DeepFluoroLabeling-IPCAI2020 (train_test_code/unet.py, dice.py, ncc.py, util.py ensemble).
+ *
+ * The reference has no FFI layer: its hot path is torch.nn calls made from Python.  Each entry
+ * point below replaces one group of those calls and cites it (paths relative to the reference repo root).
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative dfl_status; it never throws and never allocates or
+ *     frees device memory: the caller owns every buffer and passes raw device pointers;
+ *   - work is enqueued asynchronously on the given hipStream_t (pass the host framework's current stream);
+ *   - re-entrant; no global mutable state except the thread-local last-error string;
+ *   - arithmetic type: fp32 (exact-f32 MFMA v_mfma_f32_32x32x2_f32 for the contractions, fp64 for the
+ *     cross-block part of the statistics/loss reductions);
+ *   - ACTIVATION LAYOUT inside the network is NHWC ("pixel-major"): element (n,y,x,c) of a tensor with pixel
+ *     stride ld (in floats, ld >= C) lives at ((n*H + y)*W + x)*ld + c.  A channel slice of a wider buffer is
+ *     expressed by offsetting the pointer and keeping ld (this is how torch.cat in unet.py:256-257 is made
+ *     free).  The network input (C = 1) and the two outputs (seg / heat maps) are plain NCHW as in the
+ *     reference, so the layout is invisible at the boundary.
+ */
+#ifndef DFL_HIP_H
+#define DFL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dfl_stream_t; /* hipStream_t */
+
+typedef enum {
+  DFL_OK = 0,
+  DFL_ERR_INVALID_ARG = -1,
+  DFL_ERR_UNSUPPORTED = -2,
+  DFL_ERR_LAUNCH = -3,
+  DFL_ERR_WORKSPACE = -4
+} dfl_status;
+
+/* Library version (major*10000 + minor*100 + patch) and the last error message of the calling thread. */
+int dfl_version(void);
+const char* dfl_last_error(void);
+/* sizeof() of the argument structs, in declaration order (conv, wgrad, pack_job, bn_finalize, colstats,
+ * bn_bwd_finalize, bn_relu_bwd, affine_copy, pool, head_fwd, head_bwd, loss, ensemble, op): lets a binding written
+ * in another language verify its struct mirrors at load time.  Returns -1 past the end. */
+int dfl_sizeof(int which);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Convolution as a gather-GEMM on the fp32 matrix cores.
+ *   y[m, n] = epilogue( sum_{t < KH*KW} sum_{c < Cin} X(m, t, c) * w[(t*Cin + c)*Ntot + n] )
+ * m runs over the N*Hout*Wout output pixels; X(m,t,c) is the input at pixel (oy*stride - pad + t/KW,
+ * ox*stride - pad + t%KW), channel c, after the optional per-channel affine in_scale/in_shift (BatchNorm
+ * applied on load), and 0 outside the image (zero padding is applied AFTER the affine, as the reference pads
+ * the BatchNorm output).
+ * Replaces nn.Conv2d 3x3 (unet.py:211,218), 1x1 residual (unet.py:207,229-231), 2x2/stride-2 down-sampling
+ * (unet.py:93,171), nn.ConvTranspose2d(k=2,s=2) (unet.py:240,255; scatter2x2 = 1) and -- with the packed
+ * weights of dfl_pack_weights -- every data-gradient of those layers (torch autograd, train.py:422).
+ * Epilogue order: + bias[n]; ReLU (unet.py:213,220); + add[m,n]*add_scale[n] + add_shift[n] (the BatchNorm
+ * of the block's last conv, summed with the residual: unet.py:229-231); + old y (accumulate); store;
+ * per-channel partial sums of v and v*u for BatchNorm (u = v, or u = stat_other[m,n]).
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* x;        /* input activations, NHWC, pixel stride ldx */
+  const float* w;        /* packed weights [KH*KW*Cin][Ntot] (dfl_pack_weights) */
+  const float* bias;     /* [Ntot / (scatter2x2 ? 4 : 1)] or NULL */
+  const float* in_scale; /* [Cin] or NULL */
+  const float* in_shift; /* [Cin] or NULL (required when in_scale is given) */
+  const float* add;      /* [M][ldadd] or NULL */
+  const float* add_scale;/* [Ntot] or NULL (=> scale 1, shift 0) */
+  const float* add_shift;
+  const float* stat_other; /* [M][ldso] or NULL (=> u = v) */
+  float* y;              /* output, NHWC, pixel stride ldy */
+  float* stat_partials;  /* [gridM][2][Ntot] or NULL; gridM = dfl_conv_grid_m(args) */
+  int32_t N, Hin, Win, Cin, ldx;
+  int32_t KH, KW, stride, pad;
+  int32_t Hout, Wout, Ntot, ldy;
+  int32_t ldadd, ldso;
+  int32_t relu;
+  int32_t accumulate;
+  int32_t scatter2x2;    /* ConvTranspose2d(k2,s2): Ntot = 4*Cout, column ab*Cout+co of input pixel (i,j) is stored
+                            at output pixel (2i + ab/2, 2j + ab%2) of an [N, Hout, Wout] image, channel co */
+  int32_t reserved;
+} dfl_conv_args;
+
+int dfl_conv2d(const dfl_conv_args* a, dfl_stream_t stream);
+/* Number of row blocks dfl_conv2d will launch for these args (= first dim of stat_partials). */
+int dfl_conv_grid_m(const dfl_conv_args* a);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Weight gradient of the same family of layers (torch autograd of unet.py:93,207,211,218,240):
+ *   dw[(cm*Cg + cg)*T + t] = sum_m d[m, cm] * G(m, t, cg)
+ * G is gathered exactly like X above (taps, stride, pad, affine-on-load, zero padding); d is dense over the
+ * same M pixels.  Conv2d: G = layer input, d = output gradient, (cm,cg) = (Cout,Cin) => dw has the torch
+ * layout [Cout][Cin][KH][KW].  ConvTranspose2d(k2,s2): G = output gradient gathered with stride 2, d = layer
+ * input => [Cin][Cout][2][2].  The pixel range is split over `splits` blocks; with splits > 1 the kernel writes
+ * partial[split][Cm][Cg][T] to `partial` and dfl_sum_partials finishes the sum into dw.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* g;        /* gathered tensor, NHWC, pixel stride ldg */
+  const float* d;        /* dense tensor [M][ldd] */
+  const float* in_scale; /* [Cg] or NULL: affine on load of g */
+  const float* in_shift;
+  float* dw;             /* [Cm][Cg][T] when splits == 1 */
+  float* partial;        /* [splits][Cm][Cg][T] when splits > 1 */
+  int32_t N, Hin, Win, Cg, ldg;
+  int32_t KH, KW, stride, pad;
+  int32_t Hout, Wout, Cm, ldd;
+  int32_t splits;
+  int32_t reserved;
+} dfl_wgrad_args;
+
+int dfl_conv2d_wgrad(const dfl_wgrad_args* a, dfl_stream_t stream);
+/* Suggested number of splits for a problem (>= 1); the caller sizes `partial` from it. */
+int dfl_wgrad_suggest_splits(const dfl_wgrad_args* a);
+
+/* dst[i] = sum_{s < splits} src[s*n + i], i < n. */
+int dfl_sum_partials(const float* src, float* dst, int64_t n, int32_t splits, dfl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Batched weight re-layout (one launch for the whole network).  Job j copies
+ *   dst[(i0*D1 + i1)*D2 + i2] = src[off + i0*s0 + i1*s1 + i2*s2]        (strides may be negative)
+ * which turns torch's [Cout][Cin][KH][KW] / [Cin][Cout][2][2] parameters into the [K][Ntot] matrices
+ * dfl_conv2d consumes (forward, flipped+transposed data-gradient, scatter forms).
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* src;
+  float* dst;
+  int64_t off;
+  int32_t D0, D1, D2;
+  int32_t s0, s1, s2;
+} dfl_pack_job;
+
+/* jobs: DEVICE pointer to njobs dfl_pack_job records; max_elems = max over jobs of D0*D1*D2. */
+int dfl_pack_weights(const dfl_pack_job* jobs_dev, int32_t njobs, int64_t max_elems, dfl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * BatchNorm2d (unet.py:215,222; torch defaults eps 1e-5, momentum 0.1).
+ * Training forward: the producing dfl_conv2d leaves per-block partial sums; dfl_bn_finalize reduces them in
+ * fp64, emits scale = gamma*invstd, shift = beta - mean*scale (consumers apply them on load), saves mean and
+ * invstd for backward, and updates running_mean / running_var (unbiased) / num_batches_tracked.
+ * Eval forward (util.py:120,173,261,313): dfl_bn_eval_prepare derives scale/shift from the running statistics.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* partials; /* [nblocks][2][C]: sum x, sum x^2 */
+  const float* gamma;    /* [C] */
+  const float* beta;     /* [C] */
+  float* running_mean;   /* [C] or NULL */
+  float* running_var;    /* [C] or NULL */
+  int64_t* num_batches_tracked; /* scalar or NULL */
+  float* scale;          /* [C] out */
+  float* shift;          /* [C] out */
+  float* save_mean;      /* [C] out */
+  float* save_invstd;    /* [C] out */
+  int64_t count;         /* N*H*W */
+  int32_t nblocks, C;
+  float eps, momentum;
+} dfl_bn_finalize_args;
+
+int dfl_bn_finalize(const dfl_bn_finalize_args* a, dfl_stream_t stream);
+int dfl_bn_eval_prepare(const float* gamma, const float* beta, const float* running_mean,
+                        const float* running_var, float* scale, float* shift, int32_t C, float eps,
+                        dfl_stream_t stream);
+
+/* Row-block count the streaming reductions below use for an [M][C] tensor (pure function; the caller sizes the
+ * partial buffers and sets `nblocks` from it). */
+int dfl_rowblock_count(int64_t M, int32_t C);
+
+/* Per-channel partial sums over pixels: partials[blk][0][c] = sum a, partials[blk][1][c] = sum a*b (b NULL => a*a);
+ * `partials` holds nblocks*2*C floats, nblocks = dfl_rowblock_count(M, C). */
+typedef struct {
+  const float* a; const float* b;
+  float* partials;
+  int64_t M;
+  int32_t C, lda, ldb, nblocks;
+} dfl_colstats_args;
+int dfl_colstats(const dfl_colstats_args* a, dfl_stream_t stream);
+
+/* BatchNorm + ReLU backward (torch autograd of unet.py:213-215,220-222), two steps:
+ * dfl_bn_bwd_finalize: from partial sums of (dy, dy*r) (r = the saved ReLU output that was normalised) computes
+ *   dgamma, dbeta and the three coefficients A,B,C such that  d(pre-activation) = [r > 0] * (A*dy + B*r + C).
+ * dfl_bn_relu_bwd_apply: materialises that tensor and leaves partial sums of it (the conv bias gradient).
+ * With coef == NULL the apply step is the plain ReLU backward [r > 0] * dy (batch_norm=False). */
+typedef struct {
+  const float* partials; /* [nblocks][2][C]: sum dy, sum dy*r */
+  const float* gamma; const float* save_mean; const float* save_invstd;
+  float* dgamma; float* dbeta;   /* [C] */
+  float* coef;                   /* [3][C] */
+  int64_t count;
+  int32_t nblocks, C;
+} dfl_bn_bwd_finalize_args;
+int dfl_bn_bwd_finalize(const dfl_bn_bwd_finalize_args* a, dfl_stream_t stream);
+
+typedef struct {
+  const float* dy; const float* r; const float* coef; /* coef [3][C] or NULL */
+  float* dpre;            /* [M][ldo] */
+  float* partials;        /* [nblocks][C] sums of dpre (nblocks = dfl_rowblock_count(M, C)), or NULL */
+  int64_t M;
+  int32_t C, lddy, ldr, ldo, nblocks;
+} dfl_bn_relu_bwd_args;
+int dfl_bn_relu_bwd_apply(const dfl_bn_relu_bwd_args* a, dfl_stream_t stream);
+
+/* out[c] = sum_{b < nblocks} partials[b*stride + c]  (fp64 accumulation). */
+int dfl_reduce_partials(const float* partials, float* out, int32_t nblocks, int32_t stride, int32_t C,
+                        dfl_stream_t stream);
+
+/* y[m,c] = x[m,c]*scale[c] + shift[c] (+ y_old when accumulate).  scale NULL => copy / add.  Used for the
+ * BatchNorm output when a block has no residual branch (do_res=False, unet.py:229) and for the centre-crop copy
+ * of the bridge in unpadded mode (unet.py:248-257): src/dst are [N,H,W] windows given by offsets. */
+typedef struct {
+  const float* x; float* y; const float* scale; const float* shift;
+  int32_t N, H, W, C;           /* window size */
+  int32_t ldx, xH, xW, xoy, xox;/* source image dims and window origin */
+  int32_t ldy, yH, yW, yoy, yox;
+  int32_t accumulate;
+  int32_t reserved;
+} dfl_affine_copy_args;
+int dfl_affine_copy(const dfl_affine_copy_args* a, dfl_stream_t stream);
+
+/* F.max_pool2d(x, 2) (unet.py:169) and its backward (first maximum in scan order wins; gradient is ADDED to dx). */
+typedef struct {
+  const float* x; float* y;     /* fwd: x -> y.  bwd: x = saved input, y = dy (read), dx accumulated */
+  float* dx;
+  int32_t N, H, W, C, ldx, ldy, lddx;   /* H, W: input size; output is floor(H/2) x floor(W/2) */
+  int32_t reserved;
+} dfl_pool_args;
+int dfl_maxpool2x2_fwd(const dfl_pool_args* a, dfl_stream_t stream);
+int dfl_maxpool2x2_bwd(const dfl_pool_args* a, dfl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Output heads (unet.py:176-191): logits = seg_conv(x) (1x1, no bias); seg = Softmax2d(logits) (or logits);
+ * heat = lands_1x1[1](lands_1x1[0](cat(x, logits))) (two bias-free 1x1 convs; the second is optional).
+ * x is NHWC; seg and heat are written NCHW (the reference's output layout).
+ * Limits: n_classes <= 8, num_lands <= 16, n_mid <= 24.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* x;         /* [M][ldx], F features */
+  const float* w_seg;     /* [NC][F] */
+  const float* w_l1;      /* [NM][F+NC] or NULL when L == 0 */
+  const float* w_l2;      /* [L][NM] or NULL (single 1x1: NM == L) */
+  float* seg;             /* [N][NC][H][W] */
+  float* heat;            /* [N][L][H][W] or NULL */
+  int32_t N, H, W, F, ldx;
+  int32_t NC, NM, L;
+  int32_t softmax;
+  int32_t reserved;
+} dfl_head_fwd_args;
+int dfl_head_fwd(const dfl_head_fwd_args* a, dfl_stream_t stream);
+
+/* Head backward: reads dseg/dheat (NCHW, dheat may be NULL), the saved features and seg, writes dx (NHWC) and a
+ * per-pixel scratch [M][DFL_HEAD_SCRATCH_LD] holding cat(x,logits) | dlogits | dmid | mid | dheat (padded,
+ * offsets below) from which the three weight gradients are taken with dfl_conv2d_wgrad (1x1). */
+#define DFL_HEAD_MAX_NC 8
+#define DFL_HEAD_MAX_L 16
+#define DFL_HEAD_MAX_NM 24
+typedef struct {
+  const float* x; const float* seg; const float* dseg; const float* dheat;
+  const float* w_seg; const float* w_l1; const float* w_l2;
+  float* dx;              /* [M][lddx] */
+  float* scratch;         /* [M][scratch_ld] */
+  int32_t N, H, W, F, ldx, lddx;
+  int32_t NC, NM, L;
+  int32_t softmax;
+  int32_t scratch_ld;     /* >= dfl_head_scratch_ld(F) */
+  int32_t reserved;
+} dfl_head_bwd_args;
+int dfl_head_bwd(const dfl_head_bwd_args* a, dfl_stream_t stream);
+/* scratch row layout for F features: [0, Fc) cat(x, logits) with Fc = roundup4(F+NC_MAX) ; then dlogits (8),
+ * dmid (24), mid (24), dheat (16). */
+int dfl_head_scratch_ld(int32_t F);
+int dfl_head_scratch_off(int32_t F, int32_t which); /* which: 0 cat, 1 dlogits, 2 dmid, 3 mid, 4 dheat */
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Losses (dice.py:14-86, ncc.py:12-38) with their closed-form gradients.
+ * seg/heat are the network outputs seen through util.center_crop (util.py:92-114): 4-D strided views given by
+ * element strides (sN, sC, sH; unit stride along W) over an [B, C, h, w] window; targets likewise.
+ *   loss = dice_wgt * mean_n( sum_c d_nc / Ceff ) + heat_wgt * mean_{n,l}( -(ncc_nl + 1)/2 )
+ * with d_nc = (-2*sum(t*s) + 1e-4) / (sum t^2 + sum s^2 + 1e-4), classes c >= skip_bg.
+ * Outputs: loss (1 float), and when grads are requested dseg/dheat as dense [B,C,h,w] tensors.
+ * `sums` is a caller-provided scratch of dfl_loss_scratch_doubles(B,C,L) doubles.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* seg; const float* tseg;   /* may be NULL when C == 0 (NCC only) */
+  const float* heat; const float* theat; /* NULL when L == 0 */
+  float* loss;
+  float* dseg; float* dheat;             /* NULL => no gradient */
+  float* ncc_vals;                       /* [B][L] raw NCC values (ncc.py:38) or NULL */
+  double* sums;
+  int64_t seg_sN, seg_sC, seg_sH, tseg_sN, tseg_sC, tseg_sH;
+  int64_t heat_sN, heat_sC, heat_sH, theat_sN, theat_sC, theat_sH;
+  int32_t B, C, L, h, w;
+  int32_t skip_bg;
+  float dice_wgt, heat_wgt;
+} dfl_loss_args;
+int dfl_dice_ncc_loss(const dfl_loss_args* a, dfl_stream_t stream);
+int64_t dfl_loss_scratch_doubles(int32_t B, int32_t C, int32_t L);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Ensemble reduction for one image (util.py:326-373): labels = argmax_c( mean_nets crop(seg) ) with torch.max's
+ * first-maximum rule, uint8; heat = mean_nets( (crop(h) - min) / (max - min) ), min/max over the whole cropped
+ * [L,h,w] tensor of each net.  seg_ptrs/heat_ptrs: DEVICE arrays of nnets pointers to [C,Hp,Wp]/[L,Hp,Wp] NCHW
+ * outputs (batch 1); the crop window starts at (oy, ox).
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* const* seg_ptrs; const float* const* heat_ptrs; /* heat_ptrs NULL when L == 0 */
+  uint8_t* labels;        /* [h][w] */
+  float* avg_seg;         /* [C][h][w] or NULL */
+  float* heat_out;        /* [L][h][w] or NULL */
+  float* minmax;          /* scratch of 2*nnets*65 floats (final [nnets][2] table + partials) */
+  int32_t nnets, C, L, Hp, Wp, h, w, oy, ox;
+  int32_t raw_heat;       /* 1: plain mean of the heat maps, no min-max normalisation (util.py:217-229) */
+} dfl_ensemble_args;
+int dfl_ensemble_reduce(const dfl_ensemble_args* a, dfl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Fused multi-tensor SGD step (torch.optim.SGD as configured at train.py:333-334):
+ *   g = grad*grad_scale + wd*p ; buf = first ? g : mom*buf + g ; g = nesterov ? g + mom*buf : buf ; p -= lr*g
+ * over a flat parameter arena (all tensors laid out back to back; n = total element count).
+ * ------------------------------------------------------------------------------------------------------------ */
+int dfl_sgd_step(float* p, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
+                 float weight_decay, float grad_scale, int32_t nesterov, int32_t first_step, dfl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Program execution: run a recorded list of the calls above with ONE host->library transition.  The host builds
+ * the array once per (network, input shape) and replays it every step (forward, backward); this is the launch
+ * path bench.py times.  `args` points to the struct the matching function takes.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef enum {
+  DFL_OP_CONV = 1, DFL_OP_WGRAD = 2, DFL_OP_SUM_PARTIALS = 3, DFL_OP_PACK = 4, DFL_OP_BN_FINALIZE = 5,
+  DFL_OP_BN_EVAL = 6, DFL_OP_COLSTATS = 7, DFL_OP_BN_BWD_FINALIZE = 8, DFL_OP_BN_RELU_BWD = 9,
+  DFL_OP_REDUCE_PARTIALS = 10, DFL_OP_AFFINE_COPY = 11, DFL_OP_POOL_FWD = 12, DFL_OP_POOL_BWD = 13,
+  DFL_OP_HEAD_FWD = 14, DFL_OP_HEAD_BWD = 15, DFL_OP_MEMSET = 16
+} dfl_op_kind;
+
+typedef struct { const float* src; float* dst; int64_t n; int32_t splits; int32_t reserved; } dfl_sum_partials_args;
+typedef struct { const dfl_pack_job* jobs_dev; int64_t max_elems; int32_t njobs; int32_t reserved; } dfl_pack_args;
+typedef struct { const float* gamma; const float* beta; const float* running_mean; const float* running_var;
+                 float* scale; float* shift; int32_t C; float eps; } dfl_bn_eval_args;
+typedef struct { const float* partials; float* out; int32_t nblocks, stride, C, reserved; } dfl_reduce_partials_args;
+typedef struct { void* ptr; int64_t bytes; } dfl_memset_args; /* zero fill */
+
+typedef struct {
+  int32_t kind;          /* dfl_op_kind */
+  int32_t reserved;
+  const void* args;
+} dfl_op;
+
+int dfl_exec(const dfl_op* ops, int32_t n_ops, dfl_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFL_HIP_H */

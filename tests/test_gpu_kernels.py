@@ -1,0 +1,519 @@
+"""Per-kernel parity: every C-ABI entry point of libdfl_hip.so against a plain PyTorch fp32/fp64 CPU computation of
+the same op (and, where one exists, against the oracle).  Runs on the GPU box: pytest -m gpu."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import dfl_amd
+from dfl_amd import _native as nat
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def pack(src, D, s, off=0):
+    """Run one dfl_pack_weights job on the device."""
+    lib = nat.lib()
+    src = src.to(DEV).contiguous()
+    dst = torch.empty(D[0] * D[1] * D[2], device=DEV)
+    job = nat.PackJob(src=src.data_ptr(), dst=dst.data_ptr(), off=off, D0=D[0], D1=D[1], D2=D[2], s0=s[0], s1=s[1], s2=s[2])
+    jobs = torch.from_numpy(np.frombuffer(bytes(job), dtype=np.uint8).copy()).to(DEV)
+    nat.check(lib.dfl_pack_weights(jobs.data_ptr(), 1, D[0] * D[1] * D[2], stream()))
+    torch.cuda.synchronize()
+    return dst
+
+
+def conv_call(x, wp, Ntot, KH, KW, stride, pad, Hout, Wout, bias=None, in_aff=None, relu=0, add=None, add_aff=None,
+              y_init=None, accumulate=0, scatter=0, stats=False, stat_other=None, ldy=None, ldx_pad=0):
+    """x: NCHW cpu tensor -> runs dfl_conv2d -> returns y as NHWC cpu tensor [N,Hout,Wout,Cout] (+ stats)."""
+    lib = nat.lib()
+    N, Cin, Hin, Win = x.shape
+    xh = nhwc(x)
+    if ldx_pad:
+        xh = F.pad(xh, (0, ldx_pad))
+    xd = xh.to(DEV)
+    Cout = Ntot // 4 if scatter else Ntot
+    ldy = Cout if ldy is None else ldy
+    if y_init is not None:
+        yd = nhwc(y_init).to(DEV)
+        if ldy != Cout:
+            yd = F.pad(yd, (0, ldy - Cout)).contiguous()
+    else:
+        yd = torch.full((N, Hout, Wout, ldy), float('nan'), device=DEV)
+    a = nat.ConvArgs()
+    keep = [xd, yd, wp]
+    a.x, a.w, a.y = xd.data_ptr(), wp.data_ptr(), yd.data_ptr()
+    if bias is not None:
+        b = bias.to(DEV)
+        keep.append(b)
+        a.bias = b.data_ptr()
+    if in_aff is not None:
+        sc, sh = in_aff[0].to(DEV), in_aff[1].to(DEV)
+        keep += [sc, sh]
+        a.in_scale, a.in_shift = sc.data_ptr(), sh.data_ptr()
+    if add is not None:
+        ad = nhwc(add).to(DEV)
+        keep.append(ad)
+        a.add, a.ldadd = ad.data_ptr(), ad.shape[-1]
+        if add_aff is not None:
+            asc, ash = add_aff[0].to(DEV), add_aff[1].to(DEV)
+            keep += [asc, ash]
+            a.add_scale, a.add_shift = asc.data_ptr(), ash.data_ptr()
+    a.N, a.Hin, a.Win, a.Cin, a.ldx = N, Hin, Win, Cin, Cin + ldx_pad
+    a.KH, a.KW, a.stride, a.pad = KH, KW, stride, pad
+    a.Hout, a.Wout, a.Ntot, a.ldy = Hout, Wout, Ntot, ldy
+    a.relu, a.accumulate, a.scatter2x2 = relu, accumulate, scatter
+    part = None
+    if stats:
+        gm = nat.check(lib.dfl_conv_grid_m(C.addressof(a)))
+        part = torch.zeros(gm, 2, Ntot, device=DEV)
+        a.stat_partials = part.data_ptr()
+        if stat_other is not None:
+            so = nhwc(stat_other).to(DEV)
+            keep.append(so)
+            a.stat_other, a.ldso = so.data_ptr(), so.shape[-1]
+    nat.check(lib.dfl_conv2d(C.addressof(a), stream()), 'dfl_conv2d')
+    torch.cuda.synchronize()
+    y = yd.cpu()[..., :Cout]
+    return (y, part.cpu().double().sum(0)) if stats else y
+
+
+CONV_CASES = [
+    # N, Cin, Cout, H, W, K, stride, pad
+    (2, 8, 16, 12, 12, 3, 1, 1),
+    (1, 32, 32, 24, 20, 3, 1, 1),
+    (2, 64, 128, 13, 9, 3, 1, 1),      # odd sizes, several tile configs
+    (2, 16, 8, 10, 10, 3, 1, 0),       # valid conv
+    (3, 1, 32, 16, 16, 3, 1, 1),       # first layer: Cin = 1 (scalar gather)
+    (2, 3, 4, 9, 11, 3, 1, 1),         # odd Cin/Cout
+    (2, 32, 64, 8, 8, 1, 1, 0),        # 1x1
+    (2, 16, 16, 12, 10, 2, 2, 0),      # 2x2 stride 2
+    (2, 8, 8, 7, 9, 2, 2, 0),          # 2x2 stride 2, odd input
+    (1, 256, 256, 6, 6, 3, 1, 1),      # deep level
+    (16, 32, 32, 48, 48, 3, 1, 1),     # enough rows for the 256x32 tile
+    (4, 64, 64, 96, 96, 3, 1, 1),      # 128x64 tile
+    (4, 128, 128, 64, 64, 1, 1, 0),    # 128x128 tile
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_fwd_plain(case):
+    N, Cin, Cout, H, W, K, stride, pad = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / math.sqrt(Cin * K * K)
+    b = torch.randn(Cout, generator=g)
+    T = K * K
+    wp = pack(w, (T, Cin, Cout), (1, T, Cin * T))
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=pad)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    y = conv_call(x, wp, Cout, K, K, stride, pad, Ho, Wo, bias=b)
+    np.testing.assert_allclose(nchw(y).numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
+
+
+def test_conv_fwd_fused_epilogue_and_prologue():
+    """BN-on-load with zero padding after the affine, bias, ReLU, statistics; then the residual form."""
+    g = torch.Generator().manual_seed(5)
+    N, Cin, Cout, H, W = 2, 16, 32, 14, 10
+    x = torch.randn(N, Cin, H, W, generator=g)
+    sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / 12
+    b = torch.randn(Cout, generator=g)
+    wp = pack(w, (9, Cin, Cout), (1, 9, Cin * 9))
+    xa = x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+    ref = F.relu(F.conv2d(xa, w.double(), b.double(), padding=1))
+    y, st = conv_call(x, wp, Cout, 3, 3, 1, 1, H, W, bias=b, in_aff=(sc, sh), relu=1, stats=True)
+    np.testing.assert_allclose(nchw(y).numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(st[0].numpy(), ref.sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(st[1].numpy(), (ref * ref).sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
+    # residual: y = conv1x1(x) + bias + (r*s2 + t2), into a wider buffer (ldy > Cout), input with ldx > Cin
+    w1 = torch.randn(Cout, Cin, 1, 1, generator=g) / 4
+    w1p = pack(w1, (1, Cin, Cout), (1, 1, Cin))
+    r = torch.randn(N, Cout, H, W, generator=g)
+    s2, t2 = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    ref2 = F.conv2d(x.double(), w1.double(), b.double()) + r.double() * s2.double().view(1, -1, 1, 1) + t2.double().view(1, -1, 1, 1)
+    y2 = conv_call(x, w1p, Cout, 1, 1, 1, 0, H, W, bias=b, add=r, add_aff=(s2, t2), ldy=2 * Cout, ldx_pad=8)
+    np.testing.assert_allclose(nchw(y2).numpy(), ref2.numpy(), rtol=2e-5, atol=2e-5)
+    # accumulate + statistics against another tensor (backward use)
+    y0 = torch.randn(N, Cout, H, W, generator=g)
+    other = torch.randn(N, Cout, H, W, generator=g)
+    ref3 = F.conv2d(x.double(), w.double(), None, padding=1) + y0.double()
+    y3, st3 = conv_call(x, wp, Cout, 3, 3, 1, 1, H, W, y_init=y0, accumulate=1, stats=True, stat_other=other)
+    np.testing.assert_allclose(nchw(y3).numpy(), ref3.numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(st3[1].numpy(), (ref3 * other.double()).sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 8, 5, 7), (1, 64, 32, 6, 6), (2, 8, 4, 3, 3)])
+def test_conv_transpose_scatter(shape):
+    N, Cin, Cout, H, W = shape
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cin, Cout, 2, 2, generator=g) / 4
+    b = torch.randn(Cout, generator=g)
+    wp = pack(w, (Cin, 4, Cout), (Cout * 4, 1, 4))
+    ref = F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2)
+    y = conv_call(x, wp, 4 * Cout, 1, 1, 1, 0, 2 * H, 2 * W, bias=b, scatter=1, ldy=2 * Cout)
+    np.testing.assert_allclose(nchw(y).numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
+
+
+def test_dgrad_forms():
+    """Data gradients of conv3x3 (pad 1 / pad 0), conv2x2s2 (scatter) and convT2x2s2 vs torch autograd."""
+    g = torch.Generator().manual_seed(11)
+    N, Ci, Co, H, W = 2, 8, 16, 9, 7
+    for pad in (1, 0):
+        x = torch.randn(N, Ci, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+        w = torch.randn(Co, Ci, 3, 3, generator=g, dtype=torch.float64) / 6
+        y = F.conv2d(x, w, padding=pad)
+        dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+        y.backward(dy)
+        wd = pack(w.float(), (9, Co, Ci), (-1, Ci * 9, 9), off=8)
+        dx = conv_call(dy.float(), wd, Ci, 3, 3, 1, 2 - pad, H, W)
+        np.testing.assert_allclose(nchw(dx).numpy(), x.grad.numpy(), rtol=2e-5, atol=2e-5)
+    # conv2x2 stride 2 (odd input: last row/col get no gradient; accumulate keeps what was there)
+    x = torch.randn(N, Ci, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Ci, Ci, 2, 2, generator=g, dtype=torch.float64) / 3
+    y = F.conv2d(x, w, stride=2)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    wd = pack(w.float(), (Ci, 4, Ci), (Ci * 4, 1, 4))
+    base = torch.randn(N, Ci, H, W, generator=g)
+    dx = conv_call(dy.float(), wd, 4 * Ci, 1, 1, 1, 0, H, W, scatter=1, y_init=base, accumulate=1)
+    np.testing.assert_allclose(nchw(dx).numpy(), (x.grad + base.double()).numpy(), rtol=2e-5, atol=2e-5)
+    # convT
+    x = torch.randn(N, Ci, 4, 5, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Ci, Co, 2, 2, generator=g, dtype=torch.float64) / 3
+    y = F.conv_transpose2d(x, w, stride=2)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    wd = pack(w.float(), (4, Co, Ci), (1, 4, Co * 4))
+    dx = conv_call(dy.float(), wd, Ci, 2, 2, 2, 0, 4, 5)
+    np.testing.assert_allclose(nchw(dx).numpy(), x.grad.numpy(), rtol=2e-5, atol=2e-5)
+
+
+def wgrad_call(gx, d, KH, KW, stride, pad, Hout, Wout, in_aff=None, force_splits=None):
+    lib = nat.lib()
+    N, Cg, Hin, Win = gx.shape
+    Cm = d.shape[1]
+    gd, dd = nhwc(gx).to(DEV), nhwc(d).to(DEV)
+    T = KH * KW
+    dw = torch.full((Cm, Cg, KH, KW), float('nan'), device=DEV)
+    a = nat.WgradArgs(g=gd.data_ptr(), d=dd.data_ptr(), dw=dw.data_ptr(), N=N, Hin=Hin, Win=Win, Cg=Cg, ldg=Cg, KH=KH, KW=KW,
+                      stride=stride, pad=pad, Hout=Hout, Wout=Wout, Cm=Cm, ldd=Cm, splits=1)
+    keep = []
+    if in_aff is not None:
+        sc, sh = in_aff[0].to(DEV), in_aff[1].to(DEV)
+        keep += [sc, sh]
+        a.in_scale, a.in_shift = sc.data_ptr(), sh.data_ptr()
+    s = force_splits or nat.check(lib.dfl_wgrad_suggest_splits(C.addressof(a)))
+    a.splits = s
+    if s > 1:
+        part = torch.empty(s * Cm * Cg * T, device=DEV)
+        a.partial = part.data_ptr()
+    nat.check(lib.dfl_conv2d_wgrad(C.addressof(a), stream()), 'dfl_conv2d_wgrad')
+    if s > 1:
+        nat.check(lib.dfl_sum_partials(part.data_ptr(), dw.data_ptr(), Cm * Cg * T, s, stream()))
+    torch.cuda.synchronize()
+    return dw.cpu(), s
+
+
+WG_CASES = [
+    # N, Cin, Cout, H, W, K, stride, pad
+    (2, 8, 16, 12, 12, 3, 1, 1),
+    (2, 32, 32, 20, 24, 3, 1, 1),       # 9-tap kernel
+    (1, 128, 256, 6, 6, 3, 1, 1),       # tap-in-grid 64x64
+    (1, 256, 512, 6, 6, 3, 1, 1),       # 128x128
+    (3, 1, 32, 16, 16, 3, 1, 1),        # first layer
+    (2, 16, 8, 10, 10, 3, 1, 0),
+    (2, 32, 64, 8, 8, 1, 1, 0),
+    (2, 128, 128, 9, 9, 1, 1, 0),
+    (2, 16, 16, 12, 10, 2, 2, 0),
+    (2, 128, 128, 7, 9, 2, 2, 0),
+    (2, 7, 39, 9, 9, 1, 1, 0),          # head-like odd channel counts (scalar paths)
+]
+
+
+@pytest.mark.parametrize('case', WG_CASES)
+def test_wgrad(case):
+    N, Cin, Cout, H, W, K, stride, pad = case
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    x = torch.randn(N, Cin, H, W, generator=g, dtype=torch.float64)
+    w = torch.zeros(Cout, Cin, K, K, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x, w, stride=stride, padding=pad)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    for fs in (None, 1, 3):
+        dw, s = wgrad_call(x.float(), dy.float(), K, K, stride, pad, y.shape[2], y.shape[3], force_splits=fs)
+        scale = w.grad.abs().max().item()
+        np.testing.assert_allclose(dw.numpy(), w.grad.numpy(), rtol=1e-4, atol=2e-5 * max(scale, 1.0))
+
+
+def test_wgrad_affine_and_convT():
+    g = torch.Generator().manual_seed(2)
+    N, Ci, Co, H, W = 2, 16, 32, 10, 8
+    r = torch.randn(N, Ci, H, W, generator=g, dtype=torch.float64)
+    sc, sh = torch.rand(Ci, generator=g, dtype=torch.float64) + 0.5, torch.randn(Ci, generator=g, dtype=torch.float64)
+    z = r * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    w = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(z, w, padding=1)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    dw, _ = wgrad_call(r.float(), dy.float(), 3, 3, 1, 1, H, W, in_aff=(sc.float(), sh.float()))
+    np.testing.assert_allclose(dw.numpy(), w.grad.numpy(), rtol=1e-4, atol=1e-4)
+    # ConvTranspose2d weight gradient: gathered = dy (stride 2), dense = x  -> [Cin][Cout][2][2]
+    x = torch.randn(N, Ci, 5, 6, generator=g, dtype=torch.float64)
+    wt = torch.zeros(Ci, Co, 2, 2, dtype=torch.float64, requires_grad=True)
+    yt = F.conv_transpose2d(x, wt, stride=2)
+    dyt = torch.randn(yt.shape, generator=g, dtype=torch.float64)
+    yt.backward(dyt)
+    dwt, _ = wgrad_call(dyt.float(), x.float(), 2, 2, 2, 0, 5, 6)
+    np.testing.assert_allclose(dwt.numpy(), wt.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('C_,M', [(32, 5000), (8, 777), (1024, 576), (4, 33)])
+def test_batchnorm_forward_backward(C_, M):
+    """colstats + bn_finalize + bn_bwd_finalize + bn_relu_bwd_apply against torch's batch_norm autograd (fp64)."""
+    lib = nat.lib()
+    g = torch.Generator().manual_seed(C_ + M)
+    r = F.relu(torch.randn(M, C_, generator=g)) * 2.0
+    gamma, beta = torch.rand(C_, generator=g) + 0.5, torch.randn(C_, generator=g)
+    rm, rv = torch.randn(C_, generator=g), torch.rand(C_, generator=g) + 0.5
+    nbt = torch.tensor(7, dtype=torch.int64)
+    rd = r.to(DEV)
+    nb = lib.dfl_rowblock_count(M, C_)
+    part = torch.empty(nb, 2, C_, device=DEV)
+    nat.check(lib.dfl_colstats(C.addressof(nat.ColstatsArgs(a=rd.data_ptr(), b=None, partials=part.data_ptr(), M=M, C=C_,
+                                                            lda=C_, ldb=0, nblocks=nb)), stream()))
+    dv = {k: v.to(DEV) for k, v in dict(gamma=gamma, beta=beta, rm=rm.clone(), rv=rv.clone(), nbt=nbt.clone()).items()}
+    scale, shift, mean, invstd = (torch.empty(C_, device=DEV) for _ in range(4))
+    nat.check(lib.dfl_bn_finalize(C.addressof(nat.BnFinalizeArgs(
+        partials=part.data_ptr(), gamma=dv['gamma'].data_ptr(), beta=dv['beta'].data_ptr(), running_mean=dv['rm'].data_ptr(),
+        running_var=dv['rv'].data_ptr(), num_batches_tracked=dv['nbt'].data_ptr(), scale=scale.data_ptr(),
+        shift=shift.data_ptr(), save_mean=mean.data_ptr(), save_invstd=invstd.data_ptr(), count=M, nblocks=nb, C=C_,
+        eps=1e-5, momentum=0.1)), stream()))
+    # torch reference (double)
+    r64 = r.double().t().reshape(1, C_, M, 1).requires_grad_(True)
+    rm64, rv64 = rm.double().clone(), rv.double().clone()
+    z = F.batch_norm(r64, rm64, rv64, gamma.double(), beta.double(), training=True, momentum=0.1, eps=1e-5)
+    z_gpu = (rd * scale + shift).cpu()
+    np.testing.assert_allclose(z_gpu.numpy(), z[0, :, :, 0].t().detach().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(dv['rm'].cpu().numpy(), rm64.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dv['rv'].cpu().numpy(), rv64.numpy(), rtol=1e-5, atol=1e-6)
+    assert int(dv['nbt'].cpu()) == 8
+    # eval prepare
+    es, et = torch.empty(C_, device=DEV), torch.empty(C_, device=DEV)
+    nat.check(lib.dfl_bn_eval_prepare(dv['gamma'].data_ptr(), dv['beta'].data_ptr(), dv['rm'].data_ptr(), dv['rv'].data_ptr(),
+                                      es.data_ptr(), et.data_ptr(), C_, 1e-5, stream()))
+    ze = F.batch_norm(r.double().t().reshape(1, C_, M, 1), rm64, rv64, gamma.double(), beta.double(), training=False, eps=1e-5)
+    np.testing.assert_allclose((rd * es + et).cpu().numpy(), ze[0, :, :, 0].t().numpy(), rtol=1e-4, atol=1e-4)
+    # backward through BN then ReLU (the ReLU that produced r): d pre-activation
+    dz = torch.randn(M, C_, generator=g)
+    pre = r64  # treat r as relu(pre) with pre = r where r > 0; mask = r > 0
+    z.backward(dz.double().t().reshape(1, C_, M, 1))
+    dr_ref = r64.grad[0, :, :, 0].t() * (r.double() > 0)
+    dzd = dz.to(DEV)
+    part2 = torch.empty(nb, 2, C_, device=DEV)
+    nat.check(lib.dfl_colstats(C.addressof(nat.ColstatsArgs(a=dzd.data_ptr(), b=rd.data_ptr(), partials=part2.data_ptr(), M=M,
+                                                            C=C_, lda=C_, ldb=C_, nblocks=nb)), stream()))
+    dgamma, dbeta, coef = torch.empty(C_, device=DEV), torch.empty(C_, device=DEV), torch.empty(3, C_, device=DEV)
+    nat.check(lib.dfl_bn_bwd_finalize(C.addressof(nat.BnBwdFinalizeArgs(
+        partials=part2.data_ptr(), gamma=dv['gamma'].data_ptr(), save_mean=mean.data_ptr(), save_invstd=invstd.data_ptr(),
+        dgamma=dgamma.data_ptr(), dbeta=dbeta.data_ptr(), coef=coef.data_ptr(), count=M, nblocks=nb, C=C_)), stream()))
+    dpre = torch.empty(M, C_, device=DEV)
+    bpart = torch.empty(nb, C_, device=DEV)
+    nat.check(lib.dfl_bn_relu_bwd_apply(C.addressof(nat.BnReluBwdArgs(
+        dy=dzd.data_ptr(), r=rd.data_ptr(), coef=coef.data_ptr(), dpre=dpre.data_ptr(), partials=bpart.data_ptr(), M=M, C=C_,
+        lddy=C_, ldr=C_, ldo=C_, nblocks=nb)), stream()))
+    bsum = torch.empty(C_, device=DEV)
+    nat.check(lib.dfl_reduce_partials(bpart.data_ptr(), bsum.data_ptr(), nb, C_, C_, stream()))
+    torch.cuda.synchronize()
+    # gamma/beta grads from torch need parameters with grad: recompute analytically in fp64
+    xhat = (r.double() - r.double().mean(0)) / torch.sqrt(r.double().var(0, unbiased=False) + 1e-5)
+    np.testing.assert_allclose(dgamma.cpu().numpy(), (dz.double() * xhat).sum(0).numpy(), rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(dbeta.cpu().numpy(), dz.double().sum(0).numpy(), rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(dpre.cpu().numpy(), dr_ref.numpy(), rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(bsum.cpu().numpy(), dr_ref.sum(0).numpy(), rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize('shape', [(2, 8, 10, 12), (1, 32, 7, 9), (2, 3, 6, 6)])
+def test_maxpool(shape):
+    lib = nat.lib()
+    N, C_, H, W = shape
+    g = torch.Generator().manual_seed(1)
+    x = torch.randint(0, 4, shape, generator=g).float()        # many ties -> exercises the first-max rule
+    x.requires_grad_(True)
+    y = F.max_pool2d(x, 2)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    xd = nhwc(x.detach()).to(DEV)
+    yd = torch.empty(N, H // 2, W // 2, C_, device=DEV)
+    nat.check(lib.dfl_maxpool2x2_fwd(C.addressof(nat.PoolArgs(x=xd.data_ptr(), y=yd.data_ptr(), N=N, H=H, W=W, C=C_, ldx=C_,
+                                                              ldy=C_)), stream()))
+    base = torch.randn(N, H, W, C_, generator=g)
+    dxd = base.to(DEV)
+    dyd = nhwc(dy).to(DEV)
+    nat.check(lib.dfl_maxpool2x2_bwd(C.addressof(nat.PoolArgs(x=xd.data_ptr(), y=dyd.data_ptr(), dx=dxd.data_ptr(), N=N, H=H,
+                                                              W=W, C=C_, ldx=C_, ldy=C_, lddx=C_)), stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(nchw(yd.cpu()), y.detach())
+    np.testing.assert_allclose(nchw(dxd.cpu() - base).numpy(), x.grad.numpy(), rtol=1e-6, atol=1e-6)
+
+
+def test_affine_copy_window():
+    lib = nat.lib()
+    g = torch.Generator().manual_seed(4)
+    N, C_, H, W = 2, 8, 9, 11
+    x = torch.randn(N, H, W, C_, generator=g)
+    sc, sh = torch.rand(C_, generator=g), torch.randn(C_, generator=g)
+    xd, scd, shd = x.to(DEV), sc.to(DEV), sh.to(DEV)
+    yd = torch.zeros(N, 5, 6, 2 * C_, device=DEV)
+    a = nat.AffineCopyArgs(x=xd.data_ptr(), y=yd.data_ptr() + 4 * C_, scale=scd.data_ptr(), shift=shd.data_ptr(), N=N, H=5, W=6,
+                           C=C_, ldx=C_, xH=H, xW=W, xoy=2, xox=3, ldy=2 * C_, yH=5, yW=6)
+    nat.check(lib.dfl_affine_copy(C.addressof(a), stream()))
+    torch.cuda.synchronize()
+    ref = x[:, 2:7, 3:9, :] * sc + sh
+    np.testing.assert_allclose(yd.cpu()[..., C_:].numpy(), ref.numpy(), rtol=1e-6, atol=1e-6)
+    assert float(yd.cpu()[..., :C_].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('NC,L,two,softmax,F_', [(7, 14, True, True, 32), (3, 14, False, True, 8), (5, 0, True, False, 8),
+                                                 (7, 14, True, True, 4)])
+def test_heads_forward_backward(NC, L, two, softmax, F_):
+    lib = nat.lib()
+    g = torch.Generator().manual_seed(NC + L)
+    N, H, W = 2, 11, 13
+    x = torch.randn(N, F_, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    wseg = (torch.randn(NC, F_, 1, 1, generator=g, dtype=torch.float64) / 3).requires_grad_(True)
+    NM = (NC + L if two else L) if L > 0 else 0
+    params = [wseg]
+    logits = F.conv2d(x, wseg)
+    seg = torch.softmax(logits, 1) if softmax else logits
+    outs = [seg]
+    if L > 0:
+        w1 = (torch.randn(NM, F_ + NC, 1, 1, generator=g, dtype=torch.float64) / 3).requires_grad_(True)
+        params.append(w1)
+        mid = F.conv2d(torch.cat((x, logits), 1), w1)
+        heat = mid
+        if two:
+            w2 = (torch.randn(L, NM, 1, 1, generator=g, dtype=torch.float64) / 3).requires_grad_(True)
+            params.append(w2)
+            heat = F.conv2d(mid, w2)
+        outs.append(heat)
+    gouts = [torch.randn(o.shape, generator=g, dtype=torch.float64) for o in outs]
+    torch.autograd.backward(outs, gouts)
+    dv = lambda t: t.detach().float().contiguous().to(DEV)
+    xd = nhwc(x.detach().float()).to(DEV)
+    wsd = dv(wseg)
+    w1d = dv(w1) if L > 0 else None
+    w2d = dv(w2) if (L > 0 and two) else None
+    segd = torch.empty(N, NC, H, W, device=DEV)
+    heatd = torch.empty(N, L, H, W, device=DEV) if L > 0 else None
+    nat.check(lib.dfl_head_fwd(C.addressof(nat.HeadFwdArgs(
+        x=xd.data_ptr(), w_seg=wsd.data_ptr(), w_l1=nat.ptr(w1d), w_l2=nat.ptr(w2d), seg=segd.data_ptr(), heat=nat.ptr(heatd),
+        N=N, H=H, W=W, F=F_, ldx=F_, NC=NC, NM=NM, L=L, softmax=int(softmax))), stream()))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(segd.cpu().numpy(), seg.detach().numpy(), rtol=1e-5, atol=1e-6)
+    if L > 0:
+        np.testing.assert_allclose(heatd.cpu().numpy(), heat.detach().numpy(), rtol=1e-5, atol=1e-5)
+    # backward
+    sld = lib.dfl_head_scratch_ld(F_)
+    scratch = torch.full((N * H * W, sld), float('nan'), device=DEV)
+    dxd = torch.empty(N, H, W, F_, device=DEV)
+    dsegd = dv(gouts[0])
+    dheatd = dv(gouts[1]) if L > 0 else None
+    nat.check(lib.dfl_head_bwd(C.addressof(nat.HeadBwdArgs(
+        x=xd.data_ptr(), seg=segd.data_ptr(), dseg=dsegd.data_ptr(), dheat=nat.ptr(dheatd), w_seg=wsd.data_ptr(),
+        w_l1=nat.ptr(w1d), w_l2=nat.ptr(w2d), dx=dxd.data_ptr(), scratch=scratch.data_ptr(), N=N, H=H, W=W, F=F_, ldx=F_,
+        lddx=F_, NC=NC, NM=NM, L=L, softmax=int(softmax), scratch_ld=sld)), stream()))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(nchw(dxd.cpu()).numpy(), x.grad.numpy(), rtol=1e-4, atol=1e-5)
+    sc = scratch.cpu().double()
+    assert torch.isfinite(sc).all()
+    off = [lib.dfl_head_scratch_off(F_, k) for k in range(5)]
+    dwseg = sc[:, off[1]:off[1] + NC].t() @ sc[:, off[0]:off[0] + F_]
+    np.testing.assert_allclose(dwseg.numpy(), wseg.grad[:, :, 0, 0].numpy(), rtol=1e-4, atol=1e-4)
+    if L > 0:
+        dw1 = sc[:, off[2]:off[2] + NM].t() @ sc[:, off[0]:off[0] + F_ + NC]
+        np.testing.assert_allclose(dw1.numpy(), w1.grad[:, :, 0, 0].numpy(), rtol=1e-4, atol=1e-4)
+        if two:
+            dw2 = sc[:, off[4]:off[4] + L].t() @ sc[:, off[3]:off[3] + NM]
+            np.testing.assert_allclose(dw2.numpy(), w2.grad[:, :, 0, 0].numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_losses_against_golden_and_oracle(golden):
+    g = golden('losses')
+    s = torch.from_numpy(g['dice_in']).float().to(DEV).requires_grad_(True)
+    t = torch.from_numpy(g['dice_tgt']).float().to(DEV)
+    for sb in (True, False):
+        s.grad = None
+        l = dfl_amd.DiceLoss2D(skip_bg=sb)(s, t)
+        l.backward()
+        assert abs(l.item() - float(g['dice_sb%d' % int(sb)])) < 2e-6
+        np.testing.assert_allclose(s.grad.cpu().numpy(), g['dice_sb%d_grad' % int(sb)], rtol=1e-4, atol=1e-8)
+    assert abs(dfl_amd.DiceLoss2D(skip_bg=False)(t, t).item() - float(g['dice_perfect'])) < 2e-6
+    X = torch.from_numpy(g['ncc_x']).float().to(DEV)
+    Y = torch.from_numpy(g['ncc_y']).float().to(DEV)
+    np.testing.assert_allclose(dfl_amd.ncc_2d(X, Y).cpu().numpy(), g['ncc'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(dfl_amd.ncc_2d(Y, Y).cpu().numpy(), g['ncc_self'], rtol=1e-5)
+    X.requires_grad_(True)
+    s.grad = None
+    l = dfl_amd.DiceAndHeatMapLoss2D(skip_bg=False, heatmap_wgt=0.3)((s, X), (t, Y))
+    l.backward()
+    assert abs(l.item() - float(g['dh_loss'])) < 2e-6
+    np.testing.assert_allclose(s.grad.cpu().numpy(), g['dh_gseg'], rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(X.grad.cpu().numpy(), g['dh_gheat'], rtol=2e-4, atol=1e-8)
+
+
+def test_loss_on_cropped_views_full_size():
+    """BASELINE config-2 sized loss on center-cropped (strided) views vs the oracle."""
+    g = torch.Generator().manual_seed(9)
+    B = 4
+    seg = torch.softmax(torch.randn(B, 7, 192, 192, generator=g), 1)
+    heat = torch.randn(B, 14, 192, 192, generator=g) * 0.01
+    lab = torch.randint(0, 7, (B, 184, 184), generator=g)
+    tseg = R.one_hot_masks(lab, 7)
+    theat = torch.rand(B, 14, 184, 184, generator=g) * 0.02
+    sr, hr = seg.clone().requires_grad_(True), heat.clone().requires_grad_(True)
+    lr = R.dice_and_heatmap_loss_2d((R.center_crop(sr, tseg.shape), R.center_crop(hr, theat.shape)), (tseg, theat), False, 0.5)
+    lr.backward()
+    sd, hd = seg.to(DEV).requires_grad_(True), heat.to(DEV).requires_grad_(True)
+    ld = dfl_amd.DiceAndHeatMapLoss2D(skip_bg=False, heatmap_wgt=0.5)(
+        (dfl_amd.center_crop(sd, tseg.shape), dfl_amd.center_crop(hd, theat.shape)), (tseg.to(DEV), theat.to(DEV)))
+    ld.backward()
+    assert abs(ld.item() - lr.item()) < 2e-6
+    np.testing.assert_allclose(sd.grad.cpu().numpy(), sr.grad.numpy(), rtol=1e-3, atol=1e-10)
+    np.testing.assert_allclose(hd.grad.cpu().numpy(), hr.grad.numpy(), rtol=1e-3, atol=1e-9)
+
+
+def test_sgd_step():
+    lib = nat.lib()
+    g = torch.Generator().manual_seed(6)
+    n = 10007
+    p = torch.randn(n, generator=g)
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.SGD([pr], lr=0.1, momentum=0.9, weight_decay=1e-4, nesterov=True)
+    pd, buf = p.to(DEV), torch.zeros(n, device=DEV)
+    for step in range(3):
+        gr = torch.randn(n, generator=g)
+        pr.grad = gr.clone()
+        opt.step()
+        grd = gr.to(DEV)
+        nat.check(lib.dfl_sgd_step(pd.data_ptr(), grd.data_ptr(), buf.data_ptr(), n, 0.1, 0.9, 1e-4, 1.0, 1, int(step == 0), stream()))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(pd.cpu().numpy(), pr.detach().numpy(), rtol=1e-5, atol=1e-6)
