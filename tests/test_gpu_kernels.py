@@ -298,15 +298,15 @@ def test_batchnorm_forward_backward(C_, M):
     rd = r.to(DEV)
     nb = lib.dfl_rowblock_count(M, C_)
     part = torch.empty(nb, 2, C_, device=DEV)
-    nat.check(lib.dfl_colstats(C.addressof(nat.ColstatsArgs(a=rd.data_ptr(), b=None, partials=part.data_ptr(), M=M, C=C_,
-                                                            lda=C_, ldb=0, nblocks=nb)), stream()))
+    nat.call('dfl_colstats', nat.ColstatsArgs(a=rd.data_ptr(), b=None, partials=part.data_ptr(), M=M, C=C_,
+                                                            lda=C_, ldb=0, nblocks=nb), stream())
     dv = {k: v.to(DEV) for k, v in dict(gamma=gamma, beta=beta, rm=rm.clone(), rv=rv.clone(), nbt=nbt.clone()).items()}
     scale, shift, mean, invstd = (torch.empty(C_, device=DEV) for _ in range(4))
-    nat.check(lib.dfl_bn_finalize(C.addressof(nat.BnFinalizeArgs(
+    nat.call('dfl_bn_finalize', nat.BnFinalizeArgs(
         partials=part.data_ptr(), gamma=dv['gamma'].data_ptr(), beta=dv['beta'].data_ptr(), running_mean=dv['rm'].data_ptr(),
         running_var=dv['rv'].data_ptr(), num_batches_tracked=dv['nbt'].data_ptr(), scale=scale.data_ptr(),
         shift=shift.data_ptr(), save_mean=mean.data_ptr(), save_invstd=invstd.data_ptr(), count=M, nblocks=nb, C=C_,
-        eps=1e-5, momentum=0.1)), stream()))
+        eps=1e-5, momentum=0.1), stream())
     # torch reference (double)
     r64 = r.double().t().reshape(1, C_, M, 1).requires_grad_(True)
     rm64, rv64 = rm.double().clone(), rv.double().clone()
@@ -329,17 +329,17 @@ def test_batchnorm_forward_backward(C_, M):
     dr_ref = r64.grad[0, :, :, 0].t() * (r.double() > 0)
     dzd = dz.to(DEV)
     part2 = torch.empty(nb, 2, C_, device=DEV)
-    nat.check(lib.dfl_colstats(C.addressof(nat.ColstatsArgs(a=dzd.data_ptr(), b=rd.data_ptr(), partials=part2.data_ptr(), M=M,
-                                                            C=C_, lda=C_, ldb=C_, nblocks=nb)), stream()))
+    nat.call('dfl_colstats', nat.ColstatsArgs(a=dzd.data_ptr(), b=rd.data_ptr(), partials=part2.data_ptr(), M=M,
+                                                            C=C_, lda=C_, ldb=C_, nblocks=nb), stream())
     dgamma, dbeta, coef = torch.empty(C_, device=DEV), torch.empty(C_, device=DEV), torch.empty(3, C_, device=DEV)
-    nat.check(lib.dfl_bn_bwd_finalize(C.addressof(nat.BnBwdFinalizeArgs(
+    nat.call('dfl_bn_bwd_finalize', nat.BnBwdFinalizeArgs(
         partials=part2.data_ptr(), gamma=dv['gamma'].data_ptr(), save_mean=mean.data_ptr(), save_invstd=invstd.data_ptr(),
-        dgamma=dgamma.data_ptr(), dbeta=dbeta.data_ptr(), coef=coef.data_ptr(), count=M, nblocks=nb, C=C_)), stream()))
+        dgamma=dgamma.data_ptr(), dbeta=dbeta.data_ptr(), coef=coef.data_ptr(), count=M, nblocks=nb, C=C_), stream())
     dpre = torch.empty(M, C_, device=DEV)
     bpart = torch.empty(nb, C_, device=DEV)
-    nat.check(lib.dfl_bn_relu_bwd_apply(C.addressof(nat.BnReluBwdArgs(
+    nat.call('dfl_bn_relu_bwd_apply', nat.BnReluBwdArgs(
         dy=dzd.data_ptr(), r=rd.data_ptr(), coef=coef.data_ptr(), dpre=dpre.data_ptr(), partials=bpart.data_ptr(), M=M, C=C_,
-        lddy=C_, ldr=C_, ldo=C_, nblocks=nb)), stream()))
+        lddy=C_, ldr=C_, ldo=C_, nblocks=nb), stream())
     bsum = torch.empty(C_, device=DEV)
     nat.check(lib.dfl_reduce_partials(bpart.data_ptr(), bsum.data_ptr(), nb, C_, C_, stream()))
     torch.cuda.synchronize()
@@ -363,13 +363,13 @@ def test_maxpool(shape):
     y.backward(dy)
     xd = nhwc(x.detach()).to(DEV)
     yd = torch.empty(N, H // 2, W // 2, C_, device=DEV)
-    nat.check(lib.dfl_maxpool2x2_fwd(C.addressof(nat.PoolArgs(x=xd.data_ptr(), y=yd.data_ptr(), N=N, H=H, W=W, C=C_, ldx=C_,
-                                                              ldy=C_)), stream()))
+    nat.call('dfl_maxpool2x2_fwd', nat.PoolArgs(x=xd.data_ptr(), y=yd.data_ptr(), N=N, H=H, W=W, C=C_, ldx=C_,
+                                                              ldy=C_), stream())
     base = torch.randn(N, H, W, C_, generator=g)
     dxd = base.to(DEV)
     dyd = nhwc(dy).to(DEV)
-    nat.check(lib.dfl_maxpool2x2_bwd(C.addressof(nat.PoolArgs(x=xd.data_ptr(), y=dyd.data_ptr(), dx=dxd.data_ptr(), N=N, H=H,
-                                                              W=W, C=C_, ldx=C_, ldy=C_, lddx=C_)), stream()))
+    nat.call('dfl_maxpool2x2_bwd', nat.PoolArgs(x=xd.data_ptr(), y=dyd.data_ptr(), dx=dxd.data_ptr(), N=N, H=H,
+                                                              W=W, C=C_, ldx=C_, ldy=C_, lddx=C_), stream())
     torch.cuda.synchronize()
     assert torch.equal(nchw(yd.cpu()), y.detach())
     np.testing.assert_allclose(nchw(dxd.cpu() - base).numpy(), x.grad.numpy(), rtol=1e-6, atol=1e-6)
@@ -424,9 +424,9 @@ def test_heads_forward_backward(NC, L, two, softmax, F_):
     w2d = dv(w2) if (L > 0 and two) else None
     segd = torch.empty(N, NC, H, W, device=DEV)
     heatd = torch.empty(N, L, H, W, device=DEV) if L > 0 else None
-    nat.check(lib.dfl_head_fwd(C.addressof(nat.HeadFwdArgs(
+    nat.call('dfl_head_fwd', nat.HeadFwdArgs(
         x=xd.data_ptr(), w_seg=wsd.data_ptr(), w_l1=nat.ptr(w1d), w_l2=nat.ptr(w2d), seg=segd.data_ptr(), heat=nat.ptr(heatd),
-        N=N, H=H, W=W, F=F_, ldx=F_, NC=NC, NM=NM, L=L, softmax=int(softmax))), stream()))
+        N=N, H=H, W=W, F=F_, ldx=F_, NC=NC, NM=NM, L=L, softmax=int(softmax)), stream())
     torch.cuda.synchronize()
     np.testing.assert_allclose(segd.cpu().numpy(), seg.detach().numpy(), rtol=1e-5, atol=1e-6)
     if L > 0:
@@ -437,10 +437,10 @@ def test_heads_forward_backward(NC, L, two, softmax, F_):
     dxd = torch.empty(N, H, W, F_, device=DEV)
     dsegd = dv(gouts[0])
     dheatd = dv(gouts[1]) if L > 0 else None
-    nat.check(lib.dfl_head_bwd(C.addressof(nat.HeadBwdArgs(
+    nat.call('dfl_head_bwd', nat.HeadBwdArgs(
         x=xd.data_ptr(), seg=segd.data_ptr(), dseg=dsegd.data_ptr(), dheat=nat.ptr(dheatd), w_seg=wsd.data_ptr(),
         w_l1=nat.ptr(w1d), w_l2=nat.ptr(w2d), dx=dxd.data_ptr(), scratch=scratch.data_ptr(), N=N, H=H, W=W, F=F_, ldx=F_,
-        lddx=F_, NC=NC, NM=NM, L=L, softmax=int(softmax), scratch_ld=sld)), stream()))
+        lddx=F_, NC=NC, NM=NM, L=L, softmax=int(softmax), scratch_ld=sld), stream())
     torch.cuda.synchronize()
     np.testing.assert_allclose(nchw(dxd.cpu()).numpy(), x.grad.numpy(), rtol=1e-4, atol=1e-5)
     sc = scratch.cpu().double()

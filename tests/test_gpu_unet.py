@@ -245,7 +245,7 @@ def test_full_size_properties():
     seg, heat = net(x)
     assert seg.shape == (16, 7, 192, 192) and heat.shape == (16, 14, 192, 192)
     assert torch.isfinite(seg).all() and torch.isfinite(heat).all()
-    assert float((seg.sum(1) - 1).abs().max()) < 1e-5
+    assert float((seg.detach().sum(1) - 1).abs().max()) < 1e-5
     perm = torch.randperm(16, generator=gen).to(DEV)
     with torch.no_grad():
         seg_p, heat_p = net(x[perm])
