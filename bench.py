@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Benchmark of the U-Net hot path on MI355X: training images/sec (BASELINE.json's metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): the paper architecture (depth 6, 32..1024 channels, BatchNorm, zero padding,
+strided-conv down-sampling, residual blocks) with the seg + 14-landmark heat-map heads, batch 16 PER GPU of synthetic
+1x192x192 images (184x184 reflect-padded size), Dice + NCC loss, SGD(nesterov 0.9, wd 1e-4): one step =
+zero_grad -> forward -> crop -> loss -> backward -> optimizer step -> loss.item(), exactly train.py:405-430.
+Inputs and targets are resident in HBM before the timed region.  Arithmetic is fp32 (exact-f32 MFMA); no step of the
+loop is skipped.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PAPER = dict(n_classes=7, depth=6, wf=5, batch_norm=True, padding=True, max_pool=False, num_lands=14, do_res=True,
+             block_depth=2)
+F32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+CONV_KERNELS = ['conv_gemm_kernel<2,2,2,2>', 'conv_gemm_kernel<2,2,2,1>', 'conv_gemm_kernel<4,1,2,1>',
+                'conv_gemm_kernel<2,2,1,1>', 'conv_gemm_kernel<1,2,1,1>']
+WGRAD_KERNELS = ['wgrad_kernel<2,2,2,2,1>', 'wgrad_kernel<2,2,1,1,1>', 'wgrad_kernel<1,1,1,1,9>',
+                 'wgrad_kernel<1,1,1,1,4>', 'wgrad_kernel<1,1,1,1,1>']
+
+
+def synth_batch(B, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 1, 192, 192, generator=g)
+    lab = torch.randint(0, 7, (B, 184, 184), generator=g)
+    tseg = torch.stack([(lab == c) for c in range(7)], 1).float()
+    theat = torch.rand(B, 14, 184, 184, generator=g) * 0.02
+    return x.to(dev), tseg.to(dev), theat.to(dev)
+
+
+def op_profile(plan, lib, nat, stream, detail=None):
+    """Per-kernel-family time (hipEvents around every op of one forward+backward replay) and algorithmic FLOPs."""
+    groups = {}
+
+    def account(prog, ms):
+        for st, t in zip(prog.structs, ms):
+            if isinstance(st, nat.ConvArgs):
+                cfg = lib.dfl_conv_config(C.addressof(st))
+                name = CONV_KERNELS[cfg]
+                if st.scatter2x2:
+                    M = st.N * st.Hin * st.Win
+                else:
+                    M = st.N * st.Hout * st.Wout
+                fl = 2.0 * M * st.KH * st.KW * st.Cin * st.Ntot
+            elif isinstance(st, nat.WgradArgs):
+                cfg = lib.dfl_wgrad_config(C.addressof(st))
+                name = WGRAD_KERNELS[cfg]
+                fl = 2.0 * st.N * st.Hout * st.Wout * st.Cm * st.Cg * st.KH * st.KW
+            else:
+                name, fl = type(st).__name__, 0.0
+            if detail is not None:
+                if isinstance(st, nat.ConvArgs):
+                    desc = 'N%d %dx%d Cin%d -> %dx%d Ntot%d k%d s%d' % (st.N, st.Hin, st.Win, st.Cin, st.Hout, st.Wout,
+                                                                         st.Ntot, st.KH, st.stride)
+                elif isinstance(st, nat.WgradArgs):
+                    desc = 'N%d %dx%d Cg%d Cm%d k%d splits%d' % (st.N, st.Hin, st.Win, st.Cg, st.Cm, st.KH, st.splits)
+                elif isinstance(st, nat.SumPartialsArgs):
+                    desc = 'n%d splits%d' % (st.n, st.splits)
+                else:
+                    desc = ''
+                detail.append('%-28s %8.3f ms %7.1f TF  %s' % (name, t, fl / (t * 1e-3) / 1e12 if t > 0 else 0, desc))
+            gr = groups.setdefault(name, [0.0, 0.0, 0])
+            gr[0] += t
+            gr[1] += fl
+            gr[2] += 1
+    account(plan.fwd, plan.fwd.run_timed(stream))
+    if detail is not None:
+        detail.append('---- backward ----')
+    account(plan.bwd, plan.bwd.run_timed(stream))
+    return groups
+
+
+def cpu_baseline(B, steps=2):
+    """The oracle (CPU restatement of the reference, checked against it in tests/test_oracle_golden.py) on this box's
+    host cores, same workload and step body."""
+    from oracle import ref_cpu as R
+    torch.manual_seed(1234)
+    net = R.OracleUNet(**PAPER)
+    opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4, nesterov=True)
+    x, tseg, theat = synth_batch(B, 4321, 'cpu')
+    net.train()
+    R.train_step(net, opt, x, tseg, theat, 0.5)          # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        R.train_step(net, opt, x, tseg, theat, 0.5)
+    dt = time.perf_counter() - t0
+    return B * steps / dt, steps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=16, help='images per GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-profile', action='store_true')
+    ap.add_argument('--detail', action='store_true', help='per-op table on stderr')
+    ap.add_argument('--no-overlap', action='store_true', help='all-reduce after backward instead of overlapped buckets')
+    args = ap.parse_args()
+
+    import dfl_amd
+    from dfl_amd import _native as nat
+    from dfl_amd.parallel import DataParallel, init_process_group_from_env
+    import torch.distributed as dist
+
+    rank, world, local = init_process_group_from_env('nccl')
+    if world != args.gpus and world > 1:
+        raise SystemExit('--gpus %d does not match WORLD_SIZE %d' % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit('launch with torch.distributed.run for --gpus > 1')
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    lib = nat.lib()
+
+    torch.manual_seed(1234)
+    net = dfl_amd.UNet(**PAPER).to(dev)
+    dp = DataParallel(net, overlap=not args.no_overlap) if world > 1 else None
+    crit = dfl_amd.DiceAndHeatMapLoss2D(skip_bg=False, heatmap_wgt=0.5)
+    opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4, nesterov=True)
+    B = args.batch
+    x, tseg, theat = synth_batch(B, 4321 + rank, dev)
+    net.train()
+
+    def step():
+        opt.zero_grad()
+        seg, heat = net(x)
+        loss = crit((dfl_amd.center_crop(seg, tseg.shape), dfl_amd.center_crop(heat, theat.shape)), (tseg, theat))
+        loss.backward()
+        opt.step()
+        return loss.item()          # train.py:430 synchronises every step; so do we
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = 0.0
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = B * world * args.steps / dt
+
+    roofline = None
+    extra = {}
+    if rank == 0 and not args.no_profile:
+        # one more forward/backward, replayed op by op with hipEvents on the launch stream
+        plan = [p for plans in net._plans.values() for p in plans if p.need_grad][0]
+        seg, heat = net(x)
+        hold = (torch.randn_like(seg) * 1e-6, torch.randn_like(heat) * 1e-6)
+        plan.head_bwd.seg, plan.head_bwd.dseg, plan.head_bwd.dheat = seg.data_ptr(), hold[0].data_ptr(), hold[1].data_ptr()
+        stream = torch.cuda.current_stream().cuda_stream
+        plan.bwd.run(stream)
+        torch.cuda.synchronize()
+        detail = [] if args.detail else None
+        groups = op_profile(plan, lib, nat, stream, detail)
+        if detail:
+            sys.stderr.write('\n'.join(detail) + '\n')
+        plan.busy = False
+        tot_ms = sum(v[0] for v in groups.values())
+        dom = max(groups.items(), key=lambda kv: kv[1][0])
+        name, (ms, fl, n) = dom
+        achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        roofline = {'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 2), 'peak': F32_MFMA_PEAK_TFLOPS,
+                    'unit': 'TFLOP/s', 'frac': round(achieved / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                    'launches_per_step': n, 'avg_launch_ms': round(ms / n, 4),
+                    'share_of_kernel_time': round(ms / tot_ms, 3)}
+        fl_all = sum(v[1] for v in groups.values())
+        extra['kernel_time_ms_per_step'] = round(tot_ms, 3)
+        extra['whole_step_tflops'] = round(fl_all / (ms_per_step * 1e-3) / 1e12, 2)
+        extra['kernels'] = {k: {'ms': round(v[0], 3), 'tflops': round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[0] > 0 and v[1] > 0 else None,
+                                'launches': v[2]} for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0])}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        v, nst = cpu_baseline(B)
+        cpu = {'value': round(v, 2), 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
+               'sample': '%d training steps (after 1 warm-up) of the same batch-%d paper dual-head workload, oracle/ref_cpu.py '
+                         '(PyTorch CPU fp32)' % (nst, B)}
+
+    if rank == 0:
+        out = {'metric': 'train images/sec, paper U-Net (depth 6, wf 5, BN, strided-conv down, seg + 14-landmark heads), '
+                         '1x192x192 (8x-downsampled 184x184 padded)',
+               'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+               'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+               'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': 'BASELINE configs[1]: 8x-downsampled, seg + 14-landmark heat-map dual head, '
+                                      'batch %d per GPU, Dice+NCC loss, SGD nesterov' % B,
+                          'global_batch': B * world, 'image': '1x192x192', 'parallelism': 'dp%d' % world,
+                          'optimizer': 'torch.optim.SGD(momentum 0.9, nesterov, wd 1e-4)', 'last_loss': round(last, 6)},
+               'roofline': roofline, 'cpu_baseline': cpu}
+        out.update(extra)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -15,11 +15,12 @@ fp = C.c_void_p   # every device pointer is passed as a plain address
 class ConvArgs(C.Structure):
     _fields_ = [('x', fp), ('w', fp), ('bias', fp), ('in_scale', fp), ('in_shift', fp), ('add', fp),
                 ('add_scale', fp), ('add_shift', fp), ('stat_other', fp), ('y', fp), ('stat_partials', fp),
+                ('partial', fp),
                 ('N', i32), ('Hin', i32), ('Win', i32), ('Cin', i32), ('ldx', i32),
                 ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32),
                 ('Hout', i32), ('Wout', i32), ('Ntot', i32), ('ldy', i32),
                 ('ldadd', i32), ('ldso', i32), ('relu', i32), ('accumulate', i32), ('scatter2x2', i32),
-                ('reserved', i32)]
+                ('splits', i32)]
 
 
 class WgradArgs(C.Structure):
@@ -141,7 +142,8 @@ EXPORTS = ['dfl_version', 'dfl_last_error', 'dfl_sizeof', 'dfl_conv2d', 'dfl_con
            'dfl_bn_eval_prepare', 'dfl_rowblock_count', 'dfl_colstats', 'dfl_bn_bwd_finalize',
            'dfl_bn_relu_bwd_apply', 'dfl_reduce_partials', 'dfl_affine_copy', 'dfl_maxpool2x2_fwd',
            'dfl_maxpool2x2_bwd', 'dfl_head_fwd', 'dfl_head_bwd', 'dfl_head_scratch_ld', 'dfl_head_scratch_off',
-           'dfl_dice_ncc_loss', 'dfl_loss_scratch_doubles', 'dfl_ensemble_reduce', 'dfl_sgd_step', 'dfl_exec']
+           'dfl_dice_ncc_loss', 'dfl_loss_scratch_doubles', 'dfl_ensemble_reduce', 'dfl_sgd_step', 'dfl_exec',
+           'dfl_exec_timed', 'dfl_conv_config', 'dfl_wgrad_config', 'dfl_conv_suggest_splits']
 
 
 class DflError(RuntimeError):
@@ -173,11 +175,14 @@ def lib():
     L.dfl_reduce_partials.argtypes = [fp, fp, i32, i32, i32, fp]
     L.dfl_sgd_step.argtypes = [fp, fp, fp, i64, f32, f32, f32, f32, i32, i32, fp]
     L.dfl_exec.argtypes = [fp, i32, fp]
+    L.dfl_exec_timed.argtypes = [fp, i32, fp, fp]
+    L.dfl_conv_config.argtypes = [fp]
+    L.dfl_wgrad_config.argtypes = [fp]
     for fn in ('dfl_conv2d', 'dfl_conv2d_wgrad', 'dfl_bn_finalize', 'dfl_colstats', 'dfl_bn_bwd_finalize',
                'dfl_bn_relu_bwd_apply', 'dfl_affine_copy', 'dfl_maxpool2x2_fwd', 'dfl_maxpool2x2_bwd',
                'dfl_head_fwd', 'dfl_head_bwd', 'dfl_dice_ncc_loss', 'dfl_ensemble_reduce'):
         getattr(L, fn).argtypes = [fp, fp]
-    for fn in ('dfl_conv_grid_m', 'dfl_wgrad_suggest_splits'):
+    for fn in ('dfl_conv_grid_m', 'dfl_wgrad_suggest_splits', 'dfl_conv_suggest_splits'):
         getattr(L, fn).argtypes = [fp]
     for k, cls in enumerate(_SIZEOF_ORDER):
         if L.dfl_sizeof(k) != C.sizeof(cls):
@@ -237,6 +242,15 @@ class Program:
             arr[i].kind = k
             arr[i].args = C.addressof(s)
         self._ops = arr
+
+    def run_timed(self, stream):
+        """Replay with a hipEvent pair around every op (on `stream`); returns the per-op milliseconds."""
+        if self._ops is None:
+            self._build()
+        n = len(self.structs)
+        ms = (C.c_float * n)()
+        check(lib().dfl_exec_timed(C.addressof(self._ops), n, stream, C.addressof(ms)), 'dfl_exec_timed')
+        return list(ms)
 
     def run(self, stream, start=0, count=None):
         if not self.structs:

@@ -30,12 +30,50 @@ extern "C" int dfl_sizeof(int which) {
   return sizes[which];
 }
 
+static int exec_one(const dfl_op* ops, int i, dfl_stream_t stream);
+
 extern "C" int dfl_exec(const dfl_op* ops, int32_t n_ops, dfl_stream_t stream) {
   if (ops == nullptr || n_ops < 0) {
     dfl::set_error("dfl_exec: bad arguments");
     return DFL_ERR_INVALID_ARG;
   }
   for (int i = 0; i < n_ops; ++i) {
+    int rc = exec_one(ops, i, stream);
+    if (rc != DFL_OK) return rc;
+  }
+  return DFL_OK;
+}
+
+extern "C" int dfl_exec_timed(const dfl_op* ops, int32_t n_ops, dfl_stream_t stream, float* ms_out) {
+  if (ops == nullptr || n_ops <= 0 || ms_out == nullptr) {
+    dfl::set_error("dfl_exec_timed: bad arguments");
+    return DFL_ERR_INVALID_ARG;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipEvent_t* ev = new hipEvent_t[n_ops + 1];
+  for (int i = 0; i <= n_ops; ++i) hipEventCreate(&ev[i]);
+  int rc = DFL_OK;
+  hipEventRecord(ev[0], s);
+  int done = 0;
+  for (int i = 0; i < n_ops; ++i) {
+    rc = exec_one(ops, i, stream);
+    if (rc != DFL_OK) break;
+    hipEventRecord(ev[i + 1], s);
+    done = i + 1;
+  }
+  hipStreamSynchronize(s);
+  for (int i = 0; i < done; ++i) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+    ms_out[i] = ms;
+  }
+  for (int i = 0; i <= n_ops; ++i) hipEventDestroy(ev[i]);
+  delete[] ev;
+  return rc;
+}
+
+static int exec_one(const dfl_op* ops, int i, dfl_stream_t stream) {
+  {
     const void* p = ops[i].args;
     int rc = DFL_OK;
     switch (ops[i].kind) {
@@ -92,3 +130,6 @@ extern "C" int dfl_exec(const dfl_op* ops, int32_t n_ops, dfl_stream_t stream) {
   }
   return DFL_OK;
 }
+
+extern "C" int dfl_conv_config(const dfl_conv_args* a);
+extern "C" int dfl_wgrad_config(const dfl_wgrad_args* a);

@@ -26,9 +26,10 @@ struct ConvK {
   dfl_conv_args a;
   int Mtot, Ktot, Hg, Wg, Cout;
   int vecA, vecB;
+  int splits, cps;   // split-K: number of K slices and chunks per slice
 };
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool VEC>
 __global__ void __launch_bounds__(WM* WN * 64) conv_gemm_kernel(const ConvK p) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -75,35 +76,40 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_gemm_kernel(const ConvK p) {
 
   float4 ra[QA];
   float4 rb[QB];
+  const bool has_aff = a.in_scale != nullptr;
+  const float* aff_sc = has_aff ? a.in_scale : a.w;   // a.w: any valid 16-byte aligned address
+  const float* aff_sh = has_aff ? a.in_shift : a.w;
+
+  // Gather discipline (both matter on gfx950 / hipcc):
+  //  * every load is UNCONDITIONAL, from a clamped (always valid) address, and the zero-fill is a select: a load
+  //    under a runtime condition makes hipcc branch around it and wait vmcnt(0) per element, serialising the slab
+  //    into dependent round trips (cdna_hip_programming.md, ".s-level traps" (c));
+  //  * load_*() only ISSUES the loads into raw registers; the select / BatchNorm affine / LDS write happen in
+  //    store_AB() AFTER the MFMA block of the current chunk, so the s_waitcnt lands behind the MFMAs and the
+  //    HBM/L2 latency of chunk c+1 hides under the matrix work of chunk c.
+  float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  bool okA[QA][VEC ? 1 : 4];
+  bool okB[QB][4];
 
   auto load_A = [&](int kc0) {
     const int k = kc0 + 4 * aq;
-    if (p.vecA) {
+    if constexpr (VEC) {
       const bool kvalid = k < Ktot;
       const int t = kvalid ? k / Cin : 0;
       const int c = kvalid ? k - t * Cin : 0;
       const int dy = t / KW, dx = t - dy * KW;
-      float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (a.in_scale != nullptr && kvalid) {
-        sc = *reinterpret_cast<const float4*>(a.in_scale + c);
-        sh = *reinterpret_cast<const float4*>(a.in_shift + c);
-      }
+      sc4 = *reinterpret_cast<const float4*>(aff_sc + (has_aff ? c : 0));
+      sh4 = *reinterpret_cast<const float4*>(aff_sh + (has_aff ? c : 0));
 #pragma unroll
       for (int r = 0; r < QA; ++r) {
         const int iy = a_iy0[r] + dy, ix = a_ix0[r] + dx;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (kvalid && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win) {
-          const int64_t pix = (int64_t)a_base[r] + (int64_t)iy * Win + ix;
-          v = *reinterpret_cast<const float4*>(a.x + pix * a.ldx + c);
-          v.x = fmaf(v.x, sc.x, sh.x);
-          v.y = fmaf(v.y, sc.y, sh.y);
-          v.z = fmaf(v.z, sc.z, sh.z);
-          v.w = fmaf(v.w, sc.w, sh.w);
-        }
-        ra[r] = v;
+        const bool ok = kvalid && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
+        const int64_t pix = ok ? ((int64_t)a_base[r] + (int64_t)iy * Win + ix) : 0;
+        okA[r][0] = ok;
+        ra[r] = *reinterpret_cast<const float4*>(a.x + pix * a.ldx + (ok ? c : 0));
       }
     } else {
-      float vals[QA][4];
+      float vals[QA][4], scv[4], shv[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int kj = k + j;
@@ -111,22 +117,19 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_gemm_kernel(const ConvK p) {
         const int t = kvalid ? kj / Cin : 0;
         const int c = kvalid ? kj - t * Cin : 0;
         const int dy = t / KW, dx = t - dy * KW;
-        float sc = 1.f, sh = 0.f;
-        if (a.in_scale != nullptr && kvalid) {
-          sc = a.in_scale[c];
-          sh = a.in_shift[c];
-        }
+        scv[j] = aff_sc[has_aff ? c : 0];
+        shv[j] = aff_sh[has_aff ? c : 0];
 #pragma unroll
         for (int r = 0; r < QA; ++r) {
           const int iy = a_iy0[r] + dy, ix = a_ix0[r] + dx;
-          float v = 0.f;
-          if (kvalid && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win) {
-            const int64_t pix = (int64_t)a_base[r] + (int64_t)iy * Win + ix;
-            v = fmaf(a.x[pix * a.ldx + c], sc, sh);
-          }
-          vals[r][j] = v;
+          const bool ok = kvalid && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
+          const int64_t pix = ok ? ((int64_t)a_base[r] + (int64_t)iy * Win + ix) : 0;
+          okA[r][VEC ? 0 : j] = ok;
+          vals[r][j] = a.x[pix * a.ldx + (ok ? c : 0)];
         }
       }
+      sc4 = make_float4(scv[0], scv[1], scv[2], scv[3]);
+      sh4 = make_float4(shv[0], shv[1], shv[2], shv[3]);
 #pragma unroll
       for (int r = 0; r < QA; ++r) ra[r] = make_float4(vals[r][0], vals[r][1], vals[r][2], vals[r][3]);
     }
@@ -136,35 +139,35 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_gemm_kernel(const ConvK p) {
 #pragma unroll
     for (int r = 0; r < QB; ++r) {
       const int idx = tid + r * NT;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx < NQB) {
-        const int krow = idx / BQ, nq = idx - krow * BQ;
-        const int k = kc0 + krow, n = n0 + 4 * nq;
-        if (k < Ktot) {
-          const float* src = a.w + (int64_t)k * Ntot + n;
-          if (p.vecB) {
-            if (n < Ntot) v = *reinterpret_cast<const float4*>(src);
-          } else {
-            if (n + 0 < Ntot) v.x = src[0];
-            if (n + 1 < Ntot) v.y = src[1];
-            if (n + 2 < Ntot) v.z = src[2];
-            if (n + 3 < Ntot) v.w = src[3];
-          }
-        }
+      const int krow = idx / BQ, nq = idx - krow * BQ;
+      const int k = kc0 + krow, n = n0 + 4 * nq;
+      const bool ok = (idx < NQB) && (k < Ktot) && (n < Ntot);
+      const float* src = a.w + (ok ? ((int64_t)k * Ntot + n) : 0);
+      if constexpr (VEC) {
+        okB[r][0] = okB[r][1] = okB[r][2] = okB[r][3] = ok;
+        rb[r] = *reinterpret_cast<const float4*>(src);
+      } else {
+        okB[r][0] = ok;
+        okB[r][1] = ok && (n + 1 < Ntot);
+        okB[r][2] = ok && (n + 2 < Ntot);
+        okB[r][3] = ok && (n + 3 < Ntot);
+        rb[r] = make_float4(src[0], src[okB[r][1] ? 1 : 0], src[okB[r][2] ? 2 : 0], src[okB[r][3] ? 3 : 0]);
       }
-      rb[r] = v;
     }
   };
 
   auto store_AB = [&](int buf) {
     float* Ab = As + buf * KC * LDA;
+    const float s0 = has_aff ? sc4.x : 1.f, s1 = has_aff ? sc4.y : 1.f, s2 = has_aff ? sc4.z : 1.f, s3 = has_aff ? sc4.w : 1.f;
+    const float h0 = has_aff ? sh4.x : 0.f, h1 = has_aff ? sh4.y : 0.f, h2 = has_aff ? sh4.z : 0.f, h3 = has_aff ? sh4.w : 0.f;
 #pragma unroll
     for (int r = 0; r < QA; ++r) {
       const int row = (tid >> 2) + r * RPP;
-      Ab[(4 * aq + 0) * LDA + row] = ra[r].x;
-      Ab[(4 * aq + 1) * LDA + row] = ra[r].y;
-      Ab[(4 * aq + 2) * LDA + row] = ra[r].z;
-      Ab[(4 * aq + 3) * LDA + row] = ra[r].w;
+      const bool k0 = okA[r][0], k1 = okA[r][VEC ? 0 : 1], k2 = okA[r][VEC ? 0 : 2], k3 = okA[r][VEC ? 0 : 3];
+      Ab[(4 * aq + 0) * LDA + row] = k0 ? fmaf(ra[r].x, s0, h0) : 0.f;
+      Ab[(4 * aq + 1) * LDA + row] = k1 ? fmaf(ra[r].y, s1, h1) : 0.f;
+      Ab[(4 * aq + 2) * LDA + row] = k2 ? fmaf(ra[r].z, s2, h2) : 0.f;
+      Ab[(4 * aq + 3) * LDA + row] = k3 ? fmaf(ra[r].w, s3, h3) : 0.f;
     }
     float* Bb = Bs + buf * KC * LDB;
 #pragma unroll
@@ -172,7 +175,12 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_gemm_kernel(const ConvK p) {
       const int idx = tid + r * NT;
       if (idx < NQB) {
         const int krow = idx / BQ, nq = idx - krow * BQ;
-        *reinterpret_cast<float4*>(Bb + krow * LDB + 4 * nq) = rb[r];
+        float4 v;
+        v.x = okB[r][0] ? rb[r].x : 0.f;
+        v.y = okB[r][1] ? rb[r].y : 0.f;
+        v.z = okB[r][2] ? rb[r].z : 0.f;
+        v.w = okB[r][3] ? rb[r].w : 0.f;
+        *reinterpret_cast<float4*>(Bb + krow * LDB + 4 * nq) = v;
       }
     }
   };
@@ -186,14 +194,18 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_gemm_kernel(const ConvK p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nchunks = (Ktot + KC - 1) / KC;
-  load_A(0);
-  load_B(0);
-  store_AB(0);
+  const int ch_begin = blockIdx.z * p.cps;
+  const int ch_end = min(ch_begin + p.cps, nchunks);
+  if (ch_begin < ch_end) {
+    load_A(ch_begin * KC);
+    load_B(ch_begin * KC);
+    store_AB(0);
+  }
   __syncthreads();
 
-  for (int ch = 0; ch < nchunks; ++ch) {
-    const int buf = ch & 1;
-    const bool more = (ch + 1) < nchunks;
+  for (int ch = ch_begin; ch < ch_end; ++ch) {
+    const int buf = (ch - ch_begin) & 1;
+    const bool more = (ch + 1) < ch_end;
     if (more) {
       load_A((ch + 1) * KC);
       load_B((ch + 1) * KC);
@@ -215,6 +227,24 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_gemm_kernel(const ConvK p) {
     }
     if (more) store_AB(buf ^ 1);
     __syncthreads();
+  }
+
+  // ---- split-K: leave the raw partial sums, conv_finish_kernel applies the epilogue --------------------
+  if (p.splits > 1) {
+    float* part = a.partial + (int64_t)blockIdx.z * p.Mtot * Ntot;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * (TN * 32) + j * 32 + li;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * (TM * 32) + i * 32 + mfma32_row(r, lane);
+          if (n < Ntot && m < p.Mtot) part[(int64_t)m * Ntot + n] = acc[i][j][r];
+        }
+      }
+    }
+    return;
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------
@@ -299,6 +329,72 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_gemm_kernel(const ConvK p) {
   }
 }
 
+// Split-K finish: y = epilogue(sum_s partial[s]) with the same epilogue as above (bias, ReLU, + BN(other),
+// accumulate, NHWC / 2x2-scatter store, per-channel statistics per row block).  HBM-bound stream.
+__global__ void __launch_bounds__(256) conv_finish_kernel(const ConvK p, int TX, int rows_per_block) {
+  __shared__ float red[2][256];
+  const dfl_conv_args& a = p.a;
+  const int Ntot = a.Ntot;
+  const int TY = 256 / TX;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int n = blockIdx.y * TX + tx;
+  const bool nok = n < Ntot;
+  int co = n, ab = 0;
+  if (a.scatter2x2 && nok) {
+    ab = n / p.Cout;
+    co = n - ab * p.Cout;
+  }
+  const float bias = (a.bias != nullptr && nok) ? a.bias[co] : 0.f;
+  float asc = 1.f, ash = 0.f;
+  if (a.add != nullptr && a.add_scale != nullptr && nok) {
+    asc = a.add_scale[n];
+    ash = a.add_shift[n];
+  }
+  const int64_t slice = (int64_t)p.Mtot * Ntot;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(r0 + rows_per_block, p.Mtot);
+  float s1 = 0.f, s2 = 0.f;
+  if (nok) {
+    for (int m = r0 + ty; m < r1; m += TY) {
+      const float* pp = a.partial + (int64_t)m * Ntot + n;
+      float v = 0.f;
+      for (int s = 0; s < p.splits; ++s) v += pp[(int64_t)s * slice];
+      v += bias;
+      if (a.relu) v = fmaxf(v, 0.f);
+      if (a.add != nullptr) v += fmaf(a.add[(int64_t)m * a.ldadd + n], asc, ash);
+      float* dst;
+      if (a.scatter2x2) {
+        const int jx = m % p.Wg;
+        const int t = m / p.Wg;
+        const int iy = t % p.Hg;
+        const int ni = t / p.Hg;
+        const int64_t opix = ((int64_t)ni * a.Hout + 2 * iy + (ab >> 1)) * a.Wout + 2 * jx + (ab & 1);
+        dst = a.y + opix * a.ldy + co;
+      } else {
+        dst = a.y + (int64_t)m * a.ldy + n;
+      }
+      if (a.accumulate) v += *dst;
+      *dst = v;
+      const float u = (a.stat_other != nullptr) ? a.stat_other[(int64_t)m * a.ldso + n] : v;
+      s1 += v;
+      s2 = fmaf(v, u, s2);
+    }
+  }
+  if (a.stat_partials == nullptr) return;
+  red[0][threadIdx.x] = s1;
+  red[1][threadIdx.x] = s2;
+  __syncthreads();
+  if (ty == 0 && nok) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int y = 0; y < TY; ++y) {
+      t1 += red[0][y * TX + tx];
+      t2 += red[1][y * TX + tx];
+    }
+    a.stat_partials[((int64_t)blockIdx.x * 2 + 0) * Ntot + n] = t1;
+    a.stat_partials[((int64_t)blockIdx.x * 2 + 1) * Ntot + n] = t2;
+  }
+}
+
 // ---- host side -------------------------------------------------------------------------------------
 
 enum ConvCfg { CFG_128x128 = 0, CFG_128x64, CFG_256x32, CFG_64x64, CFG_32x64 };
@@ -313,25 +409,38 @@ static void cfg_tile(ConvCfg c, int* bm, int* bn) {
   }
 }
 
-// Largest tile that still gives the 256 CUs a few workgroups each; small problems take the small tiles.
-static ConvCfg pick_cfg(int64_t M, int Ntot) {
+// Largest tile that still gives the 256 CUs a few workgroups each.  Problems too small for that keep the 64x64 tile
+// and are cut along K instead (split-K, see pick_splits): deep U-Net levels are M = 576..2304 pixels x K = 4608..9216.
+static ConvCfg pick_cfg(int64_t M, int Ntot, bool vec = true) {
   const int64_t want = 1024;
+  if (!vec) return CFG_64x64;   // scalar-gather variant (Cin % 4 != 0: the network's first layer) exists for one tile only
   if (Ntot <= 32) {
     if (ceil_div(M, 256) >= want / 2) return CFG_256x32;
-    return (ceil_div(M, 64) >= 256) ? CFG_64x64 : CFG_32x64;
+    return (M > 32) ? CFG_64x64 : CFG_32x64;
   }
   if (Ntot >= 128 && ceil_div(M, 128) * ceil_div(Ntot, 128) >= want) return CFG_128x128;
   if (ceil_div(M, 128) * ceil_div(Ntot, 64) >= want) return CFG_128x64;
-  if (ceil_div(M, 64) * ceil_div(Ntot, 64) >= want) return CFG_64x64;
-  return CFG_32x64;
+  return (M > 32) ? CFG_64x64 : CFG_32x64;
 }
 
-template <int WM, int WN, int TM, int TN>
+static int pick_splits(int64_t M, int Ntot, int Ktot, ConvCfg cfg) {
+  int bm, bn;
+  cfg_tile(cfg, &bm, &bn);
+  const int64_t blocks = ceil_div(M, bm) * ceil_div(Ntot, bn);
+  const int nchunks = (int)ceil_div(Ktot, KC);
+  if (blocks >= 768 || nchunks < 16) return 1;
+  int64_t s = ceil_div(1024, blocks);
+  if (s > nchunks / 8) s = nchunks / 8;   // >= 128 of K per slice
+  if (s > 32) s = 32;
+  return s < 1 ? 1 : (int)s;
+}
+
+template <int WM, int WN, int TM, int TN, bool VEC>
 static int launch(const ConvK& k, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const size_t lds = (size_t)(2 * KC * (BM + 4) + 2 * KC * (BN + 4)) * sizeof(float);
-  dim3 grid((unsigned)ceil_div(k.Mtot, BM), (unsigned)ceil_div(k.a.Ntot, BN));
-  hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, TM, TN>), grid, dim3(WM * WN * 64), lds, s, k);
+  dim3 grid((unsigned)ceil_div(k.Mtot, BM), (unsigned)ceil_div(k.a.Ntot, BN), (unsigned)k.splits);
+  hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, TM, TN, VEC>), grid, dim3(WM * WN * 64), lds, s, k);
   return check_launch("dfl_conv2d");
 }
 
@@ -369,18 +478,43 @@ static int prepare(const dfl_conv_args* a, ConvK* k) {
   k->vecA = (a->Cin % 4 == 0) && (a->ldx % 4 == 0) && aligned16(a->x) &&
             (a->in_scale == nullptr || (aligned16(a->in_scale) && aligned16(a->in_shift)));
   k->vecB = (a->Ntot % 4 == 0) && aligned16(a->w);
+  k->splits = 1;
+  k->cps = (int)ceil_div(k->Ktot, KC);
   return DFL_OK;
 }
 
+static int finish_rows(int M, int Ntot) {   // row blocks of conv_finish_kernel (= rows of stat_partials in split mode)
+  int64_t nb = ceil_div((int64_t)M * Ntot, 16384);
+  if (nb > 1024) nb = 1024;
+  if (nb > M) nb = M;
+  return nb < 1 ? 1 : (int)nb;
+}
+
 }  // namespace dfl
+
+extern "C" int dfl_conv_suggest_splits(const dfl_conv_args* a) {
+  dfl::ConvK k;
+  int rc = dfl::prepare(a, &k);
+  if (rc != DFL_OK) return rc;
+  const bool vec = k.vecA && k.vecB;
+  return dfl::pick_splits(k.Mtot, a->Ntot, k.Ktot, dfl::pick_cfg(k.Mtot, a->Ntot, vec));
+}
 
 extern "C" int dfl_conv_grid_m(const dfl_conv_args* a) {
   dfl::ConvK k;
   int rc = dfl::prepare(a, &k);
   if (rc != DFL_OK) return rc;
+  if (a->splits > 1) return dfl::finish_rows(k.Mtot, a->Ntot);
   int bm, bn;
-  dfl::cfg_tile(dfl::pick_cfg(k.Mtot, a->Ntot), &bm, &bn);
+  dfl::cfg_tile(dfl::pick_cfg(k.Mtot, a->Ntot, k.vecA && k.vecB), &bm, &bn);
   return (int)dfl::ceil_div(k.Mtot, bm);
+}
+
+extern "C" int dfl_conv_config(const dfl_conv_args* a) {
+  dfl::ConvK k;
+  int rc = dfl::prepare(a, &k);
+  if (rc != DFL_OK) return rc;
+  return (int)dfl::pick_cfg(k.Mtot, a->Ntot, k.vecA && k.vecB);
 }
 
 extern "C" int dfl_conv2d(const dfl_conv_args* a, dfl_stream_t stream) {
@@ -388,11 +522,30 @@ extern "C" int dfl_conv2d(const dfl_conv_args* a, dfl_stream_t stream) {
   int rc = dfl::prepare(a, &k);
   if (rc != DFL_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  switch (dfl::pick_cfg(k.Mtot, a->Ntot)) {
-    case dfl::CFG_128x128: return dfl::launch<2, 2, 2, 2>(k, s);
-    case dfl::CFG_128x64: return dfl::launch<2, 2, 2, 1>(k, s);
-    case dfl::CFG_256x32: return dfl::launch<4, 1, 2, 1>(k, s);
-    case dfl::CFG_64x64: return dfl::launch<2, 2, 1, 1>(k, s);
-    default: return dfl::launch<1, 2, 1, 1>(k, s);
+  if (a->splits > 1) {
+    DFL_REQUIRE(a->partial != nullptr, "dfl_conv2d: splits > 1 needs the partial buffer");
+    const int nchunks = (int)dfl::ceil_div(k.Ktot, dfl::KC);
+    DFL_REQUIRE(a->splits <= nchunks, "dfl_conv2d: more splits than K chunks");
+    k.splits = a->splits;
+    k.cps = (int)dfl::ceil_div(nchunks, a->splits);
   }
+  if (!(k.vecA && k.vecB)) {
+    rc = dfl::launch<2, 2, 1, 1, false>(k, s);
+  } else {
+    switch (dfl::pick_cfg(k.Mtot, a->Ntot)) {
+      case dfl::CFG_128x128: rc = dfl::launch<2, 2, 2, 2, true>(k, s); break;
+      case dfl::CFG_128x64: rc = dfl::launch<2, 2, 2, 1, true>(k, s); break;
+      case dfl::CFG_256x32: rc = dfl::launch<4, 1, 2, 1, true>(k, s); break;
+      case dfl::CFG_64x64: rc = dfl::launch<2, 2, 1, 1, true>(k, s); break;
+      default: rc = dfl::launch<1, 2, 1, 1, true>(k, s); break;
+    }
+  }
+  if (rc != DFL_OK || k.splits <= 1) return rc;
+  int tx = 1;
+  while (tx * 2 <= a->Ntot && tx * 2 <= 256) tx *= 2;
+  const int nb = dfl::finish_rows(k.Mtot, a->Ntot);
+  const int rpb = (int)dfl::ceil_div(k.Mtot, nb);
+  dim3 grid((unsigned)nb, (unsigned)dfl::ceil_div(a->Ntot, tx));
+  hipLaunchKernelGGL(dfl::conv_finish_kernel, grid, dim3(256), 0, s, k, tx, rpb);
+  return dfl::check_launch("dfl_conv2d (split-K finish)");
 }

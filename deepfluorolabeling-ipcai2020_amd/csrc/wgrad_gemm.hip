@@ -21,7 +21,7 @@ struct WgK {
   int vecG, vecD;
 };
 
-template <int WM, int WN, int TM, int TN, int TPB>
+template <int WM, int WN, int TM, int TN, int TPB, bool VEC>
 __global__ void __launch_bounds__(WM* WN * 64) wgrad_kernel(const WgK p) {
   constexpr int NT = WM * WN * 64;
   constexpr int BMc = WM * TM * 32, BNg = WN * TN * 32;
@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_kernel(const WgK p) {
   const int gc = cg0 + 4 * gq;
   float4 gsc = make_float4(1.f, 1.f, 1.f, 1.f), gsh = make_float4(0.f, 0.f, 0.f, 0.f);
   if (a.in_scale != nullptr) {
-    if (p.vecG) {
+    if (VEC) {
       if (gc < a.Cg) {
         gsc = *reinterpret_cast<const float4*>(a.in_scale + gc);
         gsh = *reinterpret_cast<const float4*>(a.in_shift + gc);
@@ -73,28 +73,31 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_kernel(const WgK p) {
   float4 rd[QD];
   float4 rg[TPB][QG];
 
+  // Unconditional loads from clamped addresses; selects / affine / LDS writes are deferred to store() so that the
+  // waits land behind the MFMA block (see the note in conv_gemm.hip).
+  bool okD[QD][4];
+  bool okG[TPB][QG];
+  const bool g1 = gc + 1 < a.Cg, g2 = gc + 2 < a.Cg, g3 = gc + 3 < a.Cg;
+
   auto load = [&](int ch) {
     const int mc0 = ch * KP;
 #pragma unroll
     for (int r = 0; r < QD; ++r) {
       const int idx = tid + r * NT;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx < NQD) {
-        const int pix = idx / DQ, q = idx - pix * DQ;
-        const int m = mc0 + pix, c = cm0 + 4 * q;
-        if (m < p.Mtot && c < a.Cm) {
-          const float* src = a.d + (int64_t)m * a.ldd + c;
-          if (p.vecD) {
-            v = *reinterpret_cast<const float4*>(src);
-          } else {
-            v.x = src[0];
-            if (c + 1 < a.Cm) v.y = src[1];
-            if (c + 2 < a.Cm) v.z = src[2];
-            if (c + 3 < a.Cm) v.w = src[3];
-          }
-        }
+      const int pix = idx / DQ, q = idx - pix * DQ;
+      const int m = mc0 + pix, c = cm0 + 4 * q;
+      const bool ok = (idx < NQD) && (m < p.Mtot) && (c < a.Cm);
+      const float* src = a.d + (ok ? ((int64_t)m * a.ldd + c) : 0);
+      if constexpr (VEC) {
+        okD[r][0] = okD[r][1] = okD[r][2] = okD[r][3] = ok;
+        rd[r] = *reinterpret_cast<const float4*>(src);
+      } else {
+        okD[r][0] = ok;
+        okD[r][1] = ok && (c + 1 < a.Cm);
+        okD[r][2] = ok && (c + 2 < a.Cm);
+        okD[r][3] = ok && (c + 3 < a.Cm);
+        rd[r] = make_float4(src[0], src[okD[r][1] ? 1 : 0], src[okD[r][2] ? 2 : 0], src[okD[r][3] ? 3 : 0]);
       }
-      rd[r] = v;
     }
 #pragma unroll
     for (int r = 0; r < QG; ++r) {
@@ -102,38 +105,27 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_kernel(const WgK p) {
       const int pix = idx / GQ;
       const int m = mc0 + pix;
       const bool ok = (idx < NQG) && (m < p.Mtot) && (gc < a.Cg);
-      int iy0 = 0, ix0 = 0, base = 0;
-      if (ok) {
-        const int ox = m % a.Wout;
-        const int t = m / a.Wout;
-        const int oy = t % a.Hout;
-        const int n = t / a.Hout;
-        iy0 = oy * a.stride - a.pad;
-        ix0 = ox * a.stride - a.pad;
-        base = n * Hin * Win;
-      }
+      const int mm = ok ? m : 0;
+      const int ox = mm % a.Wout;
+      const int tq = mm / a.Wout;
+      const int oy = tq % a.Hout;
+      const int n = tq / a.Hout;
+      const int iy0 = oy * a.stride - a.pad;
+      const int ix0 = ox * a.stride - a.pad;
+      const int base = n * Hin * Win;
 #pragma unroll
       for (int tt = 0; tt < TPB; ++tt) {
         const int t = (TPB == 1) ? tap0 : tt;
         const int dy = t / KW, dx = t - dy * KW;
         const int iy = iy0 + dy, ix = ix0 + dx;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win) {
-          const float* src = a.g + ((int64_t)base + (int64_t)iy * Win + ix) * a.ldg + gc;
-          if (p.vecG) {
-            v = *reinterpret_cast<const float4*>(src);
-            v.x = fmaf(v.x, gsc.x, gsh.x);
-            v.y = fmaf(v.y, gsc.y, gsh.y);
-            v.z = fmaf(v.z, gsc.z, gsh.z);
-            v.w = fmaf(v.w, gsc.w, gsh.w);
-          } else {
-            v.x = fmaf(src[0], gsc.x, gsh.x);
-            if (gc + 1 < a.Cg) v.y = fmaf(src[1], gsc.y, gsh.y);
-            if (gc + 2 < a.Cg) v.z = fmaf(src[2], gsc.z, gsh.z);
-            if (gc + 3 < a.Cg) v.w = fmaf(src[3], gsc.w, gsh.w);
-          }
+        const bool in = ok && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
+        const float* src = a.g + (in ? (((int64_t)base + (int64_t)iy * Win + ix) * a.ldg + gc) : 0);
+        okG[tt][r] = in;
+        if constexpr (VEC) {
+          rg[tt][r] = *reinterpret_cast<const float4*>(src);
+        } else {
+          rg[tt][r] = make_float4(src[0], src[(in && g1) ? 1 : 0], src[(in && g2) ? 2 : 0], src[(in && g3) ? 3 : 0]);
         }
-        rg[tt][r] = v;
       }
     }
   };
@@ -145,7 +137,12 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_kernel(const WgK p) {
       const int idx = tid + r * NT;
       if (idx < NQD) {
         const int pix = idx / DQ, q = idx - pix * DQ;
-        *reinterpret_cast<float4*>(Db + pix * LDD + 4 * q) = rd[r];
+        float4 v;
+        v.x = okD[r][0] ? rd[r].x : 0.f;
+        v.y = okD[r][1] ? rd[r].y : 0.f;
+        v.z = okD[r][2] ? rd[r].z : 0.f;
+        v.w = okD[r][3] ? rd[r].w : 0.f;
+        *reinterpret_cast<float4*>(Db + pix * LDD + 4 * q) = v;
       }
     }
     float* Gb = Gs + buf * TPB * KP * LDG;
@@ -155,8 +152,15 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_kernel(const WgK p) {
       if (idx < NQG) {
         const int pix = idx / GQ;
 #pragma unroll
-        for (int tt = 0; tt < TPB; ++tt)
-          *reinterpret_cast<float4*>(Gb + (tt * KP + pix) * LDG + 4 * gq) = rg[tt][r];
+        for (int tt = 0; tt < TPB; ++tt) {
+          const bool in = okG[tt][r];
+          float4 v;
+          v.x = in ? fmaf(rg[tt][r].x, gsc.x, gsh.x) : 0.f;
+          v.y = (in && (VEC || g1)) ? fmaf(rg[tt][r].y, gsc.y, gsh.y) : 0.f;
+          v.z = (in && (VEC || g2)) ? fmaf(rg[tt][r].z, gsc.z, gsh.z) : 0.f;
+          v.w = (in && (VEC || g3)) ? fmaf(rg[tt][r].w, gsc.w, gsh.w) : 0.f;
+          *reinterpret_cast<float4*>(Gb + (tt * KP + pix) * LDG + 4 * gq) = v;
+        }
       }
     }
   };
@@ -231,12 +235,38 @@ __global__ void sum_partials_kernel(const float* __restrict__ src, float* __rest
   }
 }
 
+// Many slices of a small tensor (narrow layers cut the pixel range into ~1000 slices): 16 outputs x 16 slice lanes per
+// workgroup, 8 independent loads in flight per thread, LDS tree over the lanes.  Same summation order every run.
+__global__ void __launch_bounds__(256) sum_partials_wide_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                                int64_t n, int splits) {
+  __shared__ float red[16][17];
+  const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int64_t i = (int64_t)blockIdx.x * 16 + o;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (i < n) {
+    int k = sl;
+    for (; k + 7 * 16 < splits; k += 8 * 16) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += src[(int64_t)(k + u * 16) * n + i];
+    }
+    for (; k < splits; k += 16) acc[0] += src[(int64_t)k * n + i];
+  }
+  red[sl][o] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (sl == 0 && i < n) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += red[j][o];
+    dst[i] = s;
+  }
+}
+
 // ---- host side -------------------------------------------------------------------------------------
 enum WgCfg { WG_128 = 0, WG_64, WG_TAPS9, WG_TAPS4, WG_32 };
 
-static WgCfg pick_wg(const dfl_wgrad_args* a) {
+static WgCfg pick_wg(const dfl_wgrad_args* a, bool vec = true) {
   const int T = a->KH * a->KW;
-  const bool narrow = (a->Cm <= 64 || a->Cg <= 64);
+  const bool narrow = (a->Cm <= 64 || a->Cg <= 64) || !vec;   // the scalar-load variants exist for the narrow tiles only
   if (narrow) {
     if (T == 9) return WG_TAPS9;
     if (T == 4) return WG_TAPS4;
@@ -284,13 +314,13 @@ static int wg_prepare(const dfl_wgrad_args* a, WgK* k, bool need_out) {
   return DFL_OK;
 }
 
-template <int WM, int WN, int TM, int TN, int TPB>
+template <int WM, int WN, int TM, int TN, int TPB, bool VEC>
 static int wg_launch(const WgK& k, hipStream_t s) {
   constexpr int BMc = WM * TM * 32, BNg = WN * TN * 32;
   const size_t lds = (size_t)(2 * KP * (BMc + 4) + 2 * TPB * KP * (BNg + 4)) * sizeof(float);
   const int tiles_g = (int)ceil_div(k.a.Cg, BNg);
   dim3 grid((unsigned)ceil_div(k.a.Cm, BMc), (unsigned)(tiles_g * (TPB == 1 ? k.T : 1)), (unsigned)k.a.splits);
-  hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, TPB>), grid, dim3(WM * WN * 64), lds, s, k);
+  hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, TPB, VEC>), grid, dim3(WM * WN * 64), lds, s, k);
   return check_launch("dfl_conv2d_wgrad");
 }
 
@@ -301,7 +331,7 @@ extern "C" int dfl_wgrad_suggest_splits(const dfl_wgrad_args* a) {
   int rc = dfl::wg_prepare(a, &k, false);
   if (rc != DFL_OK) return rc;
   int bm, bn, tpb;
-  dfl::wg_tile(dfl::pick_wg(a), &bm, &bn, &tpb);
+  dfl::wg_tile(dfl::pick_wg(a, k.vecG && k.vecD), &bm, &bn, &tpb);
   const int64_t blocks = dfl::ceil_div(a->Cm, bm) * dfl::ceil_div(a->Cg, bn) * (tpb == 1 ? k.T : 1);
   int64_t s = dfl::ceil_div(1536, blocks);
   const int64_t max_by_work = k.nchunks / 8 > 0 ? k.nchunks / 8 : 1;  // >= 128 pixels per slice
@@ -311,24 +341,37 @@ extern "C" int dfl_wgrad_suggest_splits(const dfl_wgrad_args* a) {
   return (int)s;
 }
 
+extern "C" int dfl_wgrad_config(const dfl_wgrad_args* a) {
+  dfl::WgK k;
+  int rc = dfl::wg_prepare(a, &k, false);
+  if (rc != DFL_OK) return rc;
+  return (int)dfl::pick_wg(a, k.vecG && k.vecD);
+}
+
 extern "C" int dfl_conv2d_wgrad(const dfl_wgrad_args* a, dfl_stream_t stream) {
   dfl::WgK k;
   int rc = dfl::wg_prepare(a, &k, true);
   if (rc != DFL_OK) return rc;
   k.cps = (int)dfl::ceil_div(k.nchunks, a->splits);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  switch (dfl::pick_wg(a)) {
-    case dfl::WG_128: return dfl::wg_launch<2, 2, 2, 2, 1>(k, s);
-    case dfl::WG_64: return dfl::wg_launch<2, 2, 1, 1, 1>(k, s);
-    case dfl::WG_TAPS9: return dfl::wg_launch<1, 1, 1, 1, 9>(k, s);
-    case dfl::WG_TAPS4: return dfl::wg_launch<1, 1, 1, 1, 4>(k, s);
-    default: return dfl::wg_launch<1, 1, 1, 1, 1>(k, s);
+  const bool vec = k.vecG && k.vecD;
+  switch (dfl::pick_wg(a, vec)) {
+    case dfl::WG_128: return dfl::wg_launch<2, 2, 2, 2, 1, true>(k, s);
+    case dfl::WG_64: return dfl::wg_launch<2, 2, 1, 1, 1, true>(k, s);
+    case dfl::WG_TAPS9: return vec ? dfl::wg_launch<1, 1, 1, 1, 9, true>(k, s) : dfl::wg_launch<1, 1, 1, 1, 9, false>(k, s);
+    case dfl::WG_TAPS4: return vec ? dfl::wg_launch<1, 1, 1, 1, 4, true>(k, s) : dfl::wg_launch<1, 1, 1, 1, 4, false>(k, s);
+    default: return vec ? dfl::wg_launch<1, 1, 1, 1, 1, true>(k, s) : dfl::wg_launch<1, 1, 1, 1, 1, false>(k, s);
   }
 }
 
 extern "C" int dfl_sum_partials(const float* src, float* dst, int64_t n, int32_t splits, dfl_stream_t stream) {
   DFL_REQUIRE(src && dst && n >= 0 && splits >= 1, "dfl_sum_partials: bad args");
   if (n == 0) return DFL_OK;
+  if (splits >= 32 && n <= (1 << 20)) {
+    hipLaunchKernelGGL(dfl::sum_partials_wide_kernel, dim3((unsigned)dfl::ceil_div(n, 16)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), src, dst, n, (int)splits);
+    return dfl::check_launch("dfl_sum_partials");
+  }
   int64_t blocks = dfl::ceil_div(n, 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(dfl::sum_partials_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),

@@ -1,0 +1,139 @@
+"""Data-parallel training over the GPUs of one node: one process per GPU, RCCL (torch.distributed backend "nccl")
+gradient all-reduce over xGMI.
+
+The reference has no distributed code; this is the north-star extension: every rank runs the same
+U-Net on its shard of the minibatch and the parameter gradients are averaged.  Both losses are means over per-image
+terms, so the averaged gradients equal those of the global batch; BatchNorm statistics stay per replica (= the
+reference run at the per-replica batch size).
+
+Mechanics: the backward program writes every parameter gradient into one flat fp32 arena (plan.grad_flat).  The
+program is cut into segments at bucket boundaries; after each segment an event is recorded and the bucket's slice of
+the arena is all-reduced on a side stream while the next segment's kernels run, i.e. communication of the decoder /
+deep-encoder gradients overlaps the remaining backward convolutions.  The parameter created but never used by the
+reference (downsample_convs[depth-1]) has no gradient and is skipped.
+"""
+import torch
+import torch.distributed as dist
+
+__all__ = ['DataParallel', 'init_process_group_from_env']
+
+
+def init_process_group_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract)."""
+    import os
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def bucket_ranges(offsets, sizes, order, dead, bucket_elems):
+    """Greedy contiguous buckets over the flat arena.  ``order``: parameter names in the order their gradients become
+    final during backward.  Returns a list of (ready_after_name, [(start, stop), ...]) -- the element ranges to
+    reduce once ``ready_after_name``'s gradient has been written."""
+    buckets, cur, cur_n, last = [], [], 0, None
+    for name in order:
+        if name in dead:
+            continue
+        s = offsets[name]
+        cur.append((s, s + sizes[name]))
+        cur_n += sizes[name]
+        last = name
+        if cur_n >= bucket_elems:
+            buckets.append((last, merge_ranges(cur)))
+            cur, cur_n = [], 0
+    if cur:
+        buckets.append((last, merge_ranges(cur)))
+    return buckets
+
+
+def merge_ranges(ranges, align=4):
+    """Merge element ranges that touch (allowing for the <=3-element alignment gaps of the arena)."""
+    out = []
+    for s, e in sorted(ranges):
+        if out and s - out[-1][1] < align:
+            out[-1] = (out[-1][0], max(out[-1][1], e))
+        else:
+            out.append((s, e))
+    return out
+
+
+class DataParallel:
+    """Wraps a dfl_amd.UNet for data-parallel training.  Usage::
+
+        net = UNet(...).to(dev); dp = DataParallel(net)      # broadcasts rank 0's parameters and buffers
+        out = net(x_shard); loss.backward()                   # gradients arrive averaged over ranks
+    """
+
+    def __init__(self, net, process_group=None, bucket_mb=32.0, overlap=True):
+        self.net = net
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
+        self.overlap = overlap
+        self._seg_cache = {}
+        self.comm_stream = None
+        if self.world > 1:
+            with torch.no_grad():
+                for t in list(net.parameters()) + list(net.buffers()):
+                    dist.broadcast(t, src=0, group=process_group)
+        net._backward_runner = self._run_backward
+        net.dp = self
+
+    # -------------------------------------------------------------------------------------------------------
+    def _segments(self, plan):
+        """[(op_start, op_count, [(start, stop), ...])]: run ops, then reduce those arena ranges."""
+        key = id(plan)
+        seg = self._seg_cache.get(key)
+        if seg is not None:
+            return seg
+        ready = plan.grad_ready_op            # name -> index of the last op that writes this gradient
+        sizes = {k: plan.P[k].numel() for k in plan.grad_names}
+        order = sorted((k for k in plan.grad_names if k not in plan.dead_params), key=lambda k: ready[k])
+        buckets = bucket_ranges(plan.grad_offsets, sizes, order, plan.dead_params, self.bucket_elems)
+        seg, start = [], 0
+        for last_name, ranges in buckets:
+            stop = ready[last_name] + 1
+            seg.append((start, stop - start, ranges))
+            start = stop
+        n_ops = len(plan.bwd)
+        if start < n_ops:
+            seg.append((start, n_ops - start, []))
+        self._seg_cache[key] = seg
+        return seg
+
+    def _run_backward(self, plan, stream):
+        if self.world == 1:
+            plan.bwd.run(stream)
+            return
+        flat = plan.grad_flat
+        inv = 1.0 / self.world
+        if not self.overlap or not flat.is_cuda:
+            plan.bwd.run(stream)
+            for _, _, ranges in self._segments(plan):
+                for s, e in ranges:
+                    dist.all_reduce(flat[s:e], group=self.group)
+            flat.mul_(inv)
+            return
+        cur = torch.cuda.current_stream()
+        if self.comm_stream is None:
+            self.comm_stream = torch.cuda.Stream()
+        comm = self.comm_stream
+        for op_start, op_count, ranges in self._segments(plan):
+            plan.bwd.run(stream, op_start, op_count)
+            if ranges:
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                with torch.cuda.stream(comm):
+                    comm.wait_event(ev)
+                    for s, e in ranges:
+                        view = flat[s:e]
+                        dist.all_reduce(view, group=self.group)
+                        view.mul_(inv)
+        cur.wait_stream(comm)

@@ -145,6 +145,11 @@ class UNetPlan:
         a.Hout, a.Wout = (y.H, y.W) if Hout is None else (Hout, Wout)
         a.Ntot, a.ldy = Ntot, y.ld
         a.relu, a.accumulate, a.scatter2x2 = relu, accumulate, scatter
+        sp = nat.check(self.lib.dfl_conv_suggest_splits(C.addressof(a)), 'dfl_conv_suggest_splits')
+        if sp > 1:
+            M = x.N * (x.H * x.W if scatter else a.Hout * a.Wout)
+            a.splits = sp
+            a.partial = self._shared_scratch('conv_partial', sp * M * Ntot).data_ptr()
         partials = None
         if stats:
             gm = nat.check(self.lib.dfl_conv_grid_m(C.addressof(a)), 'dfl_conv_grid_m')
@@ -175,6 +180,13 @@ class UNetPlan:
             prog.add(SumPartialsArgs(src=part.data_ptr(), dst=dw.data_ptr(), n=n, splits=s))
         else:
             prog.add(a)
+
+    def _shared_scratch(self, key, nelem):
+        t = self._scratch.get(key)
+        if t is None or t.numel() < nelem:
+            t = self._new(nelem)
+            self._scratch[key] = t
+        return t
 
     def _wg_partial(self, nelem):
         t = self._scratch.get('wg_partial')
@@ -448,7 +460,7 @@ class UNetPlan:
         for k in self.grad_names:
             offs[k] = tot
             tot += (self.P[k].numel() + 3) // 4 * 4          # keep every slice 16-byte aligned
-        self.grad_flat = self._new(tot)
+        self.grad_flat = self._new(tot).zero_()
         self.G = {k: self.grad_flat[offs[k]:offs[k] + self.P[k].numel()].view(self.P[k].shape) for k in self.grad_names}
         self.grad_offsets = offs
         self.dead_params = set()
@@ -527,6 +539,14 @@ class UNetPlan:
                 dxin = None
             rec['block_bw'](dout, dxin)
         self._finish_pack()
+        # index of the last backward op that writes each parameter gradient (data-parallel bucket scheduling)
+        by_ptr = {self.G[k].data_ptr(): k for k in self.grad_names}
+        self.grad_ready_op = {}
+        for idx, st in enumerate(bwd.structs):
+            for field in ('dw', 'dst', 'out', 'dgamma', 'dbeta'):
+                name = by_ptr.get(getattr(st, field, None))
+                if name is not None:
+                    self.grad_ready_op[name] = idx
 
     # ------------------------------------------------------------------------------------------ run
     def run_pack(self, stream, forward_only=False):

@@ -72,6 +72,7 @@ typedef struct {
   const float* stat_other; /* [M][ldso] or NULL (=> u = v) */
   float* y;              /* output, NHWC, pixel stride ldy */
   float* stat_partials;  /* [gridM][2][Ntot] or NULL; gridM = dfl_conv_grid_m(args) */
+  float* partial;        /* split-K scratch [splits][M][Ntot], required when splits > 1 */
   int32_t N, Hin, Win, Cin, ldx;
   int32_t KH, KW, stride, pad;
   int32_t Hout, Wout, Ntot, ldy;
@@ -80,12 +81,16 @@ typedef struct {
   int32_t accumulate;
   int32_t scatter2x2;    /* ConvTranspose2d(k2,s2): Ntot = 4*Cout, column ab*Cout+co of input pixel (i,j) is stored
                             at output pixel (2i + ab/2, 2j + ab%2) of an [N, Hout, Wout] image, channel co */
-  int32_t reserved;
+  int32_t splits;        /* 0/1: one pass.  > 1: K is cut into `splits` slices (small-M, long-K layers of the deep
+                            U-Net levels), raw sums go to `partial` and a finish kernel applies the epilogue */
 } dfl_conv_args;
 
 int dfl_conv2d(const dfl_conv_args* a, dfl_stream_t stream);
-/* Number of row blocks dfl_conv2d will launch for these args (= first dim of stat_partials). */
+/* Number of row blocks whose statistics dfl_conv2d will write for these args (= first dim of stat_partials);
+ * depends on a->splits, so set that first. */
 int dfl_conv_grid_m(const dfl_conv_args* a);
+/* Suggested split-K factor for these args (>= 1); the caller sizes `partial` as splits*M*Ntot floats. */
+int dfl_conv_suggest_splits(const dfl_conv_args* a);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Weight gradient of the same family of layers (torch autograd of unet.py:93,207,211,218,240):
@@ -346,6 +351,13 @@ typedef struct {
 } dfl_op;
 
 int dfl_exec(const dfl_op* ops, int32_t n_ops, dfl_stream_t stream);
+/* Same, with a hipEvent pair recorded on `stream` around every op; blocks until done and returns the per-op
+ * milliseconds in ms_out[n_ops].  Measurement aid for bench.py (roofline.achieved); not used on the timed path. */
+int dfl_exec_timed(const dfl_op* ops, int32_t n_ops, dfl_stream_t stream, float* ms_out);
+/* Tile configuration the launcher picks for these arguments (index into the instantiation tables documented in
+ * csrc/conv_gemm.hip / csrc/wgrad_gemm.hip); lets a profile be matched to kernel template names. */
+int dfl_conv_config(const dfl_conv_args* a);
+int dfl_wgrad_config(const dfl_wgrad_args* a);
 
 #ifdef __cplusplus
 }

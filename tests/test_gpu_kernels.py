@@ -41,7 +41,8 @@ def pack(src, D, s, off=0):
 
 
 def conv_call(x, wp, Ntot, KH, KW, stride, pad, Hout, Wout, bias=None, in_aff=None, relu=0, add=None, add_aff=None,
-              y_init=None, accumulate=0, scatter=0, stats=False, stat_other=None, ldy=None, ldx_pad=0):
+              y_init=None, accumulate=0, scatter=0, stats=False, stat_other=None, ldy=None, ldx_pad=0,
+              force_splits=None):
     """x: NCHW cpu tensor -> runs dfl_conv2d -> returns y as NHWC cpu tensor [N,Hout,Wout,Cout] (+ stats)."""
     lib = nat.lib()
     N, Cin, Hin, Win = x.shape
@@ -80,6 +81,12 @@ def conv_call(x, wp, Ntot, KH, KW, stride, pad, Hout, Wout, bias=None, in_aff=No
     a.KH, a.KW, a.stride, a.pad = KH, KW, stride, pad
     a.Hout, a.Wout, a.Ntot, a.ldy = Hout, Wout, Ntot, ldy
     a.relu, a.accumulate, a.scatter2x2 = relu, accumulate, scatter
+    sp = force_splits or nat.check(lib.dfl_conv_suggest_splits(C.addressof(a)))
+    if sp > 1:
+        Mrows = N * (Hin * Win if scatter else Hout * Wout)
+        kpart = torch.full((sp * Mrows * Ntot,), float('nan'), device=DEV)
+        keep.append(kpart)
+        a.splits, a.partial = sp, kpart.data_ptr()
     part = None
     if stats:
         gm = nat.check(lib.dfl_conv_grid_m(C.addressof(a)))
@@ -158,6 +165,42 @@ def test_conv_fwd_fused_epilogue_and_prologue():
     y3, st3 = conv_call(x, wp, Cout, 3, 3, 1, 1, H, W, y_init=y0, accumulate=1, stats=True, stat_other=other)
     np.testing.assert_allclose(nchw(y3).numpy(), ref3.numpy(), rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(st3[1].numpy(), (ref3 * other.double()).sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
+
+
+def test_conv_split_k():
+    """Deep-level shape (few pixels, long K): split-K partial sums + finish kernel with the full epilogue."""
+    g = torch.Generator().manual_seed(8)
+    N, Cin, Cout, H, W = 2, 256, 128, 6, 6
+    x = torch.randn(N, Cin, H, W, generator=g)
+    sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / 48
+    b = torch.randn(Cout, generator=g)
+    wp = pack(w, (9, Cin, Cout), (1, 9, Cin * 9))
+    xa = x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+    ref = F.relu(F.conv2d(xa, w.double(), b.double(), padding=1))
+    for fs in (None, 2, 7):
+        y, st = conv_call(x, wp, Cout, 3, 3, 1, 1, H, W, bias=b, in_aff=(sc, sh), relu=1, stats=True, force_splits=fs)
+        np.testing.assert_allclose(nchw(y).numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(st[0].numpy(), ref.sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
+        np.testing.assert_allclose(st[1].numpy(), (ref * ref).sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
+    # residual-add + accumulate + statistics against another tensor through the finish kernel
+    r = torch.randn(N, Cout, H, W, generator=g)
+    s2, t2 = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    y0 = torch.randn(N, Cout, H, W, generator=g)
+    other = torch.randn(N, Cout, H, W, generator=g)
+    ref2 = F.conv2d(x.double(), w.double(), b.double(), padding=1) + r.double() * s2.double().view(1, -1, 1, 1) \
+        + t2.double().view(1, -1, 1, 1) + y0.double()
+    y2, st2 = conv_call(x, wp, Cout, 3, 3, 1, 1, H, W, bias=b, add=r, add_aff=(s2, t2), y_init=y0, accumulate=1, stats=True,
+                        stat_other=other, force_splits=4)
+    np.testing.assert_allclose(nchw(y2).numpy(), ref2.numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(st2[1].numpy(), (ref2 * other.double()).sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
+    # transposed conv through split-K
+    wt = torch.randn(Cin, 64, 2, 2, generator=g) / 16
+    bt = torch.randn(64, generator=g)
+    wtp = pack(wt, (Cin, 4, 64), (64 * 4, 1, 4))
+    reft = F.conv_transpose2d(x.double(), wt.double(), bt.double(), stride=2)
+    yt = conv_call(x, wtp, 4 * 64, 1, 1, 1, 0, 2 * H, 2 * W, bias=bt, scatter=1, force_splits=2)
+    np.testing.assert_allclose(nchw(yt).numpy(), reft.numpy(), rtol=2e-5, atol=2e-5)
 
 
 @pytest.mark.parametrize('shape', [(2, 16, 8, 5, 7), (1, 64, 32, 6, 6), (2, 8, 4, 3, 3)])
