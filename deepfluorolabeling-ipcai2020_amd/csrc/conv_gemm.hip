@@ -29,8 +29,13 @@ struct ConvK {
   int splits, cps;   // split-K: number of K slices and chunks per slice
 };
 
+// Second launch-bound = waves per SIMD the register allocation must leave room for.  It is chosen per tile so that the
+// U-Net layer sizes fit in whole "rounds" of resident workgroups (e.g. level 1: 1152 tiles of 128x64 need 5 per CU to
+// run in one round; at 4 per CU the kernel takes two rounds at 56 % slot use).
+constexpr int conv_occ(int tiles) { return tiles >= 4 ? 2 : (tiles == 2 ? 5 : 6); }
+
 template <int WM, int WN, int TM, int TN, bool VEC>
-__global__ void __launch_bounds__(WM* WN * 64) conv_gemm_kernel(const ConvK p) {
+__global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kernel(const ConvK p) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int LDA = BM + 4, LDB = BN + 4;
@@ -73,6 +78,37 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_gemm_kernel(const ConvK p) {
       a_base[r] = 0;
     }
   }
+  // Vector path: the per-chunk address work is reduced to a bit test and one 64-bit add per row.  For every gather row
+  // keep a pointer to "tap (0,0), channel 0" (may lie outside the image; only dereferenced when the tap is valid) and a
+  // bit mask of the taps that fall inside the image; the (tap, channel) cursor of this thread's k-quad advances by KC
+  // per chunk without divisions.  (VALU instructions issued around the MFMA block are what separates this kernel from
+  // its MFMA-only skeleton: tools/exp/exp_mfma.cpp measures 113-125 TFLOP/s for the skeleton with plain loads.)
+  int64_t a_rowoff[QA];
+  uint32_t a_mask[QA];
+#pragma unroll
+  for (int r = 0; r < QA; ++r) {
+    a_rowoff[r] = ((int64_t)a_base[r] + (int64_t)a_iy0[r] * Win + a_ix0[r]) * a.ldx;
+    uint32_t mk = 0;
+    int ty = 0, tx = 0;
+    for (int t = 0; t < a.KH * KW; ++t) {
+      if ((unsigned)(a_iy0[r] + ty) < (unsigned)Hin && (unsigned)(a_ix0[r] + tx) < (unsigned)Win) mk |= (1u << t);
+      if (++tx == KW) {
+        tx = 0;
+        ++ty;
+      }
+    }
+    a_mask[r] = mk;
+  }
+  const int T = a.KH * KW;
+  // cursor of this thread's quad: k = tap * Cin + c
+  int cur_tap, cur_c, cur_dy, cur_dx;
+  {
+    const int k0 = (int)blockIdx.z * p.cps * KC + 4 * aq;
+    cur_tap = k0 / Cin;
+    cur_c = k0 - cur_tap * Cin;
+    cur_dy = cur_tap / KW;
+    cur_dx = cur_tap - cur_dy * KW;
+  }
 
   float4 ra[QA];
   float4 rb[QB];
@@ -94,19 +130,27 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_gemm_kernel(const ConvK p) {
   auto load_A = [&](int kc0) {
     const int k = kc0 + 4 * aq;
     if constexpr (VEC) {
-      const bool kvalid = k < Ktot;
-      const int t = kvalid ? k / Cin : 0;
-      const int c = kvalid ? k - t * Cin : 0;
-      const int dy = t / KW, dx = t - dy * KW;
+      // uses and advances the (tap, channel) cursor: must be called once per chunk, in order
+      const bool kvalid = cur_tap < T;
+      const int c = kvalid ? cur_c : 0;
+      const uint32_t bit = kvalid ? (1u << cur_tap) : 0u;
+      const int64_t tapoff = ((int64_t)cur_dy * Win + cur_dx) * a.ldx + c;
       sc4 = *reinterpret_cast<const float4*>(aff_sc + (has_aff ? c : 0));
       sh4 = *reinterpret_cast<const float4*>(aff_sh + (has_aff ? c : 0));
 #pragma unroll
       for (int r = 0; r < QA; ++r) {
-        const int iy = a_iy0[r] + dy, ix = a_ix0[r] + dx;
-        const bool ok = kvalid && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
-        const int64_t pix = ok ? ((int64_t)a_base[r] + (int64_t)iy * Win + ix) : 0;
+        const bool ok = (a_mask[r] & bit) != 0;
         okA[r][0] = ok;
-        ra[r] = *reinterpret_cast<const float4*>(a.x + pix * a.ldx + (ok ? c : 0));
+        ra[r] = *reinterpret_cast<const float4*>(a.x + (ok ? a_rowoff[r] + tapoff : 0));
+      }
+      cur_c += KC;
+      while (cur_c >= Cin) {
+        cur_c -= Cin;
+        ++cur_tap;
+        if (++cur_dx == KW) {
+          cur_dx = 0;
+          ++cur_dy;
+        }
       }
     } else {
       float vals[QA][4], scv[4], shv[4];
@@ -210,6 +254,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_gemm_kernel(const ConvK p) {
       load_A((ch + 1) * KC);
       load_B((ch + 1) * KC);
     }
+    __builtin_amdgcn_sched_barrier(0);
     const float* Ab = As + buf * KC * LDA + wm * (TM * 32) + li;
     const float* Bb = Bs + buf * KC * LDB + wn * (TN * 32) + li;
 #pragma unroll
@@ -225,6 +270,9 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_gemm_kernel(const ConvK p) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
+    // pin the order loads | MFMAs | selects+LDS writes: without it hipcc hoists part of store_AB() above the MFMA
+    // block and the vmcnt waits follow it there
+    __builtin_amdgcn_sched_barrier(0);
     if (more) store_AB(buf ^ 1);
     __syncthreads();
   }
@@ -255,48 +303,84 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_gemm_kernel(const ConvK p) {
     s1[j] = 0.f;
     s2[j] = 0.f;
   }
+  // Per-column constants (this lane's TN columns), then the tile in groups of 4 consecutive rows: every read the
+  // epilogue needs (residual tensor, old output, statistics partner) is issued unconditionally from a clamped
+  // address for the whole group before anything is consumed, so a group costs one memory round trip, not sixteen.
+  const bool has_add = a.add != nullptr, has_so = a.stat_other != nullptr, scat = a.scatter2x2 != 0;
+  int cn[TN], cco[TN], cab[TN];
+  bool cok[TN];
+  float cbias[TN], casc[TN], cash[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * (TN * 32) + j * 32 + li;
-    const bool nok = n < Ntot;
-    int co = n, ab = 0;
-    if (a.scatter2x2) {
-      ab = n / p.Cout;
-      co = n - ab * p.Cout;
+    cok[j] = n < Ntot;
+    cn[j] = cok[j] ? n : 0;
+    cab[j] = scat ? cn[j] / p.Cout : 0;
+    cco[j] = scat ? cn[j] - cab[j] * p.Cout : cn[j];
+    cbias[j] = 0.f;
+    casc[j] = 1.f;
+    cash[j] = 0.f;
+    if (a.bias != nullptr) cbias[j] = a.bias[cco[j]];
+    if (has_add && a.add_scale != nullptr) {
+      casc[j] = a.add_scale[cn[j]];
+      cash[j] = a.add_shift[cn[j]];
     }
-    const float bias = (a.bias != nullptr && nok) ? a.bias[co] : 0.f;
-    float asc = 1.f, ash = 0.f;
-    if (a.add != nullptr && a.add_scale != nullptr && nok) {
-      asc = a.add_scale[n];
-      ash = a.add_shift[n];
-    }
+  }
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+  for (int i = 0; i < TM; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * (TM * 32) + i * 32 + mfma32_row(r, lane);
-        if (nok && m < p.Mtot) {
-          float v = acc[i][j][r] + bias;
+    for (int g = 0; g < 4; ++g) {
+      const int mb = m0 + wm * (TM * 32) + i * 32 + 8 * g + 4 * lh;   // rows mb..mb+3 <-> accumulator regs 4g..4g+3
+      int jx = 0, iy = 0, ni = 0;
+      if (scat) {
+        const int mm = min(mb, p.Mtot - 1);
+        jx = mm % p.Wg;
+        const int t = mm / p.Wg;
+        iy = t % p.Hg;
+        ni = t / p.Hg;
+      }
+      int64_t off[4][TN];
+      bool ok[4][TN];
+      float vadd[4][TN], vold[4][TN], vso[4][TN];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int m = mb + rr;
+        const bool rok = m < p.Mtot;
+        const int mc = rok ? m : 0;
+        const int64_t rowpix = ((int64_t)ni * a.Hout + 2 * iy) * a.Wout + 2 * jx;
+        if (scat) {   // next pixel of the gather grid
+          if (++jx == p.Wg) {
+            jx = 0;
+            if (++iy == p.Hg) {
+              iy = 0;
+              ++ni;
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          ok[rr][j] = rok && cok[j];
+          const int64_t o = scat ? (rowpix + (int64_t)(cab[j] >> 1) * a.Wout + (cab[j] & 1)) * a.ldy + cco[j]
+                                 : (int64_t)mc * a.ldy + cn[j];
+          off[rr][j] = ok[rr][j] ? o : 0;
+          vadd[rr][j] = has_add ? a.add[ok[rr][j] ? ((int64_t)mc * a.ldadd + cn[j]) : 0] : 0.f;
+          vold[rr][j] = a.accumulate ? a.y[off[rr][j]] : 0.f;
+          vso[rr][j] = has_so ? a.stat_other[ok[rr][j] ? ((int64_t)mc * a.ldso + cn[j]) : 0] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          float v = acc[i][j][4 * g + rr] + cbias[j];
           if (a.relu) v = fmaxf(v, 0.f);
-          if (a.add != nullptr) v += fmaf(a.add[(int64_t)m * a.ldadd + n], asc, ash);
-          float* dst;
-          if (a.scatter2x2) {
-            const int jx = m % p.Wg;
-            const int t = m / p.Wg;
-            const int iy = t % p.Hg;
-            const int ni = t / p.Hg;
-            const int64_t opix = ((int64_t)ni * a.Hout + 2 * iy + (ab >> 1)) * a.Wout + 2 * jx + (ab & 1);
-            dst = a.y + opix * a.ldy + co;
-          } else {
-            dst = a.y + (int64_t)m * a.ldy + n;
-          }
-          if (a.accumulate) v += *dst;
-          *dst = v;
-          if (do_stats) {
-            const float u = (a.stat_other != nullptr) ? a.stat_other[(int64_t)m * a.ldso + n] : v;
-            s1[j] += v;
-            s2[j] = fmaf(v, u, s2[j]);
-          }
+          if (has_add) v += fmaf(vadd[rr][j], casc[j], cash[j]);
+          if (a.accumulate) v += vold[rr][j];
+          if (ok[rr][j]) a.y[off[rr][j]] = v;
+          const float vm = ok[rr][j] ? v : 0.f;
+          const float u = ok[rr][j] ? (has_so ? vso[rr][j] : v) : 0.f;
+          s1[j] += vm;
+          s2[j] = fmaf(vm, u, s2[j]);
         }
       }
     }
@@ -449,6 +533,7 @@ static int prepare(const dfl_conv_args* a, ConvK* k) {
   DFL_REQUIRE(a->x && a->w && a->y, "dfl_conv2d: x, w and y are required");
   DFL_REQUIRE(a->N > 0 && a->Hin > 0 && a->Win > 0 && a->Cin > 0 && a->Ntot > 0, "dfl_conv2d: bad sizes");
   DFL_REQUIRE(a->KH > 0 && a->KW > 0 && a->stride > 0 && a->pad >= 0, "dfl_conv2d: bad window");
+  DFL_REQUIRE(a->KH * a->KW <= 31, "dfl_conv2d: at most 31 taps");
   DFL_REQUIRE(a->ldx >= a->Cin, "dfl_conv2d: ldx < Cin");
   DFL_REQUIRE((a->in_scale == nullptr) == (a->in_shift == nullptr), "dfl_conv2d: in_scale/in_shift go together");
   DFL_REQUIRE((a->add_scale == nullptr) == (a->add_shift == nullptr), "dfl_conv2d: add_scale/add_shift go together");
@@ -484,8 +569,8 @@ static int prepare(const dfl_conv_args* a, ConvK* k) {
 }
 
 static int finish_rows(int M, int Ntot) {   // row blocks of conv_finish_kernel (= rows of stat_partials in split mode)
-  int64_t nb = ceil_div((int64_t)M * Ntot, 16384);
-  if (nb > 1024) nb = 1024;
+  int64_t nb = ceil_div((int64_t)M * Ntot, 1024);   // 4 elements per thread: the per-element loop over splits is serial
+  if (nb > 2048) nb = 2048;
   if (nb > M) nb = M;
   return nb < 1 ? 1 : (int)nb;
 }

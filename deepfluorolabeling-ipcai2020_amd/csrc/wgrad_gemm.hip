@@ -78,6 +78,21 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_kernel(const WgK p) {
   bool okD[QD][4];
   bool okG[TPB][QG];
   const bool g1 = gc + 1 < a.Cg, g2 = gc + 2 < a.Cg, g3 = gc + 3 < a.Cg;
+  constexpr int TKH = (TPB == 9) ? 3 : (TPB == 4 ? 2 : 1);   // multi-tap variants are square windows
+  const int tap_dy = tap0 / KW, tap_dx = tap0 - (tap0 / KW) * KW;
+  int g_pix[QG], g_ox[QG], g_oy[QG], g_n[QG];
+  bool g_ok0[QG];
+#pragma unroll
+  for (int r = 0; r < QG; ++r) {
+    const int idx = tid + r * NT;
+    g_pix[r] = idx / GQ;
+    g_ok0[r] = (idx < NQG) && (gc < a.Cg);
+    const int m = ch_begin * KP + g_pix[r];
+    g_ox[r] = m % a.Wout;
+    const int tq = m / a.Wout;
+    g_oy[r] = tq % a.Hout;
+    g_n[r] = tq / a.Hout;
+  }
 
   auto load = [&](int ch) {
     const int mc0 = ch * KP;
@@ -101,30 +116,38 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_kernel(const WgK p) {
     }
 #pragma unroll
     for (int r = 0; r < QG; ++r) {
-      const int idx = tid + r * NT;
-      const int pix = idx / GQ;
-      const int m = mc0 + pix;
-      const bool ok = (idx < NQG) && (m < p.Mtot) && (gc < a.Cg);
-      const int mm = ok ? m : 0;
-      const int ox = mm % a.Wout;
-      const int tq = mm / a.Wout;
-      const int oy = tq % a.Hout;
-      const int n = tq / a.Hout;
-      const int iy0 = oy * a.stride - a.pad;
-      const int ix0 = ox * a.stride - a.pad;
-      const int base = n * Hin * Win;
+      // pixel cursor (g_ox, g_oy, g_n) of this thread's row: advanced by KP per chunk, no divisions in the loop
+      const int m = mc0 + g_pix[r];
+      const bool ok = g_ok0[r] && (m < p.Mtot);
+      const int iy0 = g_oy[r] * a.stride - a.pad;
+      const int ix0 = g_ox[r] * a.stride - a.pad;
+      const int64_t base = (((int64_t)g_n[r] * Hin + iy0) * Win + ix0) * a.ldg + gc;
+      bool rowok[TKH], colok[TKH];
+#pragma unroll
+      for (int d = 0; d < TKH; ++d) {
+        const int dy = (TPB == 1) ? tap_dy : d, dx = (TPB == 1) ? tap_dx : d;
+        rowok[d] = (unsigned)(iy0 + dy) < (unsigned)Hin;
+        colok[d] = (unsigned)(ix0 + dx) < (unsigned)Win;
+      }
 #pragma unroll
       for (int tt = 0; tt < TPB; ++tt) {
-        const int t = (TPB == 1) ? tap0 : tt;
-        const int dy = t / KW, dx = t - dy * KW;
-        const int iy = iy0 + dy, ix = ix0 + dx;
-        const bool in = ok && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
-        const float* src = a.g + (in ? (((int64_t)base + (int64_t)iy * Win + ix) * a.ldg + gc) : 0);
+        const int dyi = (TPB == 1) ? 0 : tt / TKH, dxi = (TPB == 1) ? 0 : tt % TKH;
+        const int dy = (TPB == 1) ? tap_dy : dyi, dx = (TPB == 1) ? tap_dx : dxi;
+        const bool in = ok && rowok[dyi] && colok[dxi];
+        const float* src = a.g + (in ? (base + ((int64_t)dy * Win + dx) * a.ldg) : 0);
         okG[tt][r] = in;
         if constexpr (VEC) {
           rg[tt][r] = *reinterpret_cast<const float4*>(src);
         } else {
           rg[tt][r] = make_float4(src[0], src[(in && g1) ? 1 : 0], src[(in && g2) ? 2 : 0], src[(in && g3) ? 3 : 0]);
+        }
+      }
+      g_ox[r] += KP;
+      while (g_ox[r] >= a.Wout) {
+        g_ox[r] -= a.Wout;
+        if (++g_oy[r] == a.Hout) {
+          g_oy[r] = 0;
+          ++g_n[r];
         }
       }
     }
@@ -184,6 +207,7 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_kernel(const WgK p) {
     const int buf = (ch - ch_begin) & 1;
     const bool more = (ch + 1) < ch_end;
     if (more) load(ch + 1);
+    __builtin_amdgcn_sched_barrier(0);
     const float* Db = Ds + buf * KP * LDD + wm * (TM * 32) + li;
     const float* Gb = Gs + buf * TPB * KP * LDG + wn * (TN * 32) + li;
 #pragma unroll
@@ -203,6 +227,7 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_kernel(const WgK p) {
             acc[tt][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(dv[i], gv[j], acc[tt][i][j], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);  // keep the selects + LDS writes (and their vmcnt waits) behind the MFMA block
     if (more) store(buf ^ 1);
     __syncthreads();
   }
@@ -268,8 +293,8 @@ static WgCfg pick_wg(const dfl_wgrad_args* a, bool vec = true) {
   const int T = a->KH * a->KW;
   const bool narrow = (a->Cm <= 64 || a->Cg <= 64) || !vec;   // the scalar-load variants exist for the narrow tiles only
   if (narrow) {
-    if (T == 9) return WG_TAPS9;
-    if (T == 4) return WG_TAPS4;
+    if (a->KH == 3 && a->KW == 3) return WG_TAPS9;
+    if (a->KH == 2 && a->KW == 2) return WG_TAPS4;
     return WG_32;
   }
   if (a->Cm >= 256 && a->Cg >= 256 && (int64_t)a->Cm * a->Cg * T >= 128ll * 128 * 1024) return WG_128;
