@@ -110,6 +110,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--detail', action='store_true', help='per-op table on stderr')
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' for a self-test)")
     ap.add_argument('--no-overlap', action='store_true', help='all-reduce after backward instead of overlapped buckets')
     args = ap.parse_args()
 
@@ -118,12 +119,12 @@ def main():
     from dfl_amd.parallel import DataParallel, init_process_group_from_env
     import torch.distributed as dist
 
-    rank, world, local = init_process_group_from_env('nccl')
+    rank, world, local = init_process_group_from_env(args.backend)
     if world != args.gpus and world > 1:
         raise SystemExit('--gpus %d does not match WORLD_SIZE %d' % (args.gpus, world))
     if args.gpus > 1 and world == 1:
         raise SystemExit('launch with torch.distributed.run for --gpus > 1')
-    dev = torch.device('cuda', local)
+    dev = torch.device('cuda', local % torch.cuda.device_count())   # (gloo self-test: several ranks may share a GPU)
     torch.cuda.set_device(dev)
     lib = nat.lib()
 

@@ -28,7 +28,7 @@ def init_process_group_from_env(backend=None):
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         if backend == 'nccl':
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
@@ -115,11 +115,13 @@ class DataParallel:
         flat = plan.grad_flat
         inv = 1.0 / self.world
         if not self.overlap or not flat.is_cuda:
-            plan.bwd.run(stream)
-            for _, _, ranges in self._segments(plan):
+            # same segment walk, communication in line (also the path the CPU/gloo tests exercise)
+            for op_start, op_count, ranges in self._segments(plan):
+                plan.bwd.run(stream, op_start, op_count)
                 for s, e in ranges:
-                    dist.all_reduce(flat[s:e], group=self.group)
-            flat.mul_(inv)
+                    view = flat[s:e]
+                    dist.all_reduce(view, group=self.group)
+                    view.mul_(inv)
             return
         cur = torch.cuda.current_stream()
         if self.comm_stream is None:
