@@ -1,0 +1,109 @@
+"""CPU-side checks of the product's host layer (no kernel is launched): the C ABI loads and exports what the header
+declares, the struct mirrors match, the drop-in module reproduces the reference's state_dict / seeded init / schedule,
+plans build for every preset, and the product refuses to run without a GPU instead of falling back."""
+import ctypes as C
+import hashlib
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import dfl_amd
+from conftest import TINY_CFGS, PAPER_CFGS, load_golden, ROOT
+from dfl_amd import _native as nat
+from dfl_amd.plan import UNetPlan
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, 'include', 'dfl_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = set(re.findall(r'\b(dfl_[a-z0-9_]+)\s*\(', hdr))
+    assert len(declared) >= 30
+    lib = C.CDLL(nat.LIB_PATH)
+    missing = [f for f in sorted(declared) if not hasattr(lib, f)]
+    assert not missing, missing
+    assert set(nat.EXPORTS) <= declared
+    L = nat.lib()                              # also verifies every ctypes struct mirror against dfl_sizeof()
+    assert L.dfl_version() >= 100
+    assert L.dfl_sizeof(999) == -1
+
+
+def test_argument_validation_reports_errors_without_a_gpu():
+    L = nat.lib()
+    a = nat.ConvArgs()                         # all NULL
+    assert L.dfl_conv2d(C.addressof(a), None) == -1
+    assert b'required' in L.dfl_last_error()
+    a = nat.ConvArgs(x=16, w=16, y=16, N=1, Hin=8, Win=8, Cin=4, ldx=4, KH=3, KW=3, stride=1, pad=1, Hout=9, Wout=8,
+                     Ntot=8, ldy=8)
+    assert L.dfl_conv_grid_m(C.addressof(a)) == -1 and b'do not match' in L.dfl_last_error()
+    assert L.dfl_rowblock_count(5000, 32) == 20
+    assert L.dfl_head_scratch_ld(32) % 4 == 0
+
+
+def test_cpu_tensors_are_refused():
+    net = dfl_amd.UNet(n_classes=7, depth=2, wf=2, padding=True, batch_norm=True)
+    with pytest.raises(RuntimeError, match='GPU only'):
+        net(torch.zeros(1, 1, 8, 8))
+    with pytest.raises(RuntimeError):
+        dfl_amd.DiceLoss2D()(torch.rand(1, 2, 4, 4), torch.rand(1, 2, 4, 4))
+    with pytest.raises(RuntimeError):
+        dfl_amd.get_device(no_gpu=True)
+    with pytest.raises(NotImplementedError):
+        dfl_amd.UNet(up_mode='upsample')
+
+
+@pytest.mark.parametrize('name', sorted(PAPER_CFGS))
+def test_seeded_init_and_state_dict_match_reference(name):
+    seed, cfg = PAPER_CFGS[name]
+    g = load_golden(name)
+    torch.manual_seed(seed)
+    net = dfl_amd.UNet(**cfg)
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(g['sd_names'])
+    sha = lambda t: hashlib.sha256(t.detach().contiguous().numpy().tobytes()).hexdigest()
+    assert [sha(v) for v in sd.values()] == list(g['sd_sha'])
+    assert [k for k, _ in net.named_parameters()] == list(g['param_names'])
+
+
+@pytest.mark.parametrize('name', sorted(TINY_CFGS))
+def test_plans_build_for_every_preset(name):
+    cfg = TINY_CFGS[name]
+    g = load_golden(name)
+    net = dfl_amd.UNet(**cfg)
+    net.load_state_dict({k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith('sd0/')})
+    P, B = net._state()
+    N, _, H, W = g['x'].shape
+    plan = UNetPlan(net._cfg, P, B, N, H, W, True, True, torch.device('cpu'))   # addresses recorded, nothing launched
+    assert plan.out_hw == tuple(g['seg'].shape[-2:])
+    assert len(plan.fwd) > 0 and len(plan.bwd) > len(plan.fwd)
+    live = [k for k in plan.grad_names if k not in plan.dead_params]
+    assert set(plan.grad_ready_op) == set(live)
+    ev = UNetPlan(net._cfg, P, B, 1, H, W, False, False, torch.device('cpu'))
+    assert ev.bwd is None and len(ev.fwd) > 0
+
+
+def test_center_crop_and_schedule_against_reference_goldens():
+    x = torch.arange(2 * 3 * 9 * 8).view(2, 3, 9, 8)
+    c = dfl_amd.center_crop(x, (5, 4))
+    assert c.shape == (2, 3, 5, 4) and c.data_ptr() == x[:, :, 2:, 2:].data_ptr()   # a view, start = int(diff/2)
+    assert dfl_amd.center_crop(x, x.shape) is x
+    g = load_golden('sched')
+    import contextlib
+    import io
+    for tag, (period, growth) in {'p2g2': (2, 2), 'p3g1': (3, 1)}.items():
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([p], lr=0.1)
+        with contextlib.redirect_stdout(io.StringIO()):
+            s = dfl_amd.WarmRestartLR(opt, init_run_period_epochs=period, growth_factor=growth)
+            trace, restarts = [], []
+            for ep in range(9):
+                for k in range(4):
+                    s.intra_epoch_step((k + 1) / 4)
+                    trace.append(opt.param_groups[0]['lr'])
+                s.step()
+                trace.append(opt.param_groups[0]['lr'])
+                restarts.append(int(s.just_restarted))
+        np.testing.assert_allclose(trace, g[tag], rtol=1e-12, atol=1e-15)
+        assert restarts == list(g[tag + '_restarts'])
