@@ -31,8 +31,8 @@ class WgradArgs(C.Structure):
 
 
 class PackJob(C.Structure):
-    _fields_ = [('src', fp), ('dst', fp), ('off', i64), ('D0', i32), ('D1', i32), ('D2', i32),
-                ('s0', i32), ('s1', i32), ('s2', i32)]
+    _fields_ = [('src', fp), ('dst', fp), ('A', i32), ('B', i32), ('C', i32), ('kind', i32), ('flip', i32),
+                ('reserved', i32)]
 
 
 class BnFinalizeArgs(C.Structure):

@@ -363,16 +363,73 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const dfl_pool_args a,
 }
 
 // ------------------------------------------------------------------------------------------------ weight pack
+// GEMM operand layout of dfl_conv2d: w[kq][n][r] = W(k = 4*kq + r, n), zero for k >= K ("quad-packed": one float4 is four
+// consecutive k of one output column).  The source is always a contiguous [A][B][C] parameter (C = KH*KW) and the
+// (k, n) <-> (a, b, c) mapping is one of three kinds (include/dfl_hip.h).  Fast path: LDS-tiled -- a 32(A) x 32(B) x C
+// tile is read as 32 runs of 32*C contiguous floats and written as 512-byte runs; element-wise fallback otherwise.
+constexpr int PK_T = 32, PK_CMAX = 9;
+
+__device__ __forceinline__ float pack_src(const dfl_pack_job& j, int k, int n) {
+  int a, b, c;
+  if (j.kind == 1) {
+    c = k / j.B; b = k - c * j.B; a = n;
+  } else if (j.kind == 2) {
+    const int cp = k / j.A;
+    a = k - cp * j.A; b = n; c = j.flip ? (j.C - 1 - cp) : cp;
+  } else {
+    a = k; c = n / j.B; b = n - c * j.B;
+  }
+  return j.src[((int64_t)a * j.B + b) * j.C + c];
+}
+
 __global__ void __launch_bounds__(256) pack_kernel(const dfl_pack_job* __restrict__ jobs) {
+  __shared__ float tile[PK_T][PK_T * PK_CMAX + 1];
   const dfl_pack_job j = jobs[blockIdx.y];
-  const int64_t total = (int64_t)j.D0 * j.D1 * j.D2;
+  const int A = j.A, B = j.B, Cc = j.C;
+  const int K = (j.kind == 1) ? Cc * B : (j.kind == 2 ? Cc * A : A);
+  const int N = (j.kind == 1) ? A : (j.kind == 2 ? B : Cc * B);
+  const bool tiled = Cc <= PK_CMAX && ((j.kind == 1) ? (B % 4 == 0) : (A % 4 == 0));
+  if (tiled) {
+    const int tb = (B + PK_T - 1) / PK_T, ta = (A + PK_T - 1) / PK_T;
+    const int run = PK_T * Cc;
+    for (int tidx = blockIdx.x; tidx < ta * tb; tidx += gridDim.x) {
+      const int a0 = (tidx / tb) * PK_T, b0 = (tidx % tb) * PK_T;
+      const int nb = min(PK_T, B - b0), na = min(PK_T, A - a0);
+      __syncthreads();
+      for (int e = threadIdx.x; e < PK_T * run; e += 256) {   // 32 rows of 32*C contiguous source floats
+        const int ar = e / run, q = e - ar * run;
+        if (ar < na && q < nb * Cc) tile[ar][q] = j.src[((int64_t)(a0 + ar) * B + b0) * Cc + q];
+      }
+      __syncthreads();
+      for (int e = threadIdx.x; e < PK_T * run; e += 256) {
+        const int r = e & 3, x = (e >> 2) & 31, rest = e >> 7;   // rest in [0, 8*C)
+        if (j.kind == 1) {          // k = c*B + b, n = a: quads run along b, columns along a
+          const int c = rest >> 3, bq = rest & 7, bb = 4 * bq + r, ar = x;
+          if (ar < na && bb < nb)
+            j.dst[((int64_t)((c * B + b0) / 4 + bq) * N + a0 + ar) * 4 + r] = tile[ar][bb * Cc + c];
+        } else if (j.kind == 2) {   // k = c'*A + a, n = b: quads along a, columns along b
+          const int cp = rest >> 3, aq = rest & 7, ar = 4 * aq + r, bb = x;
+          const int c = j.flip ? (Cc - 1 - cp) : cp;
+          if (ar < na && bb < nb)
+            j.dst[((int64_t)((cp * A + a0) / 4 + aq) * N + b0 + bb) * 4 + r] = tile[ar][bb * Cc + c];
+        } else {                    // k = a, n = c*B + b
+          const int c = rest >> 3, aq = rest & 7, ar = 4 * aq + r, bb = x;
+          if (ar < na && bb < nb)
+            j.dst[((int64_t)(a0 / 4 + aq) * N + c * B + b0 + bb) * 4 + r] = tile[ar][bb * Cc + c];
+        }
+      }
+    }
+    return;
+  }
+  const int Kq = (K + 3) / 4;
+  const int64_t total = (int64_t)Kq * N * 4;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const int i2 = (int)(i % j.D2);
-    const int64_t t = i / j.D2;
-    const int i1 = (int)(t % j.D1);
-    const int i0 = (int)(t / j.D1);
-    j.dst[i] = j.src[j.off + (int64_t)i0 * j.s0 + (int64_t)i1 * j.s1 + (int64_t)i2 * j.s2];
+    const int r = (int)(i & 3);
+    const int64_t t = i >> 2;
+    const int n = (int)(t % N), kq = (int)(t / N);
+    const int k = 4 * kq + r;
+    j.dst[i] = (k < K) ? pack_src(j, k, n) : 0.f;
   }
 }
 

@@ -1,54 +1,70 @@
 // Gather-GEMM convolution on the gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32).
 //
-// One kernel family serves nn.Conv2d 3x3 / 1x1 / 2x2-stride-2, nn.ConvTranspose2d(k2,s2) (scatter epilogue)
-// and, with re-packed weights, the data gradient of each of them (reference: train_test_code/unet.py:93,207,
-// 211,218,240 and torch autograd at train.py:422).  See include/dfl_hip.h (dfl_conv2d) for the contract.
+// One kernel family serves nn.Conv2d 3x3 / 1x1 / 2x2-stride-2, nn.ConvTranspose2d(k2,s2) (scatter epilogue) and, with
+// re-packed weights, the data gradient of each of them (reference: train_test_code/unet.py:93,207,211,218,240 and torch
+// autograd at train.py:422).  Contract: include/dfl_hip.h (dfl_conv2d).
 //
-// Structure per workgroup (WM x WN waves, each wave TM x TN tiles of 32x32):
-//   K is walked in chunks of KC = 16 (k = tap*Cin + channel).  For each chunk every thread gathers its share
-//   of the [BM pixels][16] input slab straight from the NHWC activation (float4 = 4 channels of one pixel, zero
-//   outside the image, BatchNorm scale/shift applied on load) and of the [16][BN] weight slab into registers,
-//   the wave computes the previous chunk out of LDS meanwhile, then the registers are written to the other LDS
-//   buffer: one barrier per chunk.  LDS images are k-major (A: [16][BM+4], B: [16][BN+4]) so that the MFMA
-//   operand reads (lane = row/col index, lane>>5 = k parity) are unit-stride ds_read_b32, conflict free.
-//   f32 MFMA issues one 32x32x2 per 64 cycles per SIMD, so operand traffic (2 x 256 B per MFMA) is far below
-//   what LDS and L2 deliver; the kernel is bound by the matrix pipe (roofline "mfma", peak 157.3 TFLOP/s).
-// Epilogue: bias, ReLU, "+ BN(other)" (residual sum), accumulate, NHWC or 2x2-scatter store, and per-channel
-//   partial sums (v, v*u) reduced lane -> half-wave (one xor-32 shuffle) -> workgroup (LDS) -> one row of
-//   stat_partials per row block; dfl_bn_finalize adds the rows in fp64.
+// Per workgroup (WM x WN waves, each wave TM x TN tiles of 32x32), K walked in chunks of KC = 16 (k = tap*Cin + c):
+//   * gather: each thread fetches float4s (4 channels of one pixel at one tap) of the [BM pixels][16] slab straight from
+//     the NHWC activation and float4s of the quad-packed weight slab, into registers, while the MFMAs of the previous
+//     chunk run out of LDS; afterwards the registers go to the other LDS buffer (one barrier per chunk).
+//   * LDS images are row-major ([BM][16+4], [BN][16+4]); a lane reads ONE b128 per operand and 8 k-values: lane (i, h)
+//     gets k = 8g+4h..8g+4h+3 of row i, component q feeds MFMA q (k-order inside a chunk is permuted, the set is not).
+//   * the matrix pipe issues one 32x32x2 per 64 cycles per SIMD and a SIMD has only ~12 other issue slots in that time
+//     (tools/exp/exp_mfma.cpp: the bare loop reaches 100-125 TFLOP/s), so the fast path (MODE 1) is written to spend as
+//     few VALU/SALU instructions per MFMA as possible:
+//       - buffer loads with hardware bounds checking: an invalid tap/row/column gets an out-of-range offset and the load
+//         returns 0 -- no clamped address, no select, no branch (a load under a condition would make hipcc branch and
+//         wait vmcnt(0) per element);
+//       - Cin % 16 == 0 => every chunk lies inside one tap: the (tap, channel) cursor is wave-uniform (SALU), the per-row
+//         work is a bit test of a precomputed tap-validity mask and one 32-bit add;
+//       - weight slab offsets are loop invariant per thread, the chunk advance rides in the scalar offset;
+//       - selects / BatchNorm affine / LDS writes sit behind the MFMA block (sched_barrier) so the load latency of chunk
+//         c+1 hides under the matrix work of chunk c.
+//     MODE 0 is the general fallback (any Cin / alignment: the network's first layer and tiny test nets).
+// Epilogue: bias, ReLU, "+ BN(other)" (residual sum), accumulate, NHWC or 2x2-scatter store, per-channel partial sums
+//   (v, v*u) reduced lane -> half-wave (xor-32 shuffle) -> workgroup (LDS) -> one row of stat_partials per row block;
+//   dfl_bn_finalize adds the rows in fp64.  EPI 0 = the common simple form (bias/ReLU/statistics, bounds by buffer
+//   store), EPI 1 = everything.  Small-M / long-K layers are cut along K (split-K) and finished by conv_finish_kernel.
 #include "common.h"
 
 namespace dfl {
 
 constexpr int KC = 16;
+constexpr uint32_t OOB = 0x80000000u;   // buffer offset beyond any tensor we accept (< 2 GiB): the load returns 0
 
 struct ConvK {
   dfl_conv_args a;
   int Mtot, Ktot, Hg, Wg, Cout;
-  int vecA, vecB;
+  int fast;          // MODE 1 preconditions hold
   int splits, cps;   // split-K: number of K slices and chunks per slice
+  uint32_t x_bytes, w_bytes, y_bytes;
 };
 
-// Second launch-bound = waves per SIMD the register allocation must leave room for.  It is chosen per tile so that the
-// U-Net layer sizes fit in whole "rounds" of resident workgroups (e.g. level 1: 1152 tiles of 128x64 need 5 per CU to
-// run in one round; at 4 per CU the kernel takes two rounds at 56 % slot use).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+// Second launch-bound = waves per SIMD the register allocation must leave room for (residency per CU, see pick_cfg).
 constexpr int conv_occ(int tiles) { return tiles >= 4 ? 2 : (tiles == 2 ? 5 : 6); }
 
-template <int WM, int WN, int TM, int TN, bool VEC>
+template <int WM, int WN, int TM, int TN, int MODE, bool AFF, int EPI>
 __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kernel(const ConvK p) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int LDA = BM + 4, LDB = BN + 4;
+  constexpr int LDK = KC + 4;  // row pitch of both LDS images (80 B: conflict-free b128 reads and writes)
   constexpr int RPP = NT / 4;  // pixel rows covered per pass of the A gather
   constexpr int QA = BM / RPP;
   static_assert(BM % RPP == 0, "A tile must divide evenly");
-  constexpr int NQB = KC * BN / 4;
+  constexpr int NQB = (KC / 4) * BN;   // B quads per chunk: (k-quad, column)
   constexpr int QB = (NQB + NT - 1) / NT;
-  constexpr int BQ = BN / 4;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                  // [2][KC][LDA]
-  float* Bs = smem + 2 * KC * LDA;   // [2][KC][LDB]
+  float* As = smem;                  // [2][BM][LDK]  row = pixel, 16 k-values contiguous
+  float* Bs = smem + 2 * BM * LDK;   // [2][BN][LDK]  row = output column
 
   const dfl_conv_args& a = p.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -57,13 +73,17 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int Hin = a.Hin, Win = a.Win, Cin = a.Cin, KW = a.KW;
   const int Ktot = p.Ktot, Ntot = a.Ntot;
-
-  // ---- per-thread gather rows ------------------------------------------------------------------
+  const int T = a.KH * KW;
   const int aq = tid & 3;
+  const bool has_aff = a.in_scale != nullptr;
+
+  // ---- per-thread gather rows: position of tap (0,0) and the set of taps that fall inside the image ----------------
   int a_iy0[QA], a_ix0[QA], a_base[QA];
+  uint32_t a_mask[QA];
 #pragma unroll
   for (int r = 0; r < QA; ++r) {
     const int m = m0 + (tid >> 2) + r * RPP;
+    uint32_t mk = 0;
     if (m < p.Mtot) {
       const int ox = m % p.Wg;
       const int t = m / p.Wg;
@@ -72,80 +92,76 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
       a_iy0[r] = oy * a.stride - a.pad;
       a_ix0[r] = ox * a.stride - a.pad;
       a_base[r] = n * Hin * Win;
+      int ty = 0, tx = 0;
+      for (int t2 = 0; t2 < T; ++t2) {
+        if ((unsigned)(a_iy0[r] + ty) < (unsigned)Hin && (unsigned)(a_ix0[r] + tx) < (unsigned)Win) mk |= (1u << t2);
+        if (++tx == KW) {
+          tx = 0;
+          ++ty;
+        }
+      }
     } else {
-      a_iy0[r] = -(1 << 28);  // every tap lands outside the image => zeros
+      a_iy0[r] = 0;
       a_ix0[r] = 0;
       a_base[r] = 0;
     }
-  }
-  // Vector path: the per-chunk address work is reduced to a bit test and one 64-bit add per row.  For every gather row
-  // keep a pointer to "tap (0,0), channel 0" (may lie outside the image; only dereferenced when the tap is valid) and a
-  // bit mask of the taps that fall inside the image; the (tap, channel) cursor of this thread's k-quad advances by KC
-  // per chunk without divisions.  (VALU instructions issued around the MFMA block are what separates this kernel from
-  // its MFMA-only skeleton: tools/exp/exp_mfma.cpp measures 113-125 TFLOP/s for the skeleton with plain loads.)
-  int64_t a_rowoff[QA];
-  uint32_t a_mask[QA];
-#pragma unroll
-  for (int r = 0; r < QA; ++r) {
-    a_rowoff[r] = ((int64_t)a_base[r] + (int64_t)a_iy0[r] * Win + a_ix0[r]) * a.ldx;
-    uint32_t mk = 0;
-    int ty = 0, tx = 0;
-    for (int t = 0; t < a.KH * KW; ++t) {
-      if ((unsigned)(a_iy0[r] + ty) < (unsigned)Hin && (unsigned)(a_ix0[r] + tx) < (unsigned)Win) mk |= (1u << t);
-      if (++tx == KW) {
-        tx = 0;
-        ++ty;
-      }
-    }
     a_mask[r] = mk;
-  }
-  const int T = a.KH * KW;
-  // cursor of this thread's quad: k = tap * Cin + c
-  int cur_tap, cur_c, cur_dy, cur_dx;
-  {
-    const int k0 = (int)blockIdx.z * p.cps * KC + 4 * aq;
-    cur_tap = k0 / Cin;
-    cur_c = k0 - cur_tap * Cin;
-    cur_dy = cur_tap / KW;
-    cur_dx = cur_tap - cur_dy * KW;
   }
 
   float4 ra[QA];
   float4 rb[QB];
-  const bool has_aff = a.in_scale != nullptr;
-  const float* aff_sc = has_aff ? a.in_scale : a.w;   // a.w: any valid 16-byte aligned address
-  const float* aff_sh = has_aff ? a.in_shift : a.w;
-
-  // Gather discipline (both matter on gfx950 / hipcc):
-  //  * every load is UNCONDITIONAL, from a clamped (always valid) address, and the zero-fill is a select: a load
-  //    under a runtime condition makes hipcc branch around it and wait vmcnt(0) per element, serialising the slab
-  //    into dependent round trips (cdna_hip_programming.md, ".s-level traps" (c));
-  //  * load_*() only ISSUES the loads into raw registers; the select / BatchNorm affine / LDS write happen in
-  //    store_AB() AFTER the MFMA block of the current chunk, so the s_waitcnt lands behind the MFMAs and the
-  //    HBM/L2 latency of chunk c+1 hides under the matrix work of chunk c.
   float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  bool okA[QA][VEC ? 1 : 4];
-  bool okB[QB][4];
+  uint32_t okA = 0;   // MODE 1: bit r = row r valid for the chunk in flight; MODE 0: bit 4r+j
 
-  auto load_A = [&](int kc0) {
-    const int k = kc0 + 4 * aq;
-    if constexpr (VEC) {
-      // uses and advances the (tap, channel) cursor: must be called once per chunk, in order
+  // ---- MODE 1 state --------------------------------------------------------------------------------------------------
+  uint32_t a_rowb[QA];   // byte offset (mod 2^32) of (tap (0,0), channel 4*aq) of each gather row
+  uint32_t b_voff[QB];   // loop-invariant byte offset of this thread's weight quads inside a chunk slab
+  __amdgpu_buffer_rsrc_t rsA, rsB;
+  int cur_tap = 0, cur_c0 = 0, cur_dy = 0, cur_dx = 0;   // wave-uniform cursor of the chunk to load next
+  if constexpr (MODE == 1) {
+    rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)p.x_bytes, 0x00020000);
+    rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)p.w_bytes, 0x00020000);
+#pragma unroll
+    for (int r = 0; r < QA; ++r)
+      a_rowb[r] = (uint32_t)((((int64_t)a_base[r] + (int64_t)a_iy0[r] * Win + a_ix0[r]) * a.ldx + 4 * aq) * 4);
+#pragma unroll
+    for (int r = 0; r < QB; ++r) {
+      const int idx = tid + r * NT;
+      const int kq = idx / BN, nn = idx - kq * BN;
+      b_voff[r] = (idx < NQB && n0 + nn < Ntot) ? (uint32_t)(((int64_t)kq * Ntot + n0 + nn) * 16) : OOB;
+    }
+    const int k0 = (int)blockIdx.z * p.cps * KC;
+    cur_tap = k0 / Cin;
+    cur_c0 = k0 - cur_tap * Cin;
+    cur_dy = cur_tap / KW;
+    cur_dx = cur_tap - cur_dy * KW;
+  }
+
+  // Loads only ISSUE into raw registers; store_AB() (after the MFMA block) applies the affine / zero fill and writes LDS.
+  auto load_AB = [&](int ch) {
+    if constexpr (MODE == 1) {
+      // must be called once per chunk, in order: uses and advances the uniform cursor
       const bool kvalid = cur_tap < T;
-      const int c = kvalid ? cur_c : 0;
-      const uint32_t bit = kvalid ? (1u << cur_tap) : 0u;
-      const int64_t tapoff = ((int64_t)cur_dy * Win + cur_dx) * a.ldx + c;
-      sc4 = *reinterpret_cast<const float4*>(aff_sc + (has_aff ? c : 0));
-      sh4 = *reinterpret_cast<const float4*>(aff_sh + (has_aff ? c : 0));
+      const uint32_t tapb = (uint32_t)(((cur_dy * Win + cur_dx) * a.ldx + cur_c0) * 4);
+      const uint32_t tbit = kvalid ? (1u << cur_tap) : 0u;
+      okA = 0;
 #pragma unroll
       for (int r = 0; r < QA; ++r) {
-        const bool ok = (a_mask[r] & bit) != 0;
-        okA[r][0] = ok;
-        ra[r] = *reinterpret_cast<const float4*>(a.x + (ok ? a_rowoff[r] + tapoff : 0));
+        const bool ok = (a_mask[r] & tbit) != 0;
+        okA |= ok ? (1u << r) : 0u;
+        ra[r] = buf_load4(rsA, ok ? a_rowb[r] + tapb : OOB, 0);
       }
-      cur_c += KC;
-      while (cur_c >= Cin) {
-        cur_c -= Cin;
+      if constexpr (AFF) {
+        const int c = (kvalid ? cur_c0 : 0) + 4 * aq;
+        sc4 = *reinterpret_cast<const float4*>(a.in_scale + c);
+        sh4 = *reinterpret_cast<const float4*>(a.in_shift + c);
+      }
+      const uint32_t soff = (uint32_t)ch * (uint32_t)(KC / 4 * 16) * (uint32_t)Ntot;   // chunk = 4 k-quad rows
+#pragma unroll
+      for (int r = 0; r < QB; ++r) rb[r] = buf_load4(rsB, b_voff[r], soff);
+      cur_c0 += KC;
+      if (cur_c0 >= Cin) {
+        cur_c0 = 0;
         ++cur_tap;
         if (++cur_dx == KW) {
           cur_dx = 0;
@@ -153,7 +169,12 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
         }
       }
     } else {
+      // general gather: per element (tap, channel) by division, clamped unconditional loads
+      const int k = ch * KC + 4 * aq;
       float vals[QA][4], scv[4], shv[4];
+      const float* aff_sc = has_aff ? a.in_scale : a.w;
+      const float* aff_sh = has_aff ? a.in_shift : a.w;
+      okA = 0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int kj = k + j;
@@ -165,10 +186,9 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
         shv[j] = aff_sh[has_aff ? c : 0];
 #pragma unroll
         for (int r = 0; r < QA; ++r) {
-          const int iy = a_iy0[r] + dy, ix = a_ix0[r] + dx;
-          const bool ok = kvalid && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
-          const int64_t pix = ok ? ((int64_t)a_base[r] + (int64_t)iy * Win + ix) : 0;
-          okA[r][VEC ? 0 : j] = ok;
+          const bool ok = kvalid && ((a_mask[r] >> t) & 1u);
+          const int64_t pix = ok ? ((int64_t)a_base[r] + (int64_t)(a_iy0[r] + dy) * Win + a_ix0[r] + dx) : 0;
+          okA |= ok ? (1u << (4 * r + j)) : 0u;
           vals[r][j] = a.x[pix * a.ldx + (ok ? c : 0)];
         }
       }
@@ -176,55 +196,50 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
       sh4 = make_float4(shv[0], shv[1], shv[2], shv[3]);
 #pragma unroll
       for (int r = 0; r < QA; ++r) ra[r] = make_float4(vals[r][0], vals[r][1], vals[r][2], vals[r][3]);
-    }
-  };
-
-  auto load_B = [&](int kc0) {
 #pragma unroll
-    for (int r = 0; r < QB; ++r) {
-      const int idx = tid + r * NT;
-      const int krow = idx / BQ, nq = idx - krow * BQ;
-      const int k = kc0 + krow, n = n0 + 4 * nq;
-      const bool ok = (idx < NQB) && (k < Ktot) && (n < Ntot);
-      const float* src = a.w + (ok ? ((int64_t)k * Ntot + n) : 0);
-      if constexpr (VEC) {
-        okB[r][0] = okB[r][1] = okB[r][2] = okB[r][3] = ok;
-        rb[r] = *reinterpret_cast<const float4*>(src);
-      } else {
-        okB[r][0] = ok;
-        okB[r][1] = ok && (n + 1 < Ntot);
-        okB[r][2] = ok && (n + 2 < Ntot);
-        okB[r][3] = ok && (n + 3 < Ntot);
-        rb[r] = make_float4(src[0], src[okB[r][1] ? 1 : 0], src[okB[r][2] ? 2 : 0], src[okB[r][3] ? 3 : 0]);
+      for (int r = 0; r < QB; ++r) {
+        const int idx = tid + r * NT;
+        const int kq = idx / BN, nn = idx - kq * BN;
+        const int kquad = ch * (KC / 4) + kq, n = n0 + nn;
+        const bool ok = (idx < NQB) && (4 * kquad < Ktot) && (n < Ntot);
+        const float4 v = *reinterpret_cast<const float4*>(a.w + (ok ? ((int64_t)kquad * Ntot + n) * 4 : 0));
+        rb[r] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
   };
 
   auto store_AB = [&](int buf) {
-    float* Ab = As + buf * KC * LDA;
-    const float s0 = has_aff ? sc4.x : 1.f, s1 = has_aff ? sc4.y : 1.f, s2 = has_aff ? sc4.z : 1.f, s3 = has_aff ? sc4.w : 1.f;
-    const float h0 = has_aff ? sh4.x : 0.f, h1 = has_aff ? sh4.y : 0.f, h2 = has_aff ? sh4.z : 0.f, h3 = has_aff ? sh4.w : 0.f;
+    float* Ab = As + buf * BM * LDK;
 #pragma unroll
     for (int r = 0; r < QA; ++r) {
       const int row = (tid >> 2) + r * RPP;
-      const bool k0 = okA[r][0], k1 = okA[r][VEC ? 0 : 1], k2 = okA[r][VEC ? 0 : 2], k3 = okA[r][VEC ? 0 : 3];
-      Ab[(4 * aq + 0) * LDA + row] = k0 ? fmaf(ra[r].x, s0, h0) : 0.f;
-      Ab[(4 * aq + 1) * LDA + row] = k1 ? fmaf(ra[r].y, s1, h1) : 0.f;
-      Ab[(4 * aq + 2) * LDA + row] = k2 ? fmaf(ra[r].z, s2, h2) : 0.f;
-      Ab[(4 * aq + 3) * LDA + row] = k3 ? fmaf(ra[r].w, s3, h3) : 0.f;
+      float4 v = ra[r];
+      if constexpr (MODE == 1) {
+        if constexpr (AFF) {   // zero padding applies AFTER the BatchNorm affine: out-of-image taps stay 0
+          const bool ok = (okA >> r) & 1u;
+          v.x = ok ? fmaf(v.x, sc4.x, sh4.x) : 0.f;
+          v.y = ok ? fmaf(v.y, sc4.y, sh4.y) : 0.f;
+          v.z = ok ? fmaf(v.z, sc4.z, sh4.z) : 0.f;
+          v.w = ok ? fmaf(v.w, sc4.w, sh4.w) : 0.f;
+        }
+      } else {
+        const uint32_t o = okA >> (4 * r);
+        const float s0 = has_aff ? sc4.x : 1.f, s1 = has_aff ? sc4.y : 1.f, s2 = has_aff ? sc4.z : 1.f, s3 = has_aff ? sc4.w : 1.f;
+        const float h0 = has_aff ? sh4.x : 0.f, h1 = has_aff ? sh4.y : 0.f, h2 = has_aff ? sh4.z : 0.f, h3 = has_aff ? sh4.w : 0.f;
+        v.x = (o & 1u) ? fmaf(v.x, s0, h0) : 0.f;
+        v.y = (o & 2u) ? fmaf(v.y, s1, h1) : 0.f;
+        v.z = (o & 4u) ? fmaf(v.z, s2, h2) : 0.f;
+        v.w = (o & 8u) ? fmaf(v.w, s3, h3) : 0.f;
+      }
+      *reinterpret_cast<float4*>(Ab + row * LDK + 4 * aq) = v;   // one ds_write_b128, no transposition
     }
-    float* Bb = Bs + buf * KC * LDB;
+    float* Bb = Bs + buf * BN * LDK;
 #pragma unroll
     for (int r = 0; r < QB; ++r) {
       const int idx = tid + r * NT;
       if (idx < NQB) {
-        const int krow = idx / BQ, nq = idx - krow * BQ;
-        float4 v;
-        v.x = okB[r][0] ? rb[r].x : 0.f;
-        v.y = okB[r][1] ? rb[r].y : 0.f;
-        v.z = okB[r][2] ? rb[r].z : 0.f;
-        v.w = okB[r][3] ? rb[r].w : 0.f;
-        *reinterpret_cast<float4*>(Bb + krow * LDB + 4 * nq) = v;
+        const int kq = idx / BN, nn = idx - kq * BN;
+        *reinterpret_cast<float4*>(Bb + nn * LDK + 4 * kq) = rb[r];
       }
     }
   };
@@ -241,8 +256,7 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
   const int ch_begin = blockIdx.z * p.cps;
   const int ch_end = min(ch_begin + p.cps, nchunks);
   if (ch_begin < ch_end) {
-    load_A(ch_begin * KC);
-    load_B(ch_begin * KC);
+    load_AB(ch_begin);
     store_AB(0);
   }
   __syncthreads();
@@ -250,34 +264,33 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
   for (int ch = ch_begin; ch < ch_end; ++ch) {
     const int buf = (ch - ch_begin) & 1;
     const bool more = (ch + 1) < ch_end;
-    if (more) {
-      load_A((ch + 1) * KC);
-      load_B((ch + 1) * KC);
-    }
+    if (more) load_AB(ch + 1);
     __builtin_amdgcn_sched_barrier(0);
-    const float* Ab = As + buf * KC * LDA + wm * (TM * 32) + li;
-    const float* Bb = Bs + buf * KC * LDB + wn * (TN * 32) + li;
+    const float* Ab = As + buf * BM * LDK + (wm * (TM * 32) + li) * LDK + 4 * lh;
+    const float* Bb = Bs + buf * BN * LDK + (wn * (TN * 32) + li) * LDK + 4 * lh;
 #pragma unroll
-    for (int kk = 0; kk < KC / 2; ++kk) {
-      float av[TM], bv[TN];
+    for (int g = 0; g < KC / 8; ++g) {
+      float4 av[TM], bv[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) av[i] = Ab[(2 * kk + lh) * LDA + i * 32];
+      for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDK + 8 * g);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bv[j] = Bb[(2 * kk + lh) * LDB + j * 32];
+      for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDK + 8 * g);
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32((&av[i].x)[q], (&bv[j].x)[q], acc[i][j], 0, 0, 0);
     }
-    // pin the order loads | MFMAs | selects+LDS writes: without it hipcc hoists part of store_AB() above the MFMA
-    // block and the vmcnt waits follow it there
+    // pin the order loads | MFMAs | affine + LDS writes: otherwise hipcc hoists part of store_AB() (and its vmcnt
+    // waits) above the MFMA block
     __builtin_amdgcn_sched_barrier(0);
     if (more) store_AB(buf ^ 1);
     __syncthreads();
   }
 
-  // ---- split-K: leave the raw partial sums, conv_finish_kernel applies the epilogue --------------------
+  // ---- split-K: leave the raw partial sums, conv_finish_kernel applies the epilogue ---------------------------------
   if (p.splits > 1) {
     float* part = a.partial + (int64_t)blockIdx.z * p.Mtot * Ntot;
 #pragma unroll
@@ -295,7 +308,7 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
     return;
   }
 
-  // ---- epilogue ---------------------------------------------------------------------------------
+  // ---- epilogue ------------------------------------------------------------------------------------------------------
   const bool do_stats = a.stat_partials != nullptr;
   float s1[TN], s2[TN];
 #pragma unroll
@@ -303,84 +316,123 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
     s1[j] = 0.f;
     s2[j] = 0.f;
   }
-  // Per-column constants (this lane's TN columns), then the tile in groups of 4 consecutive rows: every read the
-  // epilogue needs (residual tensor, old output, statistics partner) is issued unconditionally from a clamped
-  // address for the whole group before anything is consumed, so a group costs one memory round trip, not sixteen.
-  const bool has_add = a.add != nullptr, has_so = a.stat_other != nullptr, scat = a.scatter2x2 != 0;
-  int cn[TN], cco[TN], cab[TN];
-  bool cok[TN];
-  float cbias[TN], casc[TN], cash[TN];
+  if constexpr (EPI == 0) {
+    // bias, ReLU, plain NHWC store, statistics of the stored value.  Out-of-range rows / columns get an out-of-range
+    // buffer offset: the store is dropped by the hardware, no branches.
+    __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)p.y_bytes, 0x00020000);
+    uint32_t cb[TN];
+    float cbias[TN];
+    bool cok[TN];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * (TN * 32) + j * 32 + li;
-    cok[j] = n < Ntot;
-    cn[j] = cok[j] ? n : 0;
-    cab[j] = scat ? cn[j] / p.Cout : 0;
-    cco[j] = scat ? cn[j] - cab[j] * p.Cout : cn[j];
-    cbias[j] = 0.f;
-    casc[j] = 1.f;
-    cash[j] = 0.f;
-    if (a.bias != nullptr) cbias[j] = a.bias[cco[j]];
-    if (has_add && a.add_scale != nullptr) {
-      casc[j] = a.add_scale[cn[j]];
-      cash[j] = a.add_shift[cn[j]];
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * (TN * 32) + j * 32 + li;
+      cok[j] = n < Ntot;
+      cb[j] = (uint32_t)n * 4u;
+      cbias[j] = (a.bias != nullptr && cok[j]) ? a.bias[n] : 0.f;
     }
-  }
+    const uint32_t ldyb = (uint32_t)a.ldy * 4u;
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int mb = m0 + wm * (TM * 32) + i * 32 + 8 * g + 4 * lh;   // rows mb..mb+3 <-> accumulator regs 4g..4g+3
-      int jx = 0, iy = 0, ni = 0;
-      if (scat) {
-        const int mm = min(mb, p.Mtot - 1);
-        jx = mm % p.Wg;
-        const int t = mm / p.Wg;
-        iy = t % p.Hg;
-        ni = t / p.Hg;
+      for (int g = 0; g < 4; ++g) {
+        const int mb = m0 + wm * (TM * 32) + i * 32 + 8 * g + 4 * lh;
+        const uint32_t rowb = (uint32_t)mb * ldyb;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const bool rok = (mb + rr) < p.Mtot;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            float v = acc[i][j][4 * g + rr] + cbias[j];
+            if (a.relu) v = fmaxf(v, 0.f);
+            const bool ok = rok && cok[j];
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsY, ok ? rowb + (uint32_t)rr * ldyb + cb[j] : OOB, 0, 0);
+            const float vm = ok ? v : 0.f;
+            s1[j] += vm;
+            s2[j] = fmaf(vm, vm, s2[j]);
+          }
+        }
       }
-      int64_t off[4][TN];
-      bool ok[4][TN];
-      float vadd[4][TN], vold[4][TN], vso[4][TN];
+    }
+  } else {
+    // Everything: per-column constants (this lane's TN columns), then the tile in groups of 4 consecutive rows; every
+    // read the epilogue needs (residual tensor, old output, statistics partner) is issued unconditionally from a clamped
+    // address for the whole group before anything is consumed: one memory round trip per group, not sixteen.
+    const bool has_add = a.add != nullptr, has_so = a.stat_other != nullptr, scat = a.scatter2x2 != 0;
+    int cn[TN], cco[TN], cab[TN];
+    bool cok[TN];
+    float cbias[TN], casc[TN], cash[TN];
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int m = mb + rr;
-        const bool rok = m < p.Mtot;
-        const int mc = rok ? m : 0;
-        const int64_t rowpix = ((int64_t)ni * a.Hout + 2 * iy) * a.Wout + 2 * jx;
-        if (scat) {   // next pixel of the gather grid
-          if (++jx == p.Wg) {
-            jx = 0;
-            if (++iy == p.Hg) {
-              iy = 0;
-              ++ni;
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * (TN * 32) + j * 32 + li;
+      cok[j] = n < Ntot;
+      cn[j] = cok[j] ? n : 0;
+      cab[j] = scat ? cn[j] / p.Cout : 0;
+      cco[j] = scat ? cn[j] - cab[j] * p.Cout : cn[j];
+      cbias[j] = 0.f;
+      casc[j] = 1.f;
+      cash[j] = 0.f;
+      if (a.bias != nullptr) cbias[j] = a.bias[cco[j]];
+      if (has_add && a.add_scale != nullptr) {
+        casc[j] = a.add_scale[cn[j]];
+        cash[j] = a.add_shift[cn[j]];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int mb = m0 + wm * (TM * 32) + i * 32 + 8 * g + 4 * lh;   // rows mb..mb+3 <-> accumulator regs 4g..4g+3
+        int jx = 0, iy = 0, ni = 0;
+        if (scat) {
+          const int mm = min(mb, p.Mtot - 1);
+          jx = mm % p.Wg;
+          const int t = mm / p.Wg;
+          iy = t % p.Hg;
+          ni = t / p.Hg;
+        }
+        int64_t off[4][TN];
+        bool ok[4][TN];
+        float vadd[4][TN], vold[4][TN], vso[4][TN];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int m = mb + rr;
+          const bool rok = m < p.Mtot;
+          const int mc = rok ? m : 0;
+          const int64_t rowpix = ((int64_t)ni * a.Hout + 2 * iy) * a.Wout + 2 * jx;
+          if (scat) {   // next pixel of the gather grid
+            if (++jx == p.Wg) {
+              jx = 0;
+              if (++iy == p.Hg) {
+                iy = 0;
+                ++ni;
+              }
             }
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            ok[rr][j] = rok && cok[j];
+            const int64_t o = scat ? (rowpix + (int64_t)(cab[j] >> 1) * a.Wout + (cab[j] & 1)) * a.ldy + cco[j]
+                                   : (int64_t)mc * a.ldy + cn[j];
+            off[rr][j] = ok[rr][j] ? o : 0;
+            vadd[rr][j] = has_add ? a.add[ok[rr][j] ? ((int64_t)mc * a.ldadd + cn[j]) : 0] : 0.f;
+            vold[rr][j] = a.accumulate ? a.y[off[rr][j]] : 0.f;
+            vso[rr][j] = has_so ? a.stat_other[ok[rr][j] ? ((int64_t)mc * a.ldso + cn[j]) : 0] : 0.f;
           }
         }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          ok[rr][j] = rok && cok[j];
-          const int64_t o = scat ? (rowpix + (int64_t)(cab[j] >> 1) * a.Wout + (cab[j] & 1)) * a.ldy + cco[j]
-                                 : (int64_t)mc * a.ldy + cn[j];
-          off[rr][j] = ok[rr][j] ? o : 0;
-          vadd[rr][j] = has_add ? a.add[ok[rr][j] ? ((int64_t)mc * a.ldadd + cn[j]) : 0] : 0.f;
-          vold[rr][j] = a.accumulate ? a.y[off[rr][j]] : 0.f;
-          vso[rr][j] = has_so ? a.stat_other[ok[rr][j] ? ((int64_t)mc * a.ldso + cn[j]) : 0] : 0.f;
-        }
-      }
+        for (int rr = 0; rr < 4; ++rr) {
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          float v = acc[i][j][4 * g + rr] + cbias[j];
-          if (a.relu) v = fmaxf(v, 0.f);
-          if (has_add) v += fmaf(vadd[rr][j], casc[j], cash[j]);
-          if (a.accumulate) v += vold[rr][j];
-          if (ok[rr][j]) a.y[off[rr][j]] = v;
-          const float vm = ok[rr][j] ? v : 0.f;
-          const float u = ok[rr][j] ? (has_so ? vso[rr][j] : v) : 0.f;
-          s1[j] += vm;
-          s2[j] = fmaf(vm, u, s2[j]);
+          for (int j = 0; j < TN; ++j) {
+            float v = acc[i][j][4 * g + rr] + cbias[j];
+            if (a.relu) v = fmaxf(v, 0.f);
+            if (has_add) v += fmaf(vadd[rr][j], casc[j], cash[j]);
+            if (a.accumulate) v += vold[rr][j];
+            if (ok[rr][j]) a.y[off[rr][j]] = v;
+            const float vm = ok[rr][j] ? v : 0.f;
+            const float u = ok[rr][j] ? (has_so ? vso[rr][j] : v) : 0.f;
+            s1[j] += vm;
+            s2[j] = fmaf(vm, u, s2[j]);
+          }
         }
       }
     }
@@ -495,9 +547,9 @@ static void cfg_tile(ConvCfg c, int* bm, int* bn) {
 
 // Largest tile that still gives the 256 CUs a few workgroups each.  Problems too small for that keep the 64x64 tile
 // and are cut along K instead (split-K, see pick_splits): deep U-Net levels are M = 576..2304 pixels x K = 4608..9216.
-static ConvCfg pick_cfg(int64_t M, int Ntot, bool vec = true) {
+static ConvCfg pick_cfg(int64_t M, int Ntot, bool fast = true) {
   const int64_t want = 1024;
-  if (!vec) return CFG_64x64;   // scalar-gather variant (Cin % 4 != 0: the network's first layer) exists for one tile only
+  if (!fast) return CFG_64x64;   // the general-gather variant exists for one tile only
   if (Ntot <= 32) {
     if (ceil_div(M, 256) >= want / 2) return CFG_256x32;
     return (M > 32) ? CFG_64x64 : CFG_32x64;
@@ -519,13 +571,19 @@ static int pick_splits(int64_t M, int Ntot, int Ktot, ConvCfg cfg) {
   return s < 1 ? 1 : (int)s;
 }
 
-template <int WM, int WN, int TM, int TN, bool VEC>
+template <int WM, int WN, int TM, int TN, int MODE, bool AFF, int EPI>
 static int launch(const ConvK& k, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  const size_t lds = (size_t)(2 * KC * (BM + 4) + 2 * KC * (BN + 4)) * sizeof(float);
+  const size_t lds = (size_t)(2 * (BM + BN) * (KC + 4)) * sizeof(float);
   dim3 grid((unsigned)ceil_div(k.Mtot, BM), (unsigned)ceil_div(k.a.Ntot, BN), (unsigned)k.splits);
-  hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, TM, TN, VEC>), grid, dim3(WM * WN * 64), lds, s, k);
+  hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, TM, TN, MODE, AFF, EPI>), grid, dim3(WM * WN * 64), lds, s, k);
   return check_launch("dfl_conv2d");
+}
+
+template <int WM, int WN, int TM, int TN>
+static int launch_fast(const ConvK& k, bool aff, bool general, hipStream_t s) {
+  if (aff) return general ? launch<WM, WN, TM, TN, 1, true, 1>(k, s) : launch<WM, WN, TM, TN, 1, true, 0>(k, s);
+  return general ? launch<WM, WN, TM, TN, 1, false, 1>(k, s) : launch<WM, WN, TM, TN, 1, false, 0>(k, s);
 }
 
 static int prepare(const dfl_conv_args* a, ConvK* k) {
@@ -535,6 +593,7 @@ static int prepare(const dfl_conv_args* a, ConvK* k) {
   DFL_REQUIRE(a->KH > 0 && a->KW > 0 && a->stride > 0 && a->pad >= 0, "dfl_conv2d: bad window");
   DFL_REQUIRE(a->KH * a->KW <= 31, "dfl_conv2d: at most 31 taps");
   DFL_REQUIRE(a->ldx >= a->Cin, "dfl_conv2d: ldx < Cin");
+  DFL_REQUIRE(aligned16(a->w), "dfl_conv2d: packed weights must be 16-byte aligned");
   DFL_REQUIRE((a->in_scale == nullptr) == (a->in_shift == nullptr), "dfl_conv2d: in_scale/in_shift go together");
   DFL_REQUIRE((a->add_scale == nullptr) == (a->add_shift == nullptr), "dfl_conv2d: add_scale/add_shift go together");
   k->a = *a;
@@ -560,9 +619,17 @@ static int prepare(const dfl_conv_args* a, ConvK* k) {
   DFL_REQUIRE(M < (1ll << 31) && (int64_t)a->N * a->Hin * a->Win < (1ll << 31), "dfl_conv2d: too many pixels");
   k->Mtot = (int)M;
   k->Ktot = a->KH * a->KW * a->Cin;
-  k->vecA = (a->Cin % 4 == 0) && (a->ldx % 4 == 0) && aligned16(a->x) &&
+  // byte extents as seen from the pointers (buffer descriptors of the fast path; all must stay below 2 GiB)
+  const int64_t xb = (((int64_t)a->N * a->Hin * a->Win - 1) * a->ldx + a->Cin) * 4;
+  const int64_t wb = ceil_div(k->Ktot, 4) * (int64_t)a->Ntot * 16;
+  const int64_t yb = a->scatter2x2 ? (((int64_t)a->N * a->Hout * a->Wout - 1) * a->ldy + k->Cout) * 4
+                                   : ((M - 1) * a->ldy + a->Ntot) * 4;
+  const int64_t lim = (1ll << 31) - 4096;
+  k->fast = (a->Cin % KC == 0) && (a->ldx % 4 == 0) && aligned16(a->x) && xb < lim && wb < lim && yb < lim &&
             (a->in_scale == nullptr || (aligned16(a->in_scale) && aligned16(a->in_shift)));
-  k->vecB = (a->Ntot % 4 == 0) && aligned16(a->w);
+  k->x_bytes = (uint32_t)(xb < lim ? xb : 0);
+  k->w_bytes = (uint32_t)(wb < lim ? wb : 0);
+  k->y_bytes = (uint32_t)(yb < lim ? yb : 0);
   k->splits = 1;
   k->cps = (int)ceil_div(k->Ktot, KC);
   return DFL_OK;
@@ -581,8 +648,7 @@ extern "C" int dfl_conv_suggest_splits(const dfl_conv_args* a) {
   dfl::ConvK k;
   int rc = dfl::prepare(a, &k);
   if (rc != DFL_OK) return rc;
-  const bool vec = k.vecA && k.vecB;
-  return dfl::pick_splits(k.Mtot, a->Ntot, k.Ktot, dfl::pick_cfg(k.Mtot, a->Ntot, vec));
+  return dfl::pick_splits(k.Mtot, a->Ntot, k.Ktot, dfl::pick_cfg(k.Mtot, a->Ntot, k.fast));
 }
 
 extern "C" int dfl_conv_grid_m(const dfl_conv_args* a) {
@@ -591,7 +657,7 @@ extern "C" int dfl_conv_grid_m(const dfl_conv_args* a) {
   if (rc != DFL_OK) return rc;
   if (a->splits > 1) return dfl::finish_rows(k.Mtot, a->Ntot);
   int bm, bn;
-  dfl::cfg_tile(dfl::pick_cfg(k.Mtot, a->Ntot, k.vecA && k.vecB), &bm, &bn);
+  dfl::cfg_tile(dfl::pick_cfg(k.Mtot, a->Ntot, k.fast), &bm, &bn);
   return (int)dfl::ceil_div(k.Mtot, bm);
 }
 
@@ -599,7 +665,7 @@ extern "C" int dfl_conv_config(const dfl_conv_args* a) {
   dfl::ConvK k;
   int rc = dfl::prepare(a, &k);
   if (rc != DFL_OK) return rc;
-  return (int)dfl::pick_cfg(k.Mtot, a->Ntot, k.vecA && k.vecB);
+  return (int)dfl::pick_cfg(k.Mtot, a->Ntot, k.fast);
 }
 
 extern "C" int dfl_conv2d(const dfl_conv_args* a, dfl_stream_t stream) {
@@ -614,15 +680,17 @@ extern "C" int dfl_conv2d(const dfl_conv_args* a, dfl_stream_t stream) {
     k.splits = a->splits;
     k.cps = (int)dfl::ceil_div(nchunks, a->splits);
   }
-  if (!(k.vecA && k.vecB)) {
-    rc = dfl::launch<2, 2, 1, 1, false>(k, s);
+  const bool general = a->add != nullptr || a->accumulate || a->stat_other != nullptr || a->scatter2x2;
+  const bool aff = a->in_scale != nullptr;
+  if (!k.fast) {
+    rc = dfl::launch<2, 2, 1, 1, 0, true, 1>(k, s);
   } else {
     switch (dfl::pick_cfg(k.Mtot, a->Ntot)) {
-      case dfl::CFG_128x128: rc = dfl::launch<2, 2, 2, 2, true>(k, s); break;
-      case dfl::CFG_128x64: rc = dfl::launch<2, 2, 2, 1, true>(k, s); break;
-      case dfl::CFG_256x32: rc = dfl::launch<4, 1, 2, 1, true>(k, s); break;
-      case dfl::CFG_64x64: rc = dfl::launch<2, 2, 1, 1, true>(k, s); break;
-      default: rc = dfl::launch<1, 2, 1, 1, true>(k, s); break;
+      case dfl::CFG_128x128: rc = dfl::launch_fast<2, 2, 2, 2>(k, aff, general, s); break;
+      case dfl::CFG_128x64: rc = dfl::launch_fast<2, 2, 2, 1>(k, aff, general, s); break;
+      case dfl::CFG_256x32: rc = dfl::launch_fast<4, 1, 2, 1>(k, aff, general, s); break;
+      case dfl::CFG_64x64: rc = dfl::launch_fast<2, 2, 1, 1>(k, aff, general, s); break;
+      default: rc = dfl::launch_fast<1, 2, 1, 1>(k, aff, general, s); break;
     }
   }
   if (rc != DFL_OK || k.splits <= 1) return rc;

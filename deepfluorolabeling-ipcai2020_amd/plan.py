@@ -80,36 +80,31 @@ class UNetPlan:
         return Act(t, t.data_ptr(), C, N, H, W, C)
 
     # ------------------------------------------------------------------------------------------ weights
-    def _pack(self, src, D, s, off=0):
-        """Register a re-layout job; returns the destination tensor [D0][D1][D2]."""
-        dst = self._new(D[0] * D[1] * D[2])
-        self._pack_jobs.append((src, dst, off, D, s))
+    def _pack(self, w, kind, flip=0):
+        """Register a re-layout job of parameter w = [A][B][KH][KW] into the quad-packed GEMM operand dfl_conv2d reads
+        (include/dfl_hip.h, dfl_pack_job); returns the destination tensor."""
+        A, B, KH, KW = w.shape
+        Cc = KH * KW
+        K = {1: Cc * B, 2: Cc * A, 3: A}[kind]
+        N = {1: A, 2: B, 3: Cc * B}[kind]
+        dst = self._new((K + 3) // 4 * N * 4)
+        self._pack_jobs.append((w, dst, A, B, Cc, kind, flip))
         return dst
 
-    def _pack_conv_fwd(self, w):      # [Co][Ci][KH][KW] -> [T][Ci][Co]
-        Co, Ci, KH, KW = w.shape
-        T = KH * KW
-        return self._pack(w, (T, Ci, Co), (1, T, Ci * T))
+    def _pack_conv_fwd(self, w):      # Conv2d [Co][Ci][T]: k = (tap, ci), n = co
+        return self._pack(w, 1)
 
-    def _pack_conv_dgrad(self, w):    # stride-1 conv: [Co][Ci][T] -> [T flipped][Co][Ci]
-        Co, Ci, KH, KW = w.shape
-        T = KH * KW
-        return self._pack(w, (T, Co, Ci), (-1, Ci * T, T), off=T - 1)
+    def _pack_conv_dgrad(self, w):    # stride-1 Conv2d data gradient: k = (flipped tap, co), n = ci
+        return self._pack(w, 2, flip=1)
 
-    def _pack_down_dgrad(self, w):    # conv2x2 s2: [Co][Ci][ab] -> [Co][ab][Ci] (scatter form)
-        Co, Ci, KH, KW = w.shape
-        T = KH * KW
-        return self._pack(w, (Co, T, Ci), (Ci * T, 1, T))
+    def _pack_down_dgrad(self, w):    # Conv2d(k2,s2) data gradient, scatter form: k = co, n = (ab, ci)
+        return self._pack(w, 3)
 
-    def _pack_convT_fwd(self, w):     # [Ci][Co][ab] -> [Ci][ab][Co] (scatter form)
-        Ci, Co, KH, KW = w.shape
-        T = KH * KW
-        return self._pack(w, (Ci, T, Co), (Co * T, 1, T))
+    def _pack_convT_fwd(self, w):     # ConvTranspose2d [Ci][Co][ab], scatter form: k = ci, n = (ab, co)
+        return self._pack(w, 3)
 
-    def _pack_convT_dgrad(self, w):   # [Ci][Co][ab] -> [ab][Co][Ci]
-        Ci, Co, KH, KW = w.shape
-        T = KH * KW
-        return self._pack(w, (T, Co, Ci), (1, T, Co * T))
+    def _pack_convT_dgrad(self, w):   # ConvTranspose2d data gradient = conv 2x2 s2 over dy: k = (ab, co), n = ci
+        return self._pack(w, 1)
 
     def _finish_pack(self):
         n = len(self._pack_jobs)
@@ -118,11 +113,10 @@ class UNetPlan:
             return
         arr = (PackJob * n)()
         mx = 0
-        for i, (src, dst, off, D, s) in enumerate(self._pack_jobs):
-            arr[i].src, arr[i].dst, arr[i].off = src.data_ptr(), dst.data_ptr(), off
-            arr[i].D0, arr[i].D1, arr[i].D2 = D
-            arr[i].s0, arr[i].s1, arr[i].s2 = s
-            mx = max(mx, D[0] * D[1] * D[2])
+        for i, (src, dst, A, B, Cc, kind, flip) in enumerate(self._pack_jobs):
+            arr[i].src, arr[i].dst = src.data_ptr(), dst.data_ptr()
+            arr[i].A, arr[i].B, arr[i].C, arr[i].kind, arr[i].flip = A, B, Cc, kind, flip
+            mx = max(mx, A * B * Cc)
         raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
         self._jobs_dev = torch.from_numpy(raw).to(self.dev)
         self._keep.append(self._jobs_dev)
@@ -336,8 +330,7 @@ class UNetPlan:
                 if do_res:
                     self._wgrad(bwd, xin, dout, G[prefix + '.res_conv1x1.weight'], 1, 1, 1, 0, xin.H, xin.W)
                     if dxin is not None:
-                        # 1x1 data gradient: B[k=co][n=ci] is the weight tensor itself
-                        self._conv(bwd, dout, rw, dxin, 1, 1, 1, 0, xin.C)
+                        self._conv(bwd, dout, self._pack_conv_dgrad(rw), dxin, 1, 1, 1, 0, xin.C)
                         wrote_dxin = True
                 g = dout
                 for d in reversed(range(bd)):

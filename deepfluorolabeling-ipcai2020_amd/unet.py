@@ -85,15 +85,28 @@ class _UNetFn(torch.autograd.Function):
             dheat = dheat.contiguous()
         hb.dheat = nat.ptr(dheat)
         stream = torch.cuda.current_stream().cuda_stream
+        params = net._param_list
+        # a .grad that still aliases this plan's arena (no zero_grad since the last backward) would be overwritten by
+        # the program: detach it into its own storage first so that accumulation adds old + new
+        lo = plan.grad_flat.data_ptr()
+        hi = lo + 4 * plan.grad_flat.numel()
+        for p in params:
+            if p.grad is not None and lo <= p.grad.data_ptr() < hi:
+                p.grad = p.grad.clone()
         net._backward_runner(plan, stream)
         plan.busy = False
         grads = plan.grads()
-        # the gradients are views of the plan's flat arena; if .grad already holds such a view (no zero_grad since
-        # the previous backward) autograd would add a buffer to itself, so hand out copies in that case
-        if any(p.grad is not None for p in net._param_list):
-            grads = [None if g is None else g.clone() for g in grads]
+        # Fast hand-off: the gradients are views of the plan's flat arena.  Returning them makes autograd's
+        # AccumulateGrad clone every one (135 small copies per step), so when no parameter has hooks and every .grad
+        # is empty (the zero_grad() -> backward() pattern of train.py:405-422) the views are installed as .grad
+        # directly and autograd gets None.  Otherwise the views are returned and autograd accumulates them.
+        if net.direct_grad and all(p.grad is None and not p._backward_hooks for p in params):
+            for g, p in zip(grads, params):
+                if g is not None and p.requires_grad:
+                    p.grad = g
+            return (None, None, None) + (None,) * len(params)
         out = []
-        for g, p in zip(grads, net._param_list):
+        for g, p in zip(grads, params):
             out.append(g if p.requires_grad else None)
         return (None, None, None) + tuple(out)
 
@@ -149,6 +162,7 @@ class UNet(nn.Module):
         self._pack_version = None
         self._backward_runner = self._run_backward
         self.dp = None                                # set by parallel.DataParallel
+        self.direct_grad = True                       # install gradient views as .grad without autograd copies
 
     # ---------------------------------------------------------------------------------------------- plumbing
     def _apply(self, fn, *a, **k):

@@ -48,7 +48,7 @@ int dfl_sizeof(int which);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Convolution as a gather-GEMM on the fp32 matrix cores.
- *   y[m, n] = epilogue( sum_{t < KH*KW} sum_{c < Cin} X(m, t, c) * w[(t*Cin + c)*Ntot + n] )
+ *   y[m, n] = epilogue( sum_{t < KH*KW} sum_{c < Cin} X(m, t, c) * W(k = t*Cin + c, n) )
  * m runs over the N*Hout*Wout output pixels; X(m,t,c) is the input at pixel (oy*stride - pad + t/KW,
  * ox*stride - pad + t%KW), channel c, after the optional per-channel affine in_scale/in_shift (BatchNorm
  * applied on load), and 0 outside the image (zero padding is applied AFTER the affine, as the reference pads
@@ -62,7 +62,7 @@ int dfl_sizeof(int which);
  * ------------------------------------------------------------------------------------------------------------ */
 typedef struct {
   const float* x;        /* input activations, NHWC, pixel stride ldx */
-  const float* w;        /* packed weights [KH*KW*Cin][Ntot] (dfl_pack_weights) */
+  const float* w;        /* quad-packed weights [ceil(KH*KW*Cin/4)][Ntot][4] (dfl_pack_weights), 16-byte aligned */
   const float* bias;     /* [Ntot / (scatter2x2 ? 4 : 1)] or NULL */
   const float* in_scale; /* [Cin] or NULL */
   const float* in_shift; /* [Cin] or NULL (required when in_scale is given) */
@@ -123,20 +123,25 @@ int dfl_wgrad_suggest_splits(const dfl_wgrad_args* a);
 int dfl_sum_partials(const float* src, float* dst, int64_t n, int32_t splits, dfl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
- * Batched weight re-layout (one launch for the whole network).  Job j copies
- *   dst[(i0*D1 + i1)*D2 + i2] = src[off + i0*s0 + i1*s1 + i2*s2]        (strides may be negative)
- * which turns torch's [Cout][Cin][KH][KW] / [Cin][Cout][2][2] parameters into the [K][Ntot] matrices
- * dfl_conv2d consumes (forward, flipped+transposed data-gradient, scatter forms).
+ * Batched weight re-layout (one launch for the whole network).  dfl_conv2d consumes its weights "quad-packed":
+ *   w[(k/4)*Ntot*4 + n*4 + k%4] = W(k, n),  k < K = taps*Cin rounded up to a multiple of 4 with zeros,
+ * i.e. one float4 holds four consecutive k of one output column.  Job j builds that matrix from a contiguous
+ * parameter src[A][B][C] (C = KH*KW) with one of three index maps:
+ *   kind 1: k = c*B + b,  n = a        forward operand of Conv2d        (src [Cout][Cin][T])
+ *                                      data gradient of ConvTranspose2d (src [Cin][Cout][T]: k = (tap,co), n = ci)
+ *   kind 2: k = c'*A + a, n = b        data gradient of a stride-1 Conv2d (src [Cout][Cin][T]); flip: c = C-1-c'
+ *   kind 3: k = a,  n = c*B + b        scatter forms: ConvTranspose2d forward (src [Cin][Cout][4]) and the data
+ *                                      gradient of Conv2d(k2,s2) (src [Cout][Cin][4])
  * ------------------------------------------------------------------------------------------------------------ */
 typedef struct {
   const float* src;
-  float* dst;
-  int64_t off;
-  int32_t D0, D1, D2;
-  int32_t s0, s1, s2;
+  float* dst;            /* ceil(K/4) * Ntot * 4 floats */
+  int32_t A, B, C;
+  int32_t kind, flip;
+  int32_t reserved;
 } dfl_pack_job;
 
-/* jobs: DEVICE pointer to njobs dfl_pack_job records; max_elems = max over jobs of D0*D1*D2. */
+/* jobs: DEVICE pointer to njobs dfl_pack_job records; max_elems = max over jobs of A*B*C. */
 int dfl_pack_weights(const dfl_pack_job* jobs_dev, int32_t njobs, int64_t max_elems, dfl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------

@@ -28,14 +28,18 @@ def nchw(t):
     return t.permute(0, 3, 1, 2).contiguous()
 
 
-def pack(src, D, s, off=0):
-    """Run one dfl_pack_weights job on the device."""
+def pack(w, kind, flip=0):
+    """Run one dfl_pack_weights job on the device: parameter [A][B][KH][KW] -> quad-packed GEMM operand."""
     lib = nat.lib()
-    src = src.to(DEV).contiguous()
-    dst = torch.empty(D[0] * D[1] * D[2], device=DEV)
-    job = nat.PackJob(src=src.data_ptr(), dst=dst.data_ptr(), off=off, D0=D[0], D1=D[1], D2=D[2], s0=s[0], s1=s[1], s2=s[2])
+    src = w.to(DEV).contiguous()
+    A, B, KH, KW = w.shape
+    Cc = KH * KW
+    K = {1: Cc * B, 2: Cc * A, 3: A}[kind]
+    N = {1: A, 2: B, 3: Cc * B}[kind]
+    dst = torch.full(((K + 3) // 4 * N * 4,), float('nan'), device=DEV)
+    job = nat.PackJob(src=src.data_ptr(), dst=dst.data_ptr(), A=A, B=B, C=Cc, kind=kind, flip=flip)
     jobs = torch.from_numpy(np.frombuffer(bytes(job), dtype=np.uint8).copy()).to(DEV)
-    nat.check(lib.dfl_pack_weights(jobs.data_ptr(), 1, D[0] * D[1] * D[2], stream()))
+    nat.check(lib.dfl_pack_weights(jobs.data_ptr(), 1, A * B * Cc, stream()))
     torch.cuda.synchronize()
     return dst
 
@@ -102,6 +106,31 @@ def conv_call(x, wp, Ntot, KH, KW, stride, pad, Hout, Wout, bias=None, in_aff=No
     return (y, part.cpu().double().sum(0)) if stats else y
 
 
+@pytest.mark.parametrize('shape', [(64, 32, 3), (48, 20, 3), (7, 5, 3), (32, 1, 3), (128, 64, 1), (16, 16, 2), (6, 10, 2)])
+def test_pack_weights_layout(shape):
+    """All three index maps of dfl_pack_weights (tiled and element-wise paths) against a numpy construction."""
+    A, B, KK = shape
+    g = torch.Generator().manual_seed(A + B)
+    w = torch.randn(A, B, KK, KK, generator=g)
+    Cc = KK * KK
+    wn = w.reshape(A, B, Cc).numpy()
+    for kind, flip in ((1, 0), (2, 1), (2, 0), (3, 0)):
+        if kind == 1:
+            W = wn.transpose(2, 1, 0).reshape(Cc * B, A)                       # k = c*B + b, n = a
+        elif kind == 2:
+            src = wn[:, :, ::-1] if flip else wn
+            W = src.transpose(2, 0, 1).reshape(Cc * A, B)                      # k = c'*A + a, n = b
+        else:
+            W = wn.transpose(0, 2, 1).reshape(A, Cc * B)                       # k = a, n = c*B + b
+        K, N = W.shape
+        Kq = (K + 3) // 4
+        ref = np.zeros((Kq * 4, N), dtype=np.float32)
+        ref[:K] = W
+        ref = ref.reshape(Kq, 4, N).transpose(0, 2, 1).reshape(-1)
+        got = pack(w, kind, flip).cpu().numpy()
+        assert np.array_equal(got, ref), (shape, kind, flip)
+
+
 CONV_CASES = [
     # N, Cin, Cout, H, W, K, stride, pad
     (2, 8, 16, 12, 12, 3, 1, 1),
@@ -128,7 +157,7 @@ def test_conv_fwd_plain(case):
     w = torch.randn(Cout, Cin, K, K, generator=g) / math.sqrt(Cin * K * K)
     b = torch.randn(Cout, generator=g)
     T = K * K
-    wp = pack(w, (T, Cin, Cout), (1, T, Cin * T))
+    wp = pack(w, 1)
     ref = F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=pad)
     Ho, Wo = ref.shape[2], ref.shape[3]
     y = conv_call(x, wp, Cout, K, K, stride, pad, Ho, Wo, bias=b)
@@ -143,7 +172,7 @@ def test_conv_fwd_fused_epilogue_and_prologue():
     sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g)
     w = torch.randn(Cout, Cin, 3, 3, generator=g) / 12
     b = torch.randn(Cout, generator=g)
-    wp = pack(w, (9, Cin, Cout), (1, 9, Cin * 9))
+    wp = pack(w, 1)
     xa = x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
     ref = F.relu(F.conv2d(xa, w.double(), b.double(), padding=1))
     y, st = conv_call(x, wp, Cout, 3, 3, 1, 1, H, W, bias=b, in_aff=(sc, sh), relu=1, stats=True)
@@ -152,7 +181,7 @@ def test_conv_fwd_fused_epilogue_and_prologue():
     np.testing.assert_allclose(st[1].numpy(), (ref * ref).sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
     # residual: y = conv1x1(x) + bias + (r*s2 + t2), into a wider buffer (ldy > Cout), input with ldx > Cin
     w1 = torch.randn(Cout, Cin, 1, 1, generator=g) / 4
-    w1p = pack(w1, (1, Cin, Cout), (1, 1, Cin))
+    w1p = pack(w1, 1)
     r = torch.randn(N, Cout, H, W, generator=g)
     s2, t2 = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
     ref2 = F.conv2d(x.double(), w1.double(), b.double()) + r.double() * s2.double().view(1, -1, 1, 1) + t2.double().view(1, -1, 1, 1)
@@ -175,7 +204,7 @@ def test_conv_split_k():
     sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g)
     w = torch.randn(Cout, Cin, 3, 3, generator=g) / 48
     b = torch.randn(Cout, generator=g)
-    wp = pack(w, (9, Cin, Cout), (1, 9, Cin * 9))
+    wp = pack(w, 1)
     xa = x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
     ref = F.relu(F.conv2d(xa, w.double(), b.double(), padding=1))
     for fs in (None, 2, 7):
@@ -197,7 +226,7 @@ def test_conv_split_k():
     # transposed conv through split-K
     wt = torch.randn(Cin, 64, 2, 2, generator=g) / 16
     bt = torch.randn(64, generator=g)
-    wtp = pack(wt, (Cin, 4, 64), (64 * 4, 1, 4))
+    wtp = pack(wt, 3)
     reft = F.conv_transpose2d(x.double(), wt.double(), bt.double(), stride=2)
     yt = conv_call(x, wtp, 4 * 64, 1, 1, 1, 0, 2 * H, 2 * W, bias=bt, scatter=1, force_splits=2)
     np.testing.assert_allclose(nchw(yt).numpy(), reft.numpy(), rtol=2e-5, atol=2e-5)
@@ -210,7 +239,7 @@ def test_conv_transpose_scatter(shape):
     x = torch.randn(N, Cin, H, W, generator=g)
     w = torch.randn(Cin, Cout, 2, 2, generator=g) / 4
     b = torch.randn(Cout, generator=g)
-    wp = pack(w, (Cin, 4, Cout), (Cout * 4, 1, 4))
+    wp = pack(w, 3)
     ref = F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2)
     y = conv_call(x, wp, 4 * Cout, 1, 1, 1, 0, 2 * H, 2 * W, bias=b, scatter=1, ldy=2 * Cout)
     np.testing.assert_allclose(nchw(y).numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
@@ -226,7 +255,7 @@ def test_dgrad_forms():
         y = F.conv2d(x, w, padding=pad)
         dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
         y.backward(dy)
-        wd = pack(w.float(), (9, Co, Ci), (-1, Ci * 9, 9), off=8)
+        wd = pack(w.float(), 2, flip=1)
         dx = conv_call(dy.float(), wd, Ci, 3, 3, 1, 2 - pad, H, W)
         np.testing.assert_allclose(nchw(dx).numpy(), x.grad.numpy(), rtol=2e-5, atol=2e-5)
     # conv2x2 stride 2 (odd input: last row/col get no gradient; accumulate keeps what was there)
@@ -235,7 +264,7 @@ def test_dgrad_forms():
     y = F.conv2d(x, w, stride=2)
     dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
     y.backward(dy)
-    wd = pack(w.float(), (Ci, 4, Ci), (Ci * 4, 1, 4))
+    wd = pack(w.float(), 3)
     base = torch.randn(N, Ci, H, W, generator=g)
     dx = conv_call(dy.float(), wd, 4 * Ci, 1, 1, 1, 0, H, W, scatter=1, y_init=base, accumulate=1)
     np.testing.assert_allclose(nchw(dx).numpy(), (x.grad + base.double()).numpy(), rtol=2e-5, atol=2e-5)
@@ -245,7 +274,7 @@ def test_dgrad_forms():
     y = F.conv_transpose2d(x, w, stride=2)
     dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
     y.backward(dy)
-    wd = pack(w.float(), (4, Co, Ci), (1, 4, Co * 4))
+    wd = pack(w.float(), 1)
     dx = conv_call(dy.float(), wd, Ci, 2, 2, 2, 0, 4, 5)
     np.testing.assert_allclose(nchw(dx).numpy(), x.grad.numpy(), rtol=2e-5, atol=2e-5)
 

@@ -137,7 +137,14 @@ def test_paper_golden(name):
         assert abs(got - ref) <= 2e-2 * max(ref, 1e-7), '%s: grad norm %.6e vs fp64 reference %.6e' % (k, got, ref)
         gk = 'g64/' + k
         if gk in g:
-            rel_close(p.grad.cpu().numpy(), g[gk], 2e-2, 'grad ' + k)
+            # element-wise check on the small tensors: relative L2 (the measure BASELINE.md quotes for the reference's
+            # own fp32-vs-fp64 gap: 3e-3 median, 7e-3 worst) plus a looser max-abs bound; the pre-BatchNorm conv
+            # biases are sums over ~10^5 pixels that cancel to ~1e-5, i.e. mostly rounding noise of the fp32 forward
+            ref_g = g[gk]
+            diff = p.grad.cpu().numpy().astype(np.float64) - ref_g
+            l2 = float(np.linalg.norm(diff) / max(np.linalg.norm(ref_g), 1e-12))
+            assert l2 <= 2e-2, '%s: relative L2 error %.3e' % (k, l2)
+            rel_close(p.grad.cpu().numpy(), ref_g, 8e-2, 'grad ' + k)
 
 
 def test_training_trajectory_matches_reference():
@@ -282,13 +289,21 @@ def test_repeated_forward_and_grad_accumulation():
     s1 = o1[0].detach().clone()
     o2 = net(x * 0.5)
     assert torch.equal(o1[0].detach(), s1)
-    (o2[0].sum() + o2[1].sum()).backward()
-    g1 = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
-    o3 = net(x * 0.5)
-    (o3[0].sum() + o3[1].sum()).backward()
+    w = torch.linspace(0.5, 1.5, o2[0].numel(), device=DEV).view_as(o2[0])
+
+    def grads_of(inp):
+        net.zero_grad()
+        o = net(inp)
+        ((o[0] * w).sum() + o[1].sum()).backward()
+        return {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+    ga, gb = grads_of(x * 0.5), grads_of(x * 0.25 + 0.1)
+    net.zero_grad()
+    for inp in (x * 0.5, x * 0.25 + 0.1):               # two backward passes, no zero_grad in between
+        o = net(inp)
+        ((o[0] * w).sum() + o[1].sum()).backward()
     for k, p in net.named_parameters():
         if p.grad is not None:
-            rel_close(p.grad.cpu().numpy(), 2 * g1[k].cpu().numpy(), 1e-3, 'accumulated grad ' + k)
+            rel_close(p.grad.cpu().numpy(), (ga[k] + gb[k]).cpu().numpy(), 1e-3, 'accumulated grad ' + k)
 
 
 def test_cpu_input_fails_loudly():

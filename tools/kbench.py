@@ -20,6 +20,7 @@ def main():
     N, H, W, Cin, Cout, K = [int(v) for v in sys.argv[2:8]]
     stride = int(sys.argv[8]) if len(sys.argv) > 8 else 1
     reps = int(sys.argv[9]) if len(sys.argv) > 9 else 20
+    flags = sys.argv[10] if len(sys.argv) > 10 else 'sabr'      # s: statistics, a: input affine, b: bias, r: relu
     lib = nat.lib()
     dev = 'cuda'
     pad = 1 if K == 3 else 0
@@ -39,10 +40,16 @@ def main():
         if sp > 1:
             part = torch.empty(sp * N * Ho * Wo * Cout, device=dev)
             a.splits, a.partial = sp, part.data_ptr()
-        gm = lib.dfl_conv_grid_m(C.addressof(a))
-        stats = torch.empty(gm * 2 * Cout, device=dev)
-        a.stat_partials = stats.data_ptr()
-        fn, desc = lib.dfl_conv2d, 'cfg %d splits %d' % (lib.dfl_conv_config(C.addressof(a)), sp)
+        if 'a' not in flags:
+            a.in_scale = a.in_shift = None
+        if 'b' not in flags:
+            a.bias = None
+        a.relu = int('r' in flags)
+        if 's' in flags:
+            gm = lib.dfl_conv_grid_m(C.addressof(a))
+            stats = torch.empty(gm * 2 * Cout, device=dev)
+            a.stat_partials = stats.data_ptr()
+        fn, desc = lib.dfl_conv2d, 'cfg %d splits %d flags %s' % (lib.dfl_conv_config(C.addressof(a)), sp, flags)
         flops = 2.0 * N * Ho * Wo * K * K * Cin * Cout
     else:
         d = torch.randn(N, Ho, Wo, Cout, device=dev)
