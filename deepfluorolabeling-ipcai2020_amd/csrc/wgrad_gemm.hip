@@ -2,27 +2,43 @@
 // Reference: torch autograd of nn.Conv2d / nn.ConvTranspose2d at train_test_code/unet.py:93,207,211,218,240
 // (triggered by loss.backward(), train.py:422).  Contract: include/dfl_hip.h (dfl_conv2d_wgrad).
 //
-// The contraction index is the pixel m, which is the slow dimension of both NHWC operands, so both LDS images
-// are simply [16 pixels][channels] as loaded (float4 = 4 channels of one pixel, ds_write_b128) and the MFMA
-// operand reads are unit stride over channels.  MFMA rows = cm (dense tensor d), columns = cg (gathered
-// tensor), hence the accumulator tile lands in torch's [Cout][Cin][KH][KW] order directly.
-// TPB = taps handled by one workgroup: 1 (tap comes from blockIdx.y, deep/wide layers) or all KH*KW taps
-// (narrow layers: the d slab is staged once and used by every tap; 9 accumulator tiles per wave).
-// The pixel range is cut into `splits` slices (blockIdx.z); slices write partial[split] which dfl_sum_partials adds.
+// The contraction index is the pixel m, the slow dimension of both NHWC operands, so both LDS images are simply
+// [16 pixels][channels] as loaded (float4 = 4 channels of one pixel, ds_write_b128) and the MFMA operand reads are
+// unit stride over channels.  MFMA rows = cm (dense tensor d), columns = cg (gathered tensor), hence the accumulator
+// tile lands in torch's [Cout][Cin][KH][KW] order directly.
+// TPB = taps handled by one workgroup: 1 (tap from blockIdx.y; wide layers), or a whole kernel ROW of taps (3 for 3x3,
+// 2 for 2x2: narrow layers keep a 32x32 tile per wave with one accumulator per tap, so the d slab staged for a chunk is
+// used TPB times while the wave still fits 4 per SIMD).  The pixel range is cut into `splits` slices (blockIdx.z);
+// slices write partial[split], which dfl_sum_partials adds.
+// Fast path (FAST): buffer loads with hardware bounds checking -- an out-of-image tap, a row past the end of the slice
+// or a padded channel gets an out-of-range offset and reads 0 -- so the loop carries no clamping, selects or branches;
+// the dense operand's offsets are loop invariant (the chunk advance rides in the scalar offset), the gathered operand
+// keeps a pixel cursor advanced without divisions.  The general path covers odd channel counts (first layer, heads).
 #include "common.h"
 
 namespace dfl {
 
 constexpr int KP = 16;
+constexpr uint32_t WOOB = 0x80000000u;
 
 struct WgK {
   dfl_wgrad_args a;
   int Mtot, T, nchunks, cps;
-  int vecG, vecD;
+  int vecG, vecD, fast;
+  uint32_t g_bytes, d_bytes;
 };
 
-template <int WM, int WN, int TM, int TN, int TPB, bool VEC>
-__global__ void __launch_bounds__(WM* WN * 64) wgrad_kernel(const WgK p) {
+typedef unsigned int wu32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4 wbuf_load4(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
+  const wu32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+constexpr int wg_occ(int tiles, bool fast) { return tiles >= 4 ? 2 : (fast ? 4 : 3); }
+
+template <int WM, int WN, int TM, int TN, int TPB, bool FAST>
+__global__ void __launch_bounds__(WM* WN * 64, wg_occ(TM* TN* TPB, FAST)) wgrad_kernel(const WgK p) {
   constexpr int NT = WM * WN * 64;
   constexpr int BMc = WM * TM * 32, BNg = WN * TN * 32;
   constexpr int LDD = BMc + 4, LDG = BNg + 4;
@@ -30,56 +46,46 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_kernel(const WgK p) {
   constexpr int NQD = KP * DQ, NQG = KP * GQ;
   constexpr int QD = (NQD + NT - 1) / NT, QG = (NQG + NT - 1) / NT;
   static_assert(NT % DQ == 0 && NT % GQ == 0, "thread -> channel quad mapping must be fixed per thread");
+  // one-wave workgroups keep a single LDS image (9 KB -> 16 workgroups per CU); the next chunk waits in registers
+  constexpr int NBUF = (WM * WN == 1) ? 1 : 2;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Ds = smem;                 // [2][KP][LDD]
-  float* Gs = smem + 2 * KP * LDD;  // [2][TPB][KP][LDG]
+  float* Ds = smem;                    // [NBUF][KP][LDD]
+  float* Gs = smem + NBUF * KP * LDD;  // [NBUF][TPB][KP][LDG]
 
   const dfl_wgrad_args& a = p.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, lh = lane >> 5;
   const int T = p.T;
+  const int Hin = a.Hin, Win = a.Win, KW = a.KW;
   const int cm0 = blockIdx.x * BMc;
-  int cg0, tap0;
-  if (TPB == 1) {
-    cg0 = (blockIdx.y / T) * BNg;
-    tap0 = blockIdx.y % T;
-  } else {
-    cg0 = blockIdx.y * BNg;
-    tap0 = 0;
-  }
+  // blockIdx.y = (cg tile, tap group); a tap group is one tap (TPB == 1) or one kernel row of TPB taps
+  const int ngroups = T / TPB;
+  const int cg0 = (blockIdx.y / ngroups) * BNg;
+  const int tap0 = (blockIdx.y % ngroups) * TPB;
+  const int tap_dy = tap0 / KW, tap_dx0 = tap0 - tap_dy * KW;   // TPB > 1: tap_dx0 == 0 and the group spans dx = 0..TPB-1
   const int ch_begin = blockIdx.z * p.cps;
   const int ch_end = min(ch_begin + p.cps, p.nchunks);
-  const int Hin = a.Hin, Win = a.Win, KW = a.KW;
 
   const int gq = tid % GQ;  // this thread's channel quad of the gathered tensor (same for every pass)
   const int gc = cg0 + 4 * gq;
+  const bool g1 = gc + 1 < a.Cg, g2 = gc + 2 < a.Cg, g3 = gc + 3 < a.Cg;
+  const bool has_aff = a.in_scale != nullptr;
   float4 gsc = make_float4(1.f, 1.f, 1.f, 1.f), gsh = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (a.in_scale != nullptr) {
-    if (VEC) {
-      if (gc < a.Cg) {
-        gsc = *reinterpret_cast<const float4*>(a.in_scale + gc);
-        gsh = *reinterpret_cast<const float4*>(a.in_shift + gc);
-      }
-    } else {
-      if (gc + 0 < a.Cg) { gsc.x = a.in_scale[gc + 0]; gsh.x = a.in_shift[gc + 0]; }
-      if (gc + 1 < a.Cg) { gsc.y = a.in_scale[gc + 1]; gsh.y = a.in_shift[gc + 1]; }
-      if (gc + 2 < a.Cg) { gsc.z = a.in_scale[gc + 2]; gsh.z = a.in_shift[gc + 2]; }
-      if (gc + 3 < a.Cg) { gsc.w = a.in_scale[gc + 3]; gsh.w = a.in_shift[gc + 3]; }
-    }
+  if (has_aff) {
+    if (gc + 0 < a.Cg) { gsc.x = a.in_scale[gc + 0]; gsh.x = a.in_shift[gc + 0]; }
+    if (g1) { gsc.y = a.in_scale[gc + 1]; gsh.y = a.in_shift[gc + 1]; }
+    if (g2) { gsc.z = a.in_scale[gc + 2]; gsh.z = a.in_shift[gc + 2]; }
+    if (g3) { gsc.w = a.in_scale[gc + 3]; gsh.w = a.in_shift[gc + 3]; }
   }
 
   float4 rd[QD];
   float4 rg[TPB][QG];
+  uint32_t okG = 0;      // bit (r*TPB + tt): tap tt of gather row r is inside the image (affine needs it: pad stays 0)
+  bool okD[QD][4];       // general path only
 
-  // Unconditional loads from clamped addresses; selects / affine / LDS writes are deferred to store() so that the
-  // waits land behind the MFMA block (see the note in conv_gemm.hip).
-  bool okD[QD][4];
-  bool okG[TPB][QG];
-  const bool g1 = gc + 1 < a.Cg, g2 = gc + 2 < a.Cg, g3 = gc + 3 < a.Cg;
-  constexpr int TKH = (TPB == 9) ? 3 : (TPB == 4 ? 2 : 1);   // multi-tap variants are square windows
-  const int tap_dy = tap0 / KW, tap_dx = tap0 - (tap0 / KW) * KW;
+  // pixel cursor of each gather row (advanced by KP per chunk, no divisions in the loop)
   int g_pix[QG], g_ox[QG], g_oy[QG], g_n[QG];
   bool g_ok0[QG];
 #pragma unroll
@@ -93,53 +99,73 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_kernel(const WgK p) {
     g_oy[r] = tq % a.Hout;
     g_n[r] = tq / a.Hout;
   }
-
-  auto load = [&](int ch) {
-    const int mc0 = ch * KP;
+  // FAST: loop-invariant offsets of the dense operand and per-tap byte offsets of the gathered one
+  uint32_t d_voff[QD];
+  __amdgpu_buffer_rsrc_t rsD, rsG;
+  if constexpr (FAST) {
+    rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.d), 0, (int)p.d_bytes, 0x00020000);
+    rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g), 0, (int)p.g_bytes, 0x00020000);
 #pragma unroll
     for (int r = 0; r < QD; ++r) {
       const int idx = tid + r * NT;
       const int pix = idx / DQ, q = idx - pix * DQ;
-      const int m = mc0 + pix, c = cm0 + 4 * q;
-      const bool ok = (idx < NQD) && (m < p.Mtot) && (c < a.Cm);
-      const float* src = a.d + (ok ? ((int64_t)m * a.ldd + c) : 0);
-      if constexpr (VEC) {
-        okD[r][0] = okD[r][1] = okD[r][2] = okD[r][3] = ok;
-        rd[r] = *reinterpret_cast<const float4*>(src);
-      } else {
-        okD[r][0] = ok;
-        okD[r][1] = ok && (c + 1 < a.Cm);
-        okD[r][2] = ok && (c + 2 < a.Cm);
-        okD[r][3] = ok && (c + 3 < a.Cm);
-        rd[r] = make_float4(src[0], src[okD[r][1] ? 1 : 0], src[okD[r][2] ? 2 : 0], src[okD[r][3] ? 3 : 0]);
+      const int c = cm0 + 4 * q;
+      d_voff[r] = (idx < NQD && c < a.Cm) ? (uint32_t)(((int64_t)pix * a.ldd + c) * 4) : WOOB;
+    }
+  }
+
+  auto load = [&](int ch) {
+    const int mc0 = ch * KP;
+    if constexpr (FAST) {
+      const uint32_t soff = (uint32_t)mc0 * (uint32_t)a.ldd * 4u;
+      const bool tail = mc0 + KP > p.Mtot;   // wave uniform; the scalar offset takes no part in the bounds check
+#pragma unroll
+      for (int r = 0; r < QD; ++r) {
+        const int pix = (tid + r * NT) / DQ;
+        rd[r] = wbuf_load4(rsD, (tail && mc0 + pix >= p.Mtot) ? WOOB : d_voff[r], soff);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < QD; ++r) {
+        const int idx = tid + r * NT;
+        const int pix = idx / DQ, q = idx - pix * DQ;
+        const int m = mc0 + pix, c = cm0 + 4 * q;
+        const bool ok = (idx < NQD) && (m < p.Mtot) && (c < a.Cm);
+        const float* src = a.d + (ok ? ((int64_t)m * a.ldd + c) : 0);
+        if (p.vecD) {
+          okD[r][0] = okD[r][1] = okD[r][2] = okD[r][3] = ok;
+          rd[r] = *reinterpret_cast<const float4*>(src);
+        } else {
+          okD[r][0] = ok;
+          okD[r][1] = ok && (c + 1 < a.Cm);
+          okD[r][2] = ok && (c + 2 < a.Cm);
+          okD[r][3] = ok && (c + 3 < a.Cm);
+          rd[r] = make_float4(src[0], src[okD[r][1] ? 1 : 0], src[okD[r][2] ? 2 : 0], src[okD[r][3] ? 3 : 0]);
+        }
       }
     }
+    okG = 0;
 #pragma unroll
     for (int r = 0; r < QG; ++r) {
-      // pixel cursor (g_ox, g_oy, g_n) of this thread's row: advanced by KP per chunk, no divisions in the loop
       const int m = mc0 + g_pix[r];
       const bool ok = g_ok0[r] && (m < p.Mtot);
-      const int iy0 = g_oy[r] * a.stride - a.pad;
-      const int ix0 = g_ox[r] * a.stride - a.pad;
-      const int64_t base = (((int64_t)g_n[r] * Hin + iy0) * Win + ix0) * a.ldg + gc;
-      bool rowok[TKH], colok[TKH];
-#pragma unroll
-      for (int d = 0; d < TKH; ++d) {
-        const int dy = (TPB == 1) ? tap_dy : d, dx = (TPB == 1) ? tap_dx : d;
-        rowok[d] = (unsigned)(iy0 + dy) < (unsigned)Hin;
-        colok[d] = (unsigned)(ix0 + dx) < (unsigned)Win;
-      }
+      const int iy = g_oy[r] * a.stride - a.pad + tap_dy;
+      const int ix0 = g_ox[r] * a.stride - a.pad + tap_dx0;
+      const bool rowok = ok && (unsigned)iy < (unsigned)Hin;
+      const int64_t pix0 = ((int64_t)g_n[r] * Hin + iy) * Win + ix0;
 #pragma unroll
       for (int tt = 0; tt < TPB; ++tt) {
-        const int dyi = (TPB == 1) ? 0 : tt / TKH, dxi = (TPB == 1) ? 0 : tt % TKH;
-        const int dy = (TPB == 1) ? tap_dy : dyi, dx = (TPB == 1) ? tap_dx : dxi;
-        const bool in = ok && rowok[dyi] && colok[dxi];
-        const float* src = a.g + (in ? (base + ((int64_t)dy * Win + dx) * a.ldg) : 0);
-        okG[tt][r] = in;
-        if constexpr (VEC) {
-          rg[tt][r] = *reinterpret_cast<const float4*>(src);
+        const bool in = rowok && (unsigned)(ix0 + tt) < (unsigned)Win;
+        okG |= in ? (1u << (r * TPB + tt)) : 0u;
+        if constexpr (FAST) {
+          rg[tt][r] = wbuf_load4(rsG, in ? (uint32_t)(((pix0 + tt) * a.ldg + gc) * 4) : WOOB, 0);
         } else {
-          rg[tt][r] = make_float4(src[0], src[(in && g1) ? 1 : 0], src[(in && g2) ? 2 : 0], src[(in && g3) ? 3 : 0]);
+          const float* src = a.g + (in ? ((pix0 + tt) * a.ldg + gc) : 0);
+          if (p.vecG) {
+            rg[tt][r] = *reinterpret_cast<const float4*>(src);
+          } else {
+            rg[tt][r] = make_float4(src[0], src[(in && g1) ? 1 : 0], src[(in && g2) ? 2 : 0], src[(in && g3) ? 3 : 0]);
+          }
         }
       }
       g_ox[r] += KP;
@@ -160,11 +186,13 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_kernel(const WgK p) {
       const int idx = tid + r * NT;
       if (idx < NQD) {
         const int pix = idx / DQ, q = idx - pix * DQ;
-        float4 v;
-        v.x = okD[r][0] ? rd[r].x : 0.f;
-        v.y = okD[r][1] ? rd[r].y : 0.f;
-        v.z = okD[r][2] ? rd[r].z : 0.f;
-        v.w = okD[r][3] ? rd[r].w : 0.f;
+        float4 v = rd[r];
+        if constexpr (!FAST) {
+          v.x = okD[r][0] ? v.x : 0.f;
+          v.y = okD[r][1] ? v.y : 0.f;
+          v.z = okD[r][2] ? v.z : 0.f;
+          v.w = okD[r][3] ? v.w : 0.f;
+        }
         *reinterpret_cast<float4*>(Db + pix * LDD + 4 * q) = v;
       }
     }
@@ -176,12 +204,14 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_kernel(const WgK p) {
         const int pix = idx / GQ;
 #pragma unroll
         for (int tt = 0; tt < TPB; ++tt) {
-          const bool in = okG[tt][r];
-          float4 v;
-          v.x = in ? fmaf(rg[tt][r].x, gsc.x, gsh.x) : 0.f;
-          v.y = (in && (VEC || g1)) ? fmaf(rg[tt][r].y, gsc.y, gsh.y) : 0.f;
-          v.z = (in && (VEC || g2)) ? fmaf(rg[tt][r].z, gsc.z, gsh.z) : 0.f;
-          v.w = (in && (VEC || g3)) ? fmaf(rg[tt][r].w, gsc.w, gsh.w) : 0.f;
+          float4 v = rg[tt][r];
+          const bool in = (okG >> (r * TPB + tt)) & 1u;
+          if (!FAST || has_aff) {   // FAST without affine: the hardware already returned zeros where needed
+            v.x = in ? fmaf(v.x, gsc.x, gsh.x) : 0.f;
+            v.y = (in && (FAST || g1)) ? fmaf(v.y, gsc.y, gsh.y) : 0.f;
+            v.z = (in && (FAST || g2)) ? fmaf(v.z, gsc.z, gsh.z) : 0.f;
+            v.w = (in && (FAST || g3)) ? fmaf(v.w, gsc.w, gsh.w) : 0.f;
+          }
           *reinterpret_cast<float4*>(Gb + (tt * KP + pix) * LDG + 4 * gq) = v;
         }
       }
@@ -204,7 +234,7 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_kernel(const WgK p) {
   }
   __syncthreads();
   for (int ch = ch_begin; ch < ch_end; ++ch) {
-    const int buf = (ch - ch_begin) & 1;
+    const int buf = (NBUF == 2) ? ((ch - ch_begin) & 1) : 0;
     const bool more = (ch + 1) < ch_end;
     if (more) load(ch + 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -227,15 +257,16 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_kernel(const WgK p) {
             acc[tt][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(dv[i], gv[j], acc[tt][i][j], 0, 0, 0);
       }
     }
-    __builtin_amdgcn_sched_barrier(0);  // keep the selects + LDS writes (and their vmcnt waits) behind the MFMA block
-    if (more) store(buf ^ 1);
+    __builtin_amdgcn_sched_barrier(0);  // keep the affine + LDS writes (and their vmcnt waits) behind the MFMA block
+    if constexpr (NBUF == 1) __syncthreads();
+    if (more) store(NBUF == 2 ? (buf ^ 1) : 0);
     __syncthreads();
   }
 
   float* out = (a.splits > 1) ? a.partial + (int64_t)blockIdx.z * a.Cm * a.Cg * T : a.dw;
 #pragma unroll
   for (int tt = 0; tt < TPB; ++tt) {
-    const int t = (TPB == 1) ? tap0 : tt;
+    const int t = tap0 + tt;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int cg = cg0 + wn * (TN * 32) + j * 32 + li;
@@ -287,16 +318,16 @@ __global__ void __launch_bounds__(256) sum_partials_wide_kernel(const float* __r
 }
 
 // ---- host side -------------------------------------------------------------------------------------
-enum WgCfg { WG_128 = 0, WG_64, WG_TAPS9, WG_TAPS4, WG_32 };
+enum WgCfg { WG_128 = 0, WG_64, WG_ROW3, WG_ROW2, WG_32 };
 
-static WgCfg pick_wg(const dfl_wgrad_args* a, bool vec = true) {
-  const int T = a->KH * a->KW;
-  const bool narrow = (a->Cm <= 64 || a->Cg <= 64) || !vec;   // the scalar-load variants exist for the narrow tiles only
+static WgCfg pick_wg(const dfl_wgrad_args* a) {
+  const bool narrow = (a->Cm <= 64 || a->Cg <= 64);
   if (narrow) {
-    if (a->KH == 3 && a->KW == 3) return WG_TAPS9;
-    if (a->KH == 2 && a->KW == 2) return WG_TAPS4;
+    if (a->KH == 3 && a->KW == 3) return WG_ROW3;
+    if (a->KH == 2 && a->KW == 2) return WG_ROW2;
     return WG_32;
   }
+  const int T = a->KH * a->KW;
   if (a->Cm >= 256 && a->Cg >= 256 && (int64_t)a->Cm * a->Cg * T >= 128ll * 128 * 1024) return WG_128;
   return WG_64;
 }
@@ -305,8 +336,8 @@ static void wg_tile(WgCfg c, int* bm, int* bn, int* tpb) {
   switch (c) {
     case WG_128: *bm = 128; *bn = 128; *tpb = 1; break;
     case WG_64: *bm = 64; *bn = 64; *tpb = 1; break;
-    case WG_TAPS9: *bm = 32; *bn = 32; *tpb = 9; break;
-    case WG_TAPS4: *bm = 32; *bn = 32; *tpb = 4; break;
+    case WG_ROW3: *bm = 32; *bn = 32; *tpb = 3; break;
+    case WG_ROW2: *bm = 32; *bn = 32; *tpb = 2; break;
     default: *bm = 32; *bn = 32; *tpb = 1; break;
   }
 }
@@ -333,44 +364,52 @@ static int wg_prepare(const dfl_wgrad_args* a, WgK* k, bool need_out) {
   k->T = a->KH * a->KW;
   k->nchunks = (int)ceil_div(M, KP);
   const int r4g = (a->Cg + 3) / 4 * 4, r4d = (a->Cm + 3) / 4 * 4;
-  k->vecG = (a->ldg % 4 == 0) && (a->ldg >= r4g) && aligned16(a->g) &&
-            (a->in_scale == nullptr || (a->Cg % 4 == 0 && aligned16(a->in_scale) && aligned16(a->in_shift)));
+  k->vecG = (a->ldg % 4 == 0) && (a->ldg >= r4g) && aligned16(a->g);
   k->vecD = (a->ldd % 4 == 0) && (a->ldd >= r4d) && aligned16(a->d);
+  const int64_t gb = (((int64_t)a->N * a->Hin * a->Win - 1) * a->ldg + a->Cg) * 4;
+  const int64_t db = ((M - 1) * a->ldd + a->Cm) * 4;
+  const int64_t lim = (1ll << 31) - 4096;
+  k->fast = k->vecG && k->vecD && (a->Cg % 4 == 0) && (a->Cm % 4 == 0) && gb < lim && db < lim;
+  k->g_bytes = (uint32_t)(gb < lim ? gb : 0);
+  k->d_bytes = (uint32_t)(db < lim ? db : 0);
   return DFL_OK;
 }
 
-template <int WM, int WN, int TM, int TN, int TPB, bool VEC>
+template <int WM, int WN, int TM, int TN, int TPB, bool FAST>
 static int wg_launch(const WgK& k, hipStream_t s) {
   constexpr int BMc = WM * TM * 32, BNg = WN * TN * 32;
-  const size_t lds = (size_t)(2 * KP * (BMc + 4) + 2 * TPB * KP * (BNg + 4)) * sizeof(float);
+  constexpr int NBUF = (WM * WN == 1) ? 1 : 2;
+  const size_t lds = (size_t)NBUF * (KP * (BMc + 4) + TPB * KP * (BNg + 4)) * sizeof(float);
   const int tiles_g = (int)ceil_div(k.a.Cg, BNg);
-  dim3 grid((unsigned)ceil_div(k.a.Cm, BMc), (unsigned)(tiles_g * (TPB == 1 ? k.T : 1)), (unsigned)k.a.splits);
-  hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, TPB, VEC>), grid, dim3(WM * WN * 64), lds, s, k);
+  dim3 grid((unsigned)ceil_div(k.a.Cm, BMc), (unsigned)(tiles_g * (k.T / TPB)), (unsigned)k.a.splits);
+  hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, TPB, FAST>), grid, dim3(WM * WN * 64), lds, s, k);
   return check_launch("dfl_conv2d_wgrad");
 }
 
 }  // namespace dfl
+
+extern "C" int dfl_wgrad_config(const dfl_wgrad_args* a) {
+  dfl::WgK k;
+  int rc = dfl::wg_prepare(a, &k, false);
+  if (rc != DFL_OK) return rc;
+  return (int)dfl::pick_wg(a);
+}
 
 extern "C" int dfl_wgrad_suggest_splits(const dfl_wgrad_args* a) {
   dfl::WgK k;
   int rc = dfl::wg_prepare(a, &k, false);
   if (rc != DFL_OK) return rc;
   int bm, bn, tpb;
-  dfl::wg_tile(dfl::pick_wg(a, k.vecG && k.vecD), &bm, &bn, &tpb);
-  const int64_t blocks = dfl::ceil_div(a->Cm, bm) * dfl::ceil_div(a->Cg, bn) * (tpb == 1 ? k.T : 1);
-  int64_t s = dfl::ceil_div(1536, blocks);
-  const int64_t max_by_work = k.nchunks / 8 > 0 ? k.nchunks / 8 : 1;  // >= 128 pixels per slice
+  dfl::wg_tile(dfl::pick_wg(a), &bm, &bn, &tpb);
+  const int waves = (bm >= 64) ? 4 : 1;
+  const int64_t blocks = dfl::ceil_div(a->Cm, bm) * dfl::ceil_div(a->Cg, bn) * (k.T / tpb);
+  // aim at ~4 waves per SIMD over the whole chip (4096 waves), every slice at least 128 pixels
+  int64_t s = dfl::ceil_div(4096, blocks * waves);
+  const int64_t max_by_work = k.nchunks / 8 > 0 ? k.nchunks / 8 : 1;
   if (s > max_by_work) s = max_by_work;
   if (s > 2048) s = 2048;
   if (s < 1) s = 1;
   return (int)s;
-}
-
-extern "C" int dfl_wgrad_config(const dfl_wgrad_args* a) {
-  dfl::WgK k;
-  int rc = dfl::wg_prepare(a, &k, false);
-  if (rc != DFL_OK) return rc;
-  return (int)dfl::pick_wg(a, k.vecG && k.vecD);
 }
 
 extern "C" int dfl_conv2d_wgrad(const dfl_wgrad_args* a, dfl_stream_t stream) {
@@ -379,13 +418,13 @@ extern "C" int dfl_conv2d_wgrad(const dfl_wgrad_args* a, dfl_stream_t stream) {
   if (rc != DFL_OK) return rc;
   k.cps = (int)dfl::ceil_div(k.nchunks, a->splits);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const bool vec = k.vecG && k.vecD;
-  switch (dfl::pick_wg(a, vec)) {
-    case dfl::WG_128: return dfl::wg_launch<2, 2, 2, 2, 1, true>(k, s);
-    case dfl::WG_64: return dfl::wg_launch<2, 2, 1, 1, 1, true>(k, s);
-    case dfl::WG_TAPS9: return vec ? dfl::wg_launch<1, 1, 1, 1, 9, true>(k, s) : dfl::wg_launch<1, 1, 1, 1, 9, false>(k, s);
-    case dfl::WG_TAPS4: return vec ? dfl::wg_launch<1, 1, 1, 1, 4, true>(k, s) : dfl::wg_launch<1, 1, 1, 1, 4, false>(k, s);
-    default: return vec ? dfl::wg_launch<1, 1, 1, 1, 1, true>(k, s) : dfl::wg_launch<1, 1, 1, 1, 1, false>(k, s);
+  const bool f = k.fast;
+  switch (dfl::pick_wg(a)) {
+    case dfl::WG_128: return f ? dfl::wg_launch<2, 2, 2, 2, 1, true>(k, s) : dfl::wg_launch<2, 2, 2, 2, 1, false>(k, s);
+    case dfl::WG_64: return f ? dfl::wg_launch<2, 2, 1, 1, 1, true>(k, s) : dfl::wg_launch<2, 2, 1, 1, 1, false>(k, s);
+    case dfl::WG_ROW3: return f ? dfl::wg_launch<1, 1, 1, 1, 3, true>(k, s) : dfl::wg_launch<1, 1, 1, 1, 3, false>(k, s);
+    case dfl::WG_ROW2: return f ? dfl::wg_launch<1, 1, 1, 1, 2, true>(k, s) : dfl::wg_launch<1, 1, 1, 1, 2, false>(k, s);
+    default: return f ? dfl::wg_launch<1, 1, 1, 1, 1, true>(k, s) : dfl::wg_launch<1, 1, 1, 1, 1, false>(k, s);
   }
 }
 
