@@ -120,22 +120,30 @@ class MemsetArgs(C.Structure):
     _fields_ = [('ptr', fp), ('bytes', i64)]
 
 
+class ReduceJob(C.Structure):
+    _fields_ = [('src', fp), ('dst', fp), ('n', i64), ('stride', i64), ('count', i32), ('first_block', i32)]
+
+
+class ReduceBatchArgs(C.Structure):
+    _fields_ = [('jobs_dev', fp), ('njobs', i32), ('total_blocks', i32)]
+
+
 class Op(C.Structure):
     _fields_ = [('kind', i32), ('reserved', i32), ('args', fp)]
 
 
 OP_CONV, OP_WGRAD, OP_SUM_PARTIALS, OP_PACK, OP_BN_FINALIZE, OP_BN_EVAL, OP_COLSTATS, OP_BN_BWD_FINALIZE, \
     OP_BN_RELU_BWD, OP_REDUCE_PARTIALS, OP_AFFINE_COPY, OP_POOL_FWD, OP_POOL_BWD, OP_HEAD_FWD, OP_HEAD_BWD, \
-    OP_MEMSET = range(1, 17)
+    OP_MEMSET, OP_REDUCE_BATCH = range(1, 18)
 
 _KIND_OF = {ConvArgs: OP_CONV, WgradArgs: OP_WGRAD, SumPartialsArgs: OP_SUM_PARTIALS, PackArgs: OP_PACK,
             BnFinalizeArgs: OP_BN_FINALIZE, BnEvalArgs: OP_BN_EVAL, ColstatsArgs: OP_COLSTATS,
             BnBwdFinalizeArgs: OP_BN_BWD_FINALIZE, BnReluBwdArgs: OP_BN_RELU_BWD,
             ReducePartialsArgs: OP_REDUCE_PARTIALS, AffineCopyArgs: OP_AFFINE_COPY, HeadFwdArgs: OP_HEAD_FWD,
-            HeadBwdArgs: OP_HEAD_BWD, MemsetArgs: OP_MEMSET}
+            HeadBwdArgs: OP_HEAD_BWD, MemsetArgs: OP_MEMSET, ReduceBatchArgs: OP_REDUCE_BATCH}
 
 _SIZEOF_ORDER = [ConvArgs, WgradArgs, PackJob, BnFinalizeArgs, ColstatsArgs, BnBwdFinalizeArgs, BnReluBwdArgs,
-                 AffineCopyArgs, PoolArgs, HeadFwdArgs, HeadBwdArgs, LossArgs, EnsembleArgs, Op]
+                 AffineCopyArgs, PoolArgs, HeadFwdArgs, HeadBwdArgs, LossArgs, EnsembleArgs, Op, ReduceJob]
 
 EXPORTS = ['dfl_version', 'dfl_last_error', 'dfl_sizeof', 'dfl_conv2d', 'dfl_conv_grid_m', 'dfl_conv2d_wgrad',
            'dfl_wgrad_suggest_splits', 'dfl_sum_partials', 'dfl_pack_weights', 'dfl_bn_finalize',
@@ -143,7 +151,8 @@ EXPORTS = ['dfl_version', 'dfl_last_error', 'dfl_sizeof', 'dfl_conv2d', 'dfl_con
            'dfl_bn_relu_bwd_apply', 'dfl_reduce_partials', 'dfl_affine_copy', 'dfl_maxpool2x2_fwd',
            'dfl_maxpool2x2_bwd', 'dfl_head_fwd', 'dfl_head_bwd', 'dfl_head_scratch_ld', 'dfl_head_scratch_off',
            'dfl_dice_ncc_loss', 'dfl_loss_scratch_doubles', 'dfl_ensemble_reduce', 'dfl_sgd_step', 'dfl_exec',
-           'dfl_exec_timed', 'dfl_conv_config', 'dfl_wgrad_config', 'dfl_conv_suggest_splits']
+           'dfl_exec_timed', 'dfl_conv_config', 'dfl_wgrad_config', 'dfl_conv_suggest_splits', 'dfl_reduce_batch',
+           'dfl_reduce_job_blocks']
 
 
 class DflError(RuntimeError):
@@ -173,6 +182,8 @@ def lib():
     L.dfl_pack_weights.argtypes = [fp, i32, i64, fp]
     L.dfl_bn_eval_prepare.argtypes = [fp, fp, fp, fp, fp, fp, i32, f32, fp]
     L.dfl_reduce_partials.argtypes = [fp, fp, i32, i32, i32, fp]
+    L.dfl_reduce_batch.argtypes = [fp, i32, i32, fp]
+    L.dfl_reduce_job_blocks.argtypes = [i64, i32]
     L.dfl_sgd_step.argtypes = [fp, fp, fp, i64, f32, f32, f32, f32, i32, i32, fp]
     L.dfl_exec.argtypes = [fp, i32, fp]
     L.dfl_exec_timed.argtypes = [fp, i32, fp, fp]

@@ -25,7 +25,7 @@ extern "C" int dfl_sizeof(int which) {
       (int)sizeof(dfl_bn_finalize_args), (int)sizeof(dfl_colstats_args),       (int)sizeof(dfl_bn_bwd_finalize_args),
       (int)sizeof(dfl_bn_relu_bwd_args), (int)sizeof(dfl_affine_copy_args),    (int)sizeof(dfl_pool_args),
       (int)sizeof(dfl_head_fwd_args),   (int)sizeof(dfl_head_bwd_args),        (int)sizeof(dfl_loss_args),
-      (int)sizeof(dfl_ensemble_args),   (int)sizeof(dfl_op)};
+      (int)sizeof(dfl_ensemble_args),   (int)sizeof(dfl_op),                   (int)sizeof(dfl_reduce_job)};
   if (which < 0 || which >= (int)(sizeof(sizes) / sizeof(sizes[0]))) return -1;
   return sizes[which];
 }
@@ -108,6 +108,11 @@ static int exec_one(const dfl_op* ops, int i, dfl_stream_t stream) {
       case DFL_OP_POOL_BWD: rc = dfl_maxpool2x2_bwd(static_cast<const dfl_pool_args*>(p), stream); break;
       case DFL_OP_HEAD_FWD: rc = dfl_head_fwd(static_cast<const dfl_head_fwd_args*>(p), stream); break;
       case DFL_OP_HEAD_BWD: rc = dfl_head_bwd(static_cast<const dfl_head_bwd_args*>(p), stream); break;
+      case DFL_OP_REDUCE_BATCH: {
+        const dfl_reduce_batch_args* a = static_cast<const dfl_reduce_batch_args*>(p);
+        rc = dfl_reduce_batch(a->jobs_dev, a->njobs, a->total_blocks, stream);
+        break;
+      }
       case DFL_OP_MEMSET: {
         const dfl_memset_args* a = static_cast<const dfl_memset_args*>(p);
         if (a->bytes > 0 && hipMemsetAsync(a->ptr, 0, (size_t)a->bytes, static_cast<hipStream_t>(stream)) != hipSuccess) {

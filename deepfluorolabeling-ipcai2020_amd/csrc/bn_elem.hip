@@ -98,24 +98,32 @@ __global__ void __launch_bounds__(256) colstats_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------ BN finalize
-// One workgroup per 8 channels: 32 lanes walk the partial rows, fp64 tree over them.
-__device__ __forceinline__ void sum_partials_f64(const float* __restrict__ partials, int nblocks, int C, int c,
+// One workgroup per `cpb` channels (8 for wide layers down to 1 for narrow ones, so that even a 32-channel layer with
+// thousands of partial rows spreads over tens of workgroups): 256/cpb lanes walk the partial rows, fp64 tree over them.
+__device__ __forceinline__ void sum_partials_f64(const float* __restrict__ partials, int nblocks, int C, int cpb,
                                                  double* out1, double* out2, double (*red)[256]) {
-  const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
-  double s1 = 0.0, s2 = 0.0;
+  const int cl = threadIdx.x % cpb, rl = threadIdx.x / cpb, lanes = 256 / cpb;
+  const int c = blockIdx.x * cpb + cl;
+  double s1 = 0.0, s2 = 0.0, t1 = 0.0, t2 = 0.0;
   if (c < C) {
-    for (int r = rl; r < nblocks; r += 32) {
+    int r = rl;
+    for (; r + lanes < nblocks; r += 2 * lanes) {
+      const float a1 = partials[((int64_t)r * 2 + 0) * C + c], a2 = partials[((int64_t)r * 2 + 1) * C + c];
+      const float b1 = partials[((int64_t)(r + lanes) * 2 + 0) * C + c], b2 = partials[((int64_t)(r + lanes) * 2 + 1) * C + c];
+      s1 += (double)a1; s2 += (double)a2; t1 += (double)b1; t2 += (double)b2;
+    }
+    if (r < nblocks) {
       s1 += (double)partials[((int64_t)r * 2 + 0) * C + c];
       s2 += (double)partials[((int64_t)r * 2 + 1) * C + c];
     }
   }
-  red[0][threadIdx.x] = s1;
-  red[1][threadIdx.x] = s2;
+  red[0][threadIdx.x] = s1 + t1;
+  red[1][threadIdx.x] = s2 + t2;
   __syncthreads();
-  for (int off = 16; off >= 1; off >>= 1) {
+  for (int off = lanes / 2; off >= 1; off >>= 1) {
     if (rl < off) {
-      red[0][threadIdx.x] += red[0][threadIdx.x + off * 8];
-      red[1][threadIdx.x] += red[1][threadIdx.x + off * 8];
+      red[0][threadIdx.x] += red[0][threadIdx.x + off * cpb];
+      red[1][threadIdx.x] += red[1][threadIdx.x + off * cpb];
     }
     __syncthreads();
   }
@@ -123,12 +131,14 @@ __device__ __forceinline__ void sum_partials_f64(const float* __restrict__ parti
   *out2 = red[1][cl];
 }
 
-__global__ void __launch_bounds__(256) bn_finalize_kernel(const dfl_bn_finalize_args a) {
+static inline int finalize_cpb(int C) { return C >= 512 ? 8 : (C >= 256 ? 4 : (C >= 128 ? 2 : 1)); }
+
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const dfl_bn_finalize_args a, int cpb) {
   __shared__ double red[2][256];
-  const int c = blockIdx.x * 8 + (threadIdx.x & 7);
+  const int c = blockIdx.x * cpb + (threadIdx.x % cpb);
   double s1, s2;
-  sum_partials_f64(a.partials, a.nblocks, a.C, c, &s1, &s2, red);
-  if (threadIdx.x < 8 && c < a.C) {
+  sum_partials_f64(a.partials, a.nblocks, a.C, cpb, &s1, &s2, red);
+  if (threadIdx.x < cpb && c < a.C) {
     const double cnt = (double)a.count;
     const double mean = s1 / cnt;
     double var = s2 / cnt - mean * mean;  // biased variance used for normalisation
@@ -162,12 +172,12 @@ __global__ void bn_eval_kernel(const float* __restrict__ gamma, const float* __r
 }
 
 // dy-side finalize: dgamma, dbeta and the affine form of BatchNorm+ReLU backward.
-__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const dfl_bn_bwd_finalize_args a) {
+__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const dfl_bn_bwd_finalize_args a, int cpb) {
   __shared__ double red[2][256];
-  const int c = blockIdx.x * 8 + (threadIdx.x & 7);
+  const int c = blockIdx.x * cpb + (threadIdx.x % cpb);
   double sdy, sdyr;
-  sum_partials_f64(a.partials, a.nblocks, a.C, c, &sdy, &sdyr, red);
-  if (threadIdx.x < 8 && c < a.C) {
+  sum_partials_f64(a.partials, a.nblocks, a.C, cpb, &sdy, &sdyr, red);
+  if (threadIdx.x < cpb && c < a.C) {
     const double cnt = (double)a.count;
     const double mean = (double)a.save_mean[c], invstd = (double)a.save_invstd[c], g = (double)a.gamma[c];
     const double sdyx = invstd * (sdyr - mean * sdy);  // sum dy * xhat
@@ -256,6 +266,54 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __res
     __syncthreads();
   }
   if (threadIdx.x < 8 && c < C) out[c] = (float)red[threadIdx.x];
+}
+
+// Batched sums (dfl_reduce_batch): blockIdx.x -> (job, block of the job) by binary search over the job table.
+// Many slices (count >= 64): 16 outputs x 64 slice lanes per workgroup, 4 loads in flight per lane, fp64 LDS tree.
+// Few slices: one thread per output.
+constexpr int RB_T = 1024, RB_O = 16, RB_S = 64, RB_WIDE_MIN = 64;
+static inline int reduce_job_blocks(int64_t n, int count) {
+  return (int)(count >= RB_WIDE_MIN ? ceil_div(n, RB_O) : ceil_div(n, RB_T));
+}
+
+__global__ void __launch_bounds__(RB_T) reduce_batch_kernel(const dfl_reduce_job* __restrict__ jobs, int njobs) {
+  __shared__ double red[RB_S][RB_O + 1];
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const dfl_reduce_job j = jobs[lo];
+  const int b = (int)blockIdx.x - j.first_block;
+  if (j.count >= RB_WIDE_MIN) {
+    const int o = threadIdx.x & (RB_O - 1), sl = threadIdx.x / RB_O;
+    const int64_t i = (int64_t)b * RB_O + o;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (i < j.n) {
+      const float* src = j.src + i;
+      int k = sl;
+      for (; k + 3 * RB_S < j.count; k += 4 * RB_S) {
+        const float v0 = src[(int64_t)k * j.stride], v1 = src[(int64_t)(k + RB_S) * j.stride];
+        const float v2 = src[(int64_t)(k + 2 * RB_S) * j.stride], v3 = src[(int64_t)(k + 3 * RB_S) * j.stride];
+        a0 += (double)v0; a1 += (double)v1; a2 += (double)v2; a3 += (double)v3;
+      }
+      for (; k < j.count; k += RB_S) a0 += (double)src[(int64_t)k * j.stride];
+    }
+    red[sl][o] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    for (int off = RB_S / 2; off >= 1; off >>= 1) {
+      if (sl < off) red[sl][o] += red[sl + off][o];
+      __syncthreads();
+    }
+    if (sl == 0 && i < j.n) j.dst[i] = (float)red[0][o];
+  } else {
+    const int64_t i = (int64_t)b * RB_T + threadIdx.x;
+    if (i < j.n) {
+      double s = 0.0;
+      for (int k = 0; k < j.count; ++k) s += (double)j.src[(int64_t)k * j.stride + i];
+      j.dst[i] = (float)s;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ affine copy
@@ -483,7 +541,9 @@ extern "C" int dfl_bn_finalize(const dfl_bn_finalize_args* a, dfl_stream_t strea
               "dfl_bn_finalize: missing pointer");
   DFL_REQUIRE(a->C > 0 && a->nblocks > 0 && a->count > 0, "dfl_bn_finalize: bad sizes");
   DFL_REQUIRE((a->running_mean == nullptr) == (a->running_var == nullptr), "dfl_bn_finalize: running stats go together");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(a->C, 8)), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  const int cpb = finalize_cpb(a->C);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(a->C, cpb)), dim3(256), 0, static_cast<hipStream_t>(stream), *a,
+                     cpb);
   return check_launch("dfl_bn_finalize");
 }
 
@@ -500,8 +560,9 @@ extern "C" int dfl_bn_bwd_finalize(const dfl_bn_bwd_finalize_args* a, dfl_stream
   DFL_REQUIRE(a && a->partials && a->gamma && a->save_mean && a->save_invstd && a->dgamma && a->dbeta && a->coef,
               "dfl_bn_bwd_finalize: missing pointer");
   DFL_REQUIRE(a->C > 0 && a->nblocks > 0 && a->count > 0, "dfl_bn_bwd_finalize: bad sizes");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(a->C, 8)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), *a);
+  const int cpb = finalize_cpb(a->C);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(a->C, cpb)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), *a, cpb);
   return check_launch("dfl_bn_bwd_finalize");
 }
 
@@ -527,6 +588,18 @@ extern "C" int dfl_reduce_partials(const float* partials, float* out, int32_t nb
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(C, 8)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      partials, out, (int)nblocks, (int)stride, (int)C);
   return check_launch("dfl_reduce_partials");
+}
+
+extern "C" int dfl_reduce_job_blocks(int64_t n, int32_t count) {
+  DFL_REQUIRE(n > 0 && count > 0, "dfl_reduce_job_blocks: bad args");
+  return reduce_job_blocks(n, count);
+}
+
+extern "C" int dfl_reduce_batch(const dfl_reduce_job* jobs_dev, int32_t njobs, int32_t total_blocks, dfl_stream_t stream) {
+  DFL_REQUIRE(jobs_dev && njobs > 0 && total_blocks > 0, "dfl_reduce_batch: bad args");
+  hipLaunchKernelGGL(reduce_batch_kernel, dim3((unsigned)total_blocks), dim3(RB_T), 0, static_cast<hipStream_t>(stream),
+                     jobs_dev, (int)njobs);
+  return check_launch("dfl_reduce_batch");
 }
 
 extern "C" int dfl_affine_copy(const dfl_affine_copy_args* a, dfl_stream_t stream) {

@@ -15,7 +15,7 @@ import torch
 from . import _native as nat
 from ._native import (ConvArgs, WgradArgs, PackJob, BnFinalizeArgs, ColstatsArgs, BnBwdFinalizeArgs, BnReluBwdArgs,
                       AffineCopyArgs, PoolArgs, HeadFwdArgs, HeadBwdArgs, SumPartialsArgs, PackArgs, BnEvalArgs,
-                      ReducePartialsArgs, MemsetArgs, Program)
+                      ReducePartialsArgs, MemsetArgs, ReduceJob, ReduceBatchArgs, Program)
 
 BN_EPS = 1.0e-5
 BN_MOMENTUM = 0.1
@@ -59,6 +59,9 @@ class UNetPlan:
         self.busy = False
         self.generation = 0
         self._scratch = {}
+        self._red_pending = []          # deferred sums (src, dst, n, stride, count), see _defer_sum
+        self._red_bytes = 0
+        self._red_flushes = []          # (index of the batch op in bwd, [dst pointers])
         self._build()
 
     # ------------------------------------------------------------------------------------------ memory
@@ -168,12 +171,38 @@ class UNetPlan:
         a.splits = s
         if s > 1:
             n = d.C * g.C * KH * KW
-            part = self._wg_partial(s * n)
+            big = 4 * n >= self.FLUSH_BYTES
+            part = self._wg_partial(s * n) if big else self._new(s * n)   # deferred sums keep their own slices
             a.partial = part.data_ptr()
             prog.add(a)
-            prog.add(SumPartialsArgs(src=part.data_ptr(), dst=dw.data_ptr(), n=n, splits=s))
+            self._defer_sum(prog, part.data_ptr(), dw.data_ptr(), n, n, s)
         else:
             prog.add(a)
+
+    # Small sums (bias gradients, pixel-slice partials of narrow layers) are not launched one by one: they queue up
+    # and one dfl_reduce_batch finishes the queue once FLUSH_BYTES of gradient are waiting (and at the end of backward).
+    FLUSH_BYTES = 4 << 20
+
+    def _defer_sum(self, prog, src, dst, n, stride, count):
+        self._red_pending.append((src, dst, n, stride, count))
+        self._red_bytes += 4 * n
+        if self._red_bytes >= self.FLUSH_BYTES:
+            self._flush_sums(prog)
+
+    def _flush_sums(self, prog):
+        jobs = self._red_pending
+        if not jobs:
+            return
+        arr = (ReduceJob * len(jobs))()
+        blocks = 0
+        for i, (src, dst, n, stride, count) in enumerate(jobs):
+            arr[i].src, arr[i].dst, arr[i].n, arr[i].stride, arr[i].count, arr[i].first_block = src, dst, n, stride, count, blocks
+            blocks += nat.check(self.lib.dfl_reduce_job_blocks(n, count), 'dfl_reduce_job_blocks')
+        dev = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(self.dev)
+        self._keep.append(dev)
+        self._red_flushes.append((len(prog.structs), [j[1] for j in jobs]))
+        prog.add(ReduceBatchArgs(jobs_dev=dev.data_ptr(), njobs=len(jobs), total_blocks=blocks))
+        self._red_pending, self._red_bytes = [], 0
 
     def _shared_scratch(self, key, nelem):
         t = self._scratch.get(key)
@@ -194,7 +223,7 @@ class UNetPlan:
         nb = self.lib.dfl_rowblock_count(a.M, a.C)
         part = self._new(nb * 2 * a.C)
         prog.add(ColstatsArgs(a=a.ptr, b=None, partials=part.data_ptr(), M=a.M, C=a.C, lda=a.ld, ldb=0, nblocks=nb))
-        prog.add(ReducePartialsArgs(partials=part.data_ptr(), out=out.data_ptr(), nblocks=nb, stride=2 * a.C, C=a.C))
+        self._defer_sum(prog, part.data_ptr(), out.data_ptr(), a.C, 2 * a.C, nb)
 
     # ------------------------------------------------------------------------------------------ build
     def _build(self):
@@ -352,17 +381,15 @@ class UNetPlan:
                                                   count=r.M, nblocks=nb, C=Cout))
                         if do_res and d == bd - 1:
                             # residual bias gradient = column sums of dout, already in the same partials
-                            bwd.add(ReducePartialsArgs(partials=part.data_ptr(),
-                                                       out=G[prefix + '.res_conv1x1.bias'].data_ptr(), nblocks=nb,
-                                                       stride=2 * Cout, C=Cout))
+                            self._defer_sum(bwd, part.data_ptr(), G[prefix + '.res_conv1x1.bias'].data_ptr(), Cout,
+                                            2 * Cout, nb)
                     elif do_res and d == bd - 1:
                         self._colsum(bwd, g, G[prefix + '.res_conv1x1.bias'])
                     bpart = self._new(nb * Cout)
                     bwd.add(BnReluBwdArgs(dy=g.ptr, r=r.ptr, coef=nat.ptr(coef), dpre=dpre.ptr,
                                           partials=bpart.data_ptr(), M=r.M, C=Cout, lddy=g.ld, ldr=r.ld, ldo=dpre.ld,
                                           nblocks=nb))
-                    bwd.add(ReducePartialsArgs(partials=bpart.data_ptr(), out=G[cv['wname'] + '.bias'].data_ptr(),
-                                               nblocks=nb, stride=Cout, C=Cout))
+                    self._defer_sum(bwd, bpart.data_ptr(), G[cv['wname'] + '.bias'].data_ptr(), Cout, Cout, nb)
                     inp = cv['inp']
                     self._wgrad(bwd, inp, dpre, G[cv['wname'] + '.weight'], 3, 3, 1, pad, r.H, r.W,
                                 in_aff=cv['inp_aff'])
@@ -531,6 +558,7 @@ class UNetPlan:
             else:
                 dxin = None
             rec['block_bw'](dout, dxin)
+        self._flush_sums(bwd)
         self._finish_pack()
         # index of the last backward op that writes each parameter gradient (data-parallel bucket scheduling)
         by_ptr = {self.G[k].data_ptr(): k for k in self.grad_names}
@@ -540,6 +568,11 @@ class UNetPlan:
                 name = by_ptr.get(getattr(st, field, None))
                 if name is not None:
                     self.grad_ready_op[name] = idx
+        for idx, dsts in self._red_flushes:
+            for d in dsts:
+                name = by_ptr.get(d)
+                if name is not None:
+                    self.grad_ready_op[name] = max(idx, self.grad_ready_op.get(name, -1))
 
     # ------------------------------------------------------------------------------------------ run
     def run_pack(self, stream, forward_only=False):

@@ -214,6 +214,21 @@ int dfl_bn_relu_bwd_apply(const dfl_bn_relu_bwd_args* a, dfl_stream_t stream);
 int dfl_reduce_partials(const float* partials, float* out, int32_t nblocks, int32_t stride, int32_t C,
                         dfl_stream_t stream);
 
+/* Batched form of dfl_reduce_partials / dfl_sum_partials: ONE launch finishes many small sums (the per-layer bias
+ * gradients and the pixel-slice partials of dfl_conv2d_wgrad of a whole backward pass; the recorded program defers
+ * them to a few flush points instead of one launch per layer).  Job j:  dst[i] = sum_{k < count} src[k*stride + i],
+ * i < n, accumulated in fp64 in a fixed order (bit-reproducible).  first_block is the prefix sum of
+ * dfl_reduce_job_blocks(n, count) over the preceding jobs; total_blocks the sum over all jobs. */
+typedef struct {
+  const float* src;
+  float* dst;
+  int64_t n, stride;
+  int32_t count, first_block;
+} dfl_reduce_job;
+int dfl_reduce_job_blocks(int64_t n, int32_t count);
+/* jobs: DEVICE pointer to njobs records. */
+int dfl_reduce_batch(const dfl_reduce_job* jobs_dev, int32_t njobs, int32_t total_blocks, dfl_stream_t stream);
+
 /* y[m,c] = x[m,c]*scale[c] + shift[c] (+ y_old when accumulate).  scale NULL => copy / add.  Used for the
  * BatchNorm output when a block has no residual branch (do_res=False, unet.py:229) and for the centre-crop copy
  * of the bridge in unpadded mode (unet.py:248-257): src/dst are [N,H,W] windows given by offsets. */
@@ -339,7 +354,7 @@ typedef enum {
   DFL_OP_CONV = 1, DFL_OP_WGRAD = 2, DFL_OP_SUM_PARTIALS = 3, DFL_OP_PACK = 4, DFL_OP_BN_FINALIZE = 5,
   DFL_OP_BN_EVAL = 6, DFL_OP_COLSTATS = 7, DFL_OP_BN_BWD_FINALIZE = 8, DFL_OP_BN_RELU_BWD = 9,
   DFL_OP_REDUCE_PARTIALS = 10, DFL_OP_AFFINE_COPY = 11, DFL_OP_POOL_FWD = 12, DFL_OP_POOL_BWD = 13,
-  DFL_OP_HEAD_FWD = 14, DFL_OP_HEAD_BWD = 15, DFL_OP_MEMSET = 16
+  DFL_OP_HEAD_FWD = 14, DFL_OP_HEAD_BWD = 15, DFL_OP_MEMSET = 16, DFL_OP_REDUCE_BATCH = 17
 } dfl_op_kind;
 
 typedef struct { const float* src; float* dst; int64_t n; int32_t splits; int32_t reserved; } dfl_sum_partials_args;
@@ -348,6 +363,7 @@ typedef struct { const float* gamma; const float* beta; const float* running_mea
                  float* scale; float* shift; int32_t C; float eps; } dfl_bn_eval_args;
 typedef struct { const float* partials; float* out; int32_t nblocks, stride, C, reserved; } dfl_reduce_partials_args;
 typedef struct { void* ptr; int64_t bytes; } dfl_memset_args; /* zero fill */
+typedef struct { const dfl_reduce_job* jobs_dev; int32_t njobs, total_blocks; } dfl_reduce_batch_args;
 
 typedef struct {
   int32_t kind;          /* dfl_op_kind */

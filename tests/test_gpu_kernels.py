@@ -589,3 +589,26 @@ def test_sgd_step():
         nat.check(lib.dfl_sgd_step(pd.data_ptr(), grd.data_ptr(), buf.data_ptr(), n, 0.1, 0.9, 1e-4, 1.0, 1, int(step == 0), stream()))
     torch.cuda.synchronize()
     np.testing.assert_allclose(pd.cpu().numpy(), pr.detach().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_reduce_batch():
+    """dfl_reduce_batch: many sums of different shapes in one launch (bias gradients, weight-gradient slices)."""
+    import ctypes as C
+    lib = nat.lib()
+    g = torch.Generator().manual_seed(17)
+    shapes = [(32, 64, 9216), (9216, 9216, 1366), (5, 7, 3), (1, 1, 200), (300000, 300000, 2), (819, 819, 70), (64, 128, 64)]
+    srcs, dsts, arr, blocks = [], [], (nat.ReduceJob * len(shapes))(), 0
+    for i, (n, stride, count) in enumerate(shapes):
+        src = torch.randn(count * stride, generator=g).to(DEV)
+        dst = torch.full((n,), float('nan'), device=DEV)
+        srcs.append(src)
+        dsts.append(dst)
+        arr[i].src, arr[i].dst, arr[i].n, arr[i].stride, arr[i].count, arr[i].first_block = (
+            src.data_ptr(), dst.data_ptr(), n, stride, count, blocks)
+        blocks += nat.check(lib.dfl_reduce_job_blocks(n, count))
+    jobs = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(DEV)
+    nat.check(lib.dfl_reduce_batch(jobs.data_ptr(), len(shapes), blocks, stream()), 'dfl_reduce_batch')
+    torch.cuda.synchronize()
+    for (n, stride, count), src, dst in zip(shapes, srcs, dsts):
+        want = src.cpu().double().view(count, stride)[:, :n].sum(0)
+        np.testing.assert_allclose(dst.cpu().numpy(), want.numpy(), rtol=2e-6, atol=1e-5)

@@ -47,9 +47,10 @@ def test_buckets_cover_every_live_gradient_once():
     for k in plan.dead_params:
         s = plan.grad_offsets[k]
         assert int(covered[s:s + sizes[k]].max()) == 0
-    # heads are final first, the first encoder block last
-    assert order[0].startswith(('seg_conv', 'lands_1x1'))
-    assert order[-1].startswith('down_path.0')
+    # the heads / last decoder block are final first (small sums wait for a batched flush), the first encoder block last
+    assert order[0].startswith(('seg_conv', 'lands_1x1', 'up_path.%d.' % (net.depth - 2)))
+    assert ready['seg_conv.weight'] <= ready['down_path.0.block.0.weight']
+    assert ready['down_path.0.block.0.weight'] == max(ready.values())
 
 
 class _FakeProgram:
