@@ -49,7 +49,7 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rs, uint32_t 
 }
 
 // Second launch-bound = waves per SIMD the register allocation must leave room for (residency per CU, see pick_cfg).
-constexpr int conv_occ(int tiles) { return tiles >= 4 ? 2 : (tiles == 2 ? 5 : 6); }
+constexpr int conv_occ(int tiles) { return tiles >= 4 ? 2 : (tiles == 2 ? 4 : 5); }
 
 template <int WM, int WN, int TM, int TN, int MODE, bool AFF, int EPI>
 __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kernel(const ConvK p) {
@@ -108,10 +108,15 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
     a_mask[r] = mk;
   }
 
-  float4 ra[QA];
-  float4 rb[QB];
-  float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  uint32_t okA = 0;   // MODE 1: bit r = row r valid for the chunk in flight; MODE 0: bit 4r+j
+  // Two register sets: the loads of chunk i+2 are issued while chunk i is multiplied and chunk i+1 (issued one
+  // iteration earlier) waits to be written to LDS -- two chunks of global traffic in flight per wave, which the
+  // 64x64 tiles need to cover the L2/HBM latency at batch-16 sizes.
+  float4 ra[2][QA];
+  float4 rb[2][QB];
+  float4 sc4[2], sh4[2];
+  uint32_t okA[2] = {0, 0};   // MODE 1: bit r = row r valid for the chunk in flight; MODE 0: bit 4r+j
+  sc4[0] = sc4[1] = make_float4(1.f, 1.f, 1.f, 1.f);
+  sh4[0] = sh4[1] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   // ---- MODE 1 state --------------------------------------------------------------------------------------------------
   uint32_t a_rowb[QA];   // byte offset (mod 2^32) of (tap (0,0), channel 4*aq) of each gather row
@@ -137,28 +142,36 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
     cur_dx = cur_tap - cur_dy * KW;
   }
 
+  const int nchunks = (Ktot + KC - 1) / KC;
+  const int ch_begin = blockIdx.z * p.cps;
+  const int ch_end = min(ch_begin + p.cps, nchunks);
+
   // Loads only ISSUE into raw registers; store_AB() (after the MFMA block) applies the affine / zero fill and writes LDS.
-  auto load_AB = [&](int ch) {
+  // Straight-line code: a chunk past the end of the slice is fetched with out-of-range offsets (reads zeros), so the
+  // main loop has no conditional loads and the compiler can keep the younger set in flight across the LDS write.
+  auto load_AB = [&](int ch, int set) {
+    const bool live = ch < ch_end;
     if constexpr (MODE == 1) {
       // must be called once per chunk, in order: uses and advances the uniform cursor
-      const bool kvalid = cur_tap < T;
+      const bool kvalid = live && cur_tap < T;
       const uint32_t tapb = (uint32_t)(((cur_dy * Win + cur_dx) * a.ldx + cur_c0) * 4);
       const uint32_t tbit = kvalid ? (1u << cur_tap) : 0u;
-      okA = 0;
+      uint32_t okm = 0;
 #pragma unroll
       for (int r = 0; r < QA; ++r) {
         const bool ok = (a_mask[r] & tbit) != 0;
-        okA |= ok ? (1u << r) : 0u;
-        ra[r] = buf_load4(rsA, ok ? a_rowb[r] + tapb : OOB, 0);
+        okm |= ok ? (1u << r) : 0u;
+        ra[set][r] = buf_load4(rsA, ok ? a_rowb[r] + tapb : OOB, 0);
       }
+      okA[set] = okm;
       if constexpr (AFF) {
         const int c = (kvalid ? cur_c0 : 0) + 4 * aq;
-        sc4 = *reinterpret_cast<const float4*>(a.in_scale + c);
-        sh4 = *reinterpret_cast<const float4*>(a.in_shift + c);
+        sc4[set] = *reinterpret_cast<const float4*>(a.in_scale + c);
+        sh4[set] = *reinterpret_cast<const float4*>(a.in_shift + c);
       }
-      const uint32_t soff = (uint32_t)ch * (uint32_t)(KC / 4 * 16) * (uint32_t)Ntot;   // chunk = 4 k-quad rows
+      const uint32_t soff = live ? (uint32_t)ch * (uint32_t)(KC / 4 * 16) * (uint32_t)Ntot : 0u;   // chunk = 4 k-quad rows
 #pragma unroll
-      for (int r = 0; r < QB; ++r) rb[r] = buf_load4(rsB, b_voff[r], soff);
+      for (int r = 0; r < QB; ++r) rb[set][r] = buf_load4(rsB, live ? b_voff[r] : OOB, soff);
       cur_c0 += KC;
       if (cur_c0 >= Cin) {
         cur_c0 = 0;
@@ -174,11 +187,11 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
       float vals[QA][4], scv[4], shv[4];
       const float* aff_sc = has_aff ? a.in_scale : a.w;
       const float* aff_sh = has_aff ? a.in_shift : a.w;
-      okA = 0;
+      uint32_t okm = 0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int kj = k + j;
-        const bool kvalid = kj < Ktot;
+        const bool kvalid = live && kj < Ktot;
         const int t = kvalid ? kj / Cin : 0;
         const int c = kvalid ? kj - t * Cin : 0;
         const int dy = t / KW, dx = t - dy * KW;
@@ -188,44 +201,46 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
         for (int r = 0; r < QA; ++r) {
           const bool ok = kvalid && ((a_mask[r] >> t) & 1u);
           const int64_t pix = ok ? ((int64_t)a_base[r] + (int64_t)(a_iy0[r] + dy) * Win + a_ix0[r] + dx) : 0;
-          okA |= ok ? (1u << (4 * r + j)) : 0u;
+          okm |= ok ? (1u << (4 * r + j)) : 0u;
           vals[r][j] = a.x[pix * a.ldx + (ok ? c : 0)];
         }
       }
-      sc4 = make_float4(scv[0], scv[1], scv[2], scv[3]);
-      sh4 = make_float4(shv[0], shv[1], shv[2], shv[3]);
+      okA[set] = okm;
+      sc4[set] = make_float4(scv[0], scv[1], scv[2], scv[3]);
+      sh4[set] = make_float4(shv[0], shv[1], shv[2], shv[3]);
 #pragma unroll
-      for (int r = 0; r < QA; ++r) ra[r] = make_float4(vals[r][0], vals[r][1], vals[r][2], vals[r][3]);
+      for (int r = 0; r < QA; ++r) ra[set][r] = make_float4(vals[r][0], vals[r][1], vals[r][2], vals[r][3]);
 #pragma unroll
       for (int r = 0; r < QB; ++r) {
         const int idx = tid + r * NT;
         const int kq = idx / BN, nn = idx - kq * BN;
         const int kquad = ch * (KC / 4) + kq, n = n0 + nn;
-        const bool ok = (idx < NQB) && (4 * kquad < Ktot) && (n < Ntot);
+        const bool ok = live && (idx < NQB) && (4 * kquad < Ktot) && (n < Ntot);
         const float4 v = *reinterpret_cast<const float4*>(a.w + (ok ? ((int64_t)kquad * Ntot + n) * 4 : 0));
-        rb[r] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        rb[set][r] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
   };
 
-  auto store_AB = [&](int buf) {
+  auto store_AB = [&](int buf, int set) {   // buf == set everywhere: chunk parity picks both
     float* Ab = As + buf * BM * LDK;
 #pragma unroll
     for (int r = 0; r < QA; ++r) {
       const int row = (tid >> 2) + r * RPP;
-      float4 v = ra[r];
+      float4 v = ra[set][r];
+      const float4 sc = sc4[set], sh = sh4[set];
       if constexpr (MODE == 1) {
         if constexpr (AFF) {   // zero padding applies AFTER the BatchNorm affine: out-of-image taps stay 0
-          const bool ok = (okA >> r) & 1u;
-          v.x = ok ? fmaf(v.x, sc4.x, sh4.x) : 0.f;
-          v.y = ok ? fmaf(v.y, sc4.y, sh4.y) : 0.f;
-          v.z = ok ? fmaf(v.z, sc4.z, sh4.z) : 0.f;
-          v.w = ok ? fmaf(v.w, sc4.w, sh4.w) : 0.f;
+          const bool ok = (okA[set] >> r) & 1u;
+          v.x = ok ? fmaf(v.x, sc.x, sh.x) : 0.f;
+          v.y = ok ? fmaf(v.y, sc.y, sh.y) : 0.f;
+          v.z = ok ? fmaf(v.z, sc.z, sh.z) : 0.f;
+          v.w = ok ? fmaf(v.w, sc.w, sh.w) : 0.f;
         }
       } else {
-        const uint32_t o = okA >> (4 * r);
-        const float s0 = has_aff ? sc4.x : 1.f, s1 = has_aff ? sc4.y : 1.f, s2 = has_aff ? sc4.z : 1.f, s3 = has_aff ? sc4.w : 1.f;
-        const float h0 = has_aff ? sh4.x : 0.f, h1 = has_aff ? sh4.y : 0.f, h2 = has_aff ? sh4.z : 0.f, h3 = has_aff ? sh4.w : 0.f;
+        const uint32_t o = okA[set] >> (4 * r);
+        const float s0 = has_aff ? sc.x : 1.f, s1 = has_aff ? sc.y : 1.f, s2 = has_aff ? sc.z : 1.f, s3 = has_aff ? sc.w : 1.f;
+        const float h0 = has_aff ? sh.x : 0.f, h1 = has_aff ? sh.y : 0.f, h2 = has_aff ? sh.z : 0.f, h3 = has_aff ? sh.w : 0.f;
         v.x = (o & 1u) ? fmaf(v.x, s0, h0) : 0.f;
         v.y = (o & 2u) ? fmaf(v.y, s1, h1) : 0.f;
         v.z = (o & 4u) ? fmaf(v.z, s2, h2) : 0.f;
@@ -239,7 +254,7 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
       const int idx = tid + r * NT;
       if (idx < NQB) {
         const int kq = idx / BN, nn = idx - kq * BN;
-        *reinterpret_cast<float4*>(Bb + nn * LDK + 4 * kq) = rb[r];
+        *reinterpret_cast<float4*>(Bb + nn * LDK + 4 * kq) = rb[set][r];
       }
     }
   };
@@ -252,20 +267,7 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nchunks = (Ktot + KC - 1) / KC;
-  const int ch_begin = blockIdx.z * p.cps;
-  const int ch_end = min(ch_begin + p.cps, nchunks);
-  if (ch_begin < ch_end) {
-    load_AB(ch_begin);
-    store_AB(0);
-  }
-  __syncthreads();
-
-  for (int ch = ch_begin; ch < ch_end; ++ch) {
-    const int buf = (ch - ch_begin) & 1;
-    const bool more = (ch + 1) < ch_end;
-    if (more) load_AB(ch + 1);
-    __builtin_amdgcn_sched_barrier(0);
+  auto compute = [&](int buf) {
     const float* Ab = As + buf * BM * LDK + (wm * (TM * 32) + li) * LDK + 4 * lh;
     const float* Bb = Bs + buf * BN * LDK + (wn * (TN * 32) + li) * LDK + 4 * lh;
 #pragma unroll
@@ -283,10 +285,27 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32((&av[i].x)[q], (&bv[j].x)[q], acc[i][j], 0, 0, 0);
     }
-    // pin the order loads | MFMAs | affine + LDS writes: otherwise hipcc hoists part of store_AB() (and its vmcnt
-    // waits) above the MFMA block
+  };
+
+  load_AB(ch_begin, 0);
+  load_AB(ch_begin + 1, 1);
+  store_AB(0, 0);
+  __syncthreads();
+  // Chunks are taken two at a time so that register set and LDS image are compile-time constants; an odd slice
+  // multiplies one all-zero chunk at the end.  The sched_barriers pin the order loads | MFMAs | affine + LDS writes:
+  // otherwise hipcc hoists part of store_AB() (and its vmcnt waits) above the MFMA block.
+  for (int ch = ch_begin; ch < ch_end; ch += 2) {
+    load_AB(ch + 2, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if (more) store_AB(buf ^ 1);
+    compute(0);
+    __builtin_amdgcn_sched_barrier(0);
+    store_AB(1, 1);
+    __syncthreads();
+    load_AB(ch + 3, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(1);
+    __builtin_amdgcn_sched_barrier(0);
+    store_AB(0, 0);
     __syncthreads();
   }
 
