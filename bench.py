@@ -111,6 +111,8 @@ def main():
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--detail', action='store_true', help='per-op table on stderr')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' for a self-test)")
+    ap.add_argument('--optimizer', default='dfl', choices=['dfl', 'torch'],
+                    help="dfl = dfl_amd.SGD (one dfl_sgd_step launch per contiguous run); torch = torch.optim.SGD")
     ap.add_argument('--no-overlap', action='store_true', help='all-reduce after backward instead of overlapped buckets')
     args = ap.parse_args()
 
@@ -132,7 +134,8 @@ def main():
     net = dfl_amd.UNet(**PAPER).to(dev)
     dp = DataParallel(net, overlap=not args.no_overlap) if world > 1 else None
     crit = dfl_amd.DiceAndHeatMapLoss2D(skip_bg=False, heatmap_wgt=0.5)
-    opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4, nesterov=True)
+    SGD = dfl_amd.SGD if args.optimizer == 'dfl' else torch.optim.SGD
+    opt = SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4, nesterov=True)
     B = args.batch
     x, tseg, theat = synth_batch(B, 4321 + rank, dev)
     net.train()
@@ -211,7 +214,7 @@ def main():
                'config': {'workload': 'BASELINE configs[1]: 8x-downsampled, seg + 14-landmark heat-map dual head, '
                                       'batch %d per GPU, Dice+NCC loss, SGD nesterov' % B,
                           'global_batch': B * world, 'image': '1x192x192', 'parallelism': 'dp%d' % world,
-                          'optimizer': 'torch.optim.SGD(momentum 0.9, nesterov, wd 1e-4)', 'last_loss': round(last, 6)},
+                          'optimizer': '%s(momentum 0.9, nesterov, wd 1e-4)' % ('dfl_amd.SGD' if args.optimizer == 'dfl' else 'torch.optim.SGD'), 'last_loss': round(last, 6)},
                'roofline': roofline, 'cpu_baseline': cpu}
         out.update(extra)
         print(json.dumps(out))

@@ -9,5 +9,6 @@ from .dice import DiceLoss2D, DiceAndHeatMapLoss2D
 from .ncc import ncc_2d
 from .util import center_crop, get_device
 from .warm_restarts_lr import WarmRestartLR
+from .sgd import SGD
 
-__all__ = ['UNet', 'DiceLoss2D', 'DiceAndHeatMapLoss2D', 'ncc_2d', 'center_crop', 'get_device', 'WarmRestartLR']
+__all__ = ['UNet', 'DiceLoss2D', 'DiceAndHeatMapLoss2D', 'ncc_2d', 'center_crop', 'get_device', 'WarmRestartLR', 'SGD']

@@ -1,0 +1,91 @@
+"""SGD with momentum / Nesterov / weight decay, torch.optim.SGD semantics, on the flat parameter arena.
+
+Reference: train.py:287-290 builds ``optim.SGD(net.parameters(), lr, momentum, weight_decay, nesterov)`` and calls
+``optimizer.step()`` once per batch (train.py:423).  torch runs that as several multi-tensor kernels over ~140 tensors;
+here parameters (UNet._flatten_parameters), gradients (plan.grad_flat) and momentum buffers share one layout, so a step
+is one dfl_sgd_step launch per contiguous run of live parameters (two runs for the paper network: the never-used
+``downsample_convs[depth-1]`` has no gradient and, exactly as in torch, is skipped -- no weight decay either).
+Parameters whose tensors do not line up (foreign modules, accumulated gradients) are updated tensor by tensor with
+the same kernel.  CPU tensors are refused: there is no fallback path.
+"""
+import torch
+from torch.optim.optimizer import Optimizer, required
+
+from . import _native as nat
+
+
+class SGD(Optimizer):
+    def __init__(self, params, lr=required, momentum=0, dampening=0, weight_decay=0, nesterov=False):
+        if lr is not required and lr < 0.0:
+            raise ValueError('Invalid learning rate: {}'.format(lr))
+        if momentum < 0.0:
+            raise ValueError('Invalid momentum value: {}'.format(momentum))
+        if weight_decay < 0.0:
+            raise ValueError('Invalid weight_decay value: {}'.format(weight_decay))
+        if nesterov and (momentum <= 0 or dampening != 0):
+            raise ValueError('Nesterov momentum requires a momentum and zero dampening')
+        if dampening != 0:
+            raise NotImplementedError('dampening != 0 is not implemented in the HIP path (no reference CLI selects it)')
+        defaults = dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay, nesterov=nesterov)
+        super().__init__(params, defaults)
+        self.grad_scale = 1.0          # parallel.DataParallel leaves SUMMED gradients when asked to; see there
+        self._lib = nat.lib()
+
+    def _momentum_buffers(self, group):
+        """Zero momentum buffers for parameters that have none (torch's first step, buf = g, is mom*0 + g).  When the
+        whole group is new and its parameters share one arena, the buffers get one arena with the same layout."""
+        ps = [p for p in group['params'] if p.grad is not None and 'momentum_buffer' not in self.state.get(p, {})]
+        if not ps:
+            return
+        fresh = all('momentum_buffer' not in self.state.get(p, {}) for p in group['params'])
+        base = min(p.data_ptr() for p in group['params'])
+        end = max(p.data_ptr() + 4 * p.numel() for p in group['params'])
+        span = (end - base) // 4
+        total = sum(p.numel() for p in group['params'])
+        if fresh and len({p.device for p in group['params']}) == 1 and span <= total + 4 * len(group['params']):
+            flat = torch.zeros(span, dtype=torch.float32, device=ps[0].device)
+            for p in ps:                      # like torch: only parameters that received a gradient get state
+                o = (p.data_ptr() - base) // 4
+                self.state[p]['momentum_buffer'] = flat[o:o + p.numel()].view(p.shape)
+        else:
+            for p in ps:
+                self.state[p]['momentum_buffer'] = torch.zeros_like(p.data)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = self._lib
+        for group in self.param_groups:
+            lr, mom, wd, nest = group['lr'], group['momentum'], group['weight_decay'], group['nesterov']
+            live = [p for p in group['params'] if p.grad is not None]
+            if not live:
+                continue
+            for p in live:
+                if not p.is_cuda or not p.grad.is_cuda:
+                    raise nat.DflError('sgd.SGD needs parameters and gradients on the GPU (no CPU path)')
+                if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or not p.grad.is_contiguous():
+                    raise nat.DflError('sgd.SGD needs contiguous float32 parameters and gradients')
+            if mom != 0:
+                self._momentum_buffers(group)
+            stream = torch.cuda.current_stream(live[0].device).cuda_stream
+            # contiguous runs: parameter, gradient and buffer addresses all advance by the same number of bytes
+            runs, cur = [], None
+            for p in live:
+                pp, gp, n = p.data_ptr(), p.grad.data_ptr(), p.numel()
+                bp = self.state[p]['momentum_buffer'].data_ptr() if mom != 0 else 0
+                if cur is not None and pp - cur[0] == gp - cur[1] and (mom == 0 or pp - cur[0] == bp - cur[2]) \
+                        and 0 <= pp - cur[0] - 4 * cur[3] <= 12:
+                    cur[3] = (pp - cur[0]) // 4 + n          # absorbs the alignment padding between slices
+                else:
+                    cur = [pp, gp, bp, n]
+                    runs.append(cur)
+            for pp, gp, bp, n in runs:
+                nat.check(lib.dfl_sgd_step(pp, gp, bp or None, n, lr, mom, wd, self.grad_scale, int(nest), 0, stream),
+                          'dfl_sgd_step')
+            # the kernel wrote behind autograd's back: bump the version counters like an in-place torch op would (the
+            # network re-packs its weights when they move, and autograd must see saved tensors as modified)
+            torch.autograd.graph.increment_version(live)
+        return loss

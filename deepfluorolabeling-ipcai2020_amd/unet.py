@@ -163,12 +163,34 @@ class UNet(nn.Module):
         self._backward_runner = self._run_backward
         self.dp = None                                # set by parallel.DataParallel
         self.direct_grad = True                       # install gradient views as .grad without autograd copies
+        self._flatten_parameters()
 
     # ---------------------------------------------------------------------------------------------- plumbing
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
+        self._flatten_parameters()
         self.invalidate_plans()
         return out
+
+    def _flatten_parameters(self):
+        """Keep every parameter as a view of ONE arena, in parameters() order, each slice padded to 4 floats -- the
+        layout of the gradient arena the backward program fills (plan.grad_flat).  sgd.SGD then updates the whole
+        network with one dfl_sgd_step per contiguous run instead of one launch per tensor."""
+        ps = list(self.parameters())
+        if not ps or any(p.dtype != torch.float32 for p in ps) or len({p.device for p in ps}) != 1:
+            self._param_flat = None
+            return
+        tot = sum((p.numel() + 3) // 4 * 4 for p in ps)
+        flat = torch.zeros(tot, dtype=torch.float32, device=ps[0].device)
+        off = 0
+        with torch.no_grad():
+            for p in ps:
+                n = p.numel()
+                v = flat[off:off + n].view(p.shape)
+                v.copy_(p.data)
+                p.data = v
+                off += (n + 3) // 4 * 4
+        self._param_flat = flat
 
     def invalidate_plans(self):
         """Forget recorded programs (they hold raw parameter addresses)."""

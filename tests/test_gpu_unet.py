@@ -10,6 +10,7 @@ import pytest
 import torch
 
 import dfl_amd
+from dfl_amd import _native as nat
 from conftest import TINY_CFGS, PAPER_CFGS, load_golden
 from oracle import ref_cpu as R
 
@@ -147,8 +148,10 @@ def test_paper_golden(name):
             rel_close(p.grad.cpu().numpy(), ref_g, 8e-2, 'grad ' + k)
 
 
-def test_training_trajectory_matches_reference():
-    """30 SGD steps wired as train.py:405-430 on the toy-ellipses set: per-step loss vs the reference's run."""
+@pytest.mark.parametrize('optimizer', ['torch', 'dfl'])
+def test_training_trajectory_matches_reference(optimizer):
+    """30 SGD steps wired as train.py:405-430 on the toy-ellipses set: per-step loss vs the reference's run, with
+    torch.optim.SGD and with the one-launch dfl_amd.SGD."""
     g = load_golden('trajectory')
     cfg = dict(n_classes=7, depth=3, wf=3, batch_norm=True, padding=True, max_pool=False, num_lands=14, do_res=True,
                block_depth=2)
@@ -160,7 +163,8 @@ def test_training_trajectory_matches_reference():
     P = torch.stack([R.preprocess_proj(projs[i:i + 1], pad) for i in range(8)]).to(DEV)
     S = R.one_hot_masks(segs, 7).to(DEV)
     Hm = torch.stack([R.gaussian_heatmaps(lm[i], H, W) for i in range(8)]).view(8, 14, H, W).to(DEV)
-    opt = torch.optim.SGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4, nesterov=True)
+    SGD = torch.optim.SGD if optimizer == 'torch' else dfl_amd.SGD
+    opt = SGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4, nesterov=True)
     crit = dfl_amd.DiceAndHeatMapLoss2D(skip_bg=False, heatmap_wgt=0.5)
     net.train()
     losses = []
@@ -310,3 +314,53 @@ def test_cpu_input_fails_loudly():
     net = dfl_amd.UNet(n_classes=7, depth=2, wf=2, padding=True, batch_norm=True)
     with pytest.raises(RuntimeError):
         net(torch.zeros(1, 1, 8, 8))
+
+
+def test_fused_sgd_matches_torch_sgd():
+    """dfl_amd.SGD == torch.optim.SGD (train.py:287-290 settings) step for step on the same gradients; the network's
+    parameters sit in one arena, so the whole update is two launches (the unused last down-sampling conv splits it)."""
+    cfg = dict(n_classes=4, depth=3, wf=3, batch_norm=True, padding=True, max_pool=False, num_lands=3)
+    torch.manual_seed(5)
+    na = dfl_amd.UNet(1, **cfg).to(DEV)
+    nb = dfl_amd.UNet(1, **cfg).to(DEV)
+    nb.load_state_dict(na.state_dict())
+    assert na._param_flat is not None and na._param_flat.is_cuda
+    oa = dfl_amd.SGD(na.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-3, nesterov=True)
+    ob = torch.optim.SGD(nb.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-3, nesterov=True)
+    x = torch.randn(2, 1, 32, 32, device=DEV)
+    calls = []
+    real = oa._lib.dfl_sgd_step
+    for step in range(4):
+        for net, opt in ((na, oa), (nb, ob)):
+            opt.zero_grad()
+            seg, heat = net(x)
+            (seg.square().mean() + heat.square().mean()).backward()
+        if step == 3:
+            class Spy:
+                def __getattr__(self, k):
+                    return getattr(type(self).lib, k)
+
+                def dfl_sgd_step(self, *a):
+                    calls.append(a[3])
+                    return real(*a)
+            Spy.lib = oa._lib
+            oa._lib = Spy()
+        oa.step()
+        ob.step()
+        if step == 1:                       # learning-rate schedulers write param_groups[...]['lr']
+            oa.param_groups[0]['lr'] = ob.param_groups[0]['lr'] = 0.03
+    torch.cuda.synchronize()
+    for (k, pa), pb in zip(na.named_parameters(), nb.parameters()):
+        np.testing.assert_allclose(pa.detach().cpu().numpy(), pb.detach().cpu().numpy(), rtol=2e-5, atol=2e-6, err_msg=k)
+    dead = dict(na.named_parameters())['downsample_convs.2.weight']
+    assert dead.grad is None
+    assert len(calls) == 2 and sum(calls) >= sum(p.numel() for p in na.parameters() if p.grad is not None)
+    sd = oa.state_dict()
+    assert len(sd['state']) == len([p for p in na.parameters() if p.grad is not None])
+
+
+def test_fused_sgd_refuses_cpu():
+    p = torch.nn.Parameter(torch.zeros(4))
+    p.grad = torch.ones(4)
+    with pytest.raises(nat.DflError):
+        dfl_amd.SGD([p], lr=0.1).step()
