@@ -100,7 +100,7 @@ class EnsembleArgs(C.Structure):
 
 
 class SumPartialsArgs(C.Structure):
-    _fields_ = [('src', fp), ('dst', fp), ('n', i64), ('splits', i32), ('reserved', i32)]
+    _fields_ = [('src', fp), ('dst', fp), ('n', i64), ('splits', i32), ('T', i32)]
 
 
 class PackArgs(C.Structure):
@@ -121,7 +121,8 @@ class MemsetArgs(C.Structure):
 
 
 class ReduceJob(C.Structure):
-    _fields_ = [('src', fp), ('dst', fp), ('n', i64), ('stride', i64), ('count', i32), ('first_block', i32)]
+    _fields_ = [('src', fp), ('dst', fp), ('n', i64), ('stride', i64), ('count', i32), ('first_block', i32),
+                ('T', i32), ('reserved', i32)]
 
 
 class ReduceBatchArgs(C.Structure):
@@ -178,7 +179,7 @@ def lib():
     L.dfl_loss_scratch_doubles.restype = i64
     L.dfl_loss_scratch_doubles.argtypes = [i32, i32, i32]
     L.dfl_rowblock_count.argtypes = [i64, i32]
-    L.dfl_sum_partials.argtypes = [fp, fp, i64, i32, fp]
+    L.dfl_sum_partials.argtypes = [fp, fp, i64, i32, i32, fp]
     L.dfl_pack_weights.argtypes = [fp, i32, i64, fp]
     L.dfl_bn_eval_prepare.argtypes = [fp, fp, fp, fp, fp, fp, i32, f32, fp]
     L.dfl_reduce_partials.argtypes = [fp, fp, i32, i32, i32, fp]

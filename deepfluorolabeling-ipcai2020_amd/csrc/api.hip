@@ -81,7 +81,7 @@ static int exec_one(const dfl_op* ops, int i, dfl_stream_t stream) {
       case DFL_OP_WGRAD: rc = dfl_conv2d_wgrad(static_cast<const dfl_wgrad_args*>(p), stream); break;
       case DFL_OP_SUM_PARTIALS: {
         const dfl_sum_partials_args* a = static_cast<const dfl_sum_partials_args*>(p);
-        rc = dfl_sum_partials(a->src, a->dst, a->n, a->splits, stream);
+        rc = dfl_sum_partials(a->src, a->dst, a->n, a->splits, a->T, stream);
         break;
       }
       case DFL_OP_PACK: {

@@ -305,13 +305,13 @@ __global__ void __launch_bounds__(RB_T) reduce_batch_kernel(const dfl_reduce_job
       if (sl < off) red[sl][o] += red[sl + off][o];
       __syncthreads();
     }
-    if (sl == 0 && i < j.n) j.dst[i] = (float)red[0][o];
+    if (sl == 0 && i < j.n) j.dst[j.T > 1 ? (i % (j.n / j.T)) * j.T + i / (j.n / j.T) : i] = (float)red[0][o];
   } else {
     const int64_t i = (int64_t)b * RB_T + threadIdx.x;
     if (i < j.n) {
       double s = 0.0;
       for (int k = 0; k < j.count; ++k) s += (double)j.src[(int64_t)k * j.stride + i];
-      j.dst[i] = (float)s;
+      j.dst[j.T > 1 ? (i % (j.n / j.T)) * j.T + i / (j.n / j.T) : i] = (float)s;
     }
   }
 }

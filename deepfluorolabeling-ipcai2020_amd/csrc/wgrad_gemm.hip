@@ -263,7 +263,9 @@ __global__ void __launch_bounds__(WM* WN * 64, wg_occ(TM* TN* TPB, FAST)) wgrad_
     __syncthreads();
   }
 
-  float* out = (a.splits > 1) ? a.partial + (int64_t)blockIdx.z * a.Cm * a.Cg * T : a.dw;
+  // slices: tap-major [T][Cm][Cg] (each accumulator row is a contiguous 128-byte store); final result: torch order
+  const bool sliced = a.splits > 1;
+  float* out = sliced ? a.partial + (int64_t)blockIdx.z * a.Cm * a.Cg * T : a.dw;
 #pragma unroll
   for (int tt = 0; tt < TPB; ++tt) {
     const int t = tap0 + tt;
@@ -275,26 +277,30 @@ __global__ void __launch_bounds__(WM* WN * 64, wg_occ(TM* TN* TPB, FAST)) wgrad_
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int cm = cm0 + wm * (TM * 32) + i * 32 + mfma32_row(r, lane);
-          if (cm < a.Cm && cg < a.Cg) out[((int64_t)cm * a.Cg + cg) * T + t] = acc[tt][i][j][r];
+          const int64_t o = sliced ? ((int64_t)t * a.Cm + cm) * a.Cg + cg : ((int64_t)cm * a.Cg + cg) * T + t;
+          if (cm < a.Cm && cg < a.Cg) out[o] = acc[tt][i][j][r];
         }
       }
     }
   }
 }
 
-__global__ void sum_partials_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n, int splits) {
+// i walks the slices' order ([T][R]); the sum lands at [R][T]
+__global__ void sum_partials_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n, int splits,
+                                    int T) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t R = n / T;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     float s = 0.f;
     for (int k = 0; k < splits; ++k) s += src[(int64_t)k * n + i];
-    dst[i] = s;
+    dst[T > 1 ? (i % R) * T + i / R : i] = s;
   }
 }
 
 // Many slices of a small tensor (narrow layers cut the pixel range into ~1000 slices): 16 outputs x 16 slice lanes per
 // workgroup, 8 independent loads in flight per thread, LDS tree over the lanes.  Same summation order every run.
 __global__ void __launch_bounds__(256) sum_partials_wide_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                                                int64_t n, int splits) {
+                                                                int64_t n, int splits, int T) {
   __shared__ float red[16][17];
   const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int64_t i = (int64_t)blockIdx.x * 16 + o;
@@ -313,7 +319,8 @@ __global__ void __launch_bounds__(256) sum_partials_wide_kernel(const float* __r
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) s += red[j][o];
-    dst[i] = s;
+    const int64_t R = n / T;
+    dst[T > 1 ? (i % R) * T + i / R : i] = s;
   }
 }
 
@@ -428,17 +435,19 @@ extern "C" int dfl_conv2d_wgrad(const dfl_wgrad_args* a, dfl_stream_t stream) {
   }
 }
 
-extern "C" int dfl_sum_partials(const float* src, float* dst, int64_t n, int32_t splits, dfl_stream_t stream) {
+extern "C" int dfl_sum_partials(const float* src, float* dst, int64_t n, int32_t splits, int32_t T, dfl_stream_t stream) {
   DFL_REQUIRE(src && dst && n >= 0 && splits >= 1, "dfl_sum_partials: bad args");
+  if (T < 1) T = 1;
+  DFL_REQUIRE(n % T == 0, "dfl_sum_partials: n must be a multiple of T");
   if (n == 0) return DFL_OK;
   if (splits >= 32 && n <= (1 << 20)) {
     hipLaunchKernelGGL(dfl::sum_partials_wide_kernel, dim3((unsigned)dfl::ceil_div(n, 16)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), src, dst, n, (int)splits);
+                       static_cast<hipStream_t>(stream), src, dst, n, (int)splits, (int)T);
     return dfl::check_launch("dfl_sum_partials");
   }
   int64_t blocks = dfl::ceil_div(n, 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(dfl::sum_partials_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     src, dst, n, (int)splits);
+                     src, dst, n, (int)splits, (int)T);
   return dfl::check_launch("dfl_sum_partials");
 }

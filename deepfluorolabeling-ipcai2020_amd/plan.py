@@ -175,7 +175,7 @@ class UNetPlan:
             part = self._wg_partial(s * n) if big else self._new(s * n)   # deferred sums keep their own slices
             a.partial = part.data_ptr()
             prog.add(a)
-            self._defer_sum(prog, part.data_ptr(), dw.data_ptr(), n, n, s)
+            self._defer_sum(prog, part.data_ptr(), dw.data_ptr(), n, n, s, T=KH * KW)
         else:
             prog.add(a)
 
@@ -183,8 +183,8 @@ class UNetPlan:
     # and one dfl_reduce_batch finishes the queue once FLUSH_BYTES of gradient are waiting (and at the end of backward).
     FLUSH_BYTES = 4 << 20
 
-    def _defer_sum(self, prog, src, dst, n, stride, count):
-        self._red_pending.append((src, dst, n, stride, count))
+    def _defer_sum(self, prog, src, dst, n, stride, count, T=1):
+        self._red_pending.append((src, dst, n, stride, count, T))
         self._red_bytes += 4 * n
         if self._red_bytes >= self.FLUSH_BYTES:
             self._flush_sums(prog)
@@ -195,8 +195,9 @@ class UNetPlan:
             return
         arr = (ReduceJob * len(jobs))()
         blocks = 0
-        for i, (src, dst, n, stride, count) in enumerate(jobs):
+        for i, (src, dst, n, stride, count, T) in enumerate(jobs):
             arr[i].src, arr[i].dst, arr[i].n, arr[i].stride, arr[i].count, arr[i].first_block = src, dst, n, stride, count, blocks
+            arr[i].T = T
             blocks += nat.check(self.lib.dfl_reduce_job_blocks(n, count), 'dfl_reduce_job_blocks')
         dev = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(self.dev)
         self._keep.append(dev)

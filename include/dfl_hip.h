@@ -99,7 +99,8 @@ int dfl_conv_suggest_splits(const dfl_conv_args* a);
  * same M pixels.  Conv2d: G = layer input, d = output gradient, (cm,cg) = (Cout,Cin) => dw has the torch
  * layout [Cout][Cin][KH][KW].  ConvTranspose2d(k2,s2): G = output gradient gathered with stride 2, d = layer
  * input => [Cin][Cout][2][2].  The pixel range is split over `splits` blocks; with splits > 1 the kernel writes
- * partial[split][Cm][Cg][T] to `partial` and dfl_sum_partials finishes the sum into dw.
+ * partial[split][T][Cm][Cg] (tap-major: the accumulator tiles store as full 128-byte rows instead of 4-byte
+ * scatters) and dfl_sum_partials / dfl_reduce_batch finish the sum into dw, transposing to [Cm][Cg][T].
  * ------------------------------------------------------------------------------------------------------------ */
 typedef struct {
   const float* g;        /* gathered tensor, NHWC, pixel stride ldg */
@@ -107,7 +108,7 @@ typedef struct {
   const float* in_scale; /* [Cg] or NULL: affine on load of g */
   const float* in_shift;
   float* dw;             /* [Cm][Cg][T] when splits == 1 */
-  float* partial;        /* [splits][Cm][Cg][T] when splits > 1 */
+  float* partial;        /* [splits][T][Cm][Cg] when splits > 1 */
   int32_t N, Hin, Win, Cg, ldg;
   int32_t KH, KW, stride, pad;
   int32_t Hout, Wout, Cm, ldd;
@@ -119,8 +120,8 @@ int dfl_conv2d_wgrad(const dfl_wgrad_args* a, dfl_stream_t stream);
 /* Suggested number of splits for a problem (>= 1); the caller sizes `partial` from it. */
 int dfl_wgrad_suggest_splits(const dfl_wgrad_args* a);
 
-/* dst[i] = sum_{s < splits} src[s*n + i], i < n. */
-int dfl_sum_partials(const float* src, float* dst, int64_t n, int32_t splits, dfl_stream_t stream);
+/* dst[r*T + t] = sum_{s < splits} src[s*n + t*(n/T) + r],  r < n/T, t < T  (T = 1: plain sum of slices). */
+int dfl_sum_partials(const float* src, float* dst, int64_t n, int32_t splits, int32_t T, dfl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Batched weight re-layout (one launch for the whole network).  dfl_conv2d consumes its weights "quad-packed":
@@ -216,14 +217,16 @@ int dfl_reduce_partials(const float* partials, float* out, int32_t nblocks, int3
 
 /* Batched form of dfl_reduce_partials / dfl_sum_partials: ONE launch finishes many small sums (the per-layer bias
  * gradients and the pixel-slice partials of dfl_conv2d_wgrad of a whole backward pass; the recorded program defers
- * them to a few flush points instead of one launch per layer).  Job j:  dst[i] = sum_{k < count} src[k*stride + i],
- * i < n, accumulated in fp64 in a fixed order (bit-reproducible).  first_block is the prefix sum of
+ * them to a few flush points instead of one launch per layer).  Job j:  dst[i'] = sum_{k < count} src[k*stride + i],
+ * i < n, accumulated in fp64 in a fixed order (bit-reproducible); i' = i for T <= 1, else the tap-major ->
+ * [..][T] transposition i' = (i % (n/T))*T + i/(n/T) of dfl_conv2d_wgrad's slices.  first_block is the prefix sum of
  * dfl_reduce_job_blocks(n, count) over the preceding jobs; total_blocks the sum over all jobs. */
 typedef struct {
   const float* src;
   float* dst;
   int64_t n, stride;
   int32_t count, first_block;
+  int32_t T, reserved;
 } dfl_reduce_job;
 int dfl_reduce_job_blocks(int64_t n, int32_t count);
 /* jobs: DEVICE pointer to njobs records. */
@@ -357,7 +360,7 @@ typedef enum {
   DFL_OP_HEAD_FWD = 14, DFL_OP_HEAD_BWD = 15, DFL_OP_MEMSET = 16, DFL_OP_REDUCE_BATCH = 17
 } dfl_op_kind;
 
-typedef struct { const float* src; float* dst; int64_t n; int32_t splits; int32_t reserved; } dfl_sum_partials_args;
+typedef struct { const float* src; float* dst; int64_t n; int32_t splits; int32_t T; } dfl_sum_partials_args;
 typedef struct { const dfl_pack_job* jobs_dev; int64_t max_elems; int32_t njobs; int32_t reserved; } dfl_pack_args;
 typedef struct { const float* gamma; const float* beta; const float* running_mean; const float* running_var;
                  float* scale; float* shift; int32_t C; float eps; } dfl_bn_eval_args;

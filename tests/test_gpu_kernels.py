@@ -300,7 +300,7 @@ def wgrad_call(gx, d, KH, KW, stride, pad, Hout, Wout, in_aff=None, force_splits
         a.partial = part.data_ptr()
     nat.check(lib.dfl_conv2d_wgrad(C.addressof(a), stream()), 'dfl_conv2d_wgrad')
     if s > 1:
-        nat.check(lib.dfl_sum_partials(part.data_ptr(), dw.data_ptr(), Cm * Cg * T, s, stream()))
+        nat.check(lib.dfl_sum_partials(part.data_ptr(), dw.data_ptr(), Cm * Cg * T, s, T, stream()))
     torch.cuda.synchronize()
     return dw.cpu(), s
 
@@ -596,19 +596,22 @@ def test_reduce_batch():
     import ctypes as C
     lib = nat.lib()
     g = torch.Generator().manual_seed(17)
-    shapes = [(32, 64, 9216), (9216, 9216, 1366), (5, 7, 3), (1, 1, 200), (300000, 300000, 2), (819, 819, 70), (64, 128, 64)]
+    # (n, stride, count, T): T > 1 = tap-major slices of dfl_conv2d_wgrad, transposed to [..][T] while summing
+    shapes = [(32, 64, 9216, 1), (9216, 9216, 1366, 9), (5, 7, 3, 1), (1, 1, 200, 1), (300000, 300000, 2, 4),
+              (819, 819, 70, 1), (64, 128, 64, 1), (36, 36, 5, 9)]
     srcs, dsts, arr, blocks = [], [], (nat.ReduceJob * len(shapes))(), 0
-    for i, (n, stride, count) in enumerate(shapes):
+    for i, (n, stride, count, T) in enumerate(shapes):
         src = torch.randn(count * stride, generator=g).to(DEV)
         dst = torch.full((n,), float('nan'), device=DEV)
         srcs.append(src)
         dsts.append(dst)
         arr[i].src, arr[i].dst, arr[i].n, arr[i].stride, arr[i].count, arr[i].first_block = (
             src.data_ptr(), dst.data_ptr(), n, stride, count, blocks)
+        arr[i].T = T
         blocks += nat.check(lib.dfl_reduce_job_blocks(n, count))
     jobs = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(DEV)
     nat.check(lib.dfl_reduce_batch(jobs.data_ptr(), len(shapes), blocks, stream()), 'dfl_reduce_batch')
     torch.cuda.synchronize()
-    for (n, stride, count), src, dst in zip(shapes, srcs, dsts):
-        want = src.cpu().double().view(count, stride)[:, :n].sum(0)
+    for (n, stride, count, T), src, dst in zip(shapes, srcs, dsts):
+        want = src.cpu().double().view(count, stride)[:, :n].sum(0).view(T, n // T).t().reshape(-1)
         np.testing.assert_allclose(dst.cpu().numpy(), want.numpy(), rtol=2e-6, atol=1e-5)
