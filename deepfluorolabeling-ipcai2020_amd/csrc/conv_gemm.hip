@@ -37,8 +37,9 @@ struct ConvK {
   dfl_conv_args a;
   int Mtot, Ktot, Hg, Wg, Cout;
   int fast;          // MODE 1 preconditions hold
+  int so_simple;
   int splits, cps;   // split-K: number of K slices and chunks per slice
-  uint32_t x_bytes, w_bytes, y_bytes;
+  uint32_t x_bytes, w_bytes, y_bytes, so_bytes;
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -350,24 +351,66 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
       cbias[j] = (a.bias != nullptr && cok[j]) ? a.bias[n] : 0.f;
     }
     const uint32_t ldyb = (uint32_t)a.ldy * 4u;
+    if (a.stat_other == nullptr) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+      for (int i = 0; i < TM; ++i) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int mb = m0 + wm * (TM * 32) + i * 32 + 8 * g + 4 * lh;
-        const uint32_t rowb = (uint32_t)mb * ldyb;
+        for (int g = 0; g < 4; ++g) {
+          const int mb = m0 + wm * (TM * 32) + i * 32 + 8 * g + 4 * lh;
+          const uint32_t rowb = (uint32_t)mb * ldyb;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const bool rok = (mb + rr) < p.Mtot;
+          for (int rr = 0; rr < 4; ++rr) {
+            const bool rok = (mb + rr) < p.Mtot;
 #pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            float v = acc[i][j][4 * g + rr] + cbias[j];
-            if (a.relu) v = fmaxf(v, 0.f);
-            const bool ok = rok && cok[j];
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsY, ok ? rowb + (uint32_t)rr * ldyb + cb[j] : OOB, 0, 0);
-            const float vm = ok ? v : 0.f;
-            s1[j] += vm;
-            s2[j] = fmaf(vm, vm, s2[j]);
+            for (int j = 0; j < TN; ++j) {
+              float v = acc[i][j][4 * g + rr] + cbias[j];
+              if (a.relu) v = fmaxf(v, 0.f);
+              const bool ok = rok && cok[j];
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsY, ok ? rowb + (uint32_t)rr * ldyb + cb[j] : OOB, 0, 0);
+              const float vm = ok ? v : 0.f;
+              s1[j] += vm;
+              s2[j] = fmaf(vm, vm, s2[j]);
+            }
+          }
+        }
+      }
+    } else {
+      // statistics against a partner tensor u (sum v, sum v*u): u comes through a bounds-checked descriptor, the
+      // loads of a whole 32-row tile are issued before the first one is consumed
+      __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.stat_other), 0, (int)p.so_bytes, 0x00020000);
+      const uint32_t ldub = (uint32_t)a.ldso * 4u;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        float u[16][TN];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int mb = m0 + wm * (TM * 32) + i * 32 + 8 * g + 4 * lh;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const bool rok = (mb + rr) < p.Mtot;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              u[4 * g + rr][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                  rsU, (rok && cok[j]) ? (uint32_t)(mb + rr) * ldub + cb[j] : OOB, 0, 0));
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int mb = m0 + wm * (TM * 32) + i * 32 + 8 * g + 4 * lh;
+          const uint32_t rowb = (uint32_t)mb * ldyb;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const bool rok = (mb + rr) < p.Mtot;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              float v = acc[i][j][4 * g + rr] + cbias[j];
+              if (a.relu) v = fmaxf(v, 0.f);
+              const bool ok = rok && cok[j];
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsY, ok ? rowb + (uint32_t)rr * ldyb + cb[j] : OOB, 0, 0);
+              const float vm = ok ? v : 0.f;
+              s1[j] += vm;
+              s2[j] = fmaf(vm, u[4 * g + rr][j], s2[j]);
+            }
           }
         }
       }
@@ -649,6 +692,9 @@ static int prepare(const dfl_conv_args* a, ConvK* k) {
   k->x_bytes = (uint32_t)(xb < lim ? xb : 0);
   k->w_bytes = (uint32_t)(wb < lim ? wb : 0);
   k->y_bytes = (uint32_t)(yb < lim ? yb : 0);
+  const int64_t sob = (a->stat_other != nullptr) ? ((M - 1) * a->ldso + a->Ntot) * 4 : 0;
+  k->so_bytes = (uint32_t)(sob < lim ? sob : 0);
+  k->so_simple = sob < lim;     // the simple epilogue can fetch the statistics partner through a buffer descriptor
   k->splits = 1;
   k->cps = (int)ceil_div(k->Ktot, KC);
   return DFL_OK;
@@ -699,7 +745,7 @@ extern "C" int dfl_conv2d(const dfl_conv_args* a, dfl_stream_t stream) {
     k.splits = a->splits;
     k.cps = (int)dfl::ceil_div(nchunks, a->splits);
   }
-  const bool general = a->add != nullptr || a->accumulate || a->stat_other != nullptr || a->scatter2x2;
+  const bool general = a->add != nullptr || a->accumulate || a->scatter2x2 || (a->stat_other != nullptr && !k.so_simple);
   const bool aff = a->in_scale != nullptr;
   if (!k.fast) {
     rc = dfl::launch<2, 2, 1, 1, 0, true, 1>(k, s);

@@ -8,6 +8,7 @@ channel halves of one buffer (pixel stride 2C); BatchNorm is never applied as a 
 ride on the next consumer's loads (see include/dfl_hip.h).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -182,6 +183,7 @@ class UNetPlan:
     # Small sums (bias gradients, pixel-slice partials of narrow layers) are not launched one by one: they queue up
     # and one dfl_reduce_batch finishes the queue once FLUSH_BYTES of gradient are waiting (and at the end of backward).
     FLUSH_BYTES = 4 << 20
+    FUSE_BWD_STATS = os.environ.get('DFL_FUSE_BWD_STATS', '1') != '0'
 
     def _defer_sum(self, prog, src, dst, n, stride, count, T=1):
         self._red_pending.append((src, dst, n, stride, count, T))
@@ -363,6 +365,7 @@ class UNetPlan:
                         self._conv(bwd, dout, self._pack_conv_dgrad(rw), dxin, 1, 1, 1, 0, xin.C)
                         wrote_dxin = True
                 g = dout
+                fused = None        # (partials, rows): BN-backward sums of g already left by the producing dgrad conv
                 for d in reversed(range(bd)):
                     cv = convs[d]
                     r = cv['r']
@@ -371,19 +374,22 @@ class UNetPlan:
                     coef = None
                     if cv['bn'] is not None:
                         gamma, mean, invstd, bname = cv['bn']
-                        part = self._new(nb * 2 * Cout)
-                        bwd.add(ColstatsArgs(a=g.ptr, b=r.ptr, partials=part.data_ptr(), M=r.M, C=Cout, lda=g.ld,
-                                             ldb=r.ld, nblocks=nb))
+                        if fused is not None:
+                            part, prow = fused
+                        else:
+                            part, prow = self._new(nb * 2 * Cout), nb
+                            bwd.add(ColstatsArgs(a=g.ptr, b=r.ptr, partials=part.data_ptr(), M=r.M, C=Cout, lda=g.ld,
+                                                 ldb=r.ld, nblocks=nb))
                         coef = self._new(3 * Cout)
                         bwd.add(BnBwdFinalizeArgs(partials=part.data_ptr(), gamma=gamma.data_ptr(),
                                                   save_mean=mean.data_ptr(), save_invstd=invstd.data_ptr(),
                                                   dgamma=G[bname + '.weight'].data_ptr(),
                                                   dbeta=G[bname + '.bias'].data_ptr(), coef=coef.data_ptr(),
-                                                  count=r.M, nblocks=nb, C=Cout))
+                                                  count=r.M, nblocks=prow, C=Cout))
                         if do_res and d == bd - 1:
                             # residual bias gradient = column sums of dout, already in the same partials
                             self._defer_sum(bwd, part.data_ptr(), G[prefix + '.res_conv1x1.bias'].data_ptr(), Cout,
-                                            2 * Cout, nb)
+                                            2 * Cout, prow)
                     elif do_res and d == bd - 1:
                         self._colsum(bwd, g, G[prefix + '.res_conv1x1.bias'])
                     bpart = self._new(nb * Cout)
@@ -397,7 +403,13 @@ class UNetPlan:
                     if d > 0:
                         wd = self._pack_conv_dgrad(cv['w'])
                         dz = self._scratch_act('dz', N, inp.H, inp.W, Cout)
-                        self._conv(bwd, dpre, wd, dz, 3, 3, 1, 2 - pad, Cout)
+                        prev = convs[d - 1]
+                        if prev['bn'] is not None and self.FUSE_BWD_STATS:
+                            # the data-gradient conv leaves sum(dz), sum(dz*r) per channel for the next BN backward
+                            fused = self._conv(bwd, dpre, wd, dz, 3, 3, 1, 2 - pad, Cout, stats=True, stat_other=prev['r'])
+                        else:
+                            fused = None
+                            self._conv(bwd, dpre, wd, dz, 3, 3, 1, 2 - pad, Cout)
                         g = dz
                     elif dxin is not None:
                         wd = self._pack_conv_dgrad(cv['w'])
