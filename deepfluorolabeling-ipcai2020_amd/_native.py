@@ -129,13 +129,17 @@ class ReduceBatchArgs(C.Structure):
     _fields_ = [('jobs_dev', fp), ('njobs', i32), ('total_blocks', i32)]
 
 
+class SyncArgs(C.Structure):
+    _fields_ = [('event', i32), ('reserved', i32)]
+
+
 class Op(C.Structure):
-    _fields_ = [('kind', i32), ('reserved', i32), ('args', fp)]
+    _fields_ = [('kind', i32), ('stream', i32), ('args', fp)]
 
 
 OP_CONV, OP_WGRAD, OP_SUM_PARTIALS, OP_PACK, OP_BN_FINALIZE, OP_BN_EVAL, OP_COLSTATS, OP_BN_BWD_FINALIZE, \
     OP_BN_RELU_BWD, OP_REDUCE_PARTIALS, OP_AFFINE_COPY, OP_POOL_FWD, OP_POOL_BWD, OP_HEAD_FWD, OP_HEAD_BWD, \
-    OP_MEMSET, OP_REDUCE_BATCH = range(1, 18)
+    OP_MEMSET, OP_REDUCE_BATCH, OP_RECORD, OP_WAIT = range(1, 20)
 
 _KIND_OF = {ConvArgs: OP_CONV, WgradArgs: OP_WGRAD, SumPartialsArgs: OP_SUM_PARTIALS, PackArgs: OP_PACK,
             BnFinalizeArgs: OP_BN_FINALIZE, BnEvalArgs: OP_BN_EVAL, ColstatsArgs: OP_COLSTATS,
@@ -228,21 +232,31 @@ class Program:
     def __init__(self):
         self.structs = []      # keeps the argument structs alive
         self.kinds = []
+        self.streams = []      # 0 = the caller's stream, 1.. = library side streams (dfl_op.stream)
         self._ops = None
         self.keep = []         # tensors referenced by raw pointers
 
-    def add(self, args_struct, kind=None):
+    def add(self, args_struct, kind=None, stream=0):
         self.structs.append(args_struct)
         self.kinds.append(kind if kind is not None else _KIND_OF[type(args_struct)])
+        self.streams.append(stream)
         self._ops = None
         return args_struct
+
+    def record(self, event, stream=0):
+        """Record library event `event` on `stream` (DFL_OP_RECORD)."""
+        return self.add(SyncArgs(event=event), OP_RECORD, stream)
+
+    def wait(self, event, stream=0):
+        """Make `stream` wait for library event `event` (DFL_OP_WAIT)."""
+        return self.add(SyncArgs(event=event), OP_WAIT, stream)
 
     def add_pool(self, args_struct, backward):
         return self.add(args_struct, OP_POOL_BWD if backward else OP_POOL_FWD)
 
     def extend(self, other):
-        for s, k in zip(other.structs, other.kinds):
-            self.add(s, k)
+        for s, k, st in zip(other.structs, other.kinds, other.streams):
+            self.add(s, k, st)
         self.keep.extend(other.keep)
 
     def __len__(self):
@@ -252,6 +266,7 @@ class Program:
         arr = (Op * len(self.structs))()
         for i, (s, k) in enumerate(zip(self.structs, self.kinds)):
             arr[i].kind = k
+            arr[i].stream = self.streams[i]
             arr[i].args = C.addressof(s)
         self._ops = arr
 

@@ -2,6 +2,9 @@
 // list of kernel calls with one host->library transition (include/dfl_hip.h: dfl_exec).
 #include <string.h>
 
+#include <mutex>
+#include <vector>
+
 #include "common.h"
 
 namespace dfl {
@@ -12,6 +15,33 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+}  // namespace dfl
+
+namespace dfl {
+// Side streams and events of the program executor (dfl_op.stream / DFL_OP_RECORD / DFL_OP_WAIT): created on first use
+// on the device that is current then (one process drives one GPU), never destroyed.
+static std::mutex g_sync_mu;
+static hipStream_t g_side[DFL_MAX_SIDE_STREAMS] = {nullptr};
+static std::vector<hipEvent_t> g_events;
+
+static hipStream_t pick_stream(int id, hipStream_t main) {
+  if (id <= 0) return main;
+  if (id > DFL_MAX_SIDE_STREAMS) return nullptr;
+  std::lock_guard<std::mutex> lk(g_sync_mu);
+  if (g_side[id - 1] == nullptr && hipStreamCreateWithFlags(&g_side[id - 1], hipStreamNonBlocking) != hipSuccess) return nullptr;
+  return g_side[id - 1];
+}
+
+static hipEvent_t pick_event(int id) {
+  if (id < 0 || id >= 65536) return nullptr;
+  std::lock_guard<std::mutex> lk(g_sync_mu);
+  while ((int)g_events.size() <= id) {
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    g_events.push_back(e);
+  }
+  return g_events[id];
 }
 }  // namespace dfl
 
@@ -30,7 +60,7 @@ extern "C" int dfl_sizeof(int which) {
   return sizes[which];
 }
 
-static int exec_one(const dfl_op* ops, int i, dfl_stream_t stream);
+static int exec_one(const dfl_op* ops, int i, dfl_stream_t stream, bool serial);
 
 extern "C" int dfl_exec(const dfl_op* ops, int32_t n_ops, dfl_stream_t stream) {
   if (ops == nullptr || n_ops < 0) {
@@ -38,7 +68,7 @@ extern "C" int dfl_exec(const dfl_op* ops, int32_t n_ops, dfl_stream_t stream) {
     return DFL_ERR_INVALID_ARG;
   }
   for (int i = 0; i < n_ops; ++i) {
-    int rc = exec_one(ops, i, stream);
+    int rc = exec_one(ops, i, stream, false);
     if (rc != DFL_OK) return rc;
   }
   return DFL_OK;
@@ -56,7 +86,7 @@ extern "C" int dfl_exec_timed(const dfl_op* ops, int32_t n_ops, dfl_stream_t str
   hipEventRecord(ev[0], s);
   int done = 0;
   for (int i = 0; i < n_ops; ++i) {
-    rc = exec_one(ops, i, stream);
+    rc = exec_one(ops, i, stream, true);   // program order on one stream is a valid schedule of any program
     if (rc != DFL_OK) break;
     hipEventRecord(ev[i + 1], s);
     done = i + 1;
@@ -72,11 +102,33 @@ extern "C" int dfl_exec_timed(const dfl_op* ops, int32_t n_ops, dfl_stream_t str
   return rc;
 }
 
-static int exec_one(const dfl_op* ops, int i, dfl_stream_t stream) {
+static int exec_one(const dfl_op* ops, int i, dfl_stream_t main_stream, bool serial) {
   {
     const void* p = ops[i].args;
     int rc = DFL_OK;
+    dfl_stream_t stream = main_stream;
+    if (!serial && ops[i].stream != 0) {
+      stream = dfl::pick_stream(ops[i].stream, static_cast<hipStream_t>(main_stream));
+      if (stream == nullptr) {
+        dfl::set_error("dfl_exec: cannot get side stream %d (op %d)", ops[i].stream, i);
+        return DFL_ERR_LAUNCH;
+      }
+    }
     switch (ops[i].kind) {
+      case DFL_OP_RECORD:
+      case DFL_OP_WAIT: {
+        if (serial) break;
+        const dfl_sync_args* a = static_cast<const dfl_sync_args*>(p);
+        hipEvent_t e = dfl::pick_event(a->event);
+        hipError_t err = (e == nullptr) ? hipErrorInvalidValue
+                         : (ops[i].kind == DFL_OP_RECORD ? hipEventRecord(e, static_cast<hipStream_t>(stream))
+                                                         : hipStreamWaitEvent(static_cast<hipStream_t>(stream), e, 0));
+        if (err != hipSuccess) {
+          dfl::set_error("dfl_exec: event %d: %s", a->event, hipGetErrorString(err));
+          rc = DFL_ERR_LAUNCH;
+        }
+        break;
+      }
       case DFL_OP_CONV: rc = dfl_conv2d(static_cast<const dfl_conv_args*>(p), stream); break;
       case DFL_OP_WGRAD: rc = dfl_conv2d_wgrad(static_cast<const dfl_wgrad_args*>(p), stream); break;
       case DFL_OP_SUM_PARTIALS: {

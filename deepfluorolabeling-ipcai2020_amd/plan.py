@@ -63,6 +63,7 @@ class UNetPlan:
         self._red_pending = []          # deferred sums (src, dst, n, stride, count), see _defer_sum
         self._red_bytes = 0
         self._red_flushes = []          # (index of the batch op in bwd, [dst pointers])
+        self._side = []                 # weight gradients running on the side stream: dict(done=event, op=index, waited=index|None)
         self._build()
 
     # ------------------------------------------------------------------------------------------ memory
@@ -159,7 +160,22 @@ class UNetPlan:
         prog.add(a)
         return partials
 
-    def _wgrad(self, prog, g, d, dw, KH, KW, stride, pad, Hout, Wout, in_aff=None):
+    # A layer's weight gradient and data gradient both read dpre and are independent: for all but the largest layers
+    # neither fills the 256 CUs on its own at batch 16, so the weight gradient goes to the library's side stream
+    # (fork after dpre is written; joined before dpre's buffer is rewritten two layers later, before a batched sum
+    # reads its slices, and at the end of backward).  Measured: +10 % on an isolated pair for 24x24..96x96 layers, -8 % at
+    # 192x192 -- but nothing inside the real backward pass (both kernels just run slower side by side), so it is off by default.
+    SIDE_STREAM = os.environ.get('DFL_SIDE_STREAM', '0') != '0'     # off: inside the whole backward pass the pair runs no faster (r01)
+    SIDE_MAX_PIXELS = 16 * 96 * 96
+
+    def _side_join(self, prog, buf=None):
+        """Main stream waits for the side-stream weight gradients emitted so far (all, or those reading buffer `buf`)."""
+        todo = [e for e in self._side if e['waited'] is None and (buf is None or e['buf'] == buf)]
+        for e in todo:
+            e['waited'] = len(prog.structs)
+            prog.wait(e['done'], stream=0)
+
+    def _wgrad(self, prog, g, d, dw, KH, KW, stride, pad, Hout, Wout, in_aff=None, side=False, side_buf=None):
         a = WgradArgs()
         a.g, a.d, a.dw = g.ptr, d.ptr, dw.data_ptr()
         if in_aff is not None:
@@ -170,15 +186,26 @@ class UNetPlan:
         a.splits = 1
         s = nat.check(self.lib.dfl_wgrad_suggest_splits(C.addressof(a)), 'dfl_wgrad_suggest_splits')
         a.splits = s
+        n = d.C * g.C * KH * KW
         if s > 1:
-            n = d.C * g.C * KH * KW
             big = 4 * n >= self.FLUSH_BYTES
             part = self._wg_partial(s * n) if big else self._new(s * n)   # deferred sums keep their own slices
             a.partial = part.data_ptr()
-            prog.add(a)
-            self._defer_sum(prog, part.data_ptr(), dw.data_ptr(), n, n, s, T=KH * KW)
+        if side:
+            k = len(self._side)
+            prog.record(2 * k, stream=0)            # dpre is complete on the main stream
+            prog.wait(2 * k, stream=1)
+            self._side.append(dict(done=2 * k + 1, op=len(prog.structs), waited=None, buf=side_buf))
+            prog.add(a, stream=1)
+            prog.record(2 * k + 1, stream=1)
         else:
             prog.add(a)
+        if s > 1:
+            # the caller flushes (self._maybe_flush) once the main-stream work that may overlap has been emitted
+            self._red_pending.append((part.data_ptr(), dw.data_ptr(), n, n, s, KH * KW))
+            self._red_bytes += 4 * n
+            if not side:
+                self._maybe_flush(prog)
 
     # Small sums (bias gradients, pixel-slice partials of narrow layers) are not launched one by one: they queue up
     # and one dfl_reduce_batch finishes the queue once FLUSH_BYTES of gradient are waiting (and at the end of backward).
@@ -188,6 +215,9 @@ class UNetPlan:
     def _defer_sum(self, prog, src, dst, n, stride, count, T=1):
         self._red_pending.append((src, dst, n, stride, count, T))
         self._red_bytes += 4 * n
+        self._maybe_flush(prog)
+
+    def _maybe_flush(self, prog):
         if self._red_bytes >= self.FLUSH_BYTES:
             self._flush_sums(prog)
 
@@ -195,6 +225,7 @@ class UNetPlan:
         jobs = self._red_pending
         if not jobs:
             return
+        self._side_join(prog)       # the slices of side-stream weight gradients must be complete
         arr = (ReduceJob * len(jobs))()
         blocks = 0
         for i, (src, dst, n, stride, count, T) in enumerate(jobs):
@@ -273,7 +304,9 @@ class UNetPlan:
                 sizes.append((N * uh * uw, chans[i]))
                 uh, uw = uh - shrink, uw - shrink
             mx = max(m * c for m, c in sizes)
-            self._scratch['dpre'] = self._new(mx)
+            self._scratch['dpre0'] = self._new(mx)
+            self._scratch['dpre1'] = self._new(mx)
+            self._dpre_turn = 0
             self._scratch['dz'] = self._new(mx)
 
         fwd, bwd = self.fwd, self.bwd
@@ -369,7 +402,12 @@ class UNetPlan:
                 for d in reversed(range(bd)):
                     cv = convs[d]
                     r = cv['r']
-                    dpre = self._scratch_act('dpre', N, r.H, r.W, Cout)
+                    side = self.SIDE_STREAM and r.M <= self.SIDE_MAX_PIXELS
+                    # two dpre buffers alternate, so a side-stream weight gradient may still read one while the next
+                    # layer fills the other; the one about to be rewritten must be free
+                    self._dpre_turn ^= 1
+                    self._side_join(bwd, buf=self._dpre_turn)
+                    dpre = self._scratch_act('dpre%d' % self._dpre_turn, N, r.H, r.W, Cout)
                     nb = self.lib.dfl_rowblock_count(r.M, Cout)
                     coef = None
                     if cv['bn'] is not None:
@@ -399,7 +437,7 @@ class UNetPlan:
                     self._defer_sum(bwd, bpart.data_ptr(), G[cv['wname'] + '.bias'].data_ptr(), Cout, Cout, nb)
                     inp = cv['inp']
                     self._wgrad(bwd, inp, dpre, G[cv['wname'] + '.weight'], 3, 3, 1, pad, r.H, r.W,
-                                in_aff=cv['inp_aff'])
+                                in_aff=cv['inp_aff'], side=side, side_buf=self._dpre_turn)
                     if d > 0:
                         wd = self._pack_conv_dgrad(cv['w'])
                         dz = self._scratch_act('dz', N, inp.H, inp.W, Cout)
@@ -414,6 +452,7 @@ class UNetPlan:
                     elif dxin is not None:
                         wd = self._pack_conv_dgrad(cv['w'])
                         self._conv(bwd, dpre, wd, dxin, 3, 3, 1, 2 - pad, xin.C, accumulate=1 if wrote_dxin else 0)
+                    self._maybe_flush(bwd)
             return backward
 
         # ------------------------------------------------------------------ down path
@@ -572,15 +611,17 @@ class UNetPlan:
                 dxin = None
             rec['block_bw'](dout, dxin)
         self._flush_sums(bwd)
+        self._side_join(bwd)
         self._finish_pack()
         # index of the last backward op that writes each parameter gradient (data-parallel bucket scheduling)
         by_ptr = {self.G[k].data_ptr(): k for k in self.grad_names}
         self.grad_ready_op = {}
+        joined = {e['op']: e['waited'] for e in self._side}     # side-stream op -> main-stream wait that covers it
         for idx, st in enumerate(bwd.structs):
             for field in ('dw', 'dst', 'out', 'dgamma', 'dbeta'):
                 name = by_ptr.get(getattr(st, field, None))
                 if name is not None:
-                    self.grad_ready_op[name] = idx
+                    self.grad_ready_op[name] = joined.get(idx, idx)
         for idx, dsts in self._red_flushes:
             for d in dsts:
                 name = by_ptr.get(d)

@@ -357,7 +357,8 @@ typedef enum {
   DFL_OP_CONV = 1, DFL_OP_WGRAD = 2, DFL_OP_SUM_PARTIALS = 3, DFL_OP_PACK = 4, DFL_OP_BN_FINALIZE = 5,
   DFL_OP_BN_EVAL = 6, DFL_OP_COLSTATS = 7, DFL_OP_BN_BWD_FINALIZE = 8, DFL_OP_BN_RELU_BWD = 9,
   DFL_OP_REDUCE_PARTIALS = 10, DFL_OP_AFFINE_COPY = 11, DFL_OP_POOL_FWD = 12, DFL_OP_POOL_BWD = 13,
-  DFL_OP_HEAD_FWD = 14, DFL_OP_HEAD_BWD = 15, DFL_OP_MEMSET = 16, DFL_OP_REDUCE_BATCH = 17
+  DFL_OP_HEAD_FWD = 14, DFL_OP_HEAD_BWD = 15, DFL_OP_MEMSET = 16, DFL_OP_REDUCE_BATCH = 17,
+  DFL_OP_RECORD = 18, DFL_OP_WAIT = 19
 } dfl_op_kind;
 
 typedef struct { const float* src; float* dst; int64_t n; int32_t splits; int32_t T; } dfl_sum_partials_args;
@@ -368,9 +369,16 @@ typedef struct { const float* partials; float* out; int32_t nblocks, stride, C, 
 typedef struct { void* ptr; int64_t bytes; } dfl_memset_args; /* zero fill */
 typedef struct { const dfl_reduce_job* jobs_dev; int32_t njobs, total_blocks; } dfl_reduce_batch_args;
 
+/* DFL_OP_RECORD: record library event `event` on the op's stream; DFL_OP_WAIT: make the op's stream wait for it.
+ * Events are library-owned, identified by small integers the program chooses (0..65535). */
+typedef struct { int32_t event; int32_t reserved; } dfl_sync_args;
+#define DFL_MAX_SIDE_STREAMS 2
+
 typedef struct {
   int32_t kind;          /* dfl_op_kind */
-  int32_t reserved;
+  int32_t stream;        /* 0 = the stream passed to dfl_exec; 1..DFL_MAX_SIDE_STREAMS = library-owned side streams.
+                            Independent kernels of small layers (a layer's weight gradient next to its data
+                            gradient) fill the GPU better side by side; ordering is the program's job (RECORD/WAIT). */
   const void* args;
 } dfl_op;
 
