@@ -56,12 +56,14 @@ def op_profile(plan, lib, nat, stream, detail=None):
                 else:
                     M = st.N * st.Hout * st.Wout
                 fl = 2.0 * M * st.KH * st.KW * st.Cin * st.Ntot
+                by = 4.0 * (st.N * st.Hin * st.Win * st.Cin + st.KH * st.KW * st.Cin * st.Ntot + M * st.Ntot)
             elif isinstance(st, nat.WgradArgs):
                 cfg = lib.dfl_wgrad_config(C.addressof(st))
                 name = WGRAD_KERNELS[cfg]
                 fl = 2.0 * st.N * st.Hout * st.Wout * st.Cm * st.Cg * st.KH * st.KW
+                by = 4.0 * (st.N * st.Hin * st.Win * st.Cg + st.N * st.Hout * st.Wout * st.Cm + st.Cm * st.Cg * st.KH * st.KW)
             else:
-                name, fl = type(st).__name__, 0.0
+                name, fl, by = type(st).__name__, 0.0, 0.0
             if detail is not None:
                 if isinstance(st, nat.ConvArgs):
                     desc = 'N%d %dx%d Cin%d -> %dx%d Ntot%d k%d s%d' % (st.N, st.Hin, st.Win, st.Cin, st.Hout, st.Wout,
@@ -73,10 +75,11 @@ def op_profile(plan, lib, nat, stream, detail=None):
                 else:
                     desc = ''
                 detail.append('%-28s %8.3f ms %7.1f TF  %s' % (name, t, fl / (t * 1e-3) / 1e12 if t > 0 else 0, desc))
-            gr = groups.setdefault(name, [0.0, 0.0, 0])
+            gr = groups.setdefault(name, [0.0, 0.0, 0, 0.0])
             gr[0] += t
             gr[1] += fl
             gr[2] += 1
+            gr[3] += by            # compulsory bytes: each operand once (input, weights, output)
     account(plan.fwd, plan.fwd.run_timed(stream))
     if detail is not None:
         detail.append('---- backward ----')
@@ -186,12 +189,25 @@ def main():
         plan.busy = False
         tot_ms = sum(v[0] for v in groups.values())
         dom = max(groups.items(), key=lambda kv: kv[1][0])
-        name, (ms, fl, n) = dom
+        name, (ms, fl, n, by) = dom
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         roofline = {'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 2), 'peak': F32_MFMA_PEAK_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': round(achieved / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
                     'launches_per_step': n, 'avg_launch_ms': round(ms / n, 4),
-                    'share_of_kernel_time': round(ms / tot_ms, 3)}
+                    'share_of_kernel_time': round(ms / tot_ms, 3),
+                    'algorithmic_flop_per_launch': round(fl / n), 'compulsory_bytes_per_launch': round(by / n)}
+        # HBM bytes per launch of that kernel come from the separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE;
+        # tools/profile_round.sh), which cannot run inside this process; the committed summary is quoted when present
+        tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_traffic.json')
+        if os.path.exists(tfile):
+            try:
+                rec = json.load(open(tfile))['kernels'].get(name)
+                if rec:
+                    roofline['traffic'] = rec['hbm_bytes_per_launch']
+                    roofline['traffic_unit'] = 'HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB, rocprofv3 PMC passes of ' \
+                                               'the same command (profiles/r01_traffic.json)'
+            except (ValueError, KeyError):
+                pass
         fl_all = sum(v[1] for v in groups.values())
         extra['kernel_time_ms_per_step'] = round(tot_ms, 3)
         extra['whole_step_tflops'] = round(fl_all / (ms_per_step * 1e-3) / 1e12, 2)
