@@ -4,7 +4,7 @@ set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 out="$here/../lib"
 mkdir -p "$out"
-srcs=(api.hip conv_gemm.hip wgrad_gemm.hip bn_elem.hip head.hip loss.hip)
+srcs=(api.hip conv_gemm.hip wgrad_gemm.hip bn_elem.hip head.hip loss.hip prep.hip)
 objs=()
 pids=()
 for s in "${srcs[@]}"; do

@@ -1,0 +1,125 @@
+// GPU-side input pipeline: what the reference's loader computes on the host per item
+// (train_test_code/dataset.py:287-293 reflect pad + standardisation, :302-325 Gaussian heat maps, :421-429 out-of-view
+// landmarks, :448-452 one-hot masks) done on the device from the raw arrays, so a training step ships u8 labels and
+// 2*L floats of landmarks per image instead of float targets (45 MB per batch-16 step).  Contract: include/dfl_hip.h.
+// HBM-bound: one read of the raw image + labels, one write of x / masks / heats.
+#include "common.h"
+
+namespace dfl {
+
+constexpr int PREP_NB = 64;   // statistics slices per image
+
+__device__ __forceinline__ int reflect(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
+
+// partial[b][blk][2] = (sum, sum of squares) of the reflect-padded image, fp64
+__global__ void __launch_bounds__(256) prep_stats_kernel(const dfl_prep_args a, double* __restrict__ partial) {
+  __shared__ double red[2][256];
+  const int b = blockIdx.y;
+  const int Hp = a.H + 2 * a.pad, Wp = a.W + 2 * a.pad;
+  const int64_t n = (int64_t)Hp * Wp;
+  const float* src = a.proj + (int64_t)b * a.H * a.W;
+  double s1 = 0.0, s2 = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)PREP_NB * 256) {
+    const int y = (int)(i / Wp), x = (int)(i - (int64_t)y * Wp);
+    const double v = (double)src[(int64_t)reflect(y - a.pad, a.H) * a.W + reflect(x - a.pad, a.W)];
+    s1 += v;
+    s2 += v * v;
+  }
+  red[0][threadIdx.x] = s1;
+  red[1][threadIdx.x] = s2;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + off];
+      red[1][threadIdx.x] += red[1][threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    partial[((int64_t)b * PREP_NB + blockIdx.x) * 2 + 0] = red[0][0];
+    partial[((int64_t)b * PREP_NB + blockIdx.x) * 2 + 1] = red[1][0];
+  }
+}
+
+// blockIdx.z: 0 = standardised padded image, 1 = one-hot masks, 2 = heat maps; blockIdx.y = image
+__global__ void __launch_bounds__(256) prep_write_kernel(const dfl_prep_args a, const double* __restrict__ partial) {
+  const int b = blockIdx.y;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.z == 0) {
+    if (a.x == nullptr) return;
+    const int Hp = a.H + 2 * a.pad, Wp = a.W + 2 * a.pad;
+    const int64_t n = (int64_t)Hp * Wp;
+    float mean = 0.f, inv = 1.f;
+    if (a.standardize) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int k = 0; k < PREP_NB; ++k) {   // same order in every thread: bit-identical statistics
+        s1 += partial[((int64_t)b * PREP_NB + k) * 2 + 0];
+        s2 += partial[((int64_t)b * PREP_NB + k) * 2 + 1];
+      }
+      const double m = s1 / (double)n;
+      double var = (s2 - s1 * m) / (double)(n - 1);   // torch.std: unbiased
+      if (var < 0.0) var = 0.0;
+      mean = (float)m;
+      inv = (float)(1.0 / sqrt(var));
+    }
+    const float* src = a.proj + (int64_t)b * a.H * a.W;
+    float* dst = a.x + (int64_t)b * n;
+    for (int64_t i = t0; i < n; i += stride) {
+      const int y = (int)(i / Wp), x = (int)(i - (int64_t)y * Wp);
+      dst[i] = (src[(int64_t)reflect(y - a.pad, a.H) * a.W + reflect(x - a.pad, a.W)] - mean) * inv;
+    }
+  } else if (blockIdx.z == 1) {
+    if (a.masks == nullptr) return;
+    const int64_t hw = (int64_t)a.H * a.W;
+    const unsigned char* lab = a.labels + (int64_t)b * hw;
+    float* dst = a.masks + (int64_t)b * a.C * hw;
+    for (int64_t i = t0; i < hw; i += stride) {
+      const int l = lab[i];
+      for (int c = 0; c < a.C; ++c) dst[(int64_t)c * hw + i] = (l == c) ? 1.f : 0.f;
+    }
+  } else {
+    if (a.heats == nullptr) return;
+    const int64_t hw = (int64_t)a.H * a.W;
+    const float* ld = a.lands + (int64_t)b * 2 * a.L;
+    float* dst = a.heats + (int64_t)b * a.L * hw;
+    const float s2 = a.sigma * a.sigma;
+    const float kexp = 1.f / (s2 * -2.f), knorm = 1.f / (2.f * 3.14159265358979323846f * s2);
+    for (int l = 0; l < a.L; ++l) {
+      const float mx = ld[l], my = ld[a.L + l];
+      // landmarks outside the view (or already marked inf) give an all-zero map
+      const bool ok = !(isinf(mx) || isinf(my) || isnan(mx) || isnan(my)) && mx >= 0.f && mx <= (float)(a.W - 1) &&
+                      my >= 0.f && my <= (float)(a.H - 1);
+      for (int64_t i = t0; i < hw; i += stride) {
+        const int y = (int)(i / a.W), x = (int)(i - (int64_t)y * a.W);
+        const float dx = (float)x - mx, dy = (float)y - my;
+        dst[(int64_t)l * hw + i] = ok ? expf((dx * dx + dy * dy) * kexp) * knorm : 0.f;
+      }
+    }
+  }
+}
+
+}  // namespace dfl
+
+extern "C" int64_t dfl_prep_scratch_doubles(int32_t B) { return (int64_t)B * dfl::PREP_NB * 2; }
+
+extern "C" int dfl_prep_batch(const dfl_prep_args* a, dfl_stream_t stream) {
+  DFL_REQUIRE(a != nullptr, "dfl_prep_batch: null args");
+  DFL_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && a->pad >= 0, "dfl_prep_batch: bad sizes");
+  DFL_REQUIRE(a->pad < a->H && a->pad < a->W, "dfl_prep_batch: reflect padding needs pad < H, W");
+  DFL_REQUIRE(a->x == nullptr || a->proj != nullptr, "dfl_prep_batch: x needs proj");
+  DFL_REQUIRE(a->masks == nullptr || (a->labels != nullptr && a->C > 0), "dfl_prep_batch: masks need labels and C");
+  DFL_REQUIRE(a->heats == nullptr || (a->lands != nullptr && a->L > 0 && a->sigma > 0.f), "dfl_prep_batch: heats need lands, L, sigma");
+  DFL_REQUIRE(!(a->x != nullptr && a->standardize) || a->scratch != nullptr, "dfl_prep_batch: standardisation needs scratch");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (a->x != nullptr && a->standardize) {
+    hipLaunchKernelGGL(dfl::prep_stats_kernel, dim3(dfl::PREP_NB, (unsigned)a->B), dim3(256), 0, s, *a, a->scratch);
+    int rc = dfl::check_launch("dfl_prep_batch");
+    if (rc != DFL_OK) return rc;
+  }
+  const int64_t n = (int64_t)(a->H + 2 * a->pad) * (a->W + 2 * a->pad);
+  int64_t gx = dfl::ceil_div(n, 256 * 4);
+  if (gx > 1024) gx = 1024;
+  hipLaunchKernelGGL(dfl::prep_write_kernel, dim3((unsigned)gx, (unsigned)a->B, 3), dim3(256), 0, s, *a, a->scratch);
+  return dfl::check_launch("dfl_prep_batch");
+}

@@ -349,6 +349,30 @@ int dfl_sgd_step(float* p, const float* grad, float* momentum_buf, int64_t n, fl
                  float weight_decay, float grad_scale, int32_t nesterov, int32_t first_step, dfl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * GPU-side input pipeline: the deterministic part of the reference loader (train_test_code/dataset.py) from raw
+ * device arrays, for a whole batch in two launches.
+ *   x[b]     = standardise(reflect_pad(proj[b], pad))    (dataset.py:287-293; mean / unbiased std of the PADDED image)
+ *   masks[b] = one-hot(labels[b]) as float [C][H][W]     (dataset.py:448-452)
+ *   heats[b] = L Gaussian maps exp(-((x-mx)^2+(y-my)^2)/(2 sigma^2)) / (2 pi sigma^2), zero for landmarks that are
+ *              inf or outside [0,W-1]x[0,H-1]             (dataset.py:302-325, 421-429)
+ * Any of x / masks / heats may be NULL (skipped).  lands is [B][2][L]: row 0 = column (x), row 1 = row (y).
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* proj;            /* [B][H][W] raw intensities */
+  const unsigned char* labels;  /* [B][H][W] */
+  const float* lands;           /* [B][2][L] */
+  float* x;                     /* [B][1][H+2*pad][W+2*pad] */
+  float* masks;                 /* [B][C][H][W] */
+  float* heats;                 /* [B][L][H][W] */
+  double* scratch;              /* dfl_prep_scratch_doubles(B) doubles (needed when x != NULL and standardize) */
+  int32_t B, H, W, pad, C, L;
+  float sigma;
+  int32_t standardize;
+} dfl_prep_args;
+int64_t dfl_prep_scratch_doubles(int32_t B);
+int dfl_prep_batch(const dfl_prep_args* a, dfl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Program execution: run a recorded list of the calls above with ONE host->library transition.  The host builds
  * the array once per (network, input shape) and replays it every step (forward, backward); this is the launch
  * path bench.py times.  `args` points to the struct the matching function takes.

@@ -107,3 +107,13 @@ def test_center_crop_and_schedule_against_reference_goldens():
                 restarts.append(int(s.just_restarted))
         np.testing.assert_allclose(trace, g[tag], rtol=1e-12, atol=1e-15)
         assert restarts == list(g[tag + '_restarts'])
+
+
+def test_dataset_refuses_cpu_and_pad_arithmetic():
+    from dfl_amd import dataset as D
+    g = load_golden('dataset')
+    assert D.calc_pad_amount(48, 46) == int(g['pad_48_46'])
+    assert D.calc_pad_amount(192, 184) == int(g['pad_192_184'])
+    assert D.calc_pad_amount(193, 180) == int(g['pad_193_180'])
+    with pytest.raises(nat.DflError):
+        D.DeviceDataSet(torch.zeros(1, 1, 8, 8), torch.zeros(1, 8, 8, dtype=torch.uint8), num_classes=2, device='cpu')
