@@ -135,6 +135,11 @@ class PrepArgs(C.Structure):
                 ('standardize', i32)]
 
 
+class EstLandsArgs(C.Structure):
+    _fields_ = [('heats', fp), ('segs', fp), ('label_for_land', fp), ('rowcol', fp), ('ncc', fp),
+                ('B', i32), ('L', i32), ('H', i32), ('W', i32), ('sigma', f32), ('min_ncc', f32)]
+
+
 class SyncArgs(C.Structure):
     _fields_ = [('event', i32), ('reserved', i32)]
 
@@ -154,7 +159,7 @@ _KIND_OF = {ConvArgs: OP_CONV, WgradArgs: OP_WGRAD, SumPartialsArgs: OP_SUM_PART
             HeadBwdArgs: OP_HEAD_BWD, MemsetArgs: OP_MEMSET, ReduceBatchArgs: OP_REDUCE_BATCH}
 
 _SIZEOF_ORDER = [ConvArgs, WgradArgs, PackJob, BnFinalizeArgs, ColstatsArgs, BnBwdFinalizeArgs, BnReluBwdArgs,
-                 AffineCopyArgs, PoolArgs, HeadFwdArgs, HeadBwdArgs, LossArgs, EnsembleArgs, Op, ReduceJob, PrepArgs]
+                 AffineCopyArgs, PoolArgs, HeadFwdArgs, HeadBwdArgs, LossArgs, EnsembleArgs, Op, ReduceJob, PrepArgs, EstLandsArgs]
 
 EXPORTS = ['dfl_version', 'dfl_last_error', 'dfl_sizeof', 'dfl_conv2d', 'dfl_conv_grid_m', 'dfl_conv2d_wgrad',
            'dfl_wgrad_suggest_splits', 'dfl_sum_partials', 'dfl_pack_weights', 'dfl_bn_finalize',
@@ -163,7 +168,7 @@ EXPORTS = ['dfl_version', 'dfl_last_error', 'dfl_sizeof', 'dfl_conv2d', 'dfl_con
            'dfl_maxpool2x2_bwd', 'dfl_head_fwd', 'dfl_head_bwd', 'dfl_head_scratch_ld', 'dfl_head_scratch_off',
            'dfl_dice_ncc_loss', 'dfl_loss_scratch_doubles', 'dfl_ensemble_reduce', 'dfl_sgd_step', 'dfl_exec',
            'dfl_exec_timed', 'dfl_conv_config', 'dfl_wgrad_config', 'dfl_conv_suggest_splits', 'dfl_reduce_batch',
-           'dfl_reduce_job_blocks', 'dfl_prep_batch', 'dfl_prep_scratch_doubles']
+           'dfl_reduce_job_blocks', 'dfl_prep_batch', 'dfl_prep_scratch_doubles', 'dfl_est_lands']
 
 
 class DflError(RuntimeError):
@@ -198,6 +203,7 @@ def lib():
     L.dfl_prep_scratch_doubles.restype = i64
     L.dfl_prep_scratch_doubles.argtypes = [i32]
     L.dfl_prep_batch.argtypes = [fp, fp]
+    L.dfl_est_lands.argtypes = [fp, fp]
     L.dfl_sgd_step.argtypes = [fp, fp, fp, i64, f32, f32, f32, f32, i32, i32, fp]
     L.dfl_exec.argtypes = [fp, i32, fp]
     L.dfl_exec_timed.argtypes = [fp, i32, fp, fp]

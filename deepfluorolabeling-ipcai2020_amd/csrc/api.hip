@@ -56,7 +56,7 @@ extern "C" int dfl_sizeof(int which) {
       (int)sizeof(dfl_bn_relu_bwd_args), (int)sizeof(dfl_affine_copy_args),    (int)sizeof(dfl_pool_args),
       (int)sizeof(dfl_head_fwd_args),   (int)sizeof(dfl_head_bwd_args),        (int)sizeof(dfl_loss_args),
       (int)sizeof(dfl_ensemble_args),   (int)sizeof(dfl_op),                   (int)sizeof(dfl_reduce_job),
-      (int)sizeof(dfl_prep_args)};
+      (int)sizeof(dfl_prep_args),       (int)sizeof(dfl_est_lands_args)};
   if (which < 0 || which >= (int)(sizeof(sizes) / sizeof(sizes[0]))) return -1;
   return sizes[which];
 }

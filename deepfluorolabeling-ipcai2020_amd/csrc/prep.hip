@@ -123,3 +123,126 @@ extern "C" int dfl_prep_batch(const dfl_prep_args* a, dfl_stream_t stream) {
   hipLaunchKernelGGL(dfl::prep_write_kernel, dim3((unsigned)gx, (unsigned)a->B, 3), dim3(256), 0, s, *a, a->scratch);
   return dfl::check_launch("dfl_prep_batch");
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Landmark extraction (est_lands_csv.py:96-124): per (image, landmark) the arg-max of the heat map,
+// optionally restricted to the pixels of one segmentation label, accepted only if the 25x25 window around it (heat map
+// reflect-padded by 12) correlates with the Gaussian template (ncc_2d, ncc.py:12-38) at >= 0.9.  One workgroup per
+// (landmark, image); ties resolve to the lowest flat index like torch.argmax.
+namespace dfl {
+
+constexpr int LM_T = 25, LM_R = 12, LM_N = LM_T * LM_T;
+
+__device__ __forceinline__ double block_sum(double v, double* red) {
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  const double r = red[0];
+  __syncthreads();
+  return r;
+}
+
+__global__ void __launch_bounds__(256) est_lands_kernel(const dfl_est_lands_args a) {
+  __shared__ double red[256];
+  __shared__ float bv[256];
+  __shared__ int bi[256];
+  const int l = blockIdx.x, b = blockIdx.y;
+  const int H = a.H, W = a.W;
+  const int64_t hw = (int64_t)H * W;
+  const float* heat = a.heats + ((int64_t)b * a.L + l) * hw;
+  const int want = (a.segs != nullptr && a.label_for_land != nullptr) ? a.label_for_land[l] : -1;
+  const unsigned char* seg = (want >= 0) ? a.segs + (int64_t)b * hw : nullptr;
+  float best = -INFINITY;
+  int besti = 0x7fffffff;
+  for (int i = threadIdx.x; i < hw; i += 256) {
+    const float v = (seg == nullptr || seg[i] == want) ? heat[i] : -INFINITY;
+    if (v > best || (v == best && i < besti)) {
+      best = v;
+      besti = i;
+    }
+  }
+  bv[threadIdx.x] = best;
+  bi[threadIdx.x] = besti;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      const float v = bv[threadIdx.x + off];
+      const int i = bi[threadIdx.x + off];
+      if (v > bv[threadIdx.x] || (v == bv[threadIdx.x] && i < bi[threadIdx.x])) {
+        bv[threadIdx.x] = v;
+        bi[threadIdx.x] = i;
+      }
+    }
+    __syncthreads();
+  }
+  best = bv[0];
+  besti = bi[0];
+  __syncthreads();
+  int* out = a.rowcol + ((int64_t)b * a.L + l) * 2;
+  float* ncc_out = (a.ncc != nullptr) ? a.ncc + (int64_t)b * a.L + l : nullptr;
+  if (!(best > -INFINITY)) {   // nothing inside the label (or an all -inf / NaN map)
+    if (threadIdx.x == 0) {
+      out[0] = -1;
+      out[1] = -1;
+      if (ncc_out) *ncc_out = 0.f;
+    }
+    return;
+  }
+  const int row = besti / W, col = besti - row * W;
+  // window values y (reflect padded) and template t, fp32 like the reference; sums in fp64
+  float y[3], t[3];
+  double sy = 0.0, st = 0.0;
+  const float s2 = a.sigma * a.sigma;
+  const float kexp = 1.f / (s2 * -2.f), knorm = 1.f / (2.f * 3.14159265358979323846f * s2);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int e = threadIdx.x + 256 * k;
+    y[k] = 0.f;
+    t[k] = 0.f;
+    if (e < LM_N) {
+      const int wy = e / LM_T, wx = e - wy * LM_T;
+      y[k] = heat[(int64_t)reflect(row - LM_R + wy, H) * W + reflect(col - LM_R + wx, W)];
+      const float dx = (float)(wx - LM_R), dy = (float)(wy - LM_R);
+      t[k] = expf((dx * dx + dy * dy) * kexp) * knorm;
+      sy += (double)y[k];
+      st += (double)t[k];
+    }
+  }
+  const float my = (float)(block_sum(sy, red) / LM_N), mt = (float)(block_sum(st, red) / LM_N);
+  double syy = 0.0, stt = 0.0, sty = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if ((int)threadIdx.x + 256 * k < LM_N) {
+      const float yz = y[k] - my, tz = t[k] - mt;
+      syy += (double)(yz * yz);
+      stt += (double)(tz * tz);
+      sty += (double)(tz * yz);
+    }
+  }
+  syy = block_sum(syy, red);
+  stt = block_sum(stt, red);
+  sty = block_sum(sty, red);
+  if (threadIdx.x == 0) {
+    const float sdy = sqrtf((float)(syy / (LM_N - 1))), sdt = sqrtf((float)(stt / (LM_N - 1)));
+    const float ncc = (float)sty / ((float)LM_N * (sdt * sdy) + 1.0e-8f);
+    const bool ok = !(ncc < a.min_ncc);
+    out[0] = ok ? row : -1;
+    out[1] = ok ? col : -1;
+    if (ncc_out) *ncc_out = ncc;
+  }
+}
+
+}  // namespace dfl
+
+extern "C" int dfl_est_lands(const dfl_est_lands_args* a, dfl_stream_t stream) {
+  DFL_REQUIRE(a != nullptr && a->heats != nullptr && a->rowcol != nullptr, "dfl_est_lands: missing pointer");
+  DFL_REQUIRE(a->B > 0 && a->L > 0 && a->H > dfl::LM_R && a->W > dfl::LM_R, "dfl_est_lands: maps must be larger than the 12-pixel reflect border");
+  DFL_REQUIRE((int64_t)a->H * a->W < (1ll << 31), "dfl_est_lands: map too large");
+  DFL_REQUIRE(a->sigma > 0.f, "dfl_est_lands: sigma");
+  hipLaunchKernelGGL(dfl::est_lands_kernel, dim3((unsigned)a->L, (unsigned)a->B), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), *a);
+  return dfl::check_launch("dfl_est_lands");
+}

@@ -228,3 +228,32 @@ def seg_dataset_ensemble(ds, nets, h5_f, dev=None, num_lands=0, times=None):
                 heat_ds[i, :, :, :] = heats.cpu().numpy()
             count += 1
     assert count == len(ds)
+
+
+def est_lands(heats, segs=None, label_for_land=None, sigma=2.5, min_ncc=0.9, return_ncc=False):
+    """Landmark locations from heat maps, est_lands_csv.py:96-124 on the GPU (dfl_est_lands): heats [B,L,H,W] float,
+    segs [B,H,W] integer labels or None, label_for_land[l] = label restricting landmark l (None / negative = none).
+    Returns int32 [B,L,2] = (row, col), (-1,-1) where the landmark is not found."""
+    from . import _native as nat
+    if not heats.is_cuda:
+        raise nat.DflError('util.est_lands needs the heat maps on the GPU (no CPU path)')
+    h = heats.detach().to(torch.float32).contiguous()
+    if h.dim() == 5 and h.shape[2] == 1:
+        h = h.view(h.shape[0], h.shape[1], h.shape[3], h.shape[4])
+    B, L, H, W = h.shape
+    out = torch.empty((B, L, 2), dtype=torch.int32, device=h.device)
+    a = nat.EstLandsArgs(heats=h.data_ptr(), rowcol=out.data_ptr(), B=B, L=L, H=H, W=W, sigma=sigma, min_ncc=min_ncc)
+    keep = [h]
+    if segs is not None and label_for_land is not None:
+        sg = segs.detach().to(h.device, torch.uint8).contiguous()
+        assert sg.shape == (B, H, W)
+        lab = torch.tensor([-1 if v is None else int(v) for v in label_for_land], dtype=torch.int32, device=h.device)
+        assert lab.numel() == L
+        a.segs, a.label_for_land = sg.data_ptr(), lab.data_ptr()
+        keep += [sg, lab]
+    ncc = None
+    if return_ncc:
+        ncc = torch.empty((B, L), dtype=torch.float32, device=h.device)
+        a.ncc = ncc.data_ptr()
+    nat.call('dfl_est_lands', a, torch.cuda.current_stream(h.device).cuda_stream)
+    return (out, ncc) if return_ncc else out

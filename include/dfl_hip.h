@@ -373,6 +373,24 @@ int64_t dfl_prep_scratch_doubles(int32_t B);
 int dfl_prep_batch(const dfl_prep_args* a, dfl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Landmark extraction from predicted heat maps (est_lands_csv.py:96-124, the step after the network in the paper's
+ * pipeline).  For image b and landmark l:  (row, col) = arg-max of heats[b][l] over the pixels whose segmentation
+ * label equals label_for_land[l] (all pixels when segs / label_for_land is NULL or the entry is negative; ties -> lowest
+ * flat index), kept only if ncc_2d(Gaussian 25x25 template (sigma), 25x25 window of the heat map reflect-padded by 12
+ * around it) >= min_ncc (0.9 in the reference); otherwise (-1, -1).
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* heats;             /* [B][L][H][W] */
+  const unsigned char* segs;      /* [B][H][W] labels or NULL */
+  const int32_t* label_for_land;  /* [L] or NULL */
+  int32_t* rowcol;                /* [B][L][2] */
+  float* ncc;                     /* [B][L] correlation at the arg-max (0 where none), or NULL */
+  int32_t B, L, H, W;
+  float sigma, min_ncc;
+} dfl_est_lands_args;
+int dfl_est_lands(const dfl_est_lands_args* a, dfl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Program execution: run a recorded list of the calls above with ONE host->library transition.  The host builds
  * the array once per (network, input shape) and replays it every step (forward, backward); this is the launch
  * path bench.py times.  `args` points to the struct the matching function takes.

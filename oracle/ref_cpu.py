@@ -308,6 +308,45 @@ def mark_oob_landmarks(lands, H, W):
 
 
 # --------------------------------------------------------------------------------------
+# Landmark extraction from heat maps (train_test_code/est_lands_csv.py:85-124)
+# --------------------------------------------------------------------------------------
+def gaussian_template(rows, cols, sigma):
+    """util.get_gaussian_2d_heatmap (util.py:38-51) with the peak at the centre."""
+    Y, X = torch.meshgrid(torch.arange(0, rows), torch.arange(0, cols), indexing='ij')
+    return torch.exp(((X.float() - cols // 2).pow(2) + (Y.float() - rows // 2).pow(2)) / (sigma * sigma * -2)) \
+        / (2 * math.pi * sigma * sigma)
+
+
+def est_landmarks(heats, segs=None, label_for_land=None, sigma=2.5, min_ncc=0.9, return_ncc=False):
+    """heats [B,L,H,W]; segs [B,H,W] labels or None; label_for_land[l] = label whose pixels may hold landmark l (None
+    / negative: anywhere).  Returns int [B,L,2] (row, col), (-1,-1) when nothing is found (est_lands_csv.py:96-124:
+    'rule_3': masked arg-max, then the 25x25 window of the reflect-padded map must correlate >= 0.9 with the template)."""
+    B, L, H, W = heats.shape
+    tmpl = gaussian_template(25, 25, sigma)
+    out = torch.full((B, L, 2), -1, dtype=torch.int64)
+    nccs = torch.zeros(B, L)
+    for i in range(B):
+        for l in range(L):
+            cur = heats[i, l]
+            pad = F.pad(cur[None, None], (12, 12, 12, 12), mode='reflect')[0, 0]
+            lab = None if (segs is None or label_for_land is None) else label_for_land[l]
+            if lab is None or lab < 0:
+                idx = int(torch.argmax(cur))
+            else:
+                tmp = cur.clone()
+                tmp[segs[i] != lab] = -math.inf
+                idx = int(torch.argmax(tmp))
+                if tmp.view(-1)[idx] == -math.inf:
+                    continue
+            r, c = idx // W, idx % W
+            v = float(ncc_2d(tmpl, pad[r:r + 25, c:c + 25]))
+            nccs[i, l] = v
+            if not v < min_ncc:
+                out[i, l, 0], out[i, l, 1] = r, c
+    return (out, nccs) if return_ncc else out
+
+
+# --------------------------------------------------------------------------------------
 # Hard Dice (train_test_code/compute_actual_dice_on_test.py:63-93)
 # --------------------------------------------------------------------------------------
 def hard_dice(pred_labels, gt_labels, num_classes):

@@ -81,3 +81,37 @@ def test_get_dataset_from_npz(tmp_path):
     assert len(tr) == 2 and len(va) == 1 and sorted(ti + vi) == [0, 1, 2]
     with pytest.raises(NotImplementedError):
         D.get_dataset(path, [1], num_classes=7, data_aug=True, device=DEV)
+
+
+def test_landmark_extraction_matches_reference_script():
+    """dfl_est_lands against the rows est_lands_csv.py wrote for the same heat maps (golden 'est_lands')."""
+    from dfl_amd import util as U
+    g = load_golden('est_lands')
+    heats, segs = _t(g['heats']).to(DEV), _t(g['segs']).to(DEV)
+    labels = [int(v) for v in g['label_for_land']]
+    rc, ncc = U.est_lands(heats, segs, labels, return_ncc=True)
+    assert np.array_equal(rc.cpu().numpy(), g['rc_masked'])
+    assert np.array_equal(U.est_lands(heats).cpu().numpy(), g['rc_plain'])
+    want, wncc = R.est_landmarks(_t(g['heats']), _t(g['segs']), labels, return_ncc=True)
+    np.testing.assert_allclose(ncc.cpu().numpy(), wncc.numpy(), atol=2e-5)
+    # 5-D heat maps as the network's loader hands them, and a label no pixel carries
+    assert np.array_equal(U.est_lands(heats.unsqueeze(2)).cpu().numpy(), g['rc_plain'])
+    none = U.est_lands(heats, segs, [9] * 14)
+    assert int(none.max()) == -1
+
+
+def test_landmark_extraction_random_vs_oracle():
+    from dfl_amd import util as U
+    g = torch.Generator().manual_seed(3)
+    B, L, H, W = 2, 5, 64, 80
+    heats = 1e-4 * torch.rand(B, L, H, W, generator=g)
+    segs = torch.randint(0, 3, (B, H, W), generator=g)
+    for i in range(B):
+        for l in range(L):
+            r, c = int(torch.randint(14, H - 14, (1,), generator=g)), int(torch.randint(14, W - 14, (1,), generator=g))
+            heats[i, l] += R.gaussian_heatmaps(torch.tensor([[float(c)], [float(r)]]), H, W)[0, 0]
+    heats[0, 0] = heats[0, 0].max()          # constant map: ties -> index 0, zero variance -> ncc 0 -> rejected
+    labels = [1, None, 2, -1, 0]
+    got = U.est_lands(heats.to(DEV), segs.to(DEV), labels).cpu()
+    want = R.est_landmarks(heats, segs, [-1 if v is None else v for v in labels])
+    assert np.array_equal(got.numpy(), want.numpy())

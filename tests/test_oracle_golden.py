@@ -199,3 +199,18 @@ def test_trajectory():
     labels = torch.max(R.center_crop(out[0], S.shape), dim=1)[1]
     d = R.hard_dice(labels, segs.long(), 7)
     np.testing.assert_allclose(d, g['hard_dice'], atol=0.02)
+
+
+def test_landmark_extraction():
+    """oracle.est_landmarks == the reference script est_lands_csv.py (run by tools/gen_golden.py), with and without mask."""
+    g = load_golden('est_lands')
+    heats, segs = _t(g['heats']), _t(g['segs'])
+    labels = [int(v) for v in g['label_for_land']]
+    rc, ncc = R.est_landmarks(heats, segs, labels, return_ncc=True)
+    assert np.array_equal(rc.numpy(), g['rc_masked'])
+    rc2, ncc2 = R.est_landmarks(heats, None, None, return_ncc=True)
+    assert np.array_equal(rc2.numpy(), g['rc_plain'])
+    found = g['rc_plain'][..., 0] >= 0
+    assert found.any() and (~found).any()                         # both outcomes are covered ...
+    assert float((ncc2 - 0.9).abs().min()) > 2e-4                 # ... and none sits on the 0.9 threshold (fp32 noise ~1e-6)
+    assert (g['rc_masked'] != g['rc_plain']).any()                # the mask changes some answers

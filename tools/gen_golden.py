@@ -425,6 +425,75 @@ def fixture_trajectory(unet, dice, util):
     print('trajectory losses', losses[0], losses[-1], 'dice', np.mean(d))
 
 
+EST_LAND_NAMES = ['FH-l', 'FH-r', 'GSN-l', 'GSN-r', 'IOF-l', 'IOF-r', 'MOF-l', 'MOF-r', 'SPS-l', 'SPS-r', 'IPS-l', 'IPS-r',
+                  'ASIS-l', 'ASIS-r']
+EST_LABEL_FOR = [5, 6, 1, 2, 1, 2, 1, 2, 1, 2, 1, 2, 1, 2]     # est_lands_csv.py:56-73
+
+
+def fixture_est_lands(util):
+    """Landmark extraction (est_lands_csv.py:96-124) run as the reference runs it: the script itself, executed with
+    runpy on a fake HDF5 file, with and without the segmentation mask; the CSV rows are the expected outputs."""
+    import runpy
+    import tempfile
+    g = torch.Generator().manual_seed(77)
+    B, H, W, L = 3, 44, 52, 14
+    heats = 2e-4 * torch.rand(B, L, H, W, generator=g)
+    segs = torch.zeros(B, H, W, dtype=torch.uint8)
+    segs[:, :, :W // 2] = 1
+    segs[:, :, W // 2:] = 2
+    segs[:, H // 2:, : W // 4] = 5
+    segs[:, H // 2:, 3 * W // 4:] = 6
+    for i in range(B):
+        for l in range(L):
+            kind = (i * L + l) % 7
+            want = EST_LABEL_FOR[l]
+            while True:                                   # most blobs sit inside the label the masked rule looks at
+                r = int(torch.randint(0, H, (1,), generator=g))
+                c = int(torch.randint(0, W, (1,), generator=g))
+                if kind == 2 or int(segs[i, r, c]) == want:
+                    break
+            if kind == 5:
+                continue                                  # noise only: NCC far below 0.9
+            if kind == 6:
+                r, c = (0, W - 1) if l % 2 else (H - 1, 0)   # blob on the border: the reflect padding matters
+            blob = util.get_gaussian_2d_heatmap(H, W, 2.5, peak_row=r, peak_col=c)
+            if kind == 4:
+                blob = util.get_gaussian_2d_heatmap(H, W, 6.0, peak_row=r, peak_col=c) * 3   # wrong width: NCC < 0.9?
+            heats[i, l] += blob
+            if kind == 3:                                 # a second, higher peak outside the label
+                while True:
+                    r2 = int(torch.randint(0, H, (1,), generator=g))
+                    c2 = int(torch.randint(0, W, (1,), generator=g))
+                    if int(segs[i, r2, c2]) != want:
+                        break
+                heats[i, l] += 1.5 * util.get_gaussian_2d_heatmap(H, W, 2.5, peak_row=r2, peak_col=c2)
+    FAKE_FILES['heat.h5'] = {
+        'nn-heats': _FakeDS(heats.numpy()), 'nn-segs': _FakeDS(segs.numpy()),
+        'land-names': {'num-lands': _FakeDS(np.array(L)),
+                       **{'land-%02d' % l: _FakeDS(np.bytes_(EST_LAND_NAMES[l].encode())) for l in range(L)}},
+    }
+    res = {'heats': heats.numpy(), 'segs': segs.numpy(), 'label_for_land': np.array(EST_LABEL_FOR, dtype=np.int32)}
+    script = os.path.join(REF, 'est_lands_csv.py')
+    for tag, extra in (('masked', ['--use-seg', 'nn-segs']), ('plain', [])):
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, 'l.csv')
+            argv = sys.argv
+            sys.argv = [script, 'heat.h5', 'nn-heats', '--out', out, '--pat', '1'] + extra
+            try:
+                ns = runpy.run_path(script, run_name='__main__')
+                ns['csv_out'].close()       # the script leaves the file to interpreter exit
+            finally:
+                sys.argv = argv
+            rows = [ln.strip().split(',') for ln in open(out)][1:]
+        rc = np.full((B, L, 2), -7, dtype=np.int32)
+        for pat, proj, land, row, col, _t in rows:
+            rc[int(proj), int(land)] = (int(row), int(col))
+        assert (rc != -7).all(), (len(rows), rows[:3], rows[-1])
+        res['rc_' + tag] = rc
+        print('est_lands', tag, 'found', int((rc[..., 0] >= 0).sum()), 'of', B * L)
+    np.savez_compressed(os.path.join(OUT, 'est_lands.npz'), **res)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
@@ -436,6 +505,10 @@ def main():
     import warm_restarts_lr as wr
     import dataset
     torch.set_num_threads(8)
+    if '--only-est-lands' in sys.argv:
+        sys.argv.remove('--only-est-lands')
+        fixture_est_lands(util)
+        return
     base = dict(n_classes=7, depth=3, wf=2, batch_norm=True, padding=True, do_res=True, block_depth=2)
     fixture_tiny(unet, dice, util, 'tiny_sc_l14', 101, max_pool=False, num_lands=14, **base)
     fixture_tiny(unet, dice, util, 'tiny_mp_l0', 102, max_pool=True, num_lands=0, **base)
@@ -454,6 +527,7 @@ def main():
     fixture_dataset(dataset)
     fixture_ensemble(unet, util)
     fixture_trajectory(unet, dice, util)
+    fixture_est_lands(util)
     fixture_paper(unet, dice, util, 'paper_sc_l14', 1234, max_pool=False, num_lands=14)
     fixture_paper(unet, dice, util, 'paper_mp_l0', 1235, max_pool=True, num_lands=0)
 
