@@ -246,3 +246,61 @@ extern "C" int dfl_est_lands(const dfl_est_lands_args* a, dfl_stream_t stream) {
                      static_cast<hipStream_t>(stream), *a);
   return dfl::check_launch("dfl_est_lands");
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Hard Dice of label maps (compute_actual_dice_on_test.py:63-93): per image and label the pixel counts
+// |est == l|, |gt == l|, |both|; dice = 2*both / (est + gt), 1.0 when the label is absent from both.  Integer counting
+// (LDS + global integer atomics): bit-exact and order independent.
+namespace dfl {
+
+__global__ void __launch_bounds__(256) hard_dice_count_kernel(const unsigned char* __restrict__ est,
+                                                              const unsigned char* __restrict__ gt, int64_t hw, int C,
+                                                              unsigned long long* __restrict__ counts) {
+  __shared__ unsigned int loc[256 * 3];
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < 3 * C; i += 256) loc[i] = 0u;
+  __syncthreads();
+  const unsigned char* e = est + (int64_t)b * hw;
+  const unsigned char* g = gt + (int64_t)b * hw;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += (int64_t)gridDim.x * 256) {
+    const int le = e[i], lg = g[i];
+    if (le < C) atomicAdd(&loc[le * 3 + 0], 1u);
+    if (lg < C) atomicAdd(&loc[lg * 3 + 1], 1u);
+    if (le == lg && le < C) atomicAdd(&loc[le * 3 + 2], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * C; i += 256)
+    if (loc[i] != 0u) atomicAdd(&counts[(int64_t)b * C * 3 + i], (unsigned long long)loc[i]);
+}
+
+__global__ void hard_dice_final_kernel(const unsigned long long* __restrict__ counts, double* __restrict__ dice, int B, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * (C - 1)) return;
+  const int b = i / (C - 1), l = 1 + i % (C - 1);   // background excluded
+  const unsigned long long* c = counts + ((int64_t)b * C + l) * 3;
+  const double tot = (double)c[0] + (double)c[1];
+  dice[i] = tot > 0.1 ? 2.0 * (double)c[2] / tot : 1.0;
+}
+
+}  // namespace dfl
+
+extern "C" int dfl_hard_dice(const unsigned char* est, const unsigned char* gt, int64_t pixels_per_image, int32_t B,
+                             int32_t C, int64_t* counts, double* dice, dfl_stream_t stream) {
+  DFL_REQUIRE(est && gt && counts && dice, "dfl_hard_dice: missing pointer");
+  DFL_REQUIRE(B > 0 && C >= 2 && C <= 256 && pixels_per_image > 0, "dfl_hard_dice: bad sizes");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(counts, 0, (size_t)B * C * 3 * sizeof(int64_t), s) != hipSuccess) {
+    dfl::set_error("dfl_hard_dice: hipMemsetAsync failed");
+    return DFL_ERR_LAUNCH;
+  }
+  int64_t gx = dfl::ceil_div(pixels_per_image, 256 * 16);
+  if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(dfl::hard_dice_count_kernel, dim3((unsigned)gx, (unsigned)B), dim3(256), 0, s, est, gt,
+                     pixels_per_image, (int)C, reinterpret_cast<unsigned long long*>(counts));
+  int rc = dfl::check_launch("dfl_hard_dice");
+  if (rc != DFL_OK) return rc;
+  const int n = B * (C - 1);
+  hipLaunchKernelGGL(dfl::hard_dice_final_kernel, dim3((unsigned)dfl::ceil_div(n, 64)), dim3(64), 0, s,
+                     reinterpret_cast<const unsigned long long*>(counts), dice, (int)B, (int)C);
+  return dfl::check_launch("dfl_hard_dice");
+}

@@ -257,3 +257,20 @@ def est_lands(heats, segs=None, label_for_land=None, sigma=2.5, min_ncc=0.9, ret
         a.ncc = ncc.data_ptr()
     nat.call('dfl_est_lands', a, torch.cuda.current_stream(h.device).cuda_stream)
     return (out, ncc) if return_ncc else out
+
+
+def hard_dice(est_labels, gt_labels, num_classes, return_counts=False):
+    """compute_actual_dice_on_test.py:63-93 on the GPU (dfl_hard_dice): [B,H,W] integer label maps -> float64 [B, C-1]
+    Dice per image and foreground label (1.0 when a label is absent from both)."""
+    from . import _native as nat
+    if not est_labels.is_cuda:
+        raise nat.DflError('util.hard_dice needs the label maps on the GPU (no CPU path)')
+    e = est_labels.detach().to(torch.uint8).contiguous()
+    g = gt_labels.detach().to(e.device, torch.uint8).contiguous()
+    assert e.shape == g.shape and e.dim() == 3
+    B = e.shape[0]
+    counts = torch.empty((B, num_classes, 3), dtype=torch.int64, device=e.device)
+    dice = torch.empty((B, num_classes - 1), dtype=torch.float64, device=e.device)
+    nat.check(nat.lib().dfl_hard_dice(e.data_ptr(), g.data_ptr(), e.shape[1] * e.shape[2], B, num_classes, counts.data_ptr(),
+                                      dice.data_ptr(), torch.cuda.current_stream(e.device).cuda_stream), 'dfl_hard_dice')
+    return (dice, counts) if return_counts else dice

@@ -390,6 +390,12 @@ typedef struct {
 } dfl_est_lands_args;
 int dfl_est_lands(const dfl_est_lands_args* a, dfl_stream_t stream);
 
+/* Hard Dice of predicted label maps against ground truth (compute_actual_dice_on_test.py:63-93): for image b and
+ * label l = 1..C-1 (background excluded)  dice[b][l-1] = 2*|est==l & gt==l| / (|est==l| + |gt==l|), 1.0 when the label
+ * occurs in neither.  counts[b][l][3] = (|est==l|, |gt==l|, |both|) for l = 0..C-1 (exact integers). */
+int dfl_hard_dice(const unsigned char* est, const unsigned char* gt, int64_t pixels_per_image, int32_t B, int32_t C,
+                  int64_t* counts, double* dice, dfl_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Program execution: run a recorded list of the calls above with ONE host->library transition.  The host builds
  * the array once per (network, input shape) and replays it every step (forward, backward); this is the launch

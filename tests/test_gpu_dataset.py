@@ -115,3 +115,22 @@ def test_landmark_extraction_random_vs_oracle():
     got = U.est_lands(heats.to(DEV), segs.to(DEV), labels).cpu()
     want = R.est_landmarks(heats, segs, [-1 if v is None else v for v in labels])
     assert np.array_equal(got.numpy(), want.numpy())
+
+
+def test_hard_dice_exact():
+    from dfl_amd import util as U
+    g = torch.Generator().manual_seed(9)
+    B, H, W, C = 3, 70, 90, 7
+    est = torch.randint(0, C, (B, H, W), generator=g)
+    gt = torch.randint(0, C, (B, H, W), generator=g)
+    est[1][est[1] == 4] = 0
+    gt[1][gt[1] == 4] = 0                      # label 4 absent from both in image 1 -> 1.0
+    gt[2] = est[2]                             # identical -> 1.0 everywhere
+    d, counts = U.hard_dice(est.to(DEV), gt.to(DEV), C, return_counts=True)
+    for i in range(B):
+        want = R.hard_dice(est[i], gt[i], C)
+        assert d[i].cpu().tolist() == want     # integer counts, one division: exact
+    assert d[1, 3].item() == 1.0 and float(d[2].min()) == 1.0
+    assert int(counts[0, :, 0].sum()) == H * W and int(counts[0, :, 1].sum()) == H * W
+    t = load_golden('trajectory')              # the value the reference pipeline produced for the toy run is a mean of these
+    assert 'hard_dice' in t
