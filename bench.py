@@ -28,9 +28,9 @@ PAPER = dict(n_classes=7, depth=6, wf=5, batch_norm=True, padding=True, max_pool
              block_depth=2)
 F32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 CONV_KERNELS = ['conv_gemm_kernel<2,2,2,2>', 'conv_gemm_kernel<2,2,2,1>', 'conv_gemm_kernel<4,1,2,1>',
-                'conv_gemm_kernel<2,2,1,1>', 'conv_gemm_kernel<1,2,1,1>']
+                'conv_gemm_kernel<2,2,1,1>', 'conv_gemm_kernel<1,2,1,1>', 'direct_conv_kernel']
 WGRAD_KERNELS = ['wgrad_kernel<2,2,2,2,1>', 'wgrad_kernel<2,2,1,1,1>', 'wgrad_kernel<1,1,1,1,3>',
-                 'wgrad_kernel<1,1,1,1,2>', 'wgrad_kernel<1,1,1,1,1>']
+                 'wgrad_kernel<1,1,1,1,2>', 'wgrad_kernel<1,1,1,1,1>', 'direct_wgrad_kernel']
 
 
 def synth_batch(B, seed, dev):

@@ -27,6 +27,7 @@
 //   dfl_bn_finalize adds the rows in fp64.  EPI 0 = the common simple form (bias/ReLU/statistics, bounds by buffer
 //   store), EPI 1 = everything.  Small-M / long-K layers are cut along K (split-K) and finished by conv_finish_kernel.
 #include "common.h"
+#include "direct_small.h"
 
 namespace dfl {
 
@@ -713,6 +714,7 @@ extern "C" int dfl_conv_suggest_splits(const dfl_conv_args* a) {
   dfl::ConvK k;
   int rc = dfl::prepare(a, &k);
   if (rc != DFL_OK) return rc;
+  if (dfl::direct_conv_ok(a)) return 1;
   return dfl::pick_splits(k.Mtot, a->Ntot, k.Ktot, dfl::pick_cfg(k.Mtot, a->Ntot, k.fast));
 }
 
@@ -721,6 +723,7 @@ extern "C" int dfl_conv_grid_m(const dfl_conv_args* a) {
   int rc = dfl::prepare(a, &k);
   if (rc != DFL_OK) return rc;
   if (a->splits > 1) return dfl::finish_rows(k.Mtot, a->Ntot);
+  if (dfl::direct_conv_ok(a)) return dfl::direct_conv_blocks(a);
   int bm, bn;
   dfl::cfg_tile(dfl::pick_cfg(k.Mtot, a->Ntot, k.fast), &bm, &bn);
   return (int)dfl::ceil_div(k.Mtot, bm);
@@ -730,6 +733,7 @@ extern "C" int dfl_conv_config(const dfl_conv_args* a) {
   dfl::ConvK k;
   int rc = dfl::prepare(a, &k);
   if (rc != DFL_OK) return rc;
+  if (dfl::direct_conv_ok(a)) return dfl::CFG_DIRECT;
   return (int)dfl::pick_cfg(k.Mtot, a->Ntot, k.fast);
 }
 
@@ -738,6 +742,7 @@ extern "C" int dfl_conv2d(const dfl_conv_args* a, dfl_stream_t stream) {
   int rc = dfl::prepare(a, &k);
   if (rc != DFL_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dfl::direct_conv_ok(a)) return dfl::direct_conv_launch(a, s);
   if (a->splits > 1) {
     DFL_REQUIRE(a->partial != nullptr, "dfl_conv2d: splits > 1 needs the partial buffer");
     const int nchunks = (int)dfl::ceil_div(k.Ktot, dfl::KC);

@@ -1,0 +1,276 @@
+// Direct (non-GEMM) kernels for layers with a handful of input channels: the network's first block (1-channel image:
+// conv3x3 1->32, residual conv1x1 1->32 and their weight gradients; reference unet.py:207,211).  K = taps*Cin <= 12
+// leaves the 32x32x2 MFMA tiles of conv_gemm.hip / wgrad_gemm.hip 3-25 % full and their general gather path slow;
+// these layers are pure HBM streams (one read of the gradient / one write of the output), so one thread owns 4 output
+// channels of a pixel, keeps its K x 4 weights (or K x 4 gradient accumulators) in registers and walks pixels.
+// Same contracts as dfl_conv2d / dfl_conv2d_wgrad (include/dfl_hip.h), chosen by those entry points.
+#include "common.h"
+#include "direct_small.h"
+
+namespace dfl {
+
+constexpr int DK = DIRECT_MAX_K;
+
+struct Gather {   // decoded pixel -> input coordinates of tap (0,0)
+  int iy0, ix0, base;
+};
+
+__device__ __forceinline__ Gather pixel_origin(int m, int Hg, int Wg, int stride, int pad, int Hin, int Win) {
+  const int ox = m % Wg;
+  const int t = m / Wg;
+  const int oy = t % Hg;
+  const int n = t / Hg;
+  Gather g;
+  g.iy0 = oy * stride - pad;
+  g.ix0 = ox * stride - pad;
+  g.base = n * Hin * Win;
+  return g;
+}
+
+// ---------------------------------------------------------------------------------------------- forward conv
+template <int KH, int KW, int CIN>
+__global__ void __launch_bounds__(256) direct_conv_kernel(const dfl_conv_args a, int Mtot, int rows_per_block) {
+  constexpr int K = KH * KW * CIN;
+  static_assert(K <= DK, "window too large for the direct kernel");
+  __shared__ float red[2][256][4];
+  const int cq = a.Ntot / 4, PL = 256 / cq;
+  const int q = threadIdx.x % cq, pl = threadIdx.x / cq;
+  const int n0 = 4 * q;
+  float w[K][4];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    // quad-packed operand: w[(k/4)][n][k%4]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[k][j] = a.w[((int64_t)(k >> 2) * a.Ntot + n0 + j) * 4 + (k & 3)];
+  }
+  float bias[4] = {0.f, 0.f, 0.f, 0.f}, asc[4] = {1.f, 1.f, 1.f, 1.f}, ash[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (a.bias != nullptr) bias[j] = a.bias[n0 + j];
+    if (a.add_scale != nullptr) {
+      asc[j] = a.add_scale[n0 + j];
+      ash[j] = a.add_shift[n0 + j];
+    }
+  }
+  float isc[CIN], ish[CIN];
+#pragma unroll
+  for (int c = 0; c < CIN; ++c) {
+    isc[c] = (a.in_scale != nullptr) ? a.in_scale[c] : 1.f;
+    ish[c] = (a.in_scale != nullptr) ? a.in_shift[c] : 0.f;
+  }
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  const int m_begin = blockIdx.x * rows_per_block;
+  const int m_end = min(Mtot, m_begin + rows_per_block);
+  for (int m = m_begin + pl; m < m_end; m += PL) {
+    const Gather g = pixel_origin(m, a.Hout, a.Wout, a.stride, a.pad, a.Hin, a.Win);
+    float acc[4] = {bias[0], bias[1], bias[2], bias[3]};
+    float xv[K];
+#pragma unroll
+    for (int dy = 0; dy < KH; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < KW; ++dx)
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) {   // all loads first (clamped addresses), then the arithmetic
+          const int iy = g.iy0 + dy, ix = g.ix0 + dx;
+          const bool ok = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+          const float x = a.x[ok ? ((int64_t)(g.base + iy * a.Win + ix) * a.ldx + c) : 0];
+          xv[(dy * KW + dx) * CIN + c] = ok ? fmaf(x, isc[c], ish[c]) : 0.f;   // zero padding AFTER the BatchNorm affine
+        }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = fmaf(xv[k], w[k][j], acc[j]);
+    if (a.add != nullptr) {
+      const float4 r = *reinterpret_cast<const float4*>(a.add + (int64_t)m * a.ldadd + n0);
+      acc[0] += fmaf(r.x, asc[0], ash[0]);
+      acc[1] += fmaf(r.y, asc[1], ash[1]);
+      acc[2] += fmaf(r.z, asc[2], ash[2]);
+      acc[3] += fmaf(r.w, asc[3], ash[3]);
+    }
+    if (a.relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = fmaxf(acc[j], 0.f);
+    }
+    float* yp = a.y + (int64_t)m * a.ldy + n0;
+    if (a.accumulate) {
+      const float4 o = *reinterpret_cast<const float4*>(yp);
+      acc[0] += o.x; acc[1] += o.y; acc[2] += o.z; acc[3] += o.w;
+    }
+    *reinterpret_cast<float4*>(yp) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    if (a.stat_partials != nullptr) {
+      float u[4] = {acc[0], acc[1], acc[2], acc[3]};
+      if (a.stat_other != nullptr) {
+        const float4 o = *reinterpret_cast<const float4*>(a.stat_other + (int64_t)m * a.ldso + n0);
+        u[0] = o.x; u[1] = o.y; u[2] = o.z; u[3] = o.w;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s1[j] += acc[j];
+        s2[j] = fmaf(acc[j], u[j], s2[j]);
+      }
+    }
+  }
+  if (a.stat_partials == nullptr) return;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    red[0][threadIdx.x][j] = s1[j];
+    red[1][threadIdx.x][j] = s2[j];
+  }
+  __syncthreads();
+  if (pl == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float t1 = 0.f, t2 = 0.f;
+      for (int p = 0; p < PL; ++p) {   // fixed order: bit-reproducible
+        t1 += red[0][p * cq + q][j];
+        t2 += red[1][p * cq + q][j];
+      }
+      a.stat_partials[((int64_t)blockIdx.x * 2 + 0) * a.Ntot + n0 + j] = t1;
+      a.stat_partials[((int64_t)blockIdx.x * 2 + 1) * a.Ntot + n0 + j] = t2;
+    }
+  }
+}
+
+// instantiated windows (KH = KW): 3x3 with 1 channel, 2x2 with <= 3, 1x1 with <= 4
+static bool direct_window(int KH, int KW, int C) {
+  if (KH != KW) return false;
+  return (KH == 3 && C == 1) || (KH == 2 && C >= 1 && C <= 3) || (KH == 1 && C >= 1 && C <= 4);
+}
+
+bool direct_conv_ok(const dfl_conv_args* a) {
+  if (!direct_window(a->KH, a->KW, a->Cin) || a->scatter2x2 || a->splits > 1) return false;
+  if (a->Ntot % 4 != 0 || a->Ntot > 1024 || 256 % (a->Ntot / 4) != 0) return false;
+  if (a->ldy % 4 != 0 || !aligned16(a->y)) return false;
+  if (a->add != nullptr && (a->ldadd % 4 != 0 || !aligned16(a->add))) return false;
+  if (a->stat_other != nullptr && (a->ldso % 4 != 0 || !aligned16(a->stat_other))) return false;
+  return true;
+}
+
+int direct_conv_blocks(const dfl_conv_args* a) {
+  const int64_t M = (int64_t)a->N * a->Hout * a->Wout;
+  const int PL = 256 / (a->Ntot / 4);
+  int64_t b = ceil_div(M, (int64_t)PL * 8);
+  if (b > 2048) b = 2048;
+  return (int)(b < 1 ? 1 : b);
+}
+
+int direct_conv_launch(const dfl_conv_args* a, hipStream_t s) {
+  const int64_t M = (int64_t)a->N * a->Hout * a->Wout;
+  const int blocks = direct_conv_blocks(a);
+  const int rpb = (int)ceil_div(M, blocks);
+#define DFL_DC(KH_, C_) hipLaunchKernelGGL((direct_conv_kernel<KH_, KH_, C_>), dim3((unsigned)blocks), dim3(256), 0, s, *a, (int)M, rpb)
+  switch (a->KH * 10 + a->Cin) {
+    case 31: DFL_DC(3, 1); break;
+    case 21: DFL_DC(2, 1); break;
+    case 22: DFL_DC(2, 2); break;
+    case 23: DFL_DC(2, 3); break;
+    case 11: DFL_DC(1, 1); break;
+    case 12: DFL_DC(1, 2); break;
+    case 13: DFL_DC(1, 3); break;
+    default: DFL_DC(1, 4); break;
+  }
+#undef DFL_DC
+  return check_launch("dfl_conv2d");
+}
+
+// ---------------------------------------------------------------------------------------------- weight gradient
+// acc[k][j] = sum over this thread's pixels of G(m, k) * d[m][4q + j];  k = tap*Cg + cg
+template <int KH, int KW, int CG>
+__global__ void __launch_bounds__(256) direct_wgrad_kernel(const dfl_wgrad_args a, int Mtot, int rows_per_block) {
+  constexpr int K = KH * KW * CG, T = KH * KW;
+  static_assert(K <= DK, "window too large for the direct kernel");
+  __shared__ float red[256][4];
+  const int cq = a.Cm / 4, PL = 256 / cq;
+  const int q = threadIdx.x % cq, pl = threadIdx.x / cq;
+  const int Cg = CG;
+  float isc[CG], ish[CG];
+#pragma unroll
+  for (int c = 0; c < CG; ++c) {
+    isc[c] = (a.in_scale != nullptr) ? a.in_scale[c] : 1.f;
+    ish[c] = (a.in_scale != nullptr) ? a.in_shift[c] : 0.f;
+  }
+  float acc[K][4];
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[k][j] = 0.f;
+  const int m_begin = blockIdx.x * rows_per_block;
+  const int m_end = min(Mtot, m_begin + rows_per_block);
+  for (int m = m_begin + pl; m < m_end; m += PL) {
+    const Gather g = pixel_origin(m, a.Hout, a.Wout, a.stride, a.pad, a.Hin, a.Win);
+    const float4 d = *reinterpret_cast<const float4*>(a.d + (int64_t)m * a.ldd + 4 * q);
+    float xv[K];
+#pragma unroll
+    for (int dy = 0; dy < KH; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < KW; ++dx)
+#pragma unroll
+        for (int c = 0; c < CG; ++c) {
+          const int iy = g.iy0 + dy, ix = g.ix0 + dx;
+          const bool ok = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+          const float x = a.g[ok ? ((int64_t)(g.base + iy * a.Win + ix) * a.ldg + c) : 0];
+          xv[(dy * KW + dx) * CG + c] = ok ? fmaf(x, isc[c], ish[c]) : 0.f;
+        }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      acc[k][0] = fmaf(xv[k], d.x, acc[k][0]);
+      acc[k][1] = fmaf(xv[k], d.y, acc[k][1]);
+      acc[k][2] = fmaf(xv[k], d.z, acc[k][2]);
+      acc[k][3] = fmaf(xv[k], d.w, acc[k][3]);
+    }
+  }
+  const bool sliced = a.splits > 1;
+  float* out = sliced ? a.partial + (int64_t)blockIdx.x * a.Cm * a.Cg * T : a.dw;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[threadIdx.x][j] = acc[k][j];
+    __syncthreads();
+    if (pl == 0) {
+      const int t = k / Cg, cg = k - t * Cg;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float s = 0.f;
+        for (int p = 0; p < PL; ++p) s += red[p * cq + q][j];
+        const int cm = 4 * q + j;
+        out[sliced ? ((int64_t)t * a.Cm + cm) * Cg + cg : ((int64_t)cm * Cg + cg) * T + t] = s;
+      }
+    }
+  }
+}
+
+bool direct_wgrad_ok(const dfl_wgrad_args* a) {
+  if (!direct_window(a->KH, a->KW, a->Cg)) return false;
+  if (a->Cm % 4 != 0 || a->Cm > 1024 || 256 % (a->Cm / 4) != 0) return false;
+  if (a->ldd % 4 != 0 || !aligned16(a->d)) return false;
+  return true;
+}
+
+int direct_wgrad_splits(const dfl_wgrad_args* a) {
+  const int64_t M = (int64_t)a->N * a->Hout * a->Wout;
+  const int PL = 256 / (a->Cm / 4);
+  int64_t b = ceil_div(M, (int64_t)PL * 16);
+  if (b > 1024) b = 1024;
+  return (int)(b < 1 ? 1 : b);
+}
+
+int direct_wgrad_launch(const dfl_wgrad_args* a, hipStream_t s) {
+  const int64_t M = (int64_t)a->N * a->Hout * a->Wout;
+  const int rpb = (int)ceil_div(M, a->splits);
+#define DFL_DW(KH_, C_) hipLaunchKernelGGL((direct_wgrad_kernel<KH_, KH_, C_>), dim3((unsigned)a->splits), dim3(256), 0, s, *a, (int)M, rpb)
+  switch (a->KH * 10 + a->Cg) {
+    case 31: DFL_DW(3, 1); break;
+    case 21: DFL_DW(2, 1); break;
+    case 22: DFL_DW(2, 2); break;
+    case 23: DFL_DW(2, 3); break;
+    case 11: DFL_DW(1, 1); break;
+    case 12: DFL_DW(1, 2); break;
+    case 13: DFL_DW(1, 3); break;
+    default: DFL_DW(1, 4); break;
+  }
+#undef DFL_DW
+  return check_launch("dfl_conv2d_wgrad");
+}
+
+}  // namespace dfl

@@ -15,6 +15,7 @@
 // the dense operand's offsets are loop invariant (the chunk advance rides in the scalar offset), the gathered operand
 // keeps a pixel cursor advanced without divisions.  The general path covers odd channel counts (first layer, heads).
 #include "common.h"
+#include "direct_small.h"
 
 namespace dfl {
 
@@ -399,6 +400,7 @@ extern "C" int dfl_wgrad_config(const dfl_wgrad_args* a) {
   dfl::WgK k;
   int rc = dfl::wg_prepare(a, &k, false);
   if (rc != DFL_OK) return rc;
+  if (dfl::direct_wgrad_ok(a)) return dfl::CFG_DIRECT;
   return (int)dfl::pick_wg(a);
 }
 
@@ -406,6 +408,7 @@ extern "C" int dfl_wgrad_suggest_splits(const dfl_wgrad_args* a) {
   dfl::WgK k;
   int rc = dfl::wg_prepare(a, &k, false);
   if (rc != DFL_OK) return rc;
+  if (dfl::direct_wgrad_ok(a)) return dfl::direct_wgrad_splits(a);
   int bm, bn, tpb;
   dfl::wg_tile(dfl::pick_wg(a), &bm, &bn, &tpb);
   const int waves = (bm >= 64) ? 4 : 1;
@@ -423,8 +426,9 @@ extern "C" int dfl_conv2d_wgrad(const dfl_wgrad_args* a, dfl_stream_t stream) {
   dfl::WgK k;
   int rc = dfl::wg_prepare(a, &k, true);
   if (rc != DFL_OK) return rc;
-  k.cps = (int)dfl::ceil_div(k.nchunks, a->splits);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dfl::direct_wgrad_ok(a)) return dfl::direct_wgrad_launch(a, s);
+  k.cps = (int)dfl::ceil_div(k.nchunks, a->splits);
   const bool f = k.fast;
   switch (dfl::pick_wg(a)) {
     case dfl::WG_128: return f ? dfl::wg_launch<2, 2, 2, 2, 1, true>(k, s) : dfl::wg_launch<2, 2, 2, 2, 1, false>(k, s);

@@ -49,8 +49,7 @@ def test_buckets_cover_every_live_gradient_once():
         assert int(covered[s:s + sizes[k]].max()) == 0
     # the heads / last decoder block are final first (small sums wait for a batched flush), the first encoder block last
     assert order[0].startswith(('seg_conv', 'lands_1x1', 'up_path.%d.' % (net.depth - 2)))
-    assert ready['seg_conv.weight'] <= ready['down_path.0.block.0.weight']
-    assert ready['down_path.0.block.0.weight'] == max(ready.values())
+    assert max(ready.values()) == max(v for k, v in ready.items() if k.startswith('down_path.0.'))
 
 
 class _FakeProgram:
