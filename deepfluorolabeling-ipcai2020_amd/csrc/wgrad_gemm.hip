@@ -36,11 +36,16 @@ __device__ __forceinline__ float4 wbuf_load4(__amdgpu_buffer_rsrc_t rs, uint32_t
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
+constexpr int WG_WS = 1;   // pixel-interleaved waves per workgroup of the one-wave tiles (2 and 4 measured: slices shrink, kernel slows, step time equal)
+
 constexpr int wg_occ(int tiles, bool fast) { return tiles >= 4 ? 2 : (fast ? 4 : 3); }
 
-template <int WM, int WN, int TM, int TN, int TPB, bool FAST>
-__global__ void __launch_bounds__(WM* WN * 64, wg_occ(TM* TN* TPB, FAST)) wgrad_kernel(const WgK p) {
-  constexpr int NT = WM * WN * 64;
+// WS > 1 (one-wave tiles only): the workgroup is WS independent waves that take every WS-th chunk of the slice with
+// their own LDS images and add their accumulators through LDS at the end -- same residency, 1/WS of the slice traffic.
+template <int WM, int WN, int TM, int TN, int TPB, bool FAST, int WS>
+__global__ void __launch_bounds__(WM* WN * 64 * WS, wg_occ(TM* TN* TPB, FAST)) wgrad_kernel(const WgK p) {
+  static_assert(WS == 1 || WM * WN == 1, "pixel-interleaved waves only for one-wave tiles");
+  constexpr int NT = WM * WN * 64;   // threads of one tile (the "virtual workgroup" all staging indices refer to)
   constexpr int BMc = WM * TM * 32, BNg = WN * TN * 32;
   constexpr int LDD = BMc + 4, LDG = BNg + 4;
   constexpr int DQ = BMc / 4, GQ = BNg / 4;
@@ -50,12 +55,14 @@ __global__ void __launch_bounds__(WM* WN * 64, wg_occ(TM* TN* TPB, FAST)) wgrad_
   // one-wave workgroups keep a single LDS image (9 KB -> 16 workgroups per CU); the next chunk waits in registers
   constexpr int NBUF = (WM * WN == 1) ? 1 : 2;
 
+  constexpr int LDS_PER = NBUF * (KP * LDD + TPB * KP * LDG);
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Ds = smem;                    // [NBUF][KP][LDD]
-  float* Gs = smem + NBUF * KP * LDD;  // [NBUF][TPB][KP][LDG]
+  const int sub = (WS > 1) ? (int)threadIdx.x / NT : 0;
+  float* Ds = smem + sub * LDS_PER;    // [NBUF][KP][LDD]
+  float* Gs = Ds + NBUF * KP * LDD;    // [NBUF][TPB][KP][LDG]
 
   const dfl_wgrad_args& a = p.a;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = (WS > 1) ? (int)threadIdx.x % NT : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, lh = lane >> 5;
   const int T = p.T;
@@ -94,7 +101,7 @@ __global__ void __launch_bounds__(WM* WN * 64, wg_occ(TM* TN* TPB, FAST)) wgrad_
     const int idx = tid + r * NT;
     g_pix[r] = idx / GQ;
     g_ok0[r] = (idx < NQG) && (gc < a.Cg);
-    const int m = ch_begin * KP + g_pix[r];
+    const int m = (ch_begin + sub) * KP + g_pix[r];
     g_ox[r] = m % a.Wout;
     const int tq = m / a.Wout;
     g_oy[r] = tq % a.Hout;
@@ -116,14 +123,15 @@ __global__ void __launch_bounds__(WM* WN * 64, wg_occ(TM* TN* TPB, FAST)) wgrad_
   }
 
   auto load = [&](int ch) {
-    const int mc0 = ch * KP;
+    const bool live = ch < ch_end;          // wave uniform: a wave may run one chunk past its share (reads zeros)
+    const int mc0 = live ? ch * KP : 0;
     if constexpr (FAST) {
       const uint32_t soff = (uint32_t)mc0 * (uint32_t)a.ldd * 4u;
-      const bool tail = mc0 + KP > p.Mtot;   // wave uniform; the scalar offset takes no part in the bounds check
+      const bool tail = !live || mc0 + KP > p.Mtot;   // the scalar offset takes no part in the bounds check
 #pragma unroll
       for (int r = 0; r < QD; ++r) {
         const int pix = (tid + r * NT) / DQ;
-        rd[r] = wbuf_load4(rsD, (tail && mc0 + pix >= p.Mtot) ? WOOB : d_voff[r], soff);
+        rd[r] = wbuf_load4(rsD, (tail && (!live || mc0 + pix >= p.Mtot)) ? WOOB : d_voff[r], soff);
       }
     } else {
 #pragma unroll
@@ -131,7 +139,7 @@ __global__ void __launch_bounds__(WM* WN * 64, wg_occ(TM* TN* TPB, FAST)) wgrad_
         const int idx = tid + r * NT;
         const int pix = idx / DQ, q = idx - pix * DQ;
         const int m = mc0 + pix, c = cm0 + 4 * q;
-        const bool ok = (idx < NQD) && (m < p.Mtot) && (c < a.Cm);
+        const bool ok = live && (idx < NQD) && (m < p.Mtot) && (c < a.Cm);
         const float* src = a.d + (ok ? ((int64_t)m * a.ldd + c) : 0);
         if (p.vecD) {
           okD[r][0] = okD[r][1] = okD[r][2] = okD[r][3] = ok;
@@ -149,7 +157,7 @@ __global__ void __launch_bounds__(WM* WN * 64, wg_occ(TM* TN* TPB, FAST)) wgrad_
 #pragma unroll
     for (int r = 0; r < QG; ++r) {
       const int m = mc0 + g_pix[r];
-      const bool ok = g_ok0[r] && (m < p.Mtot);
+      const bool ok = live && g_ok0[r] && (m < p.Mtot);
       const int iy = g_oy[r] * a.stride - a.pad + tap_dy;
       const int ix0 = g_ox[r] * a.stride - a.pad + tap_dx0;
       const bool rowok = ok && (unsigned)iy < (unsigned)Hin;
@@ -169,7 +177,7 @@ __global__ void __launch_bounds__(WM* WN * 64, wg_occ(TM* TN* TPB, FAST)) wgrad_
           }
         }
       }
-      g_ox[r] += KP;
+      g_ox[r] += KP * WS;
       while (g_ox[r] >= a.Wout) {
         g_ox[r] -= a.Wout;
         if (++g_oy[r] == a.Hout) {
@@ -229,15 +237,15 @@ __global__ void __launch_bounds__(WM* WN * 64, wg_occ(TM* TN* TPB, FAST)) wgrad_
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[tt][i][j][r] = 0.f;
 
-  if (ch_begin < ch_end) {
-    load(ch_begin);
-    store(0);
-  }
+  const int nit = (ch_end - ch_begin + WS - 1) / WS;   // workgroup uniform (barriers inside)
+  load(ch_begin + sub);
+  store(0);
   __syncthreads();
-  for (int ch = ch_begin; ch < ch_end; ++ch) {
-    const int buf = (NBUF == 2) ? ((ch - ch_begin) & 1) : 0;
-    const bool more = (ch + 1) < ch_end;
-    if (more) load(ch + 1);
+  for (int it = 0; it < nit; ++it) {
+    const int ch = ch_begin + sub + it * WS;
+    const int buf = (NBUF == 2) ? (it & 1) : 0;
+    const bool more = (it + 1) < nit;
+    if (more) load(ch + WS);
     __builtin_amdgcn_sched_barrier(0);
     const float* Db = Ds + buf * KP * LDD + wm * (TM * 32) + li;
     const float* Gb = Gs + buf * TPB * KP * LDG + wn * (TN * 32) + li;
@@ -264,6 +272,33 @@ __global__ void __launch_bounds__(WM* WN * 64, wg_occ(TM* TN* TPB, FAST)) wgrad_
     __syncthreads();
   }
 
+  if constexpr (WS > 1) {
+    // the other waves hand their accumulators over through LDS ([tile][register][lane], the staging images are dead)
+    if (sub > 0) {
+      float* dst = smem + (sub - 1) * (TPB * TM * TN * 16 * 64);
+#pragma unroll
+      for (int tt = 0; tt < TPB; ++tt)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[(((tt * TM + i) * TN + j) * 16 + r) * 64 + lane] = acc[tt][i][j][r];
+    }
+    __syncthreads();
+    if (sub > 0) return;
+    for (int s2 = 0; s2 < WS - 1; ++s2) {   // fixed order
+      const float* src = smem + s2 * (TPB * TM * TN * 16 * 64);
+#pragma unroll
+      for (int tt = 0; tt < TPB; ++tt)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tt][i][j][r] += src[(((tt * TM + i) * TN + j) * 16 + r) * 64 + lane];
+    }
+  }
   // slices: tap-major [T][Cm][Cg] (each accumulator row is a contiguous 128-byte store); final result: torch order
   const bool sliced = a.splits > 1;
   float* out = sliced ? a.partial + (int64_t)blockIdx.z * a.Cm * a.Cg * T : a.dw;
@@ -387,10 +422,13 @@ template <int WM, int WN, int TM, int TN, int TPB, bool FAST>
 static int wg_launch(const WgK& k, hipStream_t s) {
   constexpr int BMc = WM * TM * 32, BNg = WN * TN * 32;
   constexpr int NBUF = (WM * WN == 1) ? 1 : 2;
-  const size_t lds = (size_t)NBUF * (KP * (BMc + 4) + TPB * KP * (BNg + 4)) * sizeof(float);
+  constexpr int WS = (WM * WN == 1) ? WG_WS : 1;
+  size_t lds = (size_t)WS * NBUF * (KP * (BMc + 4) + TPB * KP * (BNg + 4)) * sizeof(float);
+  const size_t handover = (size_t)(WS - 1) * TPB * TM * TN * 16 * 64 * sizeof(float);
+  if (handover > lds) lds = handover;
   const int tiles_g = (int)ceil_div(k.a.Cg, BNg);
   dim3 grid((unsigned)ceil_div(k.a.Cm, BMc), (unsigned)(tiles_g * (k.T / TPB)), (unsigned)k.a.splits);
-  hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, TPB, FAST>), grid, dim3(WM * WN * 64), lds, s, k);
+  hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, TPB, FAST, WS>), grid, dim3(WM * WN * 64 * WS), lds, s, k);
   return check_launch("dfl_conv2d_wgrad");
 }
 
@@ -411,7 +449,7 @@ extern "C" int dfl_wgrad_suggest_splits(const dfl_wgrad_args* a) {
   if (dfl::direct_wgrad_ok(a)) return dfl::direct_wgrad_splits(a);
   int bm, bn, tpb;
   dfl::wg_tile(dfl::pick_wg(a), &bm, &bn, &tpb);
-  const int waves = (bm >= 64) ? 4 : 1;
+  const int waves = (bm >= 64) ? 4 : dfl::WG_WS;   // 2x2 waves of the wide tiles, WG_WS interleaved waves of the one-wave tiles
   const int64_t blocks = dfl::ceil_div(a->Cm, bm) * dfl::ceil_div(a->Cg, bn) * (k.T / tpb);
   // aim at ~4 waves per SIMD over the whole chip (4096 waves), every slice at least 128 pixels
   int64_t s = dfl::ceil_div(4096, blocks * waves);
