@@ -117,17 +117,23 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
   float4 rb[2][QB];
   float4 sc4[2], sh4[2];
   uint32_t okA[2] = {0, 0};   // MODE 1: bit r = row r valid for the chunk in flight; MODE 0: bit 4r+j
+  bool all_in[2] = {false, false};                   // MODE 1 + AFF: every row of the wave is valid for that chunk's tap
+  constexpr uint32_t full_rows = (1u << QA) - 1u;
   sc4[0] = sc4[1] = make_float4(1.f, 1.f, 1.f, 1.f);
   sh4[0] = sh4[1] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   // ---- MODE 1 state --------------------------------------------------------------------------------------------------
   uint32_t a_rowb[QA];   // byte offset (mod 2^32) of (tap (0,0), channel 4*aq) of each gather row
   uint32_t b_voff[QB];   // loop-invariant byte offset of this thread's weight quads inside a chunk slab
-  __amdgpu_buffer_rsrc_t rsA, rsB;
+  __amdgpu_buffer_rsrc_t rsA, rsB, rsSc, rsSh;
   int cur_tap = 0, cur_c0 = 0, cur_dy = 0, cur_dx = 0;   // wave-uniform cursor of the chunk to load next
   if constexpr (MODE == 1) {
     rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)p.x_bytes, 0x00020000);
     rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)p.w_bytes, 0x00020000);
+    if constexpr (AFF) {
+      rsSc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in_scale), 0, Cin * 4, 0x00020000);
+      rsSh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in_shift), 0, Cin * 4, 0x00020000);
+    }
 #pragma unroll
     for (int r = 0; r < QA; ++r)
       a_rowb[r] = (uint32_t)((((int64_t)a_base[r] + (int64_t)a_iy0[r] * Win + a_ix0[r]) * a.ldx + 4 * aq) * 4);
@@ -166,10 +172,11 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
         ra[set][r] = buf_load4(rsA, ok ? a_rowb[r] + tapb : OOB, 0);
       }
       okA[set] = okm;
-      if constexpr (AFF) {
-        const int c = (kvalid ? cur_c0 : 0) + 4 * aq;
-        sc4[set] = *reinterpret_cast<const float4*>(a.in_scale + c);
-        sh4[set] = *reinterpret_cast<const float4*>(a.in_shift + c);
+      if constexpr (AFF) all_in[set] = __builtin_amdgcn_ballot_w64(okm == full_rows) == ~0ull;
+      if constexpr (AFF) {   // this thread's 4 channels: fixed lane offset, the chunk's first channel rides in the scalar offset
+        const uint32_t csoff = kvalid ? (uint32_t)cur_c0 * 4u : 0u;
+        sc4[set] = buf_load4(rsSc, (uint32_t)aq * 16u, csoff);
+        sh4[set] = buf_load4(rsSh, (uint32_t)aq * 16u, csoff);
       }
       const uint32_t soff = live ? (uint32_t)ch * (uint32_t)(KC / 4 * 16) * (uint32_t)Ntot : 0u;   // chunk = 4 k-quad rows
 #pragma unroll
@@ -232,12 +239,22 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
       float4 v = ra[set][r];
       const float4 sc = sc4[set], sh = sh4[set];
       if constexpr (MODE == 1) {
-        if constexpr (AFF) {   // zero padding applies AFTER the BatchNorm affine: out-of-image taps stay 0
-          const bool ok = (okA[set] >> r) & 1u;
-          v.x = ok ? fmaf(v.x, sc.x, sh.x) : 0.f;
-          v.y = ok ? fmaf(v.y, sc.y, sh.y) : 0.f;
-          v.z = ok ? fmaf(v.z, sc.z, sh.z) : 0.f;
-          v.w = ok ? fmaf(v.w, sc.w, sh.w) : 0.f;
+        if constexpr (AFF) {
+          // zero padding applies AFTER the BatchNorm affine: out-of-image taps must stay 0.  Their data already is 0
+          // (hardware bounds check), so only the shift has to be masked -- and not even that when every row of the
+          // wave sees this tap inside the image (wave-uniform test: all interior tiles, and the centre tap always).
+          typedef float f2 __attribute__((ext_vector_type(2)));
+          f2 h0 = {sh.x, sh.y}, h1 = {sh.z, sh.w};
+          if (!all_in[set]) {
+            const bool ok = (okA[set] >> r) & 1u;
+            h0.x = ok ? sh.x : 0.f;
+            h0.y = ok ? sh.y : 0.f;
+            h1.x = ok ? sh.z : 0.f;
+            h1.y = ok ? sh.w : 0.f;
+          }
+          const f2 r0 = __builtin_elementwise_fma((f2){v.x, v.y}, (f2){sc.x, sc.y}, h0);
+          const f2 r1 = __builtin_elementwise_fma((f2){v.z, v.w}, (f2){sc.z, sc.w}, h1);
+          v = make_float4(r0.x, r0.y, r1.x, r1.y);
         }
       } else {
         const uint32_t o = okA[set] >> (4 * r);
