@@ -125,7 +125,26 @@ class UNetPlan:
         raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
         self._jobs_dev = torch.from_numpy(raw).to(self.dev)
         self._keep.append(self._jobs_dev)
-        self.pack.add(PackArgs(jobs_dev=self._jobs_dev.data_ptr(), max_elems=mx, njobs=n))
+        nf = getattr(self, '_n_fwd_pack', n)
+        if not self.PACK_OVERLAP or self.bwd is None or nf in (0, n):
+            self.pack.add(PackArgs(jobs_dev=self._jobs_dev.data_ptr(), max_elems=mx, njobs=n))
+            return
+        # The layouts only the backward pass reads (flipped / transposed data-gradient operands: half of the traffic) are
+        # built on the side stream while the forward convolutions run -- an HBM-bound kernel next to matrix-bound ones.
+        # Main stream: forward layouts.  Side stream: waits for the main stream (the optimizer step), packs, signals;
+        # the backward program starts by waiting for that signal.
+        def mx_of(jobs):
+            return max(A * B * Cc for (_, _, A, B, Cc, _, _) in jobs)
+        self.pack.add(PackArgs(jobs_dev=self._jobs_dev.data_ptr(), max_elems=mx_of(self._pack_jobs[:nf]), njobs=nf))
+        self.pack.record(self.EV_PACK_FORK, stream=0)
+        self.pack.wait(self.EV_PACK_FORK, stream=1)
+        self.pack.add(PackArgs(jobs_dev=self._jobs_dev.data_ptr() + nf * C.sizeof(PackJob),
+                               max_elems=mx_of(self._pack_jobs[nf:]), njobs=n - nf), stream=1)
+        self.pack.record(self.EV_PACK_DONE, stream=1)
+        self._bwd_needs_pack_wait = True
+
+    PACK_OVERLAP = os.environ.get('DFL_PACK_OVERLAP', '1') != '0'
+    EV_PACK_FORK, EV_PACK_DONE = 60000, 60001
 
     # ------------------------------------------------------------------------------------------ op helpers
     def _conv(self, prog, x, w, y, KH, KW, stride, pad, Ntot, bias=None, in_aff=None, relu=0, add=None,
@@ -549,6 +568,8 @@ class UNetPlan:
                                     dx=dfeat.ptr, scratch=scratch.data_ptr(), N=N, H=u.H, W=u.W, F=F, ldx=u.ld,
                                     lddx=dfeat.ld, NC=NC, NM=NM, L=L, softmax=1 if cfg['do_soft_max'] else 0,
                                     scratch_ld=sld)
+        if self.PACK_OVERLAP:
+            bwd.wait(self.EV_PACK_DONE, stream=0)      # data-gradient weight layouts are packed on the side stream
         bwd.add(self.head_bwd)
         off = [self.lib.dfl_head_scratch_off(F, k) for k in range(5)]
 
