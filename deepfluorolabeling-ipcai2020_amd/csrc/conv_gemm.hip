@@ -776,13 +776,7 @@ extern "C" int dfl_conv2d(const dfl_conv_args* a, dfl_stream_t stream) {
       case dfl::CFG_128x128: rc = dfl::launch_fast<2, 2, 2, 2>(k, aff, general, s); break;
       case dfl::CFG_128x64: rc = dfl::launch_fast<2, 2, 2, 1>(k, aff, general, s); break;
       case dfl::CFG_256x32: rc = dfl::launch_fast<4, 1, 2, 1>(k, aff, general, s); break;
-      case dfl::CFG_64x64: {
-        static const int alt = getenv("DFL_CONV_ALT") ? atoi(getenv("DFL_CONV_ALT")) : 0;
-        if (alt == 1) rc = dfl::launch_fast<2, 1, 1, 2>(k, aff, general, s);
-        else if (alt == 2) rc = dfl::launch_fast<1, 2, 2, 1>(k, aff, general, s);
-        else rc = dfl::launch_fast<2, 2, 1, 1>(k, aff, general, s);
-        break;
-      }
+      case dfl::CFG_64x64: rc = dfl::launch_fast<2, 2, 1, 1>(k, aff, general, s); break;   // (2-wave 64x64 variants measured 10 % slower)
       default: rc = dfl::launch_fast<1, 2, 1, 1>(k, aff, general, s); break;
     }
   }

@@ -231,12 +231,15 @@ class UNet(nn.Module):
         plans.append(plan)
         return plan
 
-    def _run_forward(self, plan, x):
-        stream = torch.cuda.current_stream().cuda_stream
+    def _ensure_packed(self, plan, stream):
         ver = sum(p._version for p in self._weight_params)
         if self._pack_version != (id(plan), ver):
             plan.pack.run(stream)                    # weight re-layout for this plan's kernels
             self._pack_version = (id(plan), ver)
+
+    def _run_forward(self, plan, x):
+        stream = torch.cuda.current_stream().cuda_stream
+        self._ensure_packed(plan, stream)
         cin = self._cfg['in_channels']
         if cin == 1:
             plan.x_in.copy_(x.reshape(-1))
@@ -265,6 +268,9 @@ class UNet(nn.Module):
             raise NotImplementedError('gradients through eval-mode BatchNorm are not implemented in the HIP path; '
                                       'call net.train() or wrap the call in torch.no_grad()')
         plan = self._get_plan(x, need_grad)
+        # first GPU work of a training step: enqueue it before the autograd bookkeeping below (the GPU sits idle between
+        # the previous step's loss.item() and this launch)
+        self._ensure_packed(plan, torch.cuda.current_stream().cuda_stream)
         if not need_grad:
             seg, heat = self._run_forward(plan, x)
             return (seg, heat) if heat is not None else seg
