@@ -168,7 +168,8 @@ EXPORTS = ['dfl_version', 'dfl_last_error', 'dfl_sizeof', 'dfl_conv2d', 'dfl_con
            'dfl_maxpool2x2_bwd', 'dfl_head_fwd', 'dfl_head_bwd', 'dfl_head_scratch_ld', 'dfl_head_scratch_off',
            'dfl_dice_ncc_loss', 'dfl_loss_scratch_doubles', 'dfl_ensemble_reduce', 'dfl_sgd_step', 'dfl_exec',
            'dfl_exec_timed', 'dfl_conv_config', 'dfl_wgrad_config', 'dfl_conv_suggest_splits', 'dfl_reduce_batch',
-           'dfl_reduce_job_blocks', 'dfl_prep_batch', 'dfl_prep_scratch_doubles', 'dfl_est_lands', 'dfl_hard_dice']
+           'dfl_reduce_job_blocks', 'dfl_prep_batch', 'dfl_prep_scratch_doubles', 'dfl_est_lands', 'dfl_hard_dice', 'dfl_get_math_mode',
+           'dfl_set_math_mode']
 
 
 class DflError(RuntimeError):
@@ -204,6 +205,7 @@ def lib():
     L.dfl_prep_scratch_doubles.argtypes = [i32]
     L.dfl_prep_batch.argtypes = [fp, fp]
     L.dfl_est_lands.argtypes = [fp, fp]
+    L.dfl_set_math_mode.argtypes = [i32]
     L.dfl_hard_dice.argtypes = [fp, fp, i64, i32, i32, fp, fp, fp]
     L.dfl_sgd_step.argtypes = [fp, fp, fp, i64, f32, f32, f32, f32, i32, i32, fp]
     L.dfl_exec.argtypes = [fp, i32, fp]

@@ -1,5 +1,6 @@
 // Library-level entry points: version, thread-local error text, and the program executor that replays a recorded
 // list of kernel calls with one host->library transition (include/dfl_hip.h: dfl_exec).
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -44,6 +45,26 @@ static hipEvent_t pick_event(int id) {
   return g_events[id];
 }
 }  // namespace dfl
+
+namespace dfl {
+static int g_math = -1;
+int math_mode() {
+  if (g_math < 0) {
+    const char* e = getenv("DFL_MATH");
+    g_math = (e != nullptr && strcmp(e, "fp32") == 0) ? 0 : (e != nullptr && strcmp(e, "bf16x6") == 0) ? 2
+             : (e != nullptr && strcmp(e, "bf16x3") == 0) ? 1 : DFL_MATH_DEFAULT;
+  }
+  return g_math;
+}
+}  // namespace dfl
+
+extern "C" int dfl_get_math_mode(void) { return dfl::math_mode(); }
+
+extern "C" int dfl_set_math_mode(int32_t mode) {
+  DFL_REQUIRE(mode >= 0 && mode <= 2, "dfl_set_math_mode: mode must be 0 (fp32), 1 (bf16x3) or 2 (bf16x6)");
+  dfl::g_math = mode;
+  return DFL_OK;
+}
 
 extern "C" int dfl_version(void) { return 100; /* 0.1.0 */ }
 

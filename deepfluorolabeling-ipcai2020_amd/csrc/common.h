@@ -33,6 +33,30 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// ---- split-bf16 products (DFL math modes 1 "bf16x3" and 2 "bf16x6"; see conv_gemm.hip) ------------------------------
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+// x = p[0] + p[1] (+ p[2]) + O(2^-8NP |x|): successive bf16 roundings of the residual; 4 values -> 4 bf16 per part
+template <int NP>
+__device__ __forceinline__ void split_bf16(const float4 v, uint2* parts) {
+  f32x2_t a = {v.x, v.y}, b = {v.z, v.w};
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    const bf16x2_t h0 = __builtin_convertvector(a, bf16x2_t), h1 = __builtin_convertvector(b, bf16x2_t);
+    parts[q] = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
+    if (q + 1 < NP) {
+      a -= __builtin_convertvector(h0, f32x2_t);
+      b -= __builtin_convertvector(h1, f32x2_t);
+    }
+  }
+}
+
+// Product arithmetic of the fast GEMM paths: 0 = fp32 matrix instructions, 1 = bf16x3, 2 = bf16x6 (conv only; the
+// weight-gradient kernel then stays fp32).  Process-wide (dfl_set_math_mode / DFL_MATH).
+int math_mode();
+
 // wave64 butterfly step across the two 32-lane halves
 __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
 

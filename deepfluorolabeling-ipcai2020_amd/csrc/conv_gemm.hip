@@ -26,6 +26,9 @@
 //   (v, v*u) reduced lane -> half-wave (xor-32 shuffle) -> workgroup (LDS) -> one row of stat_partials per row block;
 //   dfl_bn_finalize adds the rows in fp64.  EPI 0 = the common simple form (bias/ReLU/statistics, bounds by buffer
 //   store), EPI 1 = everything.  Small-M / long-K layers are cut along K (split-K) and finished by conv_finish_kernel.
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 #include "direct_small.h"
 
@@ -53,11 +56,19 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rs, uint32_t 
 // Second launch-bound = waves per SIMD the register allocation must leave room for (residency per CU, see pick_cfg).
 constexpr int conv_occ(int tiles) { return tiles >= 4 ? 2 : (tiles == 2 ? 4 : 5); }
 
-template <int WM, int WN, int TM, int TN, int MODE, bool AFF, int EPI>
+// MATH 1 ("bf16x3") / MATH 2 ("bf16x6"): every fp32 operand value x is split at the LDS write into NP = 2 / 3 bf16
+// parts (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)) and the product is accumulated from the part
+// products of order i + j < NP on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, fp32 accumulate): 3 / 6 instructions
+// of 32 cycles per 16 k-values instead of 8 of 64.  bf16x3 drops terms of relative size 2^-16 per product (1e-4-class
+// results), bf16x6 drops 2^-24: the products are as exact as fp32 multiplication.  A row of the LDS images holds the
+// 16 values of part 0 (32 B), then part 1, (part 2): pitch 80 B like the 16 fp32 values of MATH 0 for NP = 2, 112 B for 3.
+template <int WM, int WN, int TM, int TN, int MODE, bool AFF, int EPI, int MATH>
 __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kernel(const ConvK p) {
+  static_assert(MATH == 0 || MODE == 1, "the split-bf16 product exists for the fast gather only");
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int LDK = KC + 4;  // row pitch of both LDS images (80 B: conflict-free b128 reads and writes)
+  constexpr int NP = MATH == 0 ? 0 : MATH + 1;                  // bf16 parts per value
+  constexpr int LDK = (MATH == 2) ? 28 : KC + 4;  // row pitch (words) of both LDS images (80 / 112 B: conflict-free b128 reads)
   constexpr int RPP = NT / 4;  // pixel rows covered per pass of the A gather
   constexpr int QA = BM / RPP;
   static_assert(BM % RPP == 0, "A tile must divide evenly");
@@ -265,7 +276,14 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
         v.z = (o & 4u) ? fmaf(v.z, s2, h2) : 0.f;
         v.w = (o & 8u) ? fmaf(v.w, s3, h3) : 0.f;
       }
-      *reinterpret_cast<float4*>(Ab + row * LDK + 4 * aq) = v;   // one ds_write_b128, no transposition
+      if constexpr (MATH != 0) {
+        uint2 parts[NP];
+        split_bf16<NP>(v, parts);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(Ab + row * LDK + 8 * q + 2 * aq) = parts[q];
+      } else {
+        *reinterpret_cast<float4*>(Ab + row * LDK + 4 * aq) = v;   // one ds_write_b128, no transposition
+      }
     }
     float* Bb = Bs + buf * BN * LDK;
 #pragma unroll
@@ -273,7 +291,14 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
       const int idx = tid + r * NT;
       if (idx < NQB) {
         const int kq = idx / BN, nn = idx - kq * BN;
-        *reinterpret_cast<float4*>(Bb + nn * LDK + 4 * kq) = rb[set][r];
+        if constexpr (MATH != 0) {
+          uint2 parts[NP];
+          split_bf16<NP>(rb[set][r], parts);
+#pragma unroll
+          for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(Bb + nn * LDK + 8 * q + 2 * kq) = parts[q];
+        } else {
+          *reinterpret_cast<float4*>(Bb + nn * LDK + 4 * kq) = rb[set][r];
+        }
       }
     }
   };
@@ -289,6 +314,29 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
   auto compute = [&](int buf) {
     const float* Ab = As + buf * BM * LDK + (wm * (TM * 32) + li) * LDK + 4 * lh;
     const float* Bb = Bs + buf * BN * LDK + (wn * (TN * 32) + li) * LDK + 4 * lh;
+    if constexpr (MATH != 0) {
+      // lane (row li, k-half lh): 8 consecutive bf16 of part q at byte 32*q + 16*lh of the row
+      bf16x8_t ap[TM][NP], bp[TN][NP];
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          ap[i][q] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Ab + i * 32 * LDK + 8 * q));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bp[j][q] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Bb + j * 32 * LDK + 8 * q));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int o = NP - 1; o >= 0; --o)   // order o = qa + qb, small terms first
+#pragma unroll
+            for (int qa = 0; qa <= o; ++qa)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][qa], bp[j][o - qa], acc[i][j], 0, 0, 0);
+      return;
+    }
 #pragma unroll
     for (int g = 0; g < KC / 8; ++g) {
       float4 av[TM], bv[TN];
@@ -651,17 +699,25 @@ static int pick_splits(int64_t M, int Ntot, int Ktot, ConvCfg cfg) {
   return s < 1 ? 1 : (int)s;
 }
 
-template <int WM, int WN, int TM, int TN, int MODE, bool AFF, int EPI>
+template <int WM, int WN, int TM, int TN, int MODE, bool AFF, int EPI, int MATH = 0>
 static int launch(const ConvK& k, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  const size_t lds = (size_t)(2 * (BM + BN) * (KC + 4)) * sizeof(float);
+  const size_t lds = (size_t)(2 * (BM + BN) * (MATH == 2 ? 28 : KC + 4)) * sizeof(float);
   dim3 grid((unsigned)ceil_div(k.Mtot, BM), (unsigned)ceil_div(k.a.Ntot, BN), (unsigned)k.splits);
-  hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, TM, TN, MODE, AFF, EPI>), grid, dim3(WM * WN * 64), lds, s, k);
+  hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, TM, TN, MODE, AFF, EPI, MATH>), grid, dim3(WM * WN * 64), lds, s, k);
   return check_launch("dfl_conv2d");
 }
 
 template <int WM, int WN, int TM, int TN>
 static int launch_fast(const ConvK& k, bool aff, bool general, hipStream_t s) {
+  if (math_mode() == 1) {
+    if (aff) return general ? launch<WM, WN, TM, TN, 1, true, 1, 1>(k, s) : launch<WM, WN, TM, TN, 1, true, 0, 1>(k, s);
+    return general ? launch<WM, WN, TM, TN, 1, false, 1, 1>(k, s) : launch<WM, WN, TM, TN, 1, false, 0, 1>(k, s);
+  }
+  if (math_mode() == 2) {
+    if (aff) return general ? launch<WM, WN, TM, TN, 1, true, 1, 2>(k, s) : launch<WM, WN, TM, TN, 1, true, 0, 2>(k, s);
+    return general ? launch<WM, WN, TM, TN, 1, false, 1, 2>(k, s) : launch<WM, WN, TM, TN, 1, false, 0, 2>(k, s);
+  }
   if (aff) return general ? launch<WM, WN, TM, TN, 1, true, 1>(k, s) : launch<WM, WN, TM, TN, 1, true, 0>(k, s);
   return general ? launch<WM, WN, TM, TN, 1, false, 1>(k, s) : launch<WM, WN, TM, TN, 1, false, 0>(k, s);
 }

