@@ -406,7 +406,7 @@ int dfl_hard_dice(const unsigned char* est, const unsigned char* gt, int64_t pix
  *   2 "bf16x6"  three parts, six products: as exact as fp32 multiplication (convolutions only).
  * Process-wide; initial value from the environment variable DFL_MATH, else DFL_MATH_DEFAULT.
  * ------------------------------------------------------------------------------------------------------------ */
-#define DFL_MATH_DEFAULT 1
+#define DFL_MATH_DEFAULT 0
 int dfl_get_math_mode(void);
 int dfl_set_math_mode(int32_t mode);
 

@@ -44,3 +44,23 @@ PAPER_CFGS = {
     'paper_mp_l0': (1235, dict(n_classes=7, depth=6, wf=5, batch_norm=True, padding=True, max_pool=True,
                                num_lands=0, do_res=True, block_depth=2)),
 }
+
+
+# ---- product arithmetic of the GEMM kernels (include/dfl_hip.h: dfl_set_math_mode) -------------------------------------
+# 'fp32' is the parity gate: the tolerances written in the tests are for it.  'bf16x3' (split-bf16 products, 2^-16 per
+# product) must keep every FORWARD bar (1e-4) and gets documented, looser bars where fp32 rounding noise is amplified
+# (gradients through BatchNorm cancellations, arg-max at margins below 1e-4, chaotic 30-step trajectories).
+MATH_MODES = ['fp32', 'bf16x3']
+
+
+@pytest.fixture(params=MATH_MODES)
+def math_mode(request):
+    from dfl_amd import _native as nat
+    lib = nat.lib()
+    nat.check(lib.dfl_set_math_mode(MATH_MODES.index(request.param)), 'dfl_set_math_mode')
+    yield request.param
+    nat.check(lib.dfl_set_math_mode(0), 'dfl_set_math_mode')
+
+
+def by_mode(mode, fp32, bf16x3):
+    return fp32 if mode == 'fp32' else bf16x3

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import dfl_amd
-from conftest import PAPER_CFGS
+from conftest import PAPER_CFGS, by_mode
 from oracle import ref_cpu as R
 
 pytestmark = pytest.mark.gpu
@@ -32,7 +32,7 @@ def _pair(cfg, seed, randomize_bn=False):
     return net.to(DEV), onet
 
 
-def test_config3_736_training_step_matches_oracle():
+def test_config3_736_training_step_matches_oracle(math_mode):
     """2x-downsampled 736x736 padded to 768 (configs[3]), paper U-Net, dual head: forward, loss and gradients."""
     _, cfg = PAPER_CFGS['paper_sc_l14']
     net, onet = _pair(cfg, 4242)
@@ -59,7 +59,7 @@ def test_config3_736_training_step_matches_oracle():
     assert abs(loss.item() - oloss.item()) < 2e-5
     # argmax labels: identical wherever the oracle's top-2 margin is not at rounding level
     top2 = oseg.detach().topk(2, dim=1)[0]
-    sure = (top2[:, 0] - top2[:, 1]) > 1e-5
+    sure = (top2[:, 0] - top2[:, 1]) > by_mode(math_mode, 1e-5, 1e-4)
     assert bool((seg.detach().argmax(1).cpu() == oseg.detach().argmax(1))[sure].all())
     worst = 0.0
     for (k, p), (_, q) in zip(net.named_parameters(), onet.named_parameters()):
@@ -69,11 +69,11 @@ def test_config3_736_training_step_matches_oracle():
         ref = q.grad
         rel = float((p.grad.cpu() - ref).norm() / max(float(ref.norm()), 1e-12))
         worst = max(worst, rel)
-        assert rel < 5e-2, (k, rel)             # fp32 vs fp32 with different summation orders over 1.2 M pixels
+        assert rel < by_mode(math_mode, 5e-2, 3e-1), (k, rel)   # fp32 vs fp32 with different summation orders over 1.2 M pixels
     assert worst > 0.0
 
 
-def test_config4_1436_ensemble_inference_matches_oracle():
+def test_config4_1436_ensemble_inference_matches_oracle(math_mode):
     """Full-resolution 1436x1436 padded to 1440 (configs[4]): eval-mode forward of two nets + the ensemble reduction
     of test_ensemble.py (util.py:318-373): mean softmax -> arg-max labels, per-net min-max normalised heat maps."""
     _, cfg = PAPER_CFGS['paper_sc_l14']
@@ -99,7 +99,7 @@ def test_config4_1436_ensemble_inference_matches_oracle():
     olabels, oheats, oavg = R.ensemble_reduce([o[0] for o in oouts], [o[1] for o in oouts], (H, H))
     assert labels.shape == (H, H) and heats.shape == (14, H, H)
     top2 = oavg.topk(2, dim=1)[0]
-    sure = ((top2[:, 0] - top2[:, 1]) > 1e-5)[0]
+    sure = ((top2[:, 0] - top2[:, 1]) > by_mode(math_mode, 1e-5, 1e-4))[0]
     assert bool((labels.cpu() == olabels[0])[sure].all())
     assert float((labels.cpu() != olabels[0]).float().mean()) < 1e-4
     np.testing.assert_allclose(heats.cpu().numpy(), oheats[0].numpy(), rtol=1e-3, atol=1e-5)

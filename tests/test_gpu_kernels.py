@@ -13,6 +13,22 @@ from dfl_amd import _native as nat
 from oracle import ref_cpu as R
 
 pytestmark = pytest.mark.gpu
+
+TOLK = [1.0]
+
+
+@pytest.fixture(autouse=True)
+def _both_math_modes(math_mode):
+    """Every kernel test runs with fp32 products (tolerances as written) and with split-bf16 products (x8: 2^-16 per
+    product instead of 2^-24; the non-GEMM kernels are unaffected by the mode)."""
+    TOLK[0] = 1.0 if math_mode == 'fp32' else 8.0
+    yield
+    TOLK[0] = 1.0
+
+
+def aclose(actual, desired, rtol=1e-7, atol=0.0, err_msg=''):
+    np.testing.assert_allclose(actual, desired, rtol=rtol * TOLK[0], atol=atol * TOLK[0], err_msg=err_msg)
+
 DEV = 'cuda'
 
 
@@ -161,7 +177,7 @@ def test_conv_fwd_plain(case):
     ref = F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=pad)
     Ho, Wo = ref.shape[2], ref.shape[3]
     y = conv_call(x, wp, Cout, K, K, stride, pad, Ho, Wo, bias=b)
-    np.testing.assert_allclose(nchw(y).numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
+    aclose(nchw(y).numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
 
 
 def test_conv_fwd_fused_epilogue_and_prologue():
@@ -176,9 +192,9 @@ def test_conv_fwd_fused_epilogue_and_prologue():
     xa = x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
     ref = F.relu(F.conv2d(xa, w.double(), b.double(), padding=1))
     y, st = conv_call(x, wp, Cout, 3, 3, 1, 1, H, W, bias=b, in_aff=(sc, sh), relu=1, stats=True)
-    np.testing.assert_allclose(nchw(y).numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
-    np.testing.assert_allclose(st[0].numpy(), ref.sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
-    np.testing.assert_allclose(st[1].numpy(), (ref * ref).sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
+    aclose(nchw(y).numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
+    aclose(st[0].numpy(), ref.sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
+    aclose(st[1].numpy(), (ref * ref).sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
     # residual: y = conv1x1(x) + bias + (r*s2 + t2), into a wider buffer (ldy > Cout), input with ldx > Cin
     w1 = torch.randn(Cout, Cin, 1, 1, generator=g) / 4
     w1p = pack(w1, 1)
@@ -186,14 +202,14 @@ def test_conv_fwd_fused_epilogue_and_prologue():
     s2, t2 = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
     ref2 = F.conv2d(x.double(), w1.double(), b.double()) + r.double() * s2.double().view(1, -1, 1, 1) + t2.double().view(1, -1, 1, 1)
     y2 = conv_call(x, w1p, Cout, 1, 1, 1, 0, H, W, bias=b, add=r, add_aff=(s2, t2), ldy=2 * Cout, ldx_pad=8)
-    np.testing.assert_allclose(nchw(y2).numpy(), ref2.numpy(), rtol=2e-5, atol=2e-5)
+    aclose(nchw(y2).numpy(), ref2.numpy(), rtol=2e-5, atol=2e-5)
     # accumulate + statistics against another tensor (backward use)
     y0 = torch.randn(N, Cout, H, W, generator=g)
     other = torch.randn(N, Cout, H, W, generator=g)
     ref3 = F.conv2d(x.double(), w.double(), None, padding=1) + y0.double()
     y3, st3 = conv_call(x, wp, Cout, 3, 3, 1, 1, H, W, y_init=y0, accumulate=1, stats=True, stat_other=other)
-    np.testing.assert_allclose(nchw(y3).numpy(), ref3.numpy(), rtol=2e-5, atol=2e-5)
-    np.testing.assert_allclose(st3[1].numpy(), (ref3 * other.double()).sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
+    aclose(nchw(y3).numpy(), ref3.numpy(), rtol=2e-5, atol=2e-5)
+    aclose(st3[1].numpy(), (ref3 * other.double()).sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
 
 
 def test_conv_split_k():
@@ -209,9 +225,9 @@ def test_conv_split_k():
     ref = F.relu(F.conv2d(xa, w.double(), b.double(), padding=1))
     for fs in (None, 2, 7):
         y, st = conv_call(x, wp, Cout, 3, 3, 1, 1, H, W, bias=b, in_aff=(sc, sh), relu=1, stats=True, force_splits=fs)
-        np.testing.assert_allclose(nchw(y).numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
-        np.testing.assert_allclose(st[0].numpy(), ref.sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
-        np.testing.assert_allclose(st[1].numpy(), (ref * ref).sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
+        aclose(nchw(y).numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
+        aclose(st[0].numpy(), ref.sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
+        aclose(st[1].numpy(), (ref * ref).sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
     # residual-add + accumulate + statistics against another tensor through the finish kernel
     r = torch.randn(N, Cout, H, W, generator=g)
     s2, t2 = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
@@ -221,15 +237,15 @@ def test_conv_split_k():
         + t2.double().view(1, -1, 1, 1) + y0.double()
     y2, st2 = conv_call(x, wp, Cout, 3, 3, 1, 1, H, W, bias=b, add=r, add_aff=(s2, t2), y_init=y0, accumulate=1, stats=True,
                         stat_other=other, force_splits=4)
-    np.testing.assert_allclose(nchw(y2).numpy(), ref2.numpy(), rtol=2e-5, atol=2e-5)
-    np.testing.assert_allclose(st2[1].numpy(), (ref2 * other.double()).sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
+    aclose(nchw(y2).numpy(), ref2.numpy(), rtol=2e-5, atol=2e-5)
+    aclose(st2[1].numpy(), (ref2 * other.double()).sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
     # transposed conv through split-K
     wt = torch.randn(Cin, 64, 2, 2, generator=g) / 16
     bt = torch.randn(64, generator=g)
     wtp = pack(wt, 3)
     reft = F.conv_transpose2d(x.double(), wt.double(), bt.double(), stride=2)
     yt = conv_call(x, wtp, 4 * 64, 1, 1, 1, 0, 2 * H, 2 * W, bias=bt, scatter=1, force_splits=2)
-    np.testing.assert_allclose(nchw(yt).numpy(), reft.numpy(), rtol=2e-5, atol=2e-5)
+    aclose(nchw(yt).numpy(), reft.numpy(), rtol=2e-5, atol=2e-5)
 
 
 @pytest.mark.parametrize('shape', [(2, 16, 8, 5, 7), (1, 64, 32, 6, 6), (2, 8, 4, 3, 3)])
@@ -242,7 +258,7 @@ def test_conv_transpose_scatter(shape):
     wp = pack(w, 3)
     ref = F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2)
     y = conv_call(x, wp, 4 * Cout, 1, 1, 1, 0, 2 * H, 2 * W, bias=b, scatter=1, ldy=2 * Cout)
-    np.testing.assert_allclose(nchw(y).numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
+    aclose(nchw(y).numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
 
 
 def test_dgrad_forms():
@@ -257,7 +273,7 @@ def test_dgrad_forms():
         y.backward(dy)
         wd = pack(w.float(), 2, flip=1)
         dx = conv_call(dy.float(), wd, Ci, 3, 3, 1, 2 - pad, H, W)
-        np.testing.assert_allclose(nchw(dx).numpy(), x.grad.numpy(), rtol=2e-5, atol=2e-5)
+        aclose(nchw(dx).numpy(), x.grad.numpy(), rtol=2e-5, atol=2e-5)
     # conv2x2 stride 2 (odd input: last row/col get no gradient; accumulate keeps what was there)
     x = torch.randn(N, Ci, H, W, generator=g, dtype=torch.float64, requires_grad=True)
     w = torch.randn(Ci, Ci, 2, 2, generator=g, dtype=torch.float64) / 3
@@ -267,7 +283,7 @@ def test_dgrad_forms():
     wd = pack(w.float(), 3)
     base = torch.randn(N, Ci, H, W, generator=g)
     dx = conv_call(dy.float(), wd, 4 * Ci, 1, 1, 1, 0, H, W, scatter=1, y_init=base, accumulate=1)
-    np.testing.assert_allclose(nchw(dx).numpy(), (x.grad + base.double()).numpy(), rtol=2e-5, atol=2e-5)
+    aclose(nchw(dx).numpy(), (x.grad + base.double()).numpy(), rtol=2e-5, atol=2e-5)
     # convT
     x = torch.randn(N, Ci, 4, 5, generator=g, dtype=torch.float64, requires_grad=True)
     w = torch.randn(Ci, Co, 2, 2, generator=g, dtype=torch.float64) / 3
@@ -276,7 +292,7 @@ def test_dgrad_forms():
     y.backward(dy)
     wd = pack(w.float(), 1)
     dx = conv_call(dy.float(), wd, Ci, 2, 2, 2, 0, 4, 5)
-    np.testing.assert_allclose(nchw(dx).numpy(), x.grad.numpy(), rtol=2e-5, atol=2e-5)
+    aclose(nchw(dx).numpy(), x.grad.numpy(), rtol=2e-5, atol=2e-5)
 
 
 def wgrad_call(gx, d, KH, KW, stride, pad, Hout, Wout, in_aff=None, force_splits=None):
@@ -333,7 +349,7 @@ def test_wgrad(case):
     for fs in (None, 1, 3):
         dw, s = wgrad_call(x.float(), dy.float(), K, K, stride, pad, y.shape[2], y.shape[3], force_splits=fs)
         scale = w.grad.abs().max().item()
-        np.testing.assert_allclose(dw.numpy(), w.grad.numpy(), rtol=1e-4, atol=2e-5 * max(scale, 1.0))
+        aclose(dw.numpy(), w.grad.numpy(), rtol=1e-4, atol=2e-5 * max(scale, 1.0))
 
 
 def test_wgrad_affine_and_convT():
@@ -347,7 +363,7 @@ def test_wgrad_affine_and_convT():
     dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
     y.backward(dy)
     dw, _ = wgrad_call(r.float(), dy.float(), 3, 3, 1, 1, H, W, in_aff=(sc.float(), sh.float()))
-    np.testing.assert_allclose(dw.numpy(), w.grad.numpy(), rtol=1e-4, atol=1e-4)
+    aclose(dw.numpy(), w.grad.numpy(), rtol=1e-4, atol=1e-4)
     # ConvTranspose2d weight gradient: gathered = dy (stride 2), dense = x  -> [Cin][Cout][2][2]
     x = torch.randn(N, Ci, 5, 6, generator=g, dtype=torch.float64)
     wt = torch.zeros(Ci, Co, 2, 2, dtype=torch.float64, requires_grad=True)
@@ -355,7 +371,7 @@ def test_wgrad_affine_and_convT():
     dyt = torch.randn(yt.shape, generator=g, dtype=torch.float64)
     yt.backward(dyt)
     dwt, _ = wgrad_call(dyt.float(), x.float(), 2, 2, 2, 0, 5, 6)
-    np.testing.assert_allclose(dwt.numpy(), wt.grad.numpy(), rtol=1e-4, atol=1e-4)
+    aclose(dwt.numpy(), wt.grad.numpy(), rtol=1e-4, atol=1e-4)
 
 
 @pytest.mark.parametrize('C_,M', [(32, 5000), (8, 777), (1024, 576), (4, 33)])
@@ -384,16 +400,16 @@ def test_batchnorm_forward_backward(C_, M):
     rm64, rv64 = rm.double().clone(), rv.double().clone()
     z = F.batch_norm(r64, rm64, rv64, gamma.double(), beta.double(), training=True, momentum=0.1, eps=1e-5)
     z_gpu = (rd * scale + shift).cpu()
-    np.testing.assert_allclose(z_gpu.numpy(), z[0, :, :, 0].t().detach().numpy(), rtol=1e-4, atol=1e-4)
-    np.testing.assert_allclose(dv['rm'].cpu().numpy(), rm64.numpy(), rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(dv['rv'].cpu().numpy(), rv64.numpy(), rtol=1e-5, atol=1e-6)
+    aclose(z_gpu.numpy(), z[0, :, :, 0].t().detach().numpy(), rtol=1e-4, atol=1e-4)
+    aclose(dv['rm'].cpu().numpy(), rm64.numpy(), rtol=1e-5, atol=1e-6)
+    aclose(dv['rv'].cpu().numpy(), rv64.numpy(), rtol=1e-5, atol=1e-6)
     assert int(dv['nbt'].cpu()) == 8
     # eval prepare
     es, et = torch.empty(C_, device=DEV), torch.empty(C_, device=DEV)
     nat.check(lib.dfl_bn_eval_prepare(dv['gamma'].data_ptr(), dv['beta'].data_ptr(), dv['rm'].data_ptr(), dv['rv'].data_ptr(),
                                       es.data_ptr(), et.data_ptr(), C_, 1e-5, stream()))
     ze = F.batch_norm(r.double().t().reshape(1, C_, M, 1), rm64, rv64, gamma.double(), beta.double(), training=False, eps=1e-5)
-    np.testing.assert_allclose((rd * es + et).cpu().numpy(), ze[0, :, :, 0].t().numpy(), rtol=1e-4, atol=1e-4)
+    aclose((rd * es + et).cpu().numpy(), ze[0, :, :, 0].t().numpy(), rtol=1e-4, atol=1e-4)
     # backward through BN then ReLU (the ReLU that produced r): d pre-activation
     dz = torch.randn(M, C_, generator=g)
     pre = r64  # treat r as relu(pre) with pre = r where r > 0; mask = r > 0
@@ -417,10 +433,10 @@ def test_batchnorm_forward_backward(C_, M):
     torch.cuda.synchronize()
     # gamma/beta grads from torch need parameters with grad: recompute analytically in fp64
     xhat = (r.double() - r.double().mean(0)) / torch.sqrt(r.double().var(0, unbiased=False) + 1e-5)
-    np.testing.assert_allclose(dgamma.cpu().numpy(), (dz.double() * xhat).sum(0).numpy(), rtol=1e-3, atol=1e-3)
-    np.testing.assert_allclose(dbeta.cpu().numpy(), dz.double().sum(0).numpy(), rtol=1e-3, atol=1e-3)
-    np.testing.assert_allclose(dpre.cpu().numpy(), dr_ref.numpy(), rtol=1e-3, atol=2e-5)
-    np.testing.assert_allclose(bsum.cpu().numpy(), dr_ref.sum(0).numpy(), rtol=1e-3, atol=1e-3)
+    aclose(dgamma.cpu().numpy(), (dz.double() * xhat).sum(0).numpy(), rtol=1e-3, atol=1e-3)
+    aclose(dbeta.cpu().numpy(), dz.double().sum(0).numpy(), rtol=1e-3, atol=1e-3)
+    aclose(dpre.cpu().numpy(), dr_ref.numpy(), rtol=1e-3, atol=2e-5)
+    aclose(bsum.cpu().numpy(), dr_ref.sum(0).numpy(), rtol=1e-3, atol=1e-3)
 
 
 @pytest.mark.parametrize('shape', [(2, 8, 10, 12), (1, 32, 7, 9), (2, 3, 6, 6)])
@@ -444,7 +460,7 @@ def test_maxpool(shape):
                                                               W=W, C=C_, ldx=C_, ldy=C_, lddx=C_), stream())
     torch.cuda.synchronize()
     assert torch.equal(nchw(yd.cpu()), y.detach())
-    np.testing.assert_allclose(nchw(dxd.cpu() - base).numpy(), x.grad.numpy(), rtol=1e-6, atol=1e-6)
+    aclose(nchw(dxd.cpu() - base).numpy(), x.grad.numpy(), rtol=1e-6, atol=1e-6)
 
 
 def test_affine_copy_window():
@@ -460,7 +476,7 @@ def test_affine_copy_window():
     nat.check(lib.dfl_affine_copy(C.addressof(a), stream()))
     torch.cuda.synchronize()
     ref = x[:, 2:7, 3:9, :] * sc + sh
-    np.testing.assert_allclose(yd.cpu()[..., C_:].numpy(), ref.numpy(), rtol=1e-6, atol=1e-6)
+    aclose(yd.cpu()[..., C_:].numpy(), ref.numpy(), rtol=1e-6, atol=1e-6)
     assert float(yd.cpu()[..., :C_].abs().max()) == 0.0
 
 
@@ -500,9 +516,9 @@ def test_heads_forward_backward(NC, L, two, softmax, F_):
         x=xd.data_ptr(), w_seg=wsd.data_ptr(), w_l1=nat.ptr(w1d), w_l2=nat.ptr(w2d), seg=segd.data_ptr(), heat=nat.ptr(heatd),
         N=N, H=H, W=W, F=F_, ldx=F_, NC=NC, NM=NM, L=L, softmax=int(softmax)), stream())
     torch.cuda.synchronize()
-    np.testing.assert_allclose(segd.cpu().numpy(), seg.detach().numpy(), rtol=1e-5, atol=1e-6)
+    aclose(segd.cpu().numpy(), seg.detach().numpy(), rtol=1e-5, atol=1e-6)
     if L > 0:
-        np.testing.assert_allclose(heatd.cpu().numpy(), heat.detach().numpy(), rtol=1e-5, atol=1e-5)
+        aclose(heatd.cpu().numpy(), heat.detach().numpy(), rtol=1e-5, atol=1e-5)
     # backward
     sld = lib.dfl_head_scratch_ld(F_)
     scratch = torch.full((N * H * W, sld), float('nan'), device=DEV)
@@ -514,18 +530,18 @@ def test_heads_forward_backward(NC, L, two, softmax, F_):
         w_l1=nat.ptr(w1d), w_l2=nat.ptr(w2d), dx=dxd.data_ptr(), scratch=scratch.data_ptr(), N=N, H=H, W=W, F=F_, ldx=F_,
         lddx=F_, NC=NC, NM=NM, L=L, softmax=int(softmax), scratch_ld=sld), stream())
     torch.cuda.synchronize()
-    np.testing.assert_allclose(nchw(dxd.cpu()).numpy(), x.grad.numpy(), rtol=1e-4, atol=1e-5)
+    aclose(nchw(dxd.cpu()).numpy(), x.grad.numpy(), rtol=1e-4, atol=1e-5)
     sc = scratch.cpu().double()
     assert torch.isfinite(sc).all()
     off = [lib.dfl_head_scratch_off(F_, k) for k in range(5)]
     dwseg = sc[:, off[1]:off[1] + NC].t() @ sc[:, off[0]:off[0] + F_]
-    np.testing.assert_allclose(dwseg.numpy(), wseg.grad[:, :, 0, 0].numpy(), rtol=1e-4, atol=1e-4)
+    aclose(dwseg.numpy(), wseg.grad[:, :, 0, 0].numpy(), rtol=1e-4, atol=1e-4)
     if L > 0:
         dw1 = sc[:, off[2]:off[2] + NM].t() @ sc[:, off[0]:off[0] + F_ + NC]
-        np.testing.assert_allclose(dw1.numpy(), w1.grad[:, :, 0, 0].numpy(), rtol=1e-4, atol=1e-4)
+        aclose(dw1.numpy(), w1.grad[:, :, 0, 0].numpy(), rtol=1e-4, atol=1e-4)
         if two:
             dw2 = sc[:, off[4]:off[4] + L].t() @ sc[:, off[3]:off[3] + NM]
-            np.testing.assert_allclose(dw2.numpy(), w2.grad[:, :, 0, 0].numpy(), rtol=1e-4, atol=1e-4)
+            aclose(dw2.numpy(), w2.grad[:, :, 0, 0].numpy(), rtol=1e-4, atol=1e-4)
 
 
 def test_losses_against_golden_and_oracle(golden):
@@ -537,19 +553,19 @@ def test_losses_against_golden_and_oracle(golden):
         l = dfl_amd.DiceLoss2D(skip_bg=sb)(s, t)
         l.backward()
         assert abs(l.item() - float(g['dice_sb%d' % int(sb)])) < 2e-6
-        np.testing.assert_allclose(s.grad.cpu().numpy(), g['dice_sb%d_grad' % int(sb)], rtol=1e-4, atol=1e-8)
+        aclose(s.grad.cpu().numpy(), g['dice_sb%d_grad' % int(sb)], rtol=1e-4, atol=1e-8)
     assert abs(dfl_amd.DiceLoss2D(skip_bg=False)(t, t).item() - float(g['dice_perfect'])) < 2e-6
     X = torch.from_numpy(g['ncc_x']).float().to(DEV)
     Y = torch.from_numpy(g['ncc_y']).float().to(DEV)
-    np.testing.assert_allclose(dfl_amd.ncc_2d(X, Y).cpu().numpy(), g['ncc'], rtol=1e-4, atol=1e-6)
-    np.testing.assert_allclose(dfl_amd.ncc_2d(Y, Y).cpu().numpy(), g['ncc_self'], rtol=1e-5)
+    aclose(dfl_amd.ncc_2d(X, Y).cpu().numpy(), g['ncc'], rtol=1e-4, atol=1e-6)
+    aclose(dfl_amd.ncc_2d(Y, Y).cpu().numpy(), g['ncc_self'], rtol=1e-5)
     X.requires_grad_(True)
     s.grad = None
     l = dfl_amd.DiceAndHeatMapLoss2D(skip_bg=False, heatmap_wgt=0.3)((s, X), (t, Y))
     l.backward()
     assert abs(l.item() - float(g['dh_loss'])) < 2e-6
-    np.testing.assert_allclose(s.grad.cpu().numpy(), g['dh_gseg'], rtol=1e-4, atol=1e-8)
-    np.testing.assert_allclose(X.grad.cpu().numpy(), g['dh_gheat'], rtol=2e-4, atol=1e-8)
+    aclose(s.grad.cpu().numpy(), g['dh_gseg'], rtol=1e-4, atol=1e-8)
+    aclose(X.grad.cpu().numpy(), g['dh_gheat'], rtol=2e-4, atol=1e-8)
 
 
 def test_loss_on_cropped_views_full_size():
@@ -569,8 +585,8 @@ def test_loss_on_cropped_views_full_size():
         (dfl_amd.center_crop(sd, tseg.shape), dfl_amd.center_crop(hd, theat.shape)), (tseg.to(DEV), theat.to(DEV)))
     ld.backward()
     assert abs(ld.item() - lr.item()) < 2e-6
-    np.testing.assert_allclose(sd.grad.cpu().numpy(), sr.grad.numpy(), rtol=1e-3, atol=1e-10)
-    np.testing.assert_allclose(hd.grad.cpu().numpy(), hr.grad.numpy(), rtol=1e-3, atol=1e-9)
+    aclose(sd.grad.cpu().numpy(), sr.grad.numpy(), rtol=1e-3, atol=1e-10)
+    aclose(hd.grad.cpu().numpy(), hr.grad.numpy(), rtol=1e-3, atol=1e-9)
 
 
 def test_sgd_step():
@@ -588,7 +604,7 @@ def test_sgd_step():
         grd = gr.to(DEV)
         nat.check(lib.dfl_sgd_step(pd.data_ptr(), grd.data_ptr(), buf.data_ptr(), n, 0.1, 0.9, 1e-4, 1.0, 1, int(step == 0), stream()))
     torch.cuda.synchronize()
-    np.testing.assert_allclose(pd.cpu().numpy(), pr.detach().numpy(), rtol=1e-5, atol=1e-6)
+    aclose(pd.cpu().numpy(), pr.detach().numpy(), rtol=1e-5, atol=1e-6)
 
 
 def test_reduce_batch():
@@ -614,4 +630,4 @@ def test_reduce_batch():
     torch.cuda.synchronize()
     for (n, stride, count, T), src, dst in zip(shapes, srcs, dsts):
         want = src.cpu().double().view(count, stride)[:, :n].sum(0).view(T, n // T).t().reshape(-1)
-        np.testing.assert_allclose(dst.cpu().numpy(), want.numpy(), rtol=2e-6, atol=1e-5)
+        aclose(dst.cpu().numpy(), want.numpy(), rtol=2e-6, atol=1e-5)

@@ -11,7 +11,7 @@ import torch
 
 import dfl_amd
 from dfl_amd import _native as nat
-from conftest import TINY_CFGS, PAPER_CFGS, load_golden
+from conftest import TINY_CFGS, PAPER_CFGS, load_golden, by_mode
 from oracle import ref_cpu as R
 
 pytestmark = pytest.mark.gpu
@@ -37,7 +37,11 @@ def rel_close(actual, ref, rtol, what):
 
 
 @pytest.mark.parametrize('name', sorted(TINY_CFGS))
-def test_tiny_golden(name):
+def test_tiny_golden(name, math_mode):
+    # forward bars (1e-4) are the same for both product modes; gradient bars per tensor: 2e-3 of the tensor's scale with
+    # fp32 products, 1e-1 with split-bf16 products (their 2e-5 forward noise is amplified by the BatchNorm cancellations:
+    # the worst tensors are nearly-cancelling sums) -- plus the whole gradient vector within 2e-3 / 5e-2 (relative L2)
+    gtol = by_mode(math_mode, 2e-3, 1e-1)
     cfg = TINY_CFGS[name]
     g = load_golden(name)
     net = load_net(g, cfg)
@@ -67,7 +71,11 @@ def test_tiny_golden(name):
                 assert p.grad is None, k
                 continue
             assert p.grad is not None, k
-            rel_close(p.grad.cpu().numpy(), ref, 2e-3, 'grad ' + k)
+            rel_close(p.grad.cpu().numpy(), ref, gtol, 'grad ' + k)
+        num = sum(float(((p.grad.cpu().double() - _t(g['grad/' + k]).double()) ** 2).sum()) for k, p in net.named_parameters()
+                  if g['grad/' + k].size)
+        den = sum(float((_t(g['grad/' + k]).double() ** 2).sum()) for k, p in net.named_parameters() if g['grad/' + k].size)
+        assert (num / den) ** 0.5 <= by_mode(math_mode, 2e-3, 5e-2), 'whole-gradient relative L2 error %.3e' % (num / den) ** 0.5
     elif cfg['batch_norm'] is False and cfg['do_res']:
         # the reference cannot back-propagate this configuration (in-place add on a ReLU output); ours can: compare
         # with the oracle, which uses the out-of-place form
@@ -81,7 +89,7 @@ def test_tiny_golden(name):
         ol.backward()
         for (k, p), (_, q) in zip(net.named_parameters(), onet.named_parameters()):
             if q.grad is not None:
-                rel_close(p.grad.cpu().numpy(), q.grad.numpy(), 2e-3, 'grad ' + k)
+                rel_close(p.grad.cpu().numpy(), q.grad.numpy(), gtol, 'grad ' + k)
     for k in [k for k in g if k.startswith('sd1/')]:
         np.testing.assert_allclose(net.state_dict()[k[4:]].cpu().numpy(), g[k], rtol=1e-4, atol=1e-6, err_msg=k)
     net.eval()
@@ -94,7 +102,7 @@ def test_tiny_golden(name):
 
 
 @pytest.mark.parametrize('name', sorted(PAPER_CFGS))
-def test_paper_golden(name):
+def test_paper_golden(name, math_mode):
     """Paper preset (depth 6, wf 5): seeded init reproduces the reference bit for bit, forward within 1e-4 of the
     reference's fp32 run and of its fp64 run, labels identical outside the tiny-margin pixels, grad norms vs fp64."""
     seed, cfg = PAPER_CFGS[name]
@@ -131,27 +139,35 @@ def test_paper_golden(name):
     assert np.array_equal(am[~close], g['argmax64'][~close])
     loss.backward()
     names = list(g['param_names'])
+    # the whole gradient vector: its norm against the fp64 reference's (what an SGD step sees).  Per-tensor bars for
+    # split-bf16 products are wide: at batch 2 with random weights some encoder gradients amplify forward rounding noise
+    # by ~2e4 (fp32's 1e-6 -> 2 %, bf16x3's 2e-5 -> 40 % on down_path.4.block.0.weight of the max-pool preset; both
+    # kernels are accurate to 2e-7 / 4e-6 on that very layer, tools/exp/mode_kernel_check.py)
+    tot = sum(float(p.grad.double().norm()) ** 2 for p in net.parameters() if p.grad is not None) ** 0.5
+    ref_tot = sum(float(v) ** 2 for v in g['gradnorm64'] if v >= 0) ** 0.5
+    assert abs(tot - ref_tot) <= by_mode(math_mode, 5e-3, 5e-2) * ref_tot, 'gradient norm %.6e vs fp64 %.6e' % (tot, ref_tot)
     for k, p in net.named_parameters():
         ref = float(g['gradnorm64'][names.index(k)])
         if ref < 0:
             assert p.grad is None, k
             continue
         got = p.grad.double().norm().item()
-        assert abs(got - ref) <= 2e-2 * max(ref, 1e-7), '%s: grad norm %.6e vs fp64 reference %.6e' % (k, got, ref)
+        assert abs(got - ref) <= by_mode(math_mode, 2e-2, 5e-1) * max(ref, 1e-7), '%s: grad norm %.6e vs fp64 reference %.6e' % (k, got, ref)
         gk = 'g64/' + k
-        if gk in g:
+        if gk in g and (math_mode == 'fp32' or not k.endswith('.bias')):   # (pre-BN bias gradients are pure rounding noise)
             # element-wise check on the small tensors: relative L2 (the measure BASELINE.md quotes for the reference's
             # own fp32-vs-fp64 gap: 3e-3 median, 7e-3 worst) plus a looser max-abs bound; the pre-BatchNorm conv
             # biases are sums over ~10^5 pixels that cancel to ~1e-5, i.e. mostly rounding noise of the fp32 forward
             ref_g = g[gk]
             diff = p.grad.cpu().numpy().astype(np.float64) - ref_g
             l2 = float(np.linalg.norm(diff) / max(np.linalg.norm(ref_g), 1e-12))
-            assert l2 <= 2e-2, '%s: relative L2 error %.3e' % (k, l2)
-            rel_close(p.grad.cpu().numpy(), ref_g, 8e-2, 'grad ' + k)
+            # (split-bf16 products: the same cancellations amplify 2e-5 instead of 1e-6 of forward noise)
+            assert l2 <= by_mode(math_mode, 2e-2, 5e-1), '%s: relative L2 error %.3e' % (k, l2)
+            rel_close(p.grad.cpu().numpy(), ref_g, by_mode(math_mode, 8e-2, 6e-1), 'grad ' + k)
 
 
 @pytest.mark.parametrize('optimizer', ['torch', 'dfl'])
-def test_training_trajectory_matches_reference(optimizer):
+def test_training_trajectory_matches_reference(optimizer, math_mode):
     """30 SGD steps wired as train.py:405-430 on the toy-ellipses set: per-step loss vs the reference's run, with
     torch.optim.SGD and with the one-launch dfl_amd.SGD."""
     g = load_golden('trajectory')
@@ -178,14 +194,16 @@ def test_training_trajectory_matches_reference(optimizer):
         loss.backward()
         opt.step()
         losses.append(loss.item())
-    np.testing.assert_allclose(losses[:10], g['losses'][:10], rtol=0, atol=5e-5)
-    np.testing.assert_allclose(losses, g['losses'], rtol=0, atol=5e-3)
+    # a 30-step run amplifies rounding differences step by step: the bars are per mode
+    np.testing.assert_allclose(losses[:10], g['losses'][:10], rtol=0, atol=by_mode(math_mode, 5e-5, 3e-4))
+    np.testing.assert_allclose(losses, g['losses'], rtol=0, atol=by_mode(math_mode, 5e-3, 2e-2))
     net.eval()
     with torch.no_grad():
         out = net(P)
     labels = torch.max(dfl_amd.center_crop(out[0], S.shape), dim=1)[1].cpu()
     d = R.hard_dice(labels, segs.long(), 7)
-    np.testing.assert_allclose(d, g['hard_dice'], atol=0.02)
+    np.testing.assert_allclose(d, g['hard_dice'], atol=by_mode(math_mode, 0.02, 0.06))
+    assert abs(float(np.mean(d)) - float(np.mean(g['hard_dice']))) < 0.01
 
 
 class _FakeH5DS:
