@@ -123,6 +123,7 @@ def main():
                     help='product arithmetic of the conv / weight-gradient GEMMs: bf16x3 = fp32 values split into hi+lo '
                          'bf16, 3 bf16 MFMA products, fp32 accumulate (BASELINE configs[1] is a bf16 configuration; this is '
                          'tighter: 2^-16 per product, forward within the 1e-4 parity bar); fp32 = fp32 MFMA (the parity gate)')
+    ap.add_argument('--no-fp32-reference', action='store_true', help='skip the extra fp32-product timing (profiling runs)')
     ap.add_argument('--no-overlap', action='store_true', help='all-reduce after backward instead of overlapped buckets')
     args = ap.parse_args()
 
@@ -228,7 +229,7 @@ def main():
         extra['kernels'] = {k: {'ms': round(v[0], 3), 'tflops': round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[0] > 0 and v[1] > 0 else None,
                                 'launches': v[2]} for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0])}
 
-    if rank == 0 and world == 1 and not args.no_profile and args.math != 'fp32':
+    if rank == 0 and world == 1 and not args.no_profile and args.math != 'fp32' and not args.no_fp32_reference:
         # the same step with fp32 MFMA products (the mode every parity test is written for), for reference
         nat.check(lib.dfl_set_math_mode(0), 'dfl_set_math_mode')
         for _ in range(3):
