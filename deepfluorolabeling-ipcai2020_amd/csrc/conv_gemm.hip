@@ -676,7 +676,7 @@ static void cfg_tile(ConvCfg c, int* bm, int* bn) {
 // Largest tile that still gives the 256 CUs a few workgroups each.  Problems too small for that keep the 64x64 tile
 // and are cut along K instead (split-K, see pick_splits): deep U-Net levels are M = 576..2304 pixels x K = 4608..9216.
 static ConvCfg pick_cfg(int64_t M, int Ntot, bool fast = true) {
-  const int64_t want = 1024;
+  const int64_t want = 1024;   // (512 / 256 / 128 measured with split-bf16 products as well: 1024 stays best)
   if (!fast) return CFG_64x64;   // the general-gather variant exists for one tile only
   if (Ntot <= 32) {
     if (ceil_div(M, 256) >= want / 2) return CFG_256x32;

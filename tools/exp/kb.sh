@@ -1,1 +1,2 @@
-for m in fp32 bf16x3; do export DFL_MATH=$m; echo "MATH $m"; for s in "16 192 192 32 32 3" "16 96 96 64 64 3" "16 96 96 32 64 3" "16 48 48 128 128 3" "16 24 24 256 256 3" "16 12 12 512 512 3" "16 192 192 32 64 2 2" "16 6 6 1024 1024 3"; do python tools/kbench.py wgrad $s; done; done
+export DFL_MATH=bf16x3
+for w in 1024 512 256 128; do export DFL_EXP_WANT=$w; echo "WANT $w"; for s in "16 48 48 128 128 3" "16 96 96 64 64 3" "16 24 24 256 256 3" "16 12 12 512 512 3" "16 48 48 256 128 3" "16 96 96 128 64 3"; do python tools/kbench.py conv $s 1 50 sabr; done; python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-profile | cut -c150-260; done
