@@ -20,19 +20,19 @@ class ConvArgs(C.Structure):
                 ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32),
                 ('Hout', i32), ('Wout', i32), ('Ntot', i32), ('ldy', i32),
                 ('ldadd', i32), ('ldso', i32), ('relu', i32), ('accumulate', i32), ('scatter2x2', i32),
-                ('splits', i32)]
+                ('splits', i32), ('w_split', i32), ('x_split', i32)]
 
 
 class WgradArgs(C.Structure):
     _fields_ = [('g', fp), ('d', fp), ('in_scale', fp), ('in_shift', fp), ('dw', fp), ('partial', fp),
                 ('N', i32), ('Hin', i32), ('Win', i32), ('Cg', i32), ('ldg', i32),
                 ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32),
-                ('Hout', i32), ('Wout', i32), ('Cm', i32), ('ldd', i32), ('splits', i32), ('reserved', i32)]
+                ('Hout', i32), ('Wout', i32), ('Cm', i32), ('ldd', i32), ('splits', i32), ('d_split', i32)]
 
 
 class PackJob(C.Structure):
     _fields_ = [('src', fp), ('dst', fp), ('A', i32), ('B', i32), ('C', i32), ('kind', i32), ('flip', i32),
-                ('reserved', i32)]
+                ('split', i32)]
 
 
 class BnFinalizeArgs(C.Structure):
@@ -53,7 +53,7 @@ class BnBwdFinalizeArgs(C.Structure):
 
 class BnReluBwdArgs(C.Structure):
     _fields_ = [('dy', fp), ('r', fp), ('coef', fp), ('dpre', fp), ('partials', fp), ('M', i64), ('C', i32),
-                ('lddy', i32), ('ldr', i32), ('ldo', i32), ('nblocks', i32)]
+                ('lddy', i32), ('ldr', i32), ('ldo', i32), ('nblocks', i32), ('split_out', i32)]
 
 
 class AffineCopyArgs(C.Structure):

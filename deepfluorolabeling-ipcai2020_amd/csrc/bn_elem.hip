@@ -226,7 +226,13 @@ __global__ void __launch_bounds__(256) bn_relu_bwd_kernel(const dfl_bn_relu_bwd_
         o.y = rv.y > 0.f ? fmaf(cA[1], dy.y, fmaf(cB[1], rv.y, cC[1])) : 0.f;
         o.z = rv.z > 0.f ? fmaf(cA[2], dy.z, fmaf(cB[2], rv.z, cC[2])) : 0.f;
         o.w = rv.w > 0.f ? fmaf(cA[3], dy.w, fmaf(cB[3], rv.w, cC[3])) : 0.f;
-        *reinterpret_cast<float4*>(a.dpre + r * a.ldo + c) = o;
+        if (a.split_out) {   // hi4 | lo4 bf16 in the float4's slot (consumers: split-bf16 GEMMs only)
+          uint2 parts[2];
+          split_bf16<2>(o, parts);
+          *reinterpret_cast<uint4*>(a.dpre + r * a.ldo + c) = make_uint4(parts[0].x, parts[0].y, parts[1].x, parts[1].y);
+        } else {
+          *reinterpret_cast<float4*>(a.dpre + r * a.ldo + c) = o;
+        }
         s[0] += o.x; s[1] += o.y; s[2] += o.z; s[3] += o.w;
       } else {
         const float dy = a.dy[r * a.lddy + c], rv = a.r[r * a.ldr + c];
@@ -440,6 +446,19 @@ __device__ __forceinline__ float pack_src(const dfl_pack_job& j, int k, int n) {
   return j.src[((int64_t)a * j.B + b) * j.C + c];
 }
 
+// element r of quad slot q: a float, or (split format) hi bf16 at half-word r and lo bf16 at half-word 4 + r of the slot
+__device__ __forceinline__ void pack_put(float* dst, int64_t q, int r, float v, int split) {
+  if (!split) {
+    dst[q * 4 + r] = v;
+  } else {
+    const __bf16 h = (__bf16)v;
+    const __bf16 l = (__bf16)(v - (float)h);
+    unsigned short* d16 = reinterpret_cast<unsigned short*>(dst) + q * 8;
+    d16[r] = __builtin_bit_cast(unsigned short, h);
+    d16[4 + r] = __builtin_bit_cast(unsigned short, l);
+  }
+}
+
 __global__ void __launch_bounds__(256) pack_kernel(const dfl_pack_job* __restrict__ jobs) {
   __shared__ float tile[PK_T][PK_T * PK_CMAX + 1];
   const dfl_pack_job j = jobs[blockIdx.y];
@@ -464,16 +483,16 @@ __global__ void __launch_bounds__(256) pack_kernel(const dfl_pack_job* __restric
         if (j.kind == 1) {          // k = c*B + b, n = a: quads run along b, columns along a
           const int c = rest >> 3, bq = rest & 7, bb = 4 * bq + r, ar = x;
           if (ar < na && bb < nb)
-            j.dst[((int64_t)((c * B + b0) / 4 + bq) * N + a0 + ar) * 4 + r] = tile[ar][bb * Cc + c];
+            pack_put(j.dst, (int64_t)((c * B + b0) / 4 + bq) * N + a0 + ar, r, tile[ar][bb * Cc + c], j.split);
         } else if (j.kind == 2) {   // k = c'*A + a, n = b: quads along a, columns along b
           const int cp = rest >> 3, aq = rest & 7, ar = 4 * aq + r, bb = x;
           const int c = j.flip ? (Cc - 1 - cp) : cp;
           if (ar < na && bb < nb)
-            j.dst[((int64_t)((cp * A + a0) / 4 + aq) * N + b0 + bb) * 4 + r] = tile[ar][bb * Cc + c];
+            pack_put(j.dst, (int64_t)((cp * A + a0) / 4 + aq) * N + b0 + bb, r, tile[ar][bb * Cc + c], j.split);
         } else {                    // k = a, n = c*B + b
           const int c = rest >> 3, aq = rest & 7, ar = 4 * aq + r, bb = x;
           if (ar < na && bb < nb)
-            j.dst[((int64_t)(a0 / 4 + aq) * N + c * B + b0 + bb) * 4 + r] = tile[ar][bb * Cc + c];
+            pack_put(j.dst, (int64_t)(a0 / 4 + aq) * N + c * B + b0 + bb, r, tile[ar][bb * Cc + c], j.split);
         }
       }
     }
@@ -487,7 +506,7 @@ __global__ void __launch_bounds__(256) pack_kernel(const dfl_pack_job* __restric
     const int64_t t = i >> 2;
     const int n = (int)(t % N), kq = (int)(t / N);
     const int k = 4 * kq + r;
-    j.dst[i] = (k < K) ? pack_src(j, k, n) : 0.f;
+    pack_put(j.dst, i >> 2, r, (k < K) ? pack_src(j, k, n) : 0.f, j.split);
   }
 }
 
@@ -572,6 +591,7 @@ extern "C" int dfl_bn_relu_bwd_apply(const dfl_bn_relu_bwd_args* a, dfl_stream_t
   const bool vec_ok = a->lddy % 4 == 0 && a->ldr % 4 == 0 && a->ldo % 4 == 0 && aligned16(a->dy) && aligned16(a->r) &&
                       aligned16(a->dpre);
   const RowGeom g = row_geom(a->C, vec_ok);
+  DFL_REQUIRE(!a->split_out || g.vec, "dfl_bn_relu_bwd_apply: split_out needs the vector layout (C, ld % 4 == 0, 16-byte alignment)");
   const int rpb = (int)ceil_div(a->M, a->nblocks);
   dim3 grid((unsigned)a->nblocks, (unsigned)g.gy);
   hipStream_t s = static_cast<hipStream_t>(stream);

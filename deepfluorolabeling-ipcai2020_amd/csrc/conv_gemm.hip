@@ -278,7 +278,12 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
       }
       if constexpr (MATH != 0) {
         uint2 parts[NP];
-        split_bf16<NP>(v, parts);
+        if (MATH == 1 && a.x_split) {   // the producer already left hi4 | lo4 in the slot (wave uniform)
+          parts[0] = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));
+          parts[1] = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
+        } else {
+          split_bf16<NP>(v, parts);
+        }
 #pragma unroll
         for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(Ab + row * LDK + 8 * q + 2 * aq) = parts[q];
       } else {
@@ -293,7 +298,13 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
         const int kq = idx / BN, nn = idx - kq * BN;
         if constexpr (MATH != 0) {
           uint2 parts[NP];
-          split_bf16<NP>(rb[set][r], parts);
+          if (MATH == 1 && a.w_split) {
+            const float4 v = rb[set][r];
+            parts[0] = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));
+            parts[1] = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
+          } else {
+            split_bf16<NP>(rb[set][r], parts);
+          }
 #pragma unroll
           for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(Bb + nn * LDK + 8 * q + 2 * kq) = parts[q];
         } else {
@@ -815,13 +826,21 @@ extern "C" int dfl_conv2d(const dfl_conv_args* a, dfl_stream_t stream) {
   int rc = dfl::prepare(a, &k);
   if (rc != DFL_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (dfl::direct_conv_ok(a)) return dfl::direct_conv_launch(a, s);
+  if (dfl::direct_conv_ok(a)) {
+    DFL_REQUIRE(!a->w_split && !a->x_split, "dfl_conv2d: split operands are not defined for the direct small-K kernels");
+    return dfl::direct_conv_launch(a, s);
+  }
   if (a->splits > 1) {
     DFL_REQUIRE(a->partial != nullptr, "dfl_conv2d: splits > 1 needs the partial buffer");
     const int nchunks = (int)dfl::ceil_div(k.Ktot, dfl::KC);
     DFL_REQUIRE(a->splits <= nchunks, "dfl_conv2d: more splits than K chunks");
     k.splits = a->splits;
     k.cps = (int)dfl::ceil_div(nchunks, a->splits);
+  }
+  if (a->w_split || a->x_split) {
+    DFL_REQUIRE(k.fast && dfl::math_mode() == 1 && !dfl::direct_conv_ok(a),
+                "dfl_conv2d: split operands need math mode 1 (bf16x3) and the fast path (Cin %% 16 == 0, aligned, < 2 GiB)");
+    DFL_REQUIRE(!a->x_split || a->in_scale == nullptr, "dfl_conv2d: a split input cannot take an affine on load");
   }
   const bool general = a->add != nullptr || a->accumulate || a->scatter2x2 || (a->stat_other != nullptr && !k.so_simple);
   const bool aff = a->in_scale != nullptr;

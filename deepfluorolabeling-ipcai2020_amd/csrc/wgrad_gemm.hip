@@ -14,6 +14,8 @@
 // or a padded channel gets an out-of-range offset and reads 0 -- so the loop carries no clamping, selects or branches;
 // the dense operand's offsets are loop invariant (the chunk advance rides in the scalar offset), the gathered operand
 // keeps a pixel cursor advanced without divisions.  The general path covers odd channel counts (first layer, heads).
+#include <stdlib.h>
+
 #include "common.h"
 #include "direct_small.h"
 
@@ -221,7 +223,12 @@ __global__ void __launch_bounds__(WM* WN * 64 * WS, wg_occ(TM* TN* TPB, FAST)) w
         }
         if constexpr (MATH == 1) {
           uint2 parts[2];
-          split_bf16<2>(v, parts);
+          if (a.d_split) {   // the producer already left hi4 | lo4 in the slot (wave uniform)
+            parts[0] = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));
+            parts[1] = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
+          } else {
+            split_bf16<2>(v, parts);
+          }
           *reinterpret_cast<uint2*>(Db + pix * LDD + 2 * q) = parts[0];
           *reinterpret_cast<uint2*>(Db + pix * LDD + BMc / 2 + 2 * q) = parts[1];
         } else {
@@ -512,7 +519,7 @@ extern "C" int dfl_wgrad_suggest_splits(const dfl_wgrad_args* a) {
   const int waves = (bm >= 64) ? 4 : dfl::WG_WS;   // 2x2 waves of the wide tiles, WG_WS interleaved waves of the one-wave tiles
   const int64_t blocks = dfl::ceil_div(a->Cm, bm) * dfl::ceil_div(a->Cg, bn) * (k.T / tpb);
   // aim at ~4 waves per SIMD over the whole chip (4096 waves), every slice at least 128 pixels
-  int64_t s = dfl::ceil_div(4096, blocks * waves);
+  int64_t s = dfl::ceil_div(4096, blocks * waves);   // (3072 / 2048 / 1536 measured with bf16x3 products: slower)
   const int64_t max_by_work = k.nchunks / 8 > 0 ? k.nchunks / 8 : 1;
   if (s > max_by_work) s = max_by_work;
   if (s > 2048) s = 2048;
@@ -525,9 +532,14 @@ extern "C" int dfl_conv2d_wgrad(const dfl_wgrad_args* a, dfl_stream_t stream) {
   int rc = dfl::wg_prepare(a, &k, true);
   if (rc != DFL_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (dfl::direct_wgrad_ok(a)) return dfl::direct_wgrad_launch(a, s);
+  if (dfl::direct_wgrad_ok(a)) {
+    DFL_REQUIRE(!a->d_split, "dfl_conv2d_wgrad: a split d is not defined for the direct small-K kernels");
+    return dfl::direct_wgrad_launch(a, s);
+  }
   k.cps = (int)dfl::ceil_div(k.nchunks, a->splits);
   const bool f = k.fast;
+  DFL_REQUIRE(!a->d_split || (f && dfl::math_mode() == 1 && !dfl::direct_wgrad_ok(a)),
+              "dfl_conv2d_wgrad: a split d needs math mode 1 (bf16x3) and the fast path");
   if (f && dfl::math_mode() == 1) {
     switch (dfl::pick_wg(a)) {
       case dfl::WG_128: return dfl::wg_launch<2, 2, 2, 2, 1, true, 1>(k, s);

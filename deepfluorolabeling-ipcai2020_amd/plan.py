@@ -64,6 +64,8 @@ class UNetPlan:
         self._red_bytes = 0
         self._red_flushes = []          # (index of the batch op in bwd, [dst pointers])
         self._side = []                 # weight gradients running on the side stream: dict(done=event, op=index, waited=index|None)
+        self.math = self.lib.dfl_get_math_mode()   # product arithmetic the plan is recorded for (split operand formats)
+        self._packed_split = {}         # packed-weight address -> stored as split quads
         self._build()
 
     # ------------------------------------------------------------------------------------------ memory
@@ -93,7 +95,12 @@ class UNetPlan:
         K = {1: Cc * B, 2: Cc * A, 3: A}[kind]
         N = {1: A, 2: B, 3: Cc * B}[kind]
         dst = self._new((K + 3) // 4 * N * 4)
-        self._pack_jobs.append((w, dst, A, B, Cc, kind, flip))
+        # split quads (hi4 | lo4 bf16) when the consuming conv will take the split-bf16 fast path: its input channels
+        # (B for a forward operand, A for the transposed ones) must be a multiple of 16 and K large enough for the GEMM
+        cin = B if kind == 1 else A
+        split = int(self.math == 1 and cin % 16 == 0)
+        self._packed_split[dst.data_ptr()] = split
+        self._pack_jobs.append((w, dst, A, B, Cc, kind, flip, split))
         return dst
 
     def _pack_conv_fwd(self, w):      # Conv2d [Co][Ci][T]: k = (tap, ci), n = co
@@ -118,9 +125,9 @@ class UNetPlan:
             return
         arr = (PackJob * n)()
         mx = 0
-        for i, (src, dst, A, B, Cc, kind, flip) in enumerate(self._pack_jobs):
+        for i, (src, dst, A, B, Cc, kind, flip, split) in enumerate(self._pack_jobs):
             arr[i].src, arr[i].dst = src.data_ptr(), dst.data_ptr()
-            arr[i].A, arr[i].B, arr[i].C, arr[i].kind, arr[i].flip = A, B, Cc, kind, flip
+            arr[i].A, arr[i].B, arr[i].C, arr[i].kind, arr[i].flip, arr[i].split = A, B, Cc, kind, flip, split
             mx = max(mx, A * B * Cc)
         raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
         self._jobs_dev = torch.from_numpy(raw).to(self.dev)
@@ -134,7 +141,7 @@ class UNetPlan:
         # Main stream: forward layouts.  Side stream: waits for the main stream (the optimizer step), packs, signals;
         # the backward program starts by waiting for that signal.
         def mx_of(jobs):
-            return max(A * B * Cc for (_, _, A, B, Cc, _, _) in jobs)
+            return max(A * B * Cc for (_, _, A, B, Cc, _, _, _) in jobs)
         self.pack.add(PackArgs(jobs_dev=self._jobs_dev.data_ptr(), max_elems=mx_of(self._pack_jobs[:nf]), njobs=nf))
         self.pack.record(self.EV_PACK_FORK, stream=0)
         self.pack.wait(self.EV_PACK_FORK, stream=1)
@@ -148,9 +155,11 @@ class UNetPlan:
 
     # ------------------------------------------------------------------------------------------ op helpers
     def _conv(self, prog, x, w, y, KH, KW, stride, pad, Ntot, bias=None, in_aff=None, relu=0, add=None,
-              add_aff=None, accumulate=0, scatter=0, stats=False, stat_other=None, Hout=None, Wout=None):
+              add_aff=None, accumulate=0, scatter=0, stats=False, stat_other=None, Hout=None, Wout=None, x_split=0):
         a = ConvArgs()
         a.x, a.w, a.y = x.ptr, w.data_ptr(), y.ptr
+        a.w_split = self._packed_split.get(w.data_ptr(), 0)
+        a.x_split = x_split
         a.bias = nat.ptr(bias)
         if in_aff is not None:
             a.in_scale, a.in_shift = in_aff[0].data_ptr(), in_aff[1].data_ptr()
@@ -194,8 +203,9 @@ class UNetPlan:
             e['waited'] = len(prog.structs)
             prog.wait(e['done'], stream=0)
 
-    def _wgrad(self, prog, g, d, dw, KH, KW, stride, pad, Hout, Wout, in_aff=None, side=False, side_buf=None):
+    def _wgrad(self, prog, g, d, dw, KH, KW, stride, pad, Hout, Wout, in_aff=None, side=False, side_buf=None, d_split=0):
         a = WgradArgs()
+        a.d_split = d_split
         a.g, a.d, a.dw = g.ptr, d.ptr, dw.data_ptr()
         if in_aff is not None:
             a.in_scale, a.in_shift = in_aff[0].data_ptr(), in_aff[1].data_ptr()
@@ -450,27 +460,32 @@ class UNetPlan:
                     elif do_res and d == bd - 1:
                         self._colsum(bwd, g, G[prefix + '.res_conv1x1.bias'])
                     bpart = self._new(nb * Cout)
+                    inp = cv['inp']
+                    # dpre feeds exactly two GEMMs (weight gradient: dense operand; data gradient: gathered operand);
+                    # with split-bf16 products it is written split once here instead of being split by every tile of both
+                    dsplit = int(self.math == 1 and Cout % 16 == 0 and inp.C % 4 == 0 and inp.C * 9 > 12)
                     bwd.add(BnReluBwdArgs(dy=g.ptr, r=r.ptr, coef=nat.ptr(coef), dpre=dpre.ptr,
                                           partials=bpart.data_ptr(), M=r.M, C=Cout, lddy=g.ld, ldr=r.ld, ldo=dpre.ld,
-                                          nblocks=nb))
+                                          nblocks=nb, split_out=dsplit))
                     self._defer_sum(bwd, bpart.data_ptr(), G[cv['wname'] + '.bias'].data_ptr(), Cout, Cout, nb)
-                    inp = cv['inp']
                     self._wgrad(bwd, inp, dpre, G[cv['wname'] + '.weight'], 3, 3, 1, pad, r.H, r.W,
-                                in_aff=cv['inp_aff'], side=side, side_buf=self._dpre_turn)
+                                in_aff=cv['inp_aff'], side=side, side_buf=self._dpre_turn, d_split=dsplit)
                     if d > 0:
                         wd = self._pack_conv_dgrad(cv['w'])
                         dz = self._scratch_act('dz', N, inp.H, inp.W, Cout)
                         prev = convs[d - 1]
                         if prev['bn'] is not None and self.FUSE_BWD_STATS:
                             # the data-gradient conv leaves sum(dz), sum(dz*r) per channel for the next BN backward
-                            fused = self._conv(bwd, dpre, wd, dz, 3, 3, 1, 2 - pad, Cout, stats=True, stat_other=prev['r'])
+                            fused = self._conv(bwd, dpre, wd, dz, 3, 3, 1, 2 - pad, Cout, stats=True, stat_other=prev['r'],
+                                               x_split=dsplit)
                         else:
                             fused = None
-                            self._conv(bwd, dpre, wd, dz, 3, 3, 1, 2 - pad, Cout)
+                            self._conv(bwd, dpre, wd, dz, 3, 3, 1, 2 - pad, Cout, x_split=dsplit)
                         g = dz
                     elif dxin is not None:
                         wd = self._pack_conv_dgrad(cv['w'])
-                        self._conv(bwd, dpre, wd, dxin, 3, 3, 1, 2 - pad, xin.C, accumulate=1 if wrote_dxin else 0)
+                        self._conv(bwd, dpre, wd, dxin, 3, 3, 1, 2 - pad, xin.C, accumulate=1 if wrote_dxin else 0,
+                                   x_split=dsplit)
                     self._maybe_flush(bwd)
             return backward
 

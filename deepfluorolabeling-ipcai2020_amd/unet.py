@@ -210,7 +210,7 @@ class UNet(nn.Module):
     def _get_plan(self, x, need_grad):
         P, B = self._state()
         N, _, H, W = x.shape
-        key = (N, H, W, self.training, need_grad)
+        key = (N, H, W, self.training, need_grad, nat.lib().dfl_get_math_mode())   # operand formats depend on the mode
         plans = self._plans.setdefault(key, [])
         for p in plans:
             if not p.busy:

@@ -83,6 +83,11 @@ typedef struct {
                             at output pixel (2i + ab/2, 2j + ab%2) of an [N, Hout, Wout] image, channel co */
   int32_t splits;        /* 0/1: one pass.  > 1: K is cut into `splits` slices (small-M, long-K layers of the deep
                             U-Net levels), raw sums go to `partial` and a finish kernel applies the epilogue */
+  /* "Split" operands (math mode 1, bf16x3, fast path only): the 16-byte slot of 4 consecutive fp32 values holds their
+   * 4 hi bf16 followed by their 4 lo bf16 (hi = bf16(v), lo = bf16(v - hi)) -- same addressing, and the kernel copies
+   * the slot to LDS instead of splitting it itself (a value is otherwise split once per tap and column block). */
+  int32_t w_split;       /* w was packed with dfl_pack_job.split = 1 */
+  int32_t x_split;       /* x is a split tensor (written by dfl_bn_relu_bwd_apply with split_out); needs in_scale == NULL */
 } dfl_conv_args;
 
 int dfl_conv2d(const dfl_conv_args* a, dfl_stream_t stream);
@@ -113,7 +118,7 @@ typedef struct {
   int32_t KH, KW, stride, pad;
   int32_t Hout, Wout, Cm, ldd;
   int32_t splits;
-  int32_t reserved;
+  int32_t d_split;       /* d is a split tensor (see dfl_conv_args.x_split); math mode 1 fast path only */
 } dfl_wgrad_args;
 
 int dfl_conv2d_wgrad(const dfl_wgrad_args* a, dfl_stream_t stream);
@@ -139,7 +144,7 @@ typedef struct {
   float* dst;            /* ceil(K/4) * Ntot * 4 floats */
   int32_t A, B, C;
   int32_t kind, flip;
-  int32_t reserved;
+  int32_t split;         /* 1: write split quads (4 hi bf16 | 4 lo bf16) instead of 4 floats (dfl_conv_args.w_split) */
 } dfl_pack_job;
 
 /* jobs: DEVICE pointer to njobs dfl_pack_job records; max_elems = max over jobs of A*B*C. */
@@ -208,6 +213,7 @@ typedef struct {
   float* partials;        /* [nblocks][C] sums of dpre (nblocks = dfl_rowblock_count(M, C)), or NULL */
   int64_t M;
   int32_t C, lddy, ldr, ldo, nblocks;
+  int32_t split_out;      /* 1: dpre is written as a split tensor (needs C % 4 == 0, ldo % 4 == 0, 16-byte alignment) */
 } dfl_bn_relu_bwd_args;
 int dfl_bn_relu_bwd_apply(const dfl_bn_relu_bwd_args* a, dfl_stream_t stream);
 
