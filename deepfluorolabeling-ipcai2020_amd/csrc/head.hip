@@ -2,8 +2,9 @@
 //   logits = seg_conv(x)                  1x1, no bias, F -> NC
 //   seg    = Softmax2d(logits)            (or logits when do_soft_max=False)
 //   heat   = lands_1x1(cat(x, logits))    1x1 (F+NC -> NM) [-> 1x1 (NM -> L)], no bias, no non-linearity
-// One thread per pixel: the F features are streamed once as float4 (NHWC row), all head weights sit in LDS and are
-// read as wave-wide broadcasts, logits / mid / heat stay in registers, seg and heat are stored NCHW (lane = pixel
+// One thread per pixel: the F features are streamed once as float4 (NHWC row); the head weights (5 KB) are read with
+// wave-uniform addresses through `const __restrict__` kernel parameters, i.e. as scalar loads into SGPR operands of the
+// FMAs (no LDS traffic: the LDS-broadcast version spent 224 ds_read_b128 per pixel), logits / mid / heat stay in registers, seg and heat are stored NCHW (lane = pixel
 // => unit-stride stores per channel plane).  HBM-bound: 4*F bytes in, 4*(NC+L) bytes out per pixel.
 // The backward kernel recomputes logits and mid from x (cheaper than saving them), applies the softmax Jacobian
 //  and leaves dx plus a per-pixel scratch row from which the three small weight gradients are
@@ -16,43 +17,11 @@ constexpr int MAXNC = DFL_HEAD_MAX_NC, MAXL = DFL_HEAD_MAX_L, MAXNM = DFL_HEAD_M
 
 static inline int head_fc(int F) { return ((F + MAXNC) + 3) / 4 * 4; }
 
-struct HeadLds {
-  int P1;       // row pitch of W1 in LDS (>= F + NC, multiple of 4)
-  int off_seg;  // [NC][F]
-  int off_l1;   // [NM][P1]
-  int off_l2;   // [L][NM]
-  int total;
-};
-
-__host__ __device__ inline HeadLds head_lds(int F, int NC, int NM, int L) {
-  HeadLds h;
-  h.P1 = ((F + NC) + 3) / 4 * 4;
-  h.off_seg = 0;
-  h.off_l1 = NC * F;
-  h.off_l2 = h.off_l1 + NM * h.P1;
-  h.total = h.off_l2 + L * NM;
-  return h;
-}
-
-__device__ __forceinline__ void head_load_weights(float* sm, const HeadLds& h, const float* w_seg, const float* w_l1,
-                                                  const float* w_l2, int F, int NC, int NM, int L) {
-  for (int i = threadIdx.x; i < NC * F; i += blockDim.x) sm[h.off_seg + i] = w_seg[i];
-  if (w_l1 != nullptr) {
-    const int K1 = F + NC;
-    for (int i = threadIdx.x; i < NM * h.P1; i += blockDim.x) {
-      const int j = i / h.P1, k = i - j * h.P1;
-      sm[h.off_l1 + i] = (k < K1) ? w_l1[j * K1 + k] : 0.f;
-    }
-  }
-  if (w_l2 != nullptr)
-    for (int i = threadIdx.x; i < L * NM; i += blockDim.x) sm[h.off_l2 + i] = w_l2[i];
-  __syncthreads();
-}
-
-// logits (lg) and the x-part of mid for pixel row xr; optionally copies x into `cat` (scratch row).
-__device__ __forceinline__ void head_features(const float* __restrict__ xr, const float* sm, const HeadLds& h, int F,
-                                              int NC, int NM, bool lands, float* lg, float* mid,
-                                              float* __restrict__ cat) {
+// logits (lg) and mid for pixel row xr; optionally copies x into `cat` (scratch row).  K1 = F + NC = row length of w_l1.
+__device__ __forceinline__ void head_features(const float* __restrict__ xr, const float* __restrict__ w_seg,
+                                              const float* __restrict__ w_l1, int F, int NC, int NM, bool lands,
+                                              float* lg, float* mid, float* __restrict__ cat) {
+  const int K1 = F + NC;
 #pragma unroll
   for (int c = 0; c < MAXNC; ++c) lg[c] = 0.f;
 #pragma unroll
@@ -63,16 +32,16 @@ __device__ __forceinline__ void head_features(const float* __restrict__ xr, cons
 #pragma unroll
     for (int c = 0; c < MAXNC; ++c) {
       if (c < NC) {
-        const float4 w = *reinterpret_cast<const float4*>(sm + h.off_seg + c * F + k);
-        lg[c] = fmaf(w.x, xv.x, fmaf(w.y, xv.y, fmaf(w.z, xv.z, fmaf(w.w, xv.w, lg[c]))));
+        const float* w = w_seg + c * F + k;
+        lg[c] = fmaf(w[0], xv.x, fmaf(w[1], xv.y, fmaf(w[2], xv.z, fmaf(w[3], xv.w, lg[c]))));
       }
     }
     if (lands) {
 #pragma unroll
       for (int j = 0; j < MAXNM; ++j) {
         if (j < NM) {
-          const float4 w = *reinterpret_cast<const float4*>(sm + h.off_l1 + j * h.P1 + k);
-          mid[j] = fmaf(w.x, xv.x, fmaf(w.y, xv.y, fmaf(w.z, xv.z, fmaf(w.w, xv.w, mid[j]))));
+          const float* w = w_l1 + j * K1 + k;
+          mid[j] = fmaf(w[0], xv.x, fmaf(w[1], xv.y, fmaf(w[2], xv.z, fmaf(w[3], xv.w, mid[j]))));
         }
       }
     }
@@ -83,7 +52,7 @@ __device__ __forceinline__ void head_features(const float* __restrict__ xr, cons
       if (j < NM) {
 #pragma unroll
         for (int c = 0; c < MAXNC; ++c)
-          if (c < NC) mid[j] = fmaf(sm[h.off_l1 + j * h.P1 + F + c], lg[c], mid[j]);
+          if (c < NC) mid[j] = fmaf(w_l1[j * K1 + F + c], lg[c], mid[j]);
       }
     }
   }
@@ -108,28 +77,26 @@ __device__ __forceinline__ void softmax_inplace(float* lg, int NC) {
     if (c < NC) lg[c] *= inv;
 }
 
-__global__ void __launch_bounds__(256) head_fwd_kernel(const dfl_head_fwd_args a) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
+__global__ void __launch_bounds__(256) head_fwd_kernel(const dfl_head_fwd_args a, const float* __restrict__ w_seg,
+                                                      const float* __restrict__ w_l1, const float* __restrict__ w_l2) {
   const int F = a.F, NC = a.NC, NM = a.NM, L = a.L;
-  const HeadLds h = head_lds(F, NC, NM, L);
-  head_load_weights(sm, h, a.w_seg, a.w_l1, a.w_l2, F, NC, NM, L);
   const int64_t HW = (int64_t)a.H * a.W;
   const int64_t M = (int64_t)a.N * HW;
   const bool lands = L > 0;
   for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
     float lg[MAXNC], mid[MAXNM];
-    head_features(a.x + m * a.ldx, sm, h, F, NC, NM, lands, lg, mid, nullptr);
+    head_features(a.x + m * a.ldx, w_seg, w_l1, F, NC, NM, lands, lg, mid, nullptr);
     const int64_t n = m / HW, pp = m - n * HW;
     if (lands) {
       float* hp = a.heat + n * L * HW + pp;
-      if (a.w_l2 != nullptr) {
+      if (w_l2 != nullptr) {
 #pragma unroll
         for (int l = 0; l < MAXL; ++l) {
           if (l < L) {
             float acc = 0.f;
 #pragma unroll
             for (int j = 0; j < MAXNM; ++j)
-              if (j < NM) acc = fmaf(sm[h.off_l2 + l * NM + j], mid[j], acc);
+              if (j < NM) acc = fmaf(w_l2[l * NM + j], mid[j], acc);
             hp[(int64_t)l * HW] = acc;
           }
         }
@@ -147,11 +114,10 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(const dfl_head_fwd_args a
   }
 }
 
-__global__ void __launch_bounds__(256) head_bwd_kernel(const dfl_head_bwd_args a, int Fc) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
+__global__ void __launch_bounds__(256) head_bwd_kernel(const dfl_head_bwd_args a, int Fc, const float* __restrict__ w_seg,
+                                                      const float* __restrict__ w_l1, const float* __restrict__ w_l2) {
   const int F = a.F, NC = a.NC, NM = a.NM, L = a.L;
-  const HeadLds h = head_lds(F, NC, NM, L);
-  head_load_weights(sm, h, a.w_seg, a.w_l1, a.w_l2, F, NC, NM, L);
+  const int K1 = F + NC;
   const int64_t HW = (int64_t)a.H * a.W;
   const int64_t M = (int64_t)a.N * HW;
   const bool lands = L > 0 && a.dheat != nullptr;
@@ -159,7 +125,7 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(const dfl_head_bwd_args a
   for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
     float* sr = a.scratch + m * a.scratch_ld;
     float lg[MAXNC], mid[MAXNM];
-    head_features(a.x + m * a.ldx, sm, h, F, NC, NM, L > 0, lg, mid, sr);
+    head_features(a.x + m * a.ldx, w_seg, w_l1, F, NC, NM, L > 0, lg, mid, sr);
     const int64_t n = m / HW, pp = m - n * HW;
     // cat tail: logits then zero pad
 #pragma unroll
@@ -173,10 +139,10 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(const dfl_head_bwd_args a
     for (int j = 0; j < MAXNM; ++j) {
       float acc = 0.f;
       if (lands && j < NM) {
-        if (a.w_l2 != nullptr) {
+        if (w_l2 != nullptr) {
 #pragma unroll
           for (int l = 0; l < MAXL; ++l)
-            if (l < L) acc = fmaf(sm[h.off_l2 + l * NM + j], dh[l], acc);
+            if (l < L) acc = fmaf(w_l2[l * NM + j], dh[l], acc);
         } else {
           acc = (j < MAXL) ? dh[j < MAXL ? j : 0] : 0.f;
         }
@@ -205,7 +171,7 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(const dfl_head_bwd_args a
         if (lands) {
 #pragma unroll
           for (int j = 0; j < MAXNM; ++j)
-            if (j < NM) v = fmaf(sm[h.off_l1 + j * h.P1 + F + c], dmid[j], v);
+            if (j < NM) v = fmaf(w_l1[j * K1 + F + c], dmid[j], v);
         }
       }
       dlg[c] = v;
@@ -225,18 +191,18 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(const dfl_head_bwd_args a
 #pragma unroll
       for (int c = 0; c < MAXNC; ++c) {
         if (c < NC) {
-          const float4 w = *reinterpret_cast<const float4*>(sm + h.off_seg + c * F + k);
-          acc.x = fmaf(w.x, dlg[c], acc.x); acc.y = fmaf(w.y, dlg[c], acc.y);
-          acc.z = fmaf(w.z, dlg[c], acc.z); acc.w = fmaf(w.w, dlg[c], acc.w);
+          const float* w = w_seg + c * F + k;
+          acc.x = fmaf(w[0], dlg[c], acc.x); acc.y = fmaf(w[1], dlg[c], acc.y);
+          acc.z = fmaf(w[2], dlg[c], acc.z); acc.w = fmaf(w[3], dlg[c], acc.w);
         }
       }
       if (lands) {
 #pragma unroll
         for (int j = 0; j < MAXNM; ++j) {
           if (j < NM) {
-            const float4 w = *reinterpret_cast<const float4*>(sm + h.off_l1 + j * h.P1 + k);
-            acc.x = fmaf(w.x, dmid[j], acc.x); acc.y = fmaf(w.y, dmid[j], acc.y);
-            acc.z = fmaf(w.z, dmid[j], acc.z); acc.w = fmaf(w.w, dmid[j], acc.w);
+            const float* w = w_l1 + j * K1 + k;
+            acc.x = fmaf(w[0], dmid[j], acc.x); acc.y = fmaf(w[1], dmid[j], acc.y);
+            acc.z = fmaf(w[2], dmid[j], acc.z); acc.w = fmaf(w[3], dmid[j], acc.w);
           }
         }
       }
@@ -288,10 +254,9 @@ extern "C" int dfl_head_fwd(const dfl_head_fwd_args* a, dfl_stream_t stream) {
   int rc = head_check(a->F, a->NC, a->NM, a->L, a->w_l1, a->w_l2, a->ldx, a->x);
   if (rc != DFL_OK) return rc;
   DFL_REQUIRE(a->L == 0 || a->heat != nullptr, "dfl_head_fwd: heat output required when L > 0");
-  const HeadLds h = head_lds(a->F, a->NC, a->NM, a->L);
   const int64_t M = (int64_t)a->N * a->H * a->W;
-  hipLaunchKernelGGL(head_fwd_kernel, dim3(head_grid(M)), dim3(256), (size_t)h.total * sizeof(float),
-                     static_cast<hipStream_t>(stream), *a);
+  hipLaunchKernelGGL(head_fwd_kernel, dim3(head_grid(M)), dim3(256), 0, static_cast<hipStream_t>(stream), *a, a->w_seg,
+                     a->w_l1, a->w_l2);
   return check_launch("dfl_head_fwd");
 }
 
@@ -303,9 +268,8 @@ extern "C" int dfl_head_bwd(const dfl_head_bwd_args* a, dfl_stream_t stream) {
   DFL_REQUIRE(a->lddx % 4 == 0 && aligned16(a->dx), "dfl_head_bwd: dx alignment");
   DFL_REQUIRE(a->scratch_ld >= dfl_head_scratch_ld(a->F) && a->scratch_ld % 4 == 0 && aligned16(a->scratch),
               "dfl_head_bwd: scratch_ld too small or misaligned");
-  const HeadLds h = head_lds(a->F, a->NC, a->NM, a->L);
   const int64_t M = (int64_t)a->N * a->H * a->W;
-  hipLaunchKernelGGL(head_bwd_kernel, dim3(head_grid(M)), dim3(256), (size_t)h.total * sizeof(float),
-                     static_cast<hipStream_t>(stream), *a, head_fc(a->F));
+  hipLaunchKernelGGL(head_bwd_kernel, dim3(head_grid(M)), dim3(256), 0, static_cast<hipStream_t>(stream), *a,
+                     head_fc(a->F), a->w_seg, a->w_l1, a->w_l2);
   return check_launch("dfl_head_bwd");
 }
