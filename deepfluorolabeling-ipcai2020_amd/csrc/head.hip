@@ -2,7 +2,10 @@
 //   logits = seg_conv(x)                  1x1, no bias, F -> NC
 //   seg    = Softmax2d(logits)            (or logits when do_soft_max=False)
 //   heat   = lands_1x1(cat(x, logits))    1x1 (F+NC -> NM) [-> 1x1 (NM -> L)], no bias, no non-linearity
-// One thread per pixel: the F features are streamed once as float4 (NHWC row); the head weights (5 KB) are read with
+// One thread per pixel, 256 consecutive pixels per workgroup.  A thread-private walk over its 128-byte feature row would
+// touch 64 cache lines per wave-instruction (measured: 5x the compulsory HBM reads), so the [256][F] tile is loaded
+// cooperatively (consecutive lanes = consecutive 16 bytes) into LDS (pitch F + 4: conflict-free b128 row reads) and the
+// same tile carries dx back out in the backward kernel; the head weights (5 KB) are read with
 // wave-uniform addresses through `const __restrict__` kernel parameters, i.e. as scalar loads into SGPR operands of the
 // FMAs (no LDS traffic: the LDS-broadcast version spent 224 ds_read_b128 per pixel), logits / mid / heat stay in registers, seg and heat are stored NCHW (lane = pixel
 // => unit-stride stores per channel plane).  HBM-bound: 4*F bytes in, 4*(NC+L) bytes out per pixel.
@@ -17,10 +20,36 @@ constexpr int MAXNC = DFL_HEAD_MAX_NC, MAXL = DFL_HEAD_MAX_L, MAXNM = DFL_HEAD_M
 
 static inline int head_fc(int F) { return ((F + MAXNC) + 3) / 4 * 4; }
 
-// logits (lg) and mid for pixel row xr; optionally copies x into `cat` (scratch row).  K1 = F + NC = row length of w_l1.
-__device__ __forceinline__ void head_features(const float* __restrict__ xr, const float* __restrict__ w_seg,
+constexpr int HT = 256;   // pixels per workgroup tile
+
+// tile[p][0..F) = x[m0 + p][0..F) (zeros past M); optionally the same values go to cat[(m0 + p) * cat_ld + ..] (scratch)
+__device__ __forceinline__ void head_load_tile(float* tile, int pitch, const float* __restrict__ x, int ldx, int64_t m0,
+                                               int64_t M, int F, float* __restrict__ cat, int cat_ld) {
+  const int fq = F / 4;
+  for (int e = threadIdx.x; e < HT * fq; e += HT) {
+    const int p = e / fq, q = e - p * fq;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m0 + p < M) {
+      v = *reinterpret_cast<const float4*>(x + (m0 + p) * ldx + 4 * q);
+      if (cat != nullptr) *reinterpret_cast<float4*>(cat + (m0 + p) * cat_ld + 4 * q) = v;
+    }
+    *reinterpret_cast<float4*>(tile + p * pitch + 4 * q) = v;
+  }
+}
+
+// The channel counts are template parameters for the reference's two head shapes (7 classes alone, 7 + 14 landmarks
+// through 21): with run-time bounds every 4-FMA group became its own basic block (scalar load, wait, branch -- ~950
+// branches per pixel, the kernels ran at 1 TB/s).  GEN = 1 keeps the run-time bounds for any other shape.
+#define HEAD_TPL template <int NCc, int NMc, int Lc, bool GEN>
+#define HEAD_BOUNDS                                                              \
+  constexpr int BNC = GEN ? MAXNC : NCc, BNM = GEN ? MAXNM : NMc, BL = GEN ? MAXL : Lc; \
+  (void)BNC; (void)BNM; (void)BL;
+
+// logits (lg) and mid for pixel row xr (in LDS).  K1 = F + NC = row length of w_l1.
+HEAD_TPL __device__ __forceinline__ void head_features(const float* xr, const float* __restrict__ w_seg,
                                               const float* __restrict__ w_l1, int F, int NC, int NM, bool lands,
-                                              float* lg, float* mid, float* __restrict__ cat) {
+                                              float* lg, float* mid) {
+  HEAD_BOUNDS
   const int K1 = F + NC;
 #pragma unroll
   for (int c = 0; c < MAXNC; ++c) lg[c] = 0.f;
@@ -28,18 +57,17 @@ __device__ __forceinline__ void head_features(const float* __restrict__ xr, cons
   for (int j = 0; j < MAXNM; ++j) mid[j] = 0.f;
   for (int k = 0; k < F; k += 4) {
     const float4 xv = *reinterpret_cast<const float4*>(xr + k);
-    if (cat != nullptr) *reinterpret_cast<float4*>(cat + k) = xv;
 #pragma unroll
-    for (int c = 0; c < MAXNC; ++c) {
-      if (c < NC) {
+    for (int c = 0; c < BNC; ++c) {
+      if (!GEN || c < NC) {
         const float* w = w_seg + c * F + k;
         lg[c] = fmaf(w[0], xv.x, fmaf(w[1], xv.y, fmaf(w[2], xv.z, fmaf(w[3], xv.w, lg[c]))));
       }
     }
     if (lands) {
 #pragma unroll
-      for (int j = 0; j < MAXNM; ++j) {
-        if (j < NM) {
+      for (int j = 0; j < BNM; ++j) {
+        if (!GEN || j < NM) {
           const float* w = w_l1 + j * K1 + k;
           mid[j] = fmaf(w[0], xv.x, fmaf(w[1], xv.y, fmaf(w[2], xv.z, fmaf(w[3], xv.w, mid[j]))));
         }
@@ -48,165 +76,195 @@ __device__ __forceinline__ void head_features(const float* __restrict__ xr, cons
   }
   if (lands) {
 #pragma unroll
-    for (int j = 0; j < MAXNM; ++j) {
-      if (j < NM) {
+    for (int j = 0; j < BNM; ++j) {
+      if (!GEN || j < NM) {
 #pragma unroll
-        for (int c = 0; c < MAXNC; ++c)
-          if (c < NC) mid[j] = fmaf(w_l1[j * K1 + F + c], lg[c], mid[j]);
+        for (int c = 0; c < BNC; ++c)
+          if (!GEN || c < NC) mid[j] = fmaf(w_l1[j * K1 + F + c], lg[c], mid[j]);
       }
     }
   }
 }
 
-__device__ __forceinline__ void softmax_inplace(float* lg, int NC) {
+HEAD_TPL __device__ __forceinline__ void softmax_inplace(float* lg, int NC) {
+  HEAD_BOUNDS
   float mx = lg[0];
 #pragma unroll
-  for (int c = 1; c < MAXNC; ++c)
-    if (c < NC) mx = fmaxf(mx, lg[c]);
+  for (int c = 1; c < BNC; ++c)
+    if (!GEN || c < NC) mx = fmaxf(mx, lg[c]);
   float sum = 0.f;
 #pragma unroll
-  for (int c = 0; c < MAXNC; ++c) {
-    if (c < NC) {
+  for (int c = 0; c < BNC; ++c) {
+    if (!GEN || c < NC) {
       lg[c] = expf(lg[c] - mx);
       sum += lg[c];
     }
   }
   const float inv = 1.0f / sum;
 #pragma unroll
-  for (int c = 0; c < MAXNC; ++c)
-    if (c < NC) lg[c] *= inv;
+  for (int c = 0; c < BNC; ++c)
+    if (!GEN || c < NC) lg[c] *= inv;
 }
 
-__global__ void __launch_bounds__(256) head_fwd_kernel(const dfl_head_fwd_args a, const float* __restrict__ w_seg,
+HEAD_TPL __global__ void __launch_bounds__(256) head_fwd_kernel(const dfl_head_fwd_args a, const float* __restrict__ w_seg,
                                                       const float* __restrict__ w_l1, const float* __restrict__ w_l2) {
-  const int F = a.F, NC = a.NC, NM = a.NM, L = a.L;
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  HEAD_BOUNDS
+  const int F = a.F, NC = GEN ? a.NC : NCc, NM = GEN ? a.NM : NMc, L = GEN ? a.L : Lc;
+  const int pitch = F + 4;
   const int64_t HW = (int64_t)a.H * a.W;
   const int64_t M = (int64_t)a.N * HW;
   const bool lands = L > 0;
-  for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t m0 = (int64_t)blockIdx.x * HT; m0 < M; m0 += (int64_t)gridDim.x * HT) {
+    __syncthreads();
+    head_load_tile(tile, pitch, a.x, a.ldx, m0, M, F, nullptr, 0);
+    __syncthreads();
+    const int64_t m = m0 + threadIdx.x;
+    if (m >= M) continue;
     float lg[MAXNC], mid[MAXNM];
-    head_features(a.x + m * a.ldx, w_seg, w_l1, F, NC, NM, lands, lg, mid, nullptr);
+    head_features<NCc, NMc, Lc, GEN>(tile + threadIdx.x * pitch, w_seg, w_l1, F, NC, NM, lands, lg, mid);
     const int64_t n = m / HW, pp = m - n * HW;
     if (lands) {
       float* hp = a.heat + n * L * HW + pp;
       if (w_l2 != nullptr) {
 #pragma unroll
-        for (int l = 0; l < MAXL; ++l) {
-          if (l < L) {
+        for (int l = 0; l < BL; ++l) {
+          if (!GEN || l < L) {
             float acc = 0.f;
 #pragma unroll
-            for (int j = 0; j < MAXNM; ++j)
-              if (j < NM) acc = fmaf(w_l2[l * NM + j], mid[j], acc);
+            for (int j = 0; j < BNM; ++j)
+              if (!GEN || j < NM) acc = fmaf(w_l2[l * NM + j], mid[j], acc);
             hp[(int64_t)l * HW] = acc;
           }
         }
       } else {
 #pragma unroll
-        for (int l = 0; l < MAXL; ++l)
-          if (l < L) hp[(int64_t)l * HW] = mid[l];
+        for (int l = 0; l < BL; ++l)
+          if (!GEN || l < L) hp[(int64_t)l * HW] = mid[l];
       }
     }
-    if (a.softmax) softmax_inplace(lg, NC);
+    if (a.softmax) softmax_inplace<NCc, NMc, Lc, GEN>(lg, NC);
     float* sp = a.seg + n * NC * HW + pp;
 #pragma unroll
-    for (int c = 0; c < MAXNC; ++c)
-      if (c < NC) sp[(int64_t)c * HW] = lg[c];
+    for (int c = 0; c < BNC; ++c)
+      if (!GEN || c < NC) sp[(int64_t)c * HW] = lg[c];
   }
 }
 
-__global__ void __launch_bounds__(256) head_bwd_kernel(const dfl_head_bwd_args a, int Fc, const float* __restrict__ w_seg,
+HEAD_TPL __global__ void __launch_bounds__(256) head_bwd_kernel(const dfl_head_bwd_args a, int Fc, const float* __restrict__ w_seg,
                                                       const float* __restrict__ w_l1, const float* __restrict__ w_l2) {
-  const int F = a.F, NC = a.NC, NM = a.NM, L = a.L;
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  HEAD_BOUNDS
+  const int F = a.F, NC = GEN ? a.NC : NCc, NM = GEN ? a.NM : NMc, L = GEN ? a.L : Lc;
   const int K1 = F + NC;
+  const int pitch = F + 4;
   const int64_t HW = (int64_t)a.H * a.W;
   const int64_t M = (int64_t)a.N * HW;
   const bool lands = L > 0 && a.dheat != nullptr;
-  const int o_dlg = Fc, o_dmid = Fc + MAXNC, o_mid = o_dmid + MAXNM, o_dh = o_mid + MAXNM;
-  for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
-    float* sr = a.scratch + m * a.scratch_ld;
-    float lg[MAXNC], mid[MAXNM];
-    head_features(a.x + m * a.ldx, w_seg, w_l1, F, NC, NM, L > 0, lg, mid, sr);
-    const int64_t n = m / HW, pp = m - n * HW;
-    // cat tail: logits then zero pad
+  const int o_dlg = Fc, o_dmid = Fc + MAXNC, o_mid = o_dmid + MAXNM, o_dh = o_mid + MAXNM;   // all multiples of 4
+  for (int64_t m0 = (int64_t)blockIdx.x * HT; m0 < M; m0 += (int64_t)gridDim.x * HT) {
+    __syncthreads();
+    head_load_tile(tile, pitch, a.x, a.ldx, m0, M, F, a.scratch, a.scratch_ld);   // also copies x into the cat columns
+    __syncthreads();
+    const int64_t m = m0 + threadIdx.x;
+    if (m < M) {
+      float* myrow = tile + threadIdx.x * pitch;
+      float* sr = a.scratch + m * a.scratch_ld;
+      float lg[MAXNC], mid[MAXNM];
+      head_features<NCc, NMc, Lc, GEN>(myrow, w_seg, w_l1, F, NC, NM, L > 0, lg, mid);
+      const int64_t n = m / HW, pp = m - n * HW;
+      // cat tail: logits then zero pad (16-byte stores: the scratch row is 16-byte aligned, every block a multiple of 4)
 #pragma unroll
-    for (int c = 0; c < MAXNC; ++c) sr[F + c] = (c < NC) ? lg[c] : 0.f;
-    for (int c = F + MAXNC; c < Fc; ++c) sr[c] = 0.f;
-    // landmark branch
-    float dmid[MAXNM], dh[MAXL];
+      for (int c = 0; c < MAXNC; c += 4)
+        *reinterpret_cast<float4*>(sr + F + c) = make_float4(c + 0 < NC ? lg[c + 0] : 0.f, c + 1 < NC ? lg[c + 1] : 0.f,
+                                                             c + 2 < NC ? lg[c + 2] : 0.f, c + 3 < NC ? lg[c + 3] : 0.f);
+      for (int c = F + MAXNC; c < Fc; c += 4) *reinterpret_cast<float4*>(sr + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+      // landmark branch
+      float dmid[MAXNM], dh[MAXL];
 #pragma unroll
-    for (int l = 0; l < MAXL; ++l) dh[l] = (lands && l < L) ? a.dheat[(n * L + l) * HW + pp] : 0.f;
+      for (int l = 0; l < MAXL; ++l) dh[l] = (lands && l < L) ? a.dheat[(n * L + l) * HW + pp] : 0.f;
 #pragma unroll
-    for (int j = 0; j < MAXNM; ++j) {
-      float acc = 0.f;
-      if (lands && j < NM) {
-        if (w_l2 != nullptr) {
+      for (int j = 0; j < MAXNM; ++j) {
+        float acc = 0.f;
+        if (lands && j < NM) {
+          if (w_l2 != nullptr) {
 #pragma unroll
-          for (int l = 0; l < MAXL; ++l)
-            if (l < L) acc = fmaf(w_l2[l * NM + j], dh[l], acc);
-        } else {
-          acc = (j < MAXL) ? dh[j < MAXL ? j : 0] : 0.f;
-        }
-      }
-      dmid[j] = acc;
-    }
-    // logits gradient: through cat (landmark branch) + through softmax (seg branch)
-    float dlg[MAXNC];
-    float dot = 0.f;
-#pragma unroll
-    for (int c = 0; c < MAXNC; ++c) {
-      float g = 0.f, s = 0.f;
-      if (c < NC) {
-        g = a.dseg[(n * NC + c) * HW + pp];
-        s = a.seg[(n * NC + c) * HW + pp];
-      }
-      dlg[c] = g;      // provisional: upstream gradient
-      lg[c] = s;       // reuse lg for the softmax output
-      dot = fmaf(g, s, dot);
-    }
-#pragma unroll
-    for (int c = 0; c < MAXNC; ++c) {
-      float v = 0.f;
-      if (c < NC) {
-        v = a.softmax ? lg[c] * (dlg[c] - dot) : dlg[c];
-        if (lands) {
-#pragma unroll
-          for (int j = 0; j < MAXNM; ++j)
-            if (j < NM) v = fmaf(w_l1[j * K1 + F + c], dmid[j], v);
-        }
-      }
-      dlg[c] = v;
-      sr[o_dlg + c] = v;
-    }
-#pragma unroll
-    for (int j = 0; j < MAXNM; ++j) {
-      sr[o_dmid + j] = dmid[j];
-      sr[o_mid + j] = (L > 0 && j < NM) ? mid[j] : 0.f;
-    }
-#pragma unroll
-    for (int l = 0; l < MAXL; ++l) sr[o_dh + l] = dh[l];
-    // dx = Wseg^T dlogits + W1[:, :F]^T dmid
-    float* dxr = a.dx + m * a.lddx;
-    for (int k = 0; k < F; k += 4) {
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int c = 0; c < MAXNC; ++c) {
-        if (c < NC) {
-          const float* w = w_seg + c * F + k;
-          acc.x = fmaf(w[0], dlg[c], acc.x); acc.y = fmaf(w[1], dlg[c], acc.y);
-          acc.z = fmaf(w[2], dlg[c], acc.z); acc.w = fmaf(w[3], dlg[c], acc.w);
-        }
-      }
-      if (lands) {
-#pragma unroll
-        for (int j = 0; j < MAXNM; ++j) {
-          if (j < NM) {
-            const float* w = w_l1 + j * K1 + k;
-            acc.x = fmaf(w[0], dmid[j], acc.x); acc.y = fmaf(w[1], dmid[j], acc.y);
-            acc.z = fmaf(w[2], dmid[j], acc.z); acc.w = fmaf(w[3], dmid[j], acc.w);
+            for (int l = 0; l < BL; ++l)
+              if (!GEN || l < L) acc = fmaf(w_l2[l * NM + j], dh[l], acc);
+          } else {
+            acc = (j < MAXL) ? dh[j < MAXL ? j : 0] : 0.f;
           }
         }
+        dmid[j] = acc;
       }
-      *reinterpret_cast<float4*>(dxr + k) = acc;
+      // logits gradient: through cat (landmark branch) + through softmax (seg branch)
+      float dlg[MAXNC];
+      float dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < MAXNC; ++c) {
+        float g = 0.f, sv = 0.f;
+        if (c < NC) {
+          g = a.dseg[(n * NC + c) * HW + pp];
+          sv = a.seg[(n * NC + c) * HW + pp];
+        }
+        dlg[c] = g;      // provisional: upstream gradient
+        lg[c] = sv;      // reuse lg for the softmax output
+        dot = fmaf(g, sv, dot);
+      }
+#pragma unroll
+      for (int c = 0; c < MAXNC; ++c) {
+        float v = 0.f;
+        if (c < NC) {
+          v = a.softmax ? lg[c] * (dlg[c] - dot) : dlg[c];
+          if (lands) {
+#pragma unroll
+            for (int j = 0; j < BNM; ++j)
+              if (!GEN || j < NM) v = fmaf(w_l1[j * K1 + F + c], dmid[j], v);
+          }
+        }
+        dlg[c] = v;
+      }
+#pragma unroll
+      for (int c = 0; c < MAXNC; c += 4)
+        *reinterpret_cast<float4*>(sr + o_dlg + c) = make_float4(dlg[c], dlg[c + 1], dlg[c + 2], dlg[c + 3]);
+#pragma unroll
+      for (int j = 0; j < MAXNM; j += 4) {
+        *reinterpret_cast<float4*>(sr + o_dmid + j) = make_float4(dmid[j], dmid[j + 1], dmid[j + 2], dmid[j + 3]);
+        const bool has = L > 0;
+        *reinterpret_cast<float4*>(sr + o_mid + j) = make_float4((has && j + 0 < NM) ? mid[j + 0] : 0.f, (has && j + 1 < NM) ? mid[j + 1] : 0.f,
+                                                                (has && j + 2 < NM) ? mid[j + 2] : 0.f, (has && j + 3 < NM) ? mid[j + 3] : 0.f);
+      }
+#pragma unroll
+      for (int l = 0; l < MAXL; l += 4) *reinterpret_cast<float4*>(sr + o_dh + l) = make_float4(dh[l], dh[l + 1], dh[l + 2], dh[l + 3]);
+      // dx = Wseg^T dlogits + W1[:, :F]^T dmid, into this thread's own tile row (x is no longer needed)
+      for (int k = 0; k < F; k += 4) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < BNC; ++c) {
+          if (!GEN || c < NC) {
+            const float* w = w_seg + c * F + k;
+            acc.x = fmaf(w[0], dlg[c], acc.x); acc.y = fmaf(w[1], dlg[c], acc.y);
+            acc.z = fmaf(w[2], dlg[c], acc.z); acc.w = fmaf(w[3], dlg[c], acc.w);
+          }
+        }
+        if (lands) {
+#pragma unroll
+          for (int j = 0; j < BNM; ++j) {
+            if (!GEN || j < NM) {
+              const float* w = w_l1 + j * K1 + k;
+              acc.x = fmaf(w[0], dmid[j], acc.x); acc.y = fmaf(w[1], dmid[j], acc.y);
+              acc.z = fmaf(w[2], dmid[j], acc.z); acc.w = fmaf(w[3], dmid[j], acc.w);
+            }
+          }
+        }
+        *reinterpret_cast<float4*>(myrow + k) = acc;
+      }
+    }
+    __syncthreads();
+    const int fq = F / 4;   // cooperative, coalesced store of the dx tile
+    for (int e = threadIdx.x; e < HT * fq; e += HT) {
+      const int p = e / fq, q = e - p * fq;
+      if (m0 + p < M) *reinterpret_cast<float4*>(a.dx + (m0 + p) * a.lddx + 4 * q) = *reinterpret_cast<const float4*>(tile + p * pitch + 4 * q);
     }
   }
 }
@@ -255,8 +313,12 @@ extern "C" int dfl_head_fwd(const dfl_head_fwd_args* a, dfl_stream_t stream) {
   if (rc != DFL_OK) return rc;
   DFL_REQUIRE(a->L == 0 || a->heat != nullptr, "dfl_head_fwd: heat output required when L > 0");
   const int64_t M = (int64_t)a->N * a->H * a->W;
-  hipLaunchKernelGGL(head_fwd_kernel, dim3(head_grid(M)), dim3(256), 0, static_cast<hipStream_t>(stream), *a, a->w_seg,
-                     a->w_l1, a->w_l2);
+#define DFL_HF(NC_, NM_, L_, G_) hipLaunchKernelGGL((head_fwd_kernel<NC_, NM_, L_, G_>), dim3(head_grid(M)), dim3(HT), \
+    (size_t)HT * (a->F + 4) * sizeof(float), static_cast<hipStream_t>(stream), *a, a->w_seg, a->w_l1, a->w_l2)
+  if (a->NC == 7 && a->L == 14 && a->NM == 21 && a->w_l2 != nullptr) DFL_HF(7, 21, 14, false);
+  else if (a->NC == 7 && a->L == 0) DFL_HF(7, 0, 0, false);
+  else DFL_HF(0, 0, 0, true);
+#undef DFL_HF
   return check_launch("dfl_head_fwd");
 }
 
@@ -269,7 +331,11 @@ extern "C" int dfl_head_bwd(const dfl_head_bwd_args* a, dfl_stream_t stream) {
   DFL_REQUIRE(a->scratch_ld >= dfl_head_scratch_ld(a->F) && a->scratch_ld % 4 == 0 && aligned16(a->scratch),
               "dfl_head_bwd: scratch_ld too small or misaligned");
   const int64_t M = (int64_t)a->N * a->H * a->W;
-  hipLaunchKernelGGL(head_bwd_kernel, dim3(head_grid(M)), dim3(256), 0, static_cast<hipStream_t>(stream), *a,
-                     head_fc(a->F), a->w_seg, a->w_l1, a->w_l2);
+#define DFL_HB(NC_, NM_, L_, G_) hipLaunchKernelGGL((head_bwd_kernel<NC_, NM_, L_, G_>), dim3(head_grid(M)), dim3(HT), \
+    (size_t)HT * (a->F + 4) * sizeof(float), static_cast<hipStream_t>(stream), *a, head_fc(a->F), a->w_seg, a->w_l1, a->w_l2)
+  if (a->NC == 7 && a->L == 14 && a->NM == 21 && a->w_l2 != nullptr) DFL_HB(7, 21, 14, false);
+  else if (a->NC == 7 && a->L == 0) DFL_HB(7, 0, 0, false);
+  else DFL_HB(0, 0, 0, true);
+#undef DFL_HB
   return check_launch("dfl_head_bwd");
 }
