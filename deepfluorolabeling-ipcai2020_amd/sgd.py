@@ -88,4 +88,8 @@ class SGD(Optimizer):
             # the kernel wrote behind autograd's back: bump the version counters like an in-place torch op would (the
             # network re-packs its weights when they move, and autograd must see saved tensors as modified)
             torch.autograd.graph.increment_version(live)
+            from .unet import owner_of
+            net = owner_of(live[0])
+            if net is not None:
+                net.prepack()            # next step's weight re-layout starts now, behind the update kernels
         return loss

@@ -7,6 +7,8 @@ contract (``seg`` or ``(seg, heat_maps)``, unet.py:183-193) and ordinary autogra
 replays a recorded program of hand-written HIP kernels from ``libdfl_hip.so`` (see ``plan.py``, ``include/dfl_hip.h``);
 the sub-modules below only own the parameters.  There is no CPU or eager fallback: tensors must live on the GPU.
 """
+import weakref
+
 import torch
 from torch import nn
 
@@ -56,6 +58,15 @@ class UNetUpBlock(nn.Module):
         self.conv_block = UNetConvBlock(in_size, out_size, padding, batch_norm, pad_mode, do_res, block_depth)
 
     forward = _no_forward('UNetUpBlock')
+
+
+_NETS = weakref.WeakValueDictionary()     # id(net) -> net, for parameters to find their network (plain ints pickle)
+
+
+def owner_of(param):
+    """The UNet a parameter belongs to, or None."""
+    net = _NETS.get(getattr(param, '_dfl_net_id', None))
+    return net if net is not None and any(param is q for q in net.parameters()) else None
 
 
 class _UNetFn(torch.autograd.Function):
@@ -160,6 +171,7 @@ class UNet(nn.Module):
         self._plans = {}
         self._param_list = None
         self._pack_version = None
+        self._last_train_plan = None
         self._backward_runner = self._run_backward
         self.dp = None                                # set by parallel.DataParallel
         self.direct_grad = True                       # install gradient views as .grad without autograd copies
@@ -191,6 +203,21 @@ class UNet(nn.Module):
                 p.data = v
                 off += (n + 3) // 4 * 4
         self._param_flat = flat
+        _NETS[id(self)] = self
+        for p in ps:
+            p._dfl_net_id = id(self)   # lets sgd.SGD start the next step's weight re-layout right behind its update
+
+    def __getstate__(self):
+        """Recorded programs hold raw device addresses and ctypes structures: they are rebuilt on demand, not pickled."""
+        d = self.__dict__.copy()
+        d['_plans'], d['_param_list'], d['_pack_version'], d['_last_train_plan'] = {}, None, None, None
+        d['_backward_runner'], d['dp'] = None, None
+        return d
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
+        self._backward_runner = self._run_backward
+        self._flatten_parameters()
 
     def invalidate_plans(self):
         """Forget recorded programs (they hold raw parameter addresses)."""
@@ -230,6 +257,17 @@ class UNet(nn.Module):
             raise RuntimeError(str(e))
         plans.append(plan)
         return plan
+
+    def prepack(self):
+        """Enqueue the weight re-layout of the plan the last training forward used (no-op when nothing changed).  Called
+        by sgd.SGD.step(): the GPU then packs while the host is still in loss.item() / zero_grad() / forward()'s
+        bookkeeping instead of idling until the next forward's first launch (~0.14 ms per step)."""
+        plan = self._last_train_plan() if self._last_train_plan is not None else None
+        if plan is None or self._param_list is None or not any(plan is q for ps in self._plans.values() for q in ps):
+            return
+        if plan.math != nat.lib().dfl_get_math_mode():
+            return
+        self._ensure_packed(plan, torch.cuda.current_stream(plan.dev).cuda_stream)
 
     def _ensure_packed(self, plan, stream):
         ver = sum(p._version for p in self._weight_params)
@@ -276,4 +314,5 @@ class UNet(nn.Module):
             return (seg, heat) if heat is not None else seg
         plan.busy = True
         plan.generation += 1
+        self._last_train_plan = weakref.ref(plan)
         return _UNetFn.apply(self, plan, x, *self._param_list)

@@ -117,3 +117,28 @@ def test_dataset_refuses_cpu_and_pad_arithmetic():
     assert D.calc_pad_amount(193, 180) == int(g['pad_193_180'])
     with pytest.raises(nat.DflError):
         D.DeviceDataSet(torch.zeros(1, 1, 8, 8), torch.zeros(1, 8, 8, dtype=torch.uint8), num_classes=2, device='cpu')
+
+
+def test_module_copies_and_pickles_without_its_recorded_programs():
+    """deepcopy / torch.save(net) work (plans hold ctypes structures and raw addresses: they are dropped and rebuilt) and
+    every copy keeps its parameters in one arena that knows its owner (sgd.SGD's pre-pack hook)."""
+    import copy
+    import io
+    from dfl_amd.unet import owner_of
+    net = dfl_amd.UNet(1, n_classes=3, depth=2, wf=2, padding=True, batch_norm=True, max_pool=False)
+    P, B = net._state()
+    from dfl_amd.plan import UNetPlan
+    net._plans[('dummy',)] = [UNetPlan(net._cfg, P, B, 1, 16, 16, True, True, torch.device('cpu'))]
+    n2 = copy.deepcopy(net)
+    buf = io.BytesIO()
+    torch.save(net, buf)
+    buf.seek(0)
+    n3 = torch.load(buf, weights_only=False)
+    for m in (n2, n3):
+        assert m._plans == {} and m._param_flat is not None
+        assert owner_of(next(m.parameters())) is m
+        for a, b in zip(net.state_dict().values(), m.state_dict().values()):
+            assert torch.equal(a, b)
+        base = m._param_flat.data_ptr()
+        assert all(base <= p.data_ptr() < base + 4 * m._param_flat.numel() for p in m.parameters())
+    assert owner_of(next(net.parameters())) is net
