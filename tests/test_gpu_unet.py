@@ -384,3 +384,51 @@ def test_fused_sgd_refuses_cpu():
     p.grad = torch.ones(4)
     with pytest.raises(nat.DflError):
         dfl_amd.SGD([p], lr=0.1).step()
+
+
+@pytest.mark.parametrize('max_pool', [False, True])
+@pytest.mark.parametrize('hw', [(50, 70), (37, 41), (64, 96)])
+def test_ragged_sizes_match_oracle(hw, max_pool, math_mode):
+    """Image sizes that do not divide by 2^depth (the decoder crops the bridges, unet.py:248-257) and batch 3, padded
+    mode, both down-sampling flavours: forward, loss and gradients against the oracle."""
+    H, W = hw
+    cfg = dict(n_classes=5, depth=3, wf=4, batch_norm=True, padding=True, max_pool=max_pool, num_lands=6, do_res=True,
+               block_depth=2)
+    torch.manual_seed(31 + H)
+    onet = R.OracleUNet(1, **cfg)
+    try:
+        with torch.no_grad():
+            onet(torch.zeros(1, 1, H, W))
+    except Exception:
+        pytest.skip('the reference architecture itself rejects %dx%d' % (H, W))
+    net = dfl_amd.UNet(1, **cfg)
+    net.load_state_dict(onet.state_dict())
+    net = net.to(DEV)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 1, H, W, generator=g)
+    net.train()
+    onet.train()
+    oseg, oheat = onet(x)
+    seg, heat = net(x.to(DEV))
+    assert seg.shape == oseg.shape and heat.shape == oheat.shape
+    np.testing.assert_allclose(seg.detach().cpu().numpy(), oseg.detach().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(heat.detach().cpu().numpy(), oheat.detach().numpy(), rtol=1e-4,
+                               atol=1e-4 * float(oheat.detach().abs().max()))
+    ho, wo = oseg.shape[-2:]
+    tseg = torch.softmax(torch.randn(3, 5, ho - 2, wo - 2, generator=g), 1)
+    theat = torch.rand(3, 6, ho - 2, wo - 2, generator=g) * 0.02
+    crit = dfl_amd.DiceAndHeatMapLoss2D(skip_bg=False, heatmap_wgt=0.5)
+    loss = crit((dfl_amd.center_crop(seg, tseg.shape), dfl_amd.center_crop(heat, theat.shape)), (tseg.to(DEV), theat.to(DEV)))
+    oloss = R.dice_and_heatmap_loss_2d((R.center_crop(oseg, tseg.shape), R.center_crop(oheat, theat.shape)), (tseg, theat),
+                                       skip_bg=False, heatmap_wgt=0.5)
+    assert abs(loss.item() - oloss.item()) < 1e-5
+    loss.backward()
+    oloss.backward()
+    num = den = 0.0
+    for (k, p), (_, q) in zip(net.named_parameters(), onet.named_parameters()):
+        if q.grad is None:
+            assert p.grad is None, k
+            continue
+        num += float((p.grad.cpu().double() - q.grad.double()).pow(2).sum())
+        den += float(q.grad.double().pow(2).sum())
+    assert (num / den) ** 0.5 <= by_mode(math_mode, 5e-3, 5e-2), 'whole-gradient relative L2 error %.3e' % (num / den) ** 0.5
