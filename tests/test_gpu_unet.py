@@ -432,3 +432,51 @@ def test_ragged_sizes_match_oracle(hw, max_pool, math_mode):
         num += float((p.grad.cpu().double() - q.grad.double()).pow(2).sum())
         den += float(q.grad.double().pow(2).sum())
     assert (num / den) ** 0.5 <= by_mode(math_mode, 5e-3, 5e-2), 'whole-gradient relative L2 error %.3e' % (num / den) ** 0.5
+
+
+def test_training_quality_is_the_same_with_split_bf16_products():
+    """North-star quality bar (Dice within +-0.005 of the reference): 400 SGD steps on the toy-ellipses set with fp32
+    products and with bf16x3 products from the same initial weights -- final loss and mean hard Dice agree, i.e. the
+    2^-16 product noise does not change what the network learns."""
+    g = load_golden('trajectory')
+    cfg = dict(n_classes=7, depth=3, wf=3, batch_norm=True, padding=True, max_pool=False, num_lands=14, do_res=True,
+               block_depth=2)
+    projs, segs, lands = _t(g['projs']), _t(g['segs']), _t(g['lands'])
+    H, W = projs.shape[-2:]
+    lm = R.mark_oob_landmarks(lands, H, W)
+    pad = R.calc_pad_amount(48, W)
+    P = torch.stack([R.preprocess_proj(projs[i:i + 1], pad) for i in range(8)]).to(DEV)
+    S = R.one_hot_masks(segs, 7).to(DEV)
+    Hm = torch.stack([R.gaussian_heatmaps(lm[i], H, W) for i in range(8)]).view(8, 14, H, W).to(DEV)
+    crit = dfl_amd.DiceAndHeatMapLoss2D(skip_bg=False, heatmap_wgt=0.5)
+    lib = nat.lib()
+    res = {}
+    for mode in (0, 1):
+        nat.check(lib.dfl_set_math_mode(mode), 'dfl_set_math_mode')
+        try:
+            net = load_net(g, cfg)
+            opt = dfl_amd.SGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4, nesterov=True)
+            net.train()
+            tail = []
+            for step in range(400):
+                idx = [(step * 4 + j) % 8 for j in range(4)]
+                opt.zero_grad()
+                out = net(P[idx])
+                loss = crit((dfl_amd.center_crop(out[0], S[idx].shape), dfl_amd.center_crop(out[1], Hm[idx].shape)), (S[idx], Hm[idx]))
+                loss.backward()
+                opt.step()
+                if step >= 380:
+                    tail.append(loss.item())
+            net.eval()
+            with torch.no_grad():
+                out = net(P)
+            labels = torch.max(dfl_amd.center_crop(out[0], S.shape), dim=1)[1]
+            from dfl_amd import util
+            dice = util.hard_dice(labels, segs.to(DEV), 7).mean().item()
+            res[mode] = (float(np.mean(tail)), dice)
+        finally:
+            nat.check(lib.dfl_set_math_mode(0), 'dfl_set_math_mode')
+    (l32, d32), (l3, d3) = res[0], res[1]
+    assert l32 < float(g['losses'][0]) - 0.2                     # it did train
+    assert abs(l32 - l3) < 1e-2, (l32, l3)
+    assert abs(d32 - d3) < 0.005, (d32, d3)
