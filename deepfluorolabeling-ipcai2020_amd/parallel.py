@@ -79,6 +79,8 @@ class DataParallel:
         self.overlap = overlap
         self._seg_cache = {}
         self.comm_stream = None
+        # RCCL averages inside the collective (ReduceOp.AVG); gloo (CPU tests, single-GPU self-test) sums, then we scale
+        self._avg_in_collective = dist.is_initialized() and dist.get_backend(process_group) == 'nccl'
         if self.world > 1:
             with torch.no_grad():
                 for t in list(net.parameters()) + list(net.buffers()):
@@ -108,6 +110,13 @@ class DataParallel:
         self._seg_cache[key] = seg
         return seg
 
+    def _reduce(self, view, inv):
+        if self._avg_in_collective:
+            dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(view, group=self.group)
+            view.mul_(inv)
+
     def _run_backward(self, plan, stream):
         if self.world == 1:
             plan.bwd.run(stream)
@@ -119,9 +128,7 @@ class DataParallel:
             for op_start, op_count, ranges in self._segments(plan):
                 plan.bwd.run(stream, op_start, op_count)
                 for s, e in ranges:
-                    view = flat[s:e]
-                    dist.all_reduce(view, group=self.group)
-                    view.mul_(inv)
+                    self._reduce(flat[s:e], inv)
             return
         cur = torch.cuda.current_stream()
         if self.comm_stream is None:
@@ -135,7 +142,5 @@ class DataParallel:
                 with torch.cuda.stream(comm):
                     comm.wait_event(ev)
                     for s, e in ranges:
-                        view = flat[s:e]
-                        dist.all_reduce(view, group=self.group)
-                        view.mul_(inv)
+                        self._reduce(flat[s:e], inv)
         cur.wait_stream(comm)
