@@ -80,7 +80,14 @@ class DataParallel:
         self._seg_cache = {}
         self.comm_stream = None
         # RCCL averages inside the collective (ReduceOp.AVG); gloo (CPU tests, single-GPU self-test) sums, then we scale
-        self._avg_in_collective = dist.is_initialized() and dist.get_backend(process_group) == 'nccl'
+        self._avg_in_collective = False
+        if self.world > 1 and dist.get_backend(process_group) == 'nccl':
+            try:                                   # probe once (collective: every rank takes the same branch)
+                probe = torch.ones(1, device=next(net.parameters()).device)
+                dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=process_group)
+                self._avg_in_collective = abs(float(probe.item()) - 1.0) < 1e-6
+            except Exception:
+                self._avg_in_collective = False
         if self.world > 1:
             with torch.no_grad():
                 for t in list(net.parameters()) + list(net.buffers()):
