@@ -65,9 +65,13 @@ constexpr int conv_occ(int tiles) { return tiles >= 4 ? 2 : (tiles == 2 ? 4 : 5)
 template <int WM, int WN, int TM, int TN, int MODE, bool AFF, int EPI, int MATH>
 __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kernel(const ConvK p) {
   static_assert(MATH == 0 || MODE == 1, "the split-bf16 product exists for the fast gather only");
+  // MATH 3 / 4 = bf16x3 with operand formats fixed at compile time (the loop body then is one basic block the scheduler
+  // can interleave): 3 = weights arrive as split quads, the gathered operand is split here; 4 = both arrive split.
+  constexpr bool WPRE = (MATH == 3 || MATH == 4), XPRE = (MATH == 4);
+  static_assert(!(XPRE && AFF), "a split input cannot take an affine on load");
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int NP = MATH == 0 ? 0 : MATH + 1;                  // bf16 parts per value
+  constexpr int NP = MATH == 0 ? 0 : (MATH == 2 ? 3 : 2);       // bf16 parts per value
   constexpr int LDK = (MATH == 2) ? 28 : KC + 4;  // row pitch (words) of both LDS images (80 / 112 B: conflict-free b128 reads)
   constexpr int RPP = NT / 4;  // pixel rows covered per pass of the A gather
   constexpr int QA = BM / RPP;
@@ -278,7 +282,7 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
       }
       if constexpr (MATH != 0) {
         uint2 parts[NP];
-        if (MATH == 1 && a.x_split) {   // the producer already left hi4 | lo4 in the slot (wave uniform)
+        if (XPRE || (MATH == 1 && a.x_split)) {   // the producer already left hi4 | lo4 in the slot (wave uniform)
           parts[0] = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));
           parts[1] = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
         } else {
@@ -298,7 +302,7 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
         const int kq = idx / BN, nn = idx - kq * BN;
         if constexpr (MATH != 0) {
           uint2 parts[NP];
-          if (MATH == 1 && a.w_split) {
+          if (WPRE || (MATH == 1 && a.w_split)) {
             const float4 v = rb[set][r];
             parts[0] = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));
             parts[1] = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
@@ -365,6 +369,28 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
     }
   };
 
+  // One-tile waves with compile-time operand formats and no affine: the half-iteration is one basic block, and the
+  // scheduler is told to put the LDS writes of the next chunk (which do not depend on the matrix instructions) in front
+  // of / between them instead of behind them: a wave's serial chain per chunk gets shorter (the loop is chain-bound).
+  constexpr bool HINTED = WPRE && !AFF && TM * TN == 1 && (NQB % NT == 0);
+  auto sched_hint = [&]() {
+    if constexpr (HINTED) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);        // the 4 fragment reads
+      if constexpr (XPRE) {
+        __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);      // both LDS writes (pure copies)
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);      // the 3 matrix instructions
+      } else {
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // weights: pure copy
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);      // split of the gathered operand, in two halves
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+    }
+  };
+
   load_AB(ch_begin, 0);
   load_AB(ch_begin + 1, 1);
   store_AB(0, 0);
@@ -394,16 +420,18 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
     __builtin_amdgcn_sched_barrier(0);
     compute(0);
     TR_MARK(0)   // loads issued + LDS fragment reads + matrix instructions issued
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!HINTED) __builtin_amdgcn_sched_barrier(0);
     store_AB(1, 1);
+    sched_hint();
     TR_MARK(1)   // split / affine + LDS writes
     __syncthreads();
     TR_MARK(2)   // barrier
     load_AB(ch + 3, 1);
     __builtin_amdgcn_sched_barrier(0);
     compute(1);
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!HINTED) __builtin_amdgcn_sched_barrier(0);
     store_AB(0, 0);
+    sched_hint();
     __syncthreads();
   }
 
@@ -752,6 +780,12 @@ static int launch(const ConvK& k, hipStream_t s) {
 template <int WM, int WN, int TM, int TN>
 static int launch_fast(const ConvK& k, bool aff, bool general, hipStream_t s) {
   if (math_mode() == 1) {
+    if (k.a.w_split && k.a.x_split)   // (never with an affine: checked by the caller)
+      return general ? launch<WM, WN, TM, TN, 1, false, 1, 4>(k, s) : launch<WM, WN, TM, TN, 1, false, 0, 4>(k, s);
+    if (k.a.w_split && !k.a.x_split) {
+      if (aff) return general ? launch<WM, WN, TM, TN, 1, true, 1, 3>(k, s) : launch<WM, WN, TM, TN, 1, true, 0, 3>(k, s);
+      return general ? launch<WM, WN, TM, TN, 1, false, 1, 3>(k, s) : launch<WM, WN, TM, TN, 1, false, 0, 3>(k, s);
+    }
     if (aff) return general ? launch<WM, WN, TM, TN, 1, true, 1, 1>(k, s) : launch<WM, WN, TM, TN, 1, true, 0, 1>(k, s);
     return general ? launch<WM, WN, TM, TN, 1, false, 1, 1>(k, s) : launch<WM, WN, TM, TN, 1, false, 0, 1>(k, s);
   }
