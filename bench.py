@@ -29,7 +29,7 @@ PAPER = dict(n_classes=7, depth=6, wf=5, batch_norm=True, padding=True, max_pool
 F32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0        # same guide: dense bf16 MFMA (the 5 PF marketing figure is 2:1 sparse)
 # product arithmetic of the GEMM kernels (include/dfl_hip.h): name -> (mode, bf16 MFMA products per fp32 product)
-MATH = {'fp32': (0, 0), 'bf16x3': (1, 3), 'bf16x6': (2, 6)}
+MATH = {'fp32': (0, 0), 'bf16x3': (1, 3), 'bf16x6': (2, 6), 'bf16': (3, 1)}
 CONV_KERNELS = ['conv_gemm_kernel<2,2,2,2>', 'conv_gemm_kernel<2,2,2,1>', 'conv_gemm_kernel<4,1,2,1>',
                 'conv_gemm_kernel<2,2,1,1>', 'conv_gemm_kernel<1,2,1,1>', 'direct_conv_kernel']
 WGRAD_KERNELS = ['wgrad_kernel<2,2,2,2,1>', 'wgrad_kernel<2,2,1,1,1>', 'wgrad_kernel<1,1,1,1,3>',
@@ -242,6 +242,18 @@ def main():
         torch.cuda.synchronize()
         d32 = time.perf_counter() - t0
         extra['fp32_products'] = {'value': round(B * n32 / d32, 2), 'ms_per_step': round(d32 / n32 * 1e3, 3), 'steps': n32}
+        if args.math != 'bf16':
+            # ... and with plain bf16 products (the arithmetic BASELINE configs[1] names; outside the 1e-4 forward bar)
+            nat.check(lib.dfl_set_math_mode(3), 'dfl_set_math_mode')
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n32):
+                step()
+            torch.cuda.synchronize()
+            d16 = time.perf_counter() - t0
+            extra['bf16_products'] = {'value': round(B * n32 / d16, 2), 'ms_per_step': round(d16 / n32 * 1e3, 3), 'steps': n32}
         nat.check(lib.dfl_set_math_mode(MATH[args.math][0]), 'dfl_set_math_mode')
 
     cpu = None

@@ -71,7 +71,9 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
   static_assert(!(XPRE && AFF), "a split input cannot take an affine on load");
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int NP = MATH == 0 ? 0 : (MATH == 2 ? 3 : 2);       // bf16 parts per value
+  // MATH 5 = plain bf16 products (mode 3): one part, one matrix instruction per 16 k-values; split operands are read
+  // through their hi halves.
+  constexpr int NP = MATH == 0 ? 0 : (MATH == 2 ? 3 : (MATH == 5 ? 1 : 2));       // bf16 parts per value
   constexpr int LDK = (MATH == 2) ? 28 : KC + 4;  // row pitch (words) of both LDS images (80 / 112 B: conflict-free b128 reads)
   constexpr int RPP = NT / 4;  // pixel rows covered per pass of the A gather
   constexpr int QA = BM / RPP;
@@ -282,9 +284,9 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
       }
       if constexpr (MATH != 0) {
         uint2 parts[NP];
-        if (XPRE || (MATH == 1 && a.x_split)) {   // the producer already left hi4 | lo4 in the slot (wave uniform)
+        if (XPRE || ((MATH == 1 || MATH == 5) && a.x_split)) {   // the producer already left hi4 | lo4 in the slot (wave uniform)
           parts[0] = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));
-          parts[1] = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
+          if constexpr (NP > 1) parts[1] = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
         } else {
           split_bf16<NP>(v, parts);
         }
@@ -302,10 +304,10 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
         const int kq = idx / BN, nn = idx - kq * BN;
         if constexpr (MATH != 0) {
           uint2 parts[NP];
-          if (WPRE || (MATH == 1 && a.w_split)) {
+          if (WPRE || ((MATH == 1 || MATH == 5) && a.w_split)) {
             const float4 v = rb[set][r];
             parts[0] = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));
-            parts[1] = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
+            if constexpr (NP > 1) parts[1] = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
           } else {
             split_bf16<NP>(rb[set][r], parts);
           }
@@ -789,6 +791,10 @@ static int launch_fast(const ConvK& k, bool aff, bool general, hipStream_t s) {
     if (aff) return general ? launch<WM, WN, TM, TN, 1, true, 1, 1>(k, s) : launch<WM, WN, TM, TN, 1, true, 0, 1>(k, s);
     return general ? launch<WM, WN, TM, TN, 1, false, 1, 1>(k, s) : launch<WM, WN, TM, TN, 1, false, 0, 1>(k, s);
   }
+  if (math_mode() == 3) {
+    if (aff) return general ? launch<WM, WN, TM, TN, 1, true, 1, 5>(k, s) : launch<WM, WN, TM, TN, 1, true, 0, 5>(k, s);
+    return general ? launch<WM, WN, TM, TN, 1, false, 1, 5>(k, s) : launch<WM, WN, TM, TN, 1, false, 0, 5>(k, s);
+  }
   if (math_mode() == 2) {
     if (aff) return general ? launch<WM, WN, TM, TN, 1, true, 1, 2>(k, s) : launch<WM, WN, TM, TN, 1, true, 0, 2>(k, s);
     return general ? launch<WM, WN, TM, TN, 1, false, 1, 2>(k, s) : launch<WM, WN, TM, TN, 1, false, 0, 2>(k, s);
@@ -902,8 +908,8 @@ extern "C" int dfl_conv2d(const dfl_conv_args* a, dfl_stream_t stream) {
     k.cps = (int)dfl::ceil_div(nchunks, a->splits);
   }
   if (a->w_split || a->x_split) {
-    DFL_REQUIRE(k.fast && dfl::math_mode() == 1 && !dfl::direct_conv_ok(a),
-                "dfl_conv2d: split operands need math mode 1 (bf16x3) and the fast path (Cin %% 16 == 0, aligned, < 2 GiB)");
+    DFL_REQUIRE(k.fast && (dfl::math_mode() == 1 || dfl::math_mode() == 3) && !dfl::direct_conv_ok(a),
+                "dfl_conv2d: split operands need math mode 1 or 3 (bf16x3 / bf16) and the fast path (Cin %% 16 == 0, aligned, < 2 GiB)");
     DFL_REQUIRE(!a->x_split || a->in_scale == nullptr, "dfl_conv2d: a split input cannot take an affine on load");
   }
   const bool general = a->add != nullptr || a->accumulate || a->scatter2x2 || (a->stat_other != nullptr && !k.so_simple);

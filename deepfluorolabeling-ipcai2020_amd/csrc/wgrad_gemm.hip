@@ -63,7 +63,8 @@ __device__ __forceinline__ bf16x8_t tr_read8(const float* row0, int row_words) {
 template <int WM, int WN, int TM, int TN, int TPB, bool FAST, int WS, int MATH>
 __global__ void __launch_bounds__(WM* WN * 64 * WS, wg_occ(TM* TN* TPB, FAST)) wgrad_kernel(const WgK p) {
   static_assert(WS == 1 || WM * WN == 1, "pixel-interleaved waves only for one-wave tiles");
-  static_assert(MATH == 0 || (MATH == 1 && FAST), "split-bf16 products exist for the fast path only");
+  static_assert(MATH == 0 || ((MATH == 1 || MATH == 2) && FAST), "split-bf16 products exist for the fast path only");
+  constexpr int NPW = MATH == 2 ? 1 : 2;   // MATH 2 = plain bf16 products (mode 3): hi parts only
   constexpr int NT = WM * WN * 64;   // threads of one tile (the "virtual workgroup" all staging indices refer to)
   constexpr int BMc = WM * TM * 32, BNg = WN * TN * 32;
   constexpr int LDD = BMc + (MATH ? 8 : 4), LDG = BNg + (MATH ? 8 : 4);   // words per staged pixel row
@@ -221,16 +222,16 @@ __global__ void __launch_bounds__(WM* WN * 64 * WS, wg_occ(TM* TN* TPB, FAST)) w
           v.z = okD[r][2] ? v.z : 0.f;
           v.w = okD[r][3] ? v.w : 0.f;
         }
-        if constexpr (MATH == 1) {
+        if constexpr (MATH != 0) {
           uint2 parts[2];
           if (a.d_split) {   // the producer already left hi4 | lo4 in the slot (wave uniform)
             parts[0] = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));
             parts[1] = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
           } else {
-            split_bf16<2>(v, parts);
+            split_bf16<NPW>(v, parts);
           }
           *reinterpret_cast<uint2*>(Db + pix * LDD + 2 * q) = parts[0];
-          *reinterpret_cast<uint2*>(Db + pix * LDD + BMc / 2 + 2 * q) = parts[1];
+          if constexpr (NPW > 1) *reinterpret_cast<uint2*>(Db + pix * LDD + BMc / 2 + 2 * q) = parts[1];
         } else {
           *reinterpret_cast<float4*>(Db + pix * LDD + 4 * q) = v;
         }
@@ -252,11 +253,11 @@ __global__ void __launch_bounds__(WM* WN * 64 * WS, wg_occ(TM* TN* TPB, FAST)) w
             v.z = (in && (FAST || g2)) ? fmaf(v.z, gsc.z, gsh.z) : 0.f;
             v.w = (in && (FAST || g3)) ? fmaf(v.w, gsc.w, gsh.w) : 0.f;
           }
-          if constexpr (MATH == 1) {
+          if constexpr (MATH != 0) {
             uint2 parts[2];
-            split_bf16<2>(v, parts);
+            split_bf16<NPW>(v, parts);
             *reinterpret_cast<uint2*>(Gb + (tt * KP + pix) * LDG + 2 * gq) = parts[0];
-            *reinterpret_cast<uint2*>(Gb + (tt * KP + pix) * LDG + BNg / 2 + 2 * gq) = parts[1];
+            if constexpr (NPW > 1) *reinterpret_cast<uint2*>(Gb + (tt * KP + pix) * LDG + BNg / 2 + 2 * gq) = parts[1];
           } else {
             *reinterpret_cast<float4*>(Gb + (tt * KP + pix) * LDG + 4 * gq) = v;
           }
@@ -285,7 +286,7 @@ __global__ void __launch_bounds__(WM* WN * 64 * WS, wg_occ(TM* TN* TPB, FAST)) w
     const bool more = (it + 1) < nit;
     if (more) load(ch + WS);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (MATH == 1) {
+    if constexpr (MATH != 0) {
       // this lane's transposing-read address inside a 32-channel tile: pixel row 8*lh + (lane&15)/4 (second read: +4),
       // channels 16*((lane>>4)&1) + 4*(lane&3) .. +3  (bf16: 2 per word)
       const int trow = 8 * lh + ((lane & 15) >> 2), tcw = 8 * ((lane >> 4) & 1) + 2 * (lane & 3);
@@ -295,20 +296,22 @@ __global__ void __launch_bounds__(WM* WN * 64 * WS, wg_occ(TM* TN* TPB, FAST)) w
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) dp[i][q] = tr_read8(Dt + i * 16 + q * (BMc / 2), LDD);
+        for (int q = 0; q < NPW; ++q) dp[i][q] = tr_read8(Dt + i * 16 + q * (BMc / 2), LDD);
 #pragma unroll
       for (int tt = 0; tt < TPB; ++tt) {
         bf16x8_t gp[TN][2];
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int q = 0; q < 2; ++q) gp[j][q] = tr_read8(Gt + tt * KP * LDG + j * 16 + q * (BNg / 2), LDG);
+          for (int q = 0; q < NPW; ++q) gp[j][q] = tr_read8(Gt + tt * KP * LDG + j * 16 + q * (BNg / 2), LDG);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j) {   // small terms first
-            acc[tt][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dp[i][1], gp[j][0], acc[tt][i][j], 0, 0, 0);
-            acc[tt][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dp[i][0], gp[j][1], acc[tt][i][j], 0, 0, 0);
+            if constexpr (NPW > 1) {
+              acc[tt][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dp[i][1], gp[j][0], acc[tt][i][j], 0, 0, 0);
+              acc[tt][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dp[i][0], gp[j][1], acc[tt][i][j], 0, 0, 0);
+            }
             acc[tt][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dp[i][0], gp[j][0], acc[tt][i][j], 0, 0, 0);
           }
       }
@@ -540,8 +543,17 @@ extern "C" int dfl_conv2d_wgrad(const dfl_wgrad_args* a, dfl_stream_t stream) {
   }
   k.cps = (int)dfl::ceil_div(k.nchunks, a->splits);
   const bool f = k.fast;
-  DFL_REQUIRE(!a->d_split || (f && dfl::math_mode() == 1 && !dfl::direct_wgrad_ok(a)),
-              "dfl_conv2d_wgrad: a split d needs math mode 1 (bf16x3) and the fast path");
+  DFL_REQUIRE(!a->d_split || (f && (dfl::math_mode() == 1 || dfl::math_mode() == 3) && !dfl::direct_wgrad_ok(a)),
+              "dfl_conv2d_wgrad: a split d needs math mode 1 or 3 (bf16x3 / bf16) and the fast path");
+  if (f && dfl::math_mode() == 3) {
+    switch (dfl::pick_wg(a)) {
+      case dfl::WG_128: return dfl::wg_launch<2, 2, 2, 2, 1, true, 2>(k, s);
+      case dfl::WG_64: return dfl::wg_launch<2, 2, 1, 1, 1, true, 2>(k, s);
+      case dfl::WG_ROW3: return dfl::wg_launch<1, 1, 1, 1, 3, true, 2>(k, s);
+      case dfl::WG_ROW2: return dfl::wg_launch<1, 1, 1, 1, 2, true, 2>(k, s);
+      default: return dfl::wg_launch<1, 1, 1, 1, 1, true, 2>(k, s);
+    }
+  }
   if (f && dfl::math_mode() == 1) {
     switch (dfl::pick_wg(a)) {
       case dfl::WG_128: return dfl::wg_launch<2, 2, 2, 2, 1, true, 1>(k, s);

@@ -98,7 +98,7 @@ class UNetPlan:
         # split quads (hi4 | lo4 bf16) when the consuming conv will take the split-bf16 fast path: its input channels
         # (B for a forward operand, A for the transposed ones) must be a multiple of 16 and K large enough for the GEMM
         cin = B if kind == 1 else A
-        split = int(self.math == 1 and cin % 16 == 0)
+        split = int(self.math in (1, 3) and cin % 16 == 0)
         self._packed_split[dst.data_ptr()] = split
         self._pack_jobs.append((w, dst, A, B, Cc, kind, flip, split))
         return dst
@@ -463,7 +463,7 @@ class UNetPlan:
                     inp = cv['inp']
                     # dpre feeds exactly two GEMMs (weight gradient: dense operand; data gradient: gathered operand);
                     # with split-bf16 products it is written split once here instead of being split by every tile of both
-                    dsplit = int(self.math == 1 and Cout % 16 == 0 and inp.C % 4 == 0 and inp.C * 9 > 12)
+                    dsplit = int(self.math in (1, 3) and Cout % 16 == 0 and inp.C % 4 == 0 and inp.C * 9 > 12)
                     bwd.add(BnReluBwdArgs(dy=g.ptr, r=r.ptr, coef=nat.ptr(coef), dpre=dpre.ptr,
                                           partials=bpart.data_ptr(), M=r.M, C=Cout, lddy=g.ld, ldr=r.ld, ldo=dpre.ld,
                                           nblocks=nb, split_out=dsplit))

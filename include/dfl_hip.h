@@ -410,6 +410,9 @@ int dfl_hard_dice(const unsigned char* est, const unsigned char* gt, int64_t pix
  *               -- 32x tighter than the TF32 products PyTorch uses for the reference on NVIDIA GPUs by default -- and
  *               ~1.8x the throughput of mode 0.  Forward outputs stay within the 1e-4 parity bar (measured 2e-5).
  *   2 "bf16x6"  three parts, six products: as exact as fp32 multiplication (convolutions only).
+ *   3 "bf16"    plain bf16 products (operands rounded to bf16, fp32 accumulation, fp32 tensors): 2^-9 per product; the
+ *               arithmetic BASELINE configs[1] names.  NOT inside the 1e-4 forward bar (measured ~1e-2); validated by
+ *               training quality (tests/test_gpu_unet.py).
  * Process-wide; initial value from the environment variable DFL_MATH, else DFL_MATH_DEFAULT.
  * ------------------------------------------------------------------------------------------------------------ */
 #define DFL_MATH_DEFAULT 0

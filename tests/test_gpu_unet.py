@@ -451,7 +451,7 @@ def test_training_quality_is_the_same_with_split_bf16_products():
     crit = dfl_amd.DiceAndHeatMapLoss2D(skip_bg=False, heatmap_wgt=0.5)
     lib = nat.lib()
     res = {}
-    for mode in (0, 1):
+    for mode in (0, 1, 3):
         nat.check(lib.dfl_set_math_mode(mode), 'dfl_set_math_mode')
         try:
             net = load_net(g, cfg)
@@ -476,7 +476,36 @@ def test_training_quality_is_the_same_with_split_bf16_products():
             res[mode] = (float(np.mean(tail)), dice)
         finally:
             nat.check(lib.dfl_set_math_mode(0), 'dfl_set_math_mode')
-    (l32, d32), (l3, d3) = res[0], res[1]
+    (l32, d32), (l3, d3), (lb, db) = res[0], res[1], res[3]
     assert l32 < float(g['losses'][0]) - 0.2                     # it did train
     assert abs(l32 - l3) < 1e-2, (l32, l3)
     assert abs(d32 - d3) < 0.005, (d32, d3)
+    # plain bf16 products (mode 3, the arithmetic BASELINE configs[1] names): same quality on this task
+    assert abs(l32 - lb) < 2e-2, (l32, lb)
+    assert abs(d32 - db) < 0.005, (d32, db)
+
+
+def test_plain_bf16_products_forward():
+    """Mode 3 (bf16 products, fp32 accumulate) is outside the 1e-4 bar by design; what it must keep: outputs within a few
+    1e-2 of the fp32-product run and the same labels except at small margins."""
+    seed, cfg = PAPER_CFGS['paper_sc_l14']
+    torch.manual_seed(seed)
+    net = dfl_amd.UNet(**cfg).to(DEV)
+    x = torch.randn(2, 1, 192, 192, generator=torch.Generator().manual_seed(3)).to(DEV)
+    net.eval()
+    lib = nat.lib()
+    outs = {}
+    for mode in (0, 3):
+        nat.check(lib.dfl_set_math_mode(mode), 'dfl_set_math_mode')
+        try:
+            with torch.no_grad():
+                outs[mode] = net(x)
+        finally:
+            nat.check(lib.dfl_set_math_mode(0), 'dfl_set_math_mode')
+    (s0, h0), (s3, h3) = outs[0], outs[3]
+    assert float((s0 - s3).abs().max()) < 5e-2
+    assert float((h0 - h3).abs().max()) < 5e-2 * float(h0.abs().max())
+    assert float((s0 - s3).abs().max()) > 1e-5                          # the mode really is in effect
+    top2 = s0.topk(2, dim=1)[0]
+    sure = (top2[:, 0] - top2[:, 1]) > 5e-2
+    assert bool((s0.argmax(1) == s3.argmax(1))[sure].all())
