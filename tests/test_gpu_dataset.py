@@ -134,3 +134,17 @@ def test_hard_dice_exact():
     assert int(counts[0, :, 0].sum()) == H * W and int(counts[0, :, 1].sum()) == H * W
     t = load_golden('trajectory')              # the value the reference pipeline produced for the toy run is a mean of these
     assert 'hard_dice' in t
+
+
+def test_end_to_end_example():
+    """examples/train_toy.py: loader -> two short trainings with warm restarts -> validation -> ensemble -> hard Dice ->
+    landmark extraction, all through the library; it must learn something in a few epochs."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('train_toy', os.path.join(os.path.dirname(__file__), '..', 'examples', 'train_toy.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.main(epochs=30, images=24, math='bf16x3', quiet=True)
+    first, last = res['train_loss_first_last']
+    assert last < first - 0.15, res
+    assert res['ensemble_mean_hard_dice'] > 0.2, res        # 24 random toy images do not generalise far; chance is ~0.1
+    assert res['landmarks_total'] == 8 * 14
