@@ -8,8 +8,13 @@
 //   * gather: each thread fetches float4s (4 channels of one pixel at one tap) of the [BM pixels][16] slab straight from
 //     the NHWC activation and float4s of the quad-packed weight slab, into registers, while the MFMAs of the previous
 //     chunk run out of LDS; afterwards the registers go to the other LDS buffer (one barrier per chunk).
-//   * LDS images are row-major ([BM][16+4], [BN][16+4]); a lane reads ONE b128 per operand and 8 k-values: lane (i, h)
-//     gets k = 8g+4h..8g+4h+3 of row i, component q feeds MFMA q (k-order inside a chunk is permuted, the set is not).
+//   * LDS images are planes of 32-byte rows: plane g of the fp32 image holds k = 8g..8g+7 of every row (two 16-byte
+//     units), plane q of a split-bf16 image the 16 values of part q; the two units of a row swap places when bit 3 of
+//     the row is set.  A lane reads ONE b128 per operand and 8 k-values: lane (i, h) gets unit h of row i (fp32: k =
+//     8g+4h..8g+4h+3, component c feeds MFMA c; the k-order inside a chunk is permuted, the set is not).  With that
+//     swap both the b128 fragment reads (16-lane groups {0-3,12-15,20-27}, ...) and the staging writes (b128: 2 rows x
+//     4 quads; b64: 4 rows x 4 quads per lane group) touch every bank once: no conflict cycles (the padded row-major
+//     layout this replaces spent a third of its LDS cycles on write conflicts, SQ_LDS_BANK_CONFLICT).
 //   * the matrix pipe issues one 32x32x2 per 64 cycles per SIMD and a SIMD has only ~12 other issue slots in that time
 //     (tools/exp/exp_mfma.cpp: the bare loop reaches 100-125 TFLOP/s), so the fast path (MODE 1) is written to spend as
 //     few VALU/SALU instructions per MFMA as possible:
@@ -74,16 +79,24 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
   // MATH 5 = plain bf16 products (mode 3): one part, one matrix instruction per 16 k-values; split operands are read
   // through their hi halves.
   constexpr int NP = MATH == 0 ? 0 : (MATH == 2 ? 3 : (MATH == 5 ? 1 : 2));       // bf16 parts per value
-  constexpr int LDK = (MATH == 2) ? 28 : KC + 4;  // row pitch (words) of both LDS images (80 / 112 B: conflict-free b128 reads)
+  constexpr int NPL = (MATH == 0) ? 2 : NP;                // planes per LDS image
+  constexpr int PLA = BM * 8 + 16, PLB = BN * 8 + 16;      // plane strides (words); +16: the two planes of a b128 write sit on different banks
+  constexpr int IMA = NPL * PLA, IMB = NPL * PLB;          // one image of each operand
   constexpr int RPP = NT / 4;  // pixel rows covered per pass of the A gather
+  static_assert(RPP % 16 == 0, "the unit swap of a thread's rows must not depend on the pass");
   constexpr int QA = BM / RPP;
   static_assert(BM % RPP == 0, "A tile must divide evenly");
   constexpr int NQB = (KC / 4) * BN;   // B quads per chunk: (k-quad, column)
   constexpr int QB = (NQB + NT - 1) / NT;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                  // [2][BM][LDK]  row = pixel, 16 k-values contiguous
-  float* Bs = smem + 2 * BM * LDK;   // [2][BN][LDK]  row = output column
+  float* As = smem;             // [2][NPL][BM rows of 8 words (+16)]  row = pixel
+  float* Bs = smem + 2 * IMA;   // [2][NPL][BN rows of 8 words (+16)]  row = output column
+  // weight quads of a chunk: 16 consecutive lanes take 4 columns x 4 k-quads (lanes of a quad: consecutive columns)
+  auto b_map = [&](int idx, int& kq, int& nn) {
+    kq = (idx >> 2) & 3;
+    nn = ((idx >> 4) << 2) | (idx & 3);
+  };
 
   const dfl_conv_args& a = p.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -154,10 +167,15 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
 #pragma unroll
     for (int r = 0; r < QA; ++r)
       a_rowb[r] = (uint32_t)((((int64_t)a_base[r] + (int64_t)a_iy0[r] * Win + a_ix0[r]) * a.ldx + 4 * aq) * 4);
+#ifdef DFL_EXP_SMALLA   // diagnosis: every gather row inside one small window (L2- or L1-resident), same access shape
+#pragma unroll
+    for (int r = 0; r < QA; ++r) a_rowb[r] = (a_rowb[r] & (uint32_t)(DFL_EXP_SMALLA - 1)) + 65536u;
+#endif
 #pragma unroll
     for (int r = 0; r < QB; ++r) {
       const int idx = tid + r * NT;
-      const int kq = idx / BN, nn = idx - kq * BN;
+      int kq, nn;
+      b_map(idx, kq, nn);
       b_voff[r] = (idx < NQB && n0 + nn < Ntot) ? (uint32_t)(((int64_t)kq * Ntot + n0 + nn) * 16) : OOB;
     }
     const int k0 = (int)blockIdx.z * p.cps * KC;
@@ -175,7 +193,11 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
   // Straight-line code: a chunk past the end of the slice is fetched with out-of-range offsets (reads zeros), so the
   // main loop has no conditional loads and the compiler can keep the younger set in flight across the LDS write.
   auto load_AB = [&](int ch, int set) {
+#ifdef DFL_EXP_NOLOAD   // diagnosis builds (tools/exp/loop_bounds.sh): which resource the loop waits for; results are wrong
+    const bool live = ch < ch_end && ch < ch_begin + 2;   // later chunks: out-of-range offsets, no memory traffic
+#else
     const bool live = ch < ch_end;
+#endif
     if constexpr (MODE == 1) {
       // must be called once per chunk, in order: uses and advances the uniform cursor
       const bool kvalid = live && cur_tap < T;
@@ -239,7 +261,8 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
 #pragma unroll
       for (int r = 0; r < QB; ++r) {
         const int idx = tid + r * NT;
-        const int kq = idx / BN, nn = idx - kq * BN;
+        int kq, nn;
+        b_map(idx, kq, nn);
         const int kquad = ch * (KC / 4) + kq, n = n0 + nn;
         const bool ok = live && (idx < NQB) && (4 * kquad < Ktot) && (n < Ntot);
         const float4 v = *reinterpret_cast<const float4*>(a.w + (ok ? ((int64_t)kquad * Ntot + n) * 4 : 0));
@@ -249,7 +272,8 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
   };
 
   auto store_AB = [&](int buf, int set) {   // buf == set everywhere: chunk parity picks both
-    float* Ab = As + buf * BM * LDK;
+    float* Ab = As + buf * IMA;
+    const int fA = (tid >> 5) & 1;   // unit swap of this thread's rows (bit 3 of the row tid / 4)
 #pragma unroll
     for (int r = 0; r < QA; ++r) {
       const int row = (tid >> 2) + r * RPP;
@@ -291,17 +315,22 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
           split_bf16<NP>(v, parts);
         }
 #pragma unroll
-        for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(Ab + row * LDK + 8 * q + 2 * aq) = parts[q];
+        for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(Ab + q * PLA + row * 8 + 4 * ((aq >> 1) ^ fA) + 2 * (aq & 1)) = parts[q];
       } else {
-        *reinterpret_cast<float4*>(Ab + row * LDK + 4 * aq) = v;   // one ds_write_b128, no transposition
+        *reinterpret_cast<float4*>(Ab + (aq >> 1) * PLA + row * 8 + 4 * ((aq & 1) ^ fA)) = v;   // one ds_write_b128, no transposition
       }
     }
-    float* Bb = Bs + buf * BN * LDK;
+    float* Bb = Bs + buf * IMB;
+#ifdef DFL_EXP_BDIRECT   // diagnosis: what the loop would cost if the weight fragments never went through LDS
+    if constexpr (MATH != 0) return;
+#endif
 #pragma unroll
     for (int r = 0; r < QB; ++r) {
       const int idx = tid + r * NT;
       if (NQB % NT == 0 || idx < NQB) {   // (no branch when the tile divides evenly: one scheduling region)
-        const int kq = idx / BN, nn = idx - kq * BN;
+        int kq, nn;
+        b_map(idx, kq, nn);
+        const int fB = (nn >> 3) & 1;
         if constexpr (MATH != 0) {
           uint2 parts[NP];
           if (WPRE || ((MATH == 1 || MATH == 5) && a.w_split)) {
@@ -312,9 +341,9 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
             split_bf16<NP>(rb[set][r], parts);
           }
 #pragma unroll
-          for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(Bb + nn * LDK + 8 * q + 2 * kq) = parts[q];
+          for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(Bb + q * PLB + nn * 8 + 4 * ((kq >> 1) ^ fB) + 2 * (kq & 1)) = parts[q];
         } else {
-          *reinterpret_cast<float4*>(Bb + nn * LDK + 4 * kq) = rb[set][r];
+          *reinterpret_cast<float4*>(Bb + (kq >> 1) * PLB + nn * 8 + 4 * ((kq & 1) ^ fB)) = rb[set][r];
         }
       }
     }
@@ -329,19 +358,24 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   auto compute = [&](int buf) {
-    const float* Ab = As + buf * BM * LDK + (wm * (TM * 32) + li) * LDK + 4 * lh;
-    const float* Bb = Bs + buf * BN * LDK + (wn * (TN * 32) + li) * LDK + 4 * lh;
+    const int un = 4 * (lh ^ ((li >> 3) & 1));   // this lane's unit of its row, after the swap
+    const float* Ab = As + buf * IMA + (wm * (TM * 32) + li) * 8 + un;
+    const float* Bb = Bs + buf * IMB + (wn * (TN * 32) + li) * 8 + un;
     if constexpr (MATH != 0) {
-      // lane (row li, k-half lh): 8 consecutive bf16 of part q at byte 32*q + 16*lh of the row
+      // lane (row li, k-half lh): its unit (8 consecutive bf16) of part q
       bf16x8_t ap[TM][NP], bp[TN][NP];
 #pragma unroll
       for (int q = 0; q < NP; ++q) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-          ap[i][q] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Ab + i * 32 * LDK + 8 * q));
+          ap[i][q] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Ab + i * 256 + q * PLA));
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          bp[j][q] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Bb + j * 32 * LDK + 8 * q));
+#ifdef DFL_EXP_BDIRECT
+          bp[j][q] = __builtin_bit_cast(bf16x8_t, rb[buf ^ 1][0]);
+#else
+          bp[j][q] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Bb + j * 256 + q * PLB));
+#endif
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -351,16 +385,20 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
           for (int o = NP - 1; o >= 0; --o)   // order o = qa + qb, small terms first
 #pragma unroll
             for (int qa = 0; qa <= o; ++qa)
+#ifdef DFL_EXP_NOMFMA
+              acc[i][j][0] += (float)ap[i][qa][0] + (float)bp[j][o - qa][0];   // keeps the fragment reads alive
+#else
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][qa], bp[j][o - qa], acc[i][j], 0, 0, 0);
+#endif
       return;
     }
 #pragma unroll
     for (int g = 0; g < KC / 8; ++g) {
       float4 av[TM], bv[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDK + 8 * g);
+      for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const float4*>(Ab + i * 256 + g * PLA);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDK + 8 * g);
+      for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const float4*>(Bb + j * 256 + g * PLB);
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -379,16 +417,16 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
     if constexpr (HINTED) {
       __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);        // the 4 fragment reads
       if constexpr (XPRE) {
-        __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);      // both LDS writes (pure copies)
+        __builtin_amdgcn_sched_group_barrier(0x200, 4, 0);      // the LDS writes (pure copies: hi and lo of both operands)
         __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);      // the 3 matrix instructions
       } else {
-        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // weights: pure copy
+        __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);      // weights: pure copies
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);      // split of the gathered operand, in two halves
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
       }
     }
   };
@@ -414,6 +452,11 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
 #else
 #define TR_MARK(i)
 #endif
+#ifdef DFL_EXP_NOBAR
+#define LOOP_SYNC()
+#else
+#define LOOP_SYNC() __syncthreads()
+#endif
   for (int ch = ch_begin; ch < ch_end; ch += 2) {
 #ifdef DFL_CONV_TRACE
     long long tlast = __builtin_amdgcn_s_memtime();
@@ -426,7 +469,7 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
     store_AB(1, 1);
     sched_hint();
     TR_MARK(1)   // split / affine + LDS writes
-    __syncthreads();
+    LOOP_SYNC();
     TR_MARK(2)   // barrier
     load_AB(ch + 3, 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -434,7 +477,7 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
     if constexpr (!HINTED) __builtin_amdgcn_sched_barrier(0);
     store_AB(0, 0);
     sched_hint();
-    __syncthreads();
+    LOOP_SYNC();
   }
 
 #ifdef DFL_CONV_TRACE
@@ -773,7 +816,8 @@ static int pick_splits(int64_t M, int Ntot, int Ktot, ConvCfg cfg) {
 template <int WM, int WN, int TM, int TN, int MODE, bool AFF, int EPI, int MATH = 0>
 static int launch(const ConvK& k, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  const size_t lds = (size_t)(2 * (BM + BN) * (MATH == 2 ? 28 : KC + 4)) * sizeof(float);
+  constexpr int npl = (MATH == 0 || MATH == 1 || MATH == 3 || MATH == 4) ? 2 : (MATH == 2 ? 3 : 1);   // planes per LDS image
+  const size_t lds = (size_t)(2 * npl * (BM * 8 + 16 + BN * 8 + 16)) * sizeof(float);
   dim3 grid((unsigned)ceil_div(k.Mtot, BM), (unsigned)ceil_div(k.a.Ntot, BN), (unsigned)k.splits);
   hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, TM, TN, MODE, AFF, EPI, MATH>), grid, dim3(WM * WN * 64), lds, s, k);
   return check_launch("dfl_conv2d");

@@ -20,7 +20,7 @@ def main():
     N, H, W, Cin, Cout, K = [int(v) for v in sys.argv[2:8]]
     stride = int(sys.argv[8]) if len(sys.argv) > 8 else 1
     reps = int(sys.argv[9]) if len(sys.argv) > 9 else 20
-    flags = sys.argv[10] if len(sys.argv) > 10 else 'sabr'      # s: statistics, a: input affine, b: bias, r: relu
+    flags = sys.argv[10] if len(sys.argv) > 10 else 'sabr'      # s: statistics, a: input affine, b: bias, r: relu, W / X: split weights / input
     lib = nat.lib()
     dev = 'cuda'
     pad = 1 if K == 3 else 0
@@ -45,6 +45,8 @@ def main():
         if 'b' not in flags:
             a.bias = None
         a.relu = int('r' in flags)
+        a.w_split = int('W' in flags)         # operands declared pre-split (timing only: the bits are whatever randn left)
+        a.x_split = int('X' in flags)
         if 's' in flags:
             gm = lib.dfl_conv_grid_m(C.addressof(a))
             stats = torch.empty(gm * 2 * Cout, device=dev)
