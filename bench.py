@@ -125,6 +125,8 @@ def main():
                          'tighter: 2^-16 per product, forward within the 1e-4 parity bar); fp32 = fp32 MFMA (the parity gate)')
     ap.add_argument('--no-fp32-reference', action='store_true', help='skip the extra fp32-product timing (profiling runs)')
     ap.add_argument('--no-overlap', action='store_true', help='all-reduce after backward instead of overlapped buckets')
+    ap.add_argument('--force-dp', action='store_true',
+                    help='keep the collective path on in a one-rank group (self-test of the RCCL path on a 1-GPU box)')
     args = ap.parse_args()
 
     import dfl_amd
@@ -132,7 +134,7 @@ def main():
     from dfl_amd.parallel import DataParallel, init_process_group_from_env
     import torch.distributed as dist
 
-    rank, world, local = init_process_group_from_env(args.backend)
+    rank, world, local = init_process_group_from_env(args.backend, force=args.force_dp)
     if world != args.gpus and world > 1:
         raise SystemExit('--gpus %d does not match WORLD_SIZE %d' % (args.gpus, world))
     if args.gpus > 1 and world == 1:
@@ -144,7 +146,7 @@ def main():
 
     torch.manual_seed(1234)
     net = dfl_amd.UNet(**PAPER).to(dev)
-    dp = DataParallel(net, overlap=not args.no_overlap) if world > 1 else None
+    dp = DataParallel(net, overlap=not args.no_overlap, force_collectives=args.force_dp) if (world > 1 or args.force_dp) else None
     crit = dfl_amd.DiceAndHeatMapLoss2D(skip_bg=False, heatmap_wgt=0.5)
     SGD = dfl_amd.SGD if args.optimizer == 'dfl' else torch.optim.SGD
     opt = SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4, nesterov=True)
@@ -162,7 +164,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    multi = dist.is_initialized()          # (also a one-rank group under --force-dp)
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -170,10 +173,10 @@ def main():
     for _ in range(args.steps):
         last = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -277,7 +280,7 @@ def main():
                'roofline': roofline, 'cpu_baseline': cpu}
         out.update(extra)
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

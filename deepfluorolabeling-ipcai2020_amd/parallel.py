@@ -18,13 +18,14 @@ import torch.distributed as dist
 __all__ = ['DataParallel', 'init_process_group_from_env']
 
 
-def init_process_group_from_env(backend=None):
-    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract)."""
+def init_process_group_from_env(backend=None, force=False):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).
+    ``force``: also with WORLD_SIZE 1 (a one-rank RCCL group: the self-test of the collective path on a 1-GPU box)."""
     import os
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         if backend == 'nccl':
@@ -71,24 +72,27 @@ class DataParallel:
         out = net(x_shard); loss.backward()                   # gradients arrive averaged over ranks
     """
 
-    def __init__(self, net, process_group=None, bucket_mb=32.0, overlap=True):
+    def __init__(self, net, process_group=None, bucket_mb=32.0, overlap=True, force_collectives=False):
         self.net = net
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # collectives run when there is more than one rank -- or on request in a one-rank group (self-test: the same
+        # broadcast / bucketed all-reduce / stream choreography, numerically the identity)
+        self.active = dist.is_initialized() and (self.world > 1 or force_collectives)
         self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
         self.overlap = overlap
         self._seg_cache = {}
         self.comm_stream = None
         # RCCL averages inside the collective (ReduceOp.AVG); gloo (CPU tests, single-GPU self-test) sums, then we scale
         self._avg_in_collective = False
-        if self.world > 1 and dist.get_backend(process_group) == 'nccl':
+        if self.active and dist.get_backend(process_group) == 'nccl':
             try:                                   # probe once (collective: every rank takes the same branch)
                 probe = torch.ones(1, device=next(net.parameters()).device)
                 dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=process_group)
                 self._avg_in_collective = abs(float(probe.item()) - 1.0) < 1e-6
             except Exception:
                 self._avg_in_collective = False
-        if self.world > 1:
+        if self.active:
             with torch.no_grad():
                 for t in list(net.parameters()) + list(net.buffers()):
                     dist.broadcast(t, src=0, group=process_group)
@@ -125,7 +129,7 @@ class DataParallel:
             view.mul_(inv)
 
     def _run_backward(self, plan, stream):
-        if self.world == 1:
+        if not self.active:
             plan.bwd.run(stream)
             return
         flat = plan.grad_flat

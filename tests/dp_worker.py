@@ -1,4 +1,7 @@
-"""Worker of tests/test_gpu_parallel.py: one rank of a 2-process data-parallel run sharing one GPU (gloo transport).
+"""Worker of tests/test_gpu_parallel.py: one rank of a data-parallel run on one GPU -- 2 processes sharing it over gloo
+(DP_BACKEND unset), or ONE process in a one-rank RCCL group (DP_BACKEND=nccl: RCCL refuses two ranks on one device, so
+this is how the nccl code path -- init, ReduceOp.AVG probe, broadcast, bucketed all-reduce on the comm stream -- runs
+on a 1-GPU box).
 
 Checks, on every rank: (1) parameters equal rank 0's after DataParallel construction; (2) after backward the gradients
 equal the mean over ranks of the gradients each rank computes alone on its shard; (3) overlapped and in-line
@@ -21,8 +24,10 @@ def grads_of(net):
 
 
 def main():
-    rank, world, local = init_process_group_from_env('gloo')
-    assert world == 2
+    backend = os.environ.get('DP_BACKEND', 'gloo')
+    rank, world, local = init_process_group_from_env(backend, force=True)
+    assert world == (1 if backend == 'nccl' else 2)
+    assert dist.get_backend() == backend
     dev = torch.device('cuda', 0)
     torch.cuda.set_device(dev)
     cfg = dict(n_classes=4, depth=3, wf=3, batch_norm=True, padding=True, max_pool=False, num_lands=3)
@@ -42,16 +47,17 @@ def main():
         torch.cuda.synchronize()
         return grads_of(net)
 
-    dp = DataParallel(net, bucket_mb=0.02, overlap=True)     # tiny buckets: several segments even for this toy net
+    dp = DataParallel(net, bucket_mb=0.02, overlap=True, force_collectives=True)     # tiny buckets: several segments even for this toy net
+    assert dp.active and (backend != 'nccl' or dp._avg_in_collective), 'RCCL should average inside the collective'
     flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
     ref = flat.clone()
     dist.broadcast(ref, src=0)
     assert torch.equal(flat, ref), 'parameters differ from rank 0 after DataParallel()'
     net.train()
     # (2) local gradients with communication switched off, then their mean over ranks
-    dp.world = 1
+    dp.active = False
     local_g = fwd_bwd()
-    dp.world = world
+    dp.active = True
     mean_g = local_g.clone()
     dist.all_reduce(mean_g)
     mean_g /= world
