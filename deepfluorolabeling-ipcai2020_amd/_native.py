@@ -169,7 +169,7 @@ EXPORTS = ['dfl_version', 'dfl_last_error', 'dfl_sizeof', 'dfl_conv2d', 'dfl_con
            'dfl_dice_ncc_loss', 'dfl_loss_scratch_doubles', 'dfl_ensemble_reduce', 'dfl_sgd_step', 'dfl_exec',
            'dfl_exec_timed', 'dfl_conv_config', 'dfl_wgrad_config', 'dfl_conv_suggest_splits', 'dfl_reduce_batch',
            'dfl_reduce_job_blocks', 'dfl_prep_batch', 'dfl_prep_scratch_doubles', 'dfl_est_lands', 'dfl_hard_dice', 'dfl_get_math_mode',
-           'dfl_set_math_mode']
+           'dfl_set_math_mode', 'dfl_graph_capture', 'dfl_graph_launch', 'dfl_graph_nodes', 'dfl_graph_destroy']
 
 
 class DflError(RuntimeError):
@@ -210,6 +210,10 @@ def lib():
     L.dfl_sgd_step.argtypes = [fp, fp, fp, i64, f32, f32, f32, f32, i32, i32, fp]
     L.dfl_exec.argtypes = [fp, i32, fp]
     L.dfl_exec_timed.argtypes = [fp, i32, fp, fp]
+    L.dfl_graph_capture.argtypes = [fp, i32, fp, fp]
+    L.dfl_graph_launch.argtypes = [fp, fp]
+    L.dfl_graph_nodes.argtypes = [fp]
+    L.dfl_graph_destroy.argtypes = [fp]
     L.dfl_conv_config.argtypes = [fp]
     L.dfl_wgrad_config.argtypes = [fp]
     for fn in ('dfl_conv2d', 'dfl_conv2d_wgrad', 'dfl_bn_finalize', 'dfl_colstats', 'dfl_bn_bwd_finalize',
@@ -242,6 +246,28 @@ def byref(s):
 
 def call(fn_name, args_struct, stream):
     return check(getattr(lib(), fn_name)(C.addressof(args_struct), stream), fn_name)
+
+
+class Graph:
+    """An instantiated hipGraph of (part of) a Program; keeps the program (argument structs, tensors) alive."""
+
+    def __init__(self, handle, program):
+        self.handle, self.program = handle, program
+
+    def launch(self, stream):
+        check(lib().dfl_graph_launch(self.handle, stream), 'dfl_graph_launch')
+
+    @property
+    def nodes(self):
+        return lib().dfl_graph_nodes(self.handle)
+
+    def __del__(self):
+        try:
+            if self.handle and _lib is not None:
+                _lib.dfl_graph_destroy(self.handle)
+        except Exception:
+            pass
+        self.handle = None
 
 
 class Program:
@@ -296,6 +322,16 @@ class Program:
         ms = (C.c_float * n)()
         check(lib().dfl_exec_timed(C.addressof(self._ops), n, stream, C.addressof(ms)), 'dfl_exec_timed')
         return list(ms)
+
+    def capture(self, stream, start=0, count=None):
+        """hipGraph of ops [start, start + count) (dfl_graph_capture): nothing runs now; Graph.launch(stream) replays."""
+        if self._ops is None:
+            self._build()
+        n = len(self.structs) - start if count is None else count
+        h = C.c_void_p()
+        check(lib().dfl_graph_capture(C.addressof(self._ops) + start * C.sizeof(Op), n, stream, C.addressof(h)),
+              'dfl_graph_capture')
+        return Graph(h.value, self)
 
     def run(self, stream, start=0, count=None):
         if not self.structs:

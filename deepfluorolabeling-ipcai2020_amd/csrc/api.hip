@@ -124,6 +124,81 @@ extern "C" int dfl_exec_timed(const dfl_op* ops, int32_t n_ops, dfl_stream_t str
   return rc;
 }
 
+struct dfl_graph_s {
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+  int nodes;
+};
+
+extern "C" int dfl_graph_capture(const dfl_op* ops, int32_t n_ops, dfl_stream_t stream, dfl_graph_t* graph_out) {
+  if (ops == nullptr || n_ops <= 0 || graph_out == nullptr) {
+    dfl::set_error("dfl_graph_capture: bad arguments");
+    return DFL_ERR_INVALID_ARG;
+  }
+  *graph_out = nullptr;
+  (void)stream;   // the capture runs on a private stream: the caller's may be the null stream, which cannot capture
+  hipStream_t s = nullptr;
+  hipError_t err = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  if (err != hipSuccess) {
+    dfl::set_error("dfl_graph_capture: hipStreamCreateWithFlags: %s", hipGetErrorString(err));
+    return DFL_ERR_LAUNCH;
+  }
+  err = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+  if (err != hipSuccess) {
+    (void)hipStreamDestroy(s);
+    dfl::set_error("dfl_graph_capture: hipStreamBeginCapture: %s", hipGetErrorString(err));
+    return DFL_ERR_LAUNCH;
+  }
+  int rc = DFL_OK;
+  for (int i = 0; i < n_ops && rc == DFL_OK; ++i) rc = exec_one(ops, i, static_cast<dfl_stream_t>(s), true);
+  hipGraph_t g = nullptr;
+  err = hipStreamEndCapture(s, &g);   // always end the capture, also after a failed op
+  (void)hipStreamDestroy(s);
+  if (rc != DFL_OK) {
+    if (g != nullptr) (void)hipGraphDestroy(g);
+    return rc;
+  }
+  if (err != hipSuccess || g == nullptr) {
+    dfl::set_error("dfl_graph_capture: hipStreamEndCapture: %s", hipGetErrorString(err));
+    return DFL_ERR_LAUNCH;
+  }
+  hipGraphExec_t e = nullptr;
+  err = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+  if (err != hipSuccess) {
+    (void)hipGraphDestroy(g);
+    dfl::set_error("dfl_graph_capture: hipGraphInstantiate: %s", hipGetErrorString(err));
+    return DFL_ERR_LAUNCH;
+  }
+  size_t nn = 0;
+  if (hipGraphGetNodes(g, nullptr, &nn) != hipSuccess) nn = 0;
+  dfl_graph_s* h = new dfl_graph_s{g, e, (int)nn};
+  *graph_out = h;
+  return DFL_OK;
+}
+
+extern "C" int dfl_graph_launch(dfl_graph_t graph, dfl_stream_t stream) {
+  if (graph == nullptr) {
+    dfl::set_error("dfl_graph_launch: null graph");
+    return DFL_ERR_INVALID_ARG;
+  }
+  hipError_t err = hipGraphLaunch(graph->exec, static_cast<hipStream_t>(stream));
+  if (err != hipSuccess) {
+    dfl::set_error("dfl_graph_launch: %s", hipGetErrorString(err));
+    return DFL_ERR_LAUNCH;
+  }
+  return DFL_OK;
+}
+
+extern "C" int dfl_graph_nodes(dfl_graph_t graph) { return graph == nullptr ? DFL_ERR_INVALID_ARG : graph->nodes; }
+
+extern "C" int dfl_graph_destroy(dfl_graph_t graph) {
+  if (graph == nullptr) return DFL_OK;
+  (void)hipGraphExecDestroy(graph->exec);
+  (void)hipGraphDestroy(graph->graph);
+  delete graph;
+  return DFL_OK;
+}
+
 static int exec_one(const dfl_op* ops, int i, dfl_stream_t main_stream, bool serial) {
   {
     const void* p = ops[i].args;

@@ -58,6 +58,7 @@ class UNetPlan:
         self._pack_jobs = []
         self._pack_dsts = []
         self.busy = False
+        self.graph = None               # hipGraph of the forward program (inference plans, captured on first use)
         self.generation = 0
         self._scratch = {}
         self._red_pending = []          # deferred sums (src, dst, n, stride, count), see _defer_sum

@@ -7,6 +7,7 @@ contract (``seg`` or ``(seg, heat_maps)``, unet.py:183-193) and ordinary autogra
 replays a recorded program of hand-written HIP kernels from ``libdfl_hip.so`` (see ``plan.py``, ``include/dfl_hip.h``);
 the sub-modules below only own the parameters.  There is no CPU or eager fallback: tensors must live on the GPU.
 """
+import os
 import weakref
 
 import torch
@@ -175,6 +176,8 @@ class UNet(nn.Module):
         self._backward_runner = self._run_backward
         self.dp = None                                # set by parallel.DataParallel
         self.direct_grad = True                       # install gradient views as .grad without autograd copies
+        # inference forwards replay one hipGraph per recorded plan (DFL_HIPGRAPH=0: launch the ops one by one)
+        self.use_graphs = os.environ.get('DFL_HIPGRAPH', '1') != '0'
         self._flatten_parameters()
 
     # ---------------------------------------------------------------------------------------------- plumbing
@@ -286,7 +289,17 @@ class UNet(nn.Module):
         seg, heat = plan.new_outputs()
         plan.head_fwd.seg = seg.data_ptr()
         plan.head_fwd.heat = nat.ptr(heat)
-        plan.fwd.run(stream)
+        n = len(plan.fwd)
+        if self.use_graphs and not plan.training and n > 1:
+            # inference: everything up to the heads is one hipGraph launch (BASELINE configs[4]; the per-image loops of
+            # util.test_dataset / seg_dataset_ensemble replay ~100 small launches per net).  Captured on first use; the
+            # head op writes the caller-owned outputs, whose addresses change per call, so it stays a plain launch.
+            if plan.graph is None:
+                plan.graph = plan.fwd.capture(stream, 0, n - 1)
+            plan.graph.launch(stream)
+            plan.fwd.run(stream, n - 1, 1)
+        else:
+            plan.fwd.run(stream)
         return seg, heat
 
     def _run_backward(self, plan, stream):

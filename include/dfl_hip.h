@@ -457,6 +457,19 @@ int dfl_exec(const dfl_op* ops, int32_t n_ops, dfl_stream_t stream);
 /* Same, with a hipEvent pair recorded on `stream` around every op; blocks until done and returns the per-op
  * milliseconds in ms_out[n_ops].  Measurement aid for bench.py (roofline.achieved); not used on the timed path. */
 int dfl_exec_timed(const dfl_op* ops, int32_t n_ops, dfl_stream_t stream, float* ms_out);
+
+/* hipGraph form of a program (BASELINE configs[4]: "test_ensemble.py 5-model ensemble, hipGraph-captured"; the reference
+ * enqueues every torch op of UNet.forward one by one, util.py:318-373).  dfl_graph_capture records the ops -- in program
+ * order on one stream, side-stream annotations ignored, which is a valid schedule of any program -- into a hipGraph by
+ * stream capture on a private stream (nothing executes; `stream` is accepted for symmetry and unused: callers usually
+ * sit on the null stream, which cannot capture) and instantiates it; dfl_graph_launch replays it on any stream.  The argument structs are
+ * consumed at capture time: pointers and sizes are frozen into the graph, memory CONTENTS are read at replay.  The
+ * graph stays valid as long as the buffers it names do. */
+typedef struct dfl_graph_s* dfl_graph_t;
+int dfl_graph_capture(const dfl_op* ops, int32_t n_ops, dfl_stream_t stream, dfl_graph_t* graph_out);
+int dfl_graph_launch(dfl_graph_t graph, dfl_stream_t stream);
+int dfl_graph_nodes(dfl_graph_t graph);      /* kernel / memset nodes captured (diagnostics), negative = error */
+int dfl_graph_destroy(dfl_graph_t graph);
 /* Tile configuration the launcher picks for these arguments (index into the instantiation tables documented in
  * csrc/conv_gemm.hip / csrc/wgrad_gemm.hip); lets a profile be matched to kernel template names. */
 int dfl_conv_config(const dfl_conv_args* a);

@@ -509,3 +509,64 @@ def test_plain_bf16_products_forward():
     top2 = s0.topk(2, dim=1)[0]
     sure = (top2[:, 0] - top2[:, 1]) > 5e-2
     assert bool((s0.argmax(1) == s3.argmax(1))[sure].all())
+
+
+def test_inference_hipgraph_replay_equals_plain_launches(math_mode):
+    """BASELINE configs[4] names a hipGraph-captured ensemble forward: eval-mode forwards replay ONE graph per recorded
+    plan (everything but the head op).  Replays must be bit-identical to op-by-op launches, follow weight / running
+    statistics updates (the graph freezes addresses, not contents) and survive a changed input size (new plan)."""
+    import time
+    torch.manual_seed(5)
+    cfg = dict(n_classes=7, depth=4, wf=3, batch_norm=True, padding=True, max_pool=False, num_lands=14)
+    net = dfl_amd.UNet(**cfg).to(DEV)
+    with torch.no_grad():                       # non-trivial running statistics
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+    net.eval()
+    x = torch.randn(1, 1, 96, 96, device=DEV)
+    assert net.use_graphs
+    with torch.no_grad():
+        seg_g, heat_g = net(x)
+        plan = [p for ps in net._plans.values() for p in ps][0]
+        assert plan.graph is not None and plan.graph.nodes >= len(plan.fwd) - 1, 'forward was not captured'
+        seg_g2, heat_g2 = net(x)                # second replay of the same graph
+        net.use_graphs = False
+        seg_p, heat_p = net(x)
+        net.use_graphs = True
+        assert torch.equal(seg_g, seg_p) and torch.equal(heat_g, heat_p)
+        assert torch.equal(seg_g2, seg_p) and torch.equal(heat_g2, heat_p)
+        # contents change, addresses do not: new weights and statistics must show up in the next replay
+        for p in net.parameters():
+            p.mul_(1.01)
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.add_(0.05)
+        seg_g3, heat_g3 = net(x)
+        net.use_graphs = False
+        seg_p3, heat_p3 = net(x)
+        net.use_graphs = True
+        assert torch.equal(seg_g3, seg_p3) and torch.equal(heat_g3, heat_p3)
+        assert not torch.equal(seg_g3, seg_g)
+        # another input size -> another plan with its own graph
+        x2 = torch.randn(2, 1, 64, 80, device=DEV)
+        a = net(x2)
+        net.use_graphs = False
+        b = net(x2)
+        net.use_graphs = True
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+        def timeit(flag, reps=50):
+            net.use_graphs = flag
+            net(x)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                net(x)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / reps * 1e3
+        tg, tp = timeit(True), timeit(False)
+        net.use_graphs = True
+        print('batch-1 96x96 forward: %.3f ms per image as one graph, %.3f ms op by op' % (tg, tp))
+        assert tg < tp * 1.25                   # never a slow-down worth mentioning; usually a gain at this size
