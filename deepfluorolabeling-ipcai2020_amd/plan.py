@@ -241,6 +241,7 @@ class UNetPlan:
     # and one dfl_reduce_batch finishes the queue once FLUSH_BYTES of gradient are waiting (and at the end of backward).
     FLUSH_BYTES = 4 << 20
     FUSE_BWD_STATS = os.environ.get('DFL_FUSE_BWD_STATS', '1') != '0'
+    FUSE_COLSUMS = FUSE_BWD_STATS and os.environ.get('DFL_FUSE_COLSUMS', '1') != '0'   # sums across block boundaries (see the backward program)
 
     def _defer_sum(self, prog, src, dst, n, stride, count, T=1):
         self._red_pending.append((src, dst, n, stride, count, T))
@@ -418,17 +419,21 @@ class UNetPlan:
                     a.scale, a.shift = cur_aff[0].data_ptr(), cur_aff[1].data_ptr()
                 fwd.add(a)
 
-            def backward(dout, dxin):
-                """dout: Act with d(loss)/d(block output); dxin: Act to receive d/d(xin) (None for the net input)."""
+            def backward(dout, dxin, fused_in=None, dxin_stats=False):
+                """dout: Act with d(loss)/d(block output); dxin: Act to receive d/d(xin) (None for the net input).
+                fused_in: (partials, rows) with sum(dout), sum(dout * r_last) per channel when the kernel that wrote dout
+                already left them (saves this block's first statistics pass).  dxin_stats: let the LAST kernel that
+                writes dxin leave its column sums; returns them as (partials, rows) -- the caller's bias gradient."""
                 G = self.G
                 wrote_dxin = False
+                dxin_part = None
                 if do_res:
                     self._wgrad(bwd, xin, dout, G[prefix + '.res_conv1x1.weight'], 1, 1, 1, 0, xin.H, xin.W)
                     if dxin is not None:
                         self._conv(bwd, dout, self._pack_conv_dgrad(rw), dxin, 1, 1, 1, 0, xin.C)
                         wrote_dxin = True
                 g = dout
-                fused = None        # (partials, rows): BN-backward sums of g already left by the producing dgrad conv
+                fused = fused_in if self.FUSE_COLSUMS else None   # (partials, rows): BN-backward sums of g already left by g's producer
                 for d in reversed(range(bd)):
                     cv = convs[d]
                     r = cv['r']
@@ -485,9 +490,12 @@ class UNetPlan:
                         g = dz
                     elif dxin is not None:
                         wd = self._pack_conv_dgrad(cv['w'])
-                        self._conv(bwd, dpre, wd, dxin, 3, 3, 1, 2 - pad, xin.C, accumulate=1 if wrote_dxin else 0,
-                                   x_split=dsplit)
+                        dxin_part = self._conv(bwd, dpre, wd, dxin, 3, 3, 1, 2 - pad, xin.C, accumulate=1 if wrote_dxin else 0,
+                                               x_split=dsplit, stats=dxin_stats and self.FUSE_COLSUMS)
                     self._maybe_flush(bwd)
+                return dxin_part
+            # pre-BatchNorm output of the block's last conv: what a producer of this block's dout needs for fused_in
+            backward.last_r = convs[-1]['r'] if convs[-1]['bn'] is not None else None
             return backward
 
         # ------------------------------------------------------------------ down path
@@ -598,20 +606,29 @@ class UNetPlan:
                 self._wgrad(bwd, sact(off[3], NM), sact(off[4], L), self.G['lands_1x1.1.weight'], 1, 1, 1, 0, u.H, u.W)
 
         # up path, last block first
+        # Column sums ride on the kernels that produce the tensors: the conv that completes dcat leaves sum(dy) (the
+        # transposed conv's bias gradient), the conv that produces du leaves the BatchNorm-backward sums of the block
+        # that consumes du, the conv that completes a block-input gradient leaves the down-sampling bias gradient.
         dout = dfeat
+        dout_sums = None
         for j in reversed(range(len(up_recs))):
             rec = up_recs[j]
             i = rec['level']
             Ci = chans[i]
-            rec['block_bw'](dout, dcat[i])
+            st = rec['block_bw'](dout, dcat[i], fused_in=dout_sums, dxin_stats=True)
             dy = dcat[i].chan_slice(0, Ci)                    # gradient of the transposed-conv output
             uin = rec['u']
-            self._colsum(bwd, dy, self.G[rec['name'] + '.up.bias'])
+            if st is not None:                                # rows of (sum v, sum v^2) over all 2*Ci columns of dcat
+                self._defer_sum(bwd, st[0].data_ptr(), self.G[rec['name'] + '.up.bias'].data_ptr(), Ci, 4 * Ci, st[1])
+            else:
+                self._colsum(bwd, dy, self.G[rec['name'] + '.up.bias'])
             # dW[ci][co][ab] = sum x[i,j][ci] * dy[2i+a,2j+b][co]
             self._wgrad(bwd, dy, uin, self.G[rec['name'] + '.up.weight'], 2, 2, 2, 0, uin.H, uin.W)
             wd = self._pack_convT_dgrad(rec['w'])
             du = self._act(N, uin.H, uin.W, uin.C)
-            self._conv(bwd, dy, wd, du, 2, 2, 2, 0, uin.C)
+            consumer = up_recs[j - 1]['block_bw'] if j > 0 else pending[depth - 1]['block_bw']
+            r_last = consumer.last_r if self.FUSE_COLSUMS else None
+            dout_sums = self._conv(bwd, dy, wd, du, 2, 2, 2, 0, uin.C, stats=r_last is not None, stat_other=r_last)
             dout = du
         # down path, deepest block first
         for i in reversed(range(depth)):
@@ -636,7 +653,11 @@ class UNetPlan:
                                           ldy=dnxt.ld, lddx=dout.ld), backward=True)
                 else:
                     wname = 'downsample_convs.%d' % i
-                    self._colsum(bwd, dnxt, self.G[wname + '.bias'])
+                    st = rec.get('dnxt_sums')
+                    if st is not None:
+                        self._defer_sum(bwd, st[0].data_ptr(), self.G[wname + '.bias'].data_ptr(), Ci, 2 * Ci, st[1])
+                    else:
+                        self._colsum(bwd, dnxt, self.G[wname + '.bias'])
                     self._wgrad(bwd, out, dnxt, self.G[wname + '.weight'], 2, 2, 2, 0, nxt.H, nxt.W)
                     wd = self._pack_down_dgrad(self.P[wname + '.weight'])
                     self._conv(bwd, dnxt, wd, dout, 1, 1, 1, 0, 4 * Ci, accumulate=1, scatter=1,
@@ -646,7 +667,10 @@ class UNetPlan:
                 pending[i - 1]['dnxt'] = dxin
             else:
                 dxin = None
-            rec['block_bw'](dout, dxin)
+            st = rec['block_bw'](dout, dxin, fused_in=dout_sums if i == depth - 1 else None,
+                                 dxin_stats=dxin is not None and not cfg['max_pool'])
+            if i > 0:
+                pending[i - 1]['dnxt_sums'] = st
         self._flush_sums(bwd)
         self._side_join(bwd)
         self._finish_pack()
