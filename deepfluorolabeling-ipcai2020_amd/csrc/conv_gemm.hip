@@ -155,14 +155,22 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
   // ---- MODE 1 state --------------------------------------------------------------------------------------------------
   uint32_t a_rowb[QA];   // byte offset (mod 2^32) of (tap (0,0), channel 4*aq) of each gather row
   uint32_t b_voff[QB];   // loop-invariant byte offset of this thread's weight quads inside a chunk slab
-  __amdgpu_buffer_rsrc_t rsA, rsB, rsSc, rsSh;
+  __amdgpu_buffer_rsrc_t rsA, rsB;
+  // MODE 1 + AFF: the per-channel scale / shift live in LDS behind the operand images ([Cin] + [Cin] floats, staged once):
+  // a chunk's 2 x 16 bytes per thread then are two broadcast LDS reads instead of two more vector loads through the
+  // path that already carries the operands (the loop's most contended resource).
+  float* Ssc = Bs + 2 * IMB;
+  float* Ssh = Ssc + Cin;
   int cur_tap = 0, cur_c0 = 0, cur_dy = 0, cur_dx = 0;   // wave-uniform cursor of the chunk to load next
   if constexpr (MODE == 1) {
     rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)p.x_bytes, 0x00020000);
     rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)p.w_bytes, 0x00020000);
     if constexpr (AFF) {
-      rsSc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in_scale), 0, Cin * 4, 0x00020000);
-      rsSh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in_shift), 0, Cin * 4, 0x00020000);
+      for (int c = tid; c < Cin; c += NT) {
+        Ssc[c] = a.in_scale[c];
+        Ssh[c] = a.in_shift[c];
+      }
+      __syncthreads();
     }
 #pragma unroll
     for (int r = 0; r < QA; ++r)
@@ -212,10 +220,10 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
       }
       okA[set] = okm;
       if constexpr (AFF) all_in[set] = __builtin_amdgcn_ballot_w64(okm == full_rows) == ~0ull;
-      if constexpr (AFF) {   // this thread's 4 channels: fixed lane offset, the chunk's first channel rides in the scalar offset
-        const uint32_t csoff = kvalid ? (uint32_t)cur_c0 * 4u : 0u;
-        sc4[set] = buf_load4(rsSc, (uint32_t)aq * 16u, csoff);
-        sh4[set] = buf_load4(rsSh, (uint32_t)aq * 16u, csoff);
+      if constexpr (AFF) {   // this thread's 4 channels of the chunk (lanes with equal aq read one address: broadcast)
+        const int cofs = (kvalid ? cur_c0 : 0) + 4 * aq;
+        sc4[set] = *reinterpret_cast<const float4*>(Ssc + cofs);
+        sh4[set] = *reinterpret_cast<const float4*>(Ssh + cofs);
       }
       const uint32_t soff = live ? (uint32_t)ch * (uint32_t)(KC / 4 * 16) * (uint32_t)Ntot : 0u;   // chunk = 4 k-quad rows
 #pragma unroll
@@ -817,7 +825,8 @@ template <int WM, int WN, int TM, int TN, int MODE, bool AFF, int EPI, int MATH 
 static int launch(const ConvK& k, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int npl = (MATH == 0 || MATH == 1 || MATH == 3 || MATH == 4) ? 2 : (MATH == 2 ? 3 : 1);   // planes per LDS image
-  const size_t lds = (size_t)(2 * npl * (BM * 8 + 16 + BN * 8 + 16)) * sizeof(float);
+  size_t lds = (size_t)(2 * npl * (BM * 8 + 16 + BN * 8 + 16)) * sizeof(float);
+  if (MODE == 1 && AFF) lds += (size_t)2 * k.a.Cin * sizeof(float);   // staged scale / shift
   dim3 grid((unsigned)ceil_div(k.Mtot, BM), (unsigned)ceil_div(k.a.Ntot, BN), (unsigned)k.splits);
   hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, TM, TN, MODE, AFF, EPI, MATH>), grid, dim3(WM * WN * 64), lds, s, k);
   return check_launch("dfl_conv2d");
