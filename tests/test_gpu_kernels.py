@@ -44,7 +44,7 @@ def nchw(t):
     return t.permute(0, 3, 1, 2).contiguous()
 
 
-def pack(w, kind, flip=0):
+def pack(w, kind, flip=0, split=0):
     """Run one dfl_pack_weights job on the device: parameter [A][B][KH][KW] -> quad-packed GEMM operand."""
     lib = nat.lib()
     src = w.to(DEV).contiguous()
@@ -53,7 +53,7 @@ def pack(w, kind, flip=0):
     K = {1: Cc * B, 2: Cc * A, 3: A}[kind]
     N = {1: A, 2: B, 3: Cc * B}[kind]
     dst = torch.full(((K + 3) // 4 * N * 4,), float('nan'), device=DEV)
-    job = nat.PackJob(src=src.data_ptr(), dst=dst.data_ptr(), A=A, B=B, C=Cc, kind=kind, flip=flip)
+    job = nat.PackJob(src=src.data_ptr(), dst=dst.data_ptr(), A=A, B=B, C=Cc, kind=kind, flip=flip, split=split)
     jobs = torch.from_numpy(np.frombuffer(bytes(job), dtype=np.uint8).copy()).to(DEV)
     nat.check(lib.dfl_pack_weights(jobs.data_ptr(), 1, A * B * Cc, stream()))
     torch.cuda.synchronize()
@@ -62,7 +62,7 @@ def pack(w, kind, flip=0):
 
 def conv_call(x, wp, Ntot, KH, KW, stride, pad, Hout, Wout, bias=None, in_aff=None, relu=0, add=None, add_aff=None,
               y_init=None, accumulate=0, scatter=0, stats=False, stat_other=None, ldy=None, ldx_pad=0,
-              force_splits=None):
+              force_splits=None, w_split=0, x_split=0):
     """x: NCHW cpu tensor -> runs dfl_conv2d -> returns y as NHWC cpu tensor [N,Hout,Wout,Cout] (+ stats)."""
     lib = nat.lib()
     N, Cin, Hin, Win = x.shape
@@ -70,6 +70,11 @@ def conv_call(x, wp, Ntot, KH, KW, stride, pad, Hout, Wout, bias=None, in_aff=No
     if ldx_pad:
         xh = F.pad(xh, (0, ldx_pad))
     xd = xh.to(DEV)
+    if x_split:                 # the 16-byte slot of 4 values holds their 4 hi bf16, then their 4 lo bf16
+        hi = xd.bfloat16()
+        lo = (xd - hi.float()).bfloat16()
+        q = torch.cat([hi.reshape(-1, 4), lo.reshape(-1, 4)], dim=1).contiguous()
+        xd = q.view(torch.float32).reshape(xd.shape).contiguous()
     Cout = Ntot // 4 if scatter else Ntot
     ldy = Cout if ldy is None else ldy
     if y_init is not None:
@@ -101,6 +106,7 @@ def conv_call(x, wp, Ntot, KH, KW, stride, pad, Hout, Wout, bias=None, in_aff=No
     a.KH, a.KW, a.stride, a.pad = KH, KW, stride, pad
     a.Hout, a.Wout, a.Ntot, a.ldy = Hout, Wout, Ntot, ldy
     a.relu, a.accumulate, a.scatter2x2 = relu, accumulate, scatter
+    a.w_split, a.x_split = w_split, x_split
     sp = force_splits or nat.check(lib.dfl_conv_suggest_splits(C.addressof(a)))
     if sp > 1:
         Mrows = N * (Hin * Win if scatter else Hout * Wout)
@@ -631,3 +637,45 @@ def test_reduce_batch():
     for (n, stride, count, T), src, dst in zip(shapes, srcs, dsts):
         want = src.cpu().double().view(count, stride)[:, :n].sum(0).view(T, n // T).t().reshape(-1)
         aclose(dst.cpu().numpy(), want.numpy(), rtol=2e-6, atol=1e-5)
+
+
+@pytest.mark.parametrize('shape', [(2, 128, 64, 20, 28, 3), (1, 64, 96, 13, 9, 3), (2, 32, 32, 33, 17, 3), (3, 64, 160, 6, 6, 3),
+                                   (2, 64, 32, 12, 10, 1), (2, 32, 64, 16, 12, 2)])
+def test_conv_presplit_operands(shape, math_mode):
+    """bf16x3 only: weights packed as split quads (dfl_pack_job.split), alone and together with a pre-split input tensor
+    (x_split), through the simple and the general epilogue, one pass and split-K -- against the fp32 convolution at the
+    bf16x3 bar."""
+    if math_mode != 'bf16x3':
+        pytest.skip('split operands exist for bf16x3 products')
+    N, Cin, Cout, H, W, K = shape
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g)
+    stride, pad = (2, 0) if K == 2 else (1, K // 2)
+    Ho, Wo = (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1
+    other = torch.randn(N, Cout, Ho, Wo, generator=g)
+
+    def ref(xin):
+        return nhwc(F.relu(F.conv2d(xin, w, b, stride=stride, padding=pad)))
+
+    # the affine happens before zero padding in the reference order BN -> conv: emulate by transforming x, padding after
+    x_aff = x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    for wsp in (1,):
+        wp = pack(w, 1, split=wsp)
+        y = conv_call(x, wp, Cout, K, K, stride, pad, Ho, Wo, bias=b, relu=1, w_split=wsp)
+        aclose(y.numpy(), ref(x).numpy(), rtol=2e-5, atol=2e-5, err_msg='w_split %d' % wsp)
+        y, st = conv_call(x, wp, Cout, K, K, stride, pad, Ho, Wo, bias=b, relu=1, in_aff=(sc, sh), stats=True, w_split=wsp)
+        r = ref(x_aff)
+        aclose(y.numpy(), r.numpy(), rtol=2e-5, atol=3e-5, err_msg='w_split %d + affine' % wsp)
+        aclose(st[0].numpy(), r.double().sum((0, 1, 2)).numpy(), rtol=1e-5, atol=1e-3)
+        # both operands pre-split, general epilogue (residual add), statistics against a partner tensor
+        y, st = conv_call(x, wp, Cout, K, K, stride, pad, Ho, Wo, bias=b, relu=1, add=other, stats=True, stat_other=other,
+                          w_split=wsp, x_split=1)
+        r = ref(x) + nhwc(other)
+        aclose(y.numpy(), r.numpy(), rtol=2e-5, atol=3e-5, err_msg='w_split %d + x_split' % wsp)
+        aclose(st[1].numpy(), (r.double() * nhwc(other).double()).sum((0, 1, 2)).numpy(), rtol=1e-5, atol=2e-3)
+        if Cin * K * K >= 512:
+            y = conv_call(x, wp, Cout, K, K, stride, pad, Ho, Wo, bias=b, relu=1, w_split=wsp, x_split=1, force_splits=3)
+            aclose(y.numpy(), ref(x).numpy(), rtol=2e-5, atol=2e-5, err_msg='w_split %d + x_split, split-K' % wsp)
