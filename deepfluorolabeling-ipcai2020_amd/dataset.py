@@ -136,6 +136,74 @@ def get_num_lands_from_dataset(h5_file_path):
     return n
 
 
+def get_land_names_from_dataset(h5_file_path):
+    """dataset.py:348-365: the strings 'land-names/land-XX' (bytes or str in the file)."""
+    get, close = _open_container(h5_file_path)
+    names = []
+    for l in range(int(get('land-names/num-lands'))):
+        s = get('land-names/land-{:02d}'.format(l))
+        if isinstance(s, np.ndarray):
+            s = s.item() if s.ndim == 0 else s.tobytes()
+        if isinstance(s, (bytes, np.bytes_)):
+            s = s.decode()
+        assert isinstance(s, str)
+        names.append(s)
+    close()
+    return names
+
+
+class NpzFile:
+    """Write side of the container for hosts without h5py: the few methods of an ``h5py.File`` opened for writing that
+    test_ensemble.py / util.seg_dataset* use (create_group, item assignment, create_dataset with the chunking /
+    compression keywords accepted and ignored, flush, close), collected in memory and written as ONE compressed .npz with
+    the same dataset names (slashes kept) on close()."""
+
+    class _Group:
+        def __init__(self, owner, prefix):
+            self._o, self._p = owner, prefix
+
+        def __setitem__(self, k, v):
+            self._o._d[self._p + '/' + k] = np.asarray(v)
+
+        def create_dataset(self, name, shape, dtype='f4', **kw):
+            return self._o.create_dataset(self._p + '/' + name, shape, dtype=dtype, **kw)
+
+    def __init__(self, path, mode='w'):
+        assert mode == 'w', 'NpzFile is the write side; dataset._open_container reads'
+        self._path, self._d, self._closed = path, {}, False
+
+    def create_group(self, name):
+        return NpzFile._Group(self, name)
+
+    def __setitem__(self, k, v):
+        self._d[k] = np.asarray(v)
+
+    def create_dataset(self, name, shape, dtype='f4', **kw):
+        self._d[name] = np.zeros(shape, dtype=np.dtype(dtype))
+        return self._d[name]
+
+    def flush(self):
+        pass
+
+    def close(self):
+        if not self._closed:
+            with open(self._path, 'wb') as f:          # (np.savez would append '.npz' to a bare path)
+                np.savez_compressed(f, **self._d)
+            self._closed = True
+
+
+def open_output_container(path):
+    """The reference writes its results with ``h5.File(path, 'w')`` (test_ensemble.py:123): the same here when h5py is
+    installed and the path does not end in .npz; otherwise an NpzFile with the same dataset names."""
+    if not str(path).endswith('.npz'):
+        try:
+            import h5py
+            return h5py.File(path, 'w')
+        except ImportError as e:
+            raise ImportError('writing %s needs h5py (not installed); use an output path ending in .npz' % path) from e
+    return NpzFile(path)
+
+
 def get_dataset(h5_file_path, pat_inds, num_classes, pad_img_dim=0, no_seg=False, minmax=None, data_aug=False,
                 train_valid_split=None, train_valid_idx=None, dup_data_w_left_right_flip=False, device=None):
     """dataset.py:367-555 without augmentation: concatenates the patients' arrays, marks out-of-view landmarks with inf

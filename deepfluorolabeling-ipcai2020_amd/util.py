@@ -134,7 +134,7 @@ def test_dataset(ds, net, dev=None, num_lands=0):
     count = 0
     with torch.no_grad():
         net.eval()
-        for i, (projs, masks, lands, heats) in enumerate(DataLoader(ds, batch_size=1, shuffle=False)):
+        for i, (projs, masks, lands, heats) in enumerate(_items(ds)):
             projs, masks = projs.to(dev), masks.to(dev)
             seg, heat = _split_out(net(projs), num_lands)
             seg = center_crop(seg, masks.shape)
@@ -159,7 +159,7 @@ def test_dataset_ensemble(ds, nets, dev=None, num_lands=0, dice_only=False):
     with torch.no_grad():
         for n_ in nets:
             n_.eval()
-        for i, (projs, masks, lands, heats) in enumerate(DataLoader(ds, batch_size=1, shuffle=False)):
+        for i, (projs, masks, lands, heats) in enumerate(_items(ds)):
             projs, masks = projs.to(dev), masks.to(dev)
             outs = [_split_out(n_(projs), num_lands) for n_ in nets]
             hl = [o[1] for o in outs] if num_lands > 0 else None
@@ -174,6 +174,15 @@ def test_dataset_ensemble(ds, nets, dev=None, num_lands=0, dice_only=False):
             count += 1
     assert count == len(ds)
     return torch.mean(losses), torch.std(losses)
+
+
+def _items(ds):
+    """Batches of one, in order: what ``DataLoader(ds, batch_size=1, shuffle=False)`` yields (util.py:123,298).  The
+    GPU-resident data set builds them itself -- that also covers test sets loaded without segmentations, whose item
+    tuples hold None (which torch's default collate refuses)."""
+    if hasattr(ds, 'batches'):
+        return ds.batches(1, shuffle=False)
+    return DataLoader(ds, batch_size=1, shuffle=False)
 
 
 def _create_outputs(h5_f, n_items, orig_shape, num_lands):
@@ -194,7 +203,7 @@ def seg_dataset(ds, net, h5_f, dev=None, num_lands=0):
     count = 0
     with torch.no_grad():
         net.eval()
-        for i, data in enumerate(DataLoader(ds, batch_size=1, shuffle=False)):
+        for i, data in enumerate(_items(ds)):
             seg, heat = _split_out(net(data[0].to(dev)), num_lands)
             labels, _, _ = ensemble_reduce([seg], None, shape)
             seg_ds[i, :, :] = labels.cpu().numpy()
@@ -214,7 +223,7 @@ def seg_dataset_ensemble(ds, nets, h5_f, dev=None, num_lands=0, times=None):
     with torch.no_grad():
         for n_ in nets:
             n_.eval()
-        for i, data in enumerate(DataLoader(ds, batch_size=1, shuffle=False)):
+        for i, data in enumerate(_items(ds)):
             t0 = time.time()
             projs = data[0].to(dev)
             outs = [_split_out(n_(projs), num_lands) for n_ in nets]
