@@ -18,13 +18,14 @@ pytestmark = pytest.mark.gpu
 
 H = W = 44
 L, NC = 3, 4
+LAND_NAMES = ['GSN-l', 'GSN-r', 'IOF-l']        # landmarks tied to labels 1, 2, 1 (est_lands_csv.py:57-74)
 
 
 def make_file(path, n_per_pat=(8, 4)):
     g = torch.Generator().manual_seed(3)
     d = {'land-names/num-lands': np.int64(L)}
-    for l in range(L):
-        d['land-names/land-%02d' % l] = np.array('land-%d' % l)
+    for l, name in enumerate(LAND_NAMES):
+        d['land-names/land-%02d' % l] = np.array(name)
     Y, X = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing='ij')
     for pat, n in enumerate(n_per_pat, 1):
         projs = 0.1 * torch.randn(n, H, W, generator=g)
@@ -86,7 +87,7 @@ def test_train_resume_and_ensemble(tmp_path):
     assert z['nn-segs'].dtype == np.uint8 and z['nn-segs'].shape == (4, H, W) and int(z['nn-segs'].max()) < NC
     assert z['nn-heats'].dtype == np.float32 and z['nn-heats'].shape == (4, L, H, W)
     assert float(z['nn-heats'].min()) >= 0.0 and float(z['nn-heats'].max()) <= 1.0 + 1e-6
-    assert int(z['land-names/num-lands']) == L and str(z['land-names/land-01']) == 'land-1'
+    assert int(z['land-names/num-lands']) == L and str(z['land-names/land-01']) == 'GSN-r'
     times = open(os.path.join(cwd, 't.txt')).read().split('\n')
     assert len(times) - 1 == 4 and all(fl.match(x) for x in times[:-1])
     # the file holds what the library computes for the same nets and images
@@ -104,3 +105,27 @@ def test_train_resume_and_ensemble(tmp_path):
         labels, heats, _ = util.ensemble_reduce([o[0] for o in outs], [o[1] for o in outs], (H, W))
     assert np.array_equal(labels.cpu().numpy().reshape(H, W), z['nn-segs'][1])
     np.testing.assert_allclose(heats.cpu().numpy().reshape(L, H, W), z['nn-heats'][1], rtol=0, atol=1e-6)
+
+    # hard Dice CSV (compute_actual_dice_on_test.py:61,93) and landmark CSV (est_lands_csv.py:77,127) from those outputs
+    run('compute_actual_dice_on_test.py', ['data.npz', 'out.npz', 'nn-segs', 'dice.csv', '2', '--num-classes', str(NC)], cwd)
+    rows = open(os.path.join(cwd, 'dice.csv')).read().split('\n')
+    assert rows[0] == 'pat,proj,label,dice' and rows[-1] == '' and len(rows) - 2 == 4 * (NC - 1)
+    gt = np.load(os.path.join(cwd, 'data.npz'))['02/segs']
+    k = 1
+    for proj in range(4):
+        for l in range(1, NC):
+            e, g_ = z['nn-segs'][proj] == l, gt[proj] == l
+            tot = int(e.sum()) + int(g_.sum())
+            dsc = 1.0 if tot == 0 else 2.0 * int((e & g_).sum()) / tot
+            assert rows[k] == '{},{},{},{:.2f}'.format(2, proj, l, dsc), (rows[k], dsc)
+            k += 1
+    run('est_lands_csv.py', ['out.npz', 'nn-heats', '--use-seg', 'nn-segs', '--pat', '2', '--out', 'lands.csv'], cwd)
+    rows = open(os.path.join(cwd, 'lands.csv')).read().split('\n')
+    assert rows[0] == 'pat,proj,land,row,col,time' and len(rows) - 2 == 4 * L
+    want = util.est_lands(torch.from_numpy(z['nn-heats']).cuda(), torch.from_numpy(z['nn-segs']).cuda(), [1, 2, 1]).cpu()
+    k = 1
+    for proj in range(4):
+        for l in range(L):
+            f_ = rows[k].split(',')
+            assert [int(v) for v in f_[:5]] == [2, proj, l, int(want[proj, l, 0]), int(want[proj, l, 1])] and float(f_[5]) >= 0
+            k += 1
