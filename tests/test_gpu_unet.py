@@ -570,3 +570,67 @@ def test_inference_hipgraph_replay_equals_plain_launches(math_mode):
         net.use_graphs = True
         print('batch-1 96x96 forward: %.3f ms per image as one graph, %.3f ms op by op' % (tg, tp))
         assert tg < tp * 1.25                   # never a slow-down worth mentioning; usually a gain at this size
+
+
+@pytest.mark.parametrize('seed', list(range(12)))
+def test_random_architectures_match_oracle(seed, math_mode):
+    """Seeded sweep over the constructor flags and shapes the fixed fixtures do not reach (depth, width, block depth,
+    residual / BatchNorm / pooling / padding flags, class and landmark counts, batch and image sizes): forward, loss and
+    the whole gradient against the oracle on the same weights and inputs."""
+    rng = np.random.RandomState(1000 + seed)
+    padding = bool(rng.rand() < 0.75)
+    cfg = dict(n_classes=int(rng.randint(2, 8)), depth=int(rng.randint(1, 5)), wf=int(rng.randint(2, 5)),
+               batch_norm=bool(rng.rand() < 0.7), padding=padding, max_pool=bool(rng.rand() < 0.5),
+               num_lands=int(rng.choice([0, 0, 3, 14])), do_res=bool(padding and rng.rand() < 0.7),
+               block_depth=int(rng.randint(1, 4)), do_soft_max=bool(rng.rand() < 0.8))
+    B = int(rng.randint(1, 4))
+    H, W = int(rng.randint(24, 90)), int(rng.randint(24, 90))
+    if not padding:                      # valid convolutions shrink every level: keep the deepest level alive
+        H, W = H + 60, W + 60
+    torch.manual_seed(77 + seed)
+    onet = R.OracleUNet(1, **cfg)
+    x = torch.randn(B, 1, H, W, generator=torch.Generator().manual_seed(seed))
+    onet.train()
+    try:
+        oout = onet(x)
+    except Exception:
+        pytest.skip('the reference architecture itself rejects %s at %dx%d' % (cfg, H, W))
+    net = dfl_amd.UNet(1, **cfg)
+    net.load_state_dict(onet.state_dict())
+    net = net.to(DEV).train()
+    out = net(x.to(DEV))
+    L = cfg['num_lands']
+    oseg, oheat = (oout if L > 0 else (oout, None))
+    seg, heat = (out if L > 0 else (out, None))
+    assert type(out) is type(oout) and seg.shape == oseg.shape
+    sscale = max(float(oseg.detach().abs().max()), 1e-6)
+    np.testing.assert_allclose(seg.detach().cpu().numpy(), oseg.detach().numpy(), rtol=1e-4, atol=1e-4 * sscale)
+    g = torch.Generator().manual_seed(seed + 1)
+    ho, wo = oseg.shape[-2:]
+    th, tw = max(ho - 2, 1), max(wo - 2, 1)
+    tseg = torch.softmax(torch.randn(B, cfg['n_classes'], th, tw, generator=g), 1)
+    if L > 0:
+        np.testing.assert_allclose(heat.detach().cpu().numpy(), oheat.detach().numpy(), rtol=1e-4,
+                                   atol=1e-4 * max(float(oheat.detach().abs().max()), 1e-6))
+        theat = torch.rand(B, L, th, tw, generator=g) * 0.02
+        crit = dfl_amd.DiceAndHeatMapLoss2D(skip_bg=False, heatmap_wgt=0.5)
+        loss = crit((dfl_amd.center_crop(seg, tseg.shape), dfl_amd.center_crop(heat, theat.shape)), (tseg.to(DEV), theat.to(DEV)))
+        oloss = R.dice_and_heatmap_loss_2d((R.center_crop(oseg, tseg.shape), R.center_crop(oheat, theat.shape)), (tseg, theat),
+                                           skip_bg=False, heatmap_wgt=0.5)
+    else:
+        crit = dfl_amd.DiceLoss2D(skip_bg=bool(seed % 2))
+        loss = crit(dfl_amd.center_crop(seg, tseg.shape), tseg.to(DEV))
+        oloss = R.dice_loss_2d(R.center_crop(oseg, tseg.shape), tseg, skip_bg=bool(seed % 2))
+    assert abs(loss.item() - oloss.item()) < 2e-5 * max(1.0, abs(oloss.item()))
+    loss.backward()
+    oloss.backward()
+    num = den = 0.0
+    for (k, p), (_, q) in zip(net.named_parameters(), onet.named_parameters()):
+        if q.grad is None:
+            assert p.grad is None, k
+            continue
+        assert p.grad is not None, k
+        num += float((p.grad.cpu().double() - q.grad.double()).pow(2).sum())
+        den += float(q.grad.double().pow(2).sum())
+    if den > 0:
+        assert (num / den) ** 0.5 <= by_mode(math_mode, 5e-3, 5e-2), 'whole-gradient relative L2 error %.3e (%s)' % ((num / den) ** 0.5, cfg)
