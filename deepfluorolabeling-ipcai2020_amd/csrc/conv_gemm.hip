@@ -827,6 +827,8 @@ static int launch(const ConvK& k, hipStream_t s) {
   constexpr int npl = (MATH == 0 || MATH == 1 || MATH == 3 || MATH == 4) ? 2 : (MATH == 2 ? 3 : 1);   // planes per LDS image
   size_t lds = (size_t)(2 * npl * (BM * 8 + 16 + BN * 8 + 16)) * sizeof(float);
   if (MODE == 1 && AFF) lds += (size_t)2 * k.a.Cin * sizeof(float);   // staged scale / shift
+  DFL_REQUIRE(lds <= 64 * 1024, "dfl_conv2d: %d input channels with an affine on load need %zu bytes of LDS (limit 65536)",
+              k.a.Cin, lds);
   dim3 grid((unsigned)ceil_div(k.Mtot, BM), (unsigned)ceil_div(k.a.Ntot, BN), (unsigned)k.splits);
   hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, TM, TN, MODE, AFF, EPI, MATH>), grid, dim3(WM * WN * 64), lds, s, k);
   return check_launch("dfl_conv2d");
