@@ -35,28 +35,11 @@
 #include <string.h>
 
 #include "common.h"
+#include "conv_epilogue.h"
+#include "conv_rows.h"
 #include "direct_small.h"
 
 namespace dfl {
-
-constexpr int KC = 16;
-constexpr uint32_t OOB = 0x80000000u;   // buffer offset beyond any tensor we accept (< 2 GiB): the load returns 0
-
-struct ConvK {
-  dfl_conv_args a;
-  int Mtot, Ktot, Hg, Wg, Cout;
-  int fast;          // MODE 1 preconditions hold
-  int so_simple;
-  int splits, cps;   // split-K: number of K slices and chunks per slice
-  uint32_t x_bytes, w_bytes, y_bytes, so_bytes;
-};
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
-  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
 
 // Second launch-bound = waves per SIMD the register allocation must leave room for (residency per CU, see pick_cfg).
 constexpr int conv_occ(int tiles) { return tiles >= 4 ? 2 : (tiles == 2 ? 4 : 5); }
@@ -525,84 +508,7 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
     s2[j] = 0.f;
   }
   if constexpr (EPI == 0) {
-    // bias, ReLU, plain NHWC store, statistics of the stored value.  Out-of-range rows / columns get an out-of-range
-    // buffer offset: the store is dropped by the hardware, no branches.
-    __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)p.y_bytes, 0x00020000);
-    uint32_t cb[TN];
-    float cbias[TN];
-    bool cok[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * (TN * 32) + j * 32 + li;
-      cok[j] = n < Ntot;
-      cb[j] = (uint32_t)n * 4u;
-      cbias[j] = (a.bias != nullptr && cok[j]) ? a.bias[n] : 0.f;
-    }
-    const uint32_t ldyb = (uint32_t)a.ldy * 4u;
-    if (a.stat_other == nullptr) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int mb = m0 + wm * (TM * 32) + i * 32 + 8 * g + 4 * lh;
-          const uint32_t rowb = (uint32_t)mb * ldyb;
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            const bool rok = (mb + rr) < p.Mtot;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-              float v = acc[i][j][4 * g + rr] + cbias[j];
-              if (a.relu) v = fmaxf(v, 0.f);
-              const bool ok = rok && cok[j];
-              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsY, ok ? rowb + (uint32_t)rr * ldyb + cb[j] : OOB, 0, 0);
-              const float vm = ok ? v : 0.f;
-              s1[j] += vm;
-              s2[j] = fmaf(vm, vm, s2[j]);
-            }
-          }
-        }
-      }
-    } else {
-      // statistics against a partner tensor u (sum v, sum v*u): u comes through a bounds-checked descriptor, the
-      // loads of a whole 32-row tile are issued before the first one is consumed
-      __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.stat_other), 0, (int)p.so_bytes, 0x00020000);
-      const uint32_t ldub = (uint32_t)a.ldso * 4u;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        float u[16][TN];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int mb = m0 + wm * (TM * 32) + i * 32 + 8 * g + 4 * lh;
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            const bool rok = (mb + rr) < p.Mtot;
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              u[4 * g + rr][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                  rsU, (rok && cok[j]) ? (uint32_t)(mb + rr) * ldub + cb[j] : OOB, 0, 0));
-          }
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int mb = m0 + wm * (TM * 32) + i * 32 + 8 * g + 4 * lh;
-          const uint32_t rowb = (uint32_t)mb * ldyb;
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            const bool rok = (mb + rr) < p.Mtot;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-              float v = acc[i][j][4 * g + rr] + cbias[j];
-              if (a.relu) v = fmaxf(v, 0.f);
-              const bool ok = rok && cok[j];
-              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsY, ok ? rowb + (uint32_t)rr * ldyb + cb[j] : OOB, 0, 0);
-              const float vm = ok ? v : 0.f;
-              s1[j] += vm;
-              s2[j] = fmaf(vm, u[4 * g + rr][j], s2[j]);
-            }
-          }
-        }
-      }
-    }
+    conv_epilogue_simple<WM, WN, TM, TN>(p, acc, s1, s2, m0, n0, wm, wn, li, lh);
   } else {
     // Everything: per-column constants (this lane's TN columns), then the tile in groups of 4 consecutive rows; every
     // read the epilogue needs (residual tensor, old output, statistics partner) is issued unconditionally from a clamped
@@ -688,31 +594,7 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
     }
   }
 
-  if (do_stats) {
-    // all MFMA reads of As/Bs are behind the last loop barrier: reuse the LDS for the cross-wave sums
-    float* red = smem;  // [WM][2][BN]
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const float t1 = s1[j] + xor32(s1[j]);
-      const float t2 = s2[j] + xor32(s2[j]);
-      if (lh == 0) {
-        const int col = wn * (TN * 32) + j * 32 + li;
-        red[(wm * 2 + 0) * BN + col] = t1;
-        red[(wm * 2 + 1) * BN + col] = t2;
-      }
-    }
-    __syncthreads();
-    for (int idx = tid; idx < 2 * BN; idx += NT) {
-      const int which = idx / BN, col = idx - which * BN;
-      const int n = n0 + col;
-      if (n < Ntot) {
-        float s = 0.f;
-#pragma unroll
-        for (int w = 0; w < WM; ++w) s += red[(w * 2 + which) * BN + col];
-        a.stat_partials[((int64_t)blockIdx.x * 2 + which) * Ntot + n] = s;
-      }
-    }
-  }
+  if (do_stats) conv_stats_tail<WM, WN, TM, TN>(p, s1, s2, smem, tid, n0, wm, wn, li, lh);
 }
 
 // Split-K finish: y = epilogue(sum_s partial[s]) with the same epilogue as above (bias, ReLU, + BN(other),
@@ -924,6 +806,7 @@ extern "C" int dfl_conv_suggest_splits(const dfl_conv_args* a) {
   int rc = dfl::prepare(a, &k);
   if (rc != DFL_OK) return rc;
   if (dfl::direct_conv_ok(a)) return 1;
+  if (a->splits <= 1 && dfl::conv_rows_tile(k)) return 1;
   return dfl::pick_splits(k.Mtot, a->Ntot, k.Ktot, dfl::pick_cfg(k.Mtot, a->Ntot, k.fast));
 }
 
@@ -933,6 +816,7 @@ extern "C" int dfl_conv_grid_m(const dfl_conv_args* a) {
   if (rc != DFL_OK) return rc;
   if (a->splits > 1) return dfl::finish_rows(k.Mtot, a->Ntot);
   if (dfl::direct_conv_ok(a)) return dfl::direct_conv_blocks(a);
+  if (const int t = dfl::conv_rows_tile(k)) return k.Mtot / t;
   int bm, bn;
   dfl::cfg_tile(dfl::pick_cfg(k.Mtot, a->Ntot, k.fast), &bm, &bn);
   return (int)dfl::ceil_div(k.Mtot, bm);
@@ -943,6 +827,7 @@ extern "C" int dfl_conv_config(const dfl_conv_args* a) {
   int rc = dfl::prepare(a, &k);
   if (rc != DFL_OK) return rc;
   if (dfl::direct_conv_ok(a)) return dfl::CFG_DIRECT;
+  if (const int t = dfl::conv_rows_tile(k)) return t == 192 ? dfl::CFG_ROWS192 : dfl::CFG_ROWS96;
   return (int)dfl::pick_cfg(k.Mtot, a->Ntot, k.fast);
 }
 
@@ -969,6 +854,7 @@ extern "C" int dfl_conv2d(const dfl_conv_args* a, dfl_stream_t stream) {
   }
   const bool general = a->add != nullptr || a->accumulate || a->scatter2x2 || (a->stat_other != nullptr && !k.so_simple);
   const bool aff = a->in_scale != nullptr;
+  if (!general && dfl::conv_rows_tile(k)) return dfl::conv_rows_launch(k, s);   // wide 3x3 layers with few output channels
   if (!k.fast) {
     rc = dfl::launch<2, 2, 1, 1, 0, true, 1>(k, s);
   } else {

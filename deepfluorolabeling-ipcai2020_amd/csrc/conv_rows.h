@@ -1,0 +1,9 @@
+// Row-tiled 3x3 convolution kernels (conv_rows.hip), dispatched by dfl_conv2d.
+#pragma once
+#include "conv_epilogue.h"
+
+namespace dfl {
+constexpr int CFG_ROWS192 = 6, CFG_ROWS96 = 7;   // dfl_conv_config values (192 x 32 and 96 x 64 tiles)
+int conv_rows_tile(const ConvK& k);              // 0 = not eligible, else the tile's pixel count (192 / 96)
+int conv_rows_launch(const ConvK& k, hipStream_t s);
+}  // namespace dfl

@@ -241,6 +241,7 @@ class UNetPlan:
     # and one dfl_reduce_batch finishes the queue once FLUSH_BYTES of gradient are waiting (and at the end of backward).
     FLUSH_BYTES = 4 << 20
     FUSE_BWD_STATS = os.environ.get('DFL_FUSE_BWD_STATS', '1') != '0'
+    RES_DGRAD_LAST = os.environ.get('DFL_RES_DGRAD_LAST', '1') != '0'   # residual 1x1 data gradient accumulates onto the 3x3 one (not the reverse)
     FUSE_COLSUMS = FUSE_BWD_STATS and os.environ.get('DFL_FUSE_COLSUMS', '1') != '0'   # sums across block boundaries (see the backward program)
 
     def _defer_sum(self, prog, src, dst, n, stride, count, T=1):
@@ -425,13 +426,15 @@ class UNetPlan:
                 already left them (saves this block's first statistics pass).  dxin_stats: let the LAST kernel that
                 writes dxin leave its column sums; returns them as (partials, rows) -- the caller's bias gradient."""
                 G = self.G
-                wrote_dxin = False
                 dxin_part = None
                 if do_res:
                     self._wgrad(bwd, xin, dout, G[prefix + '.res_conv1x1.weight'], 1, 1, 1, 0, xin.H, xin.W)
-                    if dxin is not None:
-                        self._conv(bwd, dout, self._pack_conv_dgrad(rw), dxin, 1, 1, 1, 0, xin.C)
-                        wrote_dxin = True
+                # dxin = (3x3 data gradient of the first conv) + (1x1 data gradient of the residual branch).  The 3x3 one
+                # writes, the cheap 1x1 one accumulates on top: the big kernel keeps its simple epilogue (and, on the wide
+                # levels, the row-tiled form), the column sums of the finished dxin come from the 1x1 kernel.
+                res_dgrad_last = do_res and dxin is not None and self.RES_DGRAD_LAST
+                if do_res and dxin is not None and not res_dgrad_last:
+                    self._conv(bwd, dout, self._pack_conv_dgrad(rw), dxin, 1, 1, 1, 0, xin.C)
                 g = dout
                 fused = fused_in if self.FUSE_COLSUMS else None   # (partials, rows): BN-backward sums of g already left by g's producer
                 for d in reversed(range(bd)):
@@ -490,8 +493,13 @@ class UNetPlan:
                         g = dz
                     elif dxin is not None:
                         wd = self._pack_conv_dgrad(cv['w'])
-                        dxin_part = self._conv(bwd, dpre, wd, dxin, 3, 3, 1, 2 - pad, xin.C, accumulate=1 if wrote_dxin else 0,
-                                               x_split=dsplit, stats=dxin_stats and self.FUSE_COLSUMS)
+                        want = dxin_stats and self.FUSE_COLSUMS
+                        dxin_part = self._conv(bwd, dpre, wd, dxin, 3, 3, 1, 2 - pad, xin.C,
+                                               accumulate=1 if (do_res and not res_dgrad_last) else 0,
+                                               x_split=dsplit, stats=want and not res_dgrad_last)
+                        if res_dgrad_last:
+                            dxin_part = self._conv(bwd, dout, self._pack_conv_dgrad(rw), dxin, 1, 1, 1, 0, xin.C,
+                                                   accumulate=1, stats=want)
                     self._maybe_flush(bwd)
                 return dxin_part
             # pre-BatchNorm output of the block's last conv: what a producer of this block's dout needs for fused_in

@@ -679,3 +679,39 @@ def test_conv_presplit_operands(shape, math_mode):
         if Cin * K * K >= 512:
             y = conv_call(x, wp, Cout, K, K, stride, pad, Ho, Wo, bias=b, relu=1, w_split=wsp, x_split=1, force_splits=3)
             aclose(y.numpy(), ref(x).numpy(), rtol=2e-5, atol=2e-5, err_msg='w_split %d + x_split, split-K' % wsp)
+
+
+@pytest.mark.parametrize('shape', [(2, 32, 32, 5, 192), (1, 64, 32, 3, 192), (2, 32, 64, 4, 96), (1, 64, 64, 3, 96),
+                                   (1, 128, 64, 2, 192), (1, 32, 20, 3, 384), (2, 64, 48, 1, 96)])
+def test_conv_row_tiles(shape, math_mode):
+    """The row-tiled 3x3 kernels (conv_rows.hip: wide images, <= 64 output channels; tiles of 192 / 96 pixels of one
+    image row, each kernel row's pixels staged once for its three taps): plain, with the BatchNorm affine on load (zero
+    padding after the affine), with statistics against a partner tensor, and -- bf16x3 -- with pre-split operands;
+    image borders, several images and ragged channel counts included."""
+    lib = nat.lib()
+    N, Cin, Cout, H, W = shape
+    g = torch.Generator().manual_seed(Cin * 7 + Cout + W)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g)
+    other = torch.randn(N, Cout, H, W, generator=g)
+    bf = math_mode == 'bf16x3'
+    wp = pack(w, 1, split=1 if bf else 0)
+    # the path under test is the one taken
+    a = nat.ConvArgs(x=wp.data_ptr(), w=wp.data_ptr(), y=wp.data_ptr(), N=N, Hin=H, Win=W, Cin=Cin, ldx=Cin, KH=3, KW=3,
+                     stride=1, pad=1, Hout=H, Wout=W, Ntot=Cout, ldy=Cout, w_split=int(bf))
+    assert nat.check(lib.dfl_conv_config(C.addressof(a))) == (6 if (Cout <= 32 and W % 192 == 0) else 7)
+    ref = nhwc(F.relu(F.conv2d(x, w, b, padding=1)))
+    y, st = conv_call(x, wp, Cout, 3, 3, 1, 1, H, W, bias=b, relu=1, stats=True, w_split=int(bf))
+    aclose(y.numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
+    aclose(st[0].numpy(), ref.double().sum((0, 1, 2)).numpy(), rtol=1e-5, atol=2e-3)
+    aclose(st[1].numpy(), (ref.double() ** 2).sum((0, 1, 2)).numpy(), rtol=1e-5, atol=2e-3)
+    x_aff = x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    refa = nhwc(F.conv2d(x_aff, w, b, padding=1))
+    y, st = conv_call(x, wp, Cout, 3, 3, 1, 1, H, W, bias=b, in_aff=(sc, sh), stats=True, stat_other=other, w_split=int(bf))
+    aclose(y.numpy(), refa.numpy(), rtol=2e-5, atol=4e-5)
+    aclose(st[1].numpy(), (refa.double() * nhwc(other).double()).sum((0, 1, 2)).numpy(), rtol=1e-5, atol=4e-3)
+    if bf:
+        y = conv_call(x, wp, Cout, 3, 3, 1, 1, H, W, bias=b, relu=1, w_split=1, x_split=1)
+        aclose(y.numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)

@@ -8,7 +8,7 @@ root=$(cd "$(dirname "$0")/../.." && pwd)
 src=$root/deepfluorolabeling-ipcai2020_amd/csrc
 out=$root/tools/exp/bin/$name
 mkdir -p $out
-for f in api conv_gemm wgrad_gemm direct_small bn_elem head loss prep; do
+for f in api conv_gemm conv_rows wgrad_gemm direct_small bn_elem head loss prep; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c $src/$f.hip -o $out/$f.o &
 done
 wait
