@@ -169,7 +169,8 @@ EXPORTS = ['dfl_version', 'dfl_last_error', 'dfl_sizeof', 'dfl_conv2d', 'dfl_con
            'dfl_dice_ncc_loss', 'dfl_loss_scratch_doubles', 'dfl_ensemble_reduce', 'dfl_sgd_step', 'dfl_exec',
            'dfl_exec_timed', 'dfl_conv_config', 'dfl_wgrad_config', 'dfl_conv_suggest_splits', 'dfl_reduce_batch',
            'dfl_reduce_job_blocks', 'dfl_prep_batch', 'dfl_prep_scratch_doubles', 'dfl_est_lands', 'dfl_hard_dice', 'dfl_get_math_mode',
-           'dfl_set_math_mode', 'dfl_graph_capture', 'dfl_graph_launch', 'dfl_graph_nodes', 'dfl_graph_destroy']
+           'dfl_set_math_mode', 'dfl_graph_capture', 'dfl_graph_launch', 'dfl_graph_nodes', 'dfl_graph_destroy',
+           'dfl_set_conv_rows_min_tiles']
 
 
 class DflError(RuntimeError):
@@ -210,6 +211,7 @@ def lib():
     L.dfl_sgd_step.argtypes = [fp, fp, fp, i64, f32, f32, f32, f32, i32, i32, fp]
     L.dfl_exec.argtypes = [fp, i32, fp]
     L.dfl_exec_timed.argtypes = [fp, i32, fp, fp]
+    L.dfl_set_conv_rows_min_tiles.argtypes = [i32]
     L.dfl_graph_capture.argtypes = [fp, i32, fp, fp]
     L.dfl_graph_launch.argtypes = [fp, fp]
     L.dfl_graph_nodes.argtypes = [fp]

@@ -806,8 +806,13 @@ extern "C" int dfl_conv_suggest_splits(const dfl_conv_args* a) {
   int rc = dfl::prepare(a, &k);
   if (rc != DFL_OK) return rc;
   if (dfl::direct_conv_ok(a)) return 1;
-  if (a->splits <= 1 && dfl::conv_rows_tile(k)) return 1;
+  if (const int rs = dfl::conv_rows_splits(k)) return rs;
   return dfl::pick_splits(k.Mtot, a->Ntot, k.Ktot, dfl::pick_cfg(k.Mtot, a->Ntot, k.fast));
+}
+
+extern "C" int dfl_set_conv_rows_min_tiles(int32_t n) {
+  DFL_REQUIRE(n >= 1, "dfl_set_conv_rows_min_tiles: n must be positive");
+  return dfl::conv_rows_set_min_tiles(n);
 }
 
 extern "C" int dfl_conv_grid_m(const dfl_conv_args* a) {
@@ -854,8 +859,9 @@ extern "C" int dfl_conv2d(const dfl_conv_args* a, dfl_stream_t stream) {
   }
   const bool general = a->add != nullptr || a->accumulate || a->scatter2x2 || (a->stat_other != nullptr && !k.so_simple);
   const bool aff = a->in_scale != nullptr;
-  if (!general && dfl::conv_rows_tile(k)) return dfl::conv_rows_launch(k, s);   // wide 3x3 layers with few output channels
-  if (!k.fast) {
+  if (dfl::conv_rows_tile(k)) {   // 3x3 layers in whole row segments (it checks the epilogue / slices it can take)
+    rc = dfl::conv_rows_launch(k, s);
+  } else if (!k.fast) {
     rc = dfl::launch<2, 2, 1, 1, 0, true, 1>(k, s);
   } else {
     switch (dfl::pick_cfg(k.Mtot, a->Ntot)) {

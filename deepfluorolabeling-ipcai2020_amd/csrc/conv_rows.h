@@ -6,4 +6,6 @@ namespace dfl {
 constexpr int CFG_ROWS192 = 6, CFG_ROWS96 = 7;   // dfl_conv_config values (192 x 32 and 96 x 64 tiles)
 int conv_rows_tile(const ConvK& k);              // 0 = not eligible, else the tile's pixel count (192 / 96)
 int conv_rows_launch(const ConvK& k, hipStream_t s);
+int conv_rows_splits(const ConvK& k);            // K slices these kernels want for the layer (0 = not their layer)
+int conv_rows_set_min_tiles(int n);              // returns the previous threshold
 }  // namespace dfl

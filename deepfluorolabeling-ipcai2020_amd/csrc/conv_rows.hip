@@ -1,12 +1,16 @@
 // Row-tiled 3x3 convolution (stride 1, pad 1) for the wide, narrow-channel levels of the U-Net.
 //
-// Same GEMM view, operands, arithmetic modes and epilogue as conv_gemm.hip (reference: nn.Conv2d 3x3 of
-// train_test_code/unet.py:207-218 and its data gradient), but the tile is BM consecutive pixels of ONE image row
-// (W % BM == 0) and K is walked as (dy, channel chunk, dx): the BM + 2 pixels x 16 channels a kernel row needs are staged
-// in LDS once and the three dx taps read them at row offsets 0 / 1 / 2, instead of being gathered three times.  With 32 or
+// Same GEMM view, operands and epilogue as conv_gemm.hip (reference: nn.Conv2d 3x3 of train_test_code/unet.py:207-218
+// and its data gradient), bf16x3 products only (math mode 1: the mode whose loop is bound by the load path), but the tile is BM consecutive pixels that form whole row
+// segments -- a piece of ONE image row (W % BM == 0) or R = BM / W complete image rows (BM % W == 0) -- and K is walked
+// as (dy, channel chunk, dx): the (segment + 2) pixels x 16 channels a kernel row needs are staged in LDS once per
+// segment and the three dx taps read them at row offsets 0 / 1 / 2, instead of being gathered three times.  With 32 or
 // 64 output channels the gathered operand dominates the load path (the loop's most contended resource, DESIGN.md
 // section 5), so this removes ~40 % of the vector loads and LDS writes per matrix instruction.  Tiles: 192 x 32 and
-// 96 x 64 (three waves): at 192 x 192 x 16 that is 3072 / 1536 workgroups = exactly 12 / 6 per CU.
+// 96 x 64 (three waves): every level of the 192 x 192 x 16 network divides into them -- 3072 / 1536 / 768 workgroups
+// at levels 0 / 1 / 2, and 384 / 192 / 96 tiles x 2 / 4 / 8 K slices = 768 at levels 3-5 (slices = ranges of
+// (dy, channel chunk) pairs, partial sums finished by conv_finish_kernel): whole multiples of the 256 CUs, where the
+// 64 x 64 tiles of the generic kernel leave 4.5 workgroups per CU.
 //
 // LDS: two stages of [A: 2 planes x (BM + 4) rows of 32 bytes][B: 3 taps x 2 planes x BN rows], layout and unit swap as
 // in conv_gemm.hip (the swap by bit 3 of the row stays conflict-free for rows shifted by 1 and 2).  One register set:
@@ -21,18 +25,16 @@ namespace dfl {
 
 template <int WM, int WN, int TM, int TN, bool AFF, int MATH>
 __global__ void __launch_bounds__(WM* WN * 64, 4) conv_rows_kernel(const ConvK p) {
-  static_assert(MATH == 0 || MATH == 3 || MATH == 4, "fp32, or bf16x3 with pre-split weights (3) / both operands (4)");
+  static_assert(MATH == 3 || MATH == 4, "bf16x3 with pre-split weights (3) / both operands pre-split (4)");
   constexpr bool XPRE = (MATH == 4);
   static_assert(!(XPRE && AFF), "a split input cannot take an affine on load");
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int EA = BM + 4;                               // staged rows: BM + 2, rounded up to whole 4-row write groups
-  constexpr int PLA = EA * 8 + 16, PLB = BN * 8 + 16;      // plane strides (words)
-  constexpr int IMA = 2 * PLA, IMB = 2 * PLB;
-  constexpr int STAGE = IMA + 3 * IMB;
+  constexpr int PLB = BN * 8 + 16, IMB = 2 * PLB;          // plane stride / image of a weight chunk (words)
   constexpr int RPP = NT / 4;
   static_assert(RPP % 16 == 0 && BM % RPP == 0 && (BM & 15) == 0, "row mapping");
   constexpr int QA = BM / RPP;
+  static_assert(RPP >= 32, "the extra pass must cover the 2 * 16 halo rows of the narrowest images");
   constexpr int NQB = 4 * BN;
   constexpr int QB = (NQB + NT - 1) / NT;
 
@@ -44,28 +46,33 @@ __global__ void __launch_bounds__(WM* WN * 64, 4) conv_rows_kernel(const ConvK p
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int H = a.Hin, W = a.Win, Cin = a.Cin, Ntot = a.Ntot;
   const int aq = tid & 3;
+  // the tile: R segments of Wt pixels = pixels x0 .. x0 + Wt - 1 of the image rows yn .. yn + R - 1 (row index over n * H)
+  const int Wt = (W >= BM) ? BM : W;
+  const int R = BM / Wt;
+  const int E = BM + 2 * R;                                // staged rows: every segment with its two halo pixels
+  const int PLA = ((E + 3) & ~3) * 8 + 16, IMA = 2 * PLA;  // plane stride / image of the staged pixels (words)
+  const int STAGE = IMA + 3 * IMB;
+  const int x0 = (W >= BM) ? m0 % W : 0;
+  const int yn = m0 / W;
   float* Ssc = smem + 2 * STAGE;   // AFF: [Cin] scale, [Cin] shift
   float* Ssh = Ssc + Cin;
-
-  // the tile: pixels x0 .. x0 + BM - 1 of image row (n, y)
-  const int x0 = m0 % W;
-  const int yn = m0 / W;
-  const int y = yn % H;
 
   __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)p.x_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)p.w_bytes, 0x00020000);
 
-  // staged row e <-> input pixel x0 - 1 + e of row y + dy - 1.  Rows 0 .. BM-1 by the regular (row, quad) mapping, rows
-  // BM and BM + 1 by the first 8 threads.
+  // staged row e = s * (Wt + 2) + c <-> input pixel x0 - 1 + c of image row yn + s + dy - 1.  Rows by the regular
+  // (row, quad) mapping; QA passes cover BM of them, one more pass the rest (at most 32).  okm: bit 3 r + dy.
   uint32_t a_rowb[QA + 1];
-  uint32_t xokm = 0;
+  uint32_t okm = 0;
 #pragma unroll
   for (int r = 0; r <= QA; ++r) {
-    const int e = (r < QA) ? (tid >> 2) + r * RPP : BM + (tid >> 2);
-    const int x = x0 - 1 + e;
-    const bool ok = (r < QA || tid < 8) && (unsigned)x < (unsigned)W;
-    xokm |= ok ? (1u << r) : 0u;
-    a_rowb[r] = (uint32_t)((((int64_t)(yn - 1) * W + x) * a.ldx + 4 * aq) * 4);
+    const int e = (tid >> 2) + r * RPP;
+    const int sg = e / (Wt + 2), x = x0 - 1 + (e - sg * (Wt + 2));
+    const int yi = (yn + sg) % H;                          // row inside its image
+    const bool ok = e < E && (unsigned)x < (unsigned)W;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) okm |= (ok && (unsigned)(yi + dy - 1) < (unsigned)H) ? (1u << (3 * r + dy)) : 0u;
+    a_rowb[r] = (uint32_t)((((int64_t)(yn + sg - 1) * W + x) * a.ldx + 4 * aq) * 4);
   }
   uint32_t b_voff[QB];
 #pragma unroll
@@ -82,18 +89,21 @@ __global__ void __launch_bounds__(WM* WN * 64, 4) conv_rows_kernel(const ConvK p
     __syncthreads();
   }
 
-  const int nit = 3 * (Cin / KC);   // (dy, channel chunk) pairs; even (Cin % 32 == 0)
+  const int cpr = Cin / KC;                                 // channel chunks per kernel row
+  const int it_begin = blockIdx.z * p.cps;                  // split-K: p.cps (dy, channel chunk) pairs per slice, an even number
+  const int nit = min(it_begin + p.cps, 3 * cpr);
   float4 ra[QA + 1];
   float4 rb[3][QB];
   float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
   uint32_t okA = 0;
-  int cur_dy = 0, cur_c0 = 0;       // wave-uniform cursor of the iteration to load next
+  int cur_dy = it_begin / cpr, cur_c0 = (it_begin - cur_dy * cpr) * KC;   // wave-uniform cursor of the iteration to load next
 
   auto load = [&](int it) {
     const bool live = it < nit;
-    const bool yok = live && (unsigned)(y + cur_dy - 1) < (unsigned)H;
     const uint32_t tapb = (uint32_t)((cur_dy * W * a.ldx + cur_c0) * 4);
-    okA = yok ? xokm : 0u;
+    okA = 0;
+#pragma unroll
+    for (int r = 0; r <= QA; ++r) okA |= (live && ((okm >> (3 * r + cur_dy)) & 1u)) ? (1u << r) : 0u;
 #pragma unroll
     for (int r = 0; r <= QA; ++r) ra[r] = buf_load4(rsA, ((okA >> r) & 1u) ? a_rowb[r] + tapb : OOB, 0);
     if constexpr (AFF) {
@@ -118,8 +128,8 @@ __global__ void __launch_bounds__(WM* WN * 64, 4) conv_rows_kernel(const ConvK p
     float* Ab = smem + stage * STAGE;
 #pragma unroll
     for (int r = 0; r <= QA; ++r) {
-      if (r == QA && tid >= 8) break;
-      const int e = (r < QA) ? (tid >> 2) + r * RPP : BM + (tid >> 2);
+      const int e = (tid >> 2) + r * RPP;
+      if (r == QA && e >= E) break;
       const int fA = (e >> 3) & 1;
       float4 v = ra[r];
       if constexpr (AFF) {   // zero padding applies AFTER the BatchNorm affine: the data already is 0 there, mask the shift
@@ -129,19 +139,15 @@ __global__ void __launch_bounds__(WM* WN * 64, 4) conv_rows_kernel(const ConvK p
         v.z = fmaf(v.z, sc4.z, ok ? sh4.z : 0.f);
         v.w = fmaf(v.w, sc4.w, ok ? sh4.w : 0.f);
       }
-      if constexpr (MATH != 0) {
-        uint2 parts[2];
-        if constexpr (XPRE) {
-          parts[0] = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));
-          parts[1] = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
-        } else {
-          split_bf16<2>(v, parts);
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) *reinterpret_cast<uint2*>(Ab + q * PLA + e * 8 + 4 * ((aq >> 1) ^ fA) + 2 * (aq & 1)) = parts[q];
+      uint2 parts[2];
+      if constexpr (XPRE) {   // the producer already left hi4 | lo4 in the slot
+        parts[0] = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));
+        parts[1] = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
       } else {
-        *reinterpret_cast<float4*>(Ab + (aq >> 1) * PLA + e * 8 + 4 * ((aq & 1) ^ fA)) = v;
+        split_bf16<2>(v, parts);
       }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) *reinterpret_cast<uint2*>(Ab + q * PLA + e * 8 + 4 * ((aq >> 1) ^ fA) + 2 * (aq & 1)) = parts[q];
     }
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
@@ -153,12 +159,9 @@ __global__ void __launch_bounds__(WM* WN * 64, 4) conv_rows_kernel(const ConvK p
           const int kq = (idx >> 2) & 3, nn = ((idx >> 4) << 2) | (idx & 3);
           const int fB = (nn >> 3) & 1;
           const float4 v = rb[dx][r];
-          if constexpr (MATH != 0) {   // weights arrive as split quads (hi4 | lo4)
-            *reinterpret_cast<uint2*>(Bb + nn * 8 + 4 * ((kq >> 1) ^ fB) + 2 * (kq & 1)) = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));
-            *reinterpret_cast<uint2*>(Bb + PLB + nn * 8 + 4 * ((kq >> 1) ^ fB) + 2 * (kq & 1)) = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
-          } else {
-            *reinterpret_cast<float4*>(Bb + (kq >> 1) * PLB + nn * 8 + 4 * ((kq & 1) ^ fB)) = v;
-          }
+          // weights arrive as split quads (hi4 | lo4)
+          *reinterpret_cast<uint2*>(Bb + nn * 8 + 4 * ((kq >> 1) ^ fB) + 2 * (kq & 1)) = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));
+          *reinterpret_cast<uint2*>(Bb + PLB + nn * 8 + 4 * ((kq >> 1) ^ fB) + 2 * (kq & 1)) = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
         }
       }
     }
@@ -173,55 +176,43 @@ __global__ void __launch_bounds__(WM* WN * 64, 4) conv_rows_kernel(const ConvK p
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int unB = 4 * (lh ^ ((li >> 3) & 1));
+  int erow[TM];                                            // staged row of this lane's pixel in tile i, tap dx = 0
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int t = wm * (TM * 32) + i * 32 + li, sg = t / Wt;
+    erow[i] = t + 2 * sg;
+  }
   auto compute = [&](int stage) {
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
-      const int un = 4 * (lh ^ (((li + dx) >> 3) & 1));   // unit of row li + dx after the swap
-      const float* Ab = smem + stage * STAGE + (wm * (TM * 32) + li + dx) * 8 + un;
+      const float* Ab = smem + stage * STAGE;
       const float* Bb = smem + stage * STAGE + IMA + dx * IMB + (wn * (TN * 32) + li) * 8 + unB;
-      if constexpr (MATH != 0) {
-        bf16x8_t ap[TM][2], bp[TN][2];
+      int aoff[TM];                                        // row erow + dx, unit after the swap by bit 3 of the row
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+      for (int i = 0; i < TM; ++i) aoff[i] = (erow[i] + dx) * 8 + 4 * (lh ^ (((erow[i] + dx) >> 3) & 1));
+      bf16x8_t ap[TM][2], bp[TN][2];
 #pragma unroll
-          for (int i = 0; i < TM; ++i) ap[i][q] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Ab + i * 256 + q * PLA));
+      for (int q = 0; q < 2; ++q) {
 #pragma unroll
-          for (int j = 0; j < TN; ++j) bp[j][q] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Bb + j * 256 + q * PLB));
-        }
+        for (int i = 0; i < TM; ++i) ap[i][q] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Ab + aoff[i] + q * PLA));
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {   // small terms first
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][0], bp[j][1], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][1], bp[j][0], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][0], bp[j][0], acc[i][j], 0, 0, 0);
-          }
-      } else {
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          float4 av[TM], bv[TN];
-#pragma unroll
-          for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const float4*>(Ab + i * 256 + g * PLA);
-#pragma unroll
-          for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const float4*>(Bb + j * 256 + g * PLB);
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[j].x, acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[j].y, acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[j].z, acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);
-            }
-        }
+        for (int j = 0; j < TN; ++j) bp[j][q] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Bb + j * 256 + q * PLB));
       }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {   // small terms first
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][0], bp[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][1], bp[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][0], bp[j][0], acc[i][j], 0, 0, 0);
+        }
     }
   };
 
-  load(0);
+  load(it_begin);
   store(0);
   __syncthreads();
-  for (int it = 0; it < nit; it += 2) {   // two at a time: the stage is a compile-time constant
+  for (int it = it_begin; it < nit; it += 2) {   // two at a time: the stage is a compile-time constant
     load(it + 1);
     __builtin_amdgcn_sched_barrier(0);
     compute(0);
@@ -236,6 +227,22 @@ __global__ void __launch_bounds__(WM* WN * 64, 4) conv_rows_kernel(const ConvK p
     __syncthreads();
   }
 
+  if (p.splits > 1) {   // raw partial sums; conv_finish_kernel applies the epilogue
+    float* part = a.partial + (int64_t)blockIdx.z * p.Mtot * Ntot;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * (TN * 32) + j * 32 + li;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * (TM * 32) + i * 32 + mfma32_row(r, lane);
+          if (n < Ntot) part[(int64_t)m * Ntot + n] = acc[i][j][r];
+        }
+      }
+    }
+    return;
+  }
   float s1[TN], s2[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -248,6 +255,8 @@ __global__ void __launch_bounds__(WM* WN * 64, 4) conv_rows_kernel(const ConvK p
 
 // ---- host side ------------------------------------------------------------------------------------------------------
 
+static int g_rows_min_tiles = 512;   // fewer workgroups than this: the generic kernel (it can cut K) fills the chip better
+
 static bool rows_enabled() {
   static const bool on = [] {
     const char* e = getenv("DFL_CONV_ROWS");
@@ -256,44 +265,94 @@ static bool rows_enabled() {
   return on;
 }
 
-// 0 = not eligible; otherwise the tile's pixel count (192: 192 x 32 tile, 96: 96 x 64 tile)
+// K slices for a layer with `tiles` row tiles: 1 when those fill the chip, else the smallest count that gives >= 768
+// workgroups with an even number (>= 4) of (dy, channel chunk) pairs per slice; 0 = no such count
+static int rows_splits(int tiles, int Cin) {
+  if (tiles >= g_rows_min_tiles) return 1;
+  const int nit = 3 * (Cin / KC);
+  for (int s = 2; s <= 16; ++s)
+    if (nit % (2 * s) == 0 && nit / s >= 4 && (int64_t)tiles * s >= 768) return s;
+  return 0;
+}
+
+// 0 = not eligible; otherwise the tile's pixel count (192: 192 x 32 tile, 96: 96 x 64 tile).  a.splits: 0 / 1 = asks
+// what the kernel would choose (conv_rows_splits), > 1 = the caller's slice count must be one this kernel can take.
 int conv_rows_tile(const ConvK& k) {
   const dfl_conv_args& a = k.a;
   if (!rows_enabled() || !k.fast) return 0;
-  if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.scatter2x2 || a.add != nullptr || a.accumulate) return 0;
-  if (a.splits > 1 || a.Cin % 32 != 0 || a.Hout != a.Hin || a.Wout != a.Win) return 0;
-  const int mode = math_mode();
-  if (mode == 0) {
-    if (a.w_split || a.x_split) return 0;
-  } else if (mode == 1) {
-    if (a.w_split != 1) return 0;                        // bf16x3 with the weights split by the pack kernel
-    if (a.x_split && a.in_scale != nullptr) return 0;
-  } else {
-    return 0;
-  }
+  if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.scatter2x2) return 0;
+  if (a.splits <= 1 && (a.add != nullptr || a.accumulate)) return 0;     // one pass: simple epilogue only (slices: the finish kernel has them all)
+  if (a.Cin % 32 != 0 || a.Hout != a.Hin || a.Wout != a.Win) return 0;
+  // bf16x3 products with the weights split by the pack kernel.  (fp32 products are bound by the matrix pipe, not by the
+  // load path: measured there, these tiles lose 3-5 % of the step against the generic kernel's, so that mode keeps it.)
+  if (math_mode() != 1 || a.w_split != 1) return 0;
+  if (a.x_split && a.in_scale != nullptr) return 0;
   if (a.in_scale != nullptr && (size_t)2 * a.Cin * sizeof(float) > 16 * 1024) return 0;
-  if (a.Ntot <= 32 && a.Win % 192 == 0) return 192;
-  if (a.Ntot <= 64 && a.Win % 96 == 0) return 96;
+  // whole row segments per tile: a piece of one image row, or up to 16 complete image rows; enough tiles for 256 CUs
+  // (there is no split-K form of this kernel)
+  auto fits = [&](int bm, int bn) {
+    const bool seg = (a.Win % bm == 0) || (bm % a.Win == 0 && bm / a.Win <= 16);
+    if (!seg || k.Mtot % bm != 0) return false;
+    const int tiles = (int)((int64_t)(k.Mtot / bm) * ceil_div(a.Ntot, bn));
+    if (a.splits > 1) {
+      const int nit = 3 * (a.Cin / KC);
+      return nit % (2 * a.splits) == 0 && nit / a.splits >= 2;
+    }
+    return rows_splits(tiles, a.Cin) == 1;
+  };
+  if (a.Ntot <= 32 && fits(192, 32)) return 192;
+  if (fits(96, 64)) return 96;
   return 0;
 }
 
 template <int WM, int WN, int TM, int TN, bool AFF, int MATH>
 static int rows_launch(const ConvK& k, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int stage = 2 * ((BM + 4) * 8 + 16) + 3 * 2 * (BN * 8 + 16);
+  const int Wt = k.a.Win >= BM ? BM : k.a.Win;
+  const int E = BM + 2 * (BM / Wt);
+  const int stage = 2 * (((E + 3) & ~3) * 8 + 16) + 3 * 2 * (BN * 8 + 16);
   size_t lds = (size_t)2 * stage * sizeof(float);
   if (AFF) lds += (size_t)2 * k.a.Cin * sizeof(float);
-  dim3 grid((unsigned)(k.Mtot / BM), (unsigned)ceil_div(k.a.Ntot, BN), 1);
-  hipLaunchKernelGGL((conv_rows_kernel<WM, WN, TM, TN, AFF, MATH>), grid, dim3(WM * WN * 64), lds, s, k);
+  ConvK q = k;
+  q.splits = k.a.splits > 1 ? k.a.splits : 1;
+  q.cps = 3 * (k.a.Cin / KC) / q.splits;      // (dy, channel chunk) pairs per slice
+  dim3 grid((unsigned)(k.Mtot / BM), (unsigned)ceil_div(k.a.Ntot, BN), (unsigned)q.splits);
+  hipLaunchKernelGGL((conv_rows_kernel<WM, WN, TM, TN, AFF, MATH>), grid, dim3(WM * WN * 64), lds, s, q);
   return check_launch("dfl_conv2d (row tiles)");
 }
 
 template <int WM, int WN, int TM, int TN>
 static int rows_dispatch(const ConvK& k, hipStream_t s) {
   const bool aff = k.a.in_scale != nullptr;
-  if (math_mode() == 0) return aff ? rows_launch<WM, WN, TM, TN, true, 0>(k, s) : rows_launch<WM, WN, TM, TN, false, 0>(k, s);
   if (k.a.x_split) return rows_launch<WM, WN, TM, TN, false, 4>(k, s);
   return aff ? rows_launch<WM, WN, TM, TN, true, 3>(k, s) : rows_launch<WM, WN, TM, TN, false, 3>(k, s);
+}
+
+// slice count dfl_conv_suggest_splits should answer for this layer (0 = the layer is not for these kernels)
+int conv_rows_splits(const ConvK& k) {
+  ConvK q = k;
+  q.a.splits = 1;
+  q.a.add = nullptr;          // with slices every epilogue is the finish kernel's
+  q.a.accumulate = 0;
+  const dfl_conv_args& a = q.a;
+  if (!rows_enabled() || !q.fast || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.scatter2x2) return 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int bm = pass == 0 ? 192 : 96, bn = pass == 0 ? 32 : 64;
+    if (pass == 0 && a.Ntot > 32) continue;
+    const bool seg = (a.Win % bm == 0) || (bm % a.Win == 0 && bm / a.Win <= 16);
+    if (!seg || q.Mtot % bm != 0 || a.Cin % 32 != 0) continue;
+    const int s = rows_splits((int)((int64_t)(q.Mtot / bm) * ceil_div(a.Ntot, bn)), a.Cin);
+    if (s == 0) continue;
+    q.a.splits = s;
+    if (s > 1 || (k.a.add == nullptr && !k.a.accumulate)) return conv_rows_tile(s > 1 ? q : k) == bm ? s : 0;
+  }
+  return 0;
+}
+
+int conv_rows_set_min_tiles(int n) {
+  const int old = g_rows_min_tiles;
+  g_rows_min_tiles = n;
+  return old;
 }
 
 int conv_rows_launch(const ConvK& k, hipStream_t s) {

@@ -465,6 +465,12 @@ int dfl_exec_timed(const dfl_op* ops, int32_t n_ops, dfl_stream_t stream, float*
  * sit on the null stream, which cannot capture) and instantiates it; dfl_graph_launch replays it on any stream.  The argument structs are
  * consumed at capture time: pointers and sizes are frozen into the graph, memory CONTENTS are read at replay.  The
  * graph stays valid as long as the buffers it names do. */
+/* Tuning knob (process-wide, like the math mode): dfl_conv2d takes its row-tiled 3x3 kernels (conv_rows.hip: wide
+ * images, tiles of whole row segments, each kernel row staged once for its three taps) only when they yield at least
+ * this many workgroups -- they have no split-K form; default 512.  Returns the previous value.  Tests lower it to
+ * exercise those kernels on small problems. */
+int dfl_set_conv_rows_min_tiles(int32_t n);
+
 typedef struct dfl_graph_s* dfl_graph_t;
 int dfl_graph_capture(const dfl_op* ops, int32_t n_ops, dfl_stream_t stream, dfl_graph_t* graph_out);
 int dfl_graph_launch(dfl_graph_t graph, dfl_stream_t stream);

@@ -681,9 +681,21 @@ def test_conv_presplit_operands(shape, math_mode):
             aclose(y.numpy(), ref(x).numpy(), rtol=2e-5, atol=2e-5, err_msg='w_split %d + x_split, split-K' % wsp)
 
 
+@pytest.fixture
+def rows_everywhere():
+    """Take the row-tiled kernels also for problems far below the size they are meant for."""
+    lib = nat.lib()
+    old = lib.dfl_set_conv_rows_min_tiles(1)
+    yield
+    lib.dfl_set_conv_rows_min_tiles(old)
+
+
 @pytest.mark.parametrize('shape', [(2, 32, 32, 5, 192), (1, 64, 32, 3, 192), (2, 32, 64, 4, 96), (1, 64, 64, 3, 96),
-                                   (1, 128, 64, 2, 192), (1, 32, 20, 3, 384), (2, 64, 48, 1, 96)])
-def test_conv_row_tiles(shape, math_mode):
+                                   (1, 128, 64, 2, 192), (1, 32, 20, 3, 384), (2, 64, 48, 1, 96),
+                                   # several complete image rows per tile, tiles that straddle two images
+                                   (2, 32, 64, 48, 48), (4, 64, 128, 24, 24), (8, 32, 32, 12, 12), (16, 64, 96, 6, 6),
+                                   (2, 32, 32, 24, 48), (3, 32, 64, 8, 32)])
+def test_conv_row_tiles(shape, math_mode, rows_everywhere):
     """The row-tiled 3x3 kernels (conv_rows.hip: wide images, <= 64 output channels; tiles of 192 / 96 pixels of one
     image row, each kernel row's pixels staged once for its three taps): plain, with the BatchNorm affine on load (zero
     padding after the affine), with statistics against a partner tensor, and -- bf16x3 -- with pre-split operands;
@@ -701,7 +713,10 @@ def test_conv_row_tiles(shape, math_mode):
     # the path under test is the one taken
     a = nat.ConvArgs(x=wp.data_ptr(), w=wp.data_ptr(), y=wp.data_ptr(), N=N, Hin=H, Win=W, Cin=Cin, ldx=Cin, KH=3, KW=3,
                      stride=1, pad=1, Hout=H, Wout=W, Ntot=Cout, ldy=Cout, w_split=int(bf))
-    assert nat.check(lib.dfl_conv_config(C.addressof(a))) == (6 if (Cout <= 32 and W % 192 == 0) else 7)
+    want = 6 if (Cout <= 32 and (W % 192 == 0 or 192 % W == 0) and 192 // min(W, 192) <= 16 and (N * H * W) % 192 == 0) else 7
+    if not bf:
+        pytest.skip('the row-tiled kernels exist for bf16x3 products (fp32 products are matrix-pipe bound and keep the generic tiles)')
+    assert nat.check(lib.dfl_conv_config(C.addressof(a))) == want
     ref = nhwc(F.relu(F.conv2d(x, w, b, padding=1)))
     y, st = conv_call(x, wp, Cout, 3, 3, 1, 1, H, W, bias=b, relu=1, stats=True, w_split=int(bf))
     aclose(y.numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
@@ -715,3 +730,17 @@ def test_conv_row_tiles(shape, math_mode):
     if bf:
         y = conv_call(x, wp, Cout, 3, 3, 1, 1, H, W, bias=b, relu=1, w_split=1, x_split=1)
         aclose(y.numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
+    # K slices ((dy, channel chunk) pairs dealt out over blockIdx.z) + finish kernel, which then also carries the
+    # epilogues the one-pass form leaves to the generic kernel (residual add, accumulate)
+    for sp in (2, 3):
+        if (3 * Cin // 16) % (2 * sp) != 0:
+            continue
+        a.splits = sp
+        assert nat.check(lib.dfl_conv_config(C.addressof(a))) == want
+        y, st = conv_call(x, wp, Cout, 3, 3, 1, 1, H, W, bias=b, in_aff=(sc, sh), stats=True, stat_other=other,
+                          w_split=int(bf), force_splits=sp)
+        aclose(y.numpy(), refa.numpy(), rtol=2e-5, atol=4e-5)
+        aclose(st[1].numpy(), (refa.double() * nhwc(other).double()).sum((0, 1, 2)).numpy(), rtol=1e-5, atol=4e-3)
+        y = conv_call(x, wp, Cout, 3, 3, 1, 1, H, W, bias=b, relu=1, add=other, y_init=other * 0.5, accumulate=1,
+                      w_split=int(bf), force_splits=sp)
+        aclose(y.numpy(), (ref + 1.5 * nhwc(other)).numpy(), rtol=2e-5, atol=4e-5)
