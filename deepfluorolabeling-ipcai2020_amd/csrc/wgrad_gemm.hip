@@ -60,8 +60,12 @@ __device__ __forceinline__ bf16x8_t tr_read8(const float* row0, int row_words) {
   return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-template <int WM, int WN, int TM, int TN, int TPB, bool FAST, int WS, int MATH>
+// HALO (kernel rows of a 3x3 / stride 1 / pad 1 window, Wout % 16 == 0): the 16 output pixels of a chunk lie in one image
+// row, so the three taps of a kernel row read the SAME 18 input pixels shifted by 0 / 1 / 2: they are staged once (18
+// rows instead of 3 x 16) and tap t reads rows t .. t + 15 -- a third of the gathered operand's loads and LDS writes.
+template <int WM, int WN, int TM, int TN, int TPB, bool FAST, int WS, int MATH, bool HALO = false>
 __global__ void __launch_bounds__(WM* WN * 64 * WS, wg_occ(TM* TN* TPB, FAST)) wgrad_kernel(const WgK p) {
+  static_assert(!HALO || (TPB == 3 && FAST && MATH != 0 && WS == 1), "shared halo: kernel rows of three taps, split products");
   static_assert(WS == 1 || WM * WN == 1, "pixel-interleaved waves only for one-wave tiles");
   static_assert(MATH == 0 || ((MATH == 1 || MATH == 2) && FAST), "split-bf16 products exist for the fast path only");
   constexpr int NPW = MATH == 2 ? 1 : 2;   // MATH 2 = plain bf16 products (mode 3): hi parts only
@@ -75,11 +79,13 @@ __global__ void __launch_bounds__(WM* WN * 64 * WS, wg_occ(TM* TN* TPB, FAST)) w
   // one-wave workgroups keep a single LDS image (9 KB -> 16 workgroups per CU); the next chunk waits in registers
   constexpr int NBUF = (WM * WN == 1) ? 1 : 2;
 
-  constexpr int LDS_PER = NBUF * (KP * LDD + TPB * KP * LDG);
+  constexpr int GROWS = HALO ? KP + 2 : TPB * KP;   // staged rows of the gathered operand per image
+  constexpr int QGH = ((KP + 2) * GQ + NT - 1) / NT;   // HALO: float4 per thread and chunk
+  constexpr int LDS_PER = NBUF * (KP * LDD + GROWS * LDG);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int sub = (WS > 1) ? (int)threadIdx.x / NT : 0;
   float* Ds = smem + sub * LDS_PER;    // [NBUF][KP][LDD]
-  float* Gs = Ds + NBUF * KP * LDD;    // [NBUF][TPB][KP][LDG]
+  float* Gs = Ds + NBUF * KP * LDD;    // [NBUF][TPB][KP][LDG]  (HALO: [NBUF][KP + 2][LDG])
 
   const dfl_wgrad_args& a = p.a;
   const int tid = (WS > 1) ? (int)threadIdx.x % NT : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -110,6 +116,16 @@ __global__ void __launch_bounds__(WM* WN * 64 * WS, wg_occ(TM* TN* TPB, FAST)) w
 
   float4 rd[QD];
   float4 rg[TPB][QG];
+  float4 rgh[QGH];       // HALO: the chunk's 18 staged pixel rows
+  uint32_t okGh = 0;
+  int h_ox = 0, h_oy = 0, h_n = 0;   // HALO: wave-uniform position of the chunk's first output pixel
+  if constexpr (HALO) {
+    const int m = ch_begin * KP;
+    h_ox = m % a.Wout;
+    const int tq = m / a.Wout;
+    h_oy = tq % a.Hout;
+    h_n = tq / a.Hout;
+  }
   uint32_t okG = 0;      // bit (r*TPB + tt): tap tt of gather row r is inside the image (affine needs it: pad stays 0)
   bool okD[QD][4];       // general path only
 
@@ -172,6 +188,29 @@ __global__ void __launch_bounds__(WM* WN * 64 * WS, wg_occ(TM* TN* TPB, FAST)) w
           rd[r] = make_float4(src[0], src[okD[r][1] ? 1 : 0], src[okD[r][2] ? 2 : 0], src[okD[r][3] ? 3 : 0]);
         }
       }
+    }
+    if constexpr (HALO) {
+      // staged row e <-> input pixel (h_oy - 1 + tap_dy, h_ox - 1 + e); row e = idx / GQ with idx = tid + r * NT
+      const int iy = h_oy - 1 + tap_dy;
+      const bool rowok = live && (unsigned)iy < (unsigned)Hin;
+      const int64_t pix0 = ((int64_t)h_n * Hin + iy) * Win + h_ox - 1;
+      okGh = 0;
+#pragma unroll
+      for (int r = 0; r < QGH; ++r) {
+        const int e = (tid + r * NT) / GQ;
+        const bool in = rowok && e < KP + 2 && gc < a.Cg && (unsigned)(h_ox - 1 + e) < (unsigned)Win;
+        okGh |= in ? (1u << r) : 0u;
+        rgh[r] = wbuf_load4(rsG, in ? (uint32_t)(((pix0 + e) * a.ldg + gc) * 4) : WOOB, 0);
+      }
+      h_ox += KP;
+      if (h_ox >= a.Wout) {
+        h_ox = 0;
+        if (++h_oy == a.Hout) {
+          h_oy = 0;
+          ++h_n;
+        }
+      }
+      return;
     }
     okG = 0;
 #pragma unroll
@@ -237,7 +276,28 @@ __global__ void __launch_bounds__(WM* WN * 64 * WS, wg_occ(TM* TN* TPB, FAST)) w
         }
       }
     }
-    float* Gb = Gs + buf * TPB * KP * LDG;
+    float* Gb = Gs + buf * GROWS * LDG;
+    if constexpr (HALO) {
+#pragma unroll
+      for (int r = 0; r < QGH; ++r) {
+        const int e = (tid + r * NT) / GQ;
+        if (e < KP + 2) {
+          float4 v = rgh[r];
+          if (has_aff) {   // the hardware returned zeros outside the image: the affine must leave them zero (pad after BN)
+            const bool in = (okGh >> r) & 1u;
+            v.x = in ? fmaf(v.x, gsc.x, gsh.x) : 0.f;
+            v.y = in ? fmaf(v.y, gsc.y, gsh.y) : 0.f;
+            v.z = in ? fmaf(v.z, gsc.z, gsh.z) : 0.f;
+            v.w = in ? fmaf(v.w, gsc.w, gsh.w) : 0.f;
+          }
+          uint2 parts[2];
+          split_bf16<NPW>(v, parts);
+          *reinterpret_cast<uint2*>(Gb + e * LDG + 2 * gq) = parts[0];
+          if constexpr (NPW > 1) *reinterpret_cast<uint2*>(Gb + e * LDG + BNg / 2 + 2 * gq) = parts[1];
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < QG; ++r) {
       const int idx = tid + r * NT;
@@ -291,7 +351,7 @@ __global__ void __launch_bounds__(WM* WN * 64 * WS, wg_occ(TM* TN* TPB, FAST)) w
       // channels 16*((lane>>4)&1) + 4*(lane&3) .. +3  (bf16: 2 per word)
       const int trow = 8 * lh + ((lane & 15) >> 2), tcw = 8 * ((lane >> 4) & 1) + 2 * (lane & 3);
       const float* Dt = Ds + buf * KP * LDD + trow * LDD + (wm * (TM * 32)) / 2 + tcw;
-      const float* Gt = Gs + buf * TPB * KP * LDG + trow * LDG + (wn * (TN * 32)) / 2 + tcw;
+      const float* Gt = Gs + buf * GROWS * LDG + trow * LDG + (wn * (TN * 32)) / 2 + tcw;
       bf16x8_t dp[TM][2];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -303,7 +363,7 @@ __global__ void __launch_bounds__(WM* WN * 64 * WS, wg_occ(TM* TN* TPB, FAST)) w
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int q = 0; q < NPW; ++q) gp[j][q] = tr_read8(Gt + tt * KP * LDG + j * 16 + q * (BNg / 2), LDG);
+          for (int q = 0; q < NPW; ++q) gp[j][q] = tr_read8(Gt + tt * (HALO ? 1 : KP) * LDG + j * 16 + q * (BNg / 2), LDG);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -317,7 +377,7 @@ __global__ void __launch_bounds__(WM* WN * 64 * WS, wg_occ(TM* TN* TPB, FAST)) w
       }
     }
     const float* Db = Ds + buf * KP * LDD + wm * (TM * 32) + li;
-    const float* Gb = Gs + buf * TPB * KP * LDG + wn * (TN * 32) + li;
+    const float* Gb = Gs + buf * GROWS * LDG + wn * (TN * 32) + li;
 #pragma unroll
     for (int kk = 0; kk < (MATH == 0 ? KP / 2 : 0); ++kk) {
       float dv[TM];
@@ -444,6 +504,15 @@ static WgCfg pick_wg(const dfl_wgrad_args* a) {
   return WG_64;
 }
 
+// the shared-halo form of the kernel-row variant: chunks of 16 output pixels never leave their image row
+static bool wg_halo_ok(const dfl_wgrad_args* a) {
+  static const bool on = [] {
+    const char* e = getenv("DFL_WGRAD_HALO");
+    return e == nullptr || atoi(e) != 0;
+  }();
+  return on && a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && a->Wout % KP == 0 && WG_WS == 1;
+}
+
 static void wg_tile(WgCfg c, int* bm, int* bn, int* tpb) {
   switch (c) {
     case WG_128: *bm = 128; *bn = 128; *tpb = 1; break;
@@ -489,18 +558,19 @@ static int wg_prepare(const dfl_wgrad_args* a, WgK* k, bool need_out) {
   return DFL_OK;
 }
 
-template <int WM, int WN, int TM, int TN, int TPB, bool FAST, int MATH = 0>
+template <int WM, int WN, int TM, int TN, int TPB, bool FAST, int MATH = 0, bool HALO = false>
 static int wg_launch(const WgK& k, hipStream_t s) {
   constexpr int BMc = WM * TM * 32, BNg = WN * TN * 32;
   constexpr int NBUF = (WM * WN == 1) ? 1 : 2;
   constexpr int WS = (WM * WN == 1) ? WG_WS : 1;
   constexpr int PADW = MATH ? 8 : 4;
-  size_t lds = (size_t)WS * NBUF * (KP * (BMc + PADW) + TPB * KP * (BNg + PADW)) * sizeof(float);
+  constexpr int GROWS = HALO ? KP + 2 : TPB * KP;
+  size_t lds = (size_t)WS * NBUF * (KP * (BMc + PADW) + GROWS * (BNg + PADW)) * sizeof(float);
   const size_t handover = (size_t)(WS - 1) * TPB * TM * TN * 16 * 64 * sizeof(float);
   if (handover > lds) lds = handover;
   const int tiles_g = (int)ceil_div(k.a.Cg, BNg);
   dim3 grid((unsigned)ceil_div(k.a.Cm, BMc), (unsigned)(tiles_g * (k.T / TPB)), (unsigned)k.a.splits);
-  hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, TPB, FAST, WS, MATH>), grid, dim3(WM * WN * 64 * WS), lds, s, k);
+  hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, TPB, FAST, WS, MATH, HALO>), grid, dim3(WM * WN * 64 * WS), lds, s, k);
   return check_launch("dfl_conv2d_wgrad");
 }
 
@@ -558,7 +628,9 @@ extern "C" int dfl_conv2d_wgrad(const dfl_wgrad_args* a, dfl_stream_t stream) {
     switch (dfl::pick_wg(a)) {
       case dfl::WG_128: return dfl::wg_launch<2, 2, 2, 2, 1, true, 1>(k, s);
       case dfl::WG_64: return dfl::wg_launch<2, 2, 1, 1, 1, true, 1>(k, s);
-      case dfl::WG_ROW3: return dfl::wg_launch<1, 1, 1, 1, 3, true, 1>(k, s);
+      case dfl::WG_ROW3:
+        if (dfl::wg_halo_ok(a)) return dfl::wg_launch<1, 1, 1, 1, 3, true, 1, true>(k, s);
+        return dfl::wg_launch<1, 1, 1, 1, 3, true, 1>(k, s);
       case dfl::WG_ROW2: return dfl::wg_launch<1, 1, 1, 1, 2, true, 1>(k, s);
       default: return dfl::wg_launch<1, 1, 1, 1, 1, true, 1>(k, s);
     }

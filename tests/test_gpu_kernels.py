@@ -340,6 +340,9 @@ WG_CASES = [
     (2, 16, 16, 12, 10, 2, 2, 0),
     (2, 128, 128, 7, 9, 2, 2, 0),
     (2, 7, 39, 9, 9, 1, 1, 0),          # head-like odd channel counts (scalar paths)
+    (2, 32, 32, 5, 48, 3, 1, 1),        # kernel-row variant with the shared 18-pixel halo (W % 16 == 0), image borders
+    (1, 64, 32, 3, 32, 3, 1, 1),
+    (3, 32, 64, 2, 16, 3, 1, 1),        # every chunk is a whole image row
 ]
 
 
@@ -370,6 +373,17 @@ def test_wgrad_affine_and_convT():
     y.backward(dy)
     dw, _ = wgrad_call(r.float(), dy.float(), 3, 3, 1, 1, H, W, in_aff=(sc.float(), sh.float()))
     aclose(dw.numpy(), w.grad.numpy(), rtol=1e-4, atol=1e-4)
+    # the same through the shared-halo kernel-row variant (W % 16 == 0): zero padding must stay zero behind the affine
+    N2, H2, W2 = 2, 6, 32
+    r2 = torch.randn(N2, 32, H2, W2, generator=g, dtype=torch.float64)
+    sc2, sh2 = torch.rand(32, generator=g, dtype=torch.float64) + 0.5, torch.randn(32, generator=g, dtype=torch.float64)
+    w2 = torch.zeros(32, 32, 3, 3, dtype=torch.float64, requires_grad=True)
+    y2 = F.conv2d(r2 * sc2.view(1, -1, 1, 1) + sh2.view(1, -1, 1, 1), w2, padding=1)
+    dy2 = torch.randn(y2.shape, generator=g, dtype=torch.float64)
+    y2.backward(dy2)
+    for fs in (None, 3):
+        dw2, _ = wgrad_call(r2.float(), dy2.float(), 3, 3, 1, 1, H2, W2, in_aff=(sc2.float(), sh2.float()), force_splits=fs)
+        aclose(dw2.numpy(), w2.grad.numpy(), rtol=1e-4, atol=2e-4)
     # ConvTranspose2d weight gradient: gathered = dy (stride 2), dense = x  -> [Cin][Cout][2][2]
     x = torch.randn(N, Ci, 5, 6, generator=g, dtype=torch.float64)
     wt = torch.zeros(Ci, Co, 2, 2, dtype=torch.float64, requires_grad=True)
