@@ -1,7 +1,7 @@
 // Row-tiled 3x3 convolution (stride 1, pad 1) for the wide, narrow-channel levels of the U-Net.
 //
 // Same GEMM view, operands and epilogue as conv_gemm.hip (reference: nn.Conv2d 3x3 of train_test_code/unet.py:207-218
-// and its data gradient), bf16x3 products only (math mode 1: the mode whose loop is bound by the load path), but the tile is BM consecutive pixels that form whole row
+// and its data gradient), split-bf16 products only (math modes 1 and 3: the modes whose loop is bound by the load path), but the tile is BM consecutive pixels that form whole row
 // segments -- a piece of ONE image row (W % BM == 0) or R = BM / W complete image rows (BM % W == 0) -- and K is walked
 // as (dy, channel chunk, dx): the (segment + 2) pixels x 16 channels a kernel row needs are staged in LDS once per
 // segment and the three dx taps read them at row offsets 0 / 1 / 2, instead of being gathered three times.  With 32 or
@@ -25,8 +25,11 @@ namespace dfl {
 
 template <int WM, int WN, int TM, int TN, bool AFF, int MATH>
 __global__ void __launch_bounds__(WM* WN * 64, 4) conv_rows_kernel(const ConvK p) {
-  static_assert(MATH == 3 || MATH == 4, "bf16x3 with pre-split weights (3) / both operands pre-split (4)");
-  constexpr bool XPRE = (MATH == 4);
+  // MATH: 3 = bf16x3, weights pre-split; 4 = bf16x3, both operands pre-split; 5 / 6 = the same two with plain bf16
+  // products (math mode 3: hi parts only, one matrix instruction per 16 k-values)
+  static_assert(MATH >= 3 && MATH <= 6, "bf16x3 or bf16 products with pre-split weights");
+  constexpr bool XPRE = (MATH == 4 || MATH == 6);
+  constexpr int NP = (MATH <= 4) ? 2 : 1;                  // bf16 parts per value that are staged and multiplied
   static_assert(!(XPRE && AFF), "a split input cannot take an affine on load");
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -144,10 +147,10 @@ __global__ void __launch_bounds__(WM* WN * 64, 4) conv_rows_kernel(const ConvK p
         parts[0] = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));
         parts[1] = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
       } else {
-        split_bf16<2>(v, parts);
+        split_bf16<NP>(v, parts);
       }
 #pragma unroll
-      for (int q = 0; q < 2; ++q) *reinterpret_cast<uint2*>(Ab + q * PLA + e * 8 + 4 * ((aq >> 1) ^ fA) + 2 * (aq & 1)) = parts[q];
+      for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(Ab + q * PLA + e * 8 + 4 * ((aq >> 1) ^ fA) + 2 * (aq & 1)) = parts[q];
     }
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
@@ -161,7 +164,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 4) conv_rows_kernel(const ConvK p
           const float4 v = rb[dx][r];
           // weights arrive as split quads (hi4 | lo4)
           *reinterpret_cast<uint2*>(Bb + nn * 8 + 4 * ((kq >> 1) ^ fB) + 2 * (kq & 1)) = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));
-          *reinterpret_cast<uint2*>(Bb + PLB + nn * 8 + 4 * ((kq >> 1) ^ fB) + 2 * (kq & 1)) = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
+          if constexpr (NP > 1) *reinterpret_cast<uint2*>(Bb + PLB + nn * 8 + 4 * ((kq >> 1) ^ fB) + 2 * (kq & 1)) = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
         }
       }
     }
@@ -192,7 +195,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 4) conv_rows_kernel(const ConvK p
       for (int i = 0; i < TM; ++i) aoff[i] = (erow[i] + dx) * 8 + 4 * (lh ^ (((erow[i] + dx) >> 3) & 1));
       bf16x8_t ap[TM][2], bp[TN][2];
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
+      for (int q = 0; q < NP; ++q) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) ap[i][q] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Ab + aoff[i] + q * PLA));
 #pragma unroll
@@ -202,8 +205,10 @@ __global__ void __launch_bounds__(WM* WN * 64, 4) conv_rows_kernel(const ConvK p
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {   // small terms first
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][0], bp[j][1], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][1], bp[j][0], acc[i][j], 0, 0, 0);
+          if constexpr (NP > 1) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][0], bp[j][1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][1], bp[j][0], acc[i][j], 0, 0, 0);
+          }
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][0], bp[j][0], acc[i][j], 0, 0, 0);
         }
     }
@@ -283,9 +288,9 @@ int conv_rows_tile(const ConvK& k) {
   if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.scatter2x2) return 0;
   if (a.splits <= 1 && (a.add != nullptr || a.accumulate)) return 0;     // one pass: simple epilogue only (slices: the finish kernel has them all)
   if (a.Cin % 32 != 0 || a.Hout != a.Hin || a.Wout != a.Win) return 0;
-  // bf16x3 products with the weights split by the pack kernel.  (fp32 products are bound by the matrix pipe, not by the
-  // load path: measured there, these tiles lose 3-5 % of the step against the generic kernel's, so that mode keeps it.)
-  if (math_mode() != 1 || a.w_split != 1) return 0;
+  // bf16x3 / bf16 products with the weights split by the pack kernel.  (fp32 products are bound by the matrix pipe, not by
+  // the load path: measured there, these tiles lose 3-5 % of the step against the generic kernel's, so that mode keeps it.)
+  if ((math_mode() != 1 && math_mode() != 3) || a.w_split != 1) return 0;
   if (a.x_split && a.in_scale != nullptr) return 0;
   if (a.in_scale != nullptr && (size_t)2 * a.Cin * sizeof(float) > 16 * 1024) return 0;
   // whole row segments per tile: a piece of one image row, or up to 16 complete image rows; enough tiles for 256 CUs
@@ -324,6 +329,10 @@ static int rows_launch(const ConvK& k, hipStream_t s) {
 template <int WM, int WN, int TM, int TN>
 static int rows_dispatch(const ConvK& k, hipStream_t s) {
   const bool aff = k.a.in_scale != nullptr;
+  if (math_mode() == 3) {
+    if (k.a.x_split) return rows_launch<WM, WN, TM, TN, false, 6>(k, s);
+    return aff ? rows_launch<WM, WN, TM, TN, true, 5>(k, s) : rows_launch<WM, WN, TM, TN, false, 5>(k, s);
+  }
   if (k.a.x_split) return rows_launch<WM, WN, TM, TN, false, 4>(k, s);
   return aff ? rows_launch<WM, WN, TM, TN, true, 3>(k, s) : rows_launch<WM, WN, TM, TN, false, 3>(k, s);
 }
