@@ -32,7 +32,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0        # same guide: dense bf16 MFMA (the 5 PF ma
 MATH = {'fp32': (0, 0), 'bf16x3': (1, 3), 'bf16x6': (2, 6), 'bf16': (3, 1)}
 CONV_KERNELS = ['conv_gemm_kernel<2,2,2,2>', 'conv_gemm_kernel<2,2,2,1>', 'conv_gemm_kernel<4,1,2,1>',
                 'conv_gemm_kernel<2,2,1,1>', 'conv_gemm_kernel<1,2,1,1>', 'direct_conv_kernel',
-                'conv_rows_kernel<3,1,2,1>', 'conv_rows_kernel<3,1,1,2>']
+                'conv_rows_kernel<3,1,2,1>', 'conv_rows_kernel<3,1,1,2>', 'conv_rows_kernel<3,1,1,1>']
 WGRAD_KERNELS = ['wgrad_kernel<2,2,2,2,1>', 'wgrad_kernel<2,2,1,1,1>', 'wgrad_kernel<1,1,1,1,3>',
                  'wgrad_kernel<1,1,1,1,2>', 'wgrad_kernel<1,1,1,1,1>', 'direct_wgrad_kernel']
 

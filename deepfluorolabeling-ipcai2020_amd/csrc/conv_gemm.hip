@@ -821,7 +821,7 @@ extern "C" int dfl_conv_grid_m(const dfl_conv_args* a) {
   if (rc != DFL_OK) return rc;
   if (a->splits > 1) return dfl::finish_rows(k.Mtot, a->Ntot);
   if (dfl::direct_conv_ok(a)) return dfl::direct_conv_blocks(a);
-  if (const int t = dfl::conv_rows_tile(k)) return k.Mtot / t;
+  if (const int t = dfl::conv_rows_tile(k)) return k.Mtot / dfl::conv_rows_bm(t);
   int bm, bn;
   dfl::cfg_tile(dfl::pick_cfg(k.Mtot, a->Ntot, k.fast), &bm, &bn);
   return (int)dfl::ceil_div(k.Mtot, bm);
@@ -832,7 +832,7 @@ extern "C" int dfl_conv_config(const dfl_conv_args* a) {
   int rc = dfl::prepare(a, &k);
   if (rc != DFL_OK) return rc;
   if (dfl::direct_conv_ok(a)) return dfl::CFG_DIRECT;
-  if (const int t = dfl::conv_rows_tile(k)) return t == 192 ? dfl::CFG_ROWS192 : dfl::CFG_ROWS96;
+  if (const int t = dfl::conv_rows_tile(k)) return t;
   return (int)dfl::pick_cfg(k.Mtot, a->Ntot, k.fast);
 }
 

@@ -280,7 +280,7 @@ static int rows_splits(int tiles, int Cin) {
   return 0;
 }
 
-// 0 = not eligible; otherwise the tile's pixel count (192: 192 x 32 tile, 96: 96 x 64 tile).  a.splits: 0 / 1 = asks
+// 0 = not eligible; otherwise the tile (ROWS_192x32 / ROWS_96x64 / ROWS_96x32).  a.splits: 0 / 1 = asks
 // what the kernel would choose (conv_rows_splits), > 1 = the caller's slice count must be one this kernel can take.
 int conv_rows_tile(const ConvK& k) {
   const dfl_conv_args& a = k.a;
@@ -305,8 +305,9 @@ int conv_rows_tile(const ConvK& k) {
     }
     return rows_splits(tiles, a.Cin) == 1;
   };
-  if (a.Ntot <= 32 && fits(192, 32)) return 192;
-  if (fits(96, 64)) return 96;
+  if (a.Ntot <= 32 && fits(192, 32)) return ROWS_192x32;
+  if (a.Ntot <= 32 && fits(96, 32)) return ROWS_96x32;       // (e.g. 1440-pixel rows: 15 x 96)
+  if (fits(96, 64)) return ROWS_96x64;
   return 0;
 }
 
@@ -345,15 +346,16 @@ int conv_rows_splits(const ConvK& k) {
   q.a.accumulate = 0;
   const dfl_conv_args& a = q.a;
   if (!rows_enabled() || !q.fast || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.scatter2x2) return 0;
-  for (int pass = 0; pass < 2; ++pass) {
-    const int bm = pass == 0 ? 192 : 96, bn = pass == 0 ? 32 : 64;
-    if (pass == 0 && a.Ntot > 32) continue;
+  for (int pass = 0; pass < 3; ++pass) {
+    const int code = pass == 0 ? ROWS_192x32 : (pass == 1 ? ROWS_96x32 : ROWS_96x64);
+    const int bm = conv_rows_bm(code), bn = pass == 2 ? 64 : 32;
+    if (pass < 2 && a.Ntot > 32) continue;
     const bool seg = (a.Win % bm == 0) || (bm % a.Win == 0 && bm / a.Win <= 16);
     if (!seg || q.Mtot % bm != 0 || a.Cin % 32 != 0) continue;
     const int s = rows_splits((int)((int64_t)(q.Mtot / bm) * ceil_div(a.Ntot, bn)), a.Cin);
     if (s == 0) continue;
     q.a.splits = s;
-    if (s > 1 || (k.a.add == nullptr && !k.a.accumulate)) return conv_rows_tile(s > 1 ? q : k) == bm ? s : 0;
+    if (s > 1 || (k.a.add == nullptr && !k.a.accumulate)) return conv_rows_tile(s > 1 ? q : k) == code ? s : 0;
   }
   return 0;
 }
@@ -366,8 +368,10 @@ int conv_rows_set_min_tiles(int n) {
 
 int conv_rows_launch(const ConvK& k, hipStream_t s) {
   const int t = conv_rows_tile(k);
-  DFL_REQUIRE(t != 0 && k.Mtot % t == 0, "dfl_conv2d: internal: row-tiled kernel called for an ineligible layer");
-  return t == 192 ? rows_dispatch<3, 1, 2, 1>(k, s) : rows_dispatch<3, 1, 1, 2>(k, s);
+  DFL_REQUIRE(t != 0 && k.Mtot % conv_rows_bm(t) == 0, "dfl_conv2d: internal: row-tiled kernel called for an ineligible layer");
+  if (t == ROWS_192x32) return rows_dispatch<3, 1, 2, 1>(k, s);
+  if (t == ROWS_96x32) return rows_dispatch<3, 1, 1, 1>(k, s);
+  return rows_dispatch<3, 1, 1, 2>(k, s);
 }
 
 }  // namespace dfl

@@ -708,7 +708,9 @@ def rows_everywhere():
                                    (1, 128, 64, 2, 192), (1, 32, 20, 3, 384), (2, 64, 48, 1, 96),
                                    # several complete image rows per tile, tiles that straddle two images
                                    (2, 32, 64, 48, 48), (4, 64, 128, 24, 24), (8, 32, 32, 12, 12), (16, 64, 96, 6, 6),
-                                   (2, 32, 32, 24, 48), (3, 32, 64, 8, 32)])
+                                   (2, 32, 32, 24, 48), (3, 32, 64, 8, 32),
+                                   # 96 x 32 tiles: narrow layers whose rows do not divide into 192 pixels
+                                   (1, 32, 32, 3, 96), (1, 32, 16, 2, 1440)])
 def test_conv_row_tiles(shape, math_mode, rows_everywhere):
     """The row-tiled 3x3 kernels (conv_rows.hip: wide images, <= 64 output channels; tiles of 192 / 96 pixels of one
     image row, each kernel row's pixels staged once for its three taps): plain, with the BatchNorm affine on load (zero
@@ -727,7 +729,9 @@ def test_conv_row_tiles(shape, math_mode, rows_everywhere):
     # the path under test is the one taken
     a = nat.ConvArgs(x=wp.data_ptr(), w=wp.data_ptr(), y=wp.data_ptr(), N=N, Hin=H, Win=W, Cin=Cin, ldx=Cin, KH=3, KW=3,
                      stride=1, pad=1, Hout=H, Wout=W, Ntot=Cout, ldy=Cout, w_split=int(bf))
-    want = 6 if (Cout <= 32 and (W % 192 == 0 or 192 % W == 0) and 192 // min(W, 192) <= 16 and (N * H * W) % 192 == 0) else 7
+    def fits(bm):
+        return (W % bm == 0 or (bm % W == 0 and bm // W <= 16)) and (N * H * W) % bm == 0
+    want = (6 if fits(192) else 8) if (Cout <= 32 and (fits(192) or fits(96))) else 7      # 192x32, 96x32, 96x64 tiles
     if not bf:
         pytest.skip('the row-tiled kernels exist for bf16x3 products (fp32 products are matrix-pipe bound and keep the generic tiles)')
     assert nat.check(lib.dfl_conv_config(C.addressof(a))) == want
