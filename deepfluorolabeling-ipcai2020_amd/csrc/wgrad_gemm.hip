@@ -490,19 +490,7 @@ __global__ void __launch_bounds__(256) sum_partials_wide_kernel(const float* __r
 }
 
 // ---- host side -------------------------------------------------------------------------------------
-enum WgCfg { WG_128 = 0, WG_64, WG_ROW3, WG_ROW2, WG_32 };
-
-static WgCfg pick_wg(const dfl_wgrad_args* a) {
-  const bool narrow = (a->Cm <= 64 || a->Cg <= 64);
-  if (narrow) {
-    if (a->KH == 3 && a->KW == 3) return WG_ROW3;
-    if (a->KH == 2 && a->KW == 2) return WG_ROW2;
-    return WG_32;
-  }
-  const int T = a->KH * a->KW;
-  if (a->Cm >= 256 && a->Cg >= 256 && (int64_t)a->Cm * a->Cg * T >= 128ll * 128 * 1024) return WG_128;
-  return WG_64;
-}
+enum WgCfg { WG_128 = 0, WG_64, WG_ROW3, WG_ROW2, WG_32, WG_64ROW };
 
 // the shared-halo form of the kernel-row variant: chunks of 16 output pixels never leave their image row
 static bool wg_halo_ok(const dfl_wgrad_args* a) {
@@ -513,10 +501,31 @@ static bool wg_halo_ok(const dfl_wgrad_args* a) {
   return on && a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && a->Wout % KP == 0 && WG_WS == 1;
 }
 
+static WgCfg pick_wg(const dfl_wgrad_args* a) {
+  const bool narrow = (a->Cm <= 64 || a->Cg <= 64);
+  if (narrow) {
+    if (a->KH == 3 && a->KW == 3) return WG_ROW3;
+    if (a->KH == 2 && a->KW == 2) return WG_ROW2;
+    return WG_32;
+  }
+  const int T = a->KH * a->KW;
+  if (a->Cm >= 256 && a->Cg >= 256 && (int64_t)a->Cm * a->Cg * T >= 128ll * 128 * 1024) return WG_128;
+  // 64 x 64 tiles with a kernel row of taps per workgroup and the shared halo (three accumulators per wave): a third of
+  // the loads per matrix instruction; the workgroup count is kept by three times the pixel slices (the extra partial-sum
+  // traffic costs less than the loads saved: 0.080 -> 0.051 + 0.008 ms at 48 x 48 x 128 x 128).  DFL_WGRAD_ROW64=0: off.
+  static const int row64 = [] {
+    const char* e = getenv("DFL_WGRAD_ROW64");
+    return e ? atoi(e) : 1;
+  }();
+  if (row64 && math_mode() == 1 && wg_halo_ok(a)) return WG_64ROW;
+  return WG_64;
+}
+
 static void wg_tile(WgCfg c, int* bm, int* bn, int* tpb) {
   switch (c) {
     case WG_128: *bm = 128; *bn = 128; *tpb = 1; break;
     case WG_64: *bm = 64; *bn = 64; *tpb = 1; break;
+    case WG_64ROW: *bm = 64; *bn = 64; *tpb = 3; break;
     case WG_ROW3: *bm = 32; *bn = 32; *tpb = 3; break;
     case WG_ROW2: *bm = 32; *bn = 32; *tpb = 2; break;
     default: *bm = 32; *bn = 32; *tpb = 1; break;
@@ -594,7 +603,11 @@ extern "C" int dfl_wgrad_suggest_splits(const dfl_wgrad_args* a) {
   const int waves = (bm >= 64) ? 4 : dfl::WG_WS;   // 2x2 waves of the wide tiles, WG_WS interleaved waves of the one-wave tiles
   const int64_t blocks = dfl::ceil_div(a->Cm, bm) * dfl::ceil_div(a->Cg, bn) * (k.T / tpb);
   // aim at ~4 waves per SIMD over the whole chip (4096 waves), every slice at least 128 pixels
-  int64_t s = dfl::ceil_div(4096, blocks * waves);   // (3072 / 2048 / 1536 measured with bf16x3 products: slower)
+  static const int target = [] {
+    const char* e = getenv("DFL_WGRAD_WAVES");
+    return e ? atoi(e) : 4096;
+  }();
+  int64_t s = dfl::ceil_div(tpb == 3 && bm == 64 ? target : 4096, blocks * waves);   // (3072 / 2048 / 1536 measured with bf16x3 products: slower)
   const int64_t max_by_work = k.nchunks / 8 > 0 ? k.nchunks / 8 : 1;
   if (s > max_by_work) s = max_by_work;
   if (s > 2048) s = 2048;
@@ -628,6 +641,7 @@ extern "C" int dfl_conv2d_wgrad(const dfl_wgrad_args* a, dfl_stream_t stream) {
     switch (dfl::pick_wg(a)) {
       case dfl::WG_128: return dfl::wg_launch<2, 2, 2, 2, 1, true, 1>(k, s);
       case dfl::WG_64: return dfl::wg_launch<2, 2, 1, 1, 1, true, 1>(k, s);
+      case dfl::WG_64ROW: return dfl::wg_launch<2, 2, 1, 1, 3, true, 1, true>(k, s);
       case dfl::WG_ROW3:
         if (dfl::wg_halo_ok(a)) return dfl::wg_launch<1, 1, 1, 1, 3, true, 1, true>(k, s);
         return dfl::wg_launch<1, 1, 1, 1, 3, true, 1>(k, s);
