@@ -60,9 +60,18 @@ __device__ __forceinline__ bf16x8_t tr_read8(const float* row0, int row_words) {
   return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-// HALO (kernel rows of a 3x3 / stride 1 / pad 1 window, Wout % 16 == 0): the 16 output pixels of a chunk lie in one image
-// row, so the three taps of a kernel row read the SAME 18 input pixels shifted by 0 / 1 / 2: they are staged once (18
-// rows instead of 3 x 16) and tap t reads rows t .. t + 15 -- a third of the gathered operand's loads and LDS writes.
+// HALO (kernel rows of a 3x3 / stride 1 / pad 1 window): the three taps of a kernel row read the SAME input pixels shifted by
+// 0 / 1 / 2, so they are staged once -- every image-row segment of the chunk's 16 output pixels with one halo pixel on each
+// side (18 rows when the chunk lies in one image row, up to 24 when it spans four rows of a 6-pixel-wide level) -- and
+// tap t of pixel j reads staged row j + 2 seg(j) + t: a third of the gathered operand's loads and LDS writes.
+// the same with the two 4-row halves at independent word offsets behind `base`
+__device__ __forceinline__ bf16x8_t tr_read8_2(const float* base, int off0, int off1) {
+  typedef __attribute__((address_space(3))) s16x4_t* lds_p;
+  const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + off0));
+  const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + off1));
+  return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
 template <int WM, int WN, int TM, int TN, int TPB, bool FAST, int WS, int MATH, bool HALO = false>
 __global__ void __launch_bounds__(WM* WN * 64 * WS, wg_occ(TM* TN* TPB, FAST)) wgrad_kernel(const WgK p) {
   static_assert(!HALO || (TPB == 3 && FAST && MATH != 0 && WS == 1), "shared halo: kernel rows of three taps, split products");
@@ -79,13 +88,14 @@ __global__ void __launch_bounds__(WM* WN * 64 * WS, wg_occ(TM* TN* TPB, FAST)) w
   // one-wave workgroups keep a single LDS image (9 KB -> 16 workgroups per CU); the next chunk waits in registers
   constexpr int NBUF = (WM * WN == 1) ? 1 : 2;
 
-  constexpr int GROWS = HALO ? KP + 2 : TPB * KP;   // staged rows of the gathered operand per image
-  constexpr int QGH = ((KP + 2) * GQ + NT - 1) / NT;   // HALO: float4 per thread and chunk
+  constexpr int HROWS = KP + 8;                        // HALO: 16 pixels + 2 halo pixels for each of at most 4 segments
+  constexpr int GROWS = HALO ? HROWS : TPB * KP;       // staged rows of the gathered operand per image
+  constexpr int QGH = (HROWS * GQ + NT - 1) / NT;      // HALO: float4 per thread and chunk
   constexpr int LDS_PER = NBUF * (KP * LDD + GROWS * LDG);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int sub = (WS > 1) ? (int)threadIdx.x / NT : 0;
   float* Ds = smem + sub * LDS_PER;    // [NBUF][KP][LDD]
-  float* Gs = Ds + NBUF * KP * LDD;    // [NBUF][TPB][KP][LDG]  (HALO: [NBUF][KP + 2][LDG])
+  float* Gs = Ds + NBUF * KP * LDD;    // [NBUF][TPB][KP][LDG]  (HALO: [NBUF][HROWS][LDG])
 
   const dfl_wgrad_args& a = p.a;
   const int tid = (WS > 1) ? (int)threadIdx.x % NT : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -116,7 +126,8 @@ __global__ void __launch_bounds__(WM* WN * 64 * WS, wg_occ(TM* TN* TPB, FAST)) w
 
   float4 rd[QD];
   float4 rg[TPB][QG];
-  float4 rgh[QGH];       // HALO: the chunk's 18 staged pixel rows
+  float4 rgh[QGH];       // HALO: the chunk's staged pixel rows
+  int ox_loaded = 0;     // HALO: first output column of the chunk load() fetched last
   uint32_t okGh = 0;
   int h_ox = 0, h_oy = 0, h_n = 0;   // HALO: wave-uniform position of the chunk's first output pixel
   if constexpr (HALO) {
@@ -190,21 +201,36 @@ __global__ void __launch_bounds__(WM* WN * 64 * WS, wg_occ(TM* TN* TPB, FAST)) w
       }
     }
     if constexpr (HALO) {
-      // staged row e <-> input pixel (h_oy - 1 + tap_dy, h_ox - 1 + e); row e = idx / GQ with idx = tid + r * NT
-      const int iy = h_oy - 1 + tap_dy;
-      const bool rowok = live && (unsigned)iy < (unsigned)Hin;
-      const int64_t pix0 = ((int64_t)h_n * Hin + iy) * Win + h_ox - 1;
+      // The chunk's pixels j = 0..15 start at column h_ox of output row h_oy: segment 0 holds the L0 pixels up to the end
+      // of that row, segments 1.. whole rows (the last one what is left).  Segment s is staged at rows
+      // start_s + 2 s .. start_s + 2 s + len_s + 1 = its pixels framed by their two neighbours; staged row
+      // e = idx / GQ (idx = tid + r * NT) therefore belongs to segment s(e) below and is input pixel
+      // (row of segment s - 1 + tap_dy, first column of segment s - 1 + (e - first staged row of s)).
+      const int Wd = a.Wout;
+      const int L0 = min(KP, Wd - h_ox);
+      const int rem = KP - L0;
+      const int E = KP + 2 * (1 + (rem > 0) + (rem > Wd) + (rem > 2 * Wd));   // staged rows of this chunk
+      ox_loaded = h_ox;
       okGh = 0;
 #pragma unroll
       for (int r = 0; r < QGH; ++r) {
         const int e = (tid + r * NT) / GQ;
-        const bool in = rowok && e < KP + 2 && gc < a.Cg && (unsigned)(h_ox - 1 + e) < (unsigned)Win;
+        const int sg = (e >= L0 + 2) + (e >= L0 + Wd + 4) + (e >= L0 + 2 * Wd + 6);
+        const int start = (sg == 0) ? 0 : L0 + (sg - 1) * Wd;            // first chunk pixel of the segment
+        const int x = ((sg == 0) ? h_ox : 0) - 1 + (e - start - 2 * sg);
+        int oy = h_oy + sg, n = h_n;
+        if (oy >= a.Hout) {
+          oy -= a.Hout;
+          ++n;
+        }
+        const int iy = oy - 1 + tap_dy;
+        const bool in = live && e < E && gc < a.Cg && (unsigned)x < (unsigned)Win && (unsigned)iy < (unsigned)Hin && n < a.N;
         okGh |= in ? (1u << r) : 0u;
-        rgh[r] = wbuf_load4(rsG, in ? (uint32_t)(((pix0 + e) * a.ldg + gc) * 4) : WOOB, 0);
+        rgh[r] = wbuf_load4(rsG, in ? (uint32_t)(((((int64_t)n * Hin + iy) * Win + x) * a.ldg + gc) * 4) : WOOB, 0);
       }
       h_ox += KP;
-      if (h_ox >= a.Wout) {
-        h_ox = 0;
+      while (h_ox >= Wd) {
+        h_ox -= Wd;
         if (++h_oy == a.Hout) {
           h_oy = 0;
           ++h_n;
@@ -281,7 +307,7 @@ __global__ void __launch_bounds__(WM* WN * 64 * WS, wg_occ(TM* TN* TPB, FAST)) w
 #pragma unroll
       for (int r = 0; r < QGH; ++r) {
         const int e = (tid + r * NT) / GQ;
-        if (e < KP + 2) {
+        if (e < HROWS) {
           float4 v = rgh[r];
           if (has_aff) {   // the hardware returned zeros outside the image: the affine must leave them zero (pad after BN)
             const bool in = (okGh >> r) & 1u;
@@ -344,6 +370,7 @@ __global__ void __launch_bounds__(WM* WN * 64 * WS, wg_occ(TM* TN* TPB, FAST)) w
     const int ch = ch_begin + sub + it * WS;
     const int buf = (NBUF == 2) ? (it & 1) : 0;
     const bool more = (it + 1) < nit;
+    const int ox_comp = ox_loaded;   // HALO: first column of the chunk multiplied in this trip
     if (more) load(ch + WS);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (MATH != 0) {
@@ -352,6 +379,13 @@ __global__ void __launch_bounds__(WM* WN * 64 * WS, wg_occ(TM* TN* TPB, FAST)) w
       const int trow = 8 * lh + ((lane & 15) >> 2), tcw = 8 * ((lane >> 4) & 1) + 2 * (lane & 3);
       const float* Dt = Ds + buf * KP * LDD + trow * LDD + (wm * (TM * 32)) / 2 + tcw;
       const float* Gt = Gs + buf * GROWS * LDG + trow * LDG + (wn * (TN * 32)) / 2 + tcw;
+      int gsh0 = 0, gsh1 = 4 * LDG;   // HALO: word offsets of this lane's two pixel rows (trow, trow + 4) behind Gt, tap 0
+      if constexpr (HALO) {
+        const int Wd = a.Wout, L0 = min(KP, Wd - ox_comp);
+        const int j0 = trow, j1 = trow + 4;
+        gsh0 = 2 * ((j0 >= L0) + (j0 >= L0 + Wd) + (j0 >= L0 + 2 * Wd)) * LDG;
+        gsh1 = (4 + 2 * ((j1 >= L0) + (j1 >= L0 + Wd) + (j1 >= L0 + 2 * Wd))) * LDG;
+      }
       bf16x8_t dp[TM][2];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -363,7 +397,9 @@ __global__ void __launch_bounds__(WM* WN * 64 * WS, wg_occ(TM* TN* TPB, FAST)) w
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int q = 0; q < NPW; ++q) gp[j][q] = tr_read8(Gt + tt * (HALO ? 1 : KP) * LDG + j * 16 + q * (BNg / 2), LDG);
+          for (int q = 0; q < NPW; ++q)
+            gp[j][q] = HALO ? tr_read8_2(Gt + tt * LDG + j * 16 + q * (BNg / 2), gsh0, gsh1)
+                            : tr_read8(Gt + tt * KP * LDG + j * 16 + q * (BNg / 2), LDG);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -498,7 +534,9 @@ static bool wg_halo_ok(const dfl_wgrad_args* a) {
     const char* e = getenv("DFL_WGRAD_HALO");
     return e == nullptr || atoi(e) != 0;
   }();
-  return on && a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && a->Wout % KP == 0 && WG_WS == 1;
+  // (chunks of 16 output pixels may span up to four image rows)
+  return on && a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && a->Wout >= 6 &&
+         ((int64_t)a->N * a->Hout * a->Wout) % KP == 0 && WG_WS == 1;
 }
 
 static WgCfg pick_wg(const dfl_wgrad_args* a) {
@@ -517,7 +555,10 @@ static WgCfg pick_wg(const dfl_wgrad_args* a) {
     const char* e = getenv("DFL_WGRAD_ROW64");
     return e ? atoi(e) : 1;
   }();
-  if (row64 && math_mode() == 1 && wg_halo_ok(a)) return WG_64ROW;
+  // Only where chunks stay inside an image row (W % 16 == 0), i.e. the wide levels: below that the layers are the deep
+  // ones, whose slices are megabytes each -- measured on the 192 x 192 network the extra partial sums eat the gain there
+  // (1876-1897 vs 1890-1918 images/s), while the 768 x 768 configuration gains 4 %.
+  if (row64 && math_mode() == 1 && wg_halo_ok(a) && a->Wout % KP == 0) return WG_64ROW;
   return WG_64;
 }
 
@@ -573,7 +614,7 @@ static int wg_launch(const WgK& k, hipStream_t s) {
   constexpr int NBUF = (WM * WN == 1) ? 1 : 2;
   constexpr int WS = (WM * WN == 1) ? WG_WS : 1;
   constexpr int PADW = MATH ? 8 : 4;
-  constexpr int GROWS = HALO ? KP + 2 : TPB * KP;
+  constexpr int GROWS = HALO ? KP + 8 : TPB * KP;
   size_t lds = (size_t)WS * NBUF * (KP * (BMc + PADW) + GROWS * (BNg + PADW)) * sizeof(float);
   const size_t handover = (size_t)(WS - 1) * TPB * TM * TN * 16 * 64 * sizeof(float);
   if (handover > lds) lds = handover;
@@ -603,11 +644,7 @@ extern "C" int dfl_wgrad_suggest_splits(const dfl_wgrad_args* a) {
   const int waves = (bm >= 64) ? 4 : dfl::WG_WS;   // 2x2 waves of the wide tiles, WG_WS interleaved waves of the one-wave tiles
   const int64_t blocks = dfl::ceil_div(a->Cm, bm) * dfl::ceil_div(a->Cg, bn) * (k.T / tpb);
   // aim at ~4 waves per SIMD over the whole chip (4096 waves), every slice at least 128 pixels
-  static const int target = [] {
-    const char* e = getenv("DFL_WGRAD_WAVES");
-    return e ? atoi(e) : 4096;
-  }();
-  int64_t s = dfl::ceil_div(tpb == 3 && bm == 64 ? target : 4096, blocks * waves);   // (3072 / 2048 / 1536 measured with bf16x3 products: slower)
+  int64_t s = dfl::ceil_div(4096, blocks * waves);   // (3072 / 2048 / 1536 measured with bf16x3 products: slower)
   const int64_t max_by_work = k.nchunks / 8 > 0 ? k.nchunks / 8 : 1;
   if (s > max_by_work) s = max_by_work;
   if (s > 2048) s = 2048;

@@ -343,6 +343,12 @@ WG_CASES = [
     (2, 32, 32, 5, 48, 3, 1, 1),        # kernel-row variant with the shared 18-pixel halo (W % 16 == 0), image borders
     (1, 64, 32, 3, 32, 3, 1, 1),
     (3, 32, 64, 2, 16, 3, 1, 1),        # every chunk is a whole image row
+    (16, 64, 32, 6, 6, 3, 1, 1),        # chunks that span 3-4 image rows and cross image boundaries (shared halo per segment)
+    (4, 128, 128, 12, 12, 3, 1, 1),     # wide layers, narrow images: one tap per workgroup
+    (2, 128, 256, 24, 24, 3, 1, 1),
+    (1, 128, 128, 3, 48, 3, 1, 1),      # wide layers, W % 16 == 0: 64 x 64 tile with three taps per workgroup
+    (3, 32, 32, 8, 10, 3, 1, 1),
+    (1, 32, 32, 4, 36, 3, 1, 1),
 ]
 
 
@@ -384,6 +390,17 @@ def test_wgrad_affine_and_convT():
     for fs in (None, 3):
         dw2, _ = wgrad_call(r2.float(), dy2.float(), 3, 3, 1, 1, H2, W2, in_aff=(sc2.float(), sh2.float()), force_splits=fs)
         aclose(dw2.numpy(), w2.grad.numpy(), rtol=1e-4, atol=2e-4)
+    # ... and with chunks that span several image rows and two images (6-pixel rows)
+    N3, H3, W3 = 8, 6, 6
+    r3 = torch.randn(N3, 64, H3, W3, generator=g, dtype=torch.float64)
+    sc3, sh3 = torch.rand(64, generator=g, dtype=torch.float64) + 0.5, torch.randn(64, generator=g, dtype=torch.float64)
+    w3 = torch.zeros(32, 64, 3, 3, dtype=torch.float64, requires_grad=True)
+    y3 = F.conv2d(r3 * sc3.view(1, -1, 1, 1) + sh3.view(1, -1, 1, 1), w3, padding=1)
+    dy3 = torch.randn(y3.shape, generator=g, dtype=torch.float64)
+    y3.backward(dy3)
+    for fs in (None, 2):
+        dw3, _ = wgrad_call(r3.float(), dy3.float(), 3, 3, 1, 1, H3, W3, in_aff=(sc3.float(), sh3.float()), force_splits=fs)
+        aclose(dw3.numpy(), w3.grad.numpy(), rtol=1e-4, atol=2e-4)
     # ConvTranspose2d weight gradient: gathered = dy (stride 2), dense = x  -> [Cin][Cout][2][2]
     x = torch.randn(N, Ci, 5, 6, generator=g, dtype=torch.float64)
     wt = torch.zeros(Ci, Co, 2, 2, dtype=torch.float64, requires_grad=True)
