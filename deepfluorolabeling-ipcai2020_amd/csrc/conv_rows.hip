@@ -23,8 +23,11 @@
 
 namespace dfl {
 
+#ifndef DFL_ROWS_OCC
+#define DFL_ROWS_OCC 4   // waves per SIMD the register allocation leaves room for (2 and 3 measured: equal within noise; 5 spills: -20 %)
+#endif
 template <int WM, int WN, int TM, int TN, bool AFF, int MATH>
-__global__ void __launch_bounds__(WM* WN * 64, 4) conv_rows_kernel(const ConvK p) {
+__global__ void __launch_bounds__(WM* WN * 64, DFL_ROWS_OCC) conv_rows_kernel(const ConvK p) {
   // MATH: 3 = bf16x3, weights pre-split; 4 = bf16x3, both operands pre-split; 5 / 6 = the same two with plain bf16
   // products (math mode 3: hi parts only, one matrix instruction per 16 k-values)
   static_assert(MATH >= 3 && MATH <= 6, "bf16x3 or bf16 products with pre-split weights");
