@@ -275,9 +275,10 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __res
 }
 
 // Batched sums (dfl_reduce_batch): blockIdx.x -> (job, block of the job) by binary search over the job table.
-// Many slices (count >= 64): 16 outputs x 64 slice lanes per workgroup, 4 loads in flight per lane, fp64 LDS tree.
+// Many slices (count >= 64): 32 outputs (one 128-byte line per slice) x 32 slice lanes per workgroup, 4 loads in flight
+// per lane, fp64 LDS tree.
 // Few slices: one thread per output.
-constexpr int RB_T = 1024, RB_O = 16, RB_S = 64, RB_WIDE_MIN = 64;
+constexpr int RB_T = 1024, RB_O = 32, RB_S = 32, RB_WIDE_MIN = 64;
 static inline int reduce_job_blocks(int64_t n, int count) {
   return (int)(count >= RB_WIDE_MIN ? ceil_div(n, RB_O) : ceil_div(n, RB_T));
 }
