@@ -15,17 +15,34 @@ struct Gather {   // decoded pixel -> input coordinates of tap (0,0)
   int iy0, ix0, base;
 };
 
-__device__ __forceinline__ Gather pixel_origin(int m, int Hg, int Wg, int stride, int pad, int Hin, int Win) {
-  const int ox = m % Wg;
-  const int t = m / Wg;
-  const int oy = t % Hg;
-  const int n = t / Hg;
-  Gather g;
-  g.iy0 = oy * stride - pad;
-  g.ix0 = ox * stride - pad;
-  g.base = n * Hin * Win;
-  return g;
-}
+// Output-pixel cursor advanced by a fixed step without divisions (the kernels are instruction-bound: three integer
+// divisions per pixel cost more than the 9 x 4 multiply-adds of the 3x3 window)
+struct PixCursor {
+  int ox, oy, n;
+  __device__ __forceinline__ void init(int m, int Hg, int Wg) {
+    ox = m % Wg;
+    const int t = m / Wg;
+    oy = t % Hg;
+    n = t / Hg;
+  }
+  __device__ __forceinline__ void advance(int step, int Hg, int Wg) {
+    ox += step;
+    while (ox >= Wg) {
+      ox -= Wg;
+      if (++oy == Hg) {
+        oy = 0;
+        ++n;
+      }
+    }
+  }
+  __device__ __forceinline__ Gather origin(int stride, int pad, int Hin, int Win) const {
+    Gather g;
+    g.iy0 = oy * stride - pad;
+    g.ix0 = ox * stride - pad;
+    g.base = n * Hin * Win;
+    return g;
+  }
+};
 
 // ---------------------------------------------------------------------------------------------- forward conv
 template <int KH, int KW, int CIN>
@@ -61,8 +78,10 @@ __global__ void __launch_bounds__(256) direct_conv_kernel(const dfl_conv_args a,
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   const int m_begin = blockIdx.x * rows_per_block;
   const int m_end = min(Mtot, m_begin + rows_per_block);
-  for (int m = m_begin + pl; m < m_end; m += PL) {
-    const Gather g = pixel_origin(m, a.Hout, a.Wout, a.stride, a.pad, a.Hin, a.Win);
+  PixCursor cur;
+  cur.init(min(m_begin + pl, Mtot - 1), a.Hout, a.Wout);
+  for (int m = m_begin + pl; m < m_end; m += PL, cur.advance(PL, a.Hout, a.Wout)) {
+    const Gather g = cur.origin(a.stride, a.pad, a.Hin, a.Win);
     float acc[4] = {bias[0], bias[1], bias[2], bias[3]};
     float xv[K];
 #pragma unroll
@@ -196,8 +215,10 @@ __global__ void __launch_bounds__(256) direct_wgrad_kernel(const dfl_wgrad_args 
     for (int j = 0; j < 4; ++j) acc[k][j] = 0.f;
   const int m_begin = blockIdx.x * rows_per_block;
   const int m_end = min(Mtot, m_begin + rows_per_block);
-  for (int m = m_begin + pl; m < m_end; m += PL) {
-    const Gather g = pixel_origin(m, a.Hout, a.Wout, a.stride, a.pad, a.Hin, a.Win);
+  PixCursor cur;
+  cur.init(min(m_begin + pl, Mtot - 1), a.Hout, a.Wout);
+  for (int m = m_begin + pl; m < m_end; m += PL, cur.advance(PL, a.Hout, a.Wout)) {
+    const Gather g = cur.origin(a.stride, a.pad, a.Hin, a.Win);
     const float4 d = *reinterpret_cast<const float4*>(a.d + (int64_t)m * a.ldd + 4 * q);
     float xv[K];
 #pragma unroll

@@ -526,7 +526,7 @@ __global__ void __launch_bounds__(256) sum_partials_wide_kernel(const float* __r
 }
 
 // ---- host side -------------------------------------------------------------------------------------
-enum WgCfg { WG_128 = 0, WG_64, WG_ROW3, WG_ROW2, WG_32, WG_64ROW };
+enum WgCfg { WG_128 = 0, WG_64, WG_ROW3, WG_ROW2, WG_32, WG_64ROW = 6 };   // (5 = CFG_DIRECT in dfl_wgrad_config)
 
 // the shared-halo form of the kernel-row variant: chunks of 16 output pixels never leave their image row
 static bool wg_halo_ok(const dfl_wgrad_args* a) {
