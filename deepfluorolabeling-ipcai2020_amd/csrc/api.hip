@@ -103,23 +103,23 @@ extern "C" int dfl_exec_timed(const dfl_op* ops, int32_t n_ops, dfl_stream_t str
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipEvent_t* ev = new hipEvent_t[n_ops + 1];
-  for (int i = 0; i <= n_ops; ++i) hipEventCreate(&ev[i]);
+  for (int i = 0; i <= n_ops; ++i) (void)hipEventCreate(&ev[i]);
   int rc = DFL_OK;
-  hipEventRecord(ev[0], s);
+  (void)hipEventRecord(ev[0], s);
   int done = 0;
   for (int i = 0; i < n_ops; ++i) {
     rc = exec_one(ops, i, stream, true);   // program order on one stream is a valid schedule of any program
     if (rc != DFL_OK) break;
-    hipEventRecord(ev[i + 1], s);
+    (void)hipEventRecord(ev[i + 1], s);
     done = i + 1;
   }
-  hipStreamSynchronize(s);
+  (void)hipStreamSynchronize(s);
   for (int i = 0; i < done; ++i) {
     float ms = 0.f;
-    hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+    (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
     ms_out[i] = ms;
   }
-  for (int i = 0; i <= n_ops; ++i) hipEventDestroy(ev[i]);
+  for (int i = 0; i <= n_ops; ++i) (void)hipEventDestroy(ev[i]);
   delete[] ev;
   return rc;
 }
