@@ -1,0 +1,110 @@
+"""Noise floor of the network's gradients: how far the ORACLE's own gradient moves when every convolution result carries
+rounding noise of a given relative size.  Test infrastructure (imports oracle/); used by tests/test_gpu_unet.py and
+tests/test_gpu_fullsize.py to derive per-tensor gradient bars for the product arithmetics instead of hand-widened ones.
+
+Why: the U-Net's BatchNorm layers subtract batch means, so a weight gradient is often a small difference of large
+sums; forward rounding noise of relative size eps then moves some tensors by 1e3..2e4 x eps (SURVEY section 7 measured
+the reference's OWN fp32-vs-fp64 gradient gap at 3e-3 median / 7e-3 worst).  What a correct kernel can be held to is
+therefore not a fixed relative bar but "inside k x the spread the same noise level causes in the fp64 oracle".
+
+Model of the noise: each nn.Conv2d / nn.ConvTranspose2d of the oracle (fp64) gets
+  * its forward output   y  <- y  + eps * rms(y)  * N(0,1)
+  * its data gradient    dx <- dx + eps * rms(dx) * N(0,1)
+  * its weight gradient  dw <- dw + eps * rms(dw) * N(0,1)
+which is what a GEMM with per-product relative error ~eps does to its three results.  eps per arithmetic is MEASURED on
+the GPU by conv_rel_error() below (one convolution of the HIP library against fp64), not assumed.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+
+def _rms(t):
+    return float(t.detach().double().pow(2).mean().sqrt())
+
+
+class _Noise:
+    def __init__(self, eps, seed):
+        self.eps = eps
+        self.gen = torch.Generator().manual_seed(seed)
+
+    def __call__(self, t):
+        if t is None or self.eps == 0.0:
+            return t
+        return t + (self.eps * _rms(t)) * torch.randn(t.shape, generator=self.gen, dtype=t.dtype)
+
+
+def noisy_gradients(onet, loss_of, eps, seed):
+    """Gradients of loss_of(onet) with noise of relative size eps injected at every convolution (see module docstring).
+    Returns name -> gradient tensor (None for parameters without gradient)."""
+    noise = _Noise(eps, seed)
+    handles = []
+    convs = [m for m in onet.modules() if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d))]
+    for m in convs:
+        handles.append(m.register_forward_hook(lambda mod, inp, out: noise(out)))
+        handles.append(m.register_full_backward_hook(
+            lambda mod, gin, gout: tuple(noise(g) for g in gin)))
+        handles.append(m.weight.register_hook(lambda g: noise(g)))
+    try:
+        onet.zero_grad()
+        loss = loss_of(onet)
+        loss.backward()
+        out = {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in onet.named_parameters()}
+    finally:
+        for h in handles:
+            h.remove()
+        onet.zero_grad()
+    return out
+
+
+def gradient_noise_floor(onet, loss_of, eps, seeds=(1, 2, 3, 4)):
+    """(clean, spread): clean = the oracle's gradients without noise; spread[name] = RMS over `seeds` of the relative L2
+    deviation || g_noisy - g_clean || / || g_clean || of that tensor, and spread['*'] the same for the whole gradient."""
+    clean = noisy_gradients(onet, loss_of, 0.0, 0)
+    acc = {k: 0.0 for k, v in clean.items() if v is not None}
+    acc['*'] = 0.0
+    den_all = sum(float(v.double().pow(2).sum()) for v in clean.values() if v is not None)
+    for s in seeds:
+        g = noisy_gradients(onet, loss_of, eps, s)
+        num_all = 0.0
+        for k, v in clean.items():
+            if v is None:
+                continue
+            num = float((g[k].double() - v.double()).pow(2).sum())
+            num_all += num
+            acc[k] += num / max(float(v.double().pow(2).sum()), 1e-300)
+        acc['*'] += num_all / max(den_all, 1e-300)
+    spread = {k: (a / len(seeds)) ** 0.5 for k, a in acc.items()}
+    return clean, spread
+
+
+def rel_l2(actual, ref):
+    a = np.asarray(actual, dtype=np.float64)
+    r = np.asarray(ref, dtype=np.float64)
+    return float(np.linalg.norm(a - r) / max(np.linalg.norm(r), 1e-300))
+
+
+_EPS_CACHE = {}
+
+
+def conv_rel_error(mode_name, dev='cuda'):
+    """Measured relative error (RMS of the error / RMS of the result) of ONE 3x3 convolution of libdfl_hip.so in the
+    current product arithmetic against fp64, on a layer shaped like the network's (64 -> 64 channels, 48x48, batch 2):
+    the eps that goes into gradient_noise_floor for this arithmetic.  Cached per mode name."""
+    if mode_name in _EPS_CACHE:
+        return _EPS_CACHE[mode_name]
+    import dfl_amd
+    g = torch.Generator().manual_seed(7)
+    net = dfl_amd.UNet(in_channels=64, n_classes=8, depth=1, wf=6, padding=True, batch_norm=False, do_res=False,
+                       block_depth=1, num_lands=0, do_soft_max=False)
+    x = torch.randn(2, 64, 48, 48, generator=g)
+    w = net.down_path[0].block[0].weight.detach().double()
+    b = net.down_path[0].block[0].bias.detach().double()
+    ws = net.seg_conv.weight.detach().double()
+    ref = torch.nn.functional.conv2d(torch.relu(torch.nn.functional.conv2d(x.double(), w, b, padding=1)), ws)
+    net = net.to(dev).eval()
+    with torch.no_grad():
+        y = net(x.to(dev)).cpu().double()
+    e = _rms(y - ref) / _rms(ref)
+    _EPS_CACHE[mode_name] = e
+    return e

@@ -425,6 +425,77 @@ def fixture_trajectory(unet, dice, util):
     print('trajectory losses', losses[0], losses[-1], 'dice', np.mean(d))
 
 
+def fixture_plateau(unet, dice, util):
+    """The reference trained to a plateau on the toy-ellipses set (16 training + 8 held-out images, 400 SGD steps wired as
+    train.py:405-430, learning rate cut 10x for the last 100): hard Dice per class on both sets (formula of
+    compute_actual_dice_on_test.py:63-93) -- the quantity north_star's "+-0.005 of reference" is about.  The reference is
+    run TWICE (8 threads / 1 thread: different summation orders in its convolutions) so that the fixture also records the
+    reference's own run-to-run spread at the plateau."""
+    import torch.optim as optim
+    import dataset
+    projs, segs, lands = toy_ellipses(24, 40, 40, seed=11)
+    kw = dict(n_classes=7, depth=3, wf=3, batch_norm=True, padding=True, max_pool=False,
+              num_lands=14, do_res=True, block_depth=2)
+    FAKE_FILES['plateau.h5'] = {'01': {'projs': _FakeDS(projs.numpy()), 'segs': _FakeDS(segs.numpy()),
+                                       'lands': _FakeDS(lands.numpy())},
+                                'land-names': {'num-lands': _FakeDS(np.array(14))}}
+    ds = dataset.get_dataset('plateau.h5', [1], num_classes=7, pad_img_dim=48)
+    items = [ds[i] for i in range(24)]
+    P = torch.stack([it[0] for it in items])
+    S = torch.stack([it[1] for it in items])
+    Hm = torch.stack([it[3] for it in items]).view(24, 14, 40, 40)
+    NTR, STEPS = 16, 400
+
+    def hard_dice(labels, gt):
+        d = []
+        for c in range(1, 7):
+            a, b = labels == c, gt == c
+            den = int(a.sum()) + int(b.sum())
+            d.append(2.0 * int((a & b).sum()) / den if den > 0 else 1.0)
+        return np.array(d)
+
+    def run(threads):
+        torch.set_num_threads(threads)
+        torch.manual_seed(4242)
+        net = unet.UNet(**kw)
+        sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+        opt = optim.SGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4, nesterov=True)
+        crit = dice.DiceAndHeatMapLoss2D(skip_bg=False, heatmap_wgt=0.5)
+        net.train()
+        losses = []
+        for step in range(STEPS):
+            if step == 300:
+                for gr in opt.param_groups:
+                    gr['lr'] = 0.005
+            idx = [(step * 4 + j) % NTR for j in range(4)]
+            opt.zero_grad()
+            out = net(P[idx])
+            loss = crit((util.center_crop(out[0], S[idx].shape), util.center_crop(out[1], Hm[idx].shape)),
+                        (S[idx], Hm[idx]))
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        net.eval()
+        with torch.no_grad():
+            out = net(P)
+        labels = torch.max(util.center_crop(out[0], S.shape), dim=1)[1]
+        gt = segs.long()
+        return sd0, np.array(losses), hard_dice(labels[:NTR], gt[:NTR]), hard_dice(labels[NTR:], gt[NTR:])
+
+    sd0, l8, dtr8, dva8 = run(8)
+    _, l1, dtr1, dva1 = run(1)
+    torch.set_num_threads(8)
+    res = {'projs': projs.numpy(), 'segs': segs.numpy(), 'lands': lands.numpy(), 'n_train': np.array(NTR),
+           'steps': np.array(STEPS), 'losses': l8, 'losses_1thread': l1,
+           'dice_train': dtr8, 'dice_valid': dva8, 'dice_train_1thread': dtr1, 'dice_valid_1thread': dva1}
+    for k, v in sd0.items():
+        res['sd0/' + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, 'plateau.npz'), **res)
+    print('plateau: loss %.4f -> %.4f; train dice %s (mean %.4f / 1 thread %.4f); valid dice %s (mean %.4f / %.4f)' % (
+        l8[0], l8[-20:].mean(), np.round(dtr8, 4), dtr8.mean(), dtr1.mean(), np.round(dva8, 4), dva8.mean(), dva1.mean()))
+    print('  per-class |8 threads - 1 thread|: train', np.round(np.abs(dtr8 - dtr1), 4), 'valid', np.round(np.abs(dva8 - dva1), 4))
+
+
 EST_LAND_NAMES = ['FH-l', 'FH-r', 'GSN-l', 'GSN-r', 'IOF-l', 'IOF-r', 'MOF-l', 'MOF-r', 'SPS-l', 'SPS-r', 'IPS-l', 'IPS-r',
                   'ASIS-l', 'ASIS-r']
 EST_LABEL_FOR = [5, 6, 1, 2, 1, 2, 1, 2, 1, 2, 1, 2, 1, 2]     # est_lands_csv.py:56-73
@@ -505,6 +576,9 @@ def main():
     import warm_restarts_lr as wr
     import dataset
     torch.set_num_threads(8)
+    if '--only-plateau' in sys.argv:
+        fixture_plateau(unet, dice, util)
+        return
     if '--only-est-lands' in sys.argv:
         sys.argv.remove('--only-est-lands')
         fixture_est_lands(util)
@@ -527,6 +601,7 @@ def main():
     fixture_dataset(dataset)
     fixture_ensemble(unet, util)
     fixture_trajectory(unet, dice, util)
+    fixture_plateau(unet, dice, util)
     fixture_est_lands(util)
     fixture_paper(unet, dice, util, 'paper_sc_l14', 1234, max_pool=False, num_lands=14)
     fixture_paper(unet, dice, util, 'paper_mp_l0', 1235, max_pool=True, num_lands=0)
