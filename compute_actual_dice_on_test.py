@@ -5,7 +5,7 @@ decimals), computed on the GPU by dfl_hard_dice (one launch for the whole patien
 
     python compute_actual_dice_on_test.py data.h5 out.h5 nn-segs dice.csv 4 [--no-hdr] [--num-classes 7]
 
-Files: HDF5 through h5py when it is installed, or .npz with the same dataset names.
+Files: the reference's HDF5 (dependency-free reader dfl_amd.h5lite) or .npz with the same dataset names.
 """
 import argparse
 import os

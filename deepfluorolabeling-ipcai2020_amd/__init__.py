@@ -10,5 +10,8 @@ from .ncc import ncc_2d
 from .util import center_crop, get_device
 from .warm_restarts_lr import WarmRestartLR
 from .sgd import SGD
+from . import parallel
+from .parallel import DataParallel
 
-__all__ = ['UNet', 'DiceLoss2D', 'DiceAndHeatMapLoss2D', 'ncc_2d', 'center_crop', 'get_device', 'WarmRestartLR', 'SGD']
+__all__ = ['UNet', 'DiceLoss2D', 'DiceAndHeatMapLoss2D', 'ncc_2d', 'center_crop', 'get_device', 'WarmRestartLR', 'SGD',
+           'DataParallel', 'parallel']

@@ -98,16 +98,25 @@ class DeviceDataSet(torch.utils.data.Dataset):
         return (x[0], masks[0] if masks is not None else None, lands[0] if lands is not None else None,
                 heats[0] if heats is not None else None)
 
-    def batches(self, batch_size, shuffle=False, drop_last=False):
-        """What ``DataLoader(ds, batch_size, shuffle)`` yields for the reference's dataset (train.py:365-372), already on the GPU."""
+    def batches(self, batch_size, shuffle=False, drop_last=False, shard=None):
+        """What ``DataLoader(ds, batch_size, shuffle)`` yields for the reference's dataset (train.py:365-372), already on
+        the GPU.  Data parallel: ``shard=(rank, world)`` -- every rank must draw the SAME permutation (same ``random``
+        seed); a step's global minibatch is ``batch_size * world`` consecutive entries of it and rank r takes the r-th
+        contiguous slice of ``batch_size``.  A ragged tail is cut into equal non-empty slices (both losses
+        are means over images, so equal shards keep mean-of-means exact); what does not divide is left out this epoch."""
         order = list(range(len(self)))
         if shuffle:
             random.shuffle(order)
-        for s in range(0, len(order), batch_size):
-            idx = order[s:s + batch_size]
-            if drop_last and len(idx) < batch_size:
+        rank, world = shard if shard is not None else (0, 1)
+        step = batch_size * world
+        for s in range(0, len(order), step):
+            glob = order[s:s + step]
+            if len(glob) < step and drop_last:
                 break
-            yield self._prepare(idx)
+            per = batch_size if len(glob) == step else len(glob) // world
+            if per == 0:
+                break
+            yield self._prepare(glob[rank * per:(rank + 1) * per])
 
 
 RandomDataAugDataSet = DeviceDataSet      # the reference's class name (dataset.py:42)

@@ -81,7 +81,6 @@ class DataParallel:
         self.active = dist.is_initialized() and (self.world > 1 or force_collectives)
         self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
         self.overlap = overlap
-        self._seg_cache = {}
         self.comm_stream = None
         # RCCL averages inside the collective (ReduceOp.AVG); gloo (CPU tests, single-GPU self-test) sums, then we scale
         self._avg_in_collective = False
@@ -102,10 +101,9 @@ class DataParallel:
     # -------------------------------------------------------------------------------------------------------
     def _segments(self, plan):
         """[(op_start, op_count, [(start, stop), ...])]: run ops, then reduce those arena ranges."""
-        key = id(plan)
-        seg = self._seg_cache.get(key)
-        if seg is not None:
-            return seg
+        seg = getattr(plan, '_dp_segments', None)      # kept ON the plan: dies with it (a dict keyed by id(plan) could hand
+        if seg is not None and seg[0] == self.bucket_elems:   # a recycled id the cut points of a dead plan)
+            return seg[1]
         ready = plan.grad_ready_op            # name -> index of the last op that writes this gradient
         sizes = {k: plan.P[k].numel() for k in plan.grad_names}
         order = sorted((k for k in plan.grad_names if k not in plan.dead_params), key=lambda k: ready[k])
@@ -118,7 +116,7 @@ class DataParallel:
         n_ops = len(plan.bwd)
         if start < n_ops:
             seg.append((start, n_ops - start, []))
-        self._seg_cache[key] = seg
+        plan._dp_segments = (self.bucket_elems, seg)
         return seg
 
     def _reduce(self, view, inv):

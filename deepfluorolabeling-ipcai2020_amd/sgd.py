@@ -51,6 +51,28 @@ class SGD(Optimizer):
             for p in ps:
                 self.state[p]['momentum_buffer'] = torch.zeros_like(p.data)
 
+    def load_state_dict(self, state_dict):
+        """torch restores every momentum buffer as a tensor of its own; put them back into one arena laid out like the
+        parameters, so that a resumed run keeps the one-launch-per-run update (otherwise: ~135 launches per step)."""
+        super().load_state_dict(state_dict)
+        for group in self.param_groups:
+            ps = group['params']
+            have = [p for p in ps if 'momentum_buffer' in self.state.get(p, {}) and self.state[p]['momentum_buffer'] is not None]
+            if not have or not all(p.is_cuda and p.dtype == torch.float32 for p in ps) or len({p.device for p in ps}) != 1:
+                continue
+            base = min(p.data_ptr() for p in ps)
+            end = max(p.data_ptr() + 4 * p.numel() for p in ps)
+            span = (end - base) // 4
+            if span > sum(p.numel() for p in ps) + 4 * len(ps):
+                continue                      # the parameters do not share an arena: nothing to line up with
+            flat = torch.zeros(span, dtype=torch.float32, device=ps[0].device)
+            with torch.no_grad():
+                for p in have:
+                    o = (p.data_ptr() - base) // 4
+                    view = flat[o:o + p.numel()].view(p.shape)
+                    view.copy_(self.state[p]['momentum_buffer'])
+                    self.state[p]['momentum_buffer'] = view
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None

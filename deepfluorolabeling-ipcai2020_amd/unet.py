@@ -206,6 +206,8 @@ class UNet(nn.Module):
                 p.data = v
                 off += (n + 3) // 4 * 4
         self._param_flat = flat
+        self._param_ptrs = tuple(p.data_ptr() for p in ps)
+        self.invalidate_plans() if hasattr(self, '_plans') else None
         _NETS[id(self)] = self
         for p in ps:
             p._dfl_net_id = id(self)   # lets sgd.SGD start the next step's weight re-layout right behind its update
@@ -228,7 +230,18 @@ class UNet(nn.Module):
         self._param_list = None
         self._pack_version = None
 
+    def mark_weights_dirty(self):
+        """Tell the network that convolution weights were edited behind autograd's back.  The 3x3 / 2x2 / transposed
+        convolution kernels read RE-LAID-OUT copies of the weights, rebuilt when a weight's autograd version counter moves
+        (optimizer steps, load_state_dict, any in-place torch op).  Writes that do not bump the counter -- ``p.data.fill_()``,
+        raw-pointer writes, foreign kernels -- need this call before the next forward; ``p.data = tensor`` rebinding is
+        detected by itself (the parameters are moved back into the arena)."""
+        self._pack_version = None
+
     def _state(self):
+        if self._param_list is not None and self._param_flat is not None and \
+                tuple(p.data_ptr() for p in self._param_list) != self._param_ptrs:
+            self._flatten_parameters()       # a parameter was re-bound (p.data = ...): recorded addresses are stale
         if self._param_list is None:
             self._param_names = [k for k, _ in self.named_parameters()]
             self._param_list = [p for _, p in self.named_parameters()]
@@ -312,6 +325,9 @@ class UNet(nn.Module):
                                'fallback); move the network and its input to the device')
         if x.dim() != 4 or x.shape[1] != self._cfg['in_channels']:
             raise RuntimeError('expected input of shape [B, %d, H, W]' % self._cfg['in_channels'])
+        if x.requires_grad and torch.is_grad_enabled():
+            raise NotImplementedError('gradients with respect to the network INPUT are not implemented in the HIP path (no '
+                                      'reference script asks for them); pass x.detach()')
         x = x.detach().to(torch.float32).contiguous()
         self._state()
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list)

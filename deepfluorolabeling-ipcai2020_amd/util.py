@@ -126,15 +126,19 @@ def _squeeze_heats(heats):
 
 
 # ------------------------------------------------------------------------------------------------ validation loops
-def test_dataset(ds, net, dev=None, num_lands=0):
-    """Eval-mode per-image loss; returns (mean, std) over the data set (util.py:116-165).  Leaves the net in eval mode."""
+def test_dataset(ds, net, dev=None, num_lands=0, shard=None):
+    """Eval-mode per-image loss; returns (mean, std) over the data set (util.py:116-165).  Leaves the net in eval mode.
+    ``shard=(rank, world)`` (data-parallel training): every rank evaluates the images i = rank mod world and the
+    per-image losses are summed over ranks, so all ranks return the same numbers as a single-process call."""
     dev = dev if dev is not None else next(net.parameters()).device
     crit = DiceAndHeatMapLoss2D(skip_bg=False) if num_lands > 0 else DiceLoss2D(skip_bg=False)
+    rank, world = shard if shard is not None else (0, 1)
     losses = torch.zeros(len(ds))
     count = 0
     with torch.no_grad():
         net.eval()
-        for i, (projs, masks, lands, heats) in enumerate(_items(ds)):
+        for i in range(rank, len(ds), world):
+            projs, masks, lands, heats = _item(ds, i)
             projs, masks = projs.to(dev), masks.to(dev)
             seg, heat = _split_out(net(projs), num_lands)
             seg = center_crop(seg, masks.shape)
@@ -145,8 +149,24 @@ def test_dataset(ds, net, dev=None, num_lands=0):
                 loss = crit(seg, masks)
             losses[i] = loss.item()
             count += 1
-    assert count == len(ds)
+    assert count == len(range(rank, len(ds), world))
+    if world > 1:
+        import torch.distributed as dist
+        if dist.get_backend() == 'nccl':
+            t = losses.to(dev)
+            dist.all_reduce(t)
+            losses = t.cpu()
+        else:
+            dist.all_reduce(losses)
     return torch.mean(losses), torch.std(losses)
+
+
+def _item(ds, i):
+    """Item i as the batch of one that ``DataLoader(ds, batch_size=1)`` yields (util.py:123)."""
+    if hasattr(ds, '_prepare'):
+        return ds._prepare([i])
+    it = ds[i]
+    return tuple(None if t is None else (t.unsqueeze(0) if torch.is_tensor(t) else torch.as_tensor(t).unsqueeze(0)) for t in it)
 
 
 def test_dataset_ensemble(ds, nets, dev=None, num_lands=0, dice_only=False):

@@ -7,7 +7,7 @@ normalised cross-correlation >= 0.9 (:96-124) for every (projection, landmark) p
     python est_lands_csv.py out.h5 nn-heats --use-seg nn-segs --pat 4 --out lands.csv
 
 The time column holds the batch's wall time divided by the number of landmarks (the reference times each one).
-Files: HDF5 through h5py when it is installed, or .npz with the same dataset names.
+Files: the reference's HDF5 (dependency-free reader dfl_amd.h5lite) or .npz with the same dataset names.
 """
 import argparse
 import os

@@ -39,6 +39,13 @@ def test_train_parser_matches_the_reference_flags():
     assert ns.pop('input_data_file_path') == 'data.h5'
     assert ns == TRAIN_FLAGS
     assert train.CHECKPOINT_KEYS == CHECKPOINT_KEYS
+    # the parser main() uses = the reference's flags + this build's extensions, all optional and inert by default
+    full = vars(train.build_full_parser().parse_args(['data.h5']))
+    assert {k: full[k] for k in TRAIN_FLAGS} == TRAIN_FLAGS
+    assert {k: v for k, v in full.items() if k not in TRAIN_FLAGS and k != 'input_data_file_path'} == train.EXTENSION_FLAGS
+    # every settings key of a checkpoint is either run state or produced from the command line
+    cfg = train.Settings.from_args(train.build_full_parser().parse_args(['data.h5', '--use-lands']))
+    assert set(cfg) | set(train.RUN_STATE_KEYS) == set(CHECKPOINT_KEYS)
     a = train.build_parser().parse_args(['d.h5', '--train-pats', '1,2', '--valid-pats', '3', '--num-classes', '7', '--use-lands',
                                          '--unet-no-max-pool', '--unet-batch-norm', '--unet-padding', '--nesterov',
                                          '--wgt-decay', '1e-4', '--max-num-restarts', '4'])
@@ -63,6 +70,71 @@ def test_entry_points_refuse_to_run_without_a_gpu(tmp_path):
         train.main(['d.npz', '--train-pats', '1', '--valid-pats', '2', '--no-gpu'])
     with pytest.raises(DflError):
         test_ensemble.main(['d.npz', 'o.npz', '--pats', '1', '--nets', 'a.pt', '--no-gpu'])
+
+
+def test_snapshot_policy_serialises_once_per_epoch(tmp_path):
+    """One serialisation per epoch; the other destinations of that epoch are copies (the reference's rule, train.py:
+    515-577); nothing is written on ranks other than 0."""
+    import train
+    writes = []
+
+    def writer(path):
+        writes.append(path)
+        open(path, 'w').write('net %d' % len(writes))
+    snap = train.Snapshots(writer)
+    ck, best, rst = (str(tmp_path / n) for n in ('ck.pt', 'best.pt', 'r_00.pt'))
+    snap.new_epoch()
+    snap.put(ck)
+    snap.put(best)
+    snap.put(rst)
+    snap.put(ck)
+    assert len(writes) == 1 and open(best).read() == open(ck).read() == open(rst).read() == 'net 1'
+    snap.new_epoch()
+    snap.put(best)                    # an epoch without a regular checkpoint: the best copy is written directly ...
+    snap.put(ck)                      # ... and the final checkpoint is a copy of it
+    assert len(writes) == 2 and open(ck).read() == 'net 2' and not os.path.exists(best + '.tmp')
+    off = train.Snapshots(writer, enabled=False)
+    off.new_epoch()
+    off.put(str(tmp_path / 'never.pt'))
+    assert len(writes) == 2 and not os.path.exists(str(tmp_path / 'never.pt'))
+
+
+def test_sharded_batches_partition_the_global_minibatch():
+    """Data-parallel batching: every rank draws the same permutation and takes the r-th contiguous slice of
+    each global minibatch; a ragged tail is cut into equal non-empty slices."""
+    import random
+    from dfl_amd.dataset import DeviceDataSet
+
+    class Probe(DeviceDataSet):
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+
+        def _prepare(self, idx):
+            return list(idx)
+    for n, b, world in ((32, 4, 2), (37, 4, 4), (10, 4, 2), (7, 4, 2), (5, 1, 4)):
+        per_rank = []
+        for r in range(world):
+            random.seed(11)
+            per_rank.append(list(Probe(n).batches(b, shuffle=True, shard=(r, world))))
+        random.seed(11)
+        order = list(range(n))
+        random.shuffle(order)
+        steps = len(per_rank[0])
+        assert all(len(p) == steps for p in per_rank)
+        seen = []
+        for s in range(steps):
+            sizes = {len(p[s]) for p in per_rank}
+            assert len(sizes) == 1 and sizes.pop() >= 1            # equal, non-empty shards
+            glob = [i for p in per_rank for i in p[s]]
+            assert glob == order[len(seen):len(seen) + len(glob)]   # contiguous slices of the same permutation, in rank order
+            seen += glob
+        assert len(seen) == len(set(seen)) and n - len(seen) < world * 1 + (n % (b * world)) % world + 1
+    random.seed(3)
+    single = list(Probe(10).batches(4, shuffle=True))
+    assert [len(x) for x in single] == [4, 4, 2]                   # one rank: exactly the DataLoader's batches
 
 
 def test_output_container_and_land_names_round_trip(tmp_path):

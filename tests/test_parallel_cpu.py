@@ -88,7 +88,7 @@ def _worker(rank, world, port):
         w0 = [p.detach().clone() for p in net.parameters()]
         gathered = [torch.zeros_like(w0[0]) for _ in range(world)]
         dist.all_gather(gathered, w0[0])
-        assert torch.equal(gathered[0], gathered[1])
+        assert all(torch.equal(gathered[0], g) for g in gathered[1:])
         plan = _FakePlan(real, rank)
         dp._run_backward(plan, None)
         # the fake backward ran segment by segment over the whole program, in order
@@ -108,8 +108,9 @@ def _worker(rank, world, port):
         dist.destroy_process_group()
 
 
-def test_data_parallel_gloo_world2():
+@pytest.mark.parametrize('world', [2, 4])
+def test_data_parallel_gloo(world):
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
-    mp.spawn(_worker, args=(2, port), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port), nprocs=world, join=True)

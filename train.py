@@ -1,20 +1,31 @@
 #!/usr/bin/env python3
-"""Training entry point: the command line, epoch loop, loss logs and checkpoint files of the reference's
-train_test_code/train.py (flags :29-100, resume :189-270, step body :393-430, checkpoint dictionary :463-513, exit
-rules :556-577), driving the MI355X path -- dfl_amd.UNet / losses / SGD / WarmRestartLR and the GPU-resident loader.
+"""Training entry point for the MI355X path, command-line compatible with the reference's train_test_code/train.py.
+
+What is kept from the reference (it is the contract a user of the reference relies on): every flag and default of its
+parser (train.py:29-100), the rule that a checkpoint file found at --checkpoint-net overrides the command line
+(:189-270), the two loss logs with one '{:.6f}' line per value (util.py:72-74), the checkpoint dictionary -- 37 keys in
+the order of :463-513, so checkpoints move between the two implementations in both directions --, the best-validation
+and pre-warm-restart copies and the three stop rules (:556-577).
+
+What is this build's own: the structure below (Settings / Snapshots / Trainer instead of one long script), the
+GPU-resident loader (dfl_amd.dataset: batches are built on the device by dfl_prep_batch, no DataLoader), the one-launch
+optimizer (dfl_amd.SGD) and DATA-PARALLEL training: started under torchrun (one process per GPU, RCCL) every rank takes
+a contiguous slice of each global minibatch, gradients are averaged by dfl_amd.DataParallel while backward is still
+running, rank 0 alone writes logs and checkpoints.  --batch-size is the batch PER GPU (BatchNorm statistics stay per
+replica, i.e. what the reference computes at that batch size); the global batch is --batch-size x world size.
 
     python train.py data.h5 --train-pats 1,2,3 --valid-pats 4 --num-classes 7 --unet-img-dim 192 --batch-size 16 \
         --unet-num-lvls 6 --unet-init-feats-exp 5 --unet-batch-norm --unet-padding --unet-no-max-pool --use-lands \
         --nesterov --wgt-decay 1e-4
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train.py data.h5 ...
 
-Checkpoints written here load in the reference's scripts and vice versa: same dictionary keys, same state_dict names.
-Differences, all loud: --no-gpu and --data-aug are refused (the HIP path has neither a CPU fallback nor the PIL-based
-random augmentation); the data file may be the reference's HDF5 (read through h5py when it is
-installed) or an .npz with the same dataset names; batches come from the loader's own GPU-side batch builder instead
-of a torch DataLoader over host tensors (same shuffling granularity: one random permutation per epoch).
+Extensions (not in the reference): --math, --seed, --dist-backend.  Refused loudly: --no-gpu (there is no CPU path) and
+--data-aug (PIL-based random augmentation is outside the HIP path).  The data file is the
+reference's HDF5 layout (read by the dependency-free dfl_amd.h5lite) or an .npz with the same dataset names.
 """
 import argparse
 import os
+import random
 import shutil
 import sys
 import time
@@ -27,7 +38,8 @@ import dfl_amd  # noqa: E402
 from dfl_amd import dataset, util  # noqa: E402
 from dfl_amd._native import DflError  # noqa: E402
 
-# keys of the checkpoint dictionary, in the reference's order (train.py:465-510)
+# The checkpoint dictionary of the reference (train.py:465-510), in its order.  The first group is run state, the rest
+# are the settings a checkpoint pins (Settings below), the last two the train/validation split.
 CHECKPOINT_KEYS = ['epoch', 'model-state-dict', 'optim-type', 'optimizer-state-dict', 'scheduler-state-dict', 'loss',
                    'best-valid-loss', 'save-best-valid', 'num-classes', 'depth', 'init-feats-exp', 'batch-norm', 'padding',
                    'no-max-pool', 'pad-img-size', 'batch-size', 'data-aug', 'opt-nesterov', 'opt-momentum',
@@ -35,330 +47,428 @@ CHECKPOINT_KEYS = ['epoch', 'model-state-dict', 'optim-type', 'optimizer-state-d
                    'lrs-meth', 'lrs-num-epochs', 'lrs-growth-factor', 'lrs-max-num-restarts',
                    'lrs-save-restart-net-prefix', 'lrs-save-after-n-restarts', 'lrs-num-restarts', 'lrs-patience',
                    'lrs-cooldown', 'checkpoint-freq', 'train-idx', 'valid-idx']
+RUN_STATE_KEYS = ('epoch', 'model-state-dict', 'optimizer-state-dict', 'scheduler-state-dict', 'loss', 'best-valid-loss',
+                  'train-idx', 'valid-idx')
+MATH_MODES = {'fp32': 0, 'bf16x3': 1, 'bf16x6': 2, 'bf16': 3}
 
 
 def build_parser():
-    p = argparse.ArgumentParser(description='Training.', formatter_class=argparse.ArgumentDefaultsHelpFormatter)
-    p.add_argument('input_data_file_path', type=str, help='Path to the datafile containing projections and segmentations')
-    p.add_argument('--train-pats', type=str, help='comma delimited list of patient IDs used for training')
-    p.add_argument('--valid-pats', type=str, help='comma delimited list of patient IDs used for validation')
-    p.add_argument('--num-classes', type=int, help='The number of label classes to be identified')
-    p.add_argument('--batch-size', type=int, default=1, help='Number of images each minibatch')
-    p.add_argument('--unet-img-dim', type=int, default=364,
-                   help='Dimension to adjust input images to before inputting into U-Net')
-    p.add_argument('--checkpoint-net', type=str, default='zz_checkpoint.pt', help='Path to network saved as checkpoint')
-    p.add_argument('--best-net', type=str, default='zz_best_valid.pt',
-                   help='Path to network saved with best score on the validation data')
-    p.add_argument('--checkpoint-freq', type=int, default=1,
-                   help='Frequency (in terms of epochs) at which to save the network checkpoint to disk.')
-    p.add_argument('--no-save-best-valid', action='store_true', help='Do not save best validation netowrk to disk.')
-    p.add_argument('--optim', type=str, default='sgd', help='Optimization strategy to use.')
-    p.add_argument('--lr-sched', type=str, default='cos',
-                   help="Learning rate scheduling method. 'cos' --> Cosine annealing with warm restarts, 'none' --> fixed "
-                        "LR (at initial), 'plateau' --> reduce learning rate when validation score plateaus")
-    p.add_argument('--init-lr', type=float, default=1.0e-2, help='Initial learning rate for SGN using cosine annealing')
-    p.add_argument('--lr-patience', type=int, default=20, help='Patience, in # epochs, when using LR plateau decay')
-    p.add_argument('--lr-cooldown', type=int, default=20, help='Cooldown, in # epochs, when using LR plateau decay')
-    p.add_argument('--nesterov', action='store_true', help='Use Nesterov momentum in SGD')
-    p.add_argument('--momentum', type=float, default=0.9, help='SGD momentum term')
-    p.add_argument('--wgt-decay', type=float, default=0, help='SGD weight decay term')
-    p.add_argument('--cos-anneal-epochs', type=int, default=10,
-                   help='Number of epochs in the cosine annealing LR scheduling. When using warm restarts with a growth '
-                        'factor, this is the initial period.')
-    p.add_argument('--cos-growth', type=int, default=2, help='Growth factor to use with warm restarts.')
-    p.add_argument('--save-restart-net', type=str,
-                   help='Prefix used to save networks before warm restart, file path will be <PREFIX>_XX.pt, where XX is '
-                        'the restart index')
-    p.add_argument('--save-after-n-restarts', type=int, default=0,
-                   help='Save networks prior to warm restart only after this number of restarts have been performed.')
-    p.add_argument('--max-num-restarts', type=int, default=-1,
-                   help='Maximum number of warm restarts; disabled when <= 0, otherwise overrides --max-num-epochs')
-    p.add_argument('--max-num-epochs', type=int, default=200, help='Maximum number of epochs')
-    p.add_argument('--train-loss-txt', type=str, default='train_iter_loss.txt', help='output file for training loss')
-    p.add_argument('--valid-loss-txt', type=str, default='valid_loss.txt', help='output file for validation loss')
-    p.add_argument('--no-gpu', action='store_true', help='Only use CPU - do not use GPU even if it is available')
-    p.add_argument('--max-hours', type=float, default=-1.0,
-                   help='Maximum number of hours to run for; terminates when the program does not expect to be able to '
-                        'complete another epoch. A non-positive value indicates no maximum limit.')
-    p.add_argument('--unet-num-lvls', type=int, default=5, help='Number of levels in the U-Net')
-    p.add_argument('--unet-init-feats-exp', type=int, default=4,
-                   help='Number of initial features used in the U-Net, two raised to this power.')
-    p.add_argument('--unet-batch-norm', action='store_true', help='Use Batch Normalization in U-Net')
-    p.add_argument('--unet-padding', action='store_true', help='Add padding to preserve image sizes for U-Net')
-    p.add_argument('--unet-no-max-pool', action='store_true', help='Learn downsampling weights instead of max-pooling')
-    p.add_argument('--unet-block-depth', type=int, default=2, help='Depth of the blocks of convolutions at each level')
-    p.add_argument('--data-aug', action='store_true', help='Randomly augment the data')
-    p.add_argument('--use-lands', action='store_true', help='Learn landmark heatmaps')
-    p.add_argument('--heat-coeff', type=float, default=0.5,
-                   help='Weighting applied to heatmap loss - dice gets one minus this.')
-    p.add_argument('--dice-valid', action='store_true',
-                   help='Use only dice validation loss even when training with dice + heatmap loss')
-    p.add_argument('--unet-no-res', action='store_true', help='Do not use residual connections in U-Net blocks')
-    p.add_argument('--train-valid-split', type=float, default=-1.0,
-                   help='Ratio of training data to keep as training, one minus this is used for validation. Enabled when '
-                        'a value in [0,1] is provided, and overrides the valid-pats flag.')
+    p = argparse.ArgumentParser(description='Train the segmentation / landmark U-Net on one MI355X, or data-parallel on '
+                                            'several (launch with torch.distributed.run).',
+                                formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    a = p.add_argument
+    a('input_data_file_path', type=str, help='pre-processed data file (HDF5 layout of the reference, or .npz)')
+    a('--train-pats', type=str, help='specimen numbers to train on, comma separated')
+    a('--valid-pats', type=str, help='specimen numbers to validate on, comma separated')
+    a('--num-classes', type=int, help='segmentation labels including background')
+    a('--batch-size', type=int, default=1, help='images per minibatch (per GPU when data parallel)')
+    a('--unet-img-dim', type=int, default=364, help='side the projections are reflect-padded to before the network')
+    a('--checkpoint-net', type=str, default='zz_checkpoint.pt', help='checkpoint file; resumed from when it exists')
+    a('--best-net', type=str, default='zz_best_valid.pt', help='copy of the checkpoint with the lowest validation loss')
+    a('--checkpoint-freq', type=int, default=1, help='epochs between checkpoints')
+    a('--no-save-best-valid', action='store_true', help='keep no best-validation copy')
+    a('--optim', type=str, default='sgd', help='sgd | adam | rmsprop')
+    a('--lr-sched', type=str, default='cos', help="cos (cosine annealing with warm restarts) | plateau | none")
+    a('--init-lr', type=float, default=1.0e-2, help='initial learning rate')
+    a('--lr-patience', type=int, default=20, help='plateau schedule: epochs without improvement before a cut')
+    a('--lr-cooldown', type=int, default=20, help='plateau schedule: epochs to wait after a cut')
+    a('--nesterov', action='store_true', help='Nesterov momentum (SGD)')
+    a('--momentum', type=float, default=0.9, help='momentum (SGD, RMSprop)')
+    a('--wgt-decay', type=float, default=0, help='weight decay')
+    a('--cos-anneal-epochs', type=int, default=10, help='length of the first cosine period in epochs')
+    a('--cos-growth', type=int, default=2, help='factor by which each cosine period is longer than the previous one')
+    a('--save-restart-net', type=str, help='keep the network from just before every warm restart as <PREFIX>_XX.pt')
+    a('--save-after-n-restarts', type=int, default=0, help='... but only from this restart on')
+    a('--max-num-restarts', type=int, default=-1, help='stop after this many warm restarts (> 0 replaces --max-num-epochs)')
+    a('--max-num-epochs', type=int, default=200, help='stop after this many epochs')
+    a('--train-loss-txt', type=str, default='train_iter_loss.txt', help='per-iteration training loss log')
+    a('--valid-loss-txt', type=str, default='valid_loss.txt', help='per-epoch validation loss log')
+    a('--no-gpu', action='store_true', help='(refused: this implementation has no CPU path)')
+    a('--max-hours', type=float, default=-1.0, help='stop before an epoch that would run past this many hours (> 0)')
+    a('--unet-num-lvls', type=int, default=5, help='U-Net depth')
+    a('--unet-init-feats-exp', type=int, default=4, help='log2 of the channel count of the first level')
+    a('--unet-batch-norm', action='store_true', help='BatchNorm after every 3x3 convolution + ReLU')
+    a('--unet-padding', action='store_true', help='zero-pad the 3x3 convolutions (output size = input size)')
+    a('--unet-no-max-pool', action='store_true', help='down-sample with learned 2x2 stride-2 convolutions')
+    a('--unet-block-depth', type=int, default=2, help='3x3 convolutions per block')
+    a('--data-aug', action='store_true', help='(refused: random augmentation is outside the HIP path)')
+    a('--use-lands', action='store_true', help='also learn the landmark heat maps (count read from the data file)')
+    a('--heat-coeff', type=float, default=0.5, help='weight of the heat-map loss; Dice gets one minus this')
+    a('--dice-valid', action='store_true', help='validate on Dice alone even when training with the heat-map loss')
+    a('--unet-no-res', action='store_true', help='no 1x1 residual branch in the blocks')
+    a('--train-valid-split', type=float, default=-1.0,
+      help='fraction in [0,1] of the training specimens\' images to train on, the rest validates (replaces --valid-pats)')
     return p
 
 
-def main(argv=None):
-    args = build_parser().parse_args(argv)
-    data_file_path = args.input_data_file_path
-    assert args.train_pats is not None
-    train_pats = [int(i) for i in args.train_pats.split(',')]
-    assert len(train_pats) > 0
-    valid_pats = None
-    if args.train_valid_split < 0:
-        assert args.valid_pats is not None
-        valid_pats = [int(i) for i in args.valid_pats.split(',')]
-        assert len(valid_pats) > 0
-    if args.no_gpu:
-        raise DflError('--no-gpu: this implementation runs on the MI355X only (HIP kernels, no CPU fallback)')
-    dev = dfl_amd.get_device()
-    if dev.type != 'cuda':
-        raise DflError('no GPU visible: this implementation runs on the MI355X only (HIP kernels, no CPU fallback)')
+EXTENSION_FLAGS = {'math': None, 'seed': None, 'dist_backend': None}
 
-    # run configuration: the command line, overridden by a checkpoint when one exists (train.py:189-270)
-    c = {'save-best-valid': not args.no_save_best_valid, 'num-classes': args.num_classes, 'optim-type': args.optim,
-         'depth': args.unet_num_lvls, 'init-feats-exp': args.unet_init_feats_exp, 'batch-norm': args.unet_batch_norm,
-         'padding': args.unet_padding, 'no-max-pool': args.unet_no_max_pool, 'pad-img-size': args.unet_img_dim,
-         'batch-size': args.batch_size, 'data-aug': args.data_aug, 'num-lands': 0, 'heat-coeff': args.heat_coeff,
-         'use-dice-valid': args.dice_valid, 'unet-use-res': not args.unet_no_res,
-         'unet-block-depth': args.unet_block_depth, 'opt-nesterov': args.nesterov, 'opt-momentum': args.momentum,
-         'opt-wgt-decay': args.wgt_decay, 'lrs-meth': args.lr_sched.lower(), 'lrs-num-epochs': args.cos_anneal_epochs,
-         'lrs-growth-factor': args.cos_growth, 'lrs-max-num-restarts': args.max_num_restarts,
-         'lrs-save-restart-net-prefix': args.save_restart_net, 'lrs-save-after-n-restarts': args.save_after_n_restarts,
-         'lrs-num-restarts': 0, 'lrs-patience': args.lr_patience, 'lrs-cooldown': args.lr_cooldown,
-         'checkpoint-freq': args.checkpoint_freq}
-    if args.use_lands:
-        c['num-lands'] = dataset.get_num_lands_from_dataset(data_file_path)
-        print('num. lands read from file: {}'.format(c['num-lands']))
-        assert c['num-lands'] > 0
-    train_valid_split = args.train_valid_split
-    train_idx = valid_idx = None
-    prev_state = None
-    load_from_checkpoint = os.path.exists(args.checkpoint_net)
-    if load_from_checkpoint:
-        print('loading state from checkpoint...')
-        prev_state = torch.load(args.checkpoint_net, map_location='cpu', weights_only=False)
-        print('loading unet params from checkpoint state dict...')
-        for k in c:
-            c[k] = prev_state[k]
-        for label, k in (('num. classes', 'num-classes'), ('optim. type', 'optim-type'), ('depth', 'depth'),
-                         ('init. feats. exp.', 'init-feats-exp'), ('batch norm.', 'batch-norm'),
-                         ('unet do pad img.', 'padding'), ('no max pool', 'no-max-pool'),
-                         ('reflect pad img. dim.', 'pad-img-size'), ('batch size', 'batch-size'), ('data aug.', 'data-aug'),
-                         ('num. landmarks', 'num-lands'), ('use dice for valid.', 'use-dice-valid'),
-                         ('unet use res.', 'unet-use-res'), ('unet block depth', 'unet-block-depth'),
-                         ('nesterov', 'opt-nesterov'), ('momentum', 'opt-momentum'), ('weight decay', 'opt-wgt-decay'),
-                         ('LR Sched. Method', 'lrs-meth'), ('LR Sched. Num. Epochs', 'lrs-num-epochs'),
-                         ('LR Sched. Growth Factor', 'lrs-growth-factor'),
-                         ('LR Sched. Max. Num. Restarts', 'lrs-max-num-restarts'),
-                         ('LR Sched. Save After Restart Prefix', 'lrs-save-restart-net-prefix'),
-                         ('LR Sched. Save After N Restarts', 'lrs-save-after-n-restarts'),
-                         ('LR Sched. Cur. Num. Restarts', 'lrs-num-restarts'), ('LR Plateau Patience', 'lrs-patience'),
-                         ('LR Plateau Cooldown', 'lrs-cooldown')):
-            print('{:>38}: {}'.format(label, c[k]))
-        print('Checkpoint Freq.: {} epochs'.format(c['checkpoint-freq']))
-        if train_valid_split >= 0:
-            print('loading previous train/valid split inds.')
-            train_idx, valid_idx = prev_state['train-idx'], prev_state['valid-idx']
-            assert train_idx is not None and valid_idx is not None
-    num_lands = c['num-lands']
-    lrs_is_cos, lrs_none, lrs_plateau = c['lrs-meth'] == 'cos', c['lrs-meth'] == 'none', c['lrs-meth'] == 'plateau'
-    enforce_max_num_restarts = c['lrs-max-num-restarts'] > 0
-    enforce_max_hours = args.max_hours > 0
-    if c['data-aug']:
-        raise NotImplementedError('--data-aug: random data augmentation is outside the HIP path (DESIGN.md section 7)')
 
-    print('initializing training dataset/dataloader')
-    train_ds = dataset.get_dataset(data_file_path, train_pats, num_classes=c['num-classes'], pad_img_dim=c['pad-img-size'],
-                                   data_aug=False, train_valid_split=train_valid_split if train_valid_split >= 0 else None,
-                                   train_valid_idx=(train_idx, valid_idx), dup_data_w_left_right_flip=False, device=dev)
-    valid_ds = None
-    if train_valid_split >= 0:
-        assert type(train_ds) is tuple
-        train_ds, valid_ds, train_idx, valid_idx = train_ds
-    train_ds_len = len(train_ds)
-    print('Length of training dataset: {}'.format(train_ds_len))
-    if train_valid_split < 0:
-        print('initializing validation dataset')
-        valid_ds = dataset.get_dataset(data_file_path, valid_pats, num_classes=c['num-classes'],
-                                       pad_img_dim=c['pad-img-size'], device=dev)
-    print('Length of validation dataset: {}'.format(len(valid_ds)))
+def build_full_parser():
+    """The reference's flags plus this build's extensions."""
+    p = build_parser()
+    p.add_argument('--math', type=str, default=None, choices=sorted(MATH_MODES),
+                   help='product arithmetic of the convolution GEMMs (default: the library default, DFL_MATH or fp32)')
+    p.add_argument('--seed', type=int, default=None, help='seed of initialisation and shuffling (default: unseeded)')
+    p.add_argument('--dist-backend', type=str, default=None, help="torch.distributed backend when launched with several "
+                                                                   "ranks (default nccl = RCCL)")
+    return p
 
-    print('creating network')
-    net = dfl_amd.UNet(n_classes=c['num-classes'], depth=c['depth'], wf=c['init-feats-exp'], batch_norm=c['batch-norm'],
-                       padding=c['padding'], max_pool=not c['no-max-pool'], num_lands=num_lands, do_res=c['unet-use-res'],
-                       block_depth=c['unet-block-depth'])
-    if load_from_checkpoint:
-        net.load_state_dict(prev_state['model-state-dict'])
-    print('moving network to device...')
-    net.to(dev)
-    print('creating loss function')
-    if num_lands > 0:
-        print('  Dice + Heatmap Loss...')
-        criterion = dfl_amd.DiceAndHeatMapLoss2D(skip_bg=False, heatmap_wgt=c['heat-coeff'])
-    else:
-        print('  Dice only...')
-        criterion = dfl_amd.DiceLoss2D(skip_bg=False)
 
-    lr_sched = None
-    if c['optim-type'] == 'sgd':
-        print('creating SGD optimizer and LR scheduler')
-        optimizer = dfl_amd.SGD(net.parameters(), lr=args.init_lr, momentum=c['opt-momentum'],
-                                weight_decay=c['opt-wgt-decay'], nesterov=c['opt-nesterov'])
-        if lrs_is_cos:
-            lr_sched = dfl_amd.WarmRestartLR(optimizer, init_run_period_epochs=c['lrs-num-epochs'],
-                                             growth_factor=c['lrs-growth-factor'])
-        elif lrs_plateau:
-            lr_sched = optim.lr_scheduler.ReduceLROnPlateau(optimizer, mode='min', factor=0.1, patience=c['lrs-patience'],
-                                                            cooldown=c['lrs-cooldown'])
+# ----------------------------------------------------------------------------------------------------- settings
+class Settings(dict):
+    """The part of a checkpoint that pins how a run is configured (every checkpoint key that is not run state).  Built
+    from the command line; when a checkpoint exists its values win (train.py:196-270 of the reference)."""
+
+    LABELS = (('num-classes', 'classes'), ('optim-type', 'optimizer'), ('depth', 'U-Net levels'),
+              ('init-feats-exp', 'first-level channels (log2)'), ('batch-norm', 'BatchNorm'), ('padding', 'padded convolutions'),
+              ('no-max-pool', 'strided-convolution down-sampling'), ('pad-img-size', 'padded image side'),
+              ('batch-size', 'batch per GPU'), ('data-aug', 'augmentation'), ('num-lands', 'landmarks'),
+              ('use-dice-valid', 'Dice-only validation'), ('unet-use-res', 'residual blocks'),
+              ('unet-block-depth', 'convolutions per block'), ('opt-nesterov', 'Nesterov'), ('opt-momentum', 'momentum'),
+              ('opt-wgt-decay', 'weight decay'), ('lrs-meth', 'LR schedule'), ('lrs-num-epochs', 'first cosine period'),
+              ('lrs-growth-factor', 'cosine period growth'), ('lrs-max-num-restarts', 'restart limit'),
+              ('lrs-save-restart-net-prefix', 'pre-restart copies'), ('lrs-save-after-n-restarts', '... from restart'),
+              ('lrs-num-restarts', 'restarts so far'), ('lrs-patience', 'plateau patience'),
+              ('lrs-cooldown', 'plateau cooldown'), ('checkpoint-freq', 'checkpoint every (epochs)'))
+
+    @classmethod
+    def from_args(cls, a):
+        return cls({'save-best-valid': not a.no_save_best_valid, 'num-classes': a.num_classes, 'optim-type': a.optim,
+                    'depth': a.unet_num_lvls, 'init-feats-exp': a.unet_init_feats_exp, 'batch-norm': a.unet_batch_norm,
+                    'padding': a.unet_padding, 'no-max-pool': a.unet_no_max_pool, 'pad-img-size': a.unet_img_dim,
+                    'batch-size': a.batch_size, 'data-aug': a.data_aug, 'num-lands': 0, 'heat-coeff': a.heat_coeff,
+                    'use-dice-valid': a.dice_valid, 'unet-use-res': not a.unet_no_res,
+                    'unet-block-depth': a.unet_block_depth, 'opt-nesterov': a.nesterov, 'opt-momentum': a.momentum,
+                    'opt-wgt-decay': a.wgt_decay, 'lrs-meth': a.lr_sched.lower(), 'lrs-num-epochs': a.cos_anneal_epochs,
+                    'lrs-growth-factor': a.cos_growth, 'lrs-max-num-restarts': a.max_num_restarts,
+                    'lrs-save-restart-net-prefix': a.save_restart_net,
+                    'lrs-save-after-n-restarts': a.save_after_n_restarts, 'lrs-num-restarts': 0,
+                    'lrs-patience': a.lr_patience, 'lrs-cooldown': a.lr_cooldown, 'checkpoint-freq': a.checkpoint_freq})
+
+    def adopt(self, checkpoint):
+        for k in self:
+            self[k] = checkpoint[k]
+
+    def describe(self, out=print):
+        for key, label in self.LABELS:
+            out('  {:<36} {}'.format(label + ':', self[key]))
+
+
+# ----------------------------------------------------------------------------------------------------- snapshots
+class Snapshots:
+    """Which files an epoch leaves behind.  A network is serialised at most once per epoch; further destinations of the
+    same epoch (best-validation copy, pre-restart copy, final checkpoint) are file copies of it."""
+
+    def __init__(self, writer, enabled=True):
+        self._write, self.enabled = writer, enabled
+        self._this_epoch = None
+
+    def new_epoch(self):
+        self._this_epoch = None
+
+    def put(self, path):
+        if not self.enabled:
+            return
+        if self._this_epoch is None:
+            tmp = path + '.tmp'
+            self._write(tmp)
+            shutil.move(tmp, path)                  # never leave a half-written checkpoint under the real name
+            self._this_epoch = path
+        elif self._this_epoch != path:
+            shutil.copy(self._this_epoch, path)
+
+
+# ----------------------------------------------------------------------------------------------------- trainer
+class Trainer:
+    def __init__(self, args):
+        self.args = args
+        self.rank, self.world, self.local = dfl_amd.parallel.init_process_group_from_env(args.dist_backend)
+        self.main = self.rank == 0
+        self.say = print if self.main else (lambda *a, **k: None)
+        if args.no_gpu:
+            raise DflError('--no-gpu: this implementation runs on the MI355X only (HIP kernels, no CPU fallback)')
+        self.dev = dfl_amd.get_device()
+        if self.dev.type != 'cuda':
+            raise DflError('no GPU visible: this implementation runs on the MI355X only (HIP kernels, no CPU fallback)')
+        if self.world > 1:
+            self.dev = torch.device('cuda', self.local % torch.cuda.device_count())
+            torch.cuda.set_device(self.dev)
+        if args.math is not None:
+            from dfl_amd import _native as nat
+            nat.check(nat.lib().dfl_set_math_mode(MATH_MODES[args.math]), 'dfl_set_math_mode')
+        self._seed(args.seed)
+
+        self.cfg = Settings.from_args(args)
+        if args.use_lands:
+            self.cfg['num-lands'] = dataset.get_num_lands_from_dataset(args.input_data_file_path)
+            self.say('num. lands read from file: {}'.format(self.cfg['num-lands']))
+            if self.cfg['num-lands'] <= 0:
+                raise ValueError('--use-lands: the data file names no landmarks')
+        self.train_idx = self.valid_idx = None
+        self.best_valid_loss = None
+        self.epoch = 0
+        self.last_loss = None
+        resume = None
+        self.resumed = os.path.exists(args.checkpoint_net)
+        if self.resumed:
+            self.say('loading state from checkpoint...')
+            resume = torch.load(args.checkpoint_net, map_location='cpu', weights_only=False)
+            self.cfg.adopt(resume)
+            self.say('settings taken from the checkpoint (they override the command line):')
+            self.cfg.describe(self.say)
+            if args.train_valid_split >= 0:
+                self.train_idx, self.valid_idx = resume['train-idx'], resume['valid-idx']
+                if self.train_idx is None or self.valid_idx is None:
+                    raise ValueError('--train-valid-split: the checkpoint holds no train/validation split')
+        c = self.cfg
+        if c['data-aug']:
+            raise NotImplementedError('--data-aug: random data augmentation is outside the HIP path (DESIGN.md section 7)')
+        self._load_data()
+        self._build_model(resume)
+        self._build_optimizer(resume)
+        if resume is not None:
+            self.best_valid_loss = resume['best-valid-loss']
+            self.epoch = resume['epoch']
+        del resume
+        self.snapshots = Snapshots(self._write_checkpoint, enabled=self.main)
+        fresh = not self.resumed
+        self.train_log = util.RunningFloatWriter(args.train_loss_txt, new_file=fresh) if self.main else None
+        self.valid_log = util.RunningFloatWriter(args.valid_loss_txt, new_file=fresh) if self.main else None
+
+    # ------------------------------------------------------------------------------------------- construction
+    def _seed(self, seed):
+        """Every rank must shuffle alike (each takes its slice of the same permutation): one seed for all of them."""
+        if self.world > 1 and seed is None:
+            import torch.distributed as dist
+            box = [random.SystemRandom().randrange(1 << 31) if self.main else None]
+            dist.broadcast_object_list(box, src=0)
+            seed = box[0]
+        if seed is not None:
+            random.seed(seed)
+            torch.manual_seed(seed)
+
+    def _load_data(self):
+        a, c = self.args, self.cfg
+        if a.train_pats is None:
+            raise ValueError('--train-pats is required')
+        train_pats = [int(i) for i in a.train_pats.split(',')]
+        split = a.train_valid_split if a.train_valid_split >= 0 else None
+        if split is None and a.valid_pats is None:
+            raise ValueError('give --valid-pats or --train-valid-split')
+        self.say('initializing training dataset/dataloader')
+        got = dataset.get_dataset(a.input_data_file_path, train_pats, num_classes=c['num-classes'],
+                                  pad_img_dim=c['pad-img-size'], data_aug=False, train_valid_split=split,
+                                  train_valid_idx=(self.train_idx, self.valid_idx), dup_data_w_left_right_flip=False,
+                                  device=self.dev)
+        if split is not None:
+            self.train_ds, self.valid_ds, self.train_idx, self.valid_idx = got
         else:
-            assert lrs_none
-    elif c['optim-type'] == 'adam':
-        print('creating ADAM optimizer')
-        optimizer = optim.Adam(net.parameters(), lr=args.init_lr, weight_decay=c['opt-wgt-decay'])
-        assert lrs_none
-    elif c['optim-type'] == 'rmsprop':
-        print('creating RMSProp optimizer')
-        optimizer = optim.RMSprop(net.parameters(), lr=args.init_lr, weight_decay=c['opt-wgt-decay'],
-                                  momentum=c['opt-momentum'])
-        assert lrs_none
-    else:
-        raise ValueError('unknown --optim {!r}'.format(c['optim-type']))
+            self.train_ds = got
+            self.valid_ds = dataset.get_dataset(a.input_data_file_path, [int(i) for i in a.valid_pats.split(',')],
+                                                num_classes=c['num-classes'], pad_img_dim=c['pad-img-size'], device=self.dev)
+        self.say('Length of training dataset: {}'.format(len(self.train_ds)))
+        self.say('Length of validation dataset: {}'.format(len(self.valid_ds)))
 
-    best_valid_loss = None
-    epoch = 0
-    if load_from_checkpoint:
-        optimizer.load_state_dict(prev_state['optimizer-state-dict'])
-        if lr_sched is not None:
-            lr_sched.load_state_dict(prev_state['scheduler-state-dict'])
-        best_valid_loss = prev_state['best-valid-loss']
-        epoch = prev_state['epoch']
-    del prev_state
+    def _build_model(self, resume):
+        c = self.cfg
+        self.say('creating network')
+        self.net = dfl_amd.UNet(n_classes=c['num-classes'], depth=c['depth'], wf=c['init-feats-exp'],
+                                batch_norm=c['batch-norm'], padding=c['padding'], max_pool=not c['no-max-pool'],
+                                num_lands=c['num-lands'], do_res=c['unet-use-res'], block_depth=c['unet-block-depth'])
+        if resume is not None:
+            self.net.load_state_dict(resume['model-state-dict'])
+        self.net.to(self.dev)
+        self.dp = dfl_amd.DataParallel(self.net) if self.world > 1 else None      # broadcasts rank 0's weights
+        if c['num-lands'] > 0:
+            self.say('loss: Dice + heat-map NCC (weight {})'.format(c['heat-coeff']))
+            self.criterion = dfl_amd.DiceAndHeatMapLoss2D(skip_bg=False, heatmap_wgt=c['heat-coeff'])
+        else:
+            self.say('loss: Dice')
+            self.criterion = dfl_amd.DiceLoss2D(skip_bg=False)
 
-    train_iter_loss_out = util.RunningFloatWriter(args.train_loss_txt, new_file=not load_from_checkpoint)
-    valid_loss_out = util.RunningFloatWriter(args.valid_loss_txt, new_file=not load_from_checkpoint)
-    tot_time_this_session_hours = 0.0
-    num_epochs_completed_this_session = 0
-    loss = None
+    def _build_optimizer(self, resume):
+        a, c = self.args, self.cfg
+        kind, meth = c['optim-type'], c['lrs-meth']
+        if meth not in ('cos', 'plateau', 'none'):
+            raise ValueError('unknown --lr-sched {!r}'.format(meth))
+        self.sched = None
+        if kind == 'sgd':
+            self.optimizer = dfl_amd.SGD(self.net.parameters(), lr=a.init_lr, momentum=c['opt-momentum'],
+                                         weight_decay=c['opt-wgt-decay'], nesterov=c['opt-nesterov'])
+            if meth == 'cos':
+                self.sched = dfl_amd.WarmRestartLR(self.optimizer, init_run_period_epochs=c['lrs-num-epochs'],
+                                                   growth_factor=c['lrs-growth-factor'])
+            elif meth == 'plateau':
+                self.sched = optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, mode='min', factor=0.1,
+                                                                  patience=c['lrs-patience'], cooldown=c['lrs-cooldown'])
+        elif kind in ('adam', 'rmsprop'):
+            if meth != 'none':
+                raise ValueError("--optim {} takes --lr-sched none".format(kind))
+            if kind == 'adam':
+                self.optimizer = optim.Adam(self.net.parameters(), lr=a.init_lr, weight_decay=c['opt-wgt-decay'])
+            else:
+                self.optimizer = optim.RMSprop(self.net.parameters(), lr=a.init_lr, weight_decay=c['opt-wgt-decay'],
+                                               momentum=c['opt-momentum'])
+        else:
+            raise ValueError('unknown --optim {!r}'.format(kind))
+        self.say('optimizer: {}, LR schedule: {}'.format(kind, meth))
+        if resume is not None:
+            self.optimizer.load_state_dict(resume['optimizer-state-dict'])
+            if self.sched is not None:
+                self.sched.load_state_dict(resume['scheduler-state-dict'])
 
-    def save_net(net_path):
-        state = dict(c)
-        state.update({'epoch': epoch, 'model-state-dict': net.state_dict(), 'optimizer-state-dict': optimizer.state_dict(),
-                      'scheduler-state-dict': lr_sched.state_dict() if lr_sched is not None else None,
-                      'loss': loss.detach() if loss is not None else None, 'best-valid-loss': best_valid_loss,
-                      'train-idx': train_idx, 'valid-idx': valid_idx})
-        tmp_name = '{}.tmp'.format(net_path)
-        torch.save({k: state[k] for k in CHECKPOINT_KEYS}, tmp_name)
-        shutil.move(tmp_name, net_path)
+    # ------------------------------------------------------------------------------------------- one epoch
+    def _mean_over_ranks(self, value):
+        if self.world == 1:
+            return value
+        import torch.distributed as dist
+        t = torch.tensor([value], dtype=torch.float64, device=self.dev if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(t)
+        return float(t.item()) / self.world
 
-    print('Start Training...')
-    keep_training = True
-    while keep_training:
-        epoch_start_time = time.time()
-        print('Epoch: {:03d}'.format(epoch))
+    def train_epoch(self):
+        c, net, opt = self.cfg, self.net, self.optimizer
+        n_lands = c['num-lands']
+        n_images = len(self.train_ds)
+        cosine = self.sched is not None and c['lrs-meth'] == 'cos'
+        report_every = int(0.05 * n_images)              # running average printed every 5 % of an epoch's images
         net.train()
-        num_batches, avg_loss = 0, 0.0
-        running_loss, running_loss_iter = 0.0, 0
-        running_loss_num_iters = int(0.05 * train_ds_len)
-        num_examples_run = 0
-        for projs, masks, lands, heats in train_ds.batches(c['batch-size'], shuffle=True):
-            if num_lands > 0 and heats.dim() > 4:
-                assert heats.dim() == 5 and heats.shape[2] == 1
-                heats = heats.view(heats.shape[0], heats.shape[1], heats.shape[3], heats.shape[4])
-            optimizer.zero_grad()
-            net_out = net(projs)
-            if num_lands > 0:
-                pred_masks = dfl_amd.center_crop(net_out[0], masks.shape)
-                pred_heat_maps = dfl_amd.center_crop(net_out[1], heats.shape)
-                loss = criterion((pred_masks, pred_heat_maps), (masks, heats))
+        seen = steps = 0
+        total = window = 0.0
+        in_window = 0
+        for projs, masks, _, heats in self.train_ds.batches(c['batch-size'], shuffle=True, shard=(self.rank, self.world)):
+            opt.zero_grad()
+            out = net(projs)
+            if n_lands > 0:
+                heats = util._squeeze_heats(heats)
+                loss = self.criterion((dfl_amd.center_crop(out[0], masks.shape), dfl_amd.center_crop(out[1], heats.shape)),
+                                      (masks, heats))
             else:
-                loss = criterion(dfl_amd.center_crop(net_out, masks.shape), masks)
-            loss.backward()
-            optimizer.step()
-            num_examples_run += projs.shape[0]
-            if lr_sched is not None and lrs_is_cos:
-                lr_sched.intra_epoch_step(num_examples_run / train_ds_len)
-            l = loss.item()
-            train_iter_loss_out.write(l)
-            avg_loss += l
-            num_batches += 1
-            running_loss += l
-            running_loss_iter += 1
-            if running_loss_iter == running_loss_num_iters:
-                print('    Running Avg. Loss: {:.6f}'.format(running_loss / running_loss_num_iters))
-                running_loss_iter, running_loss = 0, 0.0
-        avg_loss /= num_batches
+                loss = self.criterion(dfl_amd.center_crop(out, masks.shape), masks)
+            loss.backward()                              # data parallel: gradients leave this call averaged over ranks
+            opt.step()
+            seen += projs.shape[0] * self.world
+            if cosine:
+                self.sched.intra_epoch_step(seen / n_images)
+            self.last_loss = loss.detach()
+            value = self._mean_over_ranks(loss.item())   # the loss of the global minibatch (mean of equal shards)
+            if self.main:
+                self.train_log.write(value)
+            total += value
+            steps += 1
+            window += value
+            in_window += 1
+            if in_window == report_every:
+                self.say('    Running Avg. Loss: {:.6f}'.format(window / in_window))
+                window, in_window = 0.0, 0
+        if steps == 0:
+            raise ValueError('the training set ({} images) yields no minibatch of {} x {} ranks'.format(
+                n_images, c['batch-size'], self.world))
+        return total / steps
 
-        print('  Running validation')
-        avg_valid_loss, std_valid_loss = util.test_dataset(valid_ds, net, dev=dev,
-                                                           num_lands=0 if c['use-dice-valid'] else num_lands)
-        avg_valid_loss, std_valid_loss = float(avg_valid_loss), float(std_valid_loss)
-        valid_loss_out.write(avg_valid_loss)
-        print('  Avg. Training Loss: {:.6f}'.format(avg_loss))
-        print('  Validation Loss: {:.6f} +/- {:.6f}'.format(avg_valid_loss, std_valid_loss))
-        if lr_sched is not None:
-            if lrs_plateau:
-                lr_sched.step(avg_valid_loss)
-            else:
-                lr_sched.step()
-            if lrs_is_cos and lr_sched.just_restarted:
-                print('  Next epoch is warm restart...')
-                c['lrs-num-restarts'] += 1
-        epoch += 1
-        new_best_valid = best_valid_loss is None or avg_valid_loss < best_valid_loss
-        if new_best_valid:
-            best_valid_loss = avg_valid_loss
+    def validate(self):
+        c = self.cfg
+        mean, std = util.test_dataset(self.valid_ds, self.net, dev=self.dev,
+                                      num_lands=0 if c['use-dice-valid'] else c['num-lands'],
+                                      shard=(self.rank, self.world))
+        return float(mean), float(std)
 
-        net_saved_this_epoch_path = None
-        if epoch % c['checkpoint-freq'] == 0:
-            print('  Saving checkpoint')
-            save_net(args.checkpoint_net)
-            net_saved_this_epoch_path = args.checkpoint_net
-        if new_best_valid and c['save-best-valid']:
-            print('  Saving best validation (loss: {:.6f})'.format(best_valid_loss))
-            if net_saved_this_epoch_path is not None:
-                shutil.copy(net_saved_this_epoch_path, args.best_net)
+    # ------------------------------------------------------------------------------------------- checkpoints
+    def _write_checkpoint(self, path):
+        state = dict(self.cfg)
+        state.update({'epoch': self.epoch, 'model-state-dict': self.net.state_dict(),
+                      'optimizer-state-dict': self.optimizer.state_dict(),
+                      'scheduler-state-dict': self.sched.state_dict() if self.sched is not None else None,
+                      'loss': self.last_loss, 'best-valid-loss': self.best_valid_loss,
+                      'train-idx': self.train_idx, 'valid-idx': self.valid_idx})
+        torch.save({k: state[k] for k in CHECKPOINT_KEYS}, path)
+
+    def _finish_epoch(self, valid_loss):
+        """Scheduler step, bookkeeping and the files of this epoch.  Returns True when a warm restart follows."""
+        a, c, snap = self.args, self.cfg, self.snapshots
+        restarting = False
+        if self.sched is not None:
+            if c['lrs-meth'] == 'plateau':
+                self.sched.step(valid_loss)
             else:
-                save_net(args.best_net)
-                net_saved_this_epoch_path = args.best_net
+                self.sched.step()
+                restarting = bool(self.sched.just_restarted)
+        if restarting:
+            self.say('  warm restart: the next epoch starts a new cosine period')
+            c['lrs-num-restarts'] += 1
+        self.epoch += 1
+        improved = self.best_valid_loss is None or valid_loss < self.best_valid_loss
+        if improved:
+            self.best_valid_loss = valid_loss
+        snap.new_epoch()
+        if self.epoch % c['checkpoint-freq'] == 0:
+            self.say('  Saving checkpoint')
+            snap.put(a.checkpoint_net)
+        if improved and c['save-best-valid']:
+            self.say('  Saving best validation (loss: {:.6f})'.format(self.best_valid_loss))
+            snap.put(a.best_net)
         prefix = c['lrs-save-restart-net-prefix']
-        if lrs_is_cos and lr_sched.just_restarted and prefix is not None \
-                and c['lrs-num-restarts'] >= c['lrs-save-after-n-restarts']:
-            restart_net_path = '{}_{:02d}.pt'.format(prefix, c['lrs-num-restarts'] - 1)
-            print('  Saving network before restart {} to {}'.format(c['lrs-num-restarts'], restart_net_path))
-            if net_saved_this_epoch_path is not None:
-                shutil.copy(net_saved_this_epoch_path, restart_net_path)
-            else:
-                save_net(restart_net_path)
-                net_saved_this_epoch_path = restart_net_path
+        if restarting and prefix is not None and c['lrs-num-restarts'] >= c['lrs-save-after-n-restarts']:
+            path = '{}_{:02d}.pt'.format(prefix, c['lrs-num-restarts'] - 1)
+            self.say('  Saving network before restart {} to {}'.format(c['lrs-num-restarts'], path))
+            snap.put(path)
 
-        this_epoch_hours = (time.time() - epoch_start_time) / 3600.0
-        print('  This epoch took {:.4f} hours!'.format(this_epoch_hours))
-        tot_time_this_session_hours += this_epoch_hours
-        num_epochs_completed_this_session += 1
-        avg_epoch_time_hours = tot_time_this_session_hours / num_epochs_completed_this_session
-        print('  Current average epoch runtime: {:.4f} hours'.format(avg_epoch_time_hours))
-        if enforce_max_hours and tot_time_this_session_hours + avg_epoch_time_hours > args.max_hours:
-            print('  Exiting - did not expect to be able to complete next expoch within time limit!')
-            keep_training = False
-        if enforce_max_num_restarts:
+    def _stop_reason(self, hours_so_far, hours_per_epoch):
+        a, c = self.args, self.cfg
+        if a.max_hours > 0 and hours_so_far + hours_per_epoch > a.max_hours:
+            return 'another epoch would not fit into the time limit'
+        if c['lrs-max-num-restarts'] > 0:
             if c['lrs-num-restarts'] >= c['lrs-max-num-restarts']:
-                keep_training = False
-                print('  Exiting - maximum number of restarts performed!')
-        elif epoch >= args.max_num_epochs:
-            keep_training = False
-            print('  Exiting - maximum number of epochs performed!')
-        if not keep_training:
-            print('    saving checkpoint before exit!')
-            if net_saved_this_epoch_path is None:
-                save_net(args.checkpoint_net)
-            elif net_saved_this_epoch_path != args.checkpoint_net:
-                shutil.copy(net_saved_this_epoch_path, args.checkpoint_net)
-    train_iter_loss_out.close()
-    valid_loss_out.close()
-    print('Training Hours: {:.4f}'.format(tot_time_this_session_hours))
+                return 'maximum number of restarts performed'
+        elif self.epoch >= a.max_num_epochs:
+            return 'maximum number of epochs performed'
+        return None
+
+    # ------------------------------------------------------------------------------------------- driver
+    def run(self):
+        a = self.args
+        self.say('Start Training...' + (' ({} ranks, global batch {})'.format(self.world, self.world * self.cfg['batch-size'])
+                                        if self.world > 1 else ''))
+        hours = 0.0
+        done = 0
+        while True:
+            t0 = time.time()
+            self.say('Epoch: {:03d}'.format(self.epoch))
+            train_loss = self.train_epoch()
+            self.say('  Running validation')
+            valid_loss, valid_std = self.validate()
+            if self.main:
+                self.valid_log.write(valid_loss)
+            self.say('  Avg. Training Loss: {:.6f}'.format(train_loss))
+            self.say('  Validation Loss: {:.6f} +/- {:.6f}'.format(valid_loss, valid_std))
+            self._finish_epoch(valid_loss)
+            spent = (time.time() - t0) / 3600.0
+            hours += spent
+            done += 1
+            self.say('  This epoch took {:.4f} hours (average {:.4f})'.format(spent, hours / done))
+            why = self._stop_reason(hours, hours / done)
+            if self.world > 1:                      # wall-clock decisions must not differ between ranks: rank 0 decides
+                import torch.distributed as dist
+                box = [why]
+                dist.broadcast_object_list(box, src=0)
+                why = box[0]
+            if why is not None:
+                self.say('  Exiting - {}!'.format(why))
+                self.snapshots.put(a.checkpoint_net)      # the final state always ends up in the checkpoint file
+                break
+        if self.main:
+            self.train_log.close()
+            self.valid_log.close()
+        self.say('Training Hours: {:.4f}'.format(hours))
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def main(argv=None):
+    Trainer(build_full_parser().parse_args(argv)).run()
 
 
 if __name__ == '__main__':
