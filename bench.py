@@ -9,8 +9,8 @@ Workload (BASELINE.json configs[1]): the paper architecture (depth 6, 32..1024 c
 strided-conv down-sampling, residual blocks) with the seg + 14-landmark heat-map heads, batch 16 PER GPU of synthetic
 1x192x192 images (184x184 reflect-padded size), Dice + NCC loss, SGD(nesterov 0.9, wd 1e-4): one step =
 zero_grad -> forward -> crop -> loss -> backward -> optimizer step -> loss.item(), exactly train.py:405-430.
-Inputs and targets are resident in HBM before the timed region.  Arithmetic is fp32 (exact-f32 MFMA); no step of the
-loop is skipped.  Rank 0 prints ONE JSON line.
+Inputs and targets are resident in HBM before the timed region.  Product arithmetic: --math (default bf16x3; the fp32- and bf16-product timings ride along in the
+same line); no step of the loop is skipped.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes as C
@@ -30,6 +30,7 @@ F32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, 
 BF16_MFMA_PEAK_TFLOPS = 2500.0        # same guide: dense bf16 MFMA (the 5 PF marketing figure is 2:1 sparse)
 # product arithmetic of the GEMM kernels (include/dfl_hip.h): name -> (mode, bf16 MFMA products per fp32 product)
 MATH = {'fp32': (0, 0), 'bf16x3': (1, 3), 'bf16x6': (2, 6), 'bf16': (3, 1)}
+TRAFFIC_FILE = 'r01_traffic.json'      # per-kernel HBM bytes from the committed rocprofv3 --pmc passes of this round
 CONV_KERNELS = ['conv_gemm_kernel<2,2,2,2>', 'conv_gemm_kernel<2,2,2,1>', 'conv_gemm_kernel<4,1,2,1>',
                 'conv_gemm_kernel<2,2,1,1>', 'conv_gemm_kernel<1,2,1,1>', 'direct_conv_kernel',
                 'conv_rows_kernel<3,1,2,1>', 'conv_rows_kernel<3,1,1,2>', 'conv_rows_kernel<3,1,1,1>']
@@ -91,21 +92,98 @@ def op_profile(plan, lib, nat, stream, detail=None):
     return groups
 
 
-def cpu_baseline(B, steps=2):
+def _cpu_steps(net, opt, x, tseg, theat, warm, steps, R):
+    for _ in range(warm):
+        R.train_step(net, opt, x, tseg, theat, 0.5)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        R.train_step(net, opt, x, tseg, theat, 0.5)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(B):
     """The oracle (CPU restatement of the reference, checked against it in tests/test_oracle_golden.py) on this box's
-    host cores, same workload and step body."""
+    host cores: the same step body (train.py:405-430), PyTorch CPU fp32.  Thread count: swept over 8 / 16 / 32 / 64 / all
+    cores on short runs of BASELINE configs[0] (batch 4, segmentation head only), the best one is used for 10 timed steps
+    of configs[0] and for a bounded sample of the batch-`B` dual-head workload the GPU line is quoted on."""
     from oracle import ref_cpu as R
+    prev = torch.get_num_threads()
+    ncpu = os.cpu_count() or prev
+    cfg0 = dict(PAPER, num_lands=0)
+    torch.manual_seed(1234)
+    net0 = R.OracleUNet(**cfg0)
+    opt0 = torch.optim.SGD(net0.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4, nesterov=True)
+    x0, t0seg, _ = synth_batch(4, 99, 'cpu')
+    net0.train()
+    sweep = {}
+    for th in sorted({t for t in (8, 16, 32, 64, ncpu) if t <= ncpu}):
+        torch.set_num_threads(th)
+        sweep[th] = round(4 * 2 / _cpu_steps(net0, opt0, x0, t0seg, None, 1, 2, R), 2)
+    best = max(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    d0 = _cpu_steps(net0, opt0, x0, t0seg, None, 0, 10, R)
     torch.manual_seed(1234)
     net = R.OracleUNet(**PAPER)
     opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4, nesterov=True)
     x, tseg, theat = synth_batch(B, 4321, 'cpu')
     net.train()
-    R.train_step(net, opt, x, tseg, theat, 0.5)          # warm-up
+    dw = _cpu_steps(net, opt, x, tseg, theat, 0, 1, R)                    # warm-up, also sizes the sample
+    steps = max(3, min(10, int(15.0 / max(dw, 1e-3))))
+    d = _cpu_steps(net, opt, x, tseg, theat, 0, steps, R)
+    torch.set_num_threads(prev)
+    return {'value': round(B * steps / d, 2), 'unit': 'images/sec', 'cores': best, 'kind': 'port',
+            'sample': '%d training steps (after 1 warm-up) of the same batch-%d paper dual-head workload, oracle/ref_cpu.py '
+                      '(PyTorch CPU fp32), torch.set_num_threads(%d) = the best of the sweep' % (steps, B, best),
+            'host_cpus': ncpu, 'thread_sweep_images_per_sec_configs0': sweep,
+            'configs0': {'value': round(4 * 10 / d0, 2), 'unit': 'images/sec', 'steps': 10, 'threads': best,
+                         'workload': 'BASELINE configs[0]: batch 4, 7-class segmentation head only, Dice loss, SGD nesterov'}}
+
+
+def fwd_ms_per_img(lib, nat, dev):
+    """Second half of BASELINE.json's metric: eval-mode forward time per image -- batch 1 at 192x192 (the 8x-downsampled
+    size) and the 5-net full-resolution ensemble of configs[4] (1436x1436 padded to 1440, one hipGraph replay per net plus
+    the ensemble reduction of util.py:318-373)."""
+    import dfl_amd
+    from dfl_amd import util
+    out = {}
+    torch.manual_seed(7)
+    net = dfl_amd.UNet(**PAPER).to(dev).eval()
+    x = torch.randn(1, 1, 192, 192, device=dev)
+    with torch.no_grad():
+        for _ in range(5):
+            net(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            net(x)
+        torch.cuda.synchronize()
+    out['192x192_batch1'] = round((time.perf_counter() - t0) / 50 * 1e3, 4)
+    del net
+    nets = []
+    for i in range(5):
+        torch.manual_seed(10 + i)
+        nets.append(dfl_amd.UNet(**PAPER).to(dev).eval())
+    x = torch.randn(1, 1, 1440, 1440, device=dev)
+
+    def one():
+        with torch.no_grad():
+            outs = [n(x) for n in nets]
+            return util.ensemble_reduce([o[0] for o in outs], [o[1] for o in outs], (1436, 1436))
+    one()
+    one()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        R.train_step(net, opt, x, tseg, theat, 0.5)
-    dt = time.perf_counter() - t0
-    return B * steps / dt, steps
+    for _ in range(4):
+        one()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 4
+    out['1440x1440_5net_ensemble'] = round(dt * 1e3, 3)
+    out['1440x1440_per_net'] = round(dt * 1e3 / 5, 3)
+    out['unit'] = 'ms per image'
+    out['note'] = 'eval forward, inputs resident in HBM, hipGraph replay per net; ensemble figure includes dfl_ensemble_reduce'
+    del nets
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -116,6 +194,7 @@ def main():
     ap.add_argument('--batch', type=int, default=16, help='images per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
+    ap.add_argument('--no-fwd', action='store_true', help='skip the eval-forward timings (fwd_ms_per_img)')
     ap.add_argument('--detail', action='store_true', help='per-op table on stderr')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' for a self-test)")
     ap.add_argument('--optimizer', default='dfl', choices=['dfl', 'torch'],
@@ -143,6 +222,7 @@ def main():
     dev = torch.device('cuda', local % torch.cuda.device_count())   # (gloo self-test: several ranks may share a GPU)
     torch.cuda.set_device(dev)
     lib = nat.lib()
+    mode_before = lib.dfl_get_math_mode()
     nat.check(lib.dfl_set_math_mode(MATH[args.math][0]), 'dfl_set_math_mode')
 
     torch.manual_seed(1234)
@@ -205,26 +285,30 @@ def main():
         name, (ms, fl, n, by) = dom
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         nprod = MATH[args.math][1]
-        peak = F32_MFMA_PEAK_TFLOPS if nprod == 0 else BF16_MFMA_PEAK_TFLOPS / nprod
+        # peak = the guide's hardware peak of the matrix instruction this kernel issues (MI355X_MICROARCH.md): dense bf16
+        # MFMA for every bf16-product mode, fp32 MFMA for fp32 products.  `achieved` counts ALGORITHMIC flops (2 * MACs of
+        # the layer), so emulation overhead (3 / 6 bf16 products per fp32 product) shows as a lower fraction, not as a
+        # lower roof; `mfma_issue_frac` = achieved * products-per-product / peak is the share of the pipe's issue slots.
+        peak = F32_MFMA_PEAK_TFLOPS if nprod == 0 else BF16_MFMA_PEAK_TFLOPS
         roofline = {'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 2), 'peak': round(peak, 1),
                     'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': None,
-                    'peak_note': ('fp32 MFMA peak' if nprod == 0 else
-                                  'achieved = fp32-equivalent algorithmic flop/s; peak = %.0f TFLOP/s dense bf16 MFMA / %d bf16 '
-                                  'products per fp32 product (the fp32-MFMA peak is %.1f: achieved/that = %.2f)'
-                                  % (BF16_MFMA_PEAK_TFLOPS, nprod, F32_MFMA_PEAK_TFLOPS, achieved / F32_MFMA_PEAK_TFLOPS)),
+                    'mfma_issue_frac': round(achieved * max(nprod, 1) / peak, 4),
+                    'peak_note': ('fp32 MFMA peak (v_mfma_f32_32x32x2_f32)' if nprod == 0 else
+                                  'dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16); this mode issues %d bf16 product(s) per '
+                                  'algorithmic product' % nprod),
                     'launches_per_step': n, 'avg_launch_ms': round(ms / n, 4),
                     'share_of_kernel_time': round(ms / tot_ms, 3),
                     'algorithmic_flop_per_launch': round(fl / n), 'compulsory_bytes_per_launch': round(by / n)}
         # HBM bytes per launch of that kernel come from the separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE;
         # tools/profile_round.sh), which cannot run inside this process; the committed summary is quoted when present
-        tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_traffic.json')
+        tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', TRAFFIC_FILE)
         if os.path.exists(tfile):
             try:
                 rec = json.load(open(tfile))['kernels'].get(name)
                 if rec:
                     roofline['traffic'] = rec['hbm_bytes_per_launch']
                     roofline['traffic_unit'] = 'HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB, rocprofv3 PMC passes of ' \
-                                               'the same command (profiles/r01_traffic.json)'
+                                               'the same command (profiles/%s)' % TRAFFIC_FILE
             except (ValueError, KeyError):
                 pass
         fl_all = sum(v[1] for v in groups.values())
@@ -260,12 +344,13 @@ def main():
             extra['bf16_products'] = {'value': round(B * n32 / d16, 2), 'ms_per_step': round(d16 / n32 * 1e3, 3), 'steps': n32}
         nat.check(lib.dfl_set_math_mode(MATH[args.math][0]), 'dfl_set_math_mode')
 
+    if rank == 0 and world == 1 and not args.no_profile and not args.no_fwd:
+        extra['fwd_ms_per_img'] = fwd_ms_per_img(lib, nat, dev)
+    nat.check(lib.dfl_set_math_mode(mode_before), 'dfl_set_math_mode')
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        v, nst = cpu_baseline(B)
-        cpu = {'value': round(v, 2), 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
-               'sample': '%d training steps (after 1 warm-up) of the same batch-%d paper dual-head workload, oracle/ref_cpu.py '
-                         '(PyTorch CPU fp32)' % (nst, B)}
+        cpu = cpu_baseline(B)
 
     if rank == 0:
         out = {'metric': 'train images/sec, paper U-Net (depth 6, wf 5, BN, strided-conv down, seg + 14-landmark heads), '

@@ -1,10 +1,11 @@
 """Whole-path parity on the GPU: the HIP U-Net + losses against the golden fixtures produced by the reference
 (tests/golden, tools/gen_golden.py) and against the CPU oracle on the same seeded inputs.  pytest -m gpu.
 
-Tolerances: forward fp32 outputs 1e-4 relative (north_star); label argmax bit-exact wherever the fp64 reference's
-top-2 margin exceeds 1e-5; gradients are compared on the tiny presets at 2e-3 relative to the
-tensor's scale and on the paper preset against fp64 gradient norms at 2e-2 (the reference's own fp32-vs-fp64 gap
-is 3e-3 median / 7e-3 worst)."""
+Tolerances: forward fp32 outputs 1e-4 relative (north_star); label argmax bit-exact outside the pixels whose fp64 top-2
+margin is at rounding level (label_mask below); gradients inside bars DERIVED from a measured noise floor
+(tests/noise_floor.py: k x the spread of the fp64 oracle's own gradient under convolution noise of the size measured for
+the arithmetic under test, per tensor and for the whole gradient) -- no hand-widened per-mode constants; hard Dice at a
+training plateau within +-0.005 of the reference's own run (tests/golden/plateau.npz)."""
 import numpy as np
 import pytest
 import torch
@@ -13,9 +14,44 @@ import dfl_amd
 from dfl_amd import _native as nat
 from conftest import TINY_CFGS, PAPER_CFGS, load_golden, by_mode
 from oracle import ref_cpu as R
+import noise_floor as NF
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
+
+
+def oracle64(cfg, state_dict):
+    o = R.OracleUNet(**cfg).double()
+    o.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in state_dict.items()})
+    return o.train()
+
+
+def oracle_run(x, tseg, theat, skip_bg=False):
+    """run(net) -> (loss, seg) for noise_floor.GradientFloor: the loss wiring of train.py:405-421 in fp64."""
+    def run(net):
+        o = net(x.double())
+        seg = o[0] if isinstance(o, tuple) else o
+        if theat is not None:
+            loss = R.dice_and_heatmap_loss_2d((R.center_crop(seg, tseg.shape), R.center_crop(o[1], theat.shape)),
+                                              (tseg.double(), theat.double()), skip_bg=False, heatmap_wgt=0.5)
+        else:
+            loss = R.dice_loss_2d(R.center_crop(seg, tseg.shape), tseg.double(), skip_bg=skip_bg)
+        return loss, seg
+    return run
+
+
+def label_mask(seg64, hip_seg=None):
+    """Pixels where arg-max labels may legitimately differ from the fp64 reference: top-2 margin below 1e-5 (SURVEY
+    section 7: the reference's own fp32 run flips there), or -- when the HIP soft-max is given -- below 2.5 x its largest
+    deviation from fp64 (a label can only flip where the margin is under twice the deviation; the deviation itself is
+    held to the 1e-4 forward bar).  Everything outside the mask must match bit for bit."""
+    top2 = seg64.topk(2, dim=1)[0]
+    margin = (top2[:, 0] - top2[:, 1])
+    thr = 1e-5
+    if hip_seg is not None:
+        thr = max(thr, 2.5 * float((hip_seg.detach().double().cpu() - seg64).abs().max()))
+    assert thr < 2.5e-4, 'forward deviation %.3e is outside the 1e-4 bar' % (thr / 2.5)
+    return margin < thr
 
 
 def _t(a):
@@ -38,10 +74,7 @@ def rel_close(actual, ref, rtol, what):
 
 @pytest.mark.parametrize('name', sorted(TINY_CFGS))
 def test_tiny_golden(name, math_mode):
-    # forward bars (1e-4) are the same for both product modes; gradient bars per tensor: 2e-3 of the tensor's scale with
-    # fp32 products, 1e-1 with split-bf16 products (their 2e-5 forward noise is amplified by the BatchNorm cancellations:
-    # the worst tensors are nearly-cancelling sums) -- plus the whole gradient vector within 2e-3 / 5e-2 (relative L2)
-    gtol = by_mode(math_mode, 2e-3, 1e-1)
+    # forward bars (1e-4) are the same for both product modes; gradient bars come from the measured noise floor
     cfg = TINY_CFGS[name]
     g = load_golden(name)
     net = load_net(g, cfg)
@@ -63,19 +96,23 @@ def test_tiny_golden(name, math_mode):
         loss = dfl_amd.DiceLoss2D(skip_bg=False)(dfl_amd.center_crop(seg, tseg.shape), tseg)
     assert abs(loss.item() - float(g['loss'])) < 5e-6
     has_grads = any(k.startswith('grad/') for k in g)
+    sd0 = {k[4:]: _t(v) for k, v in g.items() if k.startswith('sd0/')}
     if has_grads:
         loss.backward()
+        gf = NF.GradientFloor(oracle64(cfg, sd0), oracle_run(_t(g['x']), _t(g['tseg']), _t(g['theat']) if nl > 0 else None))
+        got = {k: p.grad for k, p in net.named_parameters()}
+        gf.check(got, seg, NF.conv_rel_error(math_mode), what=name + ' ')
+        # ... and against the REFERENCE's own (fp32) gradients: inside the same bars plus the reference's own distance
+        # from fp64 on that tensor
+        _, bars = gf.bars(seg, NF.conv_rel_error(math_mode))
         for k, p in net.named_parameters():
             ref = g['grad/' + k]
             if ref.size == 0:
                 assert p.grad is None, k
                 continue
-            assert p.grad is not None, k
-            rel_close(p.grad.cpu().numpy(), ref, gtol, 'grad ' + k)
-        num = sum(float(((p.grad.cpu().double() - _t(g['grad/' + k]).double()) ** 2).sum()) for k, p in net.named_parameters()
-                  if g['grad/' + k].size)
-        den = sum(float((_t(g['grad/' + k]).double() ** 2).sum()) for k, p in net.named_parameters() if g['grad/' + k].size)
-        assert (num / den) ** 0.5 <= by_mode(math_mode, 2e-3, 5e-2), 'whole-gradient relative L2 error %.3e' % (num / den) ** 0.5
+            e_ref = NF.rel_l2(ref, gf.clean[k].numpy())
+            e = NF.rel_l2(p.grad.cpu().numpy(), ref)
+            assert e <= bars[k] + e_ref, 'grad %s vs reference: %.3e > %.3e + %.3e' % (k, e, bars[k], e_ref)
     elif cfg['batch_norm'] is False and cfg['do_res']:
         # the reference cannot back-propagate this configuration (in-place add on a ReLU output); ours can: compare
         # with the oracle, which uses the out-of-place form
@@ -87,9 +124,8 @@ def test_tiny_golden(name, math_mode):
         ol = R.dice_and_heatmap_loss_2d((R.center_crop(oo[0], g['tseg'].shape), R.center_crop(oo[1], g['theat'].shape)),
                                         (_t(g['tseg']), _t(g['theat'])), skip_bg=False, heatmap_wgt=0.5)
         ol.backward()
-        for (k, p), (_, q) in zip(net.named_parameters(), onet.named_parameters()):
-            if q.grad is not None:
-                rel_close(p.grad.cpu().numpy(), q.grad.numpy(), gtol, 'grad ' + k)
+        gf = NF.GradientFloor(oracle64(cfg, sd0), oracle_run(_t(g['x']), _t(g['tseg']), _t(g['theat'])))
+        gf.check({k: p.grad for k, p in net.named_parameters()}, seg, NF.conv_rel_error(math_mode), what=name + ' ')
     for k in [k for k in g if k.startswith('sd1/')]:
         np.testing.assert_allclose(net.state_dict()[k[4:]].cpu().numpy(), g[k], rtol=1e-4, atol=1e-6, err_msg=k)
     net.eval()
@@ -139,31 +175,72 @@ def test_paper_golden(name, math_mode):
     assert np.array_equal(am[~close], g['argmax64'][~close])
     loss.backward()
     names = list(g['param_names'])
-    # the whole gradient vector: its norm against the fp64 reference's (what an SGD step sees).  Per-tensor bars for
-    # split-bf16 products are wide: at batch 2 with random weights some encoder gradients amplify forward rounding noise
-    # by ~2e4 (fp32's 1e-6 -> 2 %, bf16x3's 2e-5 -> 40 % on down_path.4.block.0.weight of the max-pool preset; both
-    # kernels are accurate to 2e-7 / 4e-6 on that very layer, tools/exp/mode_kernel_check.py)
+    # Gradients: every tensor and the whole vector inside k x the spread the fp64 oracle's own gradient shows under
+    # convolution noise at the level of this arithmetic's measured forward error (tests/noise_floor.py).  The oracle
+    # carries the seeded weights whose SHA-256 was just checked against the reference's.
+    torch.manual_seed(seed)
+    ref_net = R.OracleUNet(**cfg)
+    gf = _paper_floor(name, cfg, ref_net.state_dict(), x, tseg.cpu(), theat.cpu() if nl > 0 else None)
+    got = {k: p.grad for k, p in net.named_parameters()}
+    worst, whole, eps_eff = gf.check(got, seg, NF.conv_rel_error(math_mode), what=name + ' ')
+    print('%s %s: conv noise %.2e, whole-gradient error %.3e, worst per-tensor error / bar %.2f' % (name, math_mode, eps_eff, whole, worst))
+    # ... and against the numbers of the REFERENCE's own fp64 run (tests/golden): per-tensor norms, small tensors in full
+    _, bars = gf.bars(seg, NF.conv_rel_error(math_mode))
     tot = sum(float(p.grad.double().norm()) ** 2 for p in net.parameters() if p.grad is not None) ** 0.5
     ref_tot = sum(float(v) ** 2 for v in g['gradnorm64'] if v >= 0) ** 0.5
-    assert abs(tot - ref_tot) <= by_mode(math_mode, 5e-3, 5e-2) * ref_tot, 'gradient norm %.6e vs fp64 %.6e' % (tot, ref_tot)
+    assert abs(tot - ref_tot) <= bars['*'] * ref_tot, 'gradient norm %.6e vs fp64 reference %.6e' % (tot, ref_tot)
     for k, p in net.named_parameters():
         ref = float(g['gradnorm64'][names.index(k)])
         if ref < 0:
             assert p.grad is None, k
             continue
-        got = p.grad.double().norm().item()
-        assert abs(got - ref) <= by_mode(math_mode, 2e-2, 5e-1) * max(ref, 1e-7), '%s: grad norm %.6e vs fp64 reference %.6e' % (k, got, ref)
+        n_got = p.grad.double().norm().item()
+        assert abs(n_got - ref) <= bars[k] * max(ref, 1e-12), '%s: grad norm %.6e vs fp64 reference %.6e (bar %.2e)' % (k, n_got, ref, bars[k])
         gk = 'g64/' + k
-        if gk in g and (math_mode == 'fp32' or not k.endswith('.bias')):   # (pre-BN bias gradients are pure rounding noise)
-            # element-wise check on the small tensors: relative L2 (the measure BASELINE.md quotes for the reference's
-            # own fp32-vs-fp64 gap: 3e-3 median, 7e-3 worst) plus a looser max-abs bound; the pre-BatchNorm conv
-            # biases are sums over ~10^5 pixels that cancel to ~1e-5, i.e. mostly rounding noise of the fp32 forward
-            ref_g = g[gk]
-            diff = p.grad.cpu().numpy().astype(np.float64) - ref_g
-            l2 = float(np.linalg.norm(diff) / max(np.linalg.norm(ref_g), 1e-12))
-            # (split-bf16 products: the same cancellations amplify 2e-5 instead of 1e-6 of forward noise)
-            assert l2 <= by_mode(math_mode, 2e-2, 5e-1), '%s: relative L2 error %.3e' % (k, l2)
-            rel_close(p.grad.cpu().numpy(), ref_g, by_mode(math_mode, 8e-2, 6e-1), 'grad ' + k)
+        if gk in g:
+            l2 = NF.rel_l2(p.grad.cpu().numpy(), g[gk])
+            assert l2 <= bars[k], '%s: relative L2 error %.3e vs the reference fp64 gradient (bar %.2e)' % (k, l2, bars[k])
+
+
+_PAPER_FLOORS = {}
+
+
+def _paper_floor(name, cfg, state_dict, x, tseg, theat):
+    """One fp64 oracle noise-floor computation per (preset, batch) and test session (4 CPU forward+backward passes)."""
+    key = (name, x.shape[0])
+    if key not in _PAPER_FLOORS:
+        torch.set_num_threads(max(torch.get_num_threads(), 32))
+        _PAPER_FLOORS[key] = NF.GradientFloor(oracle64(cfg, state_dict), oracle_run(x, tseg, theat))
+    return _PAPER_FLOORS[key]
+
+
+def test_paper_batch16_gradient(math_mode):
+    """BASELINE configs[1] itself: the paper preset with both heads at batch 16 (the benchmarked step).  Rounding noise
+    averages down with the batch: the whole gradient must be within 1e-2 (relative L2) of the fp64 oracle's in BOTH
+    product modes, and every tensor inside its noise-floor bar."""
+    seed, cfg = PAPER_CFGS['paper_sc_l14']
+    torch.manual_seed(seed)
+    onet = R.OracleUNet(**cfg)
+    net = dfl_amd.UNet(**cfg)
+    net.load_state_dict(onet.state_dict())
+    net = net.to(DEV).train()
+    gen = torch.Generator().manual_seed(seed + 16)
+    x = torch.randn(16, 1, 192, 192, generator=gen)
+    lab = torch.randint(0, 7, (16, 184, 184), generator=gen)
+    tseg = R.one_hot_masks(lab, 7)
+    theat = torch.rand(16, 14, 184, 184, generator=gen) * 0.02
+    seg, heat = net(x.to(DEV))
+    loss = dfl_amd.DiceAndHeatMapLoss2D(skip_bg=False, heatmap_wgt=0.5)(
+        (dfl_amd.center_crop(seg, tseg.shape), dfl_amd.center_crop(heat, theat.shape)), (tseg.to(DEV), theat.to(DEV)))
+    loss.backward()
+    gf = _paper_floor('paper_sc_l14', cfg, onet.state_dict(), x, tseg, theat)
+    assert float((seg.detach().double().cpu() - gf.out).abs().max()) <= 1e-4 * float(gf.out.abs().max())
+    worst, whole, eps_eff = gf.check({k: p.grad for k, p in net.named_parameters()}, seg, NF.conv_rel_error(math_mode), 'batch 16 ')
+    print('batch 16 %s: conv noise %.2e, whole-gradient error %.3e, worst per-tensor error / bar %.2f' % (math_mode, eps_eff, whole, worst))
+    assert whole <= 1e-2, 'whole-gradient relative L2 error %.3e at batch 16' % whole
+    mask = label_mask(gf.out, seg)
+    assert float(mask.float().mean()) < 2e-3
+    assert bool((seg.detach().argmax(1).cpu() == gf.out.argmax(1))[~mask].all())
 
 
 @pytest.mark.parametrize('optimizer', ['torch', 'dfl'])
@@ -202,8 +279,9 @@ def test_training_trajectory_matches_reference(optimizer, math_mode):
         out = net(P)
     labels = torch.max(dfl_amd.center_crop(out[0], S.shape), dim=1)[1].cpu()
     d = R.hard_dice(labels, segs.long(), 7)
-    np.testing.assert_allclose(d, g['hard_dice'], atol=by_mode(math_mode, 0.02, 0.06))
-    assert abs(float(np.mean(d)) - float(np.mean(g['hard_dice']))) < 0.01
+    # 30 steps in, the network is still moving fast (Dice 0.6-0.7): a sanity band only; the +-0.005 bar of north_star is
+    # checked where it is defined, at a plateau (test_plateau_dice_matches_reference)
+    assert abs(float(np.mean(d)) - float(np.mean(g['hard_dice']))) < 0.03
 
 
 class _FakeH5DS:
@@ -247,8 +325,18 @@ def test_ensemble_golden():
     assert len(times) == 2
     segs = f.d['nn-segs'].a
     assert segs.dtype == np.uint8
-    mism = (segs != g['nn_segs']).mean()
-    assert mism <= 2e-3, 'label mismatch fraction %.4f' % mism
+    # labels: bit-exact against the reference's file outside the pixels whose averaged soft-max has a rounding-level
+    # top-2 margin in fp64 (the oracle, pinned to the reference, recomputes that margin here)
+    o64 = []
+    for i in range(3):
+        o = oracle64(cfg, {k[5:]: _t(v) for k, v in g.items() if k.startswith('net%d/' % i)}).eval()
+        with torch.no_grad():
+            o64.append(o(imgs.double()))
+    avg64 = R.center_crop(sum(o[0] for o in o64) / 3.0, (28, 28))
+    mask = label_mask(avg64).numpy()
+    assert mask.mean() < 5e-3
+    assert np.array_equal(segs[~mask], g['nn_segs'][~mask]), 'labels differ from the reference outside the rounding-margin mask'
+    assert np.array_equal(segs[~mask], avg64.argmax(1).numpy().astype(np.uint8)[~mask])
     np.testing.assert_allclose(f.d['nn-heats'].a, g['nn_heats'], rtol=1e-3, atol=1e-5)
     # single-net path and validation loops run and agree with the oracle
     f2 = _FakeH5()
@@ -259,7 +347,8 @@ def test_ensemble_golden():
     with torch.no_grad():
         o = onet(imgs)
     lab = torch.max(R.center_crop(o[0], (28, 28)), dim=1)[1].numpy()
-    assert (f2.d['nn-segs'].a != lab).mean() <= 2e-3
+    m1 = label_mask(R.center_crop(o64[0][0], (28, 28))).numpy()
+    assert m1.mean() < 5e-3 and np.array_equal(f2.d['nn-segs'].a[~m1], lab.astype(np.uint8)[~m1])
     np.testing.assert_allclose(f2.d['nn-heats'].a, R.center_crop(o[1], (28, 28)).numpy(), rtol=1e-4, atol=1e-5)
 
 
@@ -424,14 +513,65 @@ def test_ragged_sizes_match_oracle(hw, max_pool, math_mode):
     assert abs(loss.item() - oloss.item()) < 1e-5
     loss.backward()
     oloss.backward()
-    num = den = 0.0
-    for (k, p), (_, q) in zip(net.named_parameters(), onet.named_parameters()):
-        if q.grad is None:
-            assert p.grad is None, k
-            continue
-        num += float((p.grad.cpu().double() - q.grad.double()).pow(2).sum())
-        den += float(q.grad.double().pow(2).sum())
-    assert (num / den) ** 0.5 <= by_mode(math_mode, 5e-3, 5e-2), 'whole-gradient relative L2 error %.3e' % (num / den) ** 0.5
+    gf = NF.GradientFloor(oracle64(cfg, onet.state_dict()), oracle_run(x, tseg, theat))
+    gf.check({k: p.grad for k, p in net.named_parameters()}, seg, NF.conv_rel_error(math_mode), 'ragged %dx%d ' % (H, W))
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16x3', 'bf16'])
+def test_plateau_dice_matches_reference(mode):
+    """North-star quality bar: hard Dice within +-0.005 of the REFERENCE.  tests/golden/plateau.npz holds a run of the
+    reference itself (tools/gen_golden.py: 400 SGD steps on 16 toy-ellipses images, learning rate cut 10x for the last
+    100, train.py:405-430 wiring) -- twice, with 8 and 1 CPU threads, which shows the reference's own run-to-run spread
+    at the plateau (mean Dice 0.9972 / 0.9955, single classes up to 0.007 apart).  The HIP path, same data, same steps:
+    mean Dice of the training images within 0.005 of the reference's runs, every class within 0.005 + the reference's own
+    spread on that class, and the plateau loss within 5e-3."""
+    g = load_golden('plateau')
+    cfg = dict(n_classes=7, depth=3, wf=3, batch_norm=True, padding=True, max_pool=False, num_lands=14, do_res=True,
+               block_depth=2)
+    lib = nat.lib()
+    prev = lib.dfl_get_math_mode()
+    nat.check(lib.dfl_set_math_mode({'fp32': 0, 'bf16x3': 1, 'bf16': 3}[mode]), 'dfl_set_math_mode')
+    try:
+        net = load_net(g, cfg)
+        projs, segs, lands = _t(g['projs']), _t(g['segs']), _t(g['lands'])
+        n_train, steps = int(g['n_train']), int(g['steps'])
+        H, W = projs.shape[-2:]
+        lm = R.mark_oob_landmarks(lands, H, W)
+        pad = R.calc_pad_amount(48, W)
+        n = projs.shape[0]
+        P = torch.stack([R.preprocess_proj(projs[i:i + 1], pad) for i in range(n)]).to(DEV)
+        S = R.one_hot_masks(segs, 7).to(DEV)
+        Hm = torch.stack([R.gaussian_heatmaps(lm[i], H, W) for i in range(n)]).view(n, 14, H, W).to(DEV)
+        opt = dfl_amd.SGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4, nesterov=True)
+        crit = dfl_amd.DiceAndHeatMapLoss2D(skip_bg=False, heatmap_wgt=0.5)
+        net.train()
+        losses = []
+        for step in range(steps):
+            if step == 300:
+                for gr in opt.param_groups:
+                    gr['lr'] = 0.005
+            idx = [(step * 4 + j) % n_train for j in range(4)]
+            opt.zero_grad()
+            out = net(P[idx])
+            loss = crit((dfl_amd.center_crop(out[0], S[idx].shape), dfl_amd.center_crop(out[1], Hm[idx].shape)), (S[idx], Hm[idx]))
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        net.eval()
+        with torch.no_grad():
+            out = net(P[:n_train])
+        labels = torch.max(dfl_amd.center_crop(out[0], S[:n_train].shape), dim=1)[1].cpu()
+        d = R.hard_dice(labels, segs[:n_train].long(), 7)
+    finally:
+        nat.check(lib.dfl_set_math_mode(prev), 'dfl_set_math_mode')
+    ref8, ref1 = g['dice_train'], g['dice_train_1thread']
+    lo, hi = min(ref8.mean(), ref1.mean()), max(ref8.mean(), ref1.mean())
+    print('plateau %s: mean Dice %.4f (reference %.4f / %.4f), per class %s' % (mode, float(np.mean(d)), ref8.mean(), ref1.mean(), np.round(d, 4)))
+    assert lo - 0.005 <= float(np.mean(d)) <= hi + 0.005, 'mean hard Dice %.4f vs reference %.4f / %.4f' % (float(np.mean(d)), ref8.mean(), ref1.mean())
+    for c in range(6):
+        a, b = min(ref8[c], ref1[c]), max(ref8[c], ref1[c])
+        assert a - 0.005 <= d[c] <= b + 0.005, 'class %d: hard Dice %.4f vs reference %.4f / %.4f' % (c + 1, d[c], ref8[c], ref1[c])
+    assert abs(float(np.mean(losses[-20:])) - float(g['losses'][-20:].mean())) < 5e-3
 
 
 def test_training_quality_is_the_same_with_split_bf16_products():
@@ -624,13 +764,5 @@ def test_random_architectures_match_oracle(seed, math_mode):
     assert abs(loss.item() - oloss.item()) < 2e-5 * max(1.0, abs(oloss.item()))
     loss.backward()
     oloss.backward()
-    num = den = 0.0
-    for (k, p), (_, q) in zip(net.named_parameters(), onet.named_parameters()):
-        if q.grad is None:
-            assert p.grad is None, k
-            continue
-        assert p.grad is not None, k
-        num += float((p.grad.cpu().double() - q.grad.double()).pow(2).sum())
-        den += float(q.grad.double().pow(2).sum())
-    if den > 0:
-        assert (num / den) ** 0.5 <= by_mode(math_mode, 5e-3, 5e-2), 'whole-gradient relative L2 error %.3e (%s)' % ((num / den) ** 0.5, cfg)
+    gf = NF.GradientFloor(oracle64(cfg, onet.state_dict()), oracle_run(x, tseg, theat if L > 0 else None, skip_bg=bool(seed % 2)))
+    gf.check({k: p.grad for k, p in net.named_parameters()}, seg, NF.conv_rel_error(math_mode), 'random architecture %d ' % seed)
