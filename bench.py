@@ -29,11 +29,13 @@ PAPER = dict(n_classes=7, depth=6, wf=5, batch_norm=True, padding=True, max_pool
 F32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0        # same guide: dense bf16 MFMA (the 5 PF marketing figure is 2:1 sparse)
 # product arithmetic of the GEMM kernels (include/dfl_hip.h): name -> (mode, bf16 MFMA products per fp32 product)
-MATH = {'fp32': (0, 0), 'bf16x3': (1, 3), 'bf16x6': (2, 6), 'bf16': (3, 1)}
+MATH = {'fp32': (0, 0), 'bf16x3': (1, 3), 'bf16x6': (2, 6), 'bf16': (3, 1), 'bf16s': (4, 1)}
 TRAFFIC_FILE = 'r01_traffic.json'      # per-kernel HBM bytes from the committed rocprofv3 --pmc passes of this round
 CONV_KERNELS = ['conv_gemm_kernel<2,2,2,2>', 'conv_gemm_kernel<2,2,2,1>', 'conv_gemm_kernel<4,1,2,1>',
                 'conv_gemm_kernel<2,2,1,1>', 'conv_gemm_kernel<1,2,1,1>', 'direct_conv_kernel',
                 'conv_rows_kernel<3,1,2,1>', 'conv_rows_kernel<3,1,1,2>', 'conv_rows_kernel<3,1,1,1>']
+CONVP_TILES = ['4,1,2,1', '4,1,1,1', '2,2,4,1', '2,2,3,1', '2,2,2,1', '1,4,2,1', '1,4,3,1', '1,4,4,1', '1,4,6,1', '1,4,9,1', '2,2,1,1',
+               '1,4,1,1']      # csrc/convp_bf16.hip kTiles: waves M x N, tiles M x N per wave
 WGRAD_KERNELS = ['wgrad_kernel<2,2,2,2,1>', 'wgrad_kernel<2,2,1,1,1>', 'wgrad_kernel<1,1,1,1,3>',
                  'wgrad_kernel<1,1,1,1,2>', 'wgrad_kernel<1,1,1,1,1>', 'direct_wgrad_kernel', 'wgrad_kernel<2,2,1,1,3>']
 
@@ -55,24 +57,25 @@ def op_profile(plan, lib, nat, stream, detail=None):
         for st, t in zip(prog.structs, ms):
             if isinstance(st, nat.ConvArgs):
                 cfg = lib.dfl_conv_config(C.addressof(st))
-                name = CONV_KERNELS[cfg]
+                name = CONV_KERNELS[cfg] if cfg < 16 else 'convp_kernel<%s>' % CONVP_TILES[cfg - 16]
                 if st.scatter2x2:
                     M = st.N * st.Hin * st.Win
                 else:
                     M = st.N * st.Hout * st.Wout
                 fl = 2.0 * M * st.KH * st.KW * st.Cin * st.Ntot
-                by = 4.0 * (st.N * st.Hin * st.Win * st.Cin + st.KH * st.KW * st.Cin * st.Ntot + M * st.Ntot)
+                esz = 2.0 if st.x_bf16 else 4.0
+                by = esz * (st.N * st.Hin * st.Win * st.Cin + st.KH * st.KW * st.Cin * st.Ntot + M * st.Ntot)
             elif isinstance(st, nat.WgradArgs):
                 cfg = lib.dfl_wgrad_config(C.addressof(st))
-                name = WGRAD_KERNELS[cfg]
+                name = WGRAD_KERNELS[cfg] if cfg < 16 else 'wgradp_kernel<%d>' % (9, 4, 1)[cfg - 16]
                 fl = 2.0 * st.N * st.Hout * st.Wout * st.Cm * st.Cg * st.KH * st.KW
-                by = 4.0 * (st.N * st.Hin * st.Win * st.Cg + st.N * st.Hout * st.Wout * st.Cm + st.Cm * st.Cg * st.KH * st.KW)
+                by = (2.0 if st.g_bf16 else 4.0) * (st.N * st.Hin * st.Win * st.Cg + st.N * st.Hout * st.Wout * st.Cm) + 4.0 * st.Cm * st.Cg * st.KH * st.KW
             else:
                 name, fl, by = type(st).__name__, 0.0, 0.0
             if detail is not None:
                 if isinstance(st, nat.ConvArgs):
-                    desc = 'N%d %dx%d Cin%d -> %dx%d Ntot%d k%d s%d' % (st.N, st.Hin, st.Win, st.Cin, st.Hout, st.Wout,
-                                                                         st.Ntot, st.KH, st.stride)
+                    desc = 'N%d %dx%d Cin%d -> %dx%d Ntot%d k%d s%d splits%d' % (st.N, st.Hin, st.Win, st.Cin, st.Hout, st.Wout,
+                                                                                  st.Ntot, st.KH, st.stride, st.splits)
                 elif isinstance(st, nat.WgradArgs):
                     desc = 'N%d %dx%d Cg%d Cm%d k%d splits%d' % (st.N, st.Hin, st.Win, st.Cg, st.Cm, st.KH, st.splits)
                 elif isinstance(st, nat.SumPartialsArgs):
@@ -357,7 +360,10 @@ def main():
                          '1x192x192 (8x-downsampled 184x184 padded)',
                'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-               'dtype': 'f32' if args.math == 'fp32' else '%s (fp32 tensors; GEMM operands split into bf16 parts, bf16 MFMA, fp32 accumulate)' % args.math,
+               'dtype': ('f32' if args.math == 'fp32' else
+                         'bf16 (bf16 activations, activation gradients and GEMM weight copies in HBM; bf16 MFMA, fp32 accumulate, '
+                         'BatchNorm statistics, losses, weight gradients and master weights)' if args.math == 'bf16s' else
+                         '%s (fp32 tensors; GEMM operands split into bf16 parts, bf16 MFMA, fp32 accumulate)' % args.math),
                'data': 'synthetic',
                'config': {'workload': 'BASELINE configs[1]: 8x-downsampled, seg + 14-landmark heat-map dual head, '
                                       'batch %d per GPU, Dice+NCC loss, SGD nesterov' % B,

@@ -20,14 +20,15 @@ class ConvArgs(C.Structure):
                 ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32),
                 ('Hout', i32), ('Wout', i32), ('Ntot', i32), ('ldy', i32),
                 ('ldadd', i32), ('ldso', i32), ('relu', i32), ('accumulate', i32), ('scatter2x2', i32),
-                ('splits', i32), ('w_split', i32), ('x_split', i32)]
+                ('splits', i32), ('w_split', i32), ('x_split', i32), ('x_bf16', i32), ('y_bf16', i32)]
 
 
 class WgradArgs(C.Structure):
     _fields_ = [('g', fp), ('d', fp), ('in_scale', fp), ('in_shift', fp), ('dw', fp), ('partial', fp),
                 ('N', i32), ('Hin', i32), ('Win', i32), ('Cg', i32), ('ldg', i32),
                 ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32),
-                ('Hout', i32), ('Wout', i32), ('Cm', i32), ('ldd', i32), ('splits', i32), ('d_split', i32)]
+                ('Hout', i32), ('Wout', i32), ('Cm', i32), ('ldd', i32), ('splits', i32), ('d_split', i32),
+                ('g_bf16', i32), ('d_bf16', i32), ('reserved', i32)]
 
 
 class PackJob(C.Structure):
@@ -43,7 +44,7 @@ class BnFinalizeArgs(C.Structure):
 
 class ColstatsArgs(C.Structure):
     _fields_ = [('a', fp), ('b', fp), ('partials', fp), ('M', i64), ('C', i32), ('lda', i32), ('ldb', i32),
-                ('nblocks', i32)]
+                ('nblocks', i32), ('bf16', i32), ('reserved', i32)]
 
 
 class BnBwdFinalizeArgs(C.Structure):
@@ -53,7 +54,8 @@ class BnBwdFinalizeArgs(C.Structure):
 
 class BnReluBwdArgs(C.Structure):
     _fields_ = [('dy', fp), ('r', fp), ('coef', fp), ('dpre', fp), ('partials', fp), ('M', i64), ('C', i32),
-                ('lddy', i32), ('ldr', i32), ('ldo', i32), ('nblocks', i32), ('split_out', i32)]
+                ('lddy', i32), ('ldr', i32), ('ldo', i32), ('nblocks', i32), ('split_out', i32), ('bf16', i32),
+                ('reserved', i32)]
 
 
 class AffineCopyArgs(C.Structure):
@@ -61,25 +63,25 @@ class AffineCopyArgs(C.Structure):
                 ('N', i32), ('H', i32), ('W', i32), ('C', i32),
                 ('ldx', i32), ('xH', i32), ('xW', i32), ('xoy', i32), ('xox', i32),
                 ('ldy', i32), ('yH', i32), ('yW', i32), ('yoy', i32), ('yox', i32),
-                ('accumulate', i32), ('reserved', i32)]
+                ('accumulate', i32), ('bf16', i32)]
 
 
 class PoolArgs(C.Structure):
     _fields_ = [('x', fp), ('y', fp), ('dx', fp), ('N', i32), ('H', i32), ('W', i32), ('C', i32),
-                ('ldx', i32), ('ldy', i32), ('lddx', i32), ('reserved', i32)]
+                ('ldx', i32), ('ldy', i32), ('lddx', i32), ('bf16', i32)]
 
 
 class HeadFwdArgs(C.Structure):
     _fields_ = [('x', fp), ('w_seg', fp), ('w_l1', fp), ('w_l2', fp), ('seg', fp), ('heat', fp),
                 ('N', i32), ('H', i32), ('W', i32), ('F', i32), ('ldx', i32),
-                ('NC', i32), ('NM', i32), ('L', i32), ('softmax', i32), ('reserved', i32)]
+                ('NC', i32), ('NM', i32), ('L', i32), ('softmax', i32), ('x_bf16', i32)]
 
 
 class HeadBwdArgs(C.Structure):
     _fields_ = [('x', fp), ('seg', fp), ('dseg', fp), ('dheat', fp), ('w_seg', fp), ('w_l1', fp), ('w_l2', fp),
                 ('dx', fp), ('scratch', fp),
                 ('N', i32), ('H', i32), ('W', i32), ('F', i32), ('ldx', i32), ('lddx', i32),
-                ('NC', i32), ('NM', i32), ('L', i32), ('softmax', i32), ('scratch_ld', i32), ('reserved', i32)]
+                ('NC', i32), ('NM', i32), ('L', i32), ('softmax', i32), ('scratch_ld', i32), ('x_bf16', i32)]
 
 
 class LossArgs(C.Structure):

@@ -52,7 +52,8 @@ int math_mode() {
   if (g_math < 0) {
     const char* e = getenv("DFL_MATH");
     g_math = (e != nullptr && strcmp(e, "fp32") == 0) ? 0 : (e != nullptr && strcmp(e, "bf16x6") == 0) ? 2
-             : (e != nullptr && strcmp(e, "bf16x3") == 0) ? 1 : (e != nullptr && strcmp(e, "bf16") == 0) ? 3 : DFL_MATH_DEFAULT;
+             : (e != nullptr && strcmp(e, "bf16x3") == 0) ? 1 : (e != nullptr && strcmp(e, "bf16") == 0) ? 3
+             : (e != nullptr && strcmp(e, "bf16s") == 0) ? 4 : DFL_MATH_DEFAULT;
   }
   return g_math;
 }
@@ -61,7 +62,7 @@ int math_mode() {
 extern "C" int dfl_get_math_mode(void) { return dfl::math_mode(); }
 
 extern "C" int dfl_set_math_mode(int32_t mode) {
-  DFL_REQUIRE(mode >= 0 && mode <= 3, "dfl_set_math_mode: mode must be 0 (fp32), 1 (bf16x3), 2 (bf16x6) or 3 (bf16)");
+  DFL_REQUIRE(mode >= 0 && mode <= 4, "dfl_set_math_mode: mode must be 0 (fp32), 1 (bf16x3), 2 (bf16x6), 3 (bf16) or 4 (bf16 storage)");
   dfl::g_math = mode;
   return DFL_OK;
 }

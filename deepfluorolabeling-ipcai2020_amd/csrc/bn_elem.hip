@@ -427,6 +427,216 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const dfl_pool_args a,
   }
 }
 
+// ------------------------------------------------------------------------------------------------ bf16 tensors (math mode 4)
+// The same streaming kernels for bf16 activations: units of 8 channels (16 bytes), fp32 arithmetic, one rounding at the
+// store.  Sums are taken from the values as stored.
+typedef unsigned int bu32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void unpack8(const bu32x4 w, float* f) {
+  f[0] = __uint_as_float(w.x << 16); f[1] = __uint_as_float(w.x & 0xffff0000u);
+  f[2] = __uint_as_float(w.y << 16); f[3] = __uint_as_float(w.y & 0xffff0000u);
+  f[4] = __uint_as_float(w.z << 16); f[5] = __uint_as_float(w.z & 0xffff0000u);
+  f[6] = __uint_as_float(w.w << 16); f[7] = __uint_as_float(w.w & 0xffff0000u);
+}
+__device__ __forceinline__ bu32x4 pack8(const float* f) {
+  bu32x4 w;
+  w.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){f[0], f[1]}, bf16x2_t));
+  w.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){f[2], f[3]}, bf16x2_t));
+  w.z = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){f[4], f[5]}, bf16x2_t));
+  w.w = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){f[6], f[7]}, bf16x2_t));
+  return w;
+}
+__device__ __forceinline__ bu32x4 ld8(const float* base, int64_t elem) {
+  return *reinterpret_cast<const bu32x4*>(reinterpret_cast<const unsigned short*>(base) + elem);
+}
+__device__ __forceinline__ void st8(float* base, int64_t elem, bu32x4 w) {
+  *reinterpret_cast<bu32x4*>(reinterpret_cast<unsigned short*>(base) + elem) = w;
+}
+
+static RowGeom row_geom8(int C) {
+  RowGeom g;
+  g.vec = 1;
+  g.units = C / 8;
+  int ux = 1;
+  while (ux * 2 <= g.units && ux * 2 <= 256) ux *= 2;
+  g.UX = ux;
+  g.RY = 256 / ux;
+  g.gy = (int)ceil_div(g.units, ux);
+  return g;
+}
+
+// per-unit partial sums of a workgroup -> partials row (red: [256][8])
+__device__ __forceinline__ void reduce_units8(float (*red)[8], const float* s, int ux, int uy, int UX, int RY, bool cok,
+                                              float* out, int c) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = s[j];
+  __syncthreads();
+  if (uy == 0 && cok) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t = 0.f;
+      for (int y = 0; y < RY; ++y) t += red[y * UX + ux][j];
+      out[c + j] = t;
+    }
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) colstats_bf16_kernel(const dfl_colstats_args a, int UX, int rows_per_block) {
+  __shared__ float red[256][8];
+  const int RY = 256 / UX;
+  const int ux = threadIdx.x % UX, uy = threadIdx.x / UX;
+  const int c = (blockIdx.y * UX + ux) * 8;
+  const bool cok = c < a.C;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > a.M) r1 = a.M;
+  float s1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, s2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (cok) {
+    for (int64_t r = r0 + uy; r < r1; r += RY) {
+      float va[8], vb[8];
+      unpack8(ld8(a.a, r * a.lda + c), va);
+      if (a.b != nullptr) unpack8(ld8(a.b, r * a.ldb + c), vb);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        s1[j] += va[j];
+        s2[j] = fmaf(va[j], a.b != nullptr ? vb[j] : va[j], s2[j]);
+      }
+    }
+  }
+  reduce_units8(red, s1, ux, uy, UX, RY, cok, a.partials + ((int64_t)blockIdx.x * 2 + 0) * a.C, c);
+  reduce_units8(red, s2, ux, uy, UX, RY, cok, a.partials + ((int64_t)blockIdx.x * 2 + 1) * a.C, c);
+}
+
+__global__ void __launch_bounds__(256) bn_relu_bwd_bf16_kernel(const dfl_bn_relu_bwd_args a, int UX, int rows_per_block) {
+  __shared__ float red[256][8];
+  const int RY = 256 / UX;
+  const int ux = threadIdx.x % UX, uy = threadIdx.x / UX;
+  const int C = a.C;
+  const int c = (blockIdx.y * UX + ux) * 8;
+  const bool cok = c < C;
+  float cA[8], cB[8], cC[8], s[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    cA[j] = 1.f; cB[j] = 0.f; cC[j] = 0.f; s[j] = 0.f;
+    if (a.coef != nullptr && cok) {
+      cA[j] = a.coef[c + j];
+      cB[j] = a.coef[C + c + j];
+      cC[j] = a.coef[2 * C + c + j];
+    }
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > a.M) r1 = a.M;
+  if (cok) {
+    for (int64_t r = r0 + uy; r < r1; r += RY) {
+      float dy[8], rv[8], o[8];
+      unpack8(ld8(a.dy, r * a.lddy + c), dy);
+      unpack8(ld8(a.r, r * a.ldr + c), rv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = rv[j] > 0.f ? fmaf(cA[j], dy[j], fmaf(cB[j], rv[j], cC[j])) : 0.f;
+      const bu32x4 w = pack8(o);
+      st8(a.dpre, r * a.ldo + c, w);
+      unpack8(w, o);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += o[j];
+    }
+  }
+  if (a.partials == nullptr) return;
+  reduce_units8(red, s, ux, uy, UX, RY, cok, a.partials + (int64_t)blockIdx.x * C, c);
+}
+
+__global__ void __launch_bounds__(256) affine_copy_bf16_kernel(const dfl_affine_copy_args a, int64_t total_units, int cq) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_units; i += stride) {
+    const int u = (int)(i % cq);
+    int64_t pix = i / cq;
+    const int xw = (int)(pix % a.W);
+    pix /= a.W;
+    const int yh = (int)(pix % a.H);
+    const int n = (int)(pix / a.H);
+    const int c = u * 8;
+    const int64_t so = (((int64_t)n * a.xH + a.xoy + yh) * a.xW + a.xox + xw) * a.ldx + c;
+    const int64_t dof = (((int64_t)n * a.yH + a.yoy + yh) * a.yW + a.yox + xw) * a.ldy + c;
+    float v[8];
+    unpack8(ld8(a.x, so), v);
+    if (a.scale != nullptr) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], a.scale[c + j], a.shift[c + j]);
+    }
+    if (a.accumulate) {
+      float o[8];
+      unpack8(ld8(a.y, dof), o);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += o[j];
+    }
+    st8(a.y, dof, pack8(v));
+  }
+}
+
+__global__ void __launch_bounds__(256) maxpool_fwd_bf16_kernel(const dfl_pool_args a, int64_t total_units, int cq) {
+  const int Ho = a.H / 2, Wo = a.W / 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_units; i += stride) {
+    const int u = (int)(i % cq);
+    int64_t pix = i / cq;
+    const int ox = (int)(pix % Wo);
+    pix /= Wo;
+    const int oy = (int)(pix % Ho);
+    const int n = (int)(pix / Ho);
+    const int c = u * 8;
+    const int64_t s00 = (((int64_t)n * a.H + 2 * oy) * a.W + 2 * ox) * a.ldx + c;
+    const int64_t s10 = s00 + (int64_t)a.W * a.ldx;
+    float v0[8], v1[8], v2[8], v3[8], m[8];
+    unpack8(ld8(a.x, s00), v0);
+    unpack8(ld8(a.x, s00 + a.ldx), v1);
+    unpack8(ld8(a.x, s10), v2);
+    unpack8(ld8(a.x, s10 + a.ldx), v3);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = fmaxf(fmaxf(v0[j], v1[j]), fmaxf(v2[j], v3[j]));
+    st8(a.y, (((int64_t)n * Ho + oy) * Wo + ox) * a.ldy + c, pack8(m));
+  }
+}
+
+__global__ void __launch_bounds__(256) maxpool_bwd_bf16_kernel(const dfl_pool_args a, int64_t total_units, int cq) {
+  const int Ho = a.H / 2, Wo = a.W / 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_units; i += stride) {
+    const int u = (int)(i % cq);
+    int64_t pix = i / cq;
+    const int ox = (int)(pix % Wo);
+    pix /= Wo;
+    const int oy = (int)(pix % Ho);
+    const int n = (int)(pix / Ho);
+    const int c = u * 8;
+    const int64_t ipix = ((int64_t)n * a.H + 2 * oy) * a.W + 2 * ox;
+    const int64_t s00 = ipix * a.ldx + c, s10 = s00 + (int64_t)a.W * a.ldx;
+    const int64_t d00 = ipix * a.lddx + c, d10 = d00 + (int64_t)a.W * a.lddx;
+    float v0[8], v1[8], v2[8], v3[8], g[8], e0[8], e1[8], e2[8], e3[8];
+    unpack8(ld8(a.x, s00), v0);
+    unpack8(ld8(a.x, s00 + a.ldx), v1);
+    unpack8(ld8(a.x, s10), v2);
+    unpack8(ld8(a.x, s10 + a.ldx), v3);
+    unpack8(ld8(a.y, (((int64_t)n * Ho + oy) * Wo + ox) * a.ldy + c), g);
+    unpack8(ld8(a.dx, d00), e0);
+    unpack8(ld8(a.dx, d00 + a.lddx), e1);
+    unpack8(ld8(a.dx, d10), e2);
+    unpack8(ld8(a.dx, d10 + a.lddx), e3);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = first_max4(v0[j], v1[j], v2[j], v3[j]);
+      e0[j] += k == 0 ? g[j] : 0.f;
+      e1[j] += k == 1 ? g[j] : 0.f;
+      e2[j] += k == 2 ? g[j] : 0.f;
+      e3[j] += k == 3 ? g[j] : 0.f;
+    }
+    st8(a.dx, d00, pack8(e0));
+    st8(a.dx, d00 + a.lddx, pack8(e1));
+    st8(a.dx, d10, pack8(e2));
+    st8(a.dx, d10 + a.lddx, pack8(e3));
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ weight pack
 // GEMM operand layout of dfl_conv2d: w[kq][n][r] = W(k = 4*kq + r, n), zero for k >= K ("quad-packed": one float4 is four
 // consecutive k of one output column).  The source is always a contiguous [A][B][C] parameter (C = KH*KW) and the
@@ -448,6 +658,7 @@ __device__ __forceinline__ float pack_src(const dfl_pack_job& j, int k, int n) {
 }
 
 // element r of quad slot q: a float, or (split format) hi bf16 at half-word r and lo bf16 at half-word 4 + r of the slot
+// (the bf16 chunk layout, split = 2, has its own path in pack_kernel)
 __device__ __forceinline__ void pack_put(float* dst, int64_t q, int r, float v, int split) {
   if (!split) {
     dst[q * 4 + r] = v;
@@ -466,6 +677,26 @@ __global__ void __launch_bounds__(256) pack_kernel(const dfl_pack_job* __restric
   const int A = j.A, B = j.B, Cc = j.C;
   const int K = (j.kind == 1) ? Cc * B : (j.kind == 2 ? Cc * A : A);
   const int N = (j.kind == 1) ? A : (j.kind == 2 ? B : Cc * B);
+  if (j.split == 2) {
+    // bf16 chunk layout [ceil(K/16)][N][16]: thread = one (chunk, column) cell of 32 bytes; consecutive threads take
+    // consecutive columns (coalesced 32-byte stores; the sources are small enough to live in L2)
+    const int Kc = (K + 15) / 16;
+    const int64_t cells = (int64_t)Kc * N;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += stride) {
+      const int n = (int)(i % N), kc = (int)(i / N);
+      float f[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = kc * 16 + r;
+        f[r] = k < K ? pack_src(j, k, n) : 0.f;
+      }
+      bu32x4* d = reinterpret_cast<bu32x4*>(reinterpret_cast<unsigned short*>(j.dst) + i * 16);
+      d[0] = pack8(f);
+      d[1] = pack8(f + 8);
+    }
+    return;
+  }
   const bool tiled = Cc <= PK_CMAX && ((j.kind == 1) ? (B % 4 == 0) : (A % 4 == 0));
   if (tiled) {
     const int tb = (B + PK_T - 1) / PK_T, ta = (A + PK_T - 1) / PK_T;
@@ -544,6 +775,14 @@ extern "C" int dfl_rowblock_count(int64_t M, int32_t C) { return rowblocks(M, C)
 extern "C" int dfl_colstats(const dfl_colstats_args* a, dfl_stream_t stream) {
   DFL_REQUIRE(a && a->a && a->partials && a->M > 0 && a->C > 0, "dfl_colstats: bad args");
   DFL_REQUIRE(a->nblocks == rowblocks(a->M, a->C), "dfl_colstats: nblocks must be dfl_rowblock_count(M, C)");
+  if (a->bf16) {
+    DFL_REQUIRE(a->C % 8 == 0 && a->lda % 8 == 0 && aligned16(a->a) && (a->b == nullptr || (a->ldb % 8 == 0 && aligned16(a->b))),
+                "dfl_colstats (bf16): C and ld must be multiples of 8, tensors 16-byte aligned");
+    const RowGeom g8 = row_geom8(a->C);
+    hipLaunchKernelGGL(colstats_bf16_kernel, dim3((unsigned)a->nblocks, (unsigned)g8.gy), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       *a, g8.UX, (int)ceil_div(a->M, a->nblocks));
+    return check_launch("dfl_colstats");
+  }
   const bool vec_ok = a->lda % 4 == 0 && aligned16(a->a) && (a->b == nullptr || (a->ldb % 4 == 0 && aligned16(a->b)));
   const RowGeom g = row_geom(a->C, vec_ok);
   const int rpb = (int)ceil_div(a->M, a->nblocks);
@@ -589,6 +828,15 @@ extern "C" int dfl_bn_bwd_finalize(const dfl_bn_bwd_finalize_args* a, dfl_stream
 extern "C" int dfl_bn_relu_bwd_apply(const dfl_bn_relu_bwd_args* a, dfl_stream_t stream) {
   DFL_REQUIRE(a && a->dy && a->r && a->dpre && a->M > 0 && a->C > 0, "dfl_bn_relu_bwd_apply: bad args");
   DFL_REQUIRE(a->nblocks == rowblocks(a->M, a->C), "dfl_bn_relu_bwd_apply: nblocks must be dfl_rowblock_count(M, C)");
+  if (a->bf16) {
+    DFL_REQUIRE(a->C % 8 == 0 && a->lddy % 8 == 0 && a->ldr % 8 == 0 && a->ldo % 8 == 0 && aligned16(a->dy) && aligned16(a->r) &&
+                    aligned16(a->dpre) && !a->split_out,
+                "dfl_bn_relu_bwd_apply (bf16): C and ld must be multiples of 8, tensors 16-byte aligned, no split output");
+    const RowGeom g8 = row_geom8(a->C);
+    hipLaunchKernelGGL(bn_relu_bwd_bf16_kernel, dim3((unsigned)a->nblocks, (unsigned)g8.gy), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), *a, g8.UX, (int)ceil_div(a->M, a->nblocks));
+    return check_launch("dfl_bn_relu_bwd_apply");
+  }
   const bool vec_ok = a->lddy % 4 == 0 && a->ldr % 4 == 0 && a->ldo % 4 == 0 && aligned16(a->dy) && aligned16(a->r) &&
                       aligned16(a->dpre);
   const RowGeom g = row_geom(a->C, vec_ok);
@@ -628,6 +876,14 @@ extern "C" int dfl_affine_copy(const dfl_affine_copy_args* a, dfl_stream_t strea
   DFL_REQUIRE(a->xoy >= 0 && a->xox >= 0 && a->xoy + a->H <= a->xH && a->xox + a->W <= a->xW, "dfl_affine_copy: source window");
   DFL_REQUIRE(a->yoy >= 0 && a->yox >= 0 && a->yoy + a->H <= a->yH && a->yox + a->W <= a->yW, "dfl_affine_copy: dest window");
   DFL_REQUIRE((a->scale == nullptr) == (a->shift == nullptr), "dfl_affine_copy: scale/shift go together");
+  if (a->bf16) {
+    DFL_REQUIRE(a->C % 8 == 0 && a->ldx % 8 == 0 && a->ldy % 8 == 0 && aligned16(a->x) && aligned16(a->y),
+                "dfl_affine_copy (bf16): C and ld must be multiples of 8, tensors 16-byte aligned");
+    const int cq8 = a->C / 8;
+    const int64_t tot8 = (int64_t)a->N * a->H * a->W * cq8;
+    hipLaunchKernelGGL(affine_copy_bf16_kernel, dim3(stream_grid(tot8)), dim3(256), 0, static_cast<hipStream_t>(stream), *a, tot8, cq8);
+    return check_launch("dfl_affine_copy");
+  }
   const bool vec = a->C % 4 == 0 && a->ldx % 4 == 0 && a->ldy % 4 == 0 && aligned16(a->x) && aligned16(a->y) &&
                    (a->scale == nullptr || (aligned16(a->scale) && aligned16(a->shift)));
   const int cq = vec ? a->C / 4 : a->C;
@@ -650,11 +906,26 @@ static int pool_common(const dfl_pool_args* a, bool bwd, bool* vec, int* cq, int
   return DFL_OK;
 }
 
+static int pool_bf16_check(const dfl_pool_args* a, bool bwd, int* cq, int64_t* total) {
+  DFL_REQUIRE(a->C % 8 == 0 && a->ldx % 8 == 0 && a->ldy % 8 == 0 && aligned16(a->x) && aligned16(a->y) &&
+                  (!bwd || (a->lddx % 8 == 0 && aligned16(a->dx))),
+              "dfl_maxpool2x2 (bf16): C and ld must be multiples of 8, tensors 16-byte aligned");
+  *cq = a->C / 8;
+  *total = (int64_t)a->N * (a->H / 2) * (a->W / 2) * *cq;
+  return DFL_OK;
+}
+
 extern "C" int dfl_maxpool2x2_fwd(const dfl_pool_args* a, dfl_stream_t stream) {
   bool vec; int cq; int64_t total;
   int rc = pool_common(a, false, &vec, &cq, &total);
   if (rc != DFL_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (a->bf16) {
+    rc = pool_bf16_check(a, false, &cq, &total);
+    if (rc != DFL_OK) return rc;
+    hipLaunchKernelGGL(maxpool_fwd_bf16_kernel, dim3(stream_grid(total)), dim3(256), 0, s, *a, total, cq);
+    return check_launch("dfl_maxpool2x2_fwd");
+  }
   if (vec) hipLaunchKernelGGL(maxpool_fwd_kernel<1>, dim3(stream_grid(total)), dim3(256), 0, s, *a, total, cq);
   else hipLaunchKernelGGL(maxpool_fwd_kernel<0>, dim3(stream_grid(total)), dim3(256), 0, s, *a, total, cq);
   return check_launch("dfl_maxpool2x2_fwd");
@@ -665,6 +936,12 @@ extern "C" int dfl_maxpool2x2_bwd(const dfl_pool_args* a, dfl_stream_t stream) {
   int rc = pool_common(a, true, &vec, &cq, &total);
   if (rc != DFL_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (a->bf16) {
+    rc = pool_bf16_check(a, true, &cq, &total);
+    if (rc != DFL_OK) return rc;
+    hipLaunchKernelGGL(maxpool_bwd_bf16_kernel, dim3(stream_grid(total)), dim3(256), 0, s, *a, total, cq);
+    return check_launch("dfl_maxpool2x2_bwd");
+  }
   if (vec) hipLaunchKernelGGL(maxpool_bwd_kernel<1>, dim3(stream_grid(total)), dim3(256), 0, s, *a, total, cq);
   else hipLaunchKernelGGL(maxpool_bwd_kernel<0>, dim3(stream_grid(total)), dim3(256), 0, s, *a, total, cq);
   return check_launch("dfl_maxpool2x2_bwd");

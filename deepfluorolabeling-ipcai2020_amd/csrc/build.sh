@@ -4,13 +4,13 @@ set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 out="$here/../lib"
 mkdir -p "$out"
-srcs=(api.hip conv_gemm.hip conv_rows.hip wgrad_gemm.hip direct_small.hip bn_elem.hip head.hip loss.hip prep.hip)
+srcs=(api.hip conv_gemm.hip conv_rows.hip convp_bf16.hip wgradp_bf16.hip wgrad_gemm.hip direct_small.hip bn_elem.hip head.hip loss.hip prep.hip)
 objs=()
 pids=()
 for s in "${srcs[@]}"; do
   o="$out/${s%.hip}.o"
   objs+=("$o")
-  if [ ! -f "$o" ] || [ "$here/$s" -nt "$o" ] || [ "$here/common.h" -nt "$o" ] || [ "$here/direct_small.h" -nt "$o" ] || [ "$here/conv_epilogue.h" -nt "$o" ] || [ "$here/conv_rows.h" -nt "$o" ] || [ "$here/../../include/dfl_hip.h" -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$here/$s" -nt "$o" ] || [ "$here/common.h" -nt "$o" ] || [ "$here/direct_small.h" -nt "$o" ] || [ "$here/conv_epilogue.h" -nt "$o" ] || [ "$here/conv_rows.h" -nt "$o" ] || [ "$here/convp.h" -nt "$o" ] || [ "$here/../../include/dfl_hip.h" -nt "$o" ]; then
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -c "$here/$s" -o "$o" &
     pids+=($!)
   fi

@@ -37,6 +37,7 @@
 #include "common.h"
 #include "conv_epilogue.h"
 #include "conv_rows.h"
+#include "convp.h"
 #include "direct_small.h"
 
 namespace dfl {
@@ -802,6 +803,11 @@ static int finish_rows(int M, int Ntot) {   // row blocks of conv_finish_kernel 
 }  // namespace dfl
 
 extern "C" int dfl_conv_suggest_splits(const dfl_conv_args* a) {
+  if (a != nullptr && a->x_bf16) {          // bf16 tensors: the patch-resident kernels plan their own K slices
+    dfl::ConvP p;
+    int rc = dfl::convp_plan(a, &p, 0);
+    return rc != DFL_OK ? rc : p.splits;
+  }
   dfl::ConvK k;
   int rc = dfl::prepare(a, &k);
   if (rc != DFL_OK) return rc;
@@ -816,6 +822,12 @@ extern "C" int dfl_set_conv_rows_min_tiles(int32_t n) {
 }
 
 extern "C" int dfl_conv_grid_m(const dfl_conv_args* a) {
+  if (a != nullptr && a->x_bf16) {
+    dfl::ConvP p;
+    int rc = dfl::convp_plan(a, &p, a->splits > 1 ? a->splits : 1);
+    if (rc != DFL_OK) return rc;
+    return p.splits > 1 ? dfl::convp_finish_rows(p) : p.npatch;
+  }
   dfl::ConvK k;
   int rc = dfl::prepare(a, &k);
   if (rc != DFL_OK) return rc;
@@ -828,6 +840,11 @@ extern "C" int dfl_conv_grid_m(const dfl_conv_args* a) {
 }
 
 extern "C" int dfl_conv_config(const dfl_conv_args* a) {
+  if (a != nullptr && a->x_bf16) {
+    dfl::ConvP p;
+    int rc = dfl::convp_plan(a, &p, a->splits > 1 ? a->splits : 1);
+    return rc != DFL_OK ? rc : 16 + p.tile;
+  }
   dfl::ConvK k;
   int rc = dfl::prepare(a, &k);
   if (rc != DFL_OK) return rc;
@@ -837,6 +854,14 @@ extern "C" int dfl_conv_config(const dfl_conv_args* a) {
 }
 
 extern "C" int dfl_conv2d(const dfl_conv_args* a, dfl_stream_t stream) {
+  if (a != nullptr && a->x_bf16) {
+    DFL_REQUIRE(a->y_bf16, "dfl_conv2d: bf16 input with fp32 output is not a configuration of the network");
+    DFL_REQUIRE(a->splits <= 1 || a->partial != nullptr, "dfl_conv2d: splits > 1 needs the partial buffer");
+    dfl::ConvP p;
+    int rc = dfl::convp_plan(a, &p, a->splits > 1 ? a->splits : 1);
+    if (rc != DFL_OK) return rc;
+    return dfl::convp_launch(p, static_cast<hipStream_t>(stream));
+  }
   dfl::ConvK k;
   int rc = dfl::prepare(a, &k);
   if (rc != DFL_OK) return rc;
@@ -845,6 +870,7 @@ extern "C" int dfl_conv2d(const dfl_conv_args* a, dfl_stream_t stream) {
     DFL_REQUIRE(!a->w_split && !a->x_split, "dfl_conv2d: split operands are not defined for the direct small-K kernels");
     return dfl::direct_conv_launch(a, s);
   }
+  DFL_REQUIRE(!a->y_bf16, "dfl_conv2d: bf16 output needs bf16 input (patch kernels) or a direct small-K layer");
   if (a->splits > 1) {
     DFL_REQUIRE(a->partial != nullptr, "dfl_conv2d: splits > 1 needs the partial buffer");
     const int nchunks = (int)dfl::ceil_div(k.Ktot, dfl::KC);

@@ -1,0 +1,32 @@
+// Patch-resident bf16 convolution and weight-gradient kernels (convp_bf16.hip, wgradp_bf16.hip), dispatched by
+// dfl_conv2d / dfl_conv2d_wgrad when the argument block says its tensors are bf16.
+#pragma once
+#include "common.h"
+
+namespace dfl {
+
+struct ConvP {
+  dfl_conv_args a;
+  int Mtot, Cout;               // GEMM rows (gather-grid pixels), channels per output pixel
+  int Hg, Wg;                   // gather grid per image (= Hout x Wout; Hin x Win for the 2x2-scatter form)
+  int PH, PW, IPP;              // patch: PH x PW grid pixels of IPP images (IPP > 1 only for whole images)
+  int npy, npx, npatch;         // patches per image along y / x, patches in all
+  int IH, IW;                   // input pixels a patch needs per image, halo included
+  int CK, nblk, blk_per_slice;  // input channels resident in LDS per block, blocks over Cin, blocks per K slice
+  int splits, T;                // K slices (grid.z), taps
+  int pix_stride, upp_shift;    // bytes per staged pixel (2 CK + 16), log2(CK / 8)
+  int lds_bytes, tile;          // staged image size, index into the tile configuration table
+  uint32_t x_bytes, w_bytes;
+};
+
+// Chooses the geometry for these arguments.  force_splits: 0 = free choice, else the K-slice count to plan for.
+int convp_plan(const dfl_conv_args* a, ConvP* p, int force_splits);
+int convp_launch(const ConvP& p, hipStream_t s);
+int convp_finish_rows(const ConvP& p);
+
+struct WgP;
+int wgradp_suggest_splits(const dfl_wgrad_args* a);
+int wgradp_launch(const dfl_wgrad_args* a, hipStream_t s);
+int wgradp_config(const dfl_wgrad_args* a);
+
+}  // namespace dfl

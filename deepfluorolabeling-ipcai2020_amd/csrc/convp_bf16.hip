@@ -1,0 +1,607 @@
+// Patch-resident convolution for bf16 tensors (math mode 4, "bf16 storage": BASELINE configs[1] as named -- bf16
+// activations and weights in HBM, fp32 accumulation / statistics / master weights).
+//
+// Serves what conv_gemm.hip / conv_rows.hip serve for fp32 tensors -- nn.Conv2d 3x3 / 1x1 / 2x2-stride-2,
+// nn.ConvTranspose2d(k2,s2) (scatter epilogue) and, with re-packed weights, every data gradient (reference:
+// train_test_code/unet.py:93,207,211,218,240; torch autograd at train.py:422) -- with a different decomposition, built
+// around what bf16 changes: the matrix pipe is 16x faster than for fp32 products, so the loop must not touch LDS or the
+// vector-load return path once per tap.
+//
+//   * A workgroup owns a PATCH of output pixels (PH x PW pixels of IPP images, WM*TM*32 GEMM rows) and BN = WN*TN*32 output
+//     columns.  The input pixels the patch needs for ALL taps -- the patch with its halo -- are staged in LDS ONCE per
+//     block of CK input channels (BatchNorm affine applied there, zero padding written as zeros), [pixel][CK] bf16 with a
+//     pixel pitch of 2*CK + 16 bytes.  Every tap then is an address offset: lane l of a 32-row tile reads its pixel's 16
+//     bytes (8 channels) with one ds_read_b128 at base(l) + tap offset + chunk offset.  The pitch (odd multiple of 16
+//     bytes) spreads the 16 pixels of a b128 lane group over all 64 banks: no conflicts for consecutive pixels.  The loop
+//     has NO barrier (the image is static while it runs) and no per-tap gather, masks or bounds logic at all.
+//   * Weights never touch LDS: they are packed [k/16][n][16 k] bf16 (dfl_pack_job.split = 2), so the MFMA B fragment of a
+//     wave -- 32 columns x 16 k -- is one fully coalesced 1 KiB buffer load straight into registers.  Waves of a
+//     workgroup that share output columns re-read those lines from L1/L2; waves split the N dimension first (WN), so this
+//     happens only for the 32/64-channel layers whose whole weight tensor is 18-147 KiB.  Fragments are prefetched two
+//     groups of four k-steps ahead (a ring of three register sets).
+//   * v_mfma_f32_32x32x16_bf16, fp32 accumulators, TM x TN tiles per wave.
+//   * Epilogue as dfl_conv2d defines it (bias, ReLU, + BN(other), accumulate, NHWC / 2x2-scatter store, per-channel
+//     statistics); values are rounded to bf16 once, the statistics are taken from the ROUNDED values (what consumers
+//     normalise).  K slices (blockIdx.z = ranges of channel blocks) leave fp32 partial sums for convp_finish_kernel.
+//
+// Geometry (patch shape, resident channels, K slices, tile configuration) is chosen on the host per layer
+// (convp_plan): candidates are scored by matrix work x rounds over the 256 CUs, including the fill of the last tiles.
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.h"
+#include "convp.h"
+
+namespace dfl {
+
+constexpr uint32_t POOB = 0x80000000u;
+typedef unsigned int pu32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ uint32_t pack_bf2(float a, float b) {
+  const bf16x2_t h = __builtin_convertvector((f32x2_t){a, b}, bf16x2_t);   // round to nearest even (v_cvt_pk_bf16_f32)
+  return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ float round_bf(float v) { return (float)(__bf16)v; }
+__device__ __forceinline__ float ld_bf(const __bf16* p) { return (float)*p; }
+
+template <int WM, int WN, int TM, int TN, bool AFF>
+__global__ void __launch_bounds__(256, (TM * TN >= 6) ? 1 : 2) convp_kernel(const ConvP p) {
+  static_assert(WM * WN == 4, "four waves per workgroup");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const dfl_conv_args& a = p.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN, li = lane & 31, lh = lane >> 5;
+  const int S = p.pix_stride;
+  const int PP = p.PH * p.PW;
+
+  // ---- which patch
+  const int per_img = p.npy * p.npx;
+  const int pg = blockIdx.x / per_img, pr = blockIdx.x - pg * per_img;
+  const int ppy = pr / p.npx, ppx = pr - ppy * p.npx;
+  const int img0 = pg * p.IPP, gy0 = ppy * p.PH, gx0 = ppx * p.PW;
+  const int n0 = blockIdx.y * (WN * TN * 32);
+
+  // ---- LDS base of each tile row of this lane (tap (0,0), channel chunk 0, this lane's k half)
+  uint32_t a_base[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    int q = (wm * TM + i) * 32 + li;
+    int img = q / PP;
+    int r = q - img * PP;
+    int py = r / p.PW, px = r - py * p.PW;
+    if (img >= p.IPP) img = 0, py = 0, px = 0;   // padding rows of the last tile: any valid address, results are dropped
+    a_base[i] = (uint32_t)(((img * p.IH + py * a.stride) * p.IW + px * a.stride) * S + lh * 16);
+  }
+
+  __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)p.x_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)p.w_bytes, 0x00020000);
+  uint32_t b_voff[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + (wn * TN + j) * 32 + li;
+    b_voff[j] = n < a.Ntot ? (uint32_t)(n * 32 + lh * 16) : POOB;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- staging geometry: 16-byte units (8 channels) of the patch image, `upp` per pixel; a thread keeps its channel
+  //      group, its pixel advances by 256 / upp per pass
+  const int upp = p.CK >> 3, upp_sh = p.upp_shift;
+  const int cg = tid & (upp - 1);
+  const int dpix = 256 >> upp_sh;
+  const int dpix_y = dpix / p.IW, dpix_x = dpix - dpix_y * p.IW;
+  const int npix = p.IPP * p.IH * p.IW;
+  const int CKC = p.CK >> 4;                       // 16-channel chunks per resident block (a power of two)
+  const int ckc_sh = p.upp_shift - 1;
+  const int S_steps = p.T * CKC;                   // k-steps per block
+  const int cin_chunks = a.Cin >> 4;
+  const int KW = a.KW;
+
+  const int blk_begin = blockIdx.z * p.blk_per_slice;
+  const int blk_end = min(blk_begin + p.blk_per_slice, p.nblk);
+  for (int blk = blk_begin; blk < blk_end; ++blk) {
+    const int c0 = blk * p.CK;
+    // ================================================================ stage the patch image of channels [c0, c0 + CK)
+    if (blk != blk_begin) __syncthreads();         // every wave is done reading the previous image
+    {
+      float sc[8], sh[8];
+      if constexpr (AFF) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          sc[e] = a.in_scale[c0 + cg * 8 + e];
+          sh[e] = a.in_shift[c0 + cg * 8 + e];
+        }
+      }
+      int pix = tid >> upp_sh;
+      int img = pix / (p.IH * p.IW);
+      int rem = pix - img * (p.IH * p.IW);
+      int iy = rem / p.IW, ix = rem - iy * p.IW;
+      const int ybase = gy0 * a.stride - a.pad, xbase = gx0 * a.stride - a.pad;
+      const uint32_t cbyte = (uint32_t)((c0 + cg * 8) * 2);
+      constexpr int U = 4;                         // loads in flight per thread
+      for (; pix < npix; pix += U * dpix) {
+        pu32x4 v[U];
+        bool ok[U];
+        int pixs[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int gy = ybase + iy, gx = xbase + ix, n = img0 + img;
+          pixs[u] = pix + u * dpix;
+          ok[u] = pixs[u] < npix && n < a.N && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
+          const uint32_t off = (uint32_t)(((n * a.Hin + gy) * a.Win + gx) * a.ldx) * 2u + cbyte;
+          v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsX, ok[u] ? off : POOB, 0, 0);
+          ix += dpix_x;
+          iy += dpix_y;
+          if (ix >= p.IW) {
+            ix -= p.IW;
+            ++iy;
+          }
+          while (iy >= p.IH) {
+            iy -= p.IH;
+            ++img;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (pixs[u] < npix) {
+            pu32x4 w = v[u];
+            if constexpr (AFF) {                   // zero padding applies AFTER the BatchNorm affine: outside pixels stay 0
+              if (ok[u]) {
+                w.x = pack_bf2(fmaf(bf_lo(w.x), sc[0], sh[0]), fmaf(bf_hi(w.x), sc[1], sh[1]));
+                w.y = pack_bf2(fmaf(bf_lo(w.y), sc[2], sh[2]), fmaf(bf_hi(w.y), sc[3], sh[3]));
+                w.z = pack_bf2(fmaf(bf_lo(w.z), sc[4], sh[4]), fmaf(bf_hi(w.z), sc[5], sh[5]));
+                w.w = pack_bf2(fmaf(bf_lo(w.w), sc[6], sh[6]), fmaf(bf_hi(w.w), sc[7], sh[7]));
+              }
+            }
+            *reinterpret_cast<pu32x4*>(smem + (uint32_t)pixs[u] * (uint32_t)S + (uint32_t)cg * 16u) = w;
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    // ================================================================ k-steps of this block: s = tap * CKC + chunk
+    // B fragments ride a ring of three register sets, loaded two groups (8 k-steps) ahead of their use.
+    constexpr int G = 4;
+    const int ngroups = (S_steps + G - 1) / G;
+    pu32x4 breg[3][G][TN];
+    auto load_group = [&](int g, int set) {
+#pragma unroll
+      for (int e = 0; e < G; ++e) {
+        const int s = g * G + e;
+        const bool live = g < ngroups && s < S_steps;
+        const int tap = s >> ckc_sh, cc = s & (CKC - 1);
+        const uint32_t soff = live ? (uint32_t)((tap * cin_chunks + blk * CKC + cc)) * (uint32_t)a.Ntot * 32u : 0u;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) breg[set][e][j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, live ? b_voff[j] : POOB, soff, 0);
+      }
+    };
+    auto compute_group = [&](int g, int set) {
+#pragma unroll
+      for (int e = 0; e < G; ++e) {
+        int s = g * G + e;
+        s = s < S_steps ? s : S_steps - 1;         // dead steps of the last group: weights were loaded as zeros
+        const int tap = s >> ckc_sh, cc = s & (CKC - 1);
+        const int ty = tap / KW, tx = tap - ty * KW;
+        const uint32_t aoff = (uint32_t)((ty * p.IW + tx) * S + cc * 32);
+        bf16x8_t af[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const pu32x4*>(smem + a_base[i] + aoff));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, breg[set][e][j]);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf, acc[i][j], 0, 0, 0);
+        }
+      }
+    };
+    load_group(0, 0);
+    load_group(1, 1);
+    for (int g = 0; g < ngroups; g += 3) {
+      load_group(g + 2, 2);
+      compute_group(g, 0);
+      if (g + 1 < ngroups) {
+        load_group(g + 3, 0);
+        compute_group(g + 1, 1);
+      }
+      if (g + 2 < ngroups) {
+        load_group(g + 4, 1);
+        compute_group(g + 2, 2);
+      }
+    }
+  }
+
+  // ==================================================================== epilogue
+  const bool sliced = p.splits > 1;
+  const bool do_stats = a.stat_partials != nullptr && !sliced;
+  const bool scat = a.scatter2x2 != 0;
+  const __bf16* addp = reinterpret_cast<const __bf16*>(a.add);
+  const __bf16* sop = reinterpret_cast<const __bf16*>(a.stat_other);
+  __bf16* yp = reinterpret_cast<__bf16*>(a.y);
+  int cn[TN], cco[TN], cab[TN];
+  bool cok[TN];
+  float cbias[TN], casc[TN], cash[TN], s1[TN], s2[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + (wn * TN + j) * 32 + li;
+    cok[j] = n < a.Ntot;
+    cn[j] = cok[j] ? n : 0;
+    cab[j] = scat ? cn[j] / p.Cout : 0;
+    cco[j] = scat ? cn[j] - cab[j] * p.Cout : cn[j];
+    cbias[j] = (a.bias != nullptr) ? a.bias[cco[j]] : 0.f;
+    casc[j] = 1.f;
+    cash[j] = 0.f;
+    if (addp != nullptr && a.add_scale != nullptr) {
+      casc[j] = a.add_scale[cn[j]];
+      cash[j] = a.add_shift[cn[j]];
+    }
+    s1[j] = 0.f;
+    s2[j] = 0.f;
+  }
+  float* part = sliced ? a.partial + (int64_t)blockIdx.z * p.Mtot * a.Ntot : nullptr;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int q = (wm * TM + i) * 32 + 8 * g + 4 * lh;     // rows q .. q+3 <-> accumulator registers 4g .. 4g+3
+      int img = q / PP;
+      int r = q - img * PP;
+      int py = r / p.PW, px = r - py * p.PW;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int n = img0 + img, gy = gy0 + py, gx = gx0 + px;
+        const bool rok = img < p.IPP && n < a.N && gy < p.Hg && gx < p.Wg;
+        const int64_t m = ((int64_t)n * p.Hg + gy) * p.Wg + gx;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const bool ok = rok && cok[j];
+          float v = acc[i][j][4 * g + rr];
+          if (sliced) {
+            if (ok) part[m * a.Ntot + cn[j]] = v;
+            continue;
+          }
+          v += cbias[j];
+          if (a.relu) v = fmaxf(v, 0.f);
+          if (addp != nullptr) v += fmaf(ok ? ld_bf(addp + m * a.ldadd + cn[j]) : 0.f, casc[j], cash[j]);
+          const int64_t o = scat ? ((((int64_t)n * a.Hout + 2 * gy + (cab[j] >> 1)) * a.Wout + 2 * gx + (cab[j] & 1)) * a.ldy + cco[j])
+                                 : (m * a.ldy + cn[j]);
+          if (a.accumulate) v += ok ? ld_bf(yp + o) : 0.f;
+          const __bf16 hv = (__bf16)v;
+          if (ok) yp[o] = hv;
+          if (do_stats) {
+            const float vm = ok ? (float)hv : 0.f;
+            const float u = (sop != nullptr) ? (ok ? ld_bf(sop + m * a.ldso + cn[j]) : 0.f) : vm;
+            s1[j] += vm;
+            s2[j] = fmaf(vm, u, s2[j]);
+          }
+        }
+        if (++px == p.PW) {
+          px = 0;
+          if (++py == p.PH) {
+            py = 0;
+            ++img;
+          }
+        }
+      }
+    }
+  }
+  if (!do_stats) return;
+  // per-column sums of the workgroup -> one row of stat_partials (rows = patches); the staging LDS is free by now
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);     // [WM][2][BN]
+  constexpr int BN = WN * TN * 32;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const float t1 = s1[j] + xor32(s1[j]);
+    const float t2 = s2[j] + xor32(s2[j]);
+    if (lh == 0) {
+      const int col = (wn * TN + j) * 32 + li;
+      red[(wm * 2 + 0) * BN + col] = t1;
+      red[(wm * 2 + 1) * BN + col] = t2;
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 2 * BN; idx += 256) {
+    const int which = idx / BN, col = idx - which * BN;
+    const int n = n0 + col;
+    if (n < a.Ntot) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) s += red[(w * 2 + which) * BN + col];
+      a.stat_partials[((int64_t)blockIdx.x * 2 + which) * a.Ntot + n] = s;
+    }
+  }
+}
+
+// K-slice finish: y = epilogue(sum_s partial[s]) -- conv_finish_kernel of conv_gemm.hip for bf16 tensors.
+__global__ void __launch_bounds__(256) convp_finish_kernel(const ConvP p, int TX, int rows_per_block) {
+  __shared__ float red[2][256];
+  const dfl_conv_args& a = p.a;
+  const int Ntot = a.Ntot;
+  const int TY = 256 / TX;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int n = blockIdx.y * TX + tx;
+  const bool nok = n < Ntot;
+  int co = n, ab = 0;
+  if (a.scatter2x2 && nok) {
+    ab = n / p.Cout;
+    co = n - ab * p.Cout;
+  }
+  const float bias = (a.bias != nullptr && nok) ? a.bias[co] : 0.f;
+  float asc = 1.f, ash = 0.f;
+  if (a.add != nullptr && a.add_scale != nullptr && nok) {
+    asc = a.add_scale[n];
+    ash = a.add_shift[n];
+  }
+  const __bf16* addp = reinterpret_cast<const __bf16*>(a.add);
+  const __bf16* sop = reinterpret_cast<const __bf16*>(a.stat_other);
+  __bf16* yp = reinterpret_cast<__bf16*>(a.y);
+  const int64_t slice = (int64_t)p.Mtot * Ntot;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(r0 + rows_per_block, p.Mtot);
+  float s1 = 0.f, s2 = 0.f;
+  if (nok) {
+    for (int m = r0 + ty; m < r1; m += TY) {
+      const float* pp = a.partial + (int64_t)m * Ntot + n;
+      float v = 0.f;
+      for (int s = 0; s < p.splits; ++s) v += pp[(int64_t)s * slice];
+      v += bias;
+      if (a.relu) v = fmaxf(v, 0.f);
+      if (addp != nullptr) v += fmaf(ld_bf(addp + (int64_t)m * a.ldadd + n), asc, ash);
+      __bf16* dst;
+      if (a.scatter2x2) {
+        const int jx = m % p.Wg;
+        const int t = m / p.Wg;
+        const int iy = t % p.Hg;
+        const int ni = t / p.Hg;
+        const int64_t opix = ((int64_t)ni * a.Hout + 2 * iy + (ab >> 1)) * a.Wout + 2 * jx + (ab & 1);
+        dst = yp + opix * a.ldy + co;
+      } else {
+        dst = yp + (int64_t)m * a.ldy + n;
+      }
+      if (a.accumulate) v += (float)*dst;
+      const __bf16 hv = (__bf16)v;
+      *dst = hv;
+      const float vr = (float)hv;
+      const float u = (sop != nullptr) ? ld_bf(sop + (int64_t)m * a.ldso + n) : vr;
+      s1 += vr;
+      s2 = fmaf(vr, u, s2);
+    }
+  }
+  if (a.stat_partials == nullptr) return;
+  red[0][threadIdx.x] = s1;
+  red[1][threadIdx.x] = s2;
+  __syncthreads();
+  if (ty == 0 && nok) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int y = 0; y < TY; ++y) {
+      t1 += red[0][y * TX + tx];
+      t2 += red[1][y * TX + tx];
+    }
+    a.stat_partials[((int64_t)blockIdx.x * 2 + 0) * Ntot + n] = t1;
+    a.stat_partials[((int64_t)blockIdx.x * 2 + 1) * Ntot + n] = t2;
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+
+struct TileCfg { int WM, WN, TM, TN; };
+// value reported by dfl_conv_config for these kernels = 16 + index
+static const TileCfg kTiles[] = {{4, 1, 2, 1}, {4, 1, 1, 1}, {2, 2, 4, 1}, {2, 2, 3, 1}, {2, 2, 2, 1}, {1, 4, 2, 1},
+                                 {1, 4, 3, 1}, {1, 4, 4, 1}, {1, 4, 6, 1}, {1, 4, 9, 1}, {2, 2, 1, 1}, {1, 4, 1, 1}};
+constexpr int kNumTiles = (int)(sizeof(kTiles) / sizeof(kTiles[0]));
+constexpr size_t kLdsSoft = 64 * 1024, kLdsHard = 150 * 1024;
+
+static int finish_rows_p(int M, int Ntot) {
+  int64_t nb = ceil_div((int64_t)M * Ntot, 1024);
+  if (nb > 2048) nb = 2048;
+  if (nb > M) nb = M;
+  return nb < 1 ? 1 : (int)nb;
+}
+
+int convp_finish_rows(const ConvP& p) { return finish_rows_p(p.Mtot, p.a.Ntot); }
+
+// Fill p's geometry for tile configuration t and a patch of (ipp images, ph x pw pixels); returns false if impossible.
+static bool try_geometry(const dfl_conv_args& a, ConvP* p, const TileCfg& t, int ipp, int ph, int pw, int want_splits,
+                         double* cost) {
+  const int QP = t.WM * t.TM * 32;
+  if (ipp < 1 || ph < 1 || pw < 1 || (int64_t)ipp * ph * pw > QP) return false;
+  if (ipp > 1 && (ph != p->Hg || pw != p->Wg)) return false;
+  p->IPP = ipp;
+  p->PH = ph;
+  p->PW = pw;
+  p->npy = (int)ceil_div(p->Hg, ph);
+  p->npx = (int)ceil_div(p->Wg, pw);
+  p->npatch = (int)ceil_div(a.N, ipp) * p->npy * p->npx;
+  p->IH = (ph - 1) * a.stride + a.KH;
+  p->IW = (pw - 1) * a.stride + a.KW;
+  const int64_t npix = (int64_t)ipp * p->IH * p->IW;
+  // resident channels: the largest power-of-two multiple of 16 (<= 128, dividing Cin) whose image fits
+  int ck = 128;
+  while (ck > 16 && (a.Cin % ck != 0 || npix * (ck * 2 + 16) > (int64_t)kLdsSoft)) ck >>= 1;
+  if (a.Cin % ck != 0) return false;
+  size_t lds = (size_t)npix * (ck * 2 + 16);
+  if (lds > kLdsHard) return false;
+  const int bn = t.WN * t.TN * 32;
+  const int ntiles = (int)ceil_div(a.Ntot, bn);
+  const int64_t wgs = (int64_t)p->npatch * ntiles;
+  int nblk = a.Cin / ck;
+  // K slices: only whole channel blocks; more blocks (smaller ck) when the layer needs the parallelism
+  int splits = 1;
+  if (want_splits > 1) {
+    splits = want_splits;
+    while (nblk % splits != 0 && ck > 16) {
+      ck >>= 1;
+      nblk = a.Cin / ck;
+    }
+    if (nblk % splits != 0) return false;
+    lds = (size_t)npix * (ck * 2 + 16);
+  }
+  p->CK = ck;
+  p->nblk = nblk;
+  p->splits = splits;
+  p->blk_per_slice = nblk / splits;
+  p->pix_stride = ck * 2 + 16;
+  int sh = 0;
+  while ((1 << sh) < (ck >> 3)) ++sh;
+  p->upp_shift = sh;
+  p->lds_bytes = (int)lds;
+  // cost model: matrix instructions per wave x rounds over the chip (two workgroups share a CU when LDS allows) +
+  // staging + the partial-sum round trip of sliced launches
+  const int occ = (2 * lds + 4096 <= 160 * 1024) ? 2 : 1;
+  const int64_t total = wgs * splits;
+  const int64_t rounds = ceil_div(total, 256 * occ);
+  const int steps = (a.KH * a.KW * (ck / 16) + 3) / 4 * 4 * p->blk_per_slice;
+  const double mfma = (double)t.TM * t.TN * steps * 32.0;                        // cycles per wave (one wave per SIMD)
+  const double stage = (double)p->blk_per_slice * (double)lds / 64.0 + 1500.0 * p->blk_per_slice;   // LDS store path + latency
+  const double ldsread = (double)t.TM * steps * 4.0 * 4.0;                       // ds_read_b128 cycles of the 4 waves
+  const double per_wg = (mfma > ldsread ? mfma : ldsread) + stage + 3000.0;      // + fixed prologue / epilogue
+  double c = (double)rounds * per_wg * occ;
+  if (splits > 1) c += (double)p->Mtot * a.Ntot * 4.0 * (splits + 1) / 2000.0;   // bytes / (B per cycle of the chip)
+  *cost = c;
+  return true;
+}
+
+int convp_plan(const dfl_conv_args* a, ConvP* p, int force_splits) {
+  DFL_REQUIRE(a->x && a->w && a->y, "dfl_conv2d (bf16): x, w and y are required");
+  DFL_REQUIRE(a->N > 0 && a->Hin > 0 && a->Win > 0 && a->Cin > 0 && a->Ntot > 0, "dfl_conv2d (bf16): bad sizes");
+  DFL_REQUIRE(a->Cin % 16 == 0 && a->ldx % 8 == 0 && aligned16(a->x) && aligned16(a->w),
+              "dfl_conv2d (bf16): needs Cin %% 16 == 0, ldx %% 8 == 0 and 16-byte aligned x / w (Cin = %d, ldx = %d)", a->Cin, a->ldx);
+  DFL_REQUIRE(a->w_split == 2, "dfl_conv2d (bf16): weights must be packed with dfl_pack_job.split = 2");
+  DFL_REQUIRE((a->in_scale == nullptr) == (a->in_shift == nullptr), "dfl_conv2d: in_scale/in_shift go together");
+  DFL_REQUIRE((a->add_scale == nullptr) == (a->add_shift == nullptr), "dfl_conv2d: add_scale/add_shift go together");
+  DFL_REQUIRE(a->KH * a->KW <= 16 && a->KH > 0 && a->KW > 0 && a->stride > 0 && a->pad >= 0, "dfl_conv2d (bf16): bad window");
+  memset(p, 0, sizeof(*p));
+  p->a = *a;
+  if (a->scatter2x2) {
+    DFL_REQUIRE(a->KH == 1 && a->KW == 1 && a->stride == 1 && a->pad == 0, "dfl_conv2d: scatter2x2 needs a 1x1 gather");
+    DFL_REQUIRE(a->Ntot % 4 == 0 && a->Hout >= 2 * a->Hin && a->Wout >= 2 * a->Win, "dfl_conv2d: scatter2x2 geometry");
+    DFL_REQUIRE(a->add == nullptr && a->stat_partials == nullptr, "dfl_conv2d: scatter2x2 has no add/stats epilogue");
+    p->Hg = a->Hin;
+    p->Wg = a->Win;
+    p->Cout = a->Ntot / 4;
+  } else {
+    const int ho = (a->Hin + 2 * a->pad - a->KH) / a->stride + 1;
+    const int wo = (a->Win + 2 * a->pad - a->KW) / a->stride + 1;
+    DFL_REQUIRE(ho == a->Hout && wo == a->Wout, "dfl_conv2d: Hout/Wout (%d,%d) do not match the window (%d,%d)", a->Hout,
+                a->Wout, ho, wo);
+    p->Hg = a->Hout;
+    p->Wg = a->Wout;
+    p->Cout = a->Ntot;
+  }
+  DFL_REQUIRE(a->ldy >= p->Cout, "dfl_conv2d: ldy < Cout");
+  const int64_t M = (int64_t)a->N * p->Hg * p->Wg;
+  DFL_REQUIRE(M < (1ll << 31), "dfl_conv2d: too many pixels");
+  p->Mtot = (int)M;
+  p->T = a->KH * a->KW;
+  const int64_t xb = (((int64_t)a->N * a->Hin * a->Win - 1) * a->ldx + a->Cin) * 2;
+  const int64_t wb = (int64_t)p->T * a->Cin * a->Ntot * 2;
+  const int64_t lim = (1ll << 31) - 4096;
+  DFL_REQUIRE(xb < lim && wb < lim, "dfl_conv2d (bf16): tensors must stay below 2 GiB");
+  p->x_bytes = (uint32_t)xb;
+  p->w_bytes = (uint32_t)wb;
+
+  // candidates: tile configurations allowed for this column count x patch shapes that fill their rows
+  double best = 1e300;
+  ConvP bestp = *p;
+  int best_tile = -1;
+  for (int ti = 0; ti < kNumTiles; ++ti) {
+    const TileCfg& t = kTiles[ti];
+    const int bn = t.WN * t.TN * 32;
+    if (a->Ntot <= 32 && t.WN != 1) continue;
+    if (a->Ntot > 32 && a->Ntot <= 64 && t.WN != 2) continue;
+    if (a->Ntot > 64 && t.WN != 4) continue;
+    (void)bn;
+    const int QP = t.WM * t.TM * 32;
+    int shapes[16][3];
+    int ns = 0;
+    const int HW = p->Hg * p->Wg;
+    if (HW <= QP) {                                  // whole images
+      shapes[ns][0] = QP / HW; shapes[ns][1] = p->Hg; shapes[ns][2] = p->Wg; ++ns;
+    }
+    if (p->Wg <= QP) {                               // whole rows
+      int ph = QP / p->Wg;
+      if (ph > p->Hg) ph = p->Hg;
+      shapes[ns][0] = 1; shapes[ns][1] = ph; shapes[ns][2] = p->Wg; ++ns;
+    }
+    for (int ph = 1; ph <= 16 && ns < 14; ph *= 2) { // row pieces
+      int pw = QP / ph;
+      if (pw >= p->Wg || ph > p->Hg) continue;
+      shapes[ns][0] = 1; shapes[ns][1] = ph; shapes[ns][2] = pw; ++ns;
+    }
+    for (int si = 0; si < ns; ++si) {
+      for (int sp = 1; sp <= 32; sp *= 2) {
+        if (force_splits > 0 && sp != force_splits) continue;
+        if (a->scatter2x2 == 0 && a->accumulate == 0 && sp > 1 && p->T * a->Cin < 1024) break;   // short K: never sliced
+        ConvP q = *p;
+        double c;
+        if (!try_geometry(*a, &q, t, shapes[si][0], shapes[si][1], shapes[si][2], sp, &c)) continue;
+        if (c < best) {
+          best = c;
+          bestp = q;
+          best_tile = ti;
+        }
+      }
+    }
+  }
+  DFL_REQUIRE(best_tile >= 0, "dfl_conv2d (bf16): no patch geometry fits this layer (%dx%d, Cin %d, Ntot %d)", a->Hin, a->Win,
+              a->Cin, a->Ntot);
+  *p = bestp;
+  p->tile = best_tile;
+  return DFL_OK;
+}
+
+template <int WM, int WN, int TM, int TN>
+static int convp_launch_t(const ConvP& p, hipStream_t s) {
+  const bool aff = p.a.in_scale != nullptr;
+  dim3 grid((unsigned)p.npatch, (unsigned)ceil_div(p.a.Ntot, WN * TN * 32), (unsigned)p.splits);
+  size_t lds = (size_t)p.lds_bytes;
+  const size_t red = (size_t)WM * 2 * WN * TN * 32 * sizeof(float);
+  if (lds < red) lds = red;
+  if (aff) {
+    auto k = convp_kernel<WM, WN, TM, TN, true>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, p);
+  } else {
+    auto k = convp_kernel<WM, WN, TM, TN, false>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, p);
+  }
+  return check_launch("dfl_conv2d (bf16)");
+}
+
+int convp_launch(const ConvP& p, hipStream_t s) {
+  int rc;
+  switch (p.tile) {
+    case 0: rc = convp_launch_t<4, 1, 2, 1>(p, s); break;
+    case 1: rc = convp_launch_t<4, 1, 1, 1>(p, s); break;
+    case 2: rc = convp_launch_t<2, 2, 4, 1>(p, s); break;
+    case 3: rc = convp_launch_t<2, 2, 3, 1>(p, s); break;
+    case 4: rc = convp_launch_t<2, 2, 2, 1>(p, s); break;
+    case 5: rc = convp_launch_t<1, 4, 2, 1>(p, s); break;
+    case 6: rc = convp_launch_t<1, 4, 3, 1>(p, s); break;
+    case 7: rc = convp_launch_t<1, 4, 4, 1>(p, s); break;
+    case 8: rc = convp_launch_t<1, 4, 6, 1>(p, s); break;
+    case 9: rc = convp_launch_t<1, 4, 9, 1>(p, s); break;
+    case 10: rc = convp_launch_t<2, 2, 1, 1>(p, s); break;
+    default: rc = convp_launch_t<1, 4, 1, 1>(p, s); break;
+  }
+  if (rc != DFL_OK || p.splits <= 1) return rc;
+  int tx = 1;
+  while (tx * 2 <= p.a.Ntot && tx * 2 <= 256) tx *= 2;
+  const int nb = finish_rows_p(p.Mtot, p.a.Ntot);
+  const int rpb = (int)ceil_div(p.Mtot, nb);
+  dim3 grid((unsigned)nb, (unsigned)ceil_div(p.a.Ntot, tx));
+  hipLaunchKernelGGL(convp_finish_kernel, grid, dim3(256), 0, s, p, tx, rpb);
+  return check_launch("dfl_conv2d (bf16, split-K finish)");
+}
+
+}  // namespace dfl

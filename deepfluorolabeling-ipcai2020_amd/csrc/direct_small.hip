@@ -44,8 +44,35 @@ struct PixCursor {
   }
 };
 
+// 4 consecutive channels of a row: fp32 (16 bytes) or bf16 (8 bytes) tensors
+template <bool BF>
+__device__ __forceinline__ float4 ld4c(const float* base, int64_t elem) {
+  if constexpr (BF) {
+    const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + elem);
+    return make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
+                       __uint_as_float(w.y & 0xffff0000u));
+  } else {
+    return *reinterpret_cast<const float4*>(base + elem);
+  }
+}
+// store (rounding to bf16 when BF) and return the values as stored
+template <bool BF>
+__device__ __forceinline__ float4 st4c(float* base, int64_t elem, float4 v) {
+  if constexpr (BF) {
+    const bf16x2_t h0 = __builtin_convertvector((f32x2_t){v.x, v.y}, bf16x2_t), h1 = __builtin_convertvector((f32x2_t){v.z, v.w}, bf16x2_t);
+    const uint2 w = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
+    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + elem) = w;
+    return make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
+                       __uint_as_float(w.y & 0xffff0000u));
+  } else {
+    *reinterpret_cast<float4*>(base + elem) = v;
+    return v;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- forward conv
-template <int KH, int KW, int CIN>
+// BF: y, add and stat_other are bf16 tensors (math mode 4; the input x of these layers is the fp32 network input)
+template <int KH, int KW, int CIN, bool BF>
 __global__ void __launch_bounds__(256) direct_conv_kernel(const dfl_conv_args a, int Mtot, int rows_per_block) {
   constexpr int K = KH * KW * CIN;
   static_assert(K <= DK, "window too large for the direct kernel");
@@ -100,7 +127,7 @@ __global__ void __launch_bounds__(256) direct_conv_kernel(const dfl_conv_args a,
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[j] = fmaf(xv[k], w[k][j], acc[j]);
     if (a.add != nullptr) {
-      const float4 r = *reinterpret_cast<const float4*>(a.add + (int64_t)m * a.ldadd + n0);
+      const float4 r = ld4c<BF>(a.add, (int64_t)m * a.ldadd + n0);
       acc[0] += fmaf(r.x, asc[0], ash[0]);
       acc[1] += fmaf(r.y, asc[1], ash[1]);
       acc[2] += fmaf(r.z, asc[2], ash[2]);
@@ -110,16 +137,17 @@ __global__ void __launch_bounds__(256) direct_conv_kernel(const dfl_conv_args a,
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[j] = fmaxf(acc[j], 0.f);
     }
-    float* yp = a.y + (int64_t)m * a.ldy + n0;
+    const int64_t yo = (int64_t)m * a.ldy + n0;
     if (a.accumulate) {
-      const float4 o = *reinterpret_cast<const float4*>(yp);
+      const float4 o = ld4c<BF>(a.y, yo);
       acc[0] += o.x; acc[1] += o.y; acc[2] += o.z; acc[3] += o.w;
     }
-    *reinterpret_cast<float4*>(yp) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    const float4 st = st4c<BF>(a.y, yo, make_float4(acc[0], acc[1], acc[2], acc[3]));
+    acc[0] = st.x; acc[1] = st.y; acc[2] = st.z; acc[3] = st.w;      // statistics of the values as stored
     if (a.stat_partials != nullptr) {
       float u[4] = {acc[0], acc[1], acc[2], acc[3]};
       if (a.stat_other != nullptr) {
-        const float4 o = *reinterpret_cast<const float4*>(a.stat_other + (int64_t)m * a.ldso + n0);
+        const float4 o = ld4c<BF>(a.stat_other, (int64_t)m * a.ldso + n0);
         u[0] = o.x; u[1] = o.y; u[2] = o.z; u[3] = o.w;
       }
 #pragma unroll
@@ -159,6 +187,7 @@ static bool direct_window(int KH, int KW, int C) {
 bool direct_conv_ok(const dfl_conv_args* a) {
   if (!direct_window(a->KH, a->KW, a->Cin) || a->scatter2x2 || a->splits > 1) return false;
   if (a->Ntot % 4 != 0 || a->Ntot > 1024 || 256 % (a->Ntot / 4) != 0) return false;
+  if (a->x_bf16) return false;                       // (the input of these layers is the fp32 network input)
   if (a->ldy % 4 != 0 || !aligned16(a->y)) return false;
   if (a->add != nullptr && (a->ldadd % 4 != 0 || !aligned16(a->add))) return false;
   if (a->stat_other != nullptr && (a->ldso % 4 != 0 || !aligned16(a->stat_other))) return false;
@@ -177,7 +206,11 @@ int direct_conv_launch(const dfl_conv_args* a, hipStream_t s) {
   const int64_t M = (int64_t)a->N * a->Hout * a->Wout;
   const int blocks = direct_conv_blocks(a);
   const int rpb = (int)ceil_div(M, blocks);
-#define DFL_DC(KH_, C_) hipLaunchKernelGGL((direct_conv_kernel<KH_, KH_, C_>), dim3((unsigned)blocks), dim3(256), 0, s, *a, (int)M, rpb)
+#define DFL_DC(KH_, C_)                                                                                                  \
+  {                                                                                                                      \
+    if (a->y_bf16) hipLaunchKernelGGL((direct_conv_kernel<KH_, KH_, C_, true>), dim3((unsigned)blocks), dim3(256), 0, s, *a, (int)M, rpb);  \
+    else hipLaunchKernelGGL((direct_conv_kernel<KH_, KH_, C_, false>), dim3((unsigned)blocks), dim3(256), 0, s, *a, (int)M, rpb);           \
+  }
   switch (a->KH * 10 + a->Cin) {
     case 31: DFL_DC(3, 1); break;
     case 21: DFL_DC(2, 1); break;
@@ -194,7 +227,8 @@ int direct_conv_launch(const dfl_conv_args* a, hipStream_t s) {
 
 // ---------------------------------------------------------------------------------------------- weight gradient
 // acc[k][j] = sum over this thread's pixels of G(m, k) * d[m][4q + j];  k = tap*Cg + cg
-template <int KH, int KW, int CG>
+// BF: d is a bf16 tensor (math mode 4; g is the fp32 network input)
+template <int KH, int KW, int CG, bool BF>
 __global__ void __launch_bounds__(256) direct_wgrad_kernel(const dfl_wgrad_args a, int Mtot, int rows_per_block) {
   constexpr int K = KH * KW * CG, T = KH * KW;
   static_assert(K <= DK, "window too large for the direct kernel");
@@ -219,7 +253,7 @@ __global__ void __launch_bounds__(256) direct_wgrad_kernel(const dfl_wgrad_args 
   cur.init(min(m_begin + pl, Mtot - 1), a.Hout, a.Wout);
   for (int m = m_begin + pl; m < m_end; m += PL, cur.advance(PL, a.Hout, a.Wout)) {
     const Gather g = cur.origin(a.stride, a.pad, a.Hin, a.Win);
-    const float4 d = *reinterpret_cast<const float4*>(a.d + (int64_t)m * a.ldd + 4 * q);
+    const float4 d = ld4c<BF>(a.d, (int64_t)m * a.ldd + 4 * q);
     float xv[K];
 #pragma unroll
     for (int dy = 0; dy < KH; ++dy)
@@ -264,7 +298,7 @@ __global__ void __launch_bounds__(256) direct_wgrad_kernel(const dfl_wgrad_args 
 bool direct_wgrad_ok(const dfl_wgrad_args* a) {
   if (!direct_window(a->KH, a->KW, a->Cg)) return false;
   if (a->Cm % 4 != 0 || a->Cm > 1024 || 256 % (a->Cm / 4) != 0) return false;
-  if (a->ldd % 4 != 0 || !aligned16(a->d)) return false;
+  if (a->ldd % 4 != 0 || !aligned16(a->d) || a->g_bf16) return false;
   return true;
 }
 
@@ -279,7 +313,11 @@ int direct_wgrad_splits(const dfl_wgrad_args* a) {
 int direct_wgrad_launch(const dfl_wgrad_args* a, hipStream_t s) {
   const int64_t M = (int64_t)a->N * a->Hout * a->Wout;
   const int rpb = (int)ceil_div(M, a->splits);
-#define DFL_DW(KH_, C_) hipLaunchKernelGGL((direct_wgrad_kernel<KH_, KH_, C_>), dim3((unsigned)a->splits), dim3(256), 0, s, *a, (int)M, rpb)
+#define DFL_DW(KH_, C_)                                                                                                  \
+  {                                                                                                                      \
+    if (a->d_bf16) hipLaunchKernelGGL((direct_wgrad_kernel<KH_, KH_, C_, true>), dim3((unsigned)a->splits), dim3(256), 0, s, *a, (int)M, rpb);  \
+    else hipLaunchKernelGGL((direct_wgrad_kernel<KH_, KH_, C_, false>), dim3((unsigned)a->splits), dim3(256), 0, s, *a, (int)M, rpb);           \
+  }
   switch (a->KH * 10 + a->Cg) {
     case 31: DFL_DW(3, 1); break;
     case 21: DFL_DW(2, 1); break;

@@ -24,7 +24,29 @@ constexpr int HT = 256;   // pixels per workgroup tile
 
 // tile[p][0..F) = x[m0 + p][0..F) (zeros past M); optionally the same values go to cat[(m0 + p) * cat_ld + ..] (scratch)
 __device__ __forceinline__ void head_load_tile(float* tile, int pitch, const float* __restrict__ x, int ldx, int64_t m0,
-                                               int64_t M, int F, float* __restrict__ cat, int cat_ld) {
+                                               int64_t M, int F, float* __restrict__ cat, int cat_ld, int x_bf16) {
+  if (x_bf16) {   // bf16 features (math mode 4): 8 channels per 16-byte load, widened to fp32 in the tile
+    const int f8 = F / 8;
+    const unsigned short* xb = reinterpret_cast<const unsigned short*>(x);
+    for (int e = threadIdx.x; e < HT * f8; e += HT) {
+      const int p = e / f8, q = e - p * f8;
+      float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+      if (m0 + p < M) {
+        const uint4 w = *reinterpret_cast<const uint4*>(xb + (m0 + p) * ldx + 8 * q);
+        lo = make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
+                         __uint_as_float(w.y & 0xffff0000u));
+        hi = make_float4(__uint_as_float(w.z << 16), __uint_as_float(w.z & 0xffff0000u), __uint_as_float(w.w << 16),
+                         __uint_as_float(w.w & 0xffff0000u));
+        if (cat != nullptr) {
+          *reinterpret_cast<float4*>(cat + (m0 + p) * cat_ld + 8 * q) = lo;
+          *reinterpret_cast<float4*>(cat + (m0 + p) * cat_ld + 8 * q + 4) = hi;
+        }
+      }
+      *reinterpret_cast<float4*>(tile + p * pitch + 8 * q) = lo;
+      *reinterpret_cast<float4*>(tile + p * pitch + 8 * q + 4) = hi;
+    }
+    return;
+  }
   const int fq = F / 4;
   for (int e = threadIdx.x; e < HT * fq; e += HT) {
     const int p = e / fq, q = e - p * fq;
@@ -117,7 +139,7 @@ HEAD_TPL __global__ void __launch_bounds__(256) head_fwd_kernel(const dfl_head_f
   const bool lands = L > 0;
   for (int64_t m0 = (int64_t)blockIdx.x * HT; m0 < M; m0 += (int64_t)gridDim.x * HT) {
     __syncthreads();
-    head_load_tile(tile, pitch, a.x, a.ldx, m0, M, F, nullptr, 0);
+    head_load_tile(tile, pitch, a.x, a.ldx, m0, M, F, nullptr, 0, a.x_bf16);
     __syncthreads();
     const int64_t m = m0 + threadIdx.x;
     if (m >= M) continue;
@@ -164,7 +186,7 @@ HEAD_TPL __global__ void __launch_bounds__(256) head_bwd_kernel(const dfl_head_b
   const int o_dlg = Fc, o_dmid = Fc + MAXNC, o_mid = o_dmid + MAXNM, o_dh = o_mid + MAXNM;   // all multiples of 4
   for (int64_t m0 = (int64_t)blockIdx.x * HT; m0 < M; m0 += (int64_t)gridDim.x * HT) {
     __syncthreads();
-    head_load_tile(tile, pitch, a.x, a.ldx, m0, M, F, a.scratch, a.scratch_ld);   // also copies x into the cat columns
+    head_load_tile(tile, pitch, a.x, a.ldx, m0, M, F, a.scratch, a.scratch_ld, a.x_bf16);   // also copies x into the cat columns
     __syncthreads();
     const int64_t m = m0 + threadIdx.x;
     if (m < M) {
@@ -261,6 +283,23 @@ HEAD_TPL __global__ void __launch_bounds__(256) head_bwd_kernel(const dfl_head_b
       }
     }
     __syncthreads();
+    if (a.x_bf16) {         // dx as bf16: 8 channels per 16-byte store
+      const int f8 = F / 8;
+      unsigned short* dxb = reinterpret_cast<unsigned short*>(a.dx);
+      for (int e = threadIdx.x; e < HT * f8; e += HT) {
+        const int p = e / f8, q = e - p * f8;
+        if (m0 + p < M) {
+          const float* t = tile + p * pitch + 8 * q;
+          uint4 w;
+          w.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){t[0], t[1]}, bf16x2_t));
+          w.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){t[2], t[3]}, bf16x2_t));
+          w.z = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){t[4], t[5]}, bf16x2_t));
+          w.w = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){t[6], t[7]}, bf16x2_t));
+          *reinterpret_cast<uint4*>(dxb + (m0 + p) * a.lddx + 8 * q) = w;
+        }
+      }
+      continue;
+    }
     const int fq = F / 4;   // cooperative, coalesced store of the dx tile
     for (int e = threadIdx.x; e < HT * fq; e += HT) {
       const int p = e / fq, q = e - p * fq;
@@ -269,8 +308,9 @@ HEAD_TPL __global__ void __launch_bounds__(256) head_bwd_kernel(const dfl_head_b
   }
 }
 
-static int head_check(int F, int NC, int NM, int L, const void* w_l1, const void* w_l2, int ldx, const void* x) {
+static int head_check(int F, int NC, int NM, int L, const void* w_l1, const void* w_l2, int ldx, const void* x, int x_bf16 = 0) {
   DFL_REQUIRE(F >= 4 && F % 4 == 0, "dfl_head: F must be a multiple of 4 (got %d)", F);
+  DFL_REQUIRE(!x_bf16 || (F % 8 == 0 && ldx % 8 == 0), "dfl_head (bf16): F and ldx must be multiples of 8");
   DFL_REQUIRE(NC >= 1 && NC <= MAXNC, "dfl_head: n_classes %d exceeds the supported maximum %d", NC, MAXNC);
   DFL_REQUIRE(L >= 0 && L <= MAXL, "dfl_head: num_lands %d exceeds the supported maximum %d", L, MAXL);
   DFL_REQUIRE(ldx % 4 == 0 && aligned16(x), "dfl_head: x must be 16-byte aligned with ld %% 4 == 0");
@@ -309,7 +349,7 @@ static unsigned head_grid(int64_t M) {
 extern "C" int dfl_head_fwd(const dfl_head_fwd_args* a, dfl_stream_t stream) {
   DFL_REQUIRE(a && a->x && a->w_seg && a->seg, "dfl_head_fwd: missing pointer");
   DFL_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->ldx >= a->F, "dfl_head_fwd: bad sizes");
-  int rc = head_check(a->F, a->NC, a->NM, a->L, a->w_l1, a->w_l2, a->ldx, a->x);
+  int rc = head_check(a->F, a->NC, a->NM, a->L, a->w_l1, a->w_l2, a->ldx, a->x, a->x_bf16);
   if (rc != DFL_OK) return rc;
   DFL_REQUIRE(a->L == 0 || a->heat != nullptr, "dfl_head_fwd: heat output required when L > 0");
   const int64_t M = (int64_t)a->N * a->H * a->W;
@@ -325,9 +365,9 @@ extern "C" int dfl_head_fwd(const dfl_head_fwd_args* a, dfl_stream_t stream) {
 extern "C" int dfl_head_bwd(const dfl_head_bwd_args* a, dfl_stream_t stream) {
   DFL_REQUIRE(a && a->x && a->seg && a->dseg && a->w_seg && a->dx && a->scratch, "dfl_head_bwd: missing pointer");
   DFL_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->ldx >= a->F && a->lddx >= a->F, "dfl_head_bwd: bad sizes");
-  int rc = head_check(a->F, a->NC, a->NM, a->L, a->w_l1, a->w_l2, a->ldx, a->x);
+  int rc = head_check(a->F, a->NC, a->NM, a->L, a->w_l1, a->w_l2, a->ldx, a->x, a->x_bf16);
   if (rc != DFL_OK) return rc;
-  DFL_REQUIRE(a->lddx % 4 == 0 && aligned16(a->dx), "dfl_head_bwd: dx alignment");
+  DFL_REQUIRE(a->lddx % (a->x_bf16 ? 8 : 4) == 0 && aligned16(a->dx), "dfl_head_bwd: dx alignment");
   DFL_REQUIRE(a->scratch_ld >= dfl_head_scratch_ld(a->F) && a->scratch_ld % 4 == 0 && aligned16(a->scratch),
               "dfl_head_bwd: scratch_ld too small or misaligned");
   const int64_t M = (int64_t)a->N * a->H * a->W;

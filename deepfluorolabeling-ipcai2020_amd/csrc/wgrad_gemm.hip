@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "convp.h"
 #include "direct_small.h"
 
 namespace dfl {
@@ -627,6 +628,7 @@ static int wg_launch(const WgK& k, hipStream_t s) {
 }  // namespace dfl
 
 extern "C" int dfl_wgrad_config(const dfl_wgrad_args* a) {
+  if (a != nullptr && a->g_bf16 && a->d_bf16) return dfl::wgradp_config(a);
   dfl::WgK k;
   int rc = dfl::wg_prepare(a, &k, false);
   if (rc != DFL_OK) return rc;
@@ -635,6 +637,7 @@ extern "C" int dfl_wgrad_config(const dfl_wgrad_args* a) {
 }
 
 extern "C" int dfl_wgrad_suggest_splits(const dfl_wgrad_args* a) {
+  if (a != nullptr && a->g_bf16 && a->d_bf16) return dfl::wgradp_suggest_splits(a);
   dfl::WgK k;
   int rc = dfl::wg_prepare(a, &k, false);
   if (rc != DFL_OK) return rc;
@@ -653,6 +656,7 @@ extern "C" int dfl_wgrad_suggest_splits(const dfl_wgrad_args* a) {
 }
 
 extern "C" int dfl_conv2d_wgrad(const dfl_wgrad_args* a, dfl_stream_t stream) {
+  if (a != nullptr && a->g_bf16 && a->d_bf16) return dfl::wgradp_launch(a, static_cast<hipStream_t>(stream));
   dfl::WgK k;
   int rc = dfl::wg_prepare(a, &k, true);
   if (rc != DFL_OK) return rc;
@@ -661,6 +665,7 @@ extern "C" int dfl_conv2d_wgrad(const dfl_wgrad_args* a, dfl_stream_t stream) {
     DFL_REQUIRE(!a->d_split, "dfl_conv2d_wgrad: a split d is not defined for the direct small-K kernels");
     return dfl::direct_wgrad_launch(a, s);
   }
+  DFL_REQUIRE(!a->g_bf16 && !a->d_bf16, "dfl_conv2d_wgrad: mixed bf16 / fp32 operands only for the direct small-K layers");
   k.cps = (int)dfl::ceil_div(k.nchunks, a->splits);
   const bool f = k.fast;
   DFL_REQUIRE(!a->d_split || (f && (dfl::math_mode() == 1 || dfl::math_mode() == 3) && !dfl::direct_wgrad_ok(a)),

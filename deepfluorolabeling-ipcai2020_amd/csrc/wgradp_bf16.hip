@@ -1,0 +1,392 @@
+// Patch-resident weight gradient for bf16 tensors (math mode 4, "bf16 storage"):
+//   dw[cm][cg][t] = sum over output pixels m of d[m][cm] * G(m, t, cg)
+// with G the layer input gathered as dfl_conv2d gathers it (taps, stride, zero padding AFTER the optional BatchNorm affine).
+// Reference: torch autograd of nn.Conv2d / nn.ConvTranspose2d at train_test_code/unet.py:93,207,211,218,240 (train.py:422).
+// Contract: include/dfl_hip.h (dfl_conv2d_wgrad with g_bf16 = d_bf16 = 1).
+//
+// Same idea as convp_bf16.hip.  A workgroup owns a 64 x 64 (or smaller) tile of (cm, cg) for ALL taps and walks a range
+// of pixel PATCHES.  Per patch it stages, once, the patch of d ([pixel][cm] bf16) and the patch of the gathered tensor with
+// its halo ([pixel][cg] bf16, affine applied, padding written as zeros) in LDS; after that every tap of every k-step (16
+// pixels) is an address offset into the same image.  The contraction index is the pixel -- the slow index of both NHWC
+// operands -- so the MFMA fragments (8 consecutive pixels of one channel per lane) come out of LDS through gfx950's
+// transposing read ds_read_b64_tr_b16 (16 lanes name 4 pixel rows x 16 channels and receive 4 pixels of one channel each).
+// A d fragment is read once per k-step and used for all taps; a wave keeps one fp32 accumulator tile per tap (9 x 16
+// registers for a 3x3 layer).  Row pitches are chosen so that the 4 rows x 64 bytes of a transposing read fall on 64
+// distinct banks (pitch = 64 or 192 bytes mod 256).
+// Waves: with 4 (cm, cg) tile pairs in the workgroup tile each wave owns a pair; with 2 or 1 pairs the waves also split
+// the k-steps of a patch (2 or 4 phases) and add up through LDS at the end.  Output: partial[slice][t][cm][cg] fp32 (tap-major:
+// full 128-byte rows), summed and transposed to torch's [cm][cg][t] by dfl_reduce_batch; a single slot writes dw itself.
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.h"
+#include "convp.h"
+
+namespace dfl {
+
+constexpr uint32_t WPOOB = 0x80000000u;
+typedef unsigned int wpu32x4 __attribute__((ext_vector_type(4)));
+typedef short ws16x4_t __attribute__((ext_vector_type(4)));
+
+struct WgP {
+  dfl_wgrad_args a;
+  int Mtot, T;
+  int PH, PW, IPP, npy, npx, npatch;   // patch of the d grid (Hout x Wout per image)
+  int IH, IW;                          // gathered pixels per patch and image
+  int P16;                             // patch pixels rounded up to 16
+  int CMT, CGT;                        // workgroup tile (multiples of 32, <= 64)
+  int pairs, phases;                   // (cm32, cg32) pairs per workgroup, k-step phases (pairs * phases = 4)
+  int zslices, patches_per_slice;      // grid.z, patches each slice walks
+  int sd, sg;                          // row pitch of the d / g images in bytes
+  int dupp_shift, gupp_shift;          // log2(CMT / 8), log2(CGT / 8)
+  int g_off;                           // byte offset of the g image behind the d image
+  int lds_bytes;
+  uint32_t g_bytes, d_bytes;
+};
+
+__device__ __forceinline__ float wbf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float wbf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ uint32_t wpack_bf2(float a, float b) {
+  const bf16x2_t h = __builtin_convertvector((f32x2_t){a, b}, bf16x2_t);
+  return __builtin_bit_cast(uint32_t, h);
+}
+
+// (image, row, column) of a pixel index walked by a constant step without divisions
+struct Walk {
+  int img, y, x;
+  __device__ __forceinline__ void init(int idx, int H, int W) {
+    img = idx / (H * W);
+    const int r = idx - img * (H * W);
+    y = r / W;
+    x = r - y * W;
+  }
+  __device__ __forceinline__ void advance(int dy, int dx, int H, int W) {
+    x += dx;
+    y += dy;
+    if (x >= W) {
+      x -= W;
+      ++y;
+    }
+    while (y >= H) {
+      y -= H;
+      ++img;
+    }
+  }
+};
+
+// 8 consecutive pixels of one channel: two transposing reads (pixel rows at byte addresses r0 and r1 as seen by this lane)
+__device__ __forceinline__ bf16x8_t wtr_read8(const unsigned char* base, uint32_t r0, uint32_t r1) {
+  typedef __attribute__((address_space(3))) ws16x4_t* lds_p;
+  const ws16x4_t x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + r0));
+  const ws16x4_t y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + r1));
+  return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <int T, bool AFF>
+__global__ void __launch_bounds__(256, (T >= 9) ? 1 : 2) wgradp_kernel(const WgP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const dfl_wgrad_args& a = p.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int pair = wave % p.pairs, phase = wave / p.pairs;
+  const int pairs_n = p.CGT >> 5;                       // pairs along cg
+  const int pm = pair / pairs_n, pn = pair - pm * pairs_n;
+  const int cm0 = blockIdx.x * p.CMT, cg0 = blockIdx.y * p.CGT;
+  unsigned char* Ds = smem;
+  unsigned char* Gs = smem + p.g_off;
+  const int KW = a.KW;
+
+  __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.d), 0, (int)p.d_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g), 0, (int)p.g_bytes, 0x00020000);
+
+  f32x16 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // transposing-read lane geometry inside a 32-channel tile: pixel row 8*lh + (lane & 15) / 4 (second read: + 4),
+  // channels 16 * ((lane >> 4) & 1) + 4 * (lane & 3) .. + 3
+  const int trow = 8 * lh + ((lane & 15) >> 2);
+  const uint32_t tcb = (uint32_t)((16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
+  const uint32_t d_col = (uint32_t)(pm * 64) + tcb, g_col = (uint32_t)(pn * 64) + tcb;
+
+  // staging: 16-byte units (8 channels); d image: P16 rows x CMT channels, g image: IPP*IH*IW rows x CGT channels
+  const int dupp = p.CMT >> 3, gupp = p.CGT >> 3;
+  const int npix_g = p.IPP * p.IH * p.IW;
+  const int per_img = p.npy * p.npx;
+
+  const int pbegin = blockIdx.z * p.patches_per_slice;
+  const int pend = min(pbegin + p.patches_per_slice, p.npatch);
+  for (int patch = pbegin; patch < pend; ++patch) {
+    const int pg = patch / per_img, pr = patch - pg * per_img;
+    const int ppy = pr / p.npx, ppx = pr - ppy * p.npx;
+    const int img0 = pg * p.IPP, oy0 = ppy * p.PH, ox0 = ppx * p.PW;
+    if (patch != pbegin) __syncthreads();
+    // ---- d: rows = patch pixels in patch order (image, row, column), zeros beyond the patch / image
+    {
+      const int cq = tid & (dupp - 1);
+      const int c = cm0 + cq * 8;
+      Walk w;
+      w.init(tid >> p.dupp_shift, p.PH, p.PW);
+      const int dk = 256 >> p.dupp_shift;
+      const int dky = dk / p.PW, dkx = dk - dky * p.PW;
+      for (int k = tid >> p.dupp_shift; k < p.P16; k += dk) {
+        const int n = img0 + w.img, oy = oy0 + w.y, ox = ox0 + w.x;
+        const bool ok = w.img < p.IPP && n < a.N && oy < a.Hout && ox < a.Wout && c < a.Cm;
+        const uint32_t off = (uint32_t)((((n * a.Hout + oy) * a.Wout + ox) * a.ldd + c) * 2);
+        const wpu32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsD, ok ? off : WPOOB, 0, 0);
+        *reinterpret_cast<wpu32x4*>(Ds + (uint32_t)k * (uint32_t)p.sd + (uint32_t)cq * 16u) = v;
+        w.advance(dky, dkx, p.PH, p.PW);
+      }
+    }
+    // ---- g: the gathered pixels of the patch with their halo, affine applied, zero outside the image
+    {
+      const int ybase = oy0 * a.stride - a.pad, xbase = ox0 * a.stride - a.pad;
+      const int cq = tid & (gupp - 1);
+      const int c = cg0 + cq * 8;
+      float sc[8], sh[8];
+      if constexpr (AFF) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          sc[e] = (c + e < a.Cg) ? a.in_scale[c + e] : 1.f;
+          sh[e] = (c + e < a.Cg) ? a.in_shift[c + e] : 0.f;
+        }
+      }
+      Walk w;
+      w.init(tid >> p.gupp_shift, p.IH, p.IW);
+      const int dk = 256 >> p.gupp_shift;
+      const int dky = dk / p.IW, dkx = dk - dky * p.IW;
+      for (int pix = tid >> p.gupp_shift; pix < npix_g; pix += dk) {
+        const int n = img0 + w.img, gy = ybase + w.y, gx = xbase + w.x;
+        const bool ok = n < a.N && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win && c < a.Cg;
+        const uint32_t off = (uint32_t)((((n * a.Hin + gy) * a.Win + gx) * a.ldg + c) * 2);
+        wpu32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsG, ok ? off : WPOOB, 0, 0);
+        if constexpr (AFF) {
+          if (ok) {
+            v.x = wpack_bf2(fmaf(wbf_lo(v.x), sc[0], sh[0]), fmaf(wbf_hi(v.x), sc[1], sh[1]));
+            v.y = wpack_bf2(fmaf(wbf_lo(v.y), sc[2], sh[2]), fmaf(wbf_hi(v.y), sc[3], sh[3]));
+            v.z = wpack_bf2(fmaf(wbf_lo(v.z), sc[4], sh[4]), fmaf(wbf_hi(v.z), sc[5], sh[5]));
+            v.w = wpack_bf2(fmaf(wbf_lo(v.w), sc[6], sh[6]), fmaf(wbf_hi(v.w), sc[7], sh[7]));
+          }
+        }
+        *reinterpret_cast<wpu32x4*>(Gs + (uint32_t)pix * (uint32_t)p.sg + (uint32_t)cq * 16u) = v;
+        w.advance(dky, dkx, p.IH, p.IW);
+      }
+    }
+    __syncthreads();
+
+    // ---- k-steps of this patch (16 pixels each), this wave's phase
+    const int nsteps = p.P16 >> 4;
+    // this lane's two pixel rows of a step: patch pixels j0 = 16 ks + trow and j0 + 4, walked without divisions
+    Walk w0, w1;
+    w0.init(phase * 16 + trow, p.PH, p.PW);
+    w1.init(phase * 16 + trow + 4, p.PH, p.PW);
+    const int dj = 16 * p.phases;
+    const int djy = dj / p.PW, djx = dj - djy * p.PW;
+    for (int ks = phase; ks < nsteps; ks += p.phases) {
+      const uint32_t dr0 = (uint32_t)(ks * 16 + trow) * (uint32_t)p.sd + d_col;
+      const uint32_t dr1 = dr0 + 4u * (uint32_t)p.sd;
+      // rows beyond the patch: d is zero there, any valid g row will do
+      const uint32_t gr0 = (w0.img < p.IPP ? (uint32_t)((w0.img * p.IH + w0.y * a.stride) * p.IW + w0.x * a.stride) : 0u) * (uint32_t)p.sg + g_col;
+      const uint32_t gr1 = (w1.img < p.IPP ? (uint32_t)((w1.img * p.IH + w1.y * a.stride) * p.IW + w1.x * a.stride) : 0u) * (uint32_t)p.sg + g_col;
+      const bf16x8_t df = wtr_read8(Ds, dr0, dr1);
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const int ty = t / KW, tx = t - ty * KW;
+        const uint32_t toff = (uint32_t)((ty * p.IW + tx)) * (uint32_t)p.sg;
+        const bf16x8_t gf = wtr_read8(Gs, gr0 + toff, gr1 + toff);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, gf, acc[t], 0, 0, 0);
+      }
+      w0.advance(djy, djx, p.PH, p.PW);
+      w1.advance(djy, djx, p.PH, p.PW);
+    }
+  }
+
+  // ---- waves that split the k-steps of the patches (phases > 1) add their accumulators through LDS, tap by tap, in a
+  //      fixed order; the wave of phase 0 then owns the workgroup's result for its (cm, cg) pair
+  if (p.phases > 1) {
+    float* red = reinterpret_cast<float*>(smem);        // [phases - 1][pairs][16][64]
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      __syncthreads();
+      if (phase > 0) {
+        float* dst = red + (((phase - 1) * p.pairs + pair) * 16) * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[r * 64] = acc[t][r];
+      }
+      __syncthreads();
+      if (phase == 0) {
+        for (int ph = 1; ph < p.phases; ++ph) {
+          const float* src = red + (((ph - 1) * p.pairs + pair) * 16) * 64 + lane;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[t][r] += src[r * 64];
+        }
+      }
+    }
+    if (phase > 0) return;
+  }
+  // ---- output: one partial slot per pixel slice
+  const bool sliced = p.zslices > 1;
+  float* out = sliced ? a.partial + (int64_t)blockIdx.z * a.Cm * a.Cg * T : a.dw;
+  const int cg = cg0 + pn * 32 + li;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int cm = cm0 + pm * 32 + mfma32_row(r, lane);
+      if (cm < a.Cm && cg < a.Cg) {
+        const int64_t o = sliced ? ((int64_t)t * a.Cm + cm) * a.Cg + cg : ((int64_t)cm * a.Cg + cg) * T + t;
+        out[o] = acc[t][r];
+      }
+    }
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+
+static int pitch_for(int channels) {        // bytes per staged pixel: data + pad so that pitch = 64 or 192 (mod 256)
+  const int data = channels * 2;
+  int pitch = data;
+  while (pitch % 256 != 64 && pitch % 256 != 192) pitch += 16;
+  return pitch;
+}
+
+static int wgp_plan(const dfl_wgrad_args* a, WgP* p, bool need_out) {
+  DFL_REQUIRE(a != nullptr, "dfl_conv2d_wgrad: null args");
+  DFL_REQUIRE(a->N > 0 && a->Hin > 0 && a->Win > 0 && a->Cg > 0 && a->Cm > 0, "dfl_conv2d_wgrad: bad sizes");
+  DFL_REQUIRE(a->KH > 0 && a->KW > 0 && a->stride > 0 && a->pad >= 0, "dfl_conv2d_wgrad: bad window");
+  const int T = a->KH * a->KW;
+  DFL_REQUIRE(T == 1 || T == 4 || T == 9, "dfl_conv2d_wgrad (bf16): 1x1, 2x2 and 3x3 windows");
+  const int ho = (a->Hin + 2 * a->pad - a->KH) / a->stride + 1;
+  const int wo = (a->Win + 2 * a->pad - a->KW) / a->stride + 1;
+  DFL_REQUIRE(ho == a->Hout && wo == a->Wout, "dfl_conv2d_wgrad: Hout/Wout (%d,%d) do not match the window (%d,%d)", a->Hout,
+              a->Wout, ho, wo);
+  DFL_REQUIRE(a->Cg % 8 == 0 && a->Cm % 8 == 0 && a->ldg % 8 == 0 && a->ldd % 8 == 0 && aligned16(a->g) && aligned16(a->d),
+              "dfl_conv2d_wgrad (bf16): channel counts and pixel strides must be multiples of 8, tensors 16-byte aligned");
+  DFL_REQUIRE((a->in_scale == nullptr) == (a->in_shift == nullptr), "dfl_conv2d_wgrad: in_scale/in_shift go together");
+  if (need_out) {
+    DFL_REQUIRE(a->g && a->d, "dfl_conv2d_wgrad: g and d are required");
+    DFL_REQUIRE(a->splits >= 1, "dfl_conv2d_wgrad: splits >= 1");
+    DFL_REQUIRE(a->splits > 1 ? a->partial != nullptr : a->dw != nullptr, "dfl_conv2d_wgrad: output buffer missing");
+  }
+  memset(p, 0, sizeof(*p));
+  p->a = *a;
+  p->T = T;
+  const int64_t M = (int64_t)a->N * a->Hout * a->Wout;
+  DFL_REQUIRE(M < (1ll << 31), "dfl_conv2d_wgrad: too many pixels");
+  p->Mtot = (int)M;
+  const int64_t gb = (((int64_t)a->N * a->Hin * a->Win - 1) * a->ldg + a->Cg) * 2;
+  const int64_t db = ((M - 1) * a->ldd + a->Cm) * 2;
+  const int64_t lim = (1ll << 31) - 4096;
+  DFL_REQUIRE(gb < lim && db < lim, "dfl_conv2d_wgrad (bf16): tensors must stay below 2 GiB");
+  p->g_bytes = (uint32_t)gb;
+  p->d_bytes = (uint32_t)db;
+  // workgroup tile and wave roles
+  p->CMT = a->Cm > 32 ? 64 : 32;
+  p->CGT = a->Cg > 32 ? 64 : 32;
+  p->pairs = (p->CMT / 32) * (p->CGT / 32);
+  p->phases = 4 / p->pairs;
+  p->dupp_shift = p->CMT == 64 ? 3 : 2;
+  p->gupp_shift = p->CGT == 64 ? 3 : 2;
+  p->sd = pitch_for(p->CMT);
+  p->sg = pitch_for(p->CGT);
+  // patch: whole images while they fit 256 pixels, else whole rows, else row pieces of 64 pixels; LDS <= ~72 KiB
+  const int HW = a->Hout * a->Wout;
+  int ipp = 1, ph, pw;
+  auto lds_of = [&](int ipp_, int ph_, int pw_) {
+    const int p16 = (ipp_ * ph_ * pw_ + 15) / 16 * 16;
+    const int ih = (ph_ - 1) * a->stride + a->KH, iw = (pw_ - 1) * a->stride + a->KW;
+    return (int64_t)p16 * p->sd + (int64_t)ipp_ * ih * iw * p->sg;
+  };
+  const int64_t budget = 72 * 1024;
+  if (HW <= 256) {
+    ipp = 256 / HW;
+    if (ipp > a->N) ipp = a->N;
+    ph = a->Hout;
+    pw = a->Wout;
+    while (ipp > 1 && lds_of(ipp, ph, pw) > budget) --ipp;
+  } else if (a->Wout <= 256) {
+    pw = a->Wout;
+    ph = 256 / pw;
+  } else {
+    pw = 64;
+    ph = 4;
+  }
+  if (ipp == 1) {
+    if (ph > a->Hout) ph = a->Hout;
+    while (ph > 1 && lds_of(1, ph, pw) > budget) --ph;
+    while (pw > 16 && lds_of(1, ph, pw) > budget) pw = (pw + 1) / 2;
+  }
+  DFL_REQUIRE(lds_of(ipp, ph, pw) <= 150 * 1024, "dfl_conv2d_wgrad (bf16): patch does not fit LDS");
+  p->IPP = ipp;
+  p->PH = ph;
+  p->PW = pw;
+  p->P16 = (ipp * ph * pw + 15) / 16 * 16;
+  p->npy = (int)ceil_div(a->Hout, ph);
+  p->npx = (int)ceil_div(a->Wout, pw);
+  p->npatch = (int)ceil_div(a->N, ipp) * p->npy * p->npx;
+  p->IH = (ph - 1) * a->stride + a->KH;
+  p->IW = (pw - 1) * a->stride + a->KW;
+  p->g_off = (p->P16 * p->sd + 255) / 256 * 256;
+  p->lds_bytes = p->g_off + ipp * p->IH * p->IW * p->sg;
+  if (p->lds_bytes < 3 * 4 * 16 * 64 * 4) p->lds_bytes = 3 * 4 * 16 * 64 * 4;   // room for the cross-phase sums
+  return DFL_OK;
+}
+
+// pixel slices so that the chip sees ~512 workgroups, every slice at least two patches when there are that many
+static int wgp_slices(const WgP& p) {
+  const int64_t tiles = ceil_div(p.a.Cm, p.CMT) * ceil_div(p.a.Cg, p.CGT);
+  int64_t z = ceil_div(512, tiles);
+  if (z > p.npatch) z = p.npatch;
+  if (z < 1) z = 1;
+  // equalise: every slice walks the same number of patches
+  const int64_t pps = ceil_div(p.npatch, z);
+  z = ceil_div(p.npatch, pps);
+  return (int)z;
+}
+
+int wgradp_suggest_splits(const dfl_wgrad_args* a) {
+  WgP p;
+  int rc = wgp_plan(a, &p, false);
+  if (rc != DFL_OK) return rc;
+  return wgp_slices(p);
+}
+
+int wgradp_config(const dfl_wgrad_args* a) {
+  WgP p;
+  int rc = wgp_plan(a, &p, false);
+  if (rc != DFL_OK) return rc;
+  return 16 + (p.T == 9 ? 0 : (p.T == 4 ? 1 : 2));
+}
+
+template <int T>
+static int wgp_launch_t(const WgP& p, hipStream_t s) {
+  dim3 grid((unsigned)ceil_div(p.a.Cm, p.CMT), (unsigned)ceil_div(p.a.Cg, p.CGT), (unsigned)p.zslices);
+  const size_t lds = (size_t)p.lds_bytes;
+  if (p.a.in_scale != nullptr) {
+    auto k = wgradp_kernel<T, true>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, p);
+  } else {
+    auto k = wgradp_kernel<T, false>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, p);
+  }
+  return check_launch("dfl_conv2d_wgrad (bf16)");
+}
+
+int wgradp_launch(const dfl_wgrad_args* a, hipStream_t s) {
+  WgP p;
+  int rc = wgp_plan(a, &p, true);
+  if (rc != DFL_OK) return rc;
+  p.zslices = a->splits;                     // partial slots = pixel slices
+  p.patches_per_slice = (int)ceil_div(p.npatch, p.zslices);
+  switch (p.T) {
+    case 9: return wgp_launch_t<9>(p, s);
+    case 4: return wgp_launch_t<4>(p, s);
+    default: return wgp_launch_t<1>(p, s);
+  }
+}
+
+}  // namespace dfl

@@ -23,18 +23,23 @@ BN_MOMENTUM = 0.1
 
 
 class Act:
-    """An NHWC activation window: channels [0, C) of rows with pixel stride ld starting at ptr."""
-    __slots__ = ('t', 'ptr', 'ld', 'N', 'H', 'W', 'C')
+    """An NHWC activation window: channels [0, C) of rows with pixel stride ld (in elements) starting at ptr; esz = bytes
+    per element (4: fp32; 2: bf16 tensors of math mode 4)."""
+    __slots__ = ('t', 'ptr', 'ld', 'N', 'H', 'W', 'C', 'esz')
 
-    def __init__(self, t, ptr, ld, N, H, W, C):
-        self.t, self.ptr, self.ld, self.N, self.H, self.W, self.C = t, ptr, ld, N, H, W, C
+    def __init__(self, t, ptr, ld, N, H, W, C, esz=4):
+        self.t, self.ptr, self.ld, self.N, self.H, self.W, self.C, self.esz = t, ptr, ld, N, H, W, C, esz
 
     @property
     def M(self):
         return self.N * self.H * self.W
 
+    @property
+    def bf16(self):
+        return int(self.esz == 2)
+
     def chan_slice(self, c0, c):
-        return Act(self.t, self.ptr + 4 * c0, self.ld, self.N, self.H, self.W, c)
+        return Act(self.t, self.ptr + self.esz * c0, self.ld, self.N, self.H, self.W, c, self.esz)
 
 
 class PlanError(RuntimeError):
@@ -66,6 +71,11 @@ class UNetPlan:
         self._red_flushes = []          # (index of the batch op in bwd, [dst pointers])
         self._side = []                 # weight gradients running on the side stream: dict(done=event, op=index, waited=index|None)
         self.math = self.lib.dfl_get_math_mode()   # product arithmetic the plan is recorded for (split operand formats)
+        # math mode 4, "bf16 storage": internal activations, their gradients and the GEMM copies of the weights are bf16
+        # tensors (BASELINE configs[1] as named); statistics, losses, master weights and weight gradients stay fp32
+        self.bf16 = self.math == 4
+        self.adt = torch.bfloat16 if self.bf16 else torch.float32
+        self.aesz = 2 if self.bf16 else 4
         self._packed_split = {}         # packed-weight address -> stored as split quads
         self._build()
 
@@ -76,8 +86,8 @@ class UNetPlan:
         return t
 
     def _act(self, N, H, W, C):
-        t = self._new(N * H * W * C)
-        return Act(t, t.data_ptr(), C, N, H, W, C)
+        t = self._new(N * H * W * C, self.adt)
+        return Act(t, t.data_ptr(), C, N, H, W, C, self.aesz)
 
     def _scratch_act(self, key, N, H, W, C):
         """Backward scratch shared by all blocks (stream order makes reuse safe)."""
@@ -85,7 +95,7 @@ class UNetPlan:
         t = self._scratch.get(key)
         if t is None or t.numel() < need:
             raise PlanError('scratch %s not sized' % key)
-        return Act(t, t.data_ptr(), C, N, H, W, C)
+        return Act(t, t.data_ptr(), C, N, H, W, C, self.aesz)
 
     # ------------------------------------------------------------------------------------------ weights
     def _pack(self, w, kind, flip=0):
@@ -95,11 +105,17 @@ class UNetPlan:
         Cc = KH * KW
         K = {1: Cc * B, 2: Cc * A, 3: A}[kind]
         N = {1: A, 2: B, 3: Cc * B}[kind]
+        cin = B if kind == 1 else A
+        if self.bf16 and cin % 16 == 0:
+            # bf16 chunk layout [K/16][N][16] of the patch-resident kernels (every layer but the 1-channel first one)
+            dst = self._new((K + 15) // 16 * N * 16, torch.bfloat16)
+            self._packed_split[dst.data_ptr()] = 2
+            self._pack_jobs.append((w, dst, A, B, Cc, kind, flip, 2))
+            return dst
         dst = self._new((K + 3) // 4 * N * 4)
         # split quads (hi4 | lo4 bf16) when the consuming conv will take the split-bf16 fast path: its input channels
         # (B for a forward operand, A for the transposed ones) must be a multiple of 16 and K large enough for the GEMM
-        cin = B if kind == 1 else A
-        split = int(self.math in (1, 3) and cin % 16 == 0)
+        split = int(self.math in (1, 3) and cin % 16 == 0 and self.WSPLIT)
         self._packed_split[dst.data_ptr()] = split
         self._pack_jobs.append((w, dst, A, B, Cc, kind, flip, split))
         return dst
@@ -152,6 +168,8 @@ class UNetPlan:
         self._bwd_needs_pack_wait = True
 
     PACK_OVERLAP = os.environ.get('DFL_PACK_OVERLAP', '1') != '0'
+    WSPLIT = os.environ.get('DFL_WSPLIT', '1') != '0'      # split-bf16 modes: weights split once by the pack kernel
+    DSPLIT = os.environ.get('DFL_DSPLIT', '1') != '0'      # ... and the BatchNorm/ReLU backward output split once by its producer
     EV_PACK_FORK, EV_PACK_DONE = 60000, 60001
 
     # ------------------------------------------------------------------------------------------ op helpers
@@ -161,6 +179,9 @@ class UNetPlan:
         a.x, a.w, a.y = x.ptr, w.data_ptr(), y.ptr
         a.w_split = self._packed_split.get(w.data_ptr(), 0)
         a.x_split = x_split
+        a.x_bf16, a.y_bf16 = x.bf16, y.bf16
+        if (add is not None and add.bf16 != y.bf16) or (stat_other is not None and stat_other.bf16 != y.bf16):
+            raise PlanError('internal: mixed element types in a convolution epilogue')
         a.bias = nat.ptr(bias)
         if in_aff is not None:
             a.in_scale, a.in_shift = in_aff[0].data_ptr(), in_aff[1].data_ptr()
@@ -207,6 +228,7 @@ class UNetPlan:
     def _wgrad(self, prog, g, d, dw, KH, KW, stride, pad, Hout, Wout, in_aff=None, side=False, side_buf=None, d_split=0):
         a = WgradArgs()
         a.d_split = d_split
+        a.g_bf16, a.d_bf16 = g.bf16, d.bf16
         a.g, a.d, a.dw = g.ptr, d.ptr, dw.data_ptr()
         if in_aff is not None:
             a.in_scale, a.in_shift = in_aff[0].data_ptr(), in_aff[1].data_ptr()
@@ -288,7 +310,8 @@ class UNetPlan:
         """out[c] = sum over pixels of a[:, c]."""
         nb = self.lib.dfl_rowblock_count(a.M, a.C)
         part = self._new(nb * 2 * a.C)
-        prog.add(ColstatsArgs(a=a.ptr, b=None, partials=part.data_ptr(), M=a.M, C=a.C, lda=a.ld, ldb=0, nblocks=nb))
+        prog.add(ColstatsArgs(a=a.ptr, b=None, partials=part.data_ptr(), M=a.M, C=a.C, lda=a.ld, ldb=0, nblocks=nb,
+                              bf16=a.bf16))
         self._defer_sum(prog, part.data_ptr(), out.data_ptr(), a.C, 2 * a.C, nb)
 
     # ------------------------------------------------------------------------------------------ build
@@ -304,6 +327,9 @@ class UNetPlan:
         for c in chans:
             if c % 4 != 0:
                 raise PlanError('channel counts must be multiples of 4 (wf >= 2)')
+            if self.bf16 and c % 16 != 0:
+                raise PlanError('math mode 4 (bf16 storage) needs channel counts that are multiples of 16 (wf >= 4); this '
+                                'network has a %d-channel level' % c)
         shrink = 0 if pad else 2 * bd
         # spatial size of every level (input / output of the block), down then up
         hin, win = [self.H], [self.W]
@@ -336,15 +362,23 @@ class UNetPlan:
                 sizes.append((N * uh * uw, chans[i]))
                 uh, uw = uh - shrink, uw - shrink
             mx = max(m * c for m, c in sizes)
-            self._scratch['dpre0'] = self._new(mx)
-            self._scratch['dpre1'] = self._new(mx)
+            self._scratch['dpre0'] = self._new(mx, self.adt)
+            self._scratch['dpre1'] = self._new(mx, self.adt)
             self._dpre_turn = 0
-            self._scratch['dz'] = self._new(mx)
+            self._scratch['dz'] = self._new(mx, self.adt)
 
         fwd, bwd = self.fwd, self.bwd
         Cin0 = cfg['in_channels']
-        self.x_in = self._new(N * self.H * self.W * Cin0)
-        x0 = Act(self.x_in, self.x_in.data_ptr(), Cin0, N, self.H, self.W, Cin0)
+        if self.bf16 and Cin0 > 4:
+            # multi-channel inputs enter the patch-resident kernels as bf16 (the 1..4-channel case keeps the fp32 image:
+            # the direct first-layer kernels read it as is)
+            if Cin0 % 16 != 0:
+                raise PlanError('math mode 4 (bf16 storage) takes 1..4 or a multiple of 16 input channels')
+            self.x_in = self._new(N * self.H * self.W * Cin0, torch.bfloat16)
+            x0 = Act(self.x_in, self.x_in.data_ptr(), Cin0, N, self.H, self.W, Cin0, 2)
+        else:
+            self.x_in = self._new(N * self.H * self.W * Cin0)
+            x0 = Act(self.x_in, self.x_in.data_ptr(), Cin0, N, self.H, self.W, Cin0)
 
         # cat buffers for the up path are allocated up front so that down blocks can write their bridge half directly
         up_hw = []           # size of the up-sampled tensor at level i (i = depth-2 .. 0)
@@ -415,7 +449,7 @@ class UNetPlan:
                 self._conv(fwd, xin, rwp, out, 1, 1, 1, 0, Cout, bias=rb, add=cur, add_aff=cur_aff)
             else:
                 a = AffineCopyArgs(x=cur.ptr, y=out.ptr, N=N, H=Hb, W=Wb, C=Cout, ldx=cur.ld, xH=Hb, xW=Wb,
-                                   ldy=out.ld, yH=out.H, yW=out.W)
+                                   ldy=out.ld, yH=out.H, yW=out.W, bf16=cur.bf16)
                 if cur_aff is not None:
                     a.scale, a.shift = cur_aff[0].data_ptr(), cur_aff[1].data_ptr()
                 fwd.add(a)
@@ -455,7 +489,7 @@ class UNetPlan:
                         else:
                             part, prow = self._new(nb * 2 * Cout), nb
                             bwd.add(ColstatsArgs(a=g.ptr, b=r.ptr, partials=part.data_ptr(), M=r.M, C=Cout, lda=g.ld,
-                                                 ldb=r.ld, nblocks=nb))
+                                                 ldb=r.ld, nblocks=nb, bf16=r.bf16))
                         coef = self._new(3 * Cout)
                         bwd.add(BnBwdFinalizeArgs(partials=part.data_ptr(), gamma=gamma.data_ptr(),
                                                   save_mean=mean.data_ptr(), save_invstd=invstd.data_ptr(),
@@ -472,10 +506,10 @@ class UNetPlan:
                     inp = cv['inp']
                     # dpre feeds exactly two GEMMs (weight gradient: dense operand; data gradient: gathered operand);
                     # with split-bf16 products it is written split once here instead of being split by every tile of both
-                    dsplit = int(self.math in (1, 3) and Cout % 16 == 0 and inp.C % 4 == 0 and inp.C * 9 > 12)
+                    dsplit = int(self.math in (1, 3) and Cout % 16 == 0 and inp.C % 4 == 0 and inp.C * 9 > 12 and self.DSPLIT)
                     bwd.add(BnReluBwdArgs(dy=g.ptr, r=r.ptr, coef=nat.ptr(coef), dpre=dpre.ptr,
                                           partials=bpart.data_ptr(), M=r.M, C=Cout, lddy=g.ld, ldr=r.ld, ldo=dpre.ld,
-                                          nblocks=nb, split_out=dsplit))
+                                          nblocks=nb, split_out=dsplit, bf16=r.bf16))
                     self._defer_sum(bwd, bpart.data_ptr(), G[cv['wname'] + '.bias'].data_ptr(), Cout, Cout, nb)
                     self._wgrad(bwd, inp, dpre, G[cv['wname'] + '.weight'], 3, 3, 1, pad, r.H, r.W,
                                 in_aff=cv['inp_aff'], side=side, side_buf=self._dpre_turn, d_split=dsplit)
@@ -526,12 +560,12 @@ class UNetPlan:
                     oy, ox = (hout[i] - ch) // 2, (wout[i] - cw) // 2
                     dst = cat[i].chan_slice(Ci, Ci)
                     fwd.add(AffineCopyArgs(x=out.ptr, y=dst.ptr, N=N, H=ch, W=cw, C=Ci, ldx=out.ld, xH=out.H, xW=out.W,
-                                           xoy=oy, xox=ox, ldy=dst.ld, yH=ch, yW=cw))
+                                           xoy=oy, xox=ox, ldy=dst.ld, yH=ch, yW=cw, bf16=out.bf16))
                     rec['crop'] = (oy, ox, ch, cw)
                 nxt = self._act(N, hin[i + 1], win[i + 1], Ci)
                 if cfg['max_pool']:
-                    fwd.add_pool(PoolArgs(x=out.ptr, y=nxt.ptr, N=N, H=out.H, W=out.W, C=Ci, ldx=out.ld, ldy=nxt.ld),
-                                 backward=False)
+                    fwd.add_pool(PoolArgs(x=out.ptr, y=nxt.ptr, N=N, H=out.H, W=out.W, C=Ci, ldx=out.ld, ldy=nxt.ld,
+                                          bf16=out.bf16), backward=False)
                 else:
                     dw_, db_ = self.P['downsample_convs.%d.weight' % i], self.P['downsample_convs.%d.bias' % i]
                     wp = self._pack_conv_fwd(dw_)
@@ -567,7 +601,7 @@ class UNetPlan:
         NM = w_l1.shape[0] if L > 0 else 0
         self.head_fwd = HeadFwdArgs(x=u.ptr, w_seg=w_seg.data_ptr(), w_l1=nat.ptr(w_l1), w_l2=nat.ptr(w_l2),
                                     N=N, H=u.H, W=u.W, F=F, ldx=u.ld, NC=NC, NM=NM, L=L,
-                                    softmax=1 if cfg['do_soft_max'] else 0)
+                                    softmax=1 if cfg['do_soft_max'] else 0, x_bf16=u.bf16)
         fwd.add(self.head_fwd)
         self.out_hw = (u.H, u.W)
 
@@ -599,7 +633,7 @@ class UNetPlan:
         self.head_bwd = HeadBwdArgs(x=u.ptr, w_seg=w_seg.data_ptr(), w_l1=nat.ptr(w_l1), w_l2=nat.ptr(w_l2),
                                     dx=dfeat.ptr, scratch=scratch.data_ptr(), N=N, H=u.H, W=u.W, F=F, ldx=u.ld,
                                     lddx=dfeat.ld, NC=NC, NM=NM, L=L, softmax=1 if cfg['do_soft_max'] else 0,
-                                    scratch_ld=sld)
+                                    scratch_ld=sld, x_bf16=u.bf16)
         if self.PACK_OVERLAP:
             bwd.wait(self.EV_PACK_DONE, stream=0)      # data-gradient weight layouts are packed on the side stream
         bwd.add(self.head_bwd)
@@ -651,14 +685,14 @@ class UNetPlan:
                     dout = self._act(N, out.H, out.W, Ci)
                     oy, ox, ch, cw = rec['crop']
                     src = dcat[i].chan_slice(Ci, Ci)
-                    bwd.add(MemsetArgs(ptr=dout.ptr, bytes=4 * dout.M * Ci))
+                    bwd.add(MemsetArgs(ptr=dout.ptr, bytes=dout.esz * dout.M * Ci))
                     bwd.add(AffineCopyArgs(x=src.ptr, y=dout.ptr, N=N, H=ch, W=cw, C=Ci, ldx=src.ld, xH=ch, xW=cw,
-                                           ldy=dout.ld, yH=out.H, yW=out.W, yoy=oy, yox=ox))
+                                           ldy=dout.ld, yH=out.H, yW=out.W, yoy=oy, yox=ox, bf16=src.bf16))
                 dnxt = rec['dnxt']
                 nxt = rec['nxt']
                 if cfg['max_pool']:
                     bwd.add_pool(PoolArgs(x=out.ptr, y=dnxt.ptr, dx=dout.ptr, N=N, H=out.H, W=out.W, C=Ci, ldx=out.ld,
-                                          ldy=dnxt.ld, lddx=dout.ld), backward=True)
+                                          ldy=dnxt.ld, lddx=dout.ld, bf16=out.bf16), backward=True)
                 else:
                     wname = 'downsample_convs.%d' % i
                     st = rec.get('dnxt_sums')

@@ -11,7 +11,10 @@
  *   - work is enqueued asynchronously on the given hipStream_t (pass the host framework's current stream);
  *   - re-entrant; no global mutable state except the thread-local last-error string;
  *   - arithmetic type: fp32 (exact-f32 MFMA v_mfma_f32_32x32x2_f32 for the contractions, fp64 for the
- *     cross-block part of the statistics/loss reductions);
+ *     cross-block part of the statistics/loss reductions); dfl_set_math_mode selects bf16-product variants, and
+ *     math mode 4 ("bf16 storage") keeps the network's internal activations, their gradients and the GEMM
+ *     copies of the weights as bf16 in HBM: argument blocks then carry *_bf16 flags, the flagged pointers address
+ *     bf16 elements (declared `float*` / `const float*` here for the common case) and their ld* count elements;
  *   - ACTIVATION LAYOUT inside the network is NHWC ("pixel-major"): element (n,y,x,c) of a tensor with pixel
  *     stride ld (in floats, ld >= C) lives at ((n*H + y)*W + x)*ld + c.  A channel slice of a wider buffer is
  *     expressed by offsetting the pointer and keeping ld (this is how torch.cat in unet.py:256-257 is made
@@ -86,8 +89,13 @@ typedef struct {
   /* "Split" operands (math mode 1, bf16x3, fast path only): the 16-byte slot of 4 consecutive fp32 values holds their
    * 4 hi bf16 followed by their 4 lo bf16 (hi = bf16(v), lo = bf16(v - hi)) -- same addressing, and the kernel copies
    * the slot to LDS instead of splitting it itself (a value is otherwise split once per tap and column block). */
-  int32_t w_split;       /* w was packed with dfl_pack_job.split = 1 */
+  int32_t w_split;       /* w was packed with dfl_pack_job.split = 1 (2: bf16 chunk layout, required when x_bf16) */
   int32_t x_split;       /* x is a split tensor (written by dfl_bn_relu_bwd_apply with split_out); needs in_scale == NULL */
+  /* bf16 tensors (math mode 4).  x_bf16: x is bf16 NHWC (Cin % 16 == 0, ldx % 8 == 0), w is the bf16 chunk layout
+   * [ceil(K/16)][Ntot][16] of dfl_pack_job.split = 2; the patch-resident kernels of csrc/convp_bf16.hip run.
+   * y_bf16: y, add and stat_other are bf16 (values are rounded once, statistics are taken from the rounded values).
+   * The direct small-K kernels (Cin <= 4: the network's first layer) take x_bf16 = 0, y_bf16 = 1. */
+  int32_t x_bf16, y_bf16;
 } dfl_conv_args;
 
 int dfl_conv2d(const dfl_conv_args* a, dfl_stream_t stream);
@@ -119,6 +127,9 @@ typedef struct {
   int32_t Hout, Wout, Cm, ldd;
   int32_t splits;
   int32_t d_split;       /* d is a split tensor (see dfl_conv_args.x_split); math mode 1 fast path only */
+  int32_t g_bf16, d_bf16;/* g / d are bf16 tensors (math mode 4; csrc/wgradp_bf16.hip when both are; the direct small-K
+                            kernels take g_bf16 = 0, d_bf16 = 1) */
+  int32_t reserved;
 } dfl_wgrad_args;
 
 int dfl_conv2d_wgrad(const dfl_wgrad_args* a, dfl_stream_t stream);
@@ -144,7 +155,9 @@ typedef struct {
   float* dst;            /* ceil(K/4) * Ntot * 4 floats */
   int32_t A, B, C;
   int32_t kind, flip;
-  int32_t split;         /* 1: write split quads (4 hi bf16 | 4 lo bf16) instead of 4 floats (dfl_conv_args.w_split) */
+  int32_t split;         /* 1: write split quads (4 hi bf16 | 4 lo bf16) instead of 4 floats (dfl_conv_args.w_split);
+                            2: bf16 chunk layout w[(k/16)*Ntot*16 + n*16 + k%16] (K rounded up to 16 with zeros): one MFMA B
+                            fragment of 32 columns is 1 KiB contiguous; dst holds ceil(K/16)*Ntot*16 bf16 */
 } dfl_pack_job;
 
 /* jobs: DEVICE pointer to njobs dfl_pack_job records; max_elems = max over jobs of A*B*C. */
@@ -189,6 +202,7 @@ typedef struct {
   float* partials;
   int64_t M;
   int32_t C, lda, ldb, nblocks;
+  int32_t bf16, reserved;   /* bf16 = 1: a and b are bf16 tensors */
 } dfl_colstats_args;
 int dfl_colstats(const dfl_colstats_args* a, dfl_stream_t stream);
 
@@ -214,6 +228,7 @@ typedef struct {
   int64_t M;
   int32_t C, lddy, ldr, ldo, nblocks;
   int32_t split_out;      /* 1: dpre is written as a split tensor (needs C % 4 == 0, ldo % 4 == 0, 16-byte alignment) */
+  int32_t bf16, reserved; /* bf16 = 1: dy, r and dpre are bf16 tensors (C % 8 == 0, ld % 8 == 0); the sums are of the rounded dpre */
 } dfl_bn_relu_bwd_args;
 int dfl_bn_relu_bwd_apply(const dfl_bn_relu_bwd_args* a, dfl_stream_t stream);
 
@@ -247,7 +262,7 @@ typedef struct {
   int32_t ldx, xH, xW, xoy, xox;/* source image dims and window origin */
   int32_t ldy, yH, yW, yoy, yox;
   int32_t accumulate;
-  int32_t reserved;
+  int32_t bf16;                 /* 1: x and y are bf16 tensors (C % 8 == 0, ld % 8 == 0) */
 } dfl_affine_copy_args;
 int dfl_affine_copy(const dfl_affine_copy_args* a, dfl_stream_t stream);
 
@@ -256,7 +271,7 @@ typedef struct {
   const float* x; float* y;     /* fwd: x -> y.  bwd: x = saved input, y = dy (read), dx accumulated */
   float* dx;
   int32_t N, H, W, C, ldx, ldy, lddx;   /* H, W: input size; output is floor(H/2) x floor(W/2) */
-  int32_t reserved;
+  int32_t bf16;                          /* 1: x, y and dx are bf16 tensors (C % 8 == 0, ld % 8 == 0) */
 } dfl_pool_args;
 int dfl_maxpool2x2_fwd(const dfl_pool_args* a, dfl_stream_t stream);
 int dfl_maxpool2x2_bwd(const dfl_pool_args* a, dfl_stream_t stream);
@@ -277,7 +292,7 @@ typedef struct {
   int32_t N, H, W, F, ldx;
   int32_t NC, NM, L;
   int32_t softmax;
-  int32_t reserved;
+  int32_t x_bf16;         /* 1: x is a bf16 tensor (F % 8 == 0, ldx % 8 == 0); seg / heat stay fp32 */
 } dfl_head_fwd_args;
 int dfl_head_fwd(const dfl_head_fwd_args* a, dfl_stream_t stream);
 
@@ -296,7 +311,7 @@ typedef struct {
   int32_t NC, NM, L;
   int32_t softmax;
   int32_t scratch_ld;     /* >= dfl_head_scratch_ld(F) */
-  int32_t reserved;
+  int32_t x_bf16;         /* 1: x and dx are bf16 tensors; the scratch rows stay fp32 */
 } dfl_head_bwd_args;
 int dfl_head_bwd(const dfl_head_bwd_args* a, dfl_stream_t stream);
 /* scratch row layout for F features: [0, Fc) cat(x, logits) with Fc = roundup4(F+NC_MAX) ; then dlogits (8),
@@ -413,6 +428,11 @@ int dfl_hard_dice(const unsigned char* est, const unsigned char* gt, int64_t pix
  *   3 "bf16"    plain bf16 products (operands rounded to bf16, fp32 accumulation, fp32 tensors): 2^-9 per product; the
  *               arithmetic BASELINE configs[1] names.  NOT inside the 1e-4 forward bar (measured ~1e-2); validated by
  *               training quality (tests/test_gpu_unet.py).
+ *   4 "bf16s"   bf16 STORAGE (BASELINE configs[1] as named): activations, activation gradients and the GEMM copies of the
+ *               weights live in HBM as bf16; products bf16, accumulation / BatchNorm statistics / losses / master weights /
+ *               weight gradients fp32.  The mode is a property of the recorded program (the caller sets the *_bf16 flags
+ *               of the argument blocks and allocates bf16 tensors); entry points look at the flags, not at the mode.
+ *               Same validation as mode 3 (training quality, label agreement).
  * Process-wide; initial value from the environment variable DFL_MATH, else DFL_MATH_DEFAULT.
  * ------------------------------------------------------------------------------------------------------------ */
 #define DFL_MATH_DEFAULT 0

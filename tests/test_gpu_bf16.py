@@ -1,0 +1,463 @@
+"""Math mode 4, "bf16 storage" (BASELINE configs[1] as named: bf16 activations / weights in HBM, fp32 accumulate, BatchNorm
+statistics, losses and master weights): the patch-resident kernels of csrc/convp_bf16.hip / wgradp_bf16.hip and the bf16
+variants of the streaming kernels through the C ABI against fp64 PyTorch on the SAME bf16-rounded operands, then the whole
+network against the fp64 oracle.  pytest -m gpu.
+
+Bars.  Kernel level: operands are exact bf16 values, products are exact in fp32, so a result differs from the fp64 one
+only by fp32 accumulation order (1e-5 relative to sum |x||w|) and by its final rounding to bf16 (2^-9 relative): 2^-8 of
+the value + the accumulation term; fp32 outputs (weight gradients, statistics) 2e-5.  Network level: the mode is outside
+the 1e-4 forward bar by construction (as mode 3); it is held to the noise-floor gradient bars of tests/noise_floor.py at
+its own measured convolution error, to label agreement outside the margin implied by its forward deviation, and -- the
+north-star quality bar -- to the reference's hard Dice at a plateau (tests/test_gpu_unet.py::test_plateau_dice...)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import dfl_amd
+from dfl_amd import _native as nat
+from conftest import PAPER_CFGS
+from oracle import ref_cpu as R
+import noise_floor as NF
+from test_gpu_unet import oracle64, oracle_run, label_mask
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+BF = torch.bfloat16
+
+
+@pytest.fixture(autouse=True)
+def _mode4():
+    lib = nat.lib()
+    prev = lib.dfl_get_math_mode()
+    nat.check(lib.dfl_set_math_mode(4), 'dfl_set_math_mode')
+    yield
+    nat.check(lib.dfl_set_math_mode(prev), 'dfl_set_math_mode')
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def rb(t):
+    """Round to bf16 and back: the values the kernels see."""
+    return t.to(BF).float()
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def pack16(w, kind, flip=0):
+    """dfl_pack_weights with split = 2: parameter [A][B][KH][KW] -> bf16 chunk layout [K/16][N][16]."""
+    lib = nat.lib()
+    src = w.to(DEV).contiguous()
+    A, B, KH, KW = w.shape
+    Cc = KH * KW
+    K = {1: Cc * B, 2: Cc * A, 3: A}[kind]
+    N = {1: A, 2: B, 3: Cc * B}[kind]
+    dst = torch.full(((K + 15) // 16 * N * 16,), float('nan'), device=DEV, dtype=BF)
+    job = nat.PackJob(src=src.data_ptr(), dst=dst.data_ptr(), A=A, B=B, C=Cc, kind=kind, flip=flip, split=2)
+    jobs = torch.from_numpy(np.frombuffer(bytes(job), dtype=np.uint8).copy()).to(DEV)
+    nat.check(lib.dfl_pack_weights(jobs.data_ptr(), 1, A * B * Cc, stream()))
+    torch.cuda.synchronize()
+    return dst
+
+
+def test_pack_bf16_chunk_layout():
+    g = torch.Generator().manual_seed(1)
+    for (A, B, KK, kind, flip) in ((32, 16, 3, 1, 0), (32, 16, 3, 2, 1), (64, 32, 1, 1, 0), (48, 16, 2, 3, 0), (16, 32, 2, 1, 0)):
+        w = torch.randn(A, B, KK, KK, generator=g)
+        Cc = KK * KK
+        wn = w.reshape(A, B, Cc).numpy()
+        if kind == 1:
+            W = wn.transpose(2, 1, 0).reshape(Cc * B, A)
+        elif kind == 2:
+            W = wn[:, :, ::-1].transpose(2, 0, 1).reshape(Cc * A, B) if flip else wn.transpose(2, 0, 1).reshape(Cc * A, B)
+        else:
+            W = wn.transpose(0, 2, 1).reshape(A, Cc * B)
+        K, N = W.shape
+        Kc = (K + 15) // 16
+        ref = np.zeros((Kc * 16, N), dtype=np.float32)
+        ref[:K] = W
+        ref = torch.from_numpy(ref.reshape(Kc, 16, N).transpose(0, 2, 1).reshape(-1).copy()).to(BF)
+        got = pack16(w, kind, flip).cpu()
+        assert torch.equal(got, ref), (A, B, KK, kind, flip)
+
+
+def conv_bf16(x, wp, Ntot, KH, KW, stride, pad, Hout, Wout, bias=None, in_aff=None, relu=0, add=None, add_aff=None,
+              y_init=None, accumulate=0, scatter=0, stats=False, stat_other=None, ldy=None, ldx_pad=0, force_splits=None):
+    """x: NCHW fp32 cpu tensor (bf16-representable) -> dfl_conv2d with bf16 tensors -> y NHWC fp32 cpu tensor (+ stats)."""
+    lib = nat.lib()
+    N, Cin, Hin, Win = x.shape
+    xh = nhwc(x)
+    if ldx_pad:
+        xh = F.pad(xh, (0, ldx_pad))
+    xd = xh.to(DEV).to(BF).contiguous()
+    Cout = Ntot // 4 if scatter else Ntot
+    ldy = Cout if ldy is None else ldy
+    if y_init is not None:
+        yd = nhwc(y_init).to(DEV).to(BF)
+        if ldy != Cout:
+            yd = F.pad(yd, (0, ldy - Cout))
+        yd = yd.contiguous()
+    else:
+        yd = torch.full((N, Hout, Wout, ldy), float('nan'), device=DEV, dtype=BF)
+    a = nat.ConvArgs()
+    keep = [xd, yd, wp]
+    a.x, a.w, a.y = xd.data_ptr(), wp.data_ptr(), yd.data_ptr()
+    a.x_bf16, a.y_bf16, a.w_split = 1, 1, 2
+    if bias is not None:
+        b = bias.to(DEV)
+        keep.append(b)
+        a.bias = b.data_ptr()
+    if in_aff is not None:
+        sc, sh = in_aff[0].to(DEV), in_aff[1].to(DEV)
+        keep += [sc, sh]
+        a.in_scale, a.in_shift = sc.data_ptr(), sh.data_ptr()
+    if add is not None:
+        ad = nhwc(add).to(DEV).to(BF).contiguous()
+        keep.append(ad)
+        a.add, a.ldadd = ad.data_ptr(), ad.shape[-1]
+        if add_aff is not None:
+            asc, ash = add_aff[0].to(DEV), add_aff[1].to(DEV)
+            keep += [asc, ash]
+            a.add_scale, a.add_shift = asc.data_ptr(), ash.data_ptr()
+    a.N, a.Hin, a.Win, a.Cin, a.ldx = N, Hin, Win, Cin, Cin + ldx_pad
+    a.KH, a.KW, a.stride, a.pad = KH, KW, stride, pad
+    a.Hout, a.Wout, a.Ntot, a.ldy = Hout, Wout, Ntot, ldy
+    a.relu, a.accumulate, a.scatter2x2 = relu, accumulate, scatter
+    sp = force_splits or nat.check(lib.dfl_conv_suggest_splits(C.addressof(a)), 'suggest')
+    if sp > 1:
+        Mrows = N * (Hin * Win if scatter else Hout * Wout)
+        kpart = torch.full((sp * Mrows * Ntot,), float('nan'), device=DEV)
+        keep.append(kpart)
+        a.splits, a.partial = sp, kpart.data_ptr()
+    part = None
+    if stats:
+        gm = nat.check(lib.dfl_conv_grid_m(C.addressof(a)), 'grid_m')
+        part = torch.zeros(gm, 2, Ntot, device=DEV)
+        a.stat_partials = part.data_ptr()
+        if stat_other is not None:
+            so = nhwc(stat_other).to(DEV).to(BF).contiguous()
+            keep.append(so)
+            a.stat_other, a.ldso = so.data_ptr(), so.shape[-1]
+    cfg = nat.check(lib.dfl_conv_config(C.addressof(a)), 'config')
+    assert cfg >= 16, 'the patch-resident kernels must take bf16 layers'
+    nat.check(lib.dfl_conv2d(C.addressof(a), stream()), 'dfl_conv2d')
+    torch.cuda.synchronize()
+    y = yd.float().cpu()[..., :Cout]
+    return (y, part.cpu().double().sum(0)) if stats else y
+
+
+def close_bf16(got, ref, what=''):
+    """got is a bf16-rounded result of ref (fp64): within 2^-8 of the value + 1e-5 of the largest magnitude."""
+    ref = ref.double()
+    err = (got.double() - ref).abs()
+    bound = ref.abs() * 2.0 ** -8 + 2e-5 * float(ref.abs().max())
+    bad = err > bound
+    assert not bool(bad.any()), '%s: %d of %d elements off; worst |err| %.3e at value %.3e' % (
+        what, int(bad.sum()), bad.numel(), float(err.max()), float(ref.flatten()[err.argmax()]))
+
+
+BCASES = [
+    # N, Cin, Cout, H, W, K, stride, pad
+    (2, 16, 16, 12, 12, 3, 1, 1),      # the smallest channel count of the mode
+    (1, 32, 32, 24, 20, 3, 1, 1),
+    (3, 64, 64, 13, 9, 3, 1, 1),       # odd sizes: ragged patches
+    (2, 64, 128, 17, 11, 3, 1, 1),
+    (2, 32, 16, 10, 10, 3, 1, 0),      # valid conv
+    (2, 32, 64, 8, 8, 1, 1, 0),        # 1x1
+    (2, 16, 32, 12, 10, 2, 2, 0),      # 2x2 stride 2
+    (2, 32, 32, 7, 9, 2, 2, 0),        # 2x2 stride 2, odd input
+    (16, 256, 256, 6, 6, 3, 1, 1),     # deepest level shape: several images per patch, K slices
+    (4, 512, 256, 12, 12, 3, 1, 1),    # decoder shape, K slices
+    (16, 32, 32, 48, 48, 3, 1, 1),     # wide level, 32 columns
+    (4, 64, 64, 96, 96, 3, 1, 1),      # 64 columns
+    (4, 128, 128, 48, 48, 3, 1, 1),    # 128 columns
+    (2, 128, 320, 24, 24, 3, 1, 1),    # columns not a multiple of the tile
+]
+
+
+@pytest.mark.parametrize('case', BCASES)
+def test_convp_plain(case):
+    N, Cin, Cout, H, W, K, stride, pad = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = rb(torch.randn(N, Cin, H, W, generator=g))
+    w = rb(torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    Ho, Wo = (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1
+    y, st = conv_bf16(x, pack16(w, 1), Cout, K, K, stride, pad, Ho, Wo, bias=b, relu=1, stats=True)
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=pad))
+    close_bf16(y, nhwc(ref), str(case))
+    # statistics are those of the STORED values
+    yd = y.double().reshape(-1, Cout)
+    np.testing.assert_allclose(st[0].numpy(), yd.sum(0).numpy(), rtol=2e-5, atol=2e-5 * float(yd.abs().sum(0).max()))
+    np.testing.assert_allclose(st[1].numpy(), (yd * yd).sum(0).numpy(), rtol=2e-5, atol=2e-5 * float((yd * yd).sum(0).max()))
+
+
+@pytest.mark.parametrize('case', [(2, 32, 32, 20, 20, 3), (2, 64, 128, 12, 12, 3), (4, 256, 256, 6, 6, 3), (2, 128, 64, 9, 7, 1)])
+@pytest.mark.parametrize('splits', [None, 2])
+def test_convp_affine_residual_epilogue(case, splits):
+    """BatchNorm affine on load with zero padding AFTER it, '+ BN(other)' residual sum, accumulate, statistics against a
+    partner tensor -- the forward block epilogue (unet.py:229-231) and the fused backward sums -- also through K slices."""
+    N, Cin, Cout, H, W, K = case
+    if splits and Cin // 16 < 2 * splits:
+        pytest.skip('too few channel blocks to slice')
+    pad = K // 2
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    x = rb(torch.randn(N, Cin, H, W, generator=g))
+    w = rb(torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    other = rb(torch.randn(N, Cout, H, W, generator=g))
+    asc, ash = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.2
+    y0 = rb(torch.randn(N, Cout, H, W, generator=g))
+    partner = rb(torch.randn(N, Cout, H, W, generator=g))
+    xa = rb(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))           # the kernel rounds the affine result to bf16 once
+    ref = F.conv2d(xa.double(), w.double(), b.double(), padding=pad)    # padding stays zero: it is applied after the affine
+    ref = ref + other.double() * asc.double().view(1, -1, 1, 1) + ash.double().view(1, -1, 1, 1) + y0.double()
+    y, st = conv_bf16(x, pack16(w, 1), Cout, K, K, 1, pad, H, W, bias=b, in_aff=(sc, sh), add=other, add_aff=(asc, ash),
+                      y_init=y0, accumulate=1, stats=True, stat_other=partner, force_splits=splits)
+    close_bf16(y, nhwc(ref), str(case))
+    yd = y.double().reshape(-1, Cout)
+    pd = nhwc(partner).double().reshape(-1, Cout)
+    np.testing.assert_allclose(st[1].numpy(), (yd * pd).sum(0).numpy(), rtol=2e-5, atol=2e-5 * float((yd * pd).abs().sum(0).max()))
+
+
+def test_convp_transposed_scatter_and_data_gradients():
+    """ConvTranspose2d(k2,s2) as a 1x1 gather with the 2x2-scatter epilogue into the channel half of a wider buffer
+    (unet.py:240,255-257), the data gradient of a stride-1 conv (flipped / transposed weights) and of a 2x2/s2 conv
+    (scatter form, accumulating)."""
+    g = torch.Generator().manual_seed(9)
+    N, Ci, Co, H, W = 2, 64, 32, 10, 7
+    x = rb(torch.randn(N, Ci, H, W, generator=g))
+    w = rb(torch.randn(Ci, Co, 2, 2, generator=g) / (4 * Ci) ** 0.5)
+    b = torch.randn(Co, generator=g)
+    y = conv_bf16(x, pack16(w, 3), 4 * Co, 1, 1, 1, 0, 2 * H, 2 * W, bias=b, scatter=1, ldy=2 * Co)
+    close_bf16(y, nhwc(F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2)), 'convT')
+    # data gradient of a 3x3 / stride 1 / pad 1 conv
+    Cin, Cout = 32, 64
+    dy = rb(torch.randn(N, Cout, 12, 9, generator=g))
+    w3 = rb(torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cout) ** 0.5)
+    dx = conv_bf16(dy, pack16(w3, 2, flip=1), Cin, 3, 3, 1, 1, 12, 9)
+    close_bf16(dx, nhwc(F.conv_transpose2d(dy.double(), w3.double(), padding=1)), 'dgrad 3x3')
+    # data gradient of conv 2x2 / stride 2 (scatter form), accumulated onto an existing gradient
+    dn = rb(torch.randn(N, 32, 6, 5, generator=g))
+    w2 = rb(torch.randn(32, 32, 2, 2, generator=g) / 128 ** 0.5)
+    d0 = rb(torch.randn(N, 32, 12, 10, generator=g))
+    dd = conv_bf16(dn, pack16(w2, 3), 4 * 32, 1, 1, 1, 0, 12, 10, scatter=1, y_init=d0, accumulate=1)
+    close_bf16(dd, nhwc(d0.double() + F.conv_transpose2d(dn.double(), w2.double(), stride=2)), 'dgrad 2x2 s2')
+    # data gradient of the transposed conv = conv 2x2 / stride 2 over dy
+    dyT = rb(torch.randn(N, Co, 2 * H, 2 * W, generator=g))
+    du = conv_bf16(dyT, pack16(w, 1), Ci, 2, 2, 2, 0, H, W)
+    ref_du = torch.einsum('nchawb,kcab->nkhw', dyT.double().reshape(N, Co, H, 2, W, 2), w.double())
+    close_bf16(du, nhwc(ref_du), 'dgrad convT')
+
+
+def wgrad_bf16(gx, d, KH, KW, stride, pad, Hout, Wout, in_aff=None, force_splits=None):
+    """gx: gathered tensor NCHW, d: dense NCHW (both bf16-representable) -> dw [Cm][Cg][KH][KW] fp32 (cpu)."""
+    lib = nat.lib()
+    N, Cg, Hin, Win = gx.shape
+    Cm = d.shape[1]
+    gd = nhwc(gx).to(DEV).to(BF).contiguous()
+    dd = nhwc(d).to(DEV).to(BF).contiguous()
+    dw = torch.full((Cm, Cg, KH, KW), float('nan'), device=DEV)
+    a = nat.WgradArgs()
+    keep = [gd, dd, dw]
+    a.g, a.d, a.dw = gd.data_ptr(), dd.data_ptr(), dw.data_ptr()
+    a.g_bf16, a.d_bf16 = 1, 1
+    if in_aff is not None:
+        sc, sh = in_aff[0].to(DEV), in_aff[1].to(DEV)
+        keep += [sc, sh]
+        a.in_scale, a.in_shift = sc.data_ptr(), sh.data_ptr()
+    a.N, a.Hin, a.Win, a.Cg, a.ldg = N, Hin, Win, Cg, Cg
+    a.KH, a.KW, a.stride, a.pad = KH, KW, stride, pad
+    a.Hout, a.Wout, a.Cm, a.ldd = Hout, Wout, Cm, Cm
+    a.splits = 1
+    s = force_splits or nat.check(lib.dfl_wgrad_suggest_splits(C.addressof(a)), 'suggest')
+    a.splits = s
+    n = Cm * Cg * KH * KW
+    if s > 1:
+        part = torch.full((s * n,), float('nan'), device=DEV)
+        keep.append(part)
+        a.partial = part.data_ptr()
+    assert nat.check(lib.dfl_wgrad_config(C.addressof(a)), 'config') >= 16
+    nat.check(lib.dfl_conv2d_wgrad(C.addressof(a), stream()), 'dfl_conv2d_wgrad')
+    if s > 1:
+        nat.check(lib.dfl_sum_partials(part.data_ptr(), dw.data_ptr(), n, s, KH * KW, stream()), 'dfl_sum_partials')
+    torch.cuda.synchronize()
+    return dw.cpu()
+
+
+WCASES = [
+    # N, Cg, Cm, H, W, K, stride, pad
+    (2, 32, 32, 24, 20, 3, 1, 1),
+    (3, 16, 16, 12, 12, 3, 1, 1),
+    (2, 64, 32, 13, 9, 3, 1, 1),       # ragged patches, two tile pairs
+    (2, 32, 64, 17, 11, 3, 1, 1),
+    (4, 128, 128, 12, 12, 3, 1, 1),    # several workgroup tiles
+    (16, 256, 128, 6, 6, 3, 1, 1),     # several images per patch
+    (2, 64, 64, 8, 8, 1, 1, 0),        # 1x1
+    (2, 32, 64, 12, 10, 2, 2, 0),      # 2x2 stride 2
+    (2, 32, 32, 96, 96, 3, 1, 1),      # wide image: row patches, many pixel slices
+    (2, 64, 64, 40, 300, 3, 1, 1),     # rows longer than a patch
+]
+
+
+@pytest.mark.parametrize('case', WCASES)
+def test_wgradp(case):
+    N, Cg, Cm, H, W, K, stride, pad = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = rb(torch.randn(N, Cg, H, W, generator=g))
+    Ho, Wo = (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1
+    d = rb(torch.randn(N, Cm, Ho, Wo, generator=g))
+    dw = wgrad_bf16(x, d, K, K, stride, pad, Ho, Wo)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (Cm, Cg, K, K), d.double(), stride=stride, padding=pad)
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(dw.numpy(), ref.numpy(), rtol=2e-5, atol=3e-5 * scale)
+    if K == 3:      # one slot (direct torch-order store) and an explicit slice count
+        for s in (1, 3):
+            if Cm > 32 and Cg > 32 or s > 1:
+                dws = wgrad_bf16(x, d, K, K, stride, pad, Ho, Wo, force_splits=s)
+                np.testing.assert_allclose(dws.numpy(), ref.numpy(), rtol=2e-5, atol=3e-5 * scale)
+
+
+def test_wgradp_affine_on_load():
+    g = torch.Generator().manual_seed(4)
+    N, Cg, Cm, H, W = 2, 64, 32, 14, 10
+    x = rb(torch.randn(N, Cg, H, W, generator=g))
+    d = rb(torch.randn(N, Cm, H, W, generator=g))
+    sc, sh = torch.rand(Cg, generator=g) + 0.5, torch.randn(Cg, generator=g) * 0.3
+    xa = rb(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    dw = wgrad_bf16(x, d, 3, 3, 1, 1, H, W, in_aff=(sc, sh))
+    ref = torch.nn.grad.conv2d_weight(xa.double(), (Cm, Cg, 3, 3), d.double(), padding=1)
+    np.testing.assert_allclose(dw.numpy(), ref.numpy(), rtol=2e-5, atol=3e-5 * float(ref.abs().max()))
+
+
+def test_streaming_kernels_bf16():
+    """dfl_bn_relu_bwd_apply, dfl_colstats, dfl_affine_copy, max-pool forward / backward with bf16 tensors."""
+    lib = nat.lib()
+    g = torch.Generator().manual_seed(11)
+    M, Cc = 1000, 48
+    dy = rb(torch.randn(M, Cc, generator=g))
+    r = rb(torch.relu(torch.randn(M, Cc, generator=g)))
+    coef = torch.randn(3, Cc, generator=g)
+    dyd, rd = dy.to(DEV).to(BF), r.to(DEV).to(BF)
+    dpre = torch.empty(M, Cc, device=DEV, dtype=BF)
+    nb = lib.dfl_rowblock_count(M, Cc)
+    part = torch.zeros(nb, Cc, device=DEV)
+    cd = coef.to(DEV)
+    nat.call('dfl_bn_relu_bwd_apply', nat.BnReluBwdArgs(dy=dyd.data_ptr(), r=rd.data_ptr(), coef=cd.data_ptr(), dpre=dpre.data_ptr(),
+                                                        partials=part.data_ptr(), M=M, C=Cc, lddy=Cc, ldr=Cc, ldo=Cc, nblocks=nb,
+                                                        bf16=1), stream())
+    ref = torch.where(r > 0, coef[0] * dy + coef[1] * r + coef[2], torch.zeros(()))
+    close_bf16(dpre.float().cpu(), ref, 'bn_relu_bwd')
+    np.testing.assert_allclose(part.sum(0).cpu().numpy(), dpre.float().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-4)
+    parts = torch.zeros(nb, 2, Cc, device=DEV)
+    nat.call('dfl_colstats', nat.ColstatsArgs(a=dyd.data_ptr(), b=rd.data_ptr(), partials=parts.data_ptr(), M=M, C=Cc, lda=Cc, ldb=Cc,
+                                             nblocks=nb, bf16=1), stream())
+    s = parts.sum(0).cpu().double()
+    np.testing.assert_allclose(s[0].numpy(), dy.double().sum(0).numpy(), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(s[1].numpy(), (dy.double() * r.double()).sum(0).numpy(), rtol=1e-5, atol=1e-4)
+    # affine copy with crop window, then max-pool forward / backward
+    N, H, W = 2, 10, 8
+    x = rb(torch.randn(N, H, W, Cc, generator=g))
+    xd = x.to(DEV).to(BF)
+    sc, sh = (torch.rand(Cc, generator=g) + 0.5).to(DEV), torch.randn(Cc, generator=g).to(DEV)
+    y = torch.zeros(N, 6, 4, Cc, device=DEV, dtype=BF)
+    nat.call('dfl_affine_copy', nat.AffineCopyArgs(x=xd.data_ptr(), y=y.data_ptr(), scale=sc.data_ptr(), shift=sh.data_ptr(), N=N, H=6,
+                                                   W=4, C=Cc, ldx=Cc, xH=H, xW=W, xoy=2, xox=3, ldy=Cc, yH=6, yW=4, bf16=1), stream())
+    close_bf16(y.float().cpu(), x[:, 2:8, 3:7] * sc.cpu() + sh.cpu(), 'affine_copy')
+    p = torch.empty(N, H // 2, W // 2, Cc, device=DEV, dtype=BF)
+    nat.call('dfl_maxpool2x2_fwd', nat.PoolArgs(x=xd.data_ptr(), y=p.data_ptr(), N=N, H=H, W=W, C=Cc, ldx=Cc, ldy=Cc, bf16=1), stream())
+    pref = F.max_pool2d(x.permute(0, 3, 1, 2), 2)
+    assert torch.equal(p.float().cpu(), pref.permute(0, 2, 3, 1))
+    gp = rb(torch.randn(N, H // 2, W // 2, Cc, generator=g))
+    gpd = gp.to(DEV).to(BF)
+    dx = torch.zeros(N, H, W, Cc, device=DEV, dtype=BF)
+    nat.call('dfl_maxpool2x2_bwd', nat.PoolArgs(x=xd.data_ptr(), y=gpd.data_ptr(), dx=dx.data_ptr(), N=N, H=H, W=W, C=Cc, ldx=Cc, ldy=Cc,
+                                                lddx=Cc, bf16=1), stream())
+    xt = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    F.max_pool2d(xt, 2).backward(gp.permute(0, 3, 1, 2))
+    assert torch.equal(dx.float().cpu(), xt.grad.permute(0, 2, 3, 1))
+
+
+# ---------------------------------------------------------------------------------------------------- whole network
+def _eps4():
+    return NF.conv_rel_error('bf16s')
+
+
+@pytest.mark.parametrize('cfgname', ['paper_sc_l14', 'paper_mp_l0'])
+def test_network_bf16_storage_against_fp64_oracle(cfgname):
+    """Paper presets, batch 2: forward deviation at the bf16 level, labels identical outside the margin that deviation
+    implies, every gradient tensor inside its noise-floor bar at the mode's own measured convolution error."""
+    seed, cfg = PAPER_CFGS[cfgname]
+    torch.manual_seed(seed)
+    onet = R.OracleUNet(**cfg)
+    net = dfl_amd.UNet(**cfg)
+    net.load_state_dict(onet.state_dict())
+    net = net.to(DEV).train()
+    gen = torch.Generator().manual_seed(seed + 1)
+    x = torch.randn(2, 1, 192, 192, generator=gen)
+    lab = torch.randint(0, 7, (2, 184, 184), generator=gen)
+    tseg = R.one_hot_masks(lab, 7)
+    nl = cfg['num_lands']
+    theat = torch.rand(2, 14, 184, 184, generator=gen) * 0.02 if nl > 0 else None
+    out = net(x.to(DEV))
+    seg = out[0] if nl > 0 else out
+    if nl > 0:
+        loss = dfl_amd.DiceAndHeatMapLoss2D(skip_bg=False, heatmap_wgt=0.5)(
+            (dfl_amd.center_crop(seg, tseg.shape), dfl_amd.center_crop(out[1], theat.shape)), (tseg.to(DEV), theat.to(DEV)))
+    else:
+        loss = dfl_amd.DiceLoss2D(skip_bg=False)(dfl_amd.center_crop(seg, tseg.shape), tseg.to(DEV))
+    loss.backward()
+    plan = [p for ps in net._plans.values() for p in ps][0]
+    assert plan.bf16 and plan.feat.t.dtype == torch.bfloat16, 'the recorded program must hold bf16 activations'
+    torch.set_num_threads(max(torch.get_num_threads(), 32))
+    gf = NF.GradientFloor(oracle64(cfg, onet.state_dict()), oracle_run(x, tseg, theat), seeds=(1, 2, 3, 4))
+    dev = float((seg.detach().double().cpu() - gf.out).abs().max())
+    assert dev < 5e-2, 'soft-max deviation %.3e from fp64' % dev
+    assert dev > 1e-5, 'the bf16 storage mode does not seem to be in effect'
+    top2 = gf.out.topk(2, dim=1)[0]
+    sure = (top2[:, 0] - top2[:, 1]) > 2.5 * dev
+    assert float(sure.float().mean()) > 0.5
+    assert bool((seg.detach().argmax(1).cpu() == gf.out.argmax(1))[sure].all())
+    worst, whole, eps_eff = gf.check({k: p.grad for k, p in net.named_parameters()}, seg, _eps4(), cfgname + ' bf16s ')
+    print('%s bf16 storage: conv noise %.2e, whole-gradient error %.3e, worst per-tensor error / bar %.2f' % (cfgname, eps_eff, whole, worst))
+
+
+def test_eval_and_inference_graph_bf16_storage():
+    """Eval-mode forward (running statistics) and its hipGraph replay in the bf16 storage mode."""
+    seed, cfg = PAPER_CFGS['paper_sc_l14']
+    torch.manual_seed(seed)
+    net = dfl_amd.UNet(**cfg).to(DEV)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+    net.eval()
+    x = torch.randn(1, 1, 192, 192, device=DEV)
+    lib = nat.lib()
+    with torch.no_grad():
+        s4, h4 = net(x)
+        s4b, h4b = net(x)
+        assert torch.equal(s4, s4b) and torch.equal(h4, h4b)
+        net.use_graphs = False
+        s4p, h4p = net(x)
+        net.use_graphs = True
+        assert torch.equal(s4, s4p) and torch.equal(h4, h4p)
+        nat.check(lib.dfl_set_math_mode(0), 'mode')
+        s0, h0 = net(x)
+        nat.check(lib.dfl_set_math_mode(4), 'mode')
+    assert float((s0 - s4).abs().max()) < 5e-2 and float((h0 - h4).abs().max()) < 5e-2 * float(h0.abs().max())
+    assert float((s4.sum(1) - 1).abs().max()) < 1e-5
+
+
+def test_small_channel_counts_are_refused():
+    net = dfl_amd.UNet(n_classes=3, depth=2, wf=3, padding=True, batch_norm=True).to(DEV)
+    with pytest.raises(RuntimeError, match='multiples of 16'):
+        net(torch.zeros(1, 1, 16, 16, device=DEV))

