@@ -529,10 +529,10 @@ __global__ void __launch_bounds__(256) bn_relu_bwd_bf16_kernel(const dfl_bn_relu
   int64_t r1 = r0 + rows_per_block;
   if (r1 > a.M) r1 = a.M;
   if (cok) {
-    for (int64_t r = r0 + uy; r < r1; r += RY) {
+    auto one = [&](const bu32x4 wdy, const bu32x4 wr, int64_t r) {
       float dy[8], rv[8], o[8];
-      unpack8(ld8(a.dy, r * a.lddy + c), dy);
-      unpack8(ld8(a.r, r * a.ldr + c), rv);
+      unpack8(wdy, dy);
+      unpack8(wr, rv);
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = rv[j] > 0.f ? fmaf(cA[j], dy[j], fmaf(cB[j], rv[j], cC[j])) : 0.f;
       const bu32x4 w = pack8(o);
@@ -540,7 +540,19 @@ __global__ void __launch_bounds__(256) bn_relu_bwd_bf16_kernel(const dfl_bn_relu
       unpack8(w, o);
 #pragma unroll
       for (int j = 0; j < 8; ++j) s[j] += o[j];
+    };
+    int64_t r = r0 + uy;
+    for (; r + 3 * RY < r1; r += 4 * RY) {     // four rows in flight per thread
+      const bu32x4 d0 = ld8(a.dy, r * a.lddy + c), d1 = ld8(a.dy, (r + RY) * a.lddy + c);
+      const bu32x4 d2 = ld8(a.dy, (r + 2 * RY) * a.lddy + c), d3 = ld8(a.dy, (r + 3 * RY) * a.lddy + c);
+      const bu32x4 q0 = ld8(a.r, r * a.ldr + c), q1 = ld8(a.r, (r + RY) * a.ldr + c);
+      const bu32x4 q2 = ld8(a.r, (r + 2 * RY) * a.ldr + c), q3 = ld8(a.r, (r + 3 * RY) * a.ldr + c);
+      one(d0, q0, r);
+      one(d1, q1, r + RY);
+      one(d2, q2, r + 2 * RY);
+      one(d3, q3, r + 3 * RY);
     }
+    for (; r < r1; r += RY) one(ld8(a.dy, r * a.lddy + c), ld8(a.r, r * a.ldr + c), r);
   }
   if (a.partials == nullptr) return;
   reduce_units8(red, s, ux, uy, UX, RY, cok, a.partials + (int64_t)blockIdx.x * C, c);

@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(256, (TM * TN >= 6) ? 1 : 2) convp_kernel(cons
       int iy = rem / p.IW, ix = rem - iy * p.IW;
       const int ybase = gy0 * a.stride - a.pad, xbase = gx0 * a.stride - a.pad;
       const uint32_t cbyte = (uint32_t)((c0 + cg * 8) * 2);
-      constexpr int U = 4;                         // loads in flight per thread
+      constexpr int U = 8;                         // loads in flight per thread
       for (; pix < npix; pix += U * dpix) {
         pu32x4 v[U];
         bool ok[U];
@@ -221,102 +221,159 @@ __global__ void __launch_bounds__(256, (TM * TN >= 6) ? 1 : 2) convp_kernel(cons
 
   // ==================================================================== epilogue
   const bool sliced = p.splits > 1;
-  const bool do_stats = a.stat_partials != nullptr && !sliced;
-  const bool scat = a.scatter2x2 != 0;
-  const __bf16* addp = reinterpret_cast<const __bf16*>(a.add);
-  const __bf16* sop = reinterpret_cast<const __bf16*>(a.stat_other);
-  __bf16* yp = reinterpret_cast<__bf16*>(a.y);
-  int cn[TN], cco[TN], cab[TN];
-  bool cok[TN];
-  float cbias[TN], casc[TN], cash[TN], s1[TN], s2[TN];
+  if (sliced) {
+    // K slices: raw fp32 partial sums, row = GEMM row, 128-byte runs per accumulator row; convp_finish_kernel does the rest
+    float* part = a.partial + (int64_t)blockIdx.z * p.Mtot * a.Ntot;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + (wn * TN + j) * 32 + li;
-    cok[j] = n < a.Ntot;
-    cn[j] = cok[j] ? n : 0;
-    cab[j] = scat ? cn[j] / p.Cout : 0;
-    cco[j] = scat ? cn[j] - cab[j] * p.Cout : cn[j];
-    cbias[j] = (a.bias != nullptr) ? a.bias[cco[j]] : 0.f;
-    casc[j] = 1.f;
-    cash[j] = 0.f;
-    if (addp != nullptr && a.add_scale != nullptr) {
-      casc[j] = a.add_scale[cn[j]];
-      cash[j] = a.add_shift[cn[j]];
-    }
-    s1[j] = 0.f;
-    s2[j] = 0.f;
-  }
-  float* part = sliced ? a.partial + (int64_t)blockIdx.z * p.Mtot * a.Ntot : nullptr;
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+      for (int g = 0; g < 4; ++g) {
+        const int q = (wm * TM + i) * 32 + 8 * g + 4 * lh;
+        int img = q / PP;
+        int r = q - img * PP;
+        int py = r / p.PW, px = r - py * p.PW;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int q = (wm * TM + i) * 32 + 8 * g + 4 * lh;     // rows q .. q+3 <-> accumulator registers 4g .. 4g+3
-      int img = q / PP;
-      int r = q - img * PP;
-      int py = r / p.PW, px = r - py * p.PW;
+        for (int rr = 0; rr < 4; ++rr) {
+          const int n = img0 + img, gy = gy0 + py, gx = gx0 + px;
+          const bool rok = img < p.IPP && n < a.N && gy < p.Hg && gx < p.Wg;
+          const int64_t m = ((int64_t)n * p.Hg + gy) * p.Wg + gx;
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int n = img0 + img, gy = gy0 + py, gx = gx0 + px;
-        const bool rok = img < p.IPP && n < a.N && gy < p.Hg && gx < p.Wg;
-        const int64_t m = ((int64_t)n * p.Hg + gy) * p.Wg + gx;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const bool ok = rok && cok[j];
-          float v = acc[i][j][4 * g + rr];
-          if (sliced) {
-            if (ok) part[m * a.Ntot + cn[j]] = v;
-            continue;
+          for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wn * TN + j) * 32 + li;
+            if (rok && col < a.Ntot) part[m * a.Ntot + col] = acc[i][j][4 * g + rr];
           }
-          v += cbias[j];
-          if (a.relu) v = fmaxf(v, 0.f);
-          if (addp != nullptr) v += fmaf(ok ? ld_bf(addp + m * a.ldadd + cn[j]) : 0.f, casc[j], cash[j]);
-          const int64_t o = scat ? ((((int64_t)n * a.Hout + 2 * gy + (cab[j] >> 1)) * a.Wout + 2 * gx + (cab[j] & 1)) * a.ldy + cco[j])
-                                 : (m * a.ldy + cn[j]);
-          if (a.accumulate) v += ok ? ld_bf(yp + o) : 0.f;
-          const __bf16 hv = (__bf16)v;
-          if (ok) yp[o] = hv;
-          if (do_stats) {
-            const float vm = ok ? (float)hv : 0.f;
-            const float u = (sop != nullptr) ? (ok ? ld_bf(sop + m * a.ldso + cn[j]) : 0.f) : vm;
-            s1[j] += vm;
-            s2[j] = fmaf(vm, u, s2[j]);
+          if (++px == p.PW) {
+            px = 0;
+            if (++py == p.PH) {
+              py = 0;
+              ++img;
+            }
           }
         }
-        if (++px == p.PW) {
-          px = 0;
-          if (++py == p.PH) {
-            py = 0;
-            ++img;
-          }
+      }
+    }
+    return;
+  }
+
+  // One pass per tile row i of the waves: the WM x WN waves drop their 32 x (TN*32) accumulator tiles into LDS as a
+  // [WM*32 rows][BN columns] fp32 image (lane = column: 128-byte runs per row), then every thread takes 8 consecutive
+  // columns of a row -- bias, ReLU, + BN(other), accumulate, statistics on 8 values at a time, ONE 16-byte bf16 store (and
+  // 16-byte loads of the partner tensors) instead of eight 2-byte accesses per tensor.
+  constexpr int BN = WN * TN * 32;
+  constexpr int EP = BN + 4;                          // row pitch in floats (+4: rows 4 apart on different banks)
+  constexpr int UPR = BN / 8;                         // 8-column units per row
+  constexpr int RPS = 256 / UPR;                      // rows per step of the 256 threads
+  static_assert(256 % UPR == 0 && (WM * 32) % RPS == 0, "row phase mapping");
+  float* ep = reinterpret_cast<float*>(smem);
+  const bool do_stats = a.stat_partials != nullptr;
+  const bool scat = a.scatter2x2 != 0;
+  const unsigned short* addp = reinterpret_cast<const unsigned short*>(a.add);
+  const unsigned short* sop = reinterpret_cast<const unsigned short*>(a.stat_other);
+  unsigned short* yp = reinterpret_cast<unsigned short*>(a.y);
+  const int ucol = (tid % UPR) * 8;                   // this thread's 8 columns inside the workgroup's BN
+  const int urow = tid / UPR;
+  const int ncol = n0 + ucol;                         // first of its GEMM columns
+  const bool cok = ncol < a.Ntot;                     // (Ntot % 8 == 0: a unit is inside or outside as a whole)
+  const int cab = (scat && cok) ? ncol / p.Cout : 0;
+  const int cco = scat ? ncol - cab * p.Cout : ncol;
+  float cbias[8], casc[8], cash[8], s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    cbias[e] = (a.bias != nullptr && cok) ? a.bias[cco + e] : 0.f;
+    casc[e] = 1.f;
+    cash[e] = 0.f;
+    if (addp != nullptr && a.add_scale != nullptr && cok) {
+      casc[e] = a.add_scale[ncol + e];
+      cash[e] = a.add_shift[ncol + e];
+    }
+    s1[e] = 0.f;
+    s2[e] = 0.f;
+  }
+  auto unpack = [](const pu32x4 w, float* f) {
+    f[0] = bf_lo(w.x); f[1] = bf_hi(w.x); f[2] = bf_lo(w.y); f[3] = bf_hi(w.y);
+    f[4] = bf_lo(w.z); f[5] = bf_hi(w.z); f[6] = bf_lo(w.w); f[7] = bf_hi(w.w);
+  };
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    __syncthreads();                                  // the previous pass (or the k loop) is done with this LDS region
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        ep[(wm * 32 + mfma32_row(r, lane)) * EP + (wn * TN + j) * 32 + li] = acc[i][j][r];
+    __syncthreads();
+    for (int rl = urow; rl < WM * 32; rl += RPS) {    // row rl of the image = row (rl / 32) * TM*32 + i*32 + rl % 32 of the patch
+      const int q = ((rl >> 5) * TM + i) * 32 + (rl & 31);
+      const int img = q / PP;
+      const int rr = q - img * PP;
+      const int py = rr / p.PW, px = rr - py * p.PW;
+      const int n = img0 + img, gy = gy0 + py, gx = gx0 + px;
+      if (!(cok && img < p.IPP && n < a.N && gy < p.Hg && gx < p.Wg)) continue;
+      const int64_t m = ((int64_t)n * p.Hg + gy) * p.Wg + gx;
+      float v[8];
+      const float4 v0 = *reinterpret_cast<const float4*>(ep + rl * EP + ucol);
+      const float4 v1 = *reinterpret_cast<const float4*>(ep + rl * EP + ucol + 4);
+      v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[e] += cbias[e];
+        if (a.relu) v[e] = fmaxf(v[e], 0.f);
+      }
+      if (addp != nullptr) {
+        float o[8];
+        unpack(*reinterpret_cast<const pu32x4*>(addp + m * a.ldadd + ncol), o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += fmaf(o[e], casc[e], cash[e]);
+      }
+      const int64_t yo = scat ? ((((int64_t)n * a.Hout + 2 * gy + (cab >> 1)) * a.Wout + 2 * gx + (cab & 1)) * a.ldy + cco)
+                              : (m * a.ldy + ncol);
+      if (a.accumulate) {
+        float o[8];
+        unpack(*reinterpret_cast<const pu32x4*>(yp + yo), o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += o[e];
+      }
+      pu32x4 w;
+      w.x = pack_bf2(v[0], v[1]);
+      w.y = pack_bf2(v[2], v[3]);
+      w.z = pack_bf2(v[4], v[5]);
+      w.w = pack_bf2(v[6], v[7]);
+      *reinterpret_cast<pu32x4*>(yp + yo) = w;
+      if (do_stats) {
+        float vr[8], u[8];
+        unpack(w, vr);                                // statistics of the values as stored
+        if (sop != nullptr) {
+          unpack(*reinterpret_cast<const pu32x4*>(sop + m * a.ldso + ncol), u);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) u[e] = vr[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          s1[e] += vr[e];
+          s2[e] = fmaf(vr[e], u[e], s2[e]);
         }
       }
     }
   }
   if (!do_stats) return;
-  // per-column sums of the workgroup -> one row of stat_partials (rows = patches); the staging LDS is free by now
+  // per-column sums of the workgroup -> one row of stat_partials (rows = patches): threads of one column unit add up
+  // through LDS in a fixed order
   __syncthreads();
-  float* red = reinterpret_cast<float*>(smem);     // [WM][2][BN]
-  constexpr int BN = WN * TN * 32;
+  float* red = reinterpret_cast<float*>(smem);        // [RPS][2][BN]
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const float t1 = s1[j] + xor32(s1[j]);
-    const float t2 = s2[j] + xor32(s2[j]);
-    if (lh == 0) {
-      const int col = (wn * TN + j) * 32 + li;
-      red[(wm * 2 + 0) * BN + col] = t1;
-      red[(wm * 2 + 1) * BN + col] = t2;
-    }
+  for (int e = 0; e < 8; ++e) {
+    red[(urow * 2 + 0) * BN + ucol + e] = s1[e];
+    red[(urow * 2 + 1) * BN + ucol + e] = s2[e];
   }
   __syncthreads();
   for (int idx = tid; idx < 2 * BN; idx += 256) {
     const int which = idx / BN, col = idx - which * BN;
     const int n = n0 + col;
     if (n < a.Ntot) {
-      float s = 0.f;
-#pragma unroll
-      for (int w = 0; w < WM; ++w) s += red[(w * 2 + which) * BN + col];
-      a.stat_partials[((int64_t)blockIdx.x * 2 + which) * a.Ntot + n] = s;
+      float sum = 0.f;
+      for (int w = 0; w < RPS; ++w) sum += red[(w * 2 + which) * BN + col];
+      a.stat_partials[((int64_t)blockIdx.x * 2 + which) * a.Ntot + n] = sum;
     }
   }
 }
@@ -396,7 +453,8 @@ __global__ void __launch_bounds__(256) convp_finish_kernel(const ConvP p, int TX
 struct TileCfg { int WM, WN, TM, TN; };
 // value reported by dfl_conv_config for these kernels = 16 + index
 static const TileCfg kTiles[] = {{4, 1, 2, 1}, {4, 1, 1, 1}, {2, 2, 4, 1}, {2, 2, 3, 1}, {2, 2, 2, 1}, {1, 4, 2, 1},
-                                 {1, 4, 3, 1}, {1, 4, 4, 1}, {1, 4, 6, 1}, {1, 4, 9, 1}, {2, 2, 1, 1}, {1, 4, 1, 1}};
+                                 {1, 4, 3, 1}, {1, 4, 4, 1}, {1, 4, 6, 1}, {1, 4, 9, 1}, {2, 2, 1, 1}, {1, 4, 1, 1},
+                                 {4, 1, 3, 1}, {4, 1, 4, 1}, {2, 2, 6, 1}};
 constexpr int kNumTiles = (int)(sizeof(kTiles) / sizeof(kTiles[0]));
 constexpr size_t kLdsSoft = 64 * 1024, kLdsHard = 150 * 1024;
 
@@ -454,18 +512,32 @@ static bool try_geometry(const dfl_conv_args& a, ConvP* p, const TileCfg& t, int
   while ((1 << sh) < (ck >> 3)) ++sh;
   p->upp_shift = sh;
   p->lds_bytes = (int)lds;
-  // cost model: matrix instructions per wave x rounds over the chip (two workgroups share a CU when LDS allows) +
-  // staging + the partial-sum round trip of sliced launches
-  const int occ = (2 * lds + 4096 <= 160 * 1024) ? 2 : 1;
+  // Cost model (cycles), fitted to per-layer timings on MI355X (tools/kbench_bf16.py).  A workgroup's k loop is bound by
+  // the matrix pipe (32 cycles per instruction and wave, one wave per SIMD), by its LDS fragment reads, or by the B
+  // fragments coming from L1/L2 (each wave 1 KiB per k-step and column tile: ~32 B/clk/CU when the four waves read
+  // different columns, more when they share them); around it sit latencies nobody inside the workgroup hides: staging
+  // the patch (one global round trip + the LDS writes) and one pass per accumulator tile row in the epilogue.  `occ`
+  // workgroups share a CU (LDS, registers: 512 / allocation of the tile configuration): while one waits another computes.
+  static const int occ_by_tm[10] = {0, 5, 4, 4, 3, 2, 2, 2, 2, 2};
+  int occ = (int)((160 * 1024) / (lds + 1024));
+  if (occ > occ_by_tm[t.TM]) occ = occ_by_tm[t.TM];
+  if (occ < 1) occ = 1;
   const int64_t total = wgs * splits;
-  const int64_t rounds = ceil_div(total, 256 * occ);
+  int64_t eff = ceil_div(total, 256);
+  if (eff > occ) eff = occ;                                                      // workgroups actually sharing a CU
+  const int64_t rounds = ceil_div(total, 256 * eff);
   const int steps = (a.KH * a.KW * (ck / 16) + 3) / 4 * 4 * p->blk_per_slice;
-  const double mfma = (double)t.TM * t.TN * steps * 32.0;                        // cycles per wave (one wave per SIMD)
-  const double stage = (double)p->blk_per_slice * (double)lds / 64.0 + 1500.0 * p->blk_per_slice;   // LDS store path + latency
+  const double mfma = (double)t.TM * t.TN * steps * 32.0;
   const double ldsread = (double)t.TM * steps * 4.0 * 4.0;                       // ds_read_b128 cycles of the 4 waves
-  const double per_wg = (mfma > ldsread ? mfma : ldsread) + stage + 3000.0;      // + fixed prologue / epilogue
-  double c = (double)rounds * per_wg * occ;
-  if (splits > 1) c += (double)p->Mtot * a.Ntot * 4.0 * (splits + 1) / 2000.0;   // bytes / (B per cycle of the chip)
+  const double bbw = t.WN == 4 ? 32.0 : (t.WN == 2 ? 48.0 : 64.0);
+  const double bload = (double)steps * t.TN * 4096.0 / bbw;
+  double loop = mfma > ldsread ? mfma : ldsread;
+  if (bload > loop) loop = bload;
+  const double lat = (double)p->blk_per_slice * (4000.0 + (double)lds / 40.0) + 2000.0 + (splits > 1 ? 1500.0 : 2500.0 * t.TM);
+  const double busy = (double)eff * (loop + (double)p->blk_per_slice * (double)lds / 40.0);   // what the CU's pipes must do per round
+  const double per_round = busy > lat + loop ? busy : lat + loop;
+  double c = (double)rounds * per_round;
+  if (splits > 1) c += (double)p->Mtot * a.Ntot * 4.0 * (splits + 1) / 2000.0 + 6000.0;   // partial sums: bytes / (B per cycle of the chip) + the finish launch
   *cost = c;
   return true;
 }
@@ -473,6 +545,9 @@ static bool try_geometry(const dfl_conv_args& a, ConvP* p, const TileCfg& t, int
 int convp_plan(const dfl_conv_args* a, ConvP* p, int force_splits) {
   DFL_REQUIRE(a->x && a->w && a->y, "dfl_conv2d (bf16): x, w and y are required");
   DFL_REQUIRE(a->N > 0 && a->Hin > 0 && a->Win > 0 && a->Cin > 0 && a->Ntot > 0, "dfl_conv2d (bf16): bad sizes");
+  DFL_REQUIRE(a->Ntot % 8 == 0 && a->ldy % 8 == 0 && aligned16(a->y) && (a->add == nullptr || (a->ldadd % 8 == 0 && aligned16(a->add))) &&
+                  (a->stat_other == nullptr || (a->ldso % 8 == 0 && aligned16(a->stat_other))),
+              "dfl_conv2d (bf16): output columns and the pixel strides of y / add / stat_other must be multiples of 8, tensors 16-byte aligned");
   DFL_REQUIRE(a->Cin % 16 == 0 && a->ldx % 8 == 0 && aligned16(a->x) && aligned16(a->w),
               "dfl_conv2d (bf16): needs Cin %% 16 == 0, ldx %% 8 == 0 and 16-byte aligned x / w (Cin = %d, ldx = %d)", a->Cin, a->ldx);
   DFL_REQUIRE(a->w_split == 2, "dfl_conv2d (bf16): weights must be packed with dfl_pack_job.split = 2");
@@ -513,7 +588,12 @@ int convp_plan(const dfl_conv_args* a, ConvP* p, int force_splits) {
   double best = 1e300;
   ConvP bestp = *p;
   int best_tile = -1;
+  static const unsigned tile_off = [] {      // DFL_CONVP_TILES_OFF: bit mask of tile configurations to leave out (A/B measurements)
+    const char* e = getenv("DFL_CONVP_TILES_OFF");
+    return e ? (unsigned)strtoul(e, nullptr, 0) : 0u;
+  }();
   for (int ti = 0; ti < kNumTiles; ++ti) {
+    if ((tile_off >> ti) & 1u) continue;
     const TileCfg& t = kTiles[ti];
     const int bn = t.WN * t.TN * 32;
     if (a->Ntot <= 32 && t.WN != 1) continue;
@@ -556,6 +636,11 @@ int convp_plan(const dfl_conv_args* a, ConvP* p, int force_splits) {
               a->Cin, a->Ntot);
   *p = bestp;
   p->tile = best_tile;
+  static const bool dbg = getenv("DFL_CONVP_DEBUG") != nullptr;
+  if (dbg && force_splits == 0)
+    fprintf(stderr, "convp %dx%d Cin%d->%d k%d s%d: tile %d,%d,%d patch %dx%dx%d CK %d blocks %d splits %d lds %d cost %.0f\n", a->Hin, a->Win,
+            a->Cin, a->Ntot, a->KH, a->stride, kTiles[best_tile].WM, kTiles[best_tile].WN, kTiles[best_tile].TM, p->IPP, p->PH, p->PW, p->CK,
+            p->nblk, p->splits, p->lds_bytes, best);
   return DFL_OK;
 }
 
@@ -564,7 +649,10 @@ static int convp_launch_t(const ConvP& p, hipStream_t s) {
   const bool aff = p.a.in_scale != nullptr;
   dim3 grid((unsigned)p.npatch, (unsigned)ceil_div(p.a.Ntot, WN * TN * 32), (unsigned)p.splits);
   size_t lds = (size_t)p.lds_bytes;
-  const size_t red = (size_t)WM * 2 * WN * TN * 32 * sizeof(float);
+  constexpr int BN_ = WN * TN * 32;
+  const size_t epi = (size_t)WM * 32 * (BN_ + 4) * sizeof(float);              // epilogue image
+  const size_t red = (size_t)(256 / (BN_ / 8)) * 2 * BN_ * sizeof(float);      // statistics scratch
+  if (lds < epi) lds = epi;
   if (lds < red) lds = red;
   if (aff) {
     auto k = convp_kernel<WM, WN, TM, TN, true>;
@@ -592,7 +680,10 @@ int convp_launch(const ConvP& p, hipStream_t s) {
     case 8: rc = convp_launch_t<1, 4, 6, 1>(p, s); break;
     case 9: rc = convp_launch_t<1, 4, 9, 1>(p, s); break;
     case 10: rc = convp_launch_t<2, 2, 1, 1>(p, s); break;
-    default: rc = convp_launch_t<1, 4, 1, 1>(p, s); break;
+    case 11: rc = convp_launch_t<1, 4, 1, 1>(p, s); break;
+    case 12: rc = convp_launch_t<4, 1, 3, 1>(p, s); break;
+    case 13: rc = convp_launch_t<4, 1, 4, 1>(p, s); break;
+    default: rc = convp_launch_t<2, 2, 6, 1>(p, s); break;
   }
   if (rc != DFL_OK || p.splits <= 1) return rc;
   int tx = 1;

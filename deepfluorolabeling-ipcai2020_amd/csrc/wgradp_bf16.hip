@@ -10,8 +10,7 @@
 // pixels) is an address offset into the same image.  The contraction index is the pixel -- the slow index of both NHWC
 // operands -- so the MFMA fragments (8 consecutive pixels of one channel per lane) come out of LDS through gfx950's
 // transposing read ds_read_b64_tr_b16 (16 lanes name 4 pixel rows x 16 channels and receive 4 pixels of one channel each).
-// A d fragment is read once per k-step and used for all taps; a wave keeps one fp32 accumulator tile per tap (9 x 16
-// registers for a 3x3 layer).  Row pitches are chosen so that the 4 rows x 64 bytes of a transposing read fall on 64
+// A wave owns one kernel ROW of taps (KW accumulator tiles): a d fragment is read once per k-step and used for its taps.  Row pitches are chosen so that the 4 rows x 64 bytes of a transposing read fall on 64
 // distinct banks (pitch = 64 or 192 bytes mod 256).
 // Waves: with 4 (cm, cg) tile pairs in the workgroup tile each wave owns a pair; with 2 or 1 pairs the waves also split
 // the k-steps of a patch (2 or 4 phases) and add up through LDS at the end.  Output: partial[slice][t][cm][cg] fp32 (tap-major:
@@ -41,6 +40,7 @@ struct WgP {
   int dupp_shift, gupp_shift;          // log2(CMT / 8), log2(CGT / 8)
   int g_off;                           // byte offset of the g image behind the d image
   int lds_bytes;
+  int kpipe;                           // fragments of the next k-step are fetched under the matrix instructions of this one
   uint32_t g_bytes, d_bytes;
 };
 
@@ -82,26 +82,32 @@ __device__ __forceinline__ bf16x8_t wtr_read8(const unsigned char* base, uint32_
   return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-template <int T, bool AFF>
-__global__ void __launch_bounds__(256, (T >= 9) ? 1 : 2) wgradp_kernel(const WgP p) {
+// KH x KW window.  4 * KH waves: wave w owns kernel row w % KH (KW taps, KW accumulator tiles) of "slot" w / KH; a slot is
+// a (cm32, cg32) pair of the workgroup tile and, when the tile has fewer than 4 pairs, a phase of the k-steps.  12 waves of
+// 48 accumulator registers (3x3) instead of 4 waves of 144: three waves per SIMD cover each other's LDS latency, the patch
+// is staged by three times the threads, and the register budget leaves room for the prefetch below.
+template <int KH, int KW, bool AFF>
+__global__ void __launch_bounds__(256 * KH) wgradp_kernel(const WgP p) {
+  constexpr int NT = 256 * KH;
+  constexpr int T = KH * KW;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const dfl_wgrad_args& a = p.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int pair = wave % p.pairs, phase = wave / p.pairs;
+  const int ty = wave % KH, slot = wave / KH;
+  const int pair = slot % p.pairs, phase = slot / p.pairs;
   const int pairs_n = p.CGT >> 5;                       // pairs along cg
   const int pm = pair / pairs_n, pn = pair - pm * pairs_n;
   const int cm0 = blockIdx.x * p.CMT, cg0 = blockIdx.y * p.CGT;
   unsigned char* Ds = smem;
   unsigned char* Gs = smem + p.g_off;
-  const int KW = a.KW;
 
   __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.d), 0, (int)p.d_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g), 0, (int)p.g_bytes, 0x00020000);
 
-  f32x16 acc[T];
+  f32x16 acc[KW];
 #pragma unroll
-  for (int t = 0; t < T; ++t)
+  for (int t = 0; t < KW; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -116,109 +122,132 @@ __global__ void __launch_bounds__(256, (T >= 9) ? 1 : 2) wgradp_kernel(const WgP
   const int npix_g = p.IPP * p.IH * p.IW;
   const int per_img = p.npy * p.npx;
 
-  const int pbegin = blockIdx.z * p.patches_per_slice;
-  const int pend = min(pbegin + p.patches_per_slice, p.npatch);
-  for (int patch = pbegin; patch < pend; ++patch) {
+  // Patch pipeline: the global loads of patch i + 1 are issued into registers before the k-steps of patch i run and are
+  // written to LDS after them.
+  constexpr int MAXD = (2048 + NT - 1) / NT, MAXG = (4096 + NT - 1) / NT;   // host: P16 * dupp <= 2048, npix_g * gupp <= 4096
+  wpu32x4 dreg[MAXD], greg[MAXG];
+  uint32_t gok = 0;
+  const int ddk = NT >> p.dupp_shift, gdk = NT >> p.gupp_shift;
+  const int dcq = tid & (dupp - 1), gcq = tid & (gupp - 1);
+  const int dc = cm0 + dcq * 8, gc = cg0 + gcq * 8;
+  float sc[8], sh[8];
+  if constexpr (AFF) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sc[e] = (gc + e < a.Cg) ? a.in_scale[gc + e] : 1.f;
+      sh[e] = (gc + e < a.Cg) ? a.in_shift[gc + e] : 0.f;
+    }
+  }
+  auto issue = [&](int patch, bool live) {
     const int pg = patch / per_img, pr = patch - pg * per_img;
     const int ppy = pr / p.npx, ppx = pr - ppy * p.npx;
     const int img0 = pg * p.IPP, oy0 = ppy * p.PH, ox0 = ppx * p.PW;
-    if (patch != pbegin) __syncthreads();
-    // ---- d: rows = patch pixels in patch order (image, row, column), zeros beyond the patch / image
-    {
-      const int cq = tid & (dupp - 1);
-      const int c = cm0 + cq * 8;
+    {   // d: rows = patch pixels in patch order (image, row, column), zeros beyond the patch / image
       Walk w;
       w.init(tid >> p.dupp_shift, p.PH, p.PW);
-      const int dk = 256 >> p.dupp_shift;
-      const int dky = dk / p.PW, dkx = dk - dky * p.PW;
-      for (int k = tid >> p.dupp_shift; k < p.P16; k += dk) {
+      const int dky = ddk / p.PW, dkx = ddk - dky * p.PW;
+#pragma unroll
+      for (int u = 0; u < MAXD; ++u) {
+        const int k = (tid >> p.dupp_shift) + u * ddk;
         const int n = img0 + w.img, oy = oy0 + w.y, ox = ox0 + w.x;
-        const bool ok = w.img < p.IPP && n < a.N && oy < a.Hout && ox < a.Wout && c < a.Cm;
-        const uint32_t off = (uint32_t)((((n * a.Hout + oy) * a.Wout + ox) * a.ldd + c) * 2);
-        const wpu32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsD, ok ? off : WPOOB, 0, 0);
-        *reinterpret_cast<wpu32x4*>(Ds + (uint32_t)k * (uint32_t)p.sd + (uint32_t)cq * 16u) = v;
+        const bool ok = live && k < p.P16 && w.img < p.IPP && n < a.N && oy < a.Hout && ox < a.Wout && dc < a.Cm;
+        const uint32_t off = (uint32_t)((((n * a.Hout + oy) * a.Wout + ox) * a.ldd + dc) * 2);
+        dreg[u] = __builtin_amdgcn_raw_buffer_load_b128(rsD, ok ? off : WPOOB, 0, 0);
         w.advance(dky, dkx, p.PH, p.PW);
       }
     }
-    // ---- g: the gathered pixels of the patch with their halo, affine applied, zero outside the image
-    {
+    {   // g: the gathered pixels of the patch with their halo, zero outside the image
       const int ybase = oy0 * a.stride - a.pad, xbase = ox0 * a.stride - a.pad;
-      const int cq = tid & (gupp - 1);
-      const int c = cg0 + cq * 8;
-      float sc[8], sh[8];
-      if constexpr (AFF) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          sc[e] = (c + e < a.Cg) ? a.in_scale[c + e] : 1.f;
-          sh[e] = (c + e < a.Cg) ? a.in_shift[c + e] : 0.f;
-        }
-      }
       Walk w;
       w.init(tid >> p.gupp_shift, p.IH, p.IW);
-      const int dk = 256 >> p.gupp_shift;
-      const int dky = dk / p.IW, dkx = dk - dky * p.IW;
-      for (int pix = tid >> p.gupp_shift; pix < npix_g; pix += dk) {
+      const int dky = gdk / p.IW, dkx = gdk - dky * p.IW;
+      gok = 0;
+#pragma unroll
+      for (int u = 0; u < MAXG; ++u) {
+        const int pix = (tid >> p.gupp_shift) + u * gdk;
         const int n = img0 + w.img, gy = ybase + w.y, gx = xbase + w.x;
-        const bool ok = n < a.N && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win && c < a.Cg;
-        const uint32_t off = (uint32_t)((((n * a.Hin + gy) * a.Win + gx) * a.ldg + c) * 2);
-        wpu32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsG, ok ? off : WPOOB, 0, 0);
-        if constexpr (AFF) {
-          if (ok) {
+        const bool ok = live && pix < npix_g && n < a.N && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win && gc < a.Cg;
+        gok |= ok ? (1u << u) : 0u;
+        const uint32_t off = (uint32_t)((((n * a.Hin + gy) * a.Win + gx) * a.ldg + gc) * 2);
+        greg[u] = __builtin_amdgcn_raw_buffer_load_b128(rsG, ok ? off : WPOOB, 0, 0);
+        w.advance(dky, dkx, p.IH, p.IW);
+      }
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < MAXD; ++u) {
+      const int k = (tid >> p.dupp_shift) + u * ddk;
+      if (k < p.P16) *reinterpret_cast<wpu32x4*>(Ds + (uint32_t)k * (uint32_t)p.sd + (uint32_t)dcq * 16u) = dreg[u];
+    }
+#pragma unroll
+    for (int u = 0; u < MAXG; ++u) {
+      const int pix = (tid >> p.gupp_shift) + u * gdk;
+      if (pix < npix_g) {
+        wpu32x4 v = greg[u];
+        if constexpr (AFF) {   // zero padding applies AFTER the BatchNorm affine: outside pixels stay 0
+          if ((gok >> u) & 1u) {
             v.x = wpack_bf2(fmaf(wbf_lo(v.x), sc[0], sh[0]), fmaf(wbf_hi(v.x), sc[1], sh[1]));
             v.y = wpack_bf2(fmaf(wbf_lo(v.y), sc[2], sh[2]), fmaf(wbf_hi(v.y), sc[3], sh[3]));
             v.z = wpack_bf2(fmaf(wbf_lo(v.z), sc[4], sh[4]), fmaf(wbf_hi(v.z), sc[5], sh[5]));
             v.w = wpack_bf2(fmaf(wbf_lo(v.w), sc[6], sh[6]), fmaf(wbf_hi(v.w), sc[7], sh[7]));
           }
         }
-        *reinterpret_cast<wpu32x4*>(Gs + (uint32_t)pix * (uint32_t)p.sg + (uint32_t)cq * 16u) = v;
-        w.advance(dky, dkx, p.IH, p.IW);
+        *reinterpret_cast<wpu32x4*>(Gs + (uint32_t)pix * (uint32_t)p.sg + (uint32_t)gcq * 16u) = v;
       }
     }
-    __syncthreads();
+  };
 
-    // ---- k-steps of this patch (16 pixels each), this wave's phase
-    const int nsteps = p.P16 >> 4;
-    // this lane's two pixel rows of a step: patch pixels j0 = 16 ks + trow and j0 + 4, walked without divisions
+  const int pbegin = blockIdx.z * p.patches_per_slice;
+  const int pend = min(pbegin + p.patches_per_slice, p.npatch);
+  const int nsteps = p.P16 >> 4;
+  const int dj = 16 * p.phases;
+  const int djy = dj / p.PW, djx = dj - djy * p.PW;
+  const uint32_t row_off = (uint32_t)(ty * p.IW) * (uint32_t)p.sg;     // this wave's kernel row
+  issue(pbegin, pbegin < pend);
+  for (int patch = pbegin; patch < pend; ++patch) {
+    if (patch != pbegin) __syncthreads();               // every wave is done reading the previous images
+    commit();
+    __syncthreads();
+    issue(patch + 1, patch + 1 < pend);
+    // ---- k-steps of this patch (16 pixels each), this wave's phase; this lane's two pixel rows of a step are the
+    //      patch pixels j0 = 16 ks + trow and j0 + 4, walked without divisions
     Walk w0, w1;
     w0.init(phase * 16 + trow, p.PH, p.PW);
     w1.init(phase * 16 + trow + 4, p.PH, p.PW);
-    const int dj = 16 * p.phases;
-    const int djy = dj / p.PW, djx = dj - djy * p.PW;
     for (int ks = phase; ks < nsteps; ks += p.phases) {
       const uint32_t dr0 = (uint32_t)(ks * 16 + trow) * (uint32_t)p.sd + d_col;
       const uint32_t dr1 = dr0 + 4u * (uint32_t)p.sd;
       // rows beyond the patch: d is zero there, any valid g row will do
-      const uint32_t gr0 = (w0.img < p.IPP ? (uint32_t)((w0.img * p.IH + w0.y * a.stride) * p.IW + w0.x * a.stride) : 0u) * (uint32_t)p.sg + g_col;
-      const uint32_t gr1 = (w1.img < p.IPP ? (uint32_t)((w1.img * p.IH + w1.y * a.stride) * p.IW + w1.x * a.stride) : 0u) * (uint32_t)p.sg + g_col;
+      const uint32_t gr0 = (w0.img < p.IPP ? (uint32_t)((w0.img * p.IH + w0.y * a.stride) * p.IW + w0.x * a.stride) : 0u) * (uint32_t)p.sg + g_col + row_off;
+      const uint32_t gr1 = (w1.img < p.IPP ? (uint32_t)((w1.img * p.IH + w1.y * a.stride) * p.IW + w1.x * a.stride) : 0u) * (uint32_t)p.sg + g_col + row_off;
       const bf16x8_t df = wtr_read8(Ds, dr0, dr1);
+      bf16x8_t gf[KW];
 #pragma unroll
-      for (int t = 0; t < T; ++t) {
-        const int ty = t / KW, tx = t - ty * KW;
-        const uint32_t toff = (uint32_t)((ty * p.IW + tx)) * (uint32_t)p.sg;
-        const bf16x8_t gf = wtr_read8(Gs, gr0 + toff, gr1 + toff);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, gf, acc[t], 0, 0, 0);
-      }
+      for (int t = 0; t < KW; ++t) gf[t] = wtr_read8(Gs, gr0 + (uint32_t)(t * p.sg), gr1 + (uint32_t)(t * p.sg));
+#pragma unroll
+      for (int t = 0; t < KW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, gf[t], acc[t], 0, 0, 0);
       w0.advance(djy, djx, p.PH, p.PW);
       w1.advance(djy, djx, p.PH, p.PW);
     }
   }
 
   // ---- waves that split the k-steps of the patches (phases > 1) add their accumulators through LDS, tap by tap, in a
-  //      fixed order; the wave of phase 0 then owns the workgroup's result for its (cm, cg) pair
+  //      fixed order; the waves of phase 0 then own the workgroup's result for their (cm, cg) pair and kernel row
   if (p.phases > 1) {
-    float* red = reinterpret_cast<float*>(smem);        // [phases - 1][pairs][16][64]
+    float* red = reinterpret_cast<float*>(smem);        // [phases - 1][pairs][KH][16][64]
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
+    for (int t = 0; t < KW; ++t) {
       __syncthreads();
       if (phase > 0) {
-        float* dst = red + (((phase - 1) * p.pairs + pair) * 16) * 64 + lane;
+        float* dst = red + ((((phase - 1) * p.pairs + pair) * KH + ty) * 16) * 64 + lane;
 #pragma unroll
         for (int r = 0; r < 16; ++r) dst[r * 64] = acc[t][r];
       }
       __syncthreads();
       if (phase == 0) {
         for (int ph = 1; ph < p.phases; ++ph) {
-          const float* src = red + (((ph - 1) * p.pairs + pair) * 16) * 64 + lane;
+          const float* src = red + ((((ph - 1) * p.pairs + pair) * KH + ty) * 16) * 64 + lane;
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[t][r] += src[r * 64];
         }
@@ -231,13 +260,14 @@ __global__ void __launch_bounds__(256, (T >= 9) ? 1 : 2) wgradp_kernel(const WgP
   float* out = sliced ? a.partial + (int64_t)blockIdx.z * a.Cm * a.Cg * T : a.dw;
   const int cg = cg0 + pn * 32 + li;
 #pragma unroll
-  for (int t = 0; t < T; ++t) {
+  for (int tx = 0; tx < KW; ++tx) {
+    const int t = ty * KW + tx;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int cm = cm0 + pm * 32 + mfma32_row(r, lane);
       if (cm < a.Cm && cg < a.Cg) {
         const int64_t o = sliced ? ((int64_t)t * a.Cm + cm) * a.Cg + cg : ((int64_t)cm * a.Cg + cg) * T + t;
-        out[o] = acc[t][r];
+        out[o] = acc[tx][r];
       }
     }
   }
@@ -257,7 +287,8 @@ static int wgp_plan(const dfl_wgrad_args* a, WgP* p, bool need_out) {
   DFL_REQUIRE(a->N > 0 && a->Hin > 0 && a->Win > 0 && a->Cg > 0 && a->Cm > 0, "dfl_conv2d_wgrad: bad sizes");
   DFL_REQUIRE(a->KH > 0 && a->KW > 0 && a->stride > 0 && a->pad >= 0, "dfl_conv2d_wgrad: bad window");
   const int T = a->KH * a->KW;
-  DFL_REQUIRE(T == 1 || T == 4 || T == 9, "dfl_conv2d_wgrad (bf16): 1x1, 2x2 and 3x3 windows");
+  DFL_REQUIRE((a->KH == 1 && a->KW == 1) || (a->KH == 2 && a->KW == 2) || (a->KH == 3 && a->KW == 3),
+              "dfl_conv2d_wgrad (bf16): 1x1, 2x2 and 3x3 windows");
   const int ho = (a->Hin + 2 * a->pad - a->KH) / a->stride + 1;
   const int wo = (a->Win + 2 * a->pad - a->KW) / a->stride + 1;
   DFL_REQUIRE(ho == a->Hout && wo == a->Wout, "dfl_conv2d_wgrad: Hout/Wout (%d,%d) do not match the window (%d,%d)", a->Hout,
@@ -291,7 +322,8 @@ static int wgp_plan(const dfl_wgrad_args* a, WgP* p, bool need_out) {
   p->gupp_shift = p->CGT == 64 ? 3 : 2;
   p->sd = pitch_for(p->CMT);
   p->sg = pitch_for(p->CGT);
-  // patch: whole images while they fit 256 pixels, else whole rows, else row pieces of 64 pixels; LDS <= ~72 KiB
+  // patch: whole images while they fit 256 pixels, else whole rows, else row pieces; bounded by the LDS budget and by
+  // what a thread can hold in flight (8 / 16 sixteen-byte units of d / g: P16 * CMT <= 16384, gathered pixels * CGT <= 32768)
   const int HW = a->Hout * a->Wout;
   int ipp = 1, ph, pw;
   auto lds_of = [&](int ipp_, int ph_, int pw_) {
@@ -299,26 +331,32 @@ static int wgp_plan(const dfl_wgrad_args* a, WgP* p, bool need_out) {
     const int ih = (ph_ - 1) * a->stride + a->KH, iw = (pw_ - 1) * a->stride + a->KW;
     return (int64_t)p16 * p->sd + (int64_t)ipp_ * ih * iw * p->sg;
   };
-  const int64_t budget = 72 * 1024;
-  if (HW <= 256) {
-    ipp = 256 / HW;
+  auto fits = [&](int ipp_, int ph_, int pw_) {
+    const int p16 = (ipp_ * ph_ * pw_ + 15) / 16 * 16;
+    const int ih = (ph_ - 1) * a->stride + a->KH, iw = (pw_ - 1) * a->stride + a->KW;
+    return lds_of(ipp_, ph_, pw_) <= 72 * 1024 && p16 * p->CMT <= 16384 && (int64_t)ipp_ * ih * iw * p->CGT <= 32768;
+  };
+  const int maxpix = 16384 / p->CMT;                     // 256 for 64-channel tiles, 512 for 32-channel ones
+  if (HW <= maxpix) {
+    ipp = maxpix / HW;
     if (ipp > a->N) ipp = a->N;
     ph = a->Hout;
     pw = a->Wout;
-    while (ipp > 1 && lds_of(ipp, ph, pw) > budget) --ipp;
-  } else if (a->Wout <= 256) {
+    while (ipp > 1 && !fits(ipp, ph, pw)) --ipp;
+  } else if (a->Wout <= maxpix) {
     pw = a->Wout;
-    ph = 256 / pw;
+    ph = maxpix / pw;
   } else {
     pw = 64;
-    ph = 4;
+    ph = maxpix / 64;
   }
   if (ipp == 1) {
     if (ph > a->Hout) ph = a->Hout;
-    while (ph > 1 && lds_of(1, ph, pw) > budget) --ph;
-    while (pw > 16 && lds_of(1, ph, pw) > budget) pw = (pw + 1) / 2;
+    while (ph > 1 && !fits(1, ph, pw)) --ph;
+    while (pw > 16 && !fits(1, ph, pw)) pw = (pw + 1) / 2;
+    while (ph * 2 <= a->Hout && fits(1, ph * 2, pw) && ph * 2 * pw <= maxpix) ph *= 2;   // narrower rows: more of them
   }
-  DFL_REQUIRE(lds_of(ipp, ph, pw) <= 150 * 1024, "dfl_conv2d_wgrad (bf16): patch does not fit LDS");
+  DFL_REQUIRE(fits(ipp, ph, pw), "dfl_conv2d_wgrad (bf16): no patch of this layer fits the staging limits");
   p->IPP = ipp;
   p->PH = ph;
   p->PW = pw;
@@ -329,15 +367,25 @@ static int wgp_plan(const dfl_wgrad_args* a, WgP* p, bool need_out) {
   p->IH = (ph - 1) * a->stride + a->KH;
   p->IW = (pw - 1) * a->stride + a->KW;
   p->g_off = (p->P16 * p->sd + 255) / 256 * 256;
+  static const int kpipe = [] {
+    const char* e = getenv("DFL_WGP_KPIPE");
+    return e ? atoi(e) : 1;
+  }();
+  p->kpipe = kpipe;
   p->lds_bytes = p->g_off + ipp * p->IH * p->IW * p->sg;
-  if (p->lds_bytes < 3 * 4 * 16 * 64 * 4) p->lds_bytes = 3 * 4 * 16 * 64 * 4;   // room for the cross-phase sums
+  if (p->lds_bytes < 3 * 4 * 3 * 16 * 64 * 4) p->lds_bytes = 3 * 4 * 3 * 16 * 64 * 4;   // room for the cross-phase sums
   return DFL_OK;
 }
 
-// pixel slices so that the chip sees ~512 workgroups, every slice at least two patches when there are that many
+// pixel slices so that the chip sees ~256 workgroups (DFL_WGP_WGS; measured 256 / 512 / 1024: 1.50 / 1.82 / 2.19 ms of weight
+// gradients per step and 0.43 / 0.74 / 1.10 ms of partial sums)
 static int wgp_slices(const WgP& p) {
   const int64_t tiles = ceil_div(p.a.Cm, p.CMT) * ceil_div(p.a.Cg, p.CGT);
-  int64_t z = ceil_div(512, tiles);
+  static const int target = [] {
+    const char* e = getenv("DFL_WGP_WGS");
+    return e ? atoi(e) : 256;
+  }();
+  int64_t z = ceil_div(target, tiles);
   if (z > p.npatch) z = p.npatch;
   if (z < 1) z = 1;
   // equalise: every slice walks the same number of patches
@@ -360,18 +408,18 @@ int wgradp_config(const dfl_wgrad_args* a) {
   return 16 + (p.T == 9 ? 0 : (p.T == 4 ? 1 : 2));
 }
 
-template <int T>
+template <int KH, int KW>
 static int wgp_launch_t(const WgP& p, hipStream_t s) {
   dim3 grid((unsigned)ceil_div(p.a.Cm, p.CMT), (unsigned)ceil_div(p.a.Cg, p.CGT), (unsigned)p.zslices);
   const size_t lds = (size_t)p.lds_bytes;
   if (p.a.in_scale != nullptr) {
-    auto k = wgradp_kernel<T, true>;
+    auto k = wgradp_kernel<KH, KW, true>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL(k, grid, dim3(256 * KH), lds, s, p);
   } else {
-    auto k = wgradp_kernel<T, false>;
+    auto k = wgradp_kernel<KH, KW, false>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL(k, grid, dim3(256 * KH), lds, s, p);
   }
   return check_launch("dfl_conv2d_wgrad (bf16)");
 }
@@ -383,9 +431,9 @@ int wgradp_launch(const dfl_wgrad_args* a, hipStream_t s) {
   p.zslices = a->splits;                     // partial slots = pixel slices
   p.patches_per_slice = (int)ceil_div(p.npatch, p.zslices);
   switch (p.T) {
-    case 9: return wgp_launch_t<9>(p, s);
-    case 4: return wgp_launch_t<4>(p, s);
-    default: return wgp_launch_t<1>(p, s);
+    case 9: return wgp_launch_t<3, 3>(p, s);
+    case 4: return wgp_launch_t<2, 2>(p, s);
+    default: return wgp_launch_t<1, 1>(p, s);
   }
 }
 
