@@ -172,7 +172,7 @@ EXPORTS = ['dfl_version', 'dfl_last_error', 'dfl_sizeof', 'dfl_conv2d', 'dfl_con
            'dfl_exec_timed', 'dfl_conv_config', 'dfl_wgrad_config', 'dfl_conv_suggest_splits', 'dfl_reduce_batch',
            'dfl_reduce_job_blocks', 'dfl_prep_batch', 'dfl_prep_scratch_doubles', 'dfl_est_lands', 'dfl_hard_dice', 'dfl_get_math_mode',
            'dfl_set_math_mode', 'dfl_graph_capture', 'dfl_graph_launch', 'dfl_graph_nodes', 'dfl_graph_destroy',
-           'dfl_set_conv_rows_min_tiles']
+           'dfl_set_conv_rows_min_tiles', 'dfl_conv_candidates', 'dfl_conv_force_geometry', 'dfl_conv_tune_add']
 
 
 class DflError(RuntimeError):
@@ -226,11 +226,38 @@ def lib():
         getattr(L, fn).argtypes = [fp, fp]
     for fn in ('dfl_conv_grid_m', 'dfl_wgrad_suggest_splits', 'dfl_conv_suggest_splits'):
         getattr(L, fn).argtypes = [fp]
+    L.dfl_conv_candidates.argtypes = [fp, fp, i32]
+    L.dfl_conv_force_geometry.argtypes = [fp]
+    L.dfl_conv_tune_add.argtypes = [fp, fp]
     for k, cls in enumerate(_SIZEOF_ORDER):
         if L.dfl_sizeof(k) != C.sizeof(cls):
             raise DflError('struct mirror %s has size %d, library says %d' % (cls.__name__, C.sizeof(cls), L.dfl_sizeof(k)))
     _lib = L
+    if os.environ.get('DFL_TUNE', '1') != '0':
+        load_tuning(L, TUNE_PATH)
     return L
+
+
+TUNE_PATH = os.environ.get('DFL_TUNE_FILE') or os.path.join(_HERE, 'tune', 'gfx950_convp.txt')
+
+
+def load_tuning(L, path):
+    """Geometry table of the bf16 convolution, measured on the device by tools/tune_convp.py: one layer per line,
+    10 key integers (N Hin Win Cin Ntot KH KW stride pad scatter) and 5 geometry integers (include/dfl_hip.h:
+    dfl_conv_tune_add).  Layers that are not listed keep the cost model's choice.  Returns the number of entries."""
+    if not os.path.exists(path):
+        return 0
+    n = 0
+    with open(path) as f:
+        for line in f:
+            line = line.split('#')[0].split()
+            if len(line) != 15:
+                continue
+            v = (i32 * 15)(*[int(t) for t in line])
+            if L.dfl_conv_tune_add(C.addressof(v), C.addressof(v) + 40) < 0:
+                raise DflError('bad tuning entry in %s: %s' % (path, ' '.join(line)))
+            n += 1
+    return n
 
 
 def check(rc, what=''):

@@ -16,6 +16,7 @@ struct ConvP {
   int splits, T;                // K slices (grid.z), taps
   int pix_stride, upp_shift;    // bytes per staged pixel (2 CK + 16), log2(CK / 8)
   int lds_bytes, tile;          // staged image size, index into the tile configuration table
+  int ntiles, grid, xcd_mode;   // column tiles; workgroups launched (linear grid); workgroup -> (patch, tile, slice) map
   uint32_t x_bytes, w_bytes;
 };
 
@@ -23,6 +24,9 @@ struct ConvP {
 int convp_plan(const dfl_conv_args* a, ConvP* p, int force_splits);
 int convp_launch(const ConvP& p, hipStream_t s);
 int convp_finish_rows(const ConvP& p);
+int convp_candidates(const dfl_conv_args* a, int32_t* out, int max);
+int convp_force(const int32_t* g);
+int convp_tune_add(const int32_t* key, const int32_t* g);
 
 struct WgP;
 int wgradp_suggest_splits(const dfl_wgrad_args* a);

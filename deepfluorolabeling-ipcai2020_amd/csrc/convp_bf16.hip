@@ -29,6 +29,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+#include <vector>
+
 #include "common.h"
 #include "convp.h"
 
@@ -56,12 +59,39 @@ __global__ void __launch_bounds__(256, (TM * TN >= 6) ? 1 : 2) convp_kernel(cons
   const int S = p.pix_stride;
   const int PP = p.PH * p.PW;
 
-  // ---- which patch
+  // ---- which patch, column tile and K slice.  The grid is linear; workgroup b runs on XCD b % 8 (observed, used for
+  //      speed only).  Layers whose weights outweigh their activations (deep levels: 5-19 MB of weights against a 4 MB
+  //      L2 per XCD) put all patches of one (column tile, K slice) pair on ONE XCD, so that every XCD streams only its
+  //      share of the weights instead of all of them; the others keep patches adjacent (activation reuse in L2).
+  int bpatch, btile, bslice;
+  {
+    const int b = blockIdx.x;
+    if (p.xcd_mode == 0) {
+      bpatch = b % p.npatch;
+      const int r = b / p.npatch;
+      btile = r % p.ntiles;
+      bslice = r / p.ntiles;
+    } else {
+      const int x = b & 7, r = b >> 3;
+      int s;
+      if (p.xcd_mode == 1) {                        // pairs round-robin over the XCDs
+        s = x + 8 * (r / p.npatch);
+        bpatch = r % p.npatch;
+      } else {                                      // fewer pairs than XCDs: 8 / pairs XCDs share one pair's patches
+        const int pairs = p.ntiles * p.splits;
+        s = x % pairs;
+        bpatch = x / pairs + (8 / pairs) * r;
+      }
+      if (s >= p.ntiles * p.splits || bpatch >= p.npatch) return;
+      btile = s % p.ntiles;
+      bslice = s / p.ntiles;
+    }
+  }
   const int per_img = p.npy * p.npx;
-  const int pg = blockIdx.x / per_img, pr = blockIdx.x - pg * per_img;
+  const int pg = bpatch / per_img, pr = bpatch - pg * per_img;
   const int ppy = pr / p.npx, ppx = pr - ppy * p.npx;
   const int img0 = pg * p.IPP, gy0 = ppy * p.PH, gx0 = ppx * p.PW;
-  const int n0 = blockIdx.y * (WN * TN * 32);
+  const int n0 = btile * (WN * TN * 32);
 
   // ---- LDS base of each tile row of this lane (tap (0,0), channel chunk 0, this lane's k half)
   uint32_t a_base[TM];
@@ -105,12 +135,27 @@ __global__ void __launch_bounds__(256, (TM * TN >= 6) ? 1 : 2) convp_kernel(cons
   const int cin_chunks = a.Cin >> 4;
   const int KW = a.KW;
 
-  const int blk_begin = blockIdx.z * p.blk_per_slice;
+#ifdef DFL_CONVP_TRACE   // diagnosis build (tools/exp/convp_trace.py): shader-clock stamps of wave 0 at the phase boundaries
+  long long tr_t[10];
+  tr_t[6] = tr_t[7] = tr_t[8] = 0;
+  tr_t[0] = __builtin_amdgcn_s_memtime();
+  tr_t[5] = __builtin_amdgcn_s_memrealtime();
+  tr_t[1] = tr_t[2] = 0;
+#define TR(i) tr_t[i] = __builtin_amdgcn_s_memtime();
+#define TRACC(i, t0) tr_t[i] += __builtin_amdgcn_s_memtime() - (t0);
+#else
+#define TR(i)
+#define TRACC(i, t0)
+#endif
+  const int blk_begin = bslice * p.blk_per_slice;
   const int blk_end = min(blk_begin + p.blk_per_slice, p.nblk);
   for (int blk = blk_begin; blk < blk_end; ++blk) {
     const int c0 = blk * p.CK;
     // ================================================================ stage the patch image of channels [c0, c0 + CK)
     if (blk != blk_begin) __syncthreads();         // every wave is done reading the previous image
+#ifdef DFL_CONVP_TRACE
+    const long long tb0 = __builtin_amdgcn_s_memtime();
+#endif
     {
       float sc[8], sh[8];
       if constexpr (AFF) {
@@ -167,10 +212,14 @@ __global__ void __launch_bounds__(256, (TM * TN >= 6) ? 1 : 2) convp_kernel(cons
       }
     }
     __syncthreads();
+    TRACC(1, tb0)
+#ifdef DFL_CONVP_TRACE
+    const long long tb1 = __builtin_amdgcn_s_memtime();
+#endif
 
     // ================================================================ k-steps of this block: s = tap * CKC + chunk
     // B fragments ride a ring of three register sets, loaded two groups (8 k-steps) ahead of their use.
-    constexpr int G = 4;
+    constexpr int G = TN == 1 ? 4 : 2;             // k-steps per ring set (the ring holds 3 * G * TN fragments)
     const int ngroups = (S_steps + G - 1) / G;
     pu32x4 breg[3][G][TN];
     auto load_group = [&](int g, int set) {
@@ -184,17 +233,24 @@ __global__ void __launch_bounds__(256, (TM * TN >= 6) ? 1 : 2) convp_kernel(cons
         for (int j = 0; j < TN; ++j) breg[set][e][j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, live ? b_voff[j] : POOB, soff, 0);
       }
     };
+    // A fragments run one k-step ahead of the matrix instructions that use them: the reads of step s + 1 are issued
+    // before the instructions of step s (a fragment read takes 64-128 cycles, an instruction 32)
+    bf16x8_t afn[TM];
+    auto fetch_a = [&](int s) {
+      s = s < S_steps ? s : S_steps - 1;           // dead steps of the last group: weights were loaded as zeros
+      const int tap = s >> ckc_sh, cc = s & (CKC - 1);
+      const int ty = tap / KW, tx = tap - ty * KW;
+      const uint32_t aoff = (uint32_t)((ty * p.IW + tx) * S + cc * 32);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) afn[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const pu32x4*>(smem + a_base[i] + aoff));
+    };
     auto compute_group = [&](int g, int set) {
 #pragma unroll
       for (int e = 0; e < G; ++e) {
-        int s = g * G + e;
-        s = s < S_steps ? s : S_steps - 1;         // dead steps of the last group: weights were loaded as zeros
-        const int tap = s >> ckc_sh, cc = s & (CKC - 1);
-        const int ty = tap / KW, tx = tap - ty * KW;
-        const uint32_t aoff = (uint32_t)((ty * p.IW + tx) * S + cc * 32);
         bf16x8_t af[TM];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const pu32x4*>(smem + a_base[i] + aoff));
+        for (int i = 0; i < TM; ++i) af[i] = afn[i];
+        fetch_a(g * G + e + 1);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, breg[set][e][j]);
@@ -203,6 +259,7 @@ __global__ void __launch_bounds__(256, (TM * TN >= 6) ? 1 : 2) convp_kernel(cons
         }
       }
     };
+    fetch_a(0);
     load_group(0, 0);
     load_group(1, 1);
     for (int g = 0; g < ngroups; g += 3) {
@@ -217,13 +274,15 @@ __global__ void __launch_bounds__(256, (TM * TN >= 6) ? 1 : 2) convp_kernel(cons
         compute_group(g + 2, 2);
       }
     }
+    TRACC(2, tb1)
   }
+  TR(3)
 
   // ==================================================================== epilogue
   const bool sliced = p.splits > 1;
   if (sliced) {
     // K slices: raw fp32 partial sums, row = GEMM row, 128-byte runs per accumulator row; convp_finish_kernel does the rest
-    float* part = a.partial + (int64_t)blockIdx.z * p.Mtot * a.Ntot;
+    float* part = a.partial + (int64_t)bslice * p.Mtot * a.Ntot;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -295,13 +354,24 @@ __global__ void __launch_bounds__(256, (TM * TN >= 6) ? 1 : 2) convp_kernel(cons
   };
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
+#ifdef DFL_CONVP_TRACE
+    const long long te0 = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();                                  // the previous pass (or the k loop) is done with this LDS region
+    TRACC(6, te0)
+#ifdef DFL_CONVP_TRACE
+    const long long te1 = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         ep[(wm * 32 + mfma32_row(r, lane)) * EP + (wn * TN + j) * 32 + li] = acc[i][j][r];
     __syncthreads();
+    TRACC(7, te1)
+#ifdef DFL_CONVP_TRACE
+    const long long te2 = __builtin_amdgcn_s_memtime();
+#endif
     for (int rl = urow; rl < WM * 32; rl += RPS) {    // row rl of the image = row (rl / 32) * TM*32 + i*32 + rl % 32 of the patch
       const int q = ((rl >> 5) * TM + i) * 32 + (rl & 31);
       const int img = q / PP;
@@ -355,7 +425,16 @@ __global__ void __launch_bounds__(256, (TM * TN >= 6) ? 1 : 2) convp_kernel(cons
         }
       }
     }
+    TRACC(8, te2)
   }
+#ifdef DFL_CONVP_TRACE
+  if (tid == 0 && a.partial != nullptr) {
+    long long* sink = reinterpret_cast<long long*>(a.partial) + (int64_t)(bpatch + p.npatch * btile) * 12;
+    sink[8] = tr_t[6]; sink[9] = tr_t[7]; sink[10] = tr_t[8];
+    sink[0] = tr_t[0]; sink[1] = tr_t[1]; sink[2] = tr_t[2]; sink[3] = tr_t[3]; sink[4] = __builtin_amdgcn_s_memtime();
+    sink[5] = tr_t[5]; sink[6] = __builtin_amdgcn_s_memrealtime(); sink[7] = 1;
+  }
+#endif
   if (!do_stats) return;
   // per-column sums of the workgroup -> one row of stat_partials (rows = patches): threads of one column unit add up
   // through LDS in a fixed order
@@ -373,7 +452,7 @@ __global__ void __launch_bounds__(256, (TM * TN >= 6) ? 1 : 2) convp_kernel(cons
     if (n < a.Ntot) {
       float sum = 0.f;
       for (int w = 0; w < RPS; ++w) sum += red[(w * 2 + which) * BN + col];
-      a.stat_partials[((int64_t)blockIdx.x * 2 + which) * a.Ntot + n] = sum;
+      a.stat_partials[((int64_t)bpatch * 2 + which) * a.Ntot + n] = sum;
     }
   }
 }
@@ -454,7 +533,9 @@ struct TileCfg { int WM, WN, TM, TN; };
 // value reported by dfl_conv_config for these kernels = 16 + index
 static const TileCfg kTiles[] = {{4, 1, 2, 1}, {4, 1, 1, 1}, {2, 2, 4, 1}, {2, 2, 3, 1}, {2, 2, 2, 1}, {1, 4, 2, 1},
                                  {1, 4, 3, 1}, {1, 4, 4, 1}, {1, 4, 6, 1}, {1, 4, 9, 1}, {2, 2, 1, 1}, {1, 4, 1, 1},
-                                 {4, 1, 3, 1}, {4, 1, 4, 1}, {2, 2, 6, 1}};
+                                 {4, 1, 3, 1}, {4, 1, 4, 1}, {2, 2, 6, 1},
+                                 // two column tiles per wave: half the LDS fragment reads per matrix instruction
+                                 {2, 2, 2, 2}, {2, 2, 3, 2}, {2, 2, 4, 2}, {4, 1, 2, 2}, {4, 1, 3, 2}, {1, 4, 2, 2}, {1, 4, 3, 2}};
 constexpr int kNumTiles = (int)(sizeof(kTiles) / sizeof(kTiles[0]));
 constexpr size_t kLdsSoft = 64 * 1024, kLdsHard = 150 * 1024;
 
@@ -506,6 +587,27 @@ static bool try_geometry(const dfl_conv_args& a, ConvP* p, const TileCfg& t, int
   p->CK = ck;
   p->nblk = nblk;
   p->splits = splits;
+  p->ntiles = ntiles;
+  {
+    // workgroup -> XCD placement (see the kernel): weight-major when one pass over the weights is the larger stream
+    static const int xcd_env = [] {
+      const char* e = getenv("DFL_CONVP_XCD");       // 0: never weight-major (A/B measurements)
+      return e ? atoi(e) : 1;
+    }();
+    const int64_t wbytes = (int64_t)a.KH * a.KW * a.Cin * a.Ntot * 2;
+    const int64_t abytes = (int64_t)a.N * a.Hin * a.Win * a.Cin * 2;
+    const int pairs = ntiles * splits;
+    p->xcd_mode = 0;
+    p->grid = p->npatch * pairs;
+    if (xcd_env != 0 && wbytes > abytes && wbytes > (1 << 20)) {
+      if (pairs >= 8 && pairs % 8 == 0) {
+        p->xcd_mode = 1;
+      } else if (pairs < 8 && 8 % pairs == 0 && p->npatch >= 8 / pairs) {
+        p->xcd_mode = 2;
+        p->grid = 8 * (int)ceil_div(p->npatch, 8 / pairs);
+      }
+    }
+  }
   p->blk_per_slice = nblk / splits;
   p->pix_stride = ck * 2 + 16;
   int sh = 0;
@@ -540,6 +642,84 @@ static bool try_geometry(const dfl_conv_args& a, ConvP* p, const TileCfg& t, int
   if (splits > 1) c += (double)p->Mtot * a.Ntot * 4.0 * (splits + 1) / 2000.0 + 6000.0;   // partial sums: bytes / (B per cycle of the chip) + the finish launch
   *cost = c;
   return true;
+}
+
+// ---- geometry candidates, forced geometry, tuning table
+struct ConvGeom { int tile, ipp, ph, pw, splits; };
+static thread_local ConvGeom t_force = {-1, 0, 0, 0, 0};
+struct TuneEntry { int key[10]; ConvGeom g; };
+static std::mutex g_tune_mu;
+static std::vector<TuneEntry> g_tune;
+
+static void tune_key(const dfl_conv_args& a, int* k) {
+  k[0] = a.N; k[1] = a.Hin; k[2] = a.Win; k[3] = a.Cin; k[4] = a.Ntot;
+  k[5] = a.KH; k[6] = a.KW; k[7] = a.stride; k[8] = a.pad; k[9] = a.scatter2x2 ? 1 : 0;
+}
+
+static bool tune_lookup(const dfl_conv_args& a, ConvGeom* g) {
+  int k[10];
+  tune_key(a, k);
+  std::lock_guard<std::mutex> lock(g_tune_mu);
+  for (const TuneEntry& e : g_tune)
+    if (memcmp(e.key, k, sizeof(k)) == 0) {
+      *g = e.g;
+      return true;
+    }
+  return false;
+}
+
+// Tile configurations x patch shapes x K slices that are valid for the layer.  The cost model looks at the tiles whose
+// column count matches the layer (`wide` false); tuners also get the narrower column tiles (more workgroups).
+template <typename F>
+static void for_each_candidate(const dfl_conv_args& a, const ConvP& base, int force_splits, bool wide, F&& f) {
+  static const unsigned tile_off = [] {      // DFL_CONVP_TILES_OFF: bit mask of tile configurations to leave out (A/B measurements)
+    const char* e = getenv("DFL_CONVP_TILES_OFF");
+    return e ? (unsigned)strtoul(e, nullptr, 0) : 0u;
+  }();
+  const int n32 = (int)ceil_div(a.Ntot, 32) * 32;
+  for (int ti = 0; ti < kNumTiles; ++ti) {
+    if ((tile_off >> ti) & 1u) continue;
+    const TileCfg& t = kTiles[ti];
+    const int bn = t.WN * t.TN * 32;
+    if (wide) {
+      if (bn > n32 || (bn < 64 && n32 >= 64) || (t.TN > 1 && bn > a.Ntot)) continue;
+    } else {
+      if (t.TN != 1) continue;                       // the model was fitted on the one-column-tile configurations
+      if (a.Ntot <= 32 && t.WN != 1) continue;
+      if (a.Ntot > 32 && a.Ntot <= 64 && t.WN != 2) continue;
+      if (a.Ntot > 64 && t.WN != 4) continue;
+    }
+    const int QP = t.WM * t.TM * 32;
+    int shapes[24][3];
+    int ns = 0;
+    const int HW = base.Hg * base.Wg;
+    if (HW <= QP) {                                  // whole images
+      shapes[ns][0] = QP / HW; shapes[ns][1] = base.Hg; shapes[ns][2] = base.Wg; ++ns;
+    }
+    if (base.Wg <= QP) {                             // whole rows
+      int ph = QP / base.Wg;
+      if (ph > base.Hg) ph = base.Hg;
+      shapes[ns][0] = 1; shapes[ns][1] = ph; shapes[ns][2] = base.Wg; ++ns;
+    }
+    static const int kPh[] = {1, 2, 4, 8, 16, 3, 6, 12};        // row pieces (the model looks at the powers of two)
+    for (int k = 0; k < (wide ? 8 : 5) && ns < 22; ++k) {
+      const int ph = kPh[k];
+      int pw = QP / ph;
+      if (pw >= base.Wg || ph > base.Hg) continue;
+      shapes[ns][0] = 1; shapes[ns][1] = ph; shapes[ns][2] = pw; ++ns;
+    }
+    for (int si = 0; si < ns; ++si) {
+      for (int sp = 1; sp <= 32; sp *= 2) {
+        if (force_splits > 0 && sp != force_splits) continue;
+        if (!wide && a.scatter2x2 == 0 && a.accumulate == 0 && sp > 1 && base.T * a.Cin < 1024) break;   // short K: never sliced
+        ConvP q = base;
+        double c;
+        if (!try_geometry(a, &q, t, shapes[si][0], shapes[si][1], shapes[si][2], sp, &c)) continue;
+        if (q.splits != sp) continue;
+        f(ti, q, c);
+      }
+    }
+  }
 }
 
 int convp_plan(const dfl_conv_args* a, ConvP* p, int force_splits) {
@@ -584,53 +764,37 @@ int convp_plan(const dfl_conv_args* a, ConvP* p, int force_splits) {
   p->x_bytes = (uint32_t)xb;
   p->w_bytes = (uint32_t)wb;
 
-  // candidates: tile configurations allowed for this column count x patch shapes that fill their rows
+  // a forced geometry (dfl_conv_force_geometry: tuners, tests) or an entry of the tuning table (dfl_conv_tune_add) wins
+  // over the cost model, as long as it is valid for this layer and agrees with the caller's K slices
   double best = 1e300;
   ConvP bestp = *p;
   int best_tile = -1;
-  static const unsigned tile_off = [] {      // DFL_CONVP_TILES_OFF: bit mask of tile configurations to leave out (A/B measurements)
-    const char* e = getenv("DFL_CONVP_TILES_OFF");
-    return e ? (unsigned)strtoul(e, nullptr, 0) : 0u;
-  }();
-  for (int ti = 0; ti < kNumTiles; ++ti) {
-    if ((tile_off >> ti) & 1u) continue;
-    const TileCfg& t = kTiles[ti];
-    const int bn = t.WN * t.TN * 32;
-    if (a->Ntot <= 32 && t.WN != 1) continue;
-    if (a->Ntot > 32 && a->Ntot <= 64 && t.WN != 2) continue;
-    if (a->Ntot > 64 && t.WN != 4) continue;
-    (void)bn;
-    const int QP = t.WM * t.TM * 32;
-    int shapes[16][3];
-    int ns = 0;
-    const int HW = p->Hg * p->Wg;
-    if (HW <= QP) {                                  // whole images
-      shapes[ns][0] = QP / HW; shapes[ns][1] = p->Hg; shapes[ns][2] = p->Wg; ++ns;
-    }
-    if (p->Wg <= QP) {                               // whole rows
-      int ph = QP / p->Wg;
-      if (ph > p->Hg) ph = p->Hg;
-      shapes[ns][0] = 1; shapes[ns][1] = ph; shapes[ns][2] = p->Wg; ++ns;
-    }
-    for (int ph = 1; ph <= 16 && ns < 14; ph *= 2) { // row pieces
-      int pw = QP / ph;
-      if (pw >= p->Wg || ph > p->Hg) continue;
-      shapes[ns][0] = 1; shapes[ns][1] = ph; shapes[ns][2] = pw; ++ns;
-    }
-    for (int si = 0; si < ns; ++si) {
-      for (int sp = 1; sp <= 32; sp *= 2) {
-        if (force_splits > 0 && sp != force_splits) continue;
-        if (a->scatter2x2 == 0 && a->accumulate == 0 && sp > 1 && p->T * a->Cin < 1024) break;   // short K: never sliced
+  {
+    ConvGeom g;
+    const bool forced = t_force.tile >= 0;
+    if (forced) g = t_force;
+    if (forced || tune_lookup(*a, &g)) {
+      if (g.tile >= 0 && g.tile < kNumTiles && (force_splits <= 0 || force_splits == g.splits)) {
         ConvP q = *p;
         double c;
-        if (!try_geometry(*a, &q, t, shapes[si][0], shapes[si][1], shapes[si][2], sp, &c)) continue;
-        if (c < best) {
+        if (try_geometry(*a, &q, kTiles[g.tile], g.ipp, g.ph, g.pw, g.splits, &c) && q.splits == g.splits) {
           best = c;
           bestp = q;
-          best_tile = ti;
+          best_tile = g.tile;
         }
       }
+      DFL_REQUIRE(!forced || best_tile >= 0, "dfl_conv2d (bf16): the forced geometry (tile %d, patch %dx%dx%d, %d slices) does not fit this layer",
+                  g.tile, g.ipp, g.ph, g.pw, g.splits);
     }
+  }
+  if (best_tile < 0) {
+    for_each_candidate(*a, *p, force_splits, false, [&](int ti, const ConvP& q, double c) {
+      if (c < best) {
+        best = c;
+        bestp = q;
+        best_tile = ti;
+      }
+    });
   }
   DFL_REQUIRE(best_tile >= 0, "dfl_conv2d (bf16): no patch geometry fits this layer (%dx%d, Cin %d, Ntot %d)", a->Hin, a->Win,
               a->Cin, a->Ntot);
@@ -647,7 +811,7 @@ int convp_plan(const dfl_conv_args* a, ConvP* p, int force_splits) {
 template <int WM, int WN, int TM, int TN>
 static int convp_launch_t(const ConvP& p, hipStream_t s) {
   const bool aff = p.a.in_scale != nullptr;
-  dim3 grid((unsigned)p.npatch, (unsigned)ceil_div(p.a.Ntot, WN * TN * 32), (unsigned)p.splits);
+  dim3 grid((unsigned)p.grid);
   size_t lds = (size_t)p.lds_bytes;
   constexpr int BN_ = WN * TN * 32;
   const size_t epi = (size_t)WM * 32 * (BN_ + 4) * sizeof(float);              // epilogue image
@@ -683,7 +847,14 @@ int convp_launch(const ConvP& p, hipStream_t s) {
     case 11: rc = convp_launch_t<1, 4, 1, 1>(p, s); break;
     case 12: rc = convp_launch_t<4, 1, 3, 1>(p, s); break;
     case 13: rc = convp_launch_t<4, 1, 4, 1>(p, s); break;
-    default: rc = convp_launch_t<2, 2, 6, 1>(p, s); break;
+    case 14: rc = convp_launch_t<2, 2, 6, 1>(p, s); break;
+    case 15: rc = convp_launch_t<2, 2, 2, 2>(p, s); break;
+    case 16: rc = convp_launch_t<2, 2, 3, 2>(p, s); break;
+    case 17: rc = convp_launch_t<2, 2, 4, 2>(p, s); break;
+    case 18: rc = convp_launch_t<4, 1, 2, 2>(p, s); break;
+    case 19: rc = convp_launch_t<4, 1, 3, 2>(p, s); break;
+    case 20: rc = convp_launch_t<1, 4, 2, 2>(p, s); break;
+    default: rc = convp_launch_t<1, 4, 3, 2>(p, s); break;
   }
   if (rc != DFL_OK || p.splits <= 1) return rc;
   int tx = 1;
@@ -695,4 +866,64 @@ int convp_launch(const ConvP& p, hipStream_t s) {
   return check_launch("dfl_conv2d (bf16, split-K finish)");
 }
 
+
+// Candidates of the geometry search for one layer (tuners: tools/tune_convp.py): up to `max` rows of 5 integers
+// (tile configuration, images per patch, patch height, patch width, K slices); returns the number of candidates.
+int convp_candidates(const dfl_conv_args* a, int32_t* out, int max) {
+  ConvP p;
+  const int saved_tile = t_force.tile;
+  t_force.tile = -1;
+  const int rc = convp_plan(a, &p, 0);               // validates the arguments and fills the layer constants
+  t_force.tile = saved_tile;
+  if (rc != DFL_OK) return -1;
+  ConvP base = p;
+  int n = 0;
+  for_each_candidate(*a, base, 0, true, [&](int ti, const ConvP& q, double) {
+    if (n < max) {
+      int32_t* o = out + 5 * n;
+      o[0] = ti; o[1] = q.IPP; o[2] = q.PH; o[3] = q.PW; o[4] = q.splits;
+    }
+    ++n;
+  });
+  return n;
+}
+
+int convp_force(const int32_t* g) {
+  if (g == nullptr) t_force.tile = -1;
+  else t_force = ConvGeom{g[0], g[1], g[2], g[3], g[4]};
+  return DFL_OK;
+}
+
+int convp_tune_add(const int32_t* key, const int32_t* g) {
+  std::lock_guard<std::mutex> lock(g_tune_mu);
+  if (key == nullptr) {
+    g_tune.clear();
+    return DFL_OK;
+  }
+  TuneEntry e;
+  for (int i = 0; i < 10; ++i) e.key[i] = key[i];
+  e.g = ConvGeom{g[0], g[1], g[2], g[3], g[4]};
+  for (TuneEntry& o : g_tune)
+    if (memcmp(o.key, e.key, sizeof(e.key)) == 0) {
+      o = e;
+      return DFL_OK;
+    }
+  g_tune.push_back(e);
+  return DFL_OK;
+}
+
 }  // namespace dfl
+
+// ---- C ABI of the geometry search (include/dfl_hip.h)
+extern "C" int dfl_conv_candidates(const dfl_conv_args* a, int32_t* out, int32_t max_rows) {
+  DFL_REQUIRE(a != nullptr && (out != nullptr || max_rows <= 0) && a->x_bf16, "dfl_conv_candidates: bf16 convolution arguments and an output table are required");
+  const int n = dfl::convp_candidates(a, out, max_rows);
+  return n < 0 ? (int)DFL_ERR_INVALID_ARG : n;
+}
+
+extern "C" int dfl_conv_force_geometry(const int32_t* geom) { return dfl::convp_force(geom); }
+
+extern "C" int dfl_conv_tune_add(const int32_t* key, const int32_t* geom) {
+  DFL_REQUIRE(key == nullptr || geom != nullptr, "dfl_conv_tune_add: a key needs a geometry");
+  return dfl::convp_tune_add(key, geom);
+}

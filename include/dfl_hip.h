@@ -105,6 +105,20 @@ int dfl_conv_grid_m(const dfl_conv_args* a);
 /* Suggested split-K factor for these args (>= 1); the caller sizes `partial` as splits*M*Ntot floats. */
 int dfl_conv_suggest_splits(const dfl_conv_args* a);
 
+/* Geometry search of the bf16 convolution (csrc/convp_bf16.hip).  A geometry is 5 integers: tile configuration (the
+ * value dfl_conv_config reports - 16), images per patch, patch height, patch width, K slices.  By default a cost model
+ * picks one per layer; a tuning table (measured on the device: tools/tune_convp.py -> dfl_amd/tune/gfx950_convp.txt,
+ * loaded when the library is opened) overrides it for the layers it lists.
+ *   dfl_conv_candidates     the valid geometries of a layer: writes up to max_rows rows of 5 integers, returns their number
+ *   dfl_conv_force_geometry every following dfl_conv_* call of this thread uses `geom` (error if invalid for the layer);
+ *                           NULL returns to the table / model.  For tuners and tests.
+ *   dfl_conv_tune_add       table entry: key = {N, Hin, Win, Cin, Ntot, KH, KW, stride, pad, scatter2x2} -> geom; a key
+ *                           that is already present is replaced; key = NULL empties the table.  An entry is used when it
+ *                           is valid and agrees with the caller's `splits`. */
+int dfl_conv_candidates(const dfl_conv_args* a, int32_t* out, int32_t max_rows);
+int dfl_conv_force_geometry(const int32_t* geom);
+int dfl_conv_tune_add(const int32_t* key, const int32_t* geom);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Weight gradient of the same family of layers (torch autograd of unet.py:93,207,211,218,240):
  *   dw[(cm*Cg + cg)*T + t] = sum_m d[m, cm] * G(m, t, cg)

@@ -198,6 +198,79 @@ def test_convp_plain(case):
     np.testing.assert_allclose(st[1].numpy(), (yd * yd).sum(0).numpy(), rtol=2e-5, atol=2e-5 * float((yd * yd).sum(0).max()))
 
 
+def _candidates(N, Cin, Cout, H, W, K, stride, pad):
+    """Geometry candidates of a layer (dfl_conv_candidates needs pointers only to be non-null)."""
+    lib = nat.lib()
+    a = nat.ConvArgs()
+    a.x = a.w = a.y = 4096
+    a.x_bf16, a.y_bf16, a.w_split = 1, 1, 2
+    a.N, a.Hin, a.Win, a.Cin, a.ldx = N, H, W, Cin, Cin
+    a.KH, a.KW, a.stride, a.pad = K, K, stride, pad
+    a.Hout, a.Wout = (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1
+    a.Ntot = a.ldy = Cout
+    out = (C.c_int32 * (5 * 4096))()
+    n = nat.check(lib.dfl_conv_candidates(C.addressof(a), C.addressof(out), 4096), 'candidates')
+    return [tuple(out[5 * i + j] for j in range(5)) for i in range(min(n, 4096))]
+
+
+@pytest.mark.parametrize('case', [(2, 64, 128, 17, 11, 3, 1, 1), (4, 128, 256, 24, 24, 3, 1, 1), (3, 64, 64, 13, 9, 3, 1, 1),
+                                  (2, 32, 32, 24, 20, 3, 1, 1), (16, 256, 256, 6, 6, 3, 1, 1)])
+def test_convp_every_tile_configuration(case):
+    """The tuning table (dfl_conv_tune_add) may select any candidate of the geometry search: every tile configuration the
+    layer admits -- including the two-column-tile ones the cost model never picks -- is forced once per K-slice count
+    (dfl_conv_force_geometry) and must give the same result."""
+    N, Cin, Cout, H, W, K, stride, pad = case
+    lib = nat.lib()
+    g = torch.Generator().manual_seed(sum(case) + 7)
+    x = rb(torch.randn(N, Cin, H, W, generator=g))
+    w = rb(torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    wp = pack16(w, 1)
+    ref = nhwc(F.relu(F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=pad)))
+    cands = _candidates(*case)
+    seen, tiles = set(), set()
+    for geom in cands:
+        if (geom[0], geom[4]) in seen or geom[4] > 4:
+            continue
+        seen.add((geom[0], geom[4]))
+        tiles.add(geom[0])
+        gv = (C.c_int32 * 5)(*geom)
+        nat.check(lib.dfl_conv_force_geometry(C.addressof(gv)), 'force')
+        try:
+            y, st = conv_bf16(x, wp, Cout, K, K, stride, pad, ref.shape[1], ref.shape[2], bias=b, relu=1, stats=True, force_splits=geom[4])
+        finally:
+            lib.dfl_conv_force_geometry(None)
+        close_bf16(y, ref, '%s geometry %s' % (case, geom))
+        yd = y.double().reshape(-1, Cout)
+        np.testing.assert_allclose(st[0].numpy(), yd.sum(0).numpy(), rtol=2e-5, atol=2e-5 * float(yd.abs().sum(0).max()))
+    assert len(tiles) >= 3, tiles
+
+
+def test_convp_tuning_table_entry_is_used_and_validated():
+    lib = nat.lib()
+    case = (2, 64, 128, 16, 16, 3, 1, 1)
+    a = nat.ConvArgs()
+    a.x = a.w = a.y = 4096
+    a.x_bf16, a.y_bf16, a.w_split = 1, 1, 2
+    a.N, a.Hin, a.Win, a.Cin, a.ldx = 2, 16, 16, 64, 64
+    a.KH = a.KW = 3
+    a.stride, a.pad, a.Hout, a.Wout, a.Ntot, a.ldy = 1, 1, 16, 16, 128, 128
+    model = lib.dfl_conv_config(C.addressof(a))
+    other = [gm for gm in _candidates(*case) if gm[0] + 16 != model and gm[4] == 1][0]
+    key = (C.c_int32 * 10)(2, 16, 16, 64, 128, 3, 3, 1, 1, 0)
+    gv = (C.c_int32 * 5)(*other)
+    try:
+        nat.check(lib.dfl_conv_tune_add(C.addressof(key), C.addressof(gv)), 'tune_add')
+        assert lib.dfl_conv_config(C.addressof(a)) == other[0] + 16
+        bad = (C.c_int32 * 5)(other[0], 1, 64, 64, 1)            # a patch larger than the tile: ignored, the model decides
+        nat.check(lib.dfl_conv_tune_add(C.addressof(key), C.addressof(bad)), 'tune_add')
+        assert lib.dfl_conv_config(C.addressof(a)) == model
+    finally:
+        # leave the table as the library loaded it
+        lib.dfl_conv_tune_add(None, None)
+        nat.load_tuning(lib, nat.TUNE_PATH)
+
+
 @pytest.mark.parametrize('case', [(2, 32, 32, 20, 20, 3), (2, 64, 128, 12, 12, 3), (4, 256, 256, 6, 6, 3), (2, 128, 64, 9, 7, 1)])
 @pytest.mark.parametrize('splits', [None, 2])
 def test_convp_affine_residual_epilogue(case, splits):

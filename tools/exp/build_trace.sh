@@ -1,0 +1,11 @@
+#!/bin/bash
+# Diagnosis build: the library with phase clocks in the patch-resident convolution kernel -> tools/exp/bin/libdfl_trace.so
+set -euo pipefail
+root="$(cd "$(dirname "${BASH_SOURCE[0]}")/../.." && pwd)"
+src="$root/deepfluorolabeling-ipcai2020_amd/csrc"; lib="$root/deepfluorolabeling-ipcai2020_amd/lib"
+bash "$src/build.sh" >/dev/null
+mkdir -p "$root/tools/exp/bin"
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -DDFL_CONVP_TRACE -c "$src/convp_bf16.hip" -o "$root/tools/exp/bin/convp_trace.o"
+objs=$(ls "$lib"/*.o | grep -v convp_bf16.o)
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$root/tools/exp/bin/libdfl_trace.so" $objs "$root/tools/exp/bin/convp_trace.o"
+echo built tools/exp/bin/libdfl_trace.so

@@ -63,3 +63,8 @@ print('%s: step %.3f ms (%.0f images/s); op time fwd+bwd %.3f ms; ' % (os.enviro
 if os.environ.get('DETAIL'):
     for k, v in sorted(tot.items(), key=lambda kv: -kv[1]):
         print('    %-28s %7.3f ms %3d launches' % (k, v / reps, cnt[k]))
+if os.environ.get('LAYERS'):
+    det = []
+    bench.op_profile(plan, lib, nat, stream, detail=det)
+    plan.busy = False
+    print('\n'.join(det))

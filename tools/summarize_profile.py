@@ -24,7 +24,7 @@ def short(name):
     if not m:
         return re.sub(r'\(.*', '', name).replace('void ', '').replace('dfl::', '')[:80]
     args = [a.strip() for a in m.group(2).split(',')]
-    keep = {'conv_gemm_kernel': 4, 'conv_rows_kernel': 4, 'wgrad_kernel': 5}.get(m.group(1), len(args))
+    keep = {'conv_gemm_kernel': 4, 'conv_rows_kernel': 4, 'wgrad_kernel': 5, 'convp_kernel': 4, 'wgradp_kernel': 2}.get(m.group(1), len(args))
     return '%s<%s>' % (m.group(1), ','.join(args[:keep]))
 
 
