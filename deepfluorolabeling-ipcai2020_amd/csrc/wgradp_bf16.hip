@@ -18,6 +18,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+#include <vector>
+
 #include "common.h"
 #include "convp.h"
 
@@ -39,8 +42,10 @@ struct WgP {
   int sd, sg;                          // row pitch of the d / g images in bytes
   int dupp_shift, gupp_shift;          // log2(CMT / 8), log2(CGT / 8)
   int g_off;                           // byte offset of the g image behind the d image
+  int tab_off;                         // byte offset of the gathered-pixel offset table (P16 words) behind the g image
   int lds_bytes;
   int kpipe;                           // fragments of the next k-step are fetched under the matrix instructions of this one
+  long long* trace;                    // diagnosis build only (-DDFL_WGP_TRACE, tools/exp/wgradp_trace.py)
   uint32_t g_bytes, d_bytes;
 };
 
@@ -50,29 +55,6 @@ __device__ __forceinline__ uint32_t wpack_bf2(float a, float b) {
   const bf16x2_t h = __builtin_convertvector((f32x2_t){a, b}, bf16x2_t);
   return __builtin_bit_cast(uint32_t, h);
 }
-
-// (image, row, column) of a pixel index walked by a constant step without divisions
-struct Walk {
-  int img, y, x;
-  __device__ __forceinline__ void init(int idx, int H, int W) {
-    img = idx / (H * W);
-    const int r = idx - img * (H * W);
-    y = r / W;
-    x = r - y * W;
-  }
-  __device__ __forceinline__ void advance(int dy, int dx, int H, int W) {
-    x += dx;
-    y += dy;
-    if (x >= W) {
-      x -= W;
-      ++y;
-    }
-    while (y >= H) {
-      y -= H;
-      ++img;
-    }
-  }
-};
 
 // 8 consecutive pixels of one channel: two transposing reads (pixel rows at byte addresses r0 and r1 as seen by this lane)
 __device__ __forceinline__ bf16x8_t wtr_read8(const unsigned char* base, uint32_t r0, uint32_t r1) {
@@ -86,8 +68,14 @@ __device__ __forceinline__ bf16x8_t wtr_read8(const unsigned char* base, uint32_
 // a (cm32, cg32) pair of the workgroup tile and, when the tile has fewer than 4 pairs, a phase of the k-steps.  12 waves of
 // 48 accumulator registers (3x3) instead of 4 waves of 144: three waves per SIMD cover each other's LDS latency, the patch
 // is staged by three times the threads, and the register budget leaves room for the prefetch below.
+// Units (16 bytes) of the d / g images a workgroup may hold in flight in registers, per window height: the 3x3 kernel
+// (768 threads) fills a CU alone; the 2x2 and 1x1 kernels (512 / 256 threads) keep their register count at 128 so that
+// two / four workgroups share a CU and cover each other's barriers and load waits.
+__host__ __device__ constexpr int wgp_max_d_units(int KH) { return KH == 3 ? 2304 : 1024; }
+__host__ __device__ constexpr int wgp_max_g_units(int KH) { return KH == 3 ? 4608 : 2048; }
+
 template <int KH, int KW, bool AFF>
-__global__ void __launch_bounds__(256 * KH) wgradp_kernel(const WgP p) {
+__global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const WgP p) {
   constexpr int NT = 256 * KH;
   constexpr int T = KH * KW;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -121,56 +109,88 @@ __global__ void __launch_bounds__(256 * KH) wgradp_kernel(const WgP p) {
   const int dupp = p.CMT >> 3, gupp = p.CGT >> 3;
   const int npix_g = p.IPP * p.IH * p.IW;
   const int per_img = p.npy * p.npx;
+  uint32_t* gtab = reinterpret_cast<uint32_t*>(smem + p.tab_off);   // LDS offset of the gathered pixel of every patch pixel
 
   // Patch pipeline: the global loads of patch i + 1 are issued into registers before the k-steps of patch i run and are
-  // written to LDS after them.
-  constexpr int MAXD = (2048 + NT - 1) / NT, MAXG = (4096 + NT - 1) / NT;   // host: P16 * dupp <= 2048, npix_g * gupp <= 4096
+  // written to LDS after them.  Everything about a unit that does not depend on WHICH patch is staged is worked out once:
+  // its position inside the patch (y | x << 12 | image << 24 | live << 31) and its byte offset from the patch origin;
+  // per patch a unit costs a bounds test against the image and one add.
+  constexpr int MAXD = wgp_max_d_units(KH) / NT, MAXG = wgp_max_g_units(KH) / NT;   // host: P16 * dupp and npix_g * gupp stay below these
   wpu32x4 dreg[MAXD], greg[MAXG];
+  uint32_t dpos[MAXD], gpos[MAXG];
   uint32_t gok = 0;
   const int ddk = NT >> p.dupp_shift, gdk = NT >> p.gupp_shift;
   const int dcq = tid & (dupp - 1), gcq = tid & (gupp - 1);
   const int dc = cm0 + dcq * 8, gc = cg0 + gcq * 8;
-  float sc[8], sh[8];
-  if constexpr (AFF) {
+  const uint32_t dpitch = (uint32_t)a.ldd * 2u, gpitch = (uint32_t)a.ldg * 2u;
+  const int nd = (p.P16 * dupp + NT - 1) / NT, ng = (npix_g * gupp + NT - 1) / NT;   // units per thread actually in use (uniform)
+  {
+    const int PHW = p.PH * p.PW;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      sc[e] = (gc + e < a.Cg) ? a.in_scale[gc + e] : 1.f;
-      sh[e] = (gc + e < a.Cg) ? a.in_shift[gc + e] : 0.f;
+    for (int u = 0; u < MAXD; ++u) {
+      const int k = (tid >> p.dupp_shift) + u * ddk;
+      const int img = k / PHW, r = k - img * PHW;
+      const int y = r / p.PW, x = r - y * p.PW;
+      const bool live = k < p.P16 && img < p.IPP && dc < a.Cm;
+      dpos[u] = (uint32_t)y | ((uint32_t)x << 12) | ((uint32_t)(img & 127) << 24) | (live ? 0x80000000u : 0u);
+    }
+    const int IHW = p.IH * p.IW;
+#pragma unroll
+    for (int u = 0; u < MAXG; ++u) {
+      const int k = (tid >> p.gupp_shift) + u * gdk;
+      const int img = k / IHW, r = k - img * IHW;
+      const int y = r / p.IW, x = r - y * p.IW;
+      const bool live = k < npix_g && gc < a.Cg;
+      gpos[u] = (uint32_t)y | ((uint32_t)x << 12) | ((uint32_t)(img & 127) << 24) | (live ? 0x80000000u : 0u);
+    }
+    for (int j = tid; j < p.P16; j += NT) {
+      const int img = j / PHW, r = j - img * PHW;
+      const int y = r / p.PW, x = r - y * p.PW;
+      // rows beyond the patch: d is zero there, any valid g row will do
+      gtab[j] = img < p.IPP ? (uint32_t)((img * p.IH + y * a.stride) * p.IW + x * a.stride) * (uint32_t)p.sg : 0u;
+    }
+  }
+  // BatchNorm affine of the gathered tensor (applied when a unit is written to LDS): this thread's 8 channels, kept in LDS
+  // behind the offset table -- 16 registers that the 3x3 kernel does not have
+  float* aff = reinterpret_cast<float*>(smem + p.tab_off + p.P16 * 4);      // [2][CGT]
+  if constexpr (AFF) {
+    for (int c = tid; c < p.CGT; c += NT) {
+      aff[c] = (cg0 + c < a.Cg) ? a.in_scale[cg0 + c] : 1.f;
+      aff[p.CGT + c] = (cg0 + c < a.Cg) ? a.in_shift[cg0 + c] : 0.f;
     }
   }
   auto issue = [&](int patch, bool live) {
     const int pg = patch / per_img, pr = patch - pg * per_img;
     const int ppy = pr / p.npx, ppx = pr - ppy * p.npx;
     const int img0 = pg * p.IPP, oy0 = ppy * p.PH, ox0 = ppx * p.PW;
+    const int nleft = live ? a.N - img0 : 0;                       // images of this patch that exist
     {   // d: rows = patch pixels in patch order (image, row, column), zeros beyond the patch / image
-      Walk w;
-      w.init(tid >> p.dupp_shift, p.PH, p.PW);
-      const int dky = ddk / p.PW, dkx = ddk - dky * p.PW;
+      const uint32_t base = (uint32_t)(((img0 * a.Hout + oy0) * a.Wout + ox0) * a.ldd + dc) * 2u;
 #pragma unroll
       for (int u = 0; u < MAXD; ++u) {
-        const int k = (tid >> p.dupp_shift) + u * ddk;
-        const int n = img0 + w.img, oy = oy0 + w.y, ox = ox0 + w.x;
-        const bool ok = live && k < p.P16 && w.img < p.IPP && n < a.N && oy < a.Hout && ox < a.Wout && dc < a.Cm;
-        const uint32_t off = (uint32_t)((((n * a.Hout + oy) * a.Wout + ox) * a.ldd + dc) * 2);
-        dreg[u] = __builtin_amdgcn_raw_buffer_load_b128(rsD, ok ? off : WPOOB, 0, 0);
-        w.advance(dky, dkx, p.PH, p.PW);
+        if (u < nd) {
+          const uint32_t q = dpos[u];
+          const int qy = (int)(q & 0xfffu), qx = (int)((q >> 12) & 0xfffu), qi = (int)((q >> 24) & 127u);
+          const bool ok = (int)q < 0 && qi < nleft && oy0 + qy < a.Hout && ox0 + qx < a.Wout;
+          const uint32_t rel = (uint32_t)((qi * a.Hout + qy) * a.Wout + qx) * dpitch;
+          dreg[u] = __builtin_amdgcn_raw_buffer_load_b128(rsD, ok ? base + rel : WPOOB, 0, 0);
+        }
       }
     }
     {   // g: the gathered pixels of the patch with their halo, zero outside the image
       const int ybase = oy0 * a.stride - a.pad, xbase = ox0 * a.stride - a.pad;
-      Walk w;
-      w.init(tid >> p.gupp_shift, p.IH, p.IW);
-      const int dky = gdk / p.IW, dkx = gdk - dky * p.IW;
+      const uint32_t base = (uint32_t)(((img0 * a.Hin + ybase) * a.Win + xbase) * a.ldg + gc) * 2u;   // may wrap: base + rel is what counts
       gok = 0;
 #pragma unroll
       for (int u = 0; u < MAXG; ++u) {
-        const int pix = (tid >> p.gupp_shift) + u * gdk;
-        const int n = img0 + w.img, gy = ybase + w.y, gx = xbase + w.x;
-        const bool ok = live && pix < npix_g && n < a.N && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win && gc < a.Cg;
-        gok |= ok ? (1u << u) : 0u;
-        const uint32_t off = (uint32_t)((((n * a.Hin + gy) * a.Win + gx) * a.ldg + gc) * 2);
-        greg[u] = __builtin_amdgcn_raw_buffer_load_b128(rsG, ok ? off : WPOOB, 0, 0);
-        w.advance(dky, dkx, p.IH, p.IW);
+        if (u < ng) {
+          const uint32_t q = gpos[u];
+          const int qy = (int)(q & 0xfffu), qx = (int)((q >> 12) & 0xfffu), qi = (int)((q >> 24) & 127u);
+          const bool ok = (int)q < 0 && qi < nleft && (unsigned)(ybase + qy) < (unsigned)a.Hin && (unsigned)(xbase + qx) < (unsigned)a.Win;
+          gok |= ok ? (1u << u) : 0u;
+          const uint32_t rel = (uint32_t)((qi * a.Hin + qy) * a.Win + qx) * gpitch;
+          greg[u] = __builtin_amdgcn_raw_buffer_load_b128(rsG, ok ? base + rel : WPOOB, 0, 0);
+        }
       }
     }
   };
@@ -178,15 +198,18 @@ __global__ void __launch_bounds__(256 * KH) wgradp_kernel(const WgP p) {
 #pragma unroll
     for (int u = 0; u < MAXD; ++u) {
       const int k = (tid >> p.dupp_shift) + u * ddk;
-      if (k < p.P16) *reinterpret_cast<wpu32x4*>(Ds + (uint32_t)k * (uint32_t)p.sd + (uint32_t)dcq * 16u) = dreg[u];
+      if (u < nd && k < p.P16) *reinterpret_cast<wpu32x4*>(Ds + (uint32_t)k * (uint32_t)p.sd + (uint32_t)dcq * 16u) = dreg[u];
     }
 #pragma unroll
     for (int u = 0; u < MAXG; ++u) {
       const int pix = (tid >> p.gupp_shift) + u * gdk;
-      if (pix < npix_g) {
+      if (u < ng && pix < npix_g) {
         wpu32x4 v = greg[u];
         if constexpr (AFF) {   // zero padding applies AFTER the BatchNorm affine: outside pixels stay 0
           if ((gok >> u) & 1u) {
+            const float4 s0 = *reinterpret_cast<const float4*>(aff + gcq * 8), s1 = *reinterpret_cast<const float4*>(aff + gcq * 8 + 4);
+            const float4 h0 = *reinterpret_cast<const float4*>(aff + p.CGT + gcq * 8), h1 = *reinterpret_cast<const float4*>(aff + p.CGT + gcq * 8 + 4);
+            const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
             v.x = wpack_bf2(fmaf(wbf_lo(v.x), sc[0], sh[0]), fmaf(wbf_hi(v.x), sc[1], sh[1]));
             v.y = wpack_bf2(fmaf(wbf_lo(v.y), sc[2], sh[2]), fmaf(wbf_hi(v.y), sc[3], sh[3]));
             v.z = wpack_bf2(fmaf(wbf_lo(v.z), sc[4], sh[4]), fmaf(wbf_hi(v.z), sc[5], sh[5]));
@@ -201,36 +224,53 @@ __global__ void __launch_bounds__(256 * KH) wgradp_kernel(const WgP p) {
   const int pbegin = blockIdx.z * p.patches_per_slice;
   const int pend = min(pbegin + p.patches_per_slice, p.npatch);
   const int nsteps = p.P16 >> 4;
-  const int dj = 16 * p.phases;
-  const int djy = dj / p.PW, djx = dj - djy * p.PW;
-  const uint32_t row_off = (uint32_t)(ty * p.IW) * (uint32_t)p.sg;     // this wave's kernel row
+  const uint32_t gadd = g_col + (uint32_t)(ty * p.IW) * (uint32_t)p.sg;     // this wave's kernel row, this lane's channels
+  const uint32_t dstep = (uint32_t)(16 * p.phases) * (uint32_t)p.sd;
+#ifdef DFL_WGP_TRACE
+  long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  tr[0] = __builtin_amdgcn_s_memtime();
+  tr[6] = __builtin_amdgcn_s_memrealtime();
+#define WTR(i, t0) tr[i] += __builtin_amdgcn_s_memtime() - (t0);
+#define WT0(name) const long long name = __builtin_amdgcn_s_memtime();
+#else
+#define WTR(i, t0)
+#define WT0(name)
+#endif
   issue(pbegin, pbegin < pend);
   for (int patch = pbegin; patch < pend; ++patch) {
+    WT0(tb0)
     if (patch != pbegin) __syncthreads();               // every wave is done reading the previous images
+    WTR(1, tb0)
+    WT0(tc0)
     commit();
+    WTR(2, tc0)
+    WT0(tb1)
     __syncthreads();
+    WTR(1, tb1)
+    WT0(ti0)
     issue(patch + 1, patch + 1 < pend);
+    WTR(3, ti0)
+    WT0(tk0)
     // ---- k-steps of this patch (16 pixels each), this wave's phase; this lane's two pixel rows of a step are the
-    //      patch pixels j0 = 16 ks + trow and j0 + 4, walked without divisions
-    Walk w0, w1;
-    w0.init(phase * 16 + trow, p.PH, p.PW);
-    w1.init(phase * 16 + trow + 4, p.PH, p.PW);
+    //      patch pixels j0 = 16 ks + trow and j0 + 4: their d rows are j0 * sd, their g rows come from the offset table
+    uint32_t dr0 = (uint32_t)(phase * 16 + trow) * (uint32_t)p.sd + d_col;
+    const uint32_t* tp = gtab + phase * 16 + trow;
     for (int ks = phase; ks < nsteps; ks += p.phases) {
-      const uint32_t dr0 = (uint32_t)(ks * 16 + trow) * (uint32_t)p.sd + d_col;
-      const uint32_t dr1 = dr0 + 4u * (uint32_t)p.sd;
-      // rows beyond the patch: d is zero there, any valid g row will do
-      const uint32_t gr0 = (w0.img < p.IPP ? (uint32_t)((w0.img * p.IH + w0.y * a.stride) * p.IW + w0.x * a.stride) : 0u) * (uint32_t)p.sg + g_col + row_off;
-      const uint32_t gr1 = (w1.img < p.IPP ? (uint32_t)((w1.img * p.IH + w1.y * a.stride) * p.IW + w1.x * a.stride) : 0u) * (uint32_t)p.sg + g_col + row_off;
-      const bf16x8_t df = wtr_read8(Ds, dr0, dr1);
+      const uint32_t gr0 = tp[0] + gadd, gr1 = tp[4] + gadd;
+      const bf16x8_t df = wtr_read8(Ds, dr0, dr0 + 4u * (uint32_t)p.sd);
       bf16x8_t gf[KW];
 #pragma unroll
       for (int t = 0; t < KW; ++t) gf[t] = wtr_read8(Gs, gr0 + (uint32_t)(t * p.sg), gr1 + (uint32_t)(t * p.sg));
 #pragma unroll
       for (int t = 0; t < KW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, gf[t], acc[t], 0, 0, 0);
-      w0.advance(djy, djx, p.PH, p.PW);
-      w1.advance(djy, djx, p.PH, p.PW);
+      dr0 += dstep;
+      tp += 16 * p.phases;
     }
+    WTR(4, tk0)
   }
+#ifdef DFL_WGP_TRACE
+  tr[5] = __builtin_amdgcn_s_memtime();
+#endif
 
   // ---- waves that split the k-steps of the patches (phases > 1) add their accumulators through LDS, tap by tap, in a
   //      fixed order; the waves of phase 0 then own the workgroup's result for their (cm, cg) pair and kernel row
@@ -255,6 +295,16 @@ __global__ void __launch_bounds__(256 * KH) wgradp_kernel(const WgP p) {
     }
     if (phase > 0) return;
   }
+#ifdef DFL_WGP_TRACE
+  if (tid == 0 && p.trace != nullptr) {
+    long long* sink = p.trace + (int64_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 10;
+    for (int i = 0; i < 6; ++i) sink[i] = tr[i];
+    sink[6] = __builtin_amdgcn_s_memtime();
+    sink[7] = tr[6];
+    sink[8] = __builtin_amdgcn_s_memrealtime();
+    sink[9] = 1;
+  }
+#endif
   // ---- output: one partial slot per pixel slice
   const bool sliced = p.zslices > 1;
   float* out = sliced ? a.partial + (int64_t)blockIdx.z * a.Cm * a.Cg * T : a.dw;
@@ -322,41 +372,75 @@ static int wgp_plan(const dfl_wgrad_args* a, WgP* p, bool need_out) {
   p->gupp_shift = p->CGT == 64 ? 3 : 2;
   p->sd = pitch_for(p->CMT);
   p->sg = pitch_for(p->CGT);
-  // patch: whole images while they fit 256 pixels, else whole rows, else row pieces; bounded by the LDS budget and by
-  // what a thread can hold in flight (8 / 16 sixteen-byte units of d / g: P16 * CMT <= 16384, gathered pixels * CGT <= 32768)
-  const int HW = a->Hout * a->Wout;
-  int ipp = 1, ph, pw;
-  auto lds_of = [&](int ipp_, int ph_, int pw_) {
+  // Patch: the (images, rows, columns) box of output pixels that costs the least over the whole layer -- bytes staged
+  // (halo and the padding of the last 16-pixel step included) plus a fixed charge per patch for its two barriers and the
+  // pipeline bubble -- within what a thread can hold in flight (2048 / 4096 sixteen-byte units of d / g per workgroup)
+  // and the LDS budget.  Whole images are grouped while they fit.
+  const int64_t max_du = wgp_max_d_units(a->KH), max_gu = wgp_max_g_units(a->KH);
+  static const int lds_env = [] {
+    const char* e = getenv("DFL_WGP_LDS_KB");
+    return e ? atoi(e) * 1024 : 0;
+  }();
+  const int lds_cap = lds_env ? lds_env : (a->KH == 3 ? 120 * 1024 : (a->KH == 2 ? 72 * 1024 : 52 * 1024));
+  auto geom = [&](int ipp_, int ph_, int pw_, int64_t* lds, int64_t* du, int64_t* gu) {
     const int p16 = (ipp_ * ph_ * pw_ + 15) / 16 * 16;
     const int ih = (ph_ - 1) * a->stride + a->KH, iw = (pw_ - 1) * a->stride + a->KW;
-    return (int64_t)p16 * p->sd + (int64_t)ipp_ * ih * iw * p->sg;
+    *du = (int64_t)p16 * (p->CMT / 8);
+    *gu = (int64_t)ipp_ * ih * iw * (p->CGT / 8);
+    *lds = (int64_t)p16 * p->sd + (int64_t)ipp_ * ih * iw * p->sg + (int64_t)p16 * 4 + 512;
   };
   auto fits = [&](int ipp_, int ph_, int pw_) {
-    const int p16 = (ipp_ * ph_ * pw_ + 15) / 16 * 16;
-    const int ih = (ph_ - 1) * a->stride + a->KH, iw = (pw_ - 1) * a->stride + a->KW;
-    return lds_of(ipp_, ph_, pw_) <= 72 * 1024 && p16 * p->CMT <= 16384 && (int64_t)ipp_ * ih * iw * p->CGT <= 32768;
+    int64_t lds, du, gu;
+    geom(ipp_, ph_, pw_, &lds, &du, &gu);
+    return lds <= lds_cap && du <= max_du && gu <= max_gu && ipp_ <= 127 && ph_ < 4096 && pw_ < 4096;
   };
-  const int maxpix = 16384 / p->CMT;                     // 256 for 64-channel tiles, 512 for 32-channel ones
-  if (HW <= maxpix) {
-    ipp = maxpix / HW;
-    if (ipp > a->N) ipp = a->N;
-    ph = a->Hout;
-    pw = a->Wout;
-    while (ipp > 1 && !fits(ipp, ph, pw)) --ipp;
-  } else if (a->Wout <= maxpix) {
-    pw = a->Wout;
-    ph = maxpix / pw;
-  } else {
-    pw = 64;
-    ph = maxpix / 64;
+  int ipp = 0, ph = 0, pw = 0;
+  double best_cost = 1e300;
+  // the search depends on few numbers and runs at every launch: remembered per shape
+  struct PatchMemo { int key[8]; int ipp, ph, pw; };
+  static std::mutex memo_mu;
+  static std::vector<PatchMemo> memo;
+  const int mkey[8] = {a->N, a->Hout, a->Wout, a->stride, a->KH, a->KW, p->CMT, p->CGT};
+  bool found = false;
+  {
+    std::lock_guard<std::mutex> lock(memo_mu);
+    for (const PatchMemo& m : memo)
+      if (memcmp(m.key, mkey, sizeof(mkey)) == 0) {
+        ipp = m.ipp; ph = m.ph; pw = m.pw;
+        found = true;
+        break;
+      }
   }
-  if (ipp == 1) {
-    if (ph > a->Hout) ph = a->Hout;
-    while (ph > 1 && !fits(1, ph, pw)) --ph;
-    while (pw > 16 && !fits(1, ph, pw)) pw = (pw + 1) / 2;
-    while (ph * 2 <= a->Hout && fits(1, ph * 2, pw) && ph * 2 * pw <= maxpix) ph *= 2;   // narrower rows: more of them
+  auto consider = [&](int ipp_, int ph_, int pw_) {
+    if (ipp_ < 1 || ph_ < 1 || pw_ < 1 || ph_ > a->Hout || pw_ > a->Wout || !fits(ipp_, ph_, pw_)) return;
+    int64_t lds, du, gu;
+    geom(ipp_, ph_, pw_, &lds, &du, &gu);
+    const double npatch = (double)ceil_div(a->N, ipp_) * (double)ceil_div(a->Hout, ph_) * (double)ceil_div(a->Wout, pw_);
+    const double cost = npatch * ((double)(du + gu) * 16.0 + 24.0 * 1024.0);
+    if (cost < best_cost) {
+      best_cost = cost;
+      ipp = ipp_;
+      ph = ph_;
+      pw = pw_;
+    }
+  };
+  if (!found) {
+    for (int n = a->N; n >= 1; --n) consider(n, a->Hout, a->Wout);      // whole images
+    for (int pw_ = 4; pw_ <= a->Wout; ++pw_) {
+      if (pw_ != a->Wout && pw_ % 4 != 0) continue;
+      for (int ph_ = 1; ph_ <= a->Hout; ++ph_) {
+        if (!fits(1, ph_, pw_)) break;
+        consider(1, ph_, pw_);
+      }
+    }
+    if (ipp == 0) consider(1, 1, a->Wout < 4 ? a->Wout : 4);
+    DFL_REQUIRE(ipp > 0, "dfl_conv2d_wgrad (bf16): no patch of this layer fits the staging limits");
+    PatchMemo m;
+    memcpy(m.key, mkey, sizeof(mkey));
+    m.ipp = ipp; m.ph = ph; m.pw = pw;
+    std::lock_guard<std::mutex> lock(memo_mu);
+    if (memo.size() < 4096) memo.push_back(m);
   }
-  DFL_REQUIRE(fits(ipp, ph, pw), "dfl_conv2d_wgrad (bf16): no patch of this layer fits the staging limits");
   p->IPP = ipp;
   p->PH = ph;
   p->PW = pw;
@@ -372,8 +456,10 @@ static int wgp_plan(const dfl_wgrad_args* a, WgP* p, bool need_out) {
     return e ? atoi(e) : 1;
   }();
   p->kpipe = kpipe;
-  p->lds_bytes = p->g_off + ipp * p->IH * p->IW * p->sg;
-  if (p->lds_bytes < 3 * 4 * 3 * 16 * 64 * 4) p->lds_bytes = 3 * 4 * 3 * 16 * 64 * 4;   // room for the cross-phase sums
+  p->tab_off = (p->g_off + ipp * p->IH * p->IW * p->sg + 255) / 256 * 256;
+  p->lds_bytes = p->tab_off + p->P16 * 4 + 2 * p->CGT * 4;
+  const int red_bytes = (p->phases - 1) * p->pairs * a->KH * 16 * 64 * 4;   // room for the cross-phase sums
+  if (p->lds_bytes < red_bytes) p->lds_bytes = red_bytes;
   return DFL_OK;
 }
 
@@ -381,10 +467,15 @@ static int wgp_plan(const dfl_wgrad_args* a, WgP* p, bool need_out) {
 // gradients per step and 0.43 / 0.74 / 1.10 ms of partial sums)
 static int wgp_slices(const WgP& p) {
   const int64_t tiles = ceil_div(p.a.Cm, p.CMT) * ceil_div(p.a.Cg, p.CGT);
-  static const int target = [] {
+  static const int target3 = [] {
     const char* e = getenv("DFL_WGP_WGS");
     return e ? atoi(e) : 256;
   }();
+  static const int target21 = [] {                    // 2x2 / 1x1 windows: several workgroups per CU
+    const char* e = getenv("DFL_WGP_WGS21");
+    return e ? atoi(e) : 512;
+  }();
+  const int target = p.a.KH == 3 ? target3 : target21;
   int64_t z = ceil_div(target, tiles);
   if (z > p.npatch) z = p.npatch;
   if (z < 1) z = 1;
@@ -430,6 +521,14 @@ int wgradp_launch(const dfl_wgrad_args* a, hipStream_t s) {
   if (rc != DFL_OK) return rc;
   p.zslices = a->splits;                     // partial slots = pixel slices
   p.patches_per_slice = (int)ceil_div(p.npatch, p.zslices);
+#ifdef DFL_WGP_TRACE
+  {
+    const char* e = getenv("DFL_WGP_TRACE_PTR");
+    p.trace = e ? reinterpret_cast<long long*>(strtoull(e, nullptr, 0)) : nullptr;
+    fprintf(stderr, "wgradp: tile %dx%d pairs %d phases %d patch %dx%dx%d (P16 %d) gathered %dx%d slices %d patches/slice %d lds %d\n", p.CMT, p.CGT, p.pairs,
+            p.phases, p.IPP, p.PH, p.PW, p.P16, p.IH, p.IW, p.zslices, p.patches_per_slice, p.lds_bytes);
+  }
+#endif
   switch (p.T) {
     case 9: return wgp_launch_t<3, 3>(p, s);
     case 4: return wgp_launch_t<2, 2>(p, s);
