@@ -30,7 +30,7 @@ F32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, 
 BF16_MFMA_PEAK_TFLOPS = 2500.0        # same guide: dense bf16 MFMA (the 5 PF marketing figure is 2:1 sparse)
 # product arithmetic of the GEMM kernels (include/dfl_hip.h): name -> (mode, bf16 MFMA products per fp32 product)
 MATH = {'fp32': (0, 0), 'bf16x3': (1, 3), 'bf16x6': (2, 6), 'bf16': (3, 1), 'bf16s': (4, 1)}
-TRAFFIC_FILE = 'r01_traffic.json'      # per-kernel HBM bytes from the committed rocprofv3 --pmc passes of this round
+TRAFFIC_FILE = 'r02_traffic.json'      # per-kernel HBM bytes from the committed rocprofv3 --pmc passes of this round
 CONV_KERNELS = ['conv_gemm_kernel<2,2,2,2>', 'conv_gemm_kernel<2,2,2,1>', 'conv_gemm_kernel<4,1,2,1>',
                 'conv_gemm_kernel<2,2,1,1>', 'conv_gemm_kernel<1,2,1,1>', 'direct_conv_kernel',
                 'conv_rows_kernel<3,1,2,1>', 'conv_rows_kernel<3,1,1,2>', 'conv_rows_kernel<3,1,1,1>']
@@ -142,7 +142,7 @@ def cpu_baseline(B):
                          'workload': 'BASELINE configs[0]: batch 4, 7-class segmentation head only, Dice loss, SGD nesterov'}}
 
 
-def fwd_ms_per_img(lib, nat, dev):
+def fwd_ms_per_img(lib, nat, dev, math_name=''):
     """Second half of BASELINE.json's metric: eval-mode forward time per image -- batch 1 at 192x192 (the 8x-downsampled
     size) and the 5-net full-resolution ensemble of configs[4] (1436x1436 padded to 1440, one hipGraph replay per net plus
     the ensemble reduction of util.py:318-373)."""
@@ -183,6 +183,7 @@ def fwd_ms_per_img(lib, nat, dev):
     out['1440x1440_5net_ensemble'] = round(dt * 1e3, 3)
     out['1440x1440_per_net'] = round(dt * 1e3 / 5, 3)
     out['unit'] = 'ms per image'
+    out['math'] = math_name
     out['note'] = 'eval forward, inputs resident in HBM, hipGraph replay per net; ensemble figure includes dfl_ensemble_reduce'
     del nets
     torch.cuda.empty_cache()
@@ -202,11 +203,15 @@ def main():
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' for a self-test)")
     ap.add_argument('--optimizer', default='dfl', choices=['dfl', 'torch'],
                     help="dfl = dfl_amd.SGD (one dfl_sgd_step launch per contiguous run); torch = torch.optim.SGD")
-    ap.add_argument('--math', default='bf16x3', choices=sorted(MATH),
-                    help='product arithmetic of the conv / weight-gradient GEMMs: bf16x3 = fp32 values split into hi+lo '
-                         'bf16, 3 bf16 MFMA products, fp32 accumulate (BASELINE configs[1] is a bf16 configuration; this is '
-                         'tighter: 2^-16 per product, forward within the 1e-4 parity bar); fp32 = fp32 MFMA (the parity gate)')
+    ap.add_argument('--math', default='bf16s', choices=sorted(MATH),
+                    help='arithmetic of the conv / weight-gradient GEMMs.  bf16s (default) = BASELINE configs[1] as named: bf16 '
+                         'activations, activation gradients and GEMM weight copies in HBM, bf16 MFMA, fp32 accumulation / BatchNorm '
+                         'statistics / losses / weight gradients / master weights.  bf16x3 = fp32 tensors, values split into hi+lo '
+                         'bf16, 3 bf16 MFMA products (2^-16 per product: forward within the 1e-4 parity bar); fp32 = fp32 MFMA '
+                         '(the parity gate); bf16 = fp32 tensors, one bf16 product.  The other modes are timed beside the chosen one.')
     ap.add_argument('--no-fp32-reference', action='store_true', help='skip the extra fp32-product timing (profiling runs)')
+    ap.add_argument('--sync-loss', action='store_true', help='loss.item() right after every optimizer step (the reference loop verbatim) '
+                    'instead of reading each loss one step late')
     ap.add_argument('--no-overlap', action='store_true', help='all-reduce after backward instead of overlapped buckets')
     ap.add_argument('--force-dp', action='store_true',
                     help='keep the collective path on in a one-rank group (self-test of the RCCL path on a 1-GPU box)')
@@ -238,16 +243,20 @@ def main():
     x, tseg, theat = synth_batch(B, 4321 + rank, dev)
     net.train()
 
+    from dfl_amd.util import LateScalars
+    late = LateScalars(depth=0 if args.sync_loss else 1)   # as train.py's loop: every loss is read, one step late
+
     def step():
         opt.zero_grad()
         seg, heat = net(x)
         loss = crit((dfl_amd.center_crop(seg, tseg.shape), dfl_amd.center_crop(heat, theat.shape)), (tseg, theat))
         loss.backward()
         opt.step()
-        return loss.item()          # train.py:430 synchronises every step; so do we
+        return late.push(loss)      # train.py:430 reads the loss of every step; so do we (all of them, see the flush below)
 
     for _ in range(args.warmup):
         step()
+    late.flush()
     multi = dist.is_initialized()          # (also a one-rank group under --force-dp)
     if multi:
         dist.barrier()
@@ -256,6 +265,7 @@ def main():
     last = 0.0
     for _ in range(args.steps):
         last = step()
+    last = (late.flush() or [last])[-1]     # inside the timed region: every loss value has reached the host
     torch.cuda.synchronize()
     if multi:
         dist.barrier()
@@ -320,35 +330,30 @@ def main():
         extra['kernels'] = {k: {'ms': round(v[0], 3), 'tflops': round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[0] > 0 and v[1] > 0 else None,
                                 'launches': v[2]} for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0])}
 
-    if rank == 0 and world == 1 and not args.no_profile and args.math != 'fp32' and not args.no_fp32_reference:
-        # the same step with fp32 MFMA products (the mode every parity test is written for), for reference
-        nat.check(lib.dfl_set_math_mode(0), 'dfl_set_math_mode')
-        for _ in range(3):
-            step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
+    if rank == 0 and world == 1 and not args.no_profile and not args.no_fp32_reference:
+        # the same step in the other arithmetic modes, for reference: fp32 MFMA products (the mode the 1e-4 forward bar is
+        # written for), fp32 tensors with 3 bf16 products per product (bf16x3, inside that bar), fp32 tensors with plain bf16
+        # products, bf16 storage (BASELINE configs[1] as named)
         n32 = 10
-        for _ in range(n32):
-            step()
-        torch.cuda.synchronize()
-        d32 = time.perf_counter() - t0
-        extra['fp32_products'] = {'value': round(B * n32 / d32, 2), 'ms_per_step': round(d32 / n32 * 1e3, 3), 'steps': n32}
-        if args.math != 'bf16':
-            # ... and with plain bf16 products (the arithmetic BASELINE configs[1] names; outside the 1e-4 forward bar)
-            nat.check(lib.dfl_set_math_mode(3), 'dfl_set_math_mode')
+        for mode, key in (('fp32', 'fp32_products'), ('bf16x3', 'bf16x3_products'), ('bf16', 'bf16_products'), ('bf16s', 'bf16_storage')):
+            if mode == args.math:
+                continue
+            nat.check(lib.dfl_set_math_mode(MATH[mode][0]), 'dfl_set_math_mode')
             for _ in range(3):
                 step()
+            late.flush()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(n32):
                 step()
+            late.flush()
             torch.cuda.synchronize()
-            d16 = time.perf_counter() - t0
-            extra['bf16_products'] = {'value': round(B * n32 / d16, 2), 'ms_per_step': round(d16 / n32 * 1e3, 3), 'steps': n32}
+            dside = time.perf_counter() - t0
+            extra[key] = {'value': round(B * n32 / dside, 2), 'ms_per_step': round(dside / n32 * 1e3, 3), 'steps': n32}
         nat.check(lib.dfl_set_math_mode(MATH[args.math][0]), 'dfl_set_math_mode')
 
     if rank == 0 and world == 1 and not args.no_profile and not args.no_fwd:
-        extra['fwd_ms_per_img'] = fwd_ms_per_img(lib, nat, dev)
+        extra['fwd_ms_per_img'] = fwd_ms_per_img(lib, nat, dev, args.math)
     nat.check(lib.dfl_set_math_mode(mode_before), 'dfl_set_math_mode')
 
     cpu = None

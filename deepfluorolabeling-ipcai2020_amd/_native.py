@@ -81,7 +81,8 @@ class HeadBwdArgs(C.Structure):
     _fields_ = [('x', fp), ('seg', fp), ('dseg', fp), ('dheat', fp), ('w_seg', fp), ('w_l1', fp), ('w_l2', fp),
                 ('dx', fp), ('scratch', fp),
                 ('N', i32), ('H', i32), ('W', i32), ('F', i32), ('ldx', i32), ('lddx', i32),
-                ('NC', i32), ('NM', i32), ('L', i32), ('softmax', i32), ('scratch_ld', i32), ('x_bf16', i32)]
+                ('NC', i32), ('NM', i32), ('L', i32), ('softmax', i32), ('scratch_ld', i32), ('x_bf16', i32),
+                ('dw_seg', fp), ('dw_l1', fp), ('dw_l2', fp), ('wg_partial', fp)]
 
 
 class LossArgs(C.Structure):
@@ -172,7 +173,8 @@ EXPORTS = ['dfl_version', 'dfl_last_error', 'dfl_sizeof', 'dfl_conv2d', 'dfl_con
            'dfl_exec_timed', 'dfl_conv_config', 'dfl_wgrad_config', 'dfl_conv_suggest_splits', 'dfl_reduce_batch',
            'dfl_reduce_job_blocks', 'dfl_prep_batch', 'dfl_prep_scratch_doubles', 'dfl_est_lands', 'dfl_hard_dice', 'dfl_get_math_mode',
            'dfl_set_math_mode', 'dfl_graph_capture', 'dfl_graph_launch', 'dfl_graph_nodes', 'dfl_graph_destroy',
-           'dfl_set_conv_rows_min_tiles', 'dfl_conv_candidates', 'dfl_conv_force_geometry', 'dfl_conv_tune_add']
+           'dfl_set_conv_rows_min_tiles', 'dfl_conv_candidates', 'dfl_conv_force_geometry', 'dfl_conv_tune_add',
+           'dfl_head_wgrad_blocks']
 
 
 class DflError(RuntimeError):
@@ -227,6 +229,7 @@ def lib():
     for fn in ('dfl_conv_grid_m', 'dfl_wgrad_suggest_splits', 'dfl_conv_suggest_splits'):
         getattr(L, fn).argtypes = [fp]
     L.dfl_conv_candidates.argtypes = [fp, fp, i32]
+    L.dfl_head_wgrad_blocks.argtypes = [i64]
     L.dfl_conv_force_geometry.argtypes = [fp]
     L.dfl_conv_tune_add.argtypes = [fp, fp]
     for k, cls in enumerate(_SIZEOF_ORDER):

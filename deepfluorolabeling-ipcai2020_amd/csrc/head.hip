@@ -11,8 +11,12 @@
 // => unit-stride stores per channel plane).  HBM-bound: 4*F bytes in, 4*(NC+L) bytes out per pixel.
 // The backward kernel recomputes logits and mid from x (cheaper than saving them), applies the softmax Jacobian
 //  and leaves dx plus a per-pixel scratch row from which the three small weight gradients are
-// taken by dfl_conv2d_wgrad.
+// taken by dfl_conv2d_wgrad.  With bf16 features (F = 32) the weight gradients are taken inside the kernel instead (the
+// scratch is 448 bytes per pixel to write and read back): a tile's rows [dlogits | dmid | dheat] and [x | logits | mid] go
+// to LDS as bf16, four waves multiply them on the matrix cores through transposing LDS reads (contraction over pixels,
+// as csrc/wgradp_bf16.hip), workgroups leave 64 x 64 fp32 partials and head_wgrad_finish_kernel adds them up.
 #include "common.h"
+
 
 namespace dfl {
 
@@ -21,6 +25,18 @@ constexpr int MAXNC = DFL_HEAD_MAX_NC, MAXL = DFL_HEAD_MAX_L, MAXNM = DFL_HEAD_M
 static inline int head_fc(int F) { return ((F + MAXNC) + 3) / 4 * 4; }
 
 constexpr int HT = 256;   // pixels per workgroup tile
+
+__device__ __forceinline__ unsigned hpack2(float x, float y) {   // two floats -> two bf16 (round to nearest even)
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){x, y}, bf16x2_t));
+}
+// 8 consecutive pixels of one column of a [pixel][column] bf16 image: two transposing reads (csrc/wgradp_bf16.hip)
+__device__ __forceinline__ bf16x8_t htr_read8(const unsigned char* base, uint32_t r0, uint32_t r1) {
+  typedef short hs16x4_t __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) hs16x4_t* lds_p;
+  const hs16x4_t x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + r0));
+  const hs16x4_t y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + r1));
+  return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7));
+}
 
 // tile[p][0..F) = x[m0 + p][0..F) (zeros past M); optionally the same values go to cat[(m0 + p) * cat_ld + ..] (scratch)
 __device__ __forceinline__ void head_load_tile(float* tile, int pitch, const float* __restrict__ x, int ldx, int64_t m0,
@@ -173,7 +189,8 @@ HEAD_TPL __global__ void __launch_bounds__(256) head_fwd_kernel(const dfl_head_f
   }
 }
 
-HEAD_TPL __global__ void __launch_bounds__(256) head_bwd_kernel(const dfl_head_bwd_args a, int Fc, const float* __restrict__ w_seg,
+template <int NCc, int NMc, int Lc, bool GEN, bool FUSED>
+__global__ void __launch_bounds__(256) head_bwd_kernel(const dfl_head_bwd_args a, int Fc, const float* __restrict__ w_seg,
                                                       const float* __restrict__ w_l1, const float* __restrict__ w_l2) {
   extern __shared__ __attribute__((aligned(16))) float tile[];
   HEAD_BOUNDS
@@ -184,23 +201,54 @@ HEAD_TPL __global__ void __launch_bounds__(256) head_bwd_kernel(const dfl_head_b
   const int64_t M = (int64_t)a.N * HW;
   const bool lands = L > 0 && a.dheat != nullptr;
   const int o_dlg = Fc, o_dmid = Fc + MAXNC, o_mid = o_dmid + MAXNM, o_dh = o_mid + MAXNM;   // all multiples of 4
+  // fused weight gradients: rows of 320 bytes behind the feature tile, 128 pixels at a time --
+  //   bytes [0,128): dlogits (8) | dmid (24) | dheat (16) | 0 (16)      bytes [128,256): x (32) | logits (8) | mid (24)   (bf16)
+  constexpr bool fused = FUSED;
+  unsigned char* ab = reinterpret_cast<unsigned char*>(tile) + (size_t)HT * pitch * sizeof(float);
+  constexpr int ABP = 320, ABH = 128;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int trow = 8 * (lane >> 5) + ((lane & 15) >> 2);
+  const uint32_t tcb = (uint32_t)((16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
+  const uint32_t a_col = (uint32_t)((wave >> 1) * 64) + tcb, b_col = 128u + (uint32_t)((wave & 1) * 64) + tcb;
+  f32x16 wacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) wacc[r] = 0.f;
   for (int64_t m0 = (int64_t)blockIdx.x * HT; m0 < M; m0 += (int64_t)gridDim.x * HT) {
     __syncthreads();
-    head_load_tile(tile, pitch, a.x, a.ldx, m0, M, F, a.scratch, a.scratch_ld, a.x_bf16);   // also copies x into the cat columns
+    head_load_tile(tile, pitch, a.x, a.ldx, m0, M, F, fused ? nullptr : a.scratch, a.scratch_ld, a.x_bf16);   // also copies x into the cat columns
     __syncthreads();
     const int64_t m = m0 + threadIdx.x;
+    uint4 rowA[8], rowB[8];                 // this pixel's two bf16 rows (fused form): 8 x 16 bytes each
+    if (fused) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) rowA[q] = rowB[q] = make_uint4(0u, 0u, 0u, 0u);
+    }
     if (m < M) {
       float* myrow = tile + threadIdx.x * pitch;
-      float* sr = a.scratch + m * a.scratch_ld;
+      float* sr = fused ? nullptr : a.scratch + m * a.scratch_ld;
       float lg[MAXNC], mid[MAXNM];
       head_features<NCc, NMc, Lc, GEN>(myrow, w_seg, w_l1, F, NC, NM, L > 0, lg, mid);
       const int64_t n = m / HW, pp = m - n * HW;
+      if (fused) {                          // x (exact: it was bf16), logits, mid
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v0 = *reinterpret_cast<const float4*>(myrow + 8 * q), v1 = *reinterpret_cast<const float4*>(myrow + 8 * q + 4);
+          rowB[q] = make_uint4(hpack2(v0.x, v0.y), hpack2(v0.z, v0.w), hpack2(v1.x, v1.y), hpack2(v1.z, v1.w));
+        }
+        rowB[4] = make_uint4(hpack2(lg[0], lg[1]), hpack2(lg[2], lg[3]), hpack2(lg[4], lg[5]), hpack2(lg[6], lg[7]));
+        const bool has = L > 0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          rowB[5 + q] = make_uint4(hpack2(has ? mid[8 * q] : 0.f, has ? mid[8 * q + 1] : 0.f), hpack2(has ? mid[8 * q + 2] : 0.f, has ? mid[8 * q + 3] : 0.f),
+                                   hpack2(has ? mid[8 * q + 4] : 0.f, has ? mid[8 * q + 5] : 0.f), hpack2(has ? mid[8 * q + 6] : 0.f, has ? mid[8 * q + 7] : 0.f));
+      } else {
       // cat tail: logits then zero pad (16-byte stores: the scratch row is 16-byte aligned, every block a multiple of 4)
 #pragma unroll
       for (int c = 0; c < MAXNC; c += 4)
         *reinterpret_cast<float4*>(sr + F + c) = make_float4(c + 0 < NC ? lg[c + 0] : 0.f, c + 1 < NC ? lg[c + 1] : 0.f,
                                                              c + 2 < NC ? lg[c + 2] : 0.f, c + 3 < NC ? lg[c + 3] : 0.f);
       for (int c = F + MAXNC; c < Fc; c += 4) *reinterpret_cast<float4*>(sr + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
       // landmark branch
       float dmid[MAXNM], dh[MAXL];
 #pragma unroll
@@ -246,6 +294,17 @@ HEAD_TPL __global__ void __launch_bounds__(256) head_bwd_kernel(const dfl_head_b
         }
         dlg[c] = v;
       }
+      if (fused) {
+        rowA[0] = make_uint4(hpack2(dlg[0], dlg[1]), hpack2(dlg[2], dlg[3]), hpack2(dlg[4], dlg[5]), hpack2(dlg[6], dlg[7]));
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          rowA[1 + q] = make_uint4(hpack2(dmid[8 * q], dmid[8 * q + 1]), hpack2(dmid[8 * q + 2], dmid[8 * q + 3]),
+                                   hpack2(dmid[8 * q + 4], dmid[8 * q + 5]), hpack2(dmid[8 * q + 6], dmid[8 * q + 7]));
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          rowA[4 + q] = make_uint4(hpack2(dh[8 * q], dh[8 * q + 1]), hpack2(dh[8 * q + 2], dh[8 * q + 3]),
+                                   hpack2(dh[8 * q + 4], dh[8 * q + 5]), hpack2(dh[8 * q + 6], dh[8 * q + 7]));
+      } else {
 #pragma unroll
       for (int c = 0; c < MAXNC; c += 4)
         *reinterpret_cast<float4*>(sr + o_dlg + c) = make_float4(dlg[c], dlg[c + 1], dlg[c + 2], dlg[c + 3]);
@@ -258,6 +317,7 @@ HEAD_TPL __global__ void __launch_bounds__(256) head_bwd_kernel(const dfl_head_b
       }
 #pragma unroll
       for (int l = 0; l < MAXL; l += 4) *reinterpret_cast<float4*>(sr + o_dh + l) = make_float4(dh[l], dh[l + 1], dh[l + 2], dh[l + 3]);
+      }
       // dx = Wseg^T dlogits + W1[:, :F]^T dmid, into this thread's own tile row (x is no longer needed)
       for (int k = 0; k < F; k += 4) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -280,6 +340,27 @@ HEAD_TPL __global__ void __launch_bounds__(256) head_bwd_kernel(const dfl_head_b
           }
         }
         *reinterpret_cast<float4*>(myrow + k) = acc;
+      }
+    }
+    if (fused) {            // weight gradients of this tile: two halves of 128 pixels through the row image
+      for (int half = 0; half < 2; ++half) {
+        if (half) __syncthreads();          // the waves are done reading the first half
+        if ((threadIdx.x >> 7) == half) {
+          uint4* dst = reinterpret_cast<uint4*>(ab + (size_t)(threadIdx.x & (ABH - 1)) * ABP);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            dst[q] = rowA[q];
+            dst[8 + q] = rowB[q];
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < ABH / 16; ++ks) {
+          const uint32_t r0 = (uint32_t)(ks * 16 + trow) * (uint32_t)ABP, r1 = r0 + 4u * (uint32_t)ABP;
+          const bf16x8_t af = htr_read8(ab, r0 + a_col, r1 + a_col);
+          const bf16x8_t bf = htr_read8(ab, r0 + b_col, r1 + b_col);
+          wacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, wacc, 0, 0, 0);
+        }
       }
     }
     __syncthreads();
@@ -306,6 +387,39 @@ HEAD_TPL __global__ void __launch_bounds__(256) head_bwd_kernel(const dfl_head_b
       if (m0 + p < M) *reinterpret_cast<float4*>(a.dx + (m0 + p) * a.lddx + 4 * q) = *reinterpret_cast<const float4*>(tile + p * pitch + 4 * q);
     }
   }
+  if (fused) {              // partial[block][row of A (64)][column of B (64)]
+    float* part = a.wg_partial + (int64_t)blockIdx.x * 4096;
+    const int col = (wave & 1) * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[((wave >> 1) * 32 + mfma32_row(r, lane)) * 64 + col] = wacc[r];
+  }
+}
+
+// Sums the workgroup partials of the fused head weight gradients (fixed order, fp64) and files the three blocks of the
+// 64 x 64 product: rows 0-7 x columns 0-31 -> dw_seg, rows 8-31 x columns 0-39 -> dw_l1, rows 32-47 x columns 40-63 -> dw_l2.
+__global__ void __launch_bounds__(256) head_wgrad_finish_kernel(const float* __restrict__ partial, int nblocks, float* __restrict__ dw_seg,
+                                                                float* __restrict__ dw_l1, float* __restrict__ dw_l2, int F, int NC, int NM, int L) {
+  const int e = blockIdx.x * 256 + threadIdx.x;       // element of the 64 x 64 product
+  const int row = e >> 6, col = e & 63;
+  float* dst = nullptr;
+  if (row < 8) {
+    if (row < NC && col < F) dst = dw_seg + row * F + col;
+  } else if (row < 32) {
+    if (dw_l1 != nullptr && row - 8 < NM && col < F + NC) dst = dw_l1 + (row - 8) * (F + NC) + col;
+  } else if (row < 48) {
+    if (dw_l2 != nullptr && row - 32 < L && col >= 40 && col - 40 < NM) dst = dw_l2 + (row - 32) * NM + (col - 40);
+  }
+  if (dst == nullptr) return;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int b = 0;
+  for (; b + 3 < nblocks; b += 4) {
+    s0 += (double)partial[(int64_t)b * 4096 + e];
+    s1 += (double)partial[(int64_t)(b + 1) * 4096 + e];
+    s2 += (double)partial[(int64_t)(b + 2) * 4096 + e];
+    s3 += (double)partial[(int64_t)(b + 3) * 4096 + e];
+  }
+  for (; b < nblocks; ++b) s0 += (double)partial[(int64_t)b * 4096 + e];
+  *dst = (float)((s0 + s1) + (s2 + s3));
 }
 
 static int head_check(int F, int NC, int NM, int L, const void* w_l1, const void* w_l2, int ldx, const void* x, int x_bf16 = 0) {
@@ -362,20 +476,56 @@ extern "C" int dfl_head_fwd(const dfl_head_fwd_args* a, dfl_stream_t stream) {
   return check_launch("dfl_head_fwd");
 }
 
+static unsigned head_wgrad_grid(int64_t M) {
+  int64_t b = ceil_div(M, HT);
+  if (b > 512) b = 512;                     // two workgroups per CU walk the tiles; one partial each
+  return (unsigned)(b < 1 ? 1 : b);
+}
+
+extern "C" int dfl_head_wgrad_blocks(int64_t M) {
+  DFL_REQUIRE(M > 0, "dfl_head_wgrad_blocks: bad size");
+  return (int)head_wgrad_grid(M);
+}
+
 extern "C" int dfl_head_bwd(const dfl_head_bwd_args* a, dfl_stream_t stream) {
-  DFL_REQUIRE(a && a->x && a->seg && a->dseg && a->w_seg && a->dx && a->scratch, "dfl_head_bwd: missing pointer");
+  DFL_REQUIRE(a && a->x && a->seg && a->dseg && a->w_seg && a->dx && (a->scratch || a->dw_seg), "dfl_head_bwd: missing pointer");
   DFL_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->ldx >= a->F && a->lddx >= a->F, "dfl_head_bwd: bad sizes");
   int rc = head_check(a->F, a->NC, a->NM, a->L, a->w_l1, a->w_l2, a->ldx, a->x, a->x_bf16);
   if (rc != DFL_OK) return rc;
   DFL_REQUIRE(a->lddx % (a->x_bf16 ? 8 : 4) == 0 && aligned16(a->dx), "dfl_head_bwd: dx alignment");
-  DFL_REQUIRE(a->scratch_ld >= dfl_head_scratch_ld(a->F) && a->scratch_ld % 4 == 0 && aligned16(a->scratch),
-              "dfl_head_bwd: scratch_ld too small or misaligned");
+  const bool fused = a->dw_seg != nullptr;
   const int64_t M = (int64_t)a->N * a->H * a->W;
-#define DFL_HB(NC_, NM_, L_, G_) hipLaunchKernelGGL((head_bwd_kernel<NC_, NM_, L_, G_>), dim3(head_grid(M)), dim3(HT), \
-    (size_t)HT * (a->F + 4) * sizeof(float), static_cast<hipStream_t>(stream), *a, head_fc(a->F), a->w_seg, a->w_l1, a->w_l2)
+  size_t lds = (size_t)HT * (a->F + 4) * sizeof(float);
+  unsigned grid = head_grid(M);
+  if (fused) {
+    DFL_REQUIRE(a->x_bf16 && a->F == 32, "dfl_head_bwd: the fused weight gradients need bf16 features with F == 32 (F = %d)", a->F);
+    DFL_REQUIRE(a->wg_partial != nullptr && aligned16(a->wg_partial), "dfl_head_bwd: wg_partial (dfl_head_wgrad_blocks(M) * 4096 floats) is required");
+    DFL_REQUIRE((a->L == 0 || a->dw_l1 != nullptr) && ((a->L > 0 && a->w_l2 != nullptr) == (a->dw_l2 != nullptr)),
+                "dfl_head_bwd: dw_l1 / dw_l2 must be given exactly for the landmark layers the head has");
+    lds += 128 * 320;
+    grid = head_wgrad_grid(M);
+  } else {
+    DFL_REQUIRE(a->scratch_ld >= dfl_head_scratch_ld(a->F) && a->scratch_ld % 4 == 0 && aligned16(a->scratch),
+                "dfl_head_bwd: scratch_ld too small or misaligned");
+  }
+  hipStream_t hs = static_cast<hipStream_t>(stream);
+#define DFL_HB(NC_, NM_, L_, G_)                                                                                              \
+  do {                                                                                                                        \
+    if (fused) {                                                                                                              \
+      auto k = head_bwd_kernel<NC_, NM_, L_, G_, true>;                                                                       \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+      hipLaunchKernelGGL(k, dim3(grid), dim3(HT), lds, hs, *a, head_fc(a->F), a->w_seg, a->w_l1, a->w_l2);                    \
+    } else {                                                                                                                  \
+      hipLaunchKernelGGL((head_bwd_kernel<NC_, NM_, L_, G_, false>), dim3(grid), dim3(HT), lds, hs, *a, head_fc(a->F), a->w_seg, a->w_l1, a->w_l2); \
+    }                                                                                                                         \
+  } while (0)
   if (a->NC == 7 && a->L == 14 && a->NM == 21 && a->w_l2 != nullptr) DFL_HB(7, 21, 14, false);
   else if (a->NC == 7 && a->L == 0) DFL_HB(7, 0, 0, false);
   else DFL_HB(0, 0, 0, true);
 #undef DFL_HB
-  return check_launch("dfl_head_bwd");
+  int rc2 = check_launch("dfl_head_bwd");
+  if (rc2 != DFL_OK || !fused) return rc2;
+  hipLaunchKernelGGL(head_wgrad_finish_kernel, dim3(16), dim3(256), 0, hs, a->wg_partial, (int)grid, a->dw_seg, a->dw_l1, a->dw_l2, a->F,
+                     a->NC, a->NM, a->L);
+  return check_launch("dfl_head_bwd (weight-gradient sums)");
 }

@@ -628,24 +628,38 @@ class UNetPlan:
         # heads
         sld = self.lib.dfl_head_scratch_ld(F)
         M = u.M
-        scratch = self._new(M * sld)
         dfeat = self._act(N, u.H, u.W, F)
+        # bf16 features of the paper's width: the head kernel takes its three weight gradients itself (include/dfl_hip.h);
+        # otherwise it leaves a per-pixel scratch row and three 1x1 weight-gradient launches follow
+        fused_head = bool(u.bf16) and F == 32 and os.environ.get('DFL_HEAD_FUSED', '1') != '0'
         self.head_bwd = HeadBwdArgs(x=u.ptr, w_seg=w_seg.data_ptr(), w_l1=nat.ptr(w_l1), w_l2=nat.ptr(w_l2),
-                                    dx=dfeat.ptr, scratch=scratch.data_ptr(), N=N, H=u.H, W=u.W, F=F, ldx=u.ld,
+                                    dx=dfeat.ptr, N=N, H=u.H, W=u.W, F=F, ldx=u.ld,
                                     lddx=dfeat.ld, NC=NC, NM=NM, L=L, softmax=1 if cfg['do_soft_max'] else 0,
                                     scratch_ld=sld, x_bf16=u.bf16)
+        if fused_head:
+            part = self._new(4096 * nat.check(self.lib.dfl_head_wgrad_blocks(M), 'dfl_head_wgrad_blocks'))
+            self.head_bwd.wg_partial = part.data_ptr()
+            self.head_bwd.dw_seg = self.G['seg_conv.weight'].data_ptr()
+            if L > 0:
+                self.head_bwd.dw_l1 = self.G['lands_1x1.0.weight'].data_ptr()
+                if w_l2 is not None:
+                    self.head_bwd.dw_l2 = self.G['lands_1x1.1.weight'].data_ptr()
+        else:
+            scratch = self._new(M * sld)
+            self.head_bwd.scratch = scratch.data_ptr()
         if self.PACK_OVERLAP:
             bwd.wait(self.EV_PACK_DONE, stream=0)      # data-gradient weight layouts are packed on the side stream
         bwd.add(self.head_bwd)
-        off = [self.lib.dfl_head_scratch_off(F, k) for k in range(5)]
+        if not fused_head:
+            off = [self.lib.dfl_head_scratch_off(F, k) for k in range(5)]
 
-        def sact(o, c):
-            return Act(scratch, scratch.data_ptr() + 4 * o, sld, N, u.H, u.W, c)
-        self._wgrad(bwd, sact(off[0], F), sact(off[1], NC), self.G['seg_conv.weight'], 1, 1, 1, 0, u.H, u.W)
-        if L > 0:
-            self._wgrad(bwd, sact(off[0], F + NC), sact(off[2], NM), self.G['lands_1x1.0.weight'], 1, 1, 1, 0, u.H, u.W)
-            if w_l2 is not None:
-                self._wgrad(bwd, sact(off[3], NM), sact(off[4], L), self.G['lands_1x1.1.weight'], 1, 1, 1, 0, u.H, u.W)
+            def sact(o, c):
+                return Act(scratch, scratch.data_ptr() + 4 * o, sld, N, u.H, u.W, c)
+            self._wgrad(bwd, sact(off[0], F), sact(off[1], NC), self.G['seg_conv.weight'], 1, 1, 1, 0, u.H, u.W)
+            if L > 0:
+                self._wgrad(bwd, sact(off[0], F + NC), sact(off[2], NM), self.G['lands_1x1.0.weight'], 1, 1, 1, 0, u.H, u.W)
+                if w_l2 is not None:
+                    self._wgrad(bwd, sact(off[3], NM), sact(off[4], L), self.G['lands_1x1.1.weight'], 1, 1, 1, 0, u.H, u.W)
 
         # up path, last block first
         # Column sums ride on the kernels that produce the tensors: the conv that completes dcat leaves sum(dy) (the

@@ -326,8 +326,16 @@ typedef struct {
   int32_t softmax;
   int32_t scratch_ld;     /* >= dfl_head_scratch_ld(F) */
   int32_t x_bf16;         /* 1: x and dx are bf16 tensors; the scratch rows stay fp32 */
+  /* Fused weight gradients (bf16 features with F == 32 only): when dw_seg is set the kernel takes the three weight
+   * gradients itself -- per pixel tile the rows [dlogits | dmid | dheat] and [x | logits | mid], rounded to bf16, are
+   * multiplied on the matrix cores (fp32 accumulation), every workgroup leaves one 64 x 64 partial in wg_partial
+   * (dfl_head_wgrad_blocks(M) * 4096 floats) and a finish kernel of the same call sums them, in a fixed order, into
+   * dw_seg [NC][F], dw_l1 [NM][F+NC] and dw_l2 [L][NM] (NULL where the head has no such layer).  `scratch` is then
+   * neither read nor written and may be NULL. */
+  float* dw_seg; float* dw_l1; float* dw_l2; float* wg_partial;
 } dfl_head_bwd_args;
 int dfl_head_bwd(const dfl_head_bwd_args* a, dfl_stream_t stream);
+int dfl_head_wgrad_blocks(int64_t M);  /* workgroups (= partial slots) of the fused form for M pixels */
 /* scratch row layout for F features: [0, Fc) cat(x, logits) with Fc = roundup4(F+NC_MAX) ; then dlogits (8),
  * dmid (24), mid (24), dheat (16). */
 int dfl_head_scratch_ld(int32_t F);

@@ -459,6 +459,60 @@ def test_streaming_kernels_bf16():
 
 
 # ---------------------------------------------------------------------------------------------------- whole network
+@pytest.mark.parametrize('NC,L,two', [(7, 14, True), (7, 0, True), (5, 9, False)])
+def test_head_backward_fused_weight_gradients(NC, L, two):
+    """dfl_head_bwd with bf16 features and dw_seg set: dx and the three head weight gradients (unet.py:176-191 under
+    autograd) without the per-pixel scratch.  The matrix-core form rounds [dlogits | dmid | dheat] and [logits | mid] to
+    bf16 (x is bf16 already): 2^-9 relative per product, averaged over the pixels -- the bar is 2^-8 of the largest
+    gradient magnitude of each tensor, dx keeps the bar of a bf16 result."""
+    lib = nat.lib()
+    g = torch.Generator().manual_seed(NC + L + 1)
+    N, H, W, F_ = 3, 37, 29, 32                                     # 3219 pixels: 13 tiles, the last one ragged
+    x = rb(torch.randn(N, F_, H, W, generator=g)).double().requires_grad_(True)
+    wseg = (torch.randn(NC, F_, 1, 1, generator=g, dtype=torch.float64) / 3).float().double().requires_grad_(True)
+    NM = (NC + L if two else L) if L > 0 else 0
+    logits = F.conv2d(x, wseg)
+    seg = torch.softmax(logits, 1)
+    outs = [seg]
+    w1 = w2 = None
+    if L > 0:
+        w1 = (torch.randn(NM, F_ + NC, 1, 1, generator=g, dtype=torch.float64) / 3).float().double().requires_grad_(True)
+        mid = F.conv2d(torch.cat((x, logits), 1), w1)
+        heat = mid
+        if two:
+            w2 = (torch.randn(L, NM, 1, 1, generator=g, dtype=torch.float64) / 3).float().double().requires_grad_(True)
+            heat = F.conv2d(mid, w2)
+        outs.append(heat)
+    gouts = [torch.randn(o.shape, generator=g, dtype=torch.float64) for o in outs]
+    torch.autograd.backward(outs, gouts)
+    dv = lambda t: t.detach().float().contiguous().to(DEV)
+    xd = nhwc(x.detach().float()).to(DEV).to(BF).contiguous()
+    wsd, w1d, w2d = dv(wseg), (dv(w1) if w1 is not None else None), (dv(w2) if w2 is not None else None)
+    segd = dv(seg)
+    dsegd = dv(gouts[0])
+    dheatd = dv(gouts[1]) if L > 0 else None
+    M = N * H * W
+    nb = nat.check(lib.dfl_head_wgrad_blocks(M), 'blocks')
+    part = torch.full((nb * 4096,), float('nan'), device=DEV)
+    dxd = torch.full((N, H, W, F_), float('nan'), device=DEV, dtype=BF)
+    dws = torch.full((NC, F_), float('nan'), device=DEV)
+    dw1 = torch.full((NM, F_ + NC), float('nan'), device=DEV) if L > 0 else None
+    dw2 = torch.full((L, NM), float('nan'), device=DEV) if (L > 0 and two) else None
+    nat.call('dfl_head_bwd', nat.HeadBwdArgs(
+        x=xd.data_ptr(), seg=segd.data_ptr(), dseg=dsegd.data_ptr(), dheat=nat.ptr(dheatd), w_seg=wsd.data_ptr(),
+        w_l1=nat.ptr(w1d), w_l2=nat.ptr(w2d), dx=dxd.data_ptr(), N=N, H=H, W=W, F=F_, ldx=F_, lddx=F_, NC=NC, NM=NM, L=L,
+        softmax=1, x_bf16=1, dw_seg=dws.data_ptr(), dw_l1=nat.ptr(dw1), dw_l2=nat.ptr(dw2), wg_partial=part.data_ptr()), stream())
+    torch.cuda.synchronize()
+    close_bf16(dxd.float().cpu(), nhwc(x.grad), 'dx')
+    for got, ref, name in ((dws, wseg.grad, 'seg_conv'), (dw1, None if w1 is None else w1.grad, 'lands_1x1.0'),
+                           (dw2, None if w2 is None else w2.grad, 'lands_1x1.1')):
+        if got is None:
+            continue
+        r = ref[:, :, 0, 0]
+        err = float((got.cpu().double() - r).abs().max())
+        assert err <= 2.0 ** -8 * float(r.abs().max()), (name, err, float(r.abs().max()))
+
+
 def _eps4():
     return NF.conv_rel_error('bf16s')
 

@@ -49,7 +49,7 @@ CHECKPOINT_KEYS = ['epoch', 'model-state-dict', 'optim-type', 'optimizer-state-d
                    'lrs-cooldown', 'checkpoint-freq', 'train-idx', 'valid-idx']
 RUN_STATE_KEYS = ('epoch', 'model-state-dict', 'optimizer-state-dict', 'scheduler-state-dict', 'loss', 'best-valid-loss',
                   'train-idx', 'valid-idx')
-MATH_MODES = {'fp32': 0, 'bf16x3': 1, 'bf16x6': 2, 'bf16': 3}
+MATH_MODES = {'fp32': 0, 'bf16x3': 1, 'bf16x6': 2, 'bf16': 3, 'bf16s': 4}
 
 
 def build_parser():
@@ -101,7 +101,7 @@ def build_parser():
     return p
 
 
-EXTENSION_FLAGS = {'math': None, 'seed': None, 'dist_backend': None}
+EXTENSION_FLAGS = {'math': None, 'seed': None, 'dist_backend': None, 'sync_loss': False}
 
 
 def build_full_parser():
@@ -112,6 +112,8 @@ def build_full_parser():
     p.add_argument('--seed', type=int, default=None, help='seed of initialisation and shuffling (default: unseeded)')
     p.add_argument('--dist-backend', type=str, default=None, help="torch.distributed backend when launched with several "
                                                                    "ranks (default nccl = RCCL)")
+    p.add_argument('--sync-loss', action='store_true', help='read every minibatch loss right after its optimizer step, as the '
+                                                             'reference does (default: one step late, the GPU never waits for the host)')
     return p
 
 
@@ -335,8 +337,8 @@ class Trainer:
         report_every = int(0.05 * n_images)              # running average printed every 5 % of an epoch's images
         net.train()
         seen = steps = 0
-        total = window = 0.0
-        in_window = 0
+        self._acc = [0.0, 0, 0.0, 0, report_every]       # total, steps, window sum, window count, window length
+        late = util.LateScalars(depth=0 if self.args.sync_loss else 1)   # loss values are read one step late (util.LateScalars)
         for projs, masks, _, heats in self.train_ds.batches(c['batch-size'], shuffle=True, shard=(self.rank, self.world)):
             opt.zero_grad()
             out = net(projs)
@@ -352,20 +354,30 @@ class Trainer:
             if cosine:
                 self.sched.intra_epoch_step(seen / n_images)
             self.last_loss = loss.detach()
-            value = self._mean_over_ranks(loss.item())   # the loss of the global minibatch (mean of equal shards)
-            if self.main:
-                self.train_log.write(value)
-            total += value
             steps += 1
-            window += value
-            in_window += 1
-            if in_window == report_every:
-                self.say('    Running Avg. Loss: {:.6f}'.format(window / in_window))
-                window, in_window = 0.0, 0
+            value = late.push(loss)
+            if value is not None:
+                self._account(value)
+        for value in late.flush():
+            self._account(value)
         if steps == 0:
             raise ValueError('the training set ({} images) yields no minibatch of {} x {} ranks'.format(
                 n_images, c['batch-size'], self.world))
-        return total / steps
+        return self._acc[0] / self._acc[1]
+
+    def _account(self, value):
+        """One minibatch loss (train.py:430-441): log line, epoch mean, running average every 5 % of the images."""
+        value = self._mean_over_ranks(value)             # the loss of the global minibatch (mean of equal shards)
+        if self.main:
+            self.train_log.write(value)
+        acc = self._acc
+        acc[0] += value
+        acc[1] += 1
+        acc[2] += value
+        acc[3] += 1
+        if acc[3] == acc[4]:
+            self.say('    Running Avg. Loss: {:.6f}'.format(acc[2] / acc[3]))
+            acc[2], acc[3] = 0.0, 0
 
     def validate(self):
         c = self.cfg
