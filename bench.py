@@ -213,6 +213,7 @@ def main():
     ap.add_argument('--sync-loss', action='store_true', help='loss.item() right after every optimizer step (the reference loop verbatim) '
                     'instead of reading each loss one step late')
     ap.add_argument('--no-overlap', action='store_true', help='all-reduce after backward instead of overlapped buckets')
+    ap.add_argument('--grad-compress', default=None, choices=['bf16'], help='all-reduce the gradient buckets as bf16 (default: fp32)')
     ap.add_argument('--force-dp', action='store_true',
                     help='keep the collective path on in a one-rank group (self-test of the RCCL path on a 1-GPU box)')
     args = ap.parse_args()
@@ -235,7 +236,7 @@ def main():
 
     torch.manual_seed(1234)
     net = dfl_amd.UNet(**PAPER).to(dev)
-    dp = DataParallel(net, overlap=not args.no_overlap, force_collectives=args.force_dp) if (world > 1 or args.force_dp) else None
+    dp = DataParallel(net, overlap=not args.no_overlap, force_collectives=args.force_dp, compress=args.grad_compress) if (world > 1 or args.force_dp) else None
     crit = dfl_amd.DiceAndHeatMapLoss2D(skip_bg=False, heatmap_wgt=0.5)
     SGD = dfl_amd.SGD if args.optimizer == 'dfl' else torch.optim.SGD
     opt = SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4, nesterov=True)

@@ -605,6 +605,29 @@ def test_losses_against_golden_and_oracle(golden):
     aclose(X.grad.cpu().numpy(), g['dh_gheat'], rtol=2e-4, atol=1e-8)
 
 
+def test_ncc_2d_is_differentiable_in_both_arguments():
+    """ncc.py:12-38 under autograd: value and gradients with respect to X and Y against the oracle (fp64), for an
+    arbitrary incoming gradient per image."""
+    g = torch.Generator().manual_seed(21)
+    X = torch.randn(3, 5, 17, 23, generator=g, dtype=torch.float64)
+    Y = (0.6 * X + 0.4 * torch.randn(3, 5, 17, 23, generator=g, dtype=torch.float64))
+    w = torch.randn(3, 5, generator=g, dtype=torch.float64)
+    Xr, Yr = X.clone().requires_grad_(True), Y.clone().requires_grad_(True)
+    (R.ncc_2d(Xr, Yr) * w).sum().backward()
+    Xd, Yd = X.float().to(DEV).requires_grad_(True), Y.float().to(DEV).requires_grad_(True)
+    out = dfl_amd.ncc_2d(Xd, Yd)
+    (out * w.float().to(DEV)).sum().backward()
+    aclose(out.detach().cpu().numpy(), R.ncc_2d(X, Y).numpy(), rtol=1e-5, atol=1e-6)
+    aclose(Xd.grad.cpu().numpy(), Xr.grad.numpy(), rtol=1e-4, atol=1e-8)
+    aclose(Yd.grad.cpu().numpy(), Yr.grad.numpy(), rtol=1e-4, atol=1e-8)
+    # only one argument needs a gradient
+    X2 = X.float().to(DEV).requires_grad_(True)
+    dfl_amd.ncc_2d(X2, Y.float().to(DEV)).sum().backward()
+    Xr.grad = None
+    R.ncc_2d(Xr, Y).sum().backward()
+    aclose(X2.grad.cpu().numpy(), Xr.grad.numpy(), rtol=1e-4, atol=1e-8)
+
+
 def test_loss_on_cropped_views_full_size():
     """BASELINE config-2 sized loss on center-cropped (strided) views vs the oracle."""
     g = torch.Generator().manual_seed(9)

@@ -78,13 +78,13 @@ class _FakePlan:
         self.bwd = _FakeProgram(self, rank)
 
 
-def _worker(rank, world, port):
+def _worker(rank, world, port, compress=None):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         torch.manual_seed(rank)                       # different initial weights per rank: broadcast must fix that
         net, real = _plan()
-        dp = DataParallel(net, bucket_mb=0.05)
+        dp = DataParallel(net, bucket_mb=0.05, compress=compress)
         w0 = [p.detach().clone() for p in net.parameters()]
         gathered = [torch.zeros_like(w0[0]) for _ in range(world)]
         dist.all_gather(gathered, w0[0])
@@ -100,7 +100,8 @@ def _worker(rank, world, port):
             s = plan.grad_offsets[name]
             n = plan.P[name].numel()
             got = plan.grad_flat[s:s + n]
-            assert torch.allclose(got, torch.full_like(got, mean_factor * (1 + op))), name
+            # bf16 buckets: every rank's value and the sum are rounded to bf16 (2^-9 each)
+            assert torch.allclose(got, torch.full_like(got, mean_factor * (1 + op)), rtol=1e-2 if compress else 1e-5), name
         for name in plan.dead_params:
             s = plan.grad_offsets[name]
             assert float(plan.grad_flat[s]) == -7.0     # untouched
@@ -108,9 +109,28 @@ def _worker(rank, world, port):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2, 4])
-def test_data_parallel_gloo(world):
+@pytest.mark.parametrize('world,compress', [(2, None), (4, None), (2, 'bf16')])
+def test_data_parallel_gloo(world, compress):
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
-    mp.spawn(_worker, args=(world, port), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, compress), nprocs=world, join=True)
+
+
+def test_bucket_of_several_slices_is_one_collective(monkeypatch):
+    """A bucket whose arena slices do not touch is gathered into one staging buffer: one all_reduce per bucket."""
+    net, real = _plan()
+    dp = DataParallel(net)
+    dp.world, dp.active = 2, True
+    calls = []
+    monkeypatch.setattr(dist, 'all_reduce', lambda t, op=None, group=None: calls.append(t.numel()))
+    plan = _FakePlan(real, 0)
+    plan.grad_flat[:] = torch.arange(plan.grad_flat.numel(), dtype=torch.float32)
+    before = plan.grad_flat.clone()
+    dp._reduce_bucket(plan, 0, [(0, 100), (200, 260), (1000, 1004)], 0.5)
+    assert calls == [164]
+    touched = torch.zeros_like(before, dtype=torch.bool)
+    for s_, e_ in ((0, 100), (200, 260), (1000, 1004)):
+        touched[s_:e_] = True
+    assert torch.equal(plan.grad_flat[~touched], before[~touched])
+    assert torch.allclose(plan.grad_flat[touched], before[touched] * 0.5)     # the (mocked) sum, then the mean

@@ -101,7 +101,7 @@ def build_parser():
     return p
 
 
-EXTENSION_FLAGS = {'math': None, 'seed': None, 'dist_backend': None, 'sync_loss': False}
+EXTENSION_FLAGS = {'math': None, 'seed': None, 'dist_backend': None, 'sync_loss': False, 'grad_compress': None}
 
 
 def build_full_parser():
@@ -112,6 +112,8 @@ def build_full_parser():
     p.add_argument('--seed', type=int, default=None, help='seed of initialisation and shuffling (default: unseeded)')
     p.add_argument('--dist-backend', type=str, default=None, help="torch.distributed backend when launched with several "
                                                                    "ranks (default nccl = RCCL)")
+    p.add_argument('--grad-compress', type=str, default=None, choices=['bf16'],
+                   help='data parallel: all-reduce the gradient buckets as bf16 (half the xGMI bytes; default: fp32)')
     p.add_argument('--sync-loss', action='store_true', help='read every minibatch loss right after its optimizer step, as the '
                                                              'reference does (default: one step late, the GPU never waits for the host)')
     return p
@@ -281,7 +283,7 @@ class Trainer:
         if resume is not None:
             self.net.load_state_dict(resume['model-state-dict'])
         self.net.to(self.dev)
-        self.dp = dfl_amd.DataParallel(self.net) if self.world > 1 else None      # broadcasts rank 0's weights
+        self.dp = dfl_amd.DataParallel(self.net, compress=args.grad_compress) if self.world > 1 else None   # broadcasts rank 0's weights
         if c['num-lands'] > 0:
             self.say('loss: Dice + heat-map NCC (weight {})'.format(c['heat-coeff']))
             self.criterion = dfl_amd.DiceAndHeatMapLoss2D(skip_bg=False, heatmap_wgt=c['heat-coeff'])
