@@ -67,7 +67,7 @@ def op_profile(plan, lib, nat, stream, detail=None):
                 by = esz * (st.N * st.Hin * st.Win * st.Cin + st.KH * st.KW * st.Cin * st.Ntot + M * st.Ntot)
             elif isinstance(st, nat.WgradArgs):
                 cfg = lib.dfl_wgrad_config(C.addressof(st))
-                name = WGRAD_KERNELS[cfg] if cfg < 16 else 'wgradp_kernel<%d>' % (9, 4, 1)[cfg - 16]
+                name = WGRAD_KERNELS[cfg] if cfg < 16 else 'wgradp_kernel<%s>' % ('3,3', '2,2', '1,1')[cfg - 16]
                 fl = 2.0 * st.N * st.Hout * st.Wout * st.Cm * st.Cg * st.KH * st.KW
                 by = (2.0 if st.g_bf16 else 4.0) * (st.N * st.Hin * st.Win * st.Cg + st.N * st.Hout * st.Wout * st.Cm) + 4.0 * st.Cm * st.Cg * st.KH * st.KW
             else:

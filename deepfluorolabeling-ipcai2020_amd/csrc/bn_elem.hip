@@ -689,6 +689,53 @@ __global__ void __launch_bounds__(256) pack_kernel(const dfl_pack_job* __restric
   const int A = j.A, B = j.B, Cc = j.C;
   const int K = (j.kind == 1) ? Cc * B : (j.kind == 2 ? Cc * A : A);
   const int N = (j.kind == 1) ? A : (j.kind == 2 ? B : Cc * B);
+  if (j.split == 2 && Cc <= PK_CMAX && ((j.kind == 1) ? (B % 16 == 0) : (A % 16 == 0))) {
+    // bf16 chunk layout [K/16][N][16], LDS-tiled: a 32(A) x 32(B) x C tile is read as 32 runs of 32*C contiguous floats;
+    // a thread then builds whole cells (16 consecutive k of one column = 32 bytes) and consecutive threads take consecutive
+    // columns: coalesced on both sides (the element-wise form below gathers 4-byte words 4*B*C bytes apart)
+    const int tb = (B + PK_T - 1) / PK_T, ta = (A + PK_T - 1) / PK_T;
+    const int run = PK_T * Cc;
+    unsigned short* dst16 = reinterpret_cast<unsigned short*>(j.dst);
+    for (int tidx = blockIdx.x; tidx < ta * tb; tidx += gridDim.x) {
+      const int a0 = (tidx / tb) * PK_T, b0 = (tidx % tb) * PK_T;
+      const int nb = min(PK_T, B - b0), na = min(PK_T, A - a0);
+      __syncthreads();
+      for (int e = threadIdx.x; e < PK_T * run; e += 256) {
+        const int ar = e / run, q = e - ar * run;
+        if (ar < na && q < nb * Cc) tile[ar][q] = j.src[((int64_t)(a0 + ar) * B + b0) * Cc + q];
+      }
+      __syncthreads();
+      for (int e = threadIdx.x; e < 64 * Cc; e += 256) {       // cells of this tile: 32 columns x 2 blocks of 16 k x C taps
+        const int x = e & 31, blk = (e >> 5) & 1, cp = e >> 6;
+        float f[16];
+        int64_t cell;
+        bool ok;
+        if (j.kind == 1) {          // k = c*B + b (16 consecutive b), n = a
+          ok = x < na && 16 * blk < nb;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) f[r] = tile[x][(16 * blk + r) * Cc + cp];
+          cell = (int64_t)((cp * B + b0) / 16 + blk) * N + a0 + x;
+        } else if (j.kind == 2) {   // k = c'*A + a (16 consecutive a), n = b
+          const int c = j.flip ? (Cc - 1 - cp) : cp;
+          ok = x < nb && 16 * blk < na;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) f[r] = tile[16 * blk + r][x * Cc + c];
+          cell = (int64_t)((cp * A + a0) / 16 + blk) * N + b0 + x;
+        } else {                    // k = a (16 consecutive a), n = c*B + b
+          ok = x < nb && 16 * blk < na;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) f[r] = tile[16 * blk + r][x * Cc + cp];
+          cell = (int64_t)(a0 / 16 + blk) * N + cp * B + b0 + x;
+        }
+        if (ok) {
+          bu32x4* d = reinterpret_cast<bu32x4*>(dst16 + cell * 16);
+          d[0] = pack8(f);
+          d[1] = pack8(f + 8);
+        }
+      }
+    }
+    return;
+  }
   if (j.split == 2) {
     // bf16 chunk layout [ceil(K/16)][N][16]: thread = one (chunk, column) cell of 32 bytes; consecutive threads take
     // consecutive columns (coalesced 32-byte stores; the sources are small enough to live in L2)

@@ -735,7 +735,7 @@ class UNetPlan:
         self.grad_ready_op = {}
         joined = {e['op']: e['waited'] for e in self._side}     # side-stream op -> main-stream wait that covers it
         for idx, st in enumerate(bwd.structs):
-            for field in ('dw', 'dst', 'out', 'dgamma', 'dbeta'):
+            for field in ('dw', 'dst', 'out', 'dgamma', 'dbeta', 'dw_seg', 'dw_l1', 'dw_l2'):   # (dw_*: head_bwd's own weight gradients)
                 name = by_ptr.get(getattr(st, field, None))
                 if name is not None:
                     self.grad_ready_op[name] = joined.get(idx, idx)

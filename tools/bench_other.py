@@ -47,7 +47,7 @@ def train_cfg3(steps=6, warmup=2, B=8, H=736, P=768):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     flop = 54.5e9 * (P * P) / (192 * 192) * B
-    print(json.dumps({'config': 'configs[3] 736x736 (padded 768) train, batch %d' % B, 'images_per_sec': round(B * steps / dt, 2),
+    print(json.dumps({'config': 'configs[3] 736x736 (padded 768) train, batch %d' % B, 'math': os.environ.get('DFL_MATH', 'fp32'), 'images_per_sec': round(B * steps / dt, 2),
                       'ms_per_step': round(dt / steps * 1e3, 2), 'tflops': round(flop / (dt / steps) / 1e12, 1),
                       'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}))
 
@@ -73,7 +73,7 @@ def infer_cfg4(reps=5, H=1436, P=1440, nnets=5):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     flop = 18.17e9 * (P * P) / (192 * 192) * nnets
-    print(json.dumps({'config': 'configs[4] 1436x1436 (padded 1440) %d-net ensemble inference' % nnets,
+    print(json.dumps({'config': 'configs[4] 1436x1436 (padded 1440) %d-net ensemble inference' % nnets, 'math': os.environ.get('DFL_MATH', 'fp32'),
                       'ms_per_image': round(dt * 1e3, 2), 'ms_per_net': round(dt * 1e3 / nnets, 2),
                       'tflops': round(flop / dt / 1e12, 1), 'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}))
 

@@ -18,5 +18,15 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU \
   -d "$out/pmc_SQ" -o p --output-format csv -- $bench --no-profile > /dev/null 2> "$out/pmc_SQ.err"
+# 4. the other BASELINE shapes (configs[3] 768x768 training, configs[4] 1440x1440 ensemble inference): kernel trace + stats
+for c in 3 4; do
+  mkdir -p "$out/cfg$c"
+  DFL_MATH=${DFL_MATH_OTHER:-bf16s} rocprofv3 --kernel-trace --stats -d "$out/cfg$c/trace" -o t --output-format csv -- python $root/tools/bench_other.py $c > "$out/cfg$c/bench_other.json" 2> "$out/cfg$c/trace.err"
+done
 cd "$root"
 python tools/summarize_profile.py "$out" "$tag"
+for c in 3 4; do
+  python tools/summarize_profile.py "$out/cfg$c" "${tag}_cfg$c"
+  cp "$out/cfg$c/bench_other.json" "$out/${tag}_cfg${c}_bench.json"
+  cp "$out/cfg$c/${tag}_cfg${c}_kernel_stats.csv" "$out/"
+done

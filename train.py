@@ -283,7 +283,7 @@ class Trainer:
         if resume is not None:
             self.net.load_state_dict(resume['model-state-dict'])
         self.net.to(self.dev)
-        self.dp = dfl_amd.DataParallel(self.net, compress=args.grad_compress) if self.world > 1 else None   # broadcasts rank 0's weights
+        self.dp = dfl_amd.DataParallel(self.net, compress=self.args.grad_compress) if self.world > 1 else None   # broadcasts rank 0's weights
         if c['num-lands'] > 0:
             self.say('loss: Dice + heat-map NCC (weight {})'.format(c['heat-coeff']))
             self.criterion = dfl_amd.DiceAndHeatMapLoss2D(skip_bg=False, heatmap_wgt=c['heat-coeff'])
