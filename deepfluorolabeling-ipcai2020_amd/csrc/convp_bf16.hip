@@ -130,6 +130,7 @@ __global__ void __launch_bounds__(256, (TM * TN >= 6) ? 1 : 2) convp_kernel(cons
   const int dpix_y = dpix / p.IW, dpix_x = dpix - dpix_y * p.IW;
   const int npix = p.IPP * p.IH * p.IW;
   const int CKC = p.CK >> 4;                       // 16-channel chunks per resident block (a power of two)
+  const int ckc_sh = p.upp_shift - 1;
   const int S_steps = p.T * CKC;                   // k-steps per block
   const int cin_chunks = a.Cin >> 4;
   const int KW = a.KW;
@@ -221,50 +222,27 @@ __global__ void __launch_bounds__(256, (TM * TN >= 6) ? 1 : 2) convp_kernel(cons
     constexpr int G = TN == 1 ? 4 : 2;             // k-steps per ring set (the ring holds 3 * G * TN fragments)
     const int ngroups = (S_steps + G - 1) / G;
     pu32x4 breg[3][G][TN];
-    // The k-steps are walked by two cursors (wave-uniform, scalar registers): one for the A fragments (LDS offset of the
-    // tap and channel chunk), one for the B fragments (byte offset of the 16-k slab of the packed weights).  Both only
-    // ever move to the next step, so a step costs a few scalar adds instead of a division by the window width and three
-    // multiplications (the loop runs with one or two waves per SIMD on the deep levels: every issue slot counts).
-    int b_s = 0, b_cc = 0;
-    uint32_t b_soff = (uint32_t)(blk * CKC) * (uint32_t)a.Ntot * 32u;
-    const uint32_t b_step = (uint32_t)a.Ntot * 32u, b_tap = (uint32_t)(cin_chunks - CKC) * (uint32_t)a.Ntot * 32u;
     auto load_group = [&](int g, int set) {
-      (void)g;
 #pragma unroll
       for (int e = 0; e < G; ++e) {
-        const bool live = b_s < S_steps;
+        const int s = g * G + e;
+        const bool live = g < ngroups && s < S_steps;
+        const int tap = s >> ckc_sh, cc = s & (CKC - 1);
+        const uint32_t soff = live ? (uint32_t)((tap * cin_chunks + blk * CKC + cc)) * (uint32_t)a.Ntot * 32u : 0u;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) breg[set][e][j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, live ? b_voff[j] : POOB, live ? b_soff : 0u, 0);
-        ++b_s;
-        b_soff += b_step;
-        if (++b_cc == CKC) {
-          b_cc = 0;
-          b_soff += b_tap;
-        }
+        for (int j = 0; j < TN; ++j) breg[set][e][j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, live ? b_voff[j] : POOB, soff, 0);
       }
     };
     // A fragments run one k-step ahead of the matrix instructions that use them: the reads of step s + 1 are issued
     // before the instructions of step s (a fragment read takes 64-128 cycles, an instruction 32)
     bf16x8_t afn[TM];
-    int a_s = 0, a_cc = 0, a_tx = 0;
-    uint32_t a_off = 0;
-    const uint32_t a_tapx = (uint32_t)S - (uint32_t)CKC * 32u, a_tapy = (uint32_t)(p.IW - KW) * (uint32_t)S;
     auto fetch_a = [&](int s) {
-      (void)s;
+      s = s < S_steps ? s : S_steps - 1;           // dead steps of the last group: weights were loaded as zeros
+      const int tap = s >> ckc_sh, cc = s & (CKC - 1);
+      const int ty = tap / KW, tx = tap - ty * KW;
+      const uint32_t aoff = (uint32_t)((ty * p.IW + tx) * S + cc * 32);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) afn[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const pu32x4*>(smem + a_base[i] + a_off));
-      if (a_s < S_steps - 1) {                     // dead steps of the last group re-read the last one: their weights are zeros
-        ++a_s;
-        a_off += 32u;
-        if (++a_cc == CKC) {
-          a_cc = 0;
-          a_off += a_tapx;
-          if (++a_tx == KW) {
-            a_tx = 0;
-            a_off += a_tapy;
-          }
-        }
-      }
+      for (int i = 0; i < TM; ++i) afn[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const pu32x4*>(smem + a_base[i] + aoff));
     };
     auto compute_group = [&](int g, int set) {
 #pragma unroll
@@ -281,94 +259,19 @@ __global__ void __launch_bounds__(256, (TM * TN >= 6) ? 1 : 2) convp_kernel(cons
         }
       }
     };
-    if ((CKC & (G - 1)) == 0) {
-      // Resident blocks of at least G chunks (64 / 128 channels: every layer below the first two levels): a ring group
-      // never straddles a tap, so the cursors move once per GROUP and the steps inside it are immediate offsets.
-      int gb = 0, gb_cc = 0;
-      uint32_t gb_soff = (uint32_t)(blk * CKC) * (uint32_t)a.Ntot * 32u;
-      auto load_g = [&](int set) {
-        if (gb < ngroups) {
-#pragma unroll
-          for (int e = 0; e < G; ++e)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) breg[set][e][j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, b_voff[j], gb_soff + (uint32_t)e * b_step, 0);
-        }
-        ++gb;
-        gb_cc += G;
-        gb_soff += (uint32_t)G * b_step;
-        if (gb_cc == CKC) {
-          gb_cc = 0;
-          gb_soff += b_tap;
-        }
-      };
-      int ga_cc = 0, ga_tx = 0;
-      uint32_t ga_off = 0;
-      auto compute_g = [&](int set, bool last) {
-        uint32_t va[TM];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) va[i] = a_base[i] + ga_off;
-        // the cursor moves on to the next group before the last step: that step prefetches the next group's first fragments
-        ga_cc += G;
-        ga_off += (uint32_t)G * 32u;
-        if (ga_cc == CKC) {
-          ga_cc = 0;
-          ga_off += a_tapx;
-          if (++ga_tx == KW) {
-            ga_tx = 0;
-            ga_off += a_tapy;
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < G; ++e) {
-          bf16x8_t af[TM];
-#pragma unroll
-          for (int i = 0; i < TM; ++i) af[i] = afn[i];
-          if (e + 1 < G) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) afn[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const pu32x4*>(smem + va[i] + (e + 1) * 32));
-          } else if (!last) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) afn[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const pu32x4*>(smem + a_base[i] + ga_off));
-          }
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, breg[set][e][j]);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf, acc[i][j], 0, 0, 0);
-          }
-        }
-      };
-#pragma unroll
-      for (int i = 0; i < TM; ++i) afn[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const pu32x4*>(smem + a_base[i]));
-      load_g(0);
-      load_g(1);
-      for (int g = 0; g < ngroups; g += 3) {
-        load_g(2);
-        compute_g(0, g + 1 >= ngroups);
-        if (g + 1 < ngroups) {
-          load_g(0);
-          compute_g(1, g + 2 >= ngroups);
-        }
-        if (g + 2 < ngroups) {
-          load_g(1);
-          compute_g(2, g + 3 >= ngroups);
-        }
+    fetch_a(0);
+    load_group(0, 0);
+    load_group(1, 1);
+    for (int g = 0; g < ngroups; g += 3) {
+      load_group(g + 2, 2);
+      compute_group(g, 0);
+      if (g + 1 < ngroups) {
+        load_group(g + 3, 0);
+        compute_group(g + 1, 1);
       }
-    } else {
-      fetch_a(0);
-      load_group(0, 0);
-      load_group(1, 1);
-      for (int g = 0; g < ngroups; g += 3) {
-        load_group(g + 2, 2);
-        compute_group(g, 0);
-        if (g + 1 < ngroups) {
-          load_group(g + 3, 0);
-          compute_group(g + 1, 1);
-        }
-        if (g + 2 < ngroups) {
-          load_group(g + 4, 1);
-          compute_group(g + 2, 2);
-        }
+      if (g + 2 < ngroups) {
+        load_group(g + 4, 1);
+        compute_group(g + 2, 2);
       }
     }
     TRACC(2, tb1)

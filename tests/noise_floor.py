@@ -11,7 +11,8 @@ Model of the noise: each nn.Conv2d / nn.ConvTranspose2d of the oracle (fp64) get
   * its forward output   y  <- y  + eps * rms(y)  * N(0,1)
   * its data gradient    dx <- dx + eps * rms(dx) * N(0,1)
   * its weight gradient  dw <- dw + eps * rms(dw) * N(0,1)
-which is what a GEMM with per-product relative error ~eps does to its three results.  eps per arithmetic is MEASURED on
+(and its bias gradient likewise), which is what a GEMM with per-product relative error ~eps does to its results; every
+nn.BatchNorm2d gets the same three injections at the fixed fp32 rounding level 2^-23 (BatchNorm is fp32 in every mode).  eps per arithmetic is MEASURED on
 the GPU, not assumed: conv_rel_error() below (one convolution of the HIP library against fp64) gives the arithmetic's own
 level, and GradientFloor.bars() raises it to the level at which the oracle's FORWARD output moves as far as the HIP
 forward output is off fp64 on the very problem under test (the forward itself is held to the 1e-4 bar separately): the
@@ -24,6 +25,9 @@ the exceptions are tensors whose error is at fp32 rounding level (1e-6 relative)
 import numpy as np
 import torch
 import torch.nn as nn
+
+
+BN_EPS = 2.0 ** -23          # fp32 rounding of the BatchNorm results (see noisy_gradients)
 
 
 def _rms(t):
@@ -47,6 +51,19 @@ def noisy_gradients(onet, loss_of, eps, seed):
     noise = _Noise(eps, seed)
     handles = []
     convs = [m for m in onet.modules() if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d))]
+    if eps > 0.0:
+        # BatchNorm runs in fp32 in every arithmetic mode (statistics, normalisation, its backward sums): its results carry
+        # fp32 rounding, 2^-23 relative to their RMS -- small next to bf16 products, the leading term next to fp32 ones
+        # (x - mean cancels: the gamma / beta gradients of the decoder are the tensors with the widest fp32-vs-fp64 gap in
+        # the reference's own run)
+        bn_noise = _Noise(BN_EPS, seed + 7919)
+        for m in onet.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                handles.append(m.register_forward_hook(lambda mod, inp, out: bn_noise(out)))
+                handles.append(m.register_full_backward_hook(lambda mod, gin, gout: tuple(bn_noise(g) for g in gin)))
+                if m.weight is not None:
+                    handles.append(m.weight.register_hook(lambda g: bn_noise(g)))
+                    handles.append(m.bias.register_hook(lambda g: bn_noise(g)))
     for m in convs:
         handles.append(m.register_forward_hook(lambda mod, inp, out: noise(out)))
         handles.append(m.register_full_backward_hook(
