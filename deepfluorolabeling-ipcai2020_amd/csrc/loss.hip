@@ -21,52 +21,97 @@ __device__ __forceinline__ void block_sum5(double* v, int nv, double (*red)[256]
   for (int k = 0; k < nv; ++k) v[k] = red[k][0];
 }
 
-// blocks [0, B*C): Dice sums (sum t*s, sum t*t, sum s*s); blocks [B*C, B*C + B*L): NCC sums (x, y, xx, yy, xy).
-__global__ void __launch_bounds__(256) loss_sums_kernel(const dfl_loss_args a) {
+// blockIdx.x in [0, B*C): Dice sums (sum t*s, sum t*t, sum s*s) of one (image, class) plane; [B*C, B*C + B*L): NCC sums
+// (x, y, xx, yy, xy) of one (image, landmark) plane; blockIdx.y = one of LOSS_NS row ranges of the plane (336 planes alone
+// would leave 1.3 waves per SIMD).  A wave walks whole rows -- lane = 4 consecutive pixels, one float4 per tensor when the
+// window is 16-byte aligned (the centre crop of a 192-wide row to 184 is: offset 4), two rows in flight -- so there is no
+// index division per pixel.  Partial sums go to part[(plane * LOSS_NS + range)][k] (fp64); the finalize kernel adds the
+// ranges in order.
+constexpr int LOSS_NS = 4;
+
+template <int NV>
+__device__ __forceinline__ void loss_acc(const float* __restrict__ p, const float* __restrict__ q, int x, int w, bool vec, double* v) {
+  float pv[4] = {0.f, 0.f, 0.f, 0.f}, qv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (vec) {
+    const float4 a4 = *reinterpret_cast<const float4*>(p + x), b4 = *reinterpret_cast<const float4*>(q + x);
+    pv[0] = a4.x; pv[1] = a4.y; pv[2] = a4.z; pv[3] = a4.w;
+    qv[0] = b4.x; qv[1] = b4.y; qv[2] = b4.z; qv[3] = b4.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (x + e < w) {
+        pv[e] = p[x + e];
+        qv[e] = q[x + e];
+      }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const double pd = (double)pv[e], qd = (double)qv[e];
+    if (NV == 3) {            // p = seg, q = target
+      v[0] += qd * pd; v[1] += qd * qd; v[2] += pd * pd;
+    } else {                  // p = x, q = y
+      v[0] += pd; v[1] += qd; v[2] += pd * pd; v[3] += qd * qd; v[4] += pd * qd;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) loss_sums_kernel(const dfl_loss_args a, double* __restrict__ part) {
   __shared__ double red[5][256];
   const int BC = a.B * a.C;
-  const int hw = a.h * a.w;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rows = (a.h + LOSS_NS - 1) / LOSS_NS;
+  const int y0 = blockIdx.y * rows, y1 = min(y0 + rows, a.h);
   double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  if ((int)blockIdx.x < BC) {
+  const bool dice = (int)blockIdx.x < BC;
+  const float *p, *q;
+  int64_t pH, qH;
+  if (dice) {
     const int n = blockIdx.x / a.C, c = blockIdx.x % a.C;
-    const float* s = a.seg + n * a.seg_sN + c * a.seg_sC;
-    const float* t = a.tseg + n * a.tseg_sN + c * a.tseg_sC;
-    for (int i = threadIdx.x; i < hw; i += 256) {
-      const int y = i / a.w, x = i - y * a.w;
-      const double sv = (double)s[y * a.seg_sH + x], tv = (double)t[y * a.tseg_sH + x];
-      v[0] += tv * sv;
-      v[1] += tv * tv;
-      v[2] += sv * sv;
-    }
-    block_sum5(v, 3, red);
-    if (threadIdx.x == 0) {
-      double* o = a.sums + (int64_t)blockIdx.x * 3;
-      o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
-    }
+    p = a.seg + n * a.seg_sN + c * a.seg_sC;
+    q = a.tseg + n * a.tseg_sN + c * a.tseg_sC;
+    pH = a.seg_sH; qH = a.tseg_sH;
   } else {
     const int b = blockIdx.x - BC;
     const int n = b / a.L, l = b % a.L;
-    const float* xp = a.heat + n * a.heat_sN + l * a.heat_sC;
-    const float* yp = a.theat + n * a.theat_sN + l * a.theat_sC;
-    for (int i = threadIdx.x; i < hw; i += 256) {
-      const int y = i / a.w, x = i - y * a.w;
-      const double xv = (double)xp[y * a.heat_sH + x], yv = (double)yp[y * a.theat_sH + x];
-      v[0] += xv; v[1] += yv; v[2] += xv * xv; v[3] += yv * yv; v[4] += xv * yv;
+    p = a.heat + n * a.heat_sN + l * a.heat_sC;
+    q = a.theat + n * a.theat_sN + l * a.theat_sC;
+    pH = a.heat_sH; qH = a.theat_sH;
+  }
+  const bool vec = (a.w & 3) == 0 && (pH & 3) == 0 && (qH & 3) == 0 && ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(q)) & 15) == 0;
+  for (int x = 4 * lane; x < a.w; x += 256) {
+    int y = y0 + wave;
+    for (; y + 4 < y1; y += 8) {          // two rows of this wave in flight
+      if (dice) {
+        loss_acc<3>(p + y * pH, q + y * qH, x, a.w, vec, v);
+        loss_acc<3>(p + (y + 4) * pH, q + (y + 4) * qH, x, a.w, vec, v);
+      } else {
+        loss_acc<5>(p + y * pH, q + y * qH, x, a.w, vec, v);
+        loss_acc<5>(p + (y + 4) * pH, q + (y + 4) * qH, x, a.w, vec, v);
+      }
     }
-    block_sum5(v, 5, red);
-    if (threadIdx.x == 0) {
-      double* o = a.sums + (int64_t)BC * 3 + (int64_t)b * 5;
+    for (; y < y1; y += 4) {
+      if (dice) loss_acc<3>(p + y * pH, q + y * qH, x, a.w, vec, v);
+      else loss_acc<5>(p + y * pH, q + y * qH, x, a.w, vec, v);
+    }
+  }
+  block_sum5(v, dice ? 3 : 5, red);
+  if (threadIdx.x == 0) {
+    if (dice) {
+      double* o = part + ((int64_t)blockIdx.x * LOSS_NS + blockIdx.y) * 3;
+      o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+    } else {
+      double* o = part + (int64_t)BC * LOSS_NS * 3 + ((int64_t)(blockIdx.x - BC) * LOSS_NS + blockIdx.y) * 5;
       for (int k = 0; k < 5; ++k) o[k] = v[k];
     }
   }
 }
 
 // Single workgroup: loss value + per-(image,channel) gradient coefficients.
-__global__ void __launch_bounds__(256) loss_finalize_kernel(const dfl_loss_args a) {
+__global__ void __launch_bounds__(256) loss_finalize_kernel(const dfl_loss_args a, const double* __restrict__ part) {
   __shared__ double red[2][256];
   const int BC = a.B * a.C, BL = a.B * a.L;
-  const double* dsum = a.sums;
-  const double* nsum = a.sums + (int64_t)BC * 3;
+  const double* dpart = part;                                   // [BC][LOSS_NS][3]
+  const double* npart = part + (int64_t)BC * LOSS_NS * 3;       // [BL][LOSS_NS][5]
   double* dcoef = a.sums + (int64_t)BC * 3 + (int64_t)BL * 5;  // [BC][2]
   double* ncoef = dcoef + (int64_t)BC * 2;                      // [BL][3]
   const int ceff = a.C - (a.skip_bg ? 1 : 0);
@@ -77,7 +122,12 @@ __global__ void __launch_bounds__(256) loss_finalize_kernel(const dfl_loss_args 
       const int c = i % a.C;
       double a1 = 0.0, a2 = 0.0;
       if (!(a.skip_bg && c == 0)) {
-        const double I = dsum[i * 3 + 0], T = dsum[i * 3 + 1], S = dsum[i * 3 + 2];
+        double I = 0.0, T = 0.0, S = 0.0;
+        for (int r = 0; r < LOSS_NS; ++r) {
+          I += dpart[(i * LOSS_NS + r) * 3 + 0];
+          T += dpart[(i * LOSS_NS + r) * 3 + 1];
+          S += dpart[(i * LOSS_NS + r) * 3 + 2];
+        }
         const double num = -2.0 * I + DICE_EPS, den = T + S + DICE_EPS;
         dice_acc += num / den;
         a1 = -2.0 / den * g;
@@ -91,8 +141,11 @@ __global__ void __launch_bounds__(256) loss_finalize_kernel(const dfl_loss_args 
     const double N = (double)a.h * (double)a.w;
     const double q = -0.5 * (double)a.heat_wgt / (double)BL;
     for (int i = threadIdx.x; i < BL; i += 256) {
-      const double sx = nsum[i * 5 + 0], sy = nsum[i * 5 + 1], sxx = nsum[i * 5 + 2], syy = nsum[i * 5 + 3],
-                   sxy = nsum[i * 5 + 4];
+      double sx = 0.0, sy = 0.0, sxx = 0.0, syy = 0.0, sxy = 0.0;
+      for (int r = 0; r < LOSS_NS; ++r) {
+        const double* o = npart + (i * LOSS_NS + r) * 5;
+        sx += o[0]; sy += o[1]; sxx += o[2]; syy += o[3]; sxy += o[4];
+      }
       const double mx = sx / N, my = sy / N;
       double va = sxx - sx * mx, vb = syy - sy * my;  // sum of squared deviations
       if (va < 0.0) va = 0.0;
@@ -259,7 +312,7 @@ __global__ void __launch_bounds__(256) ens_final(const dfl_ensemble_args a) {
 using namespace dfl;
 
 extern "C" int64_t dfl_loss_scratch_doubles(int32_t B, int32_t C, int32_t L) {
-  return (int64_t)B * C * 5 + (int64_t)B * L * 8 + 8;
+  return (int64_t)B * C * 5 + (int64_t)B * L * 8 + 8 + (int64_t)LOSS_NS * ((int64_t)B * C * 3 + (int64_t)B * L * 5);
 }
 
 extern "C" int dfl_dice_ncc_loss(const dfl_loss_args* a, dfl_stream_t stream) {
@@ -270,8 +323,9 @@ extern "C" int dfl_dice_ncc_loss(const dfl_loss_args* a, dfl_stream_t stream) {
   DFL_REQUIRE(a->L == 0 || (int64_t)a->h * a->w > 1, "dfl_dice_ncc_loss: NCC needs more than one pixel");
   DFL_REQUIRE(!(a->skip_bg && a->C < 2), "dfl_dice_ncc_loss: skip_bg needs at least 2 classes");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(loss_sums_kernel, dim3((unsigned)(a->B * (a->C + a->L))), dim3(256), 0, s, *a);
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, *a);
+  double* part = a->sums + (int64_t)a->B * a->C * 5 + (int64_t)a->B * a->L * 8 + 8;     // row-range partial sums behind the coefficients
+  hipLaunchKernelGGL(loss_sums_kernel, dim3((unsigned)(a->B * (a->C + a->L)), (unsigned)LOSS_NS), dim3(256), 0, s, *a, part);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, *a, part);
   if (a->dseg != nullptr || (a->dheat != nullptr && a->L > 0)) {
     const int64_t total = (int64_t)a->B * (a->C + a->L) * a->h * a->w;
     int64_t blocks = ceil_div(total, 256);

@@ -674,7 +674,7 @@ def test_reduce_batch():
     g = torch.Generator().manual_seed(17)
     # (n, stride, count, T): T > 1 = tap-major slices of dfl_conv2d_wgrad, transposed to [..][T] while summing
     shapes = [(32, 64, 9216, 1), (9216, 9216, 1366, 9), (5, 7, 3, 1), (1, 1, 200, 1), (300000, 300000, 2, 4),
-              (819, 819, 70, 1), (64, 128, 64, 1), (36, 36, 5, 9)]
+              (819, 819, 70, 1), (64, 128, 64, 1), (36, 36, 5, 9), (1024, 1028, 17, 4), (4096, 4096, 15, 1), (72, 72, 33, 9)]
     srcs, dsts, arr, blocks = [], [], (nat.ReduceJob * len(shapes))(), 0
     for i, (n, stride, count, T) in enumerate(shapes):
         src = torch.randn(count * stride, generator=g).to(DEV)
