@@ -92,7 +92,9 @@ class LossArgs(C.Structure):
                 ('heat_sN', i64), ('heat_sC', i64), ('heat_sH', i64), ('theat_sN', i64), ('theat_sC', i64),
                 ('theat_sH', i64),
                 ('B', i32), ('C', i32), ('L', i32), ('h', i32), ('w', i32), ('skip_bg', i32),
-                ('dice_wgt', f32), ('heat_wgt', f32)]
+                ('dice_wgt', f32), ('heat_wgt', f32), ('grad_scale', fp),
+                ('dseg_sN', i64), ('dseg_sC', i64), ('dseg_sH', i64), ('dheat_sN', i64), ('dheat_sC', i64), ('dheat_sH', i64),
+                ('stage', i32), ('reserved', i32)]
 
 
 class EnsembleArgs(C.Structure):

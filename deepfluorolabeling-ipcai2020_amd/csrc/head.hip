@@ -399,7 +399,29 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(const dfl_head_bwd_args a
 // 64 x 64 product: rows 0-7 x columns 0-31 -> dw_seg, rows 8-31 x columns 0-39 -> dw_l1, rows 32-47 x columns 40-63 -> dw_l2.
 __global__ void __launch_bounds__(256) head_wgrad_finish_kernel(const float* __restrict__ partial, int nblocks, float* __restrict__ dw_seg,
                                                                 float* __restrict__ dw_l1, float* __restrict__ dw_l2, int F, int NC, int NM, int L) {
-  const int e = blockIdx.x * 256 + threadIdx.x;       // element of the 64 x 64 product
+  // 16 elements of the 64 x 64 product per workgroup x 16 lanes over the workgroup partials (eight loads in flight per
+  // lane), lanes added up through LDS in a fixed order
+  __shared__ double red[16][17];
+  const int el = threadIdx.x & 15, ln = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + el;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int b = ln;
+  for (; b + 7 * 16 < nblocks; b += 8 * 16) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(b + u * 16) * 4096 + e];
+    s0 += (double)v[0] + (double)v[4];
+    s1 += (double)v[1] + (double)v[5];
+    s2 += (double)v[2] + (double)v[6];
+    s3 += (double)v[3] + (double)v[7];
+  }
+  for (; b < nblocks; b += 16) s0 += (double)partial[(int64_t)b * 4096 + e];
+  red[ln][el] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ln != 0) return;
+  double tot = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) tot += red[k][el];
   const int row = e >> 6, col = e & 63;
   float* dst = nullptr;
   if (row < 8) {
@@ -409,17 +431,7 @@ __global__ void __launch_bounds__(256) head_wgrad_finish_kernel(const float* __r
   } else if (row < 48) {
     if (dw_l2 != nullptr && row - 32 < L && col >= 40 && col - 40 < NM) dst = dw_l2 + (row - 32) * NM + (col - 40);
   }
-  if (dst == nullptr) return;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  int b = 0;
-  for (; b + 3 < nblocks; b += 4) {
-    s0 += (double)partial[(int64_t)b * 4096 + e];
-    s1 += (double)partial[(int64_t)(b + 1) * 4096 + e];
-    s2 += (double)partial[(int64_t)(b + 2) * 4096 + e];
-    s3 += (double)partial[(int64_t)(b + 3) * 4096 + e];
-  }
-  for (; b < nblocks; ++b) s0 += (double)partial[(int64_t)b * 4096 + e];
-  *dst = (float)((s0 + s1) + (s2 + s3));
+  if (dst != nullptr) *dst = (float)tot;
 }
 
 static int head_check(int F, int NC, int NM, int L, const void* w_l1, const void* w_l2, int ldx, const void* x, int x_bf16 = 0) {
@@ -525,7 +537,7 @@ extern "C" int dfl_head_bwd(const dfl_head_bwd_args* a, dfl_stream_t stream) {
 #undef DFL_HB
   int rc2 = check_launch("dfl_head_bwd");
   if (rc2 != DFL_OK || !fused) return rc2;
-  hipLaunchKernelGGL(head_wgrad_finish_kernel, dim3(16), dim3(256), 0, hs, a->wg_partial, (int)grid, a->dw_seg, a->dw_l1, a->dw_l2, a->F,
+  hipLaunchKernelGGL(head_wgrad_finish_kernel, dim3(256), dim3(256), 0, hs, a->wg_partial, (int)grid, a->dw_seg, a->dw_l1, a->dw_l2, a->F,
                      a->NC, a->NM, a->L);
   return check_launch("dfl_head_bwd (weight-gradient sums)");
 }

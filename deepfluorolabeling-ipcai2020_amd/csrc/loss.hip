@@ -189,6 +189,8 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(const dfl_loss_args a) {
   const int64_t nseg = (a.dseg != nullptr) ? (int64_t)BC * hw : 0;
   const int64_t nheat = (a.dheat != nullptr && a.L > 0) ? (int64_t)BL * hw : 0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const float gs = a.grad_scale != nullptr ? *a.grad_scale : 1.f;
+  const bool sdense = a.dseg_sN == 0, hdense = a.dheat_sN == 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nseg + nheat; i += stride) {
     if (i < nseg) {
       const int64_t pc = i / hw;
@@ -198,7 +200,7 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(const dfl_loss_args a) {
       const float a1 = (float)dcoef[pc * 2 + 0], a2 = (float)dcoef[pc * 2 + 1];
       const float sv = a.seg[n * a.seg_sN + c * a.seg_sC + y * a.seg_sH + x];
       const float tv = a.tseg[n * a.tseg_sN + c * a.tseg_sC + y * a.tseg_sH + x];
-      a.dseg[i] = fmaf(a1, tv, a2 * sv);
+      a.dseg[sdense ? i : (n * a.dseg_sN + c * a.dseg_sC + y * a.dseg_sH + x)] = gs * fmaf(a1, tv, a2 * sv);
     } else {
       const int64_t j = i - nseg;
       const int64_t pc = j / hw;
@@ -208,7 +210,7 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(const dfl_loss_args a) {
       const float k1 = (float)ncoef[pc * 3 + 0], k2 = (float)ncoef[pc * 3 + 1], k0 = (float)ncoef[pc * 3 + 2];
       const float xv = a.heat[n * a.heat_sN + l * a.heat_sC + y * a.heat_sH + x];
       const float yv = a.theat[n * a.theat_sN + l * a.theat_sC + y * a.theat_sH + x];
-      a.dheat[j] = fmaf(k1, yv, fmaf(k2, xv, k0));
+      a.dheat[hdense ? j : (n * a.dheat_sN + l * a.dheat_sC + y * a.dheat_sH + x)] = gs * fmaf(k1, yv, fmaf(k2, xv, k0));
     }
   }
 }
@@ -323,10 +325,14 @@ extern "C" int dfl_dice_ncc_loss(const dfl_loss_args* a, dfl_stream_t stream) {
   DFL_REQUIRE(a->L == 0 || (int64_t)a->h * a->w > 1, "dfl_dice_ncc_loss: NCC needs more than one pixel");
   DFL_REQUIRE(!(a->skip_bg && a->C < 2), "dfl_dice_ncc_loss: skip_bg needs at least 2 classes");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  DFL_REQUIRE(a->stage >= 0 && a->stage <= 2, "dfl_dice_ncc_loss: stage must be 0, 1 or 2");
+  DFL_REQUIRE((a->dseg_sN == 0) == (a->dseg_sH == 0) && (a->dheat_sN == 0) == (a->dheat_sH == 0), "dfl_dice_ncc_loss: give all gradient strides or none");
   double* part = a->sums + (int64_t)a->B * a->C * 5 + (int64_t)a->B * a->L * 8 + 8;     // row-range partial sums behind the coefficients
-  hipLaunchKernelGGL(loss_sums_kernel, dim3((unsigned)(a->B * (a->C + a->L)), (unsigned)LOSS_NS), dim3(256), 0, s, *a, part);
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, *a, part);
-  if (a->dseg != nullptr || (a->dheat != nullptr && a->L > 0)) {
+  if (a->stage != 2) {
+    hipLaunchKernelGGL(loss_sums_kernel, dim3((unsigned)(a->B * (a->C + a->L)), (unsigned)LOSS_NS), dim3(256), 0, s, *a, part);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, *a, part);
+  }
+  if (a->stage != 1 && (a->dseg != nullptr || (a->dheat != nullptr && a->L > 0))) {
     const int64_t total = (int64_t)a->B * (a->C + a->L) * a->h * a->w;
     int64_t blocks = ceil_div(total, 256);
     if (blocks > 8192) blocks = 8192;

@@ -27,7 +27,46 @@ def _view4(t, name):
     return t
 
 
+def _window_of(t, v):
+    """(full shape, r0, c0) when `t` (whose kernel view is `v`) is a centre-crop-like window of a contiguous 4-D tensor
+    with the same batch and channel counts; None otherwise."""
+    b = t._base
+    if b is None or v.data_ptr() != t.data_ptr() or b.dim() != 4 or not b.is_contiguous() or b.dtype != torch.float32:
+        return None
+    if tuple(b.shape[:2]) != tuple(t.shape[:2]) or t.stride() != b.stride():
+        return None
+    off = t.storage_offset() - b.storage_offset()
+    H, W = b.shape[2], b.shape[3]
+    r0, c0 = divmod(off, W)
+    if off < 0 or r0 + t.shape[2] > H or c0 + t.shape[3] > W:
+        return None
+    return tuple(b.shape), r0, c0
+
+
+_ZB_POOL = {}
+
+
+def _zero_border_buffer(dev, shape, window):
+    """A full-size fp32 tensor whose border around `window` = (r0, c0, h, w) is zero: the loss gradient is written into
+    its interior.  Buffers are pooled per (device, shape, window) and handed out only while nothing else refers to them
+    (a gradient still held by autograd or by the caller keeps its buffer out of circulation)."""
+    key = (str(dev), shape, window)
+    pool = _ZB_POOL.setdefault(key, [])
+    for buf in pool:
+        if buf._use_count() == 1:
+            return buf
+    buf = torch.zeros(shape, dtype=torch.float32, device=dev)
+    buf._dfl_zero_border = window
+    if len(pool) < 4:
+        pool.append(buf)
+    return buf
+
+
 class _LossFn(torch.autograd.Function):
+    """Value in forward (dfl_dice_ncc_loss stage 1: sums + value, gradient coefficients stay in the scratch), gradient in
+    backward (stage 2: one kernel, scaled by the incoming gradient on the device, written -- when the input is a window of
+    the network output, i.e. util.center_crop -- straight into a zero-bordered full-size tensor)."""
+
     @staticmethod
     def forward(ctx, seg, heat, tseg, theat, skip_bg, dice_wgt, heat_wgt):
         lib = nat.lib()
@@ -50,26 +89,51 @@ class _LossFn(torch.autograd.Function):
             a.heat_sN, a.heat_sC, a.heat_sH = heat_v.stride(0), heat_v.stride(1), heat_v.stride(2)
             a.theat_sN, a.theat_sC, a.theat_sH = theat_v.stride(0), theat_v.stride(1), theat_v.stride(2)
         dev = seg_v.device
-        want_seg = seg.requires_grad
-        want_heat = heat is not None and heat.requires_grad
         loss = torch.empty((), dtype=torch.float32, device=dev)
         sums = torch.empty(int(lib.dfl_loss_scratch_doubles(B, Cc, L)), dtype=torch.float64, device=dev)
-        dseg = torch.empty((B, Cc, h, w), dtype=torch.float32, device=dev) if want_seg else None
-        dheat = torch.empty((B, L, h, w), dtype=torch.float32, device=dev) if want_heat else None
-        a.loss, a.sums, a.dseg, a.dheat = loss.data_ptr(), sums.data_ptr(), nat.ptr(dseg), nat.ptr(dheat)
+        a.loss, a.sums = loss.data_ptr(), sums.data_ptr()
         a.B, a.C, a.L, a.h, a.w = B, Cc, L, h, w
         a.skip_bg = 1 if skip_bg else 0
         a.dice_wgt, a.heat_wgt = dice_wgt, heat_wgt
+        a.stage = 1
         nat.check(lib.dfl_dice_ncc_loss(C.addressof(a), torch.cuda.current_stream().cuda_stream), 'dfl_dice_ncc_loss')
-        ctx.dseg, ctx.dheat = dseg, dheat
-        ctx.has_heat = heat is not None
+        ctx.args = a
+        ctx.keep = (seg_v, tseg_v, heat_v, theat_v, sums, loss)       # the tensors the gradient stage reads
+        ctx.want = (seg.requires_grad, heat is not None and heat.requires_grad)
+        ctx.windows = (_window_of(seg, seg_v), _window_of(heat, heat_v) if heat is not None else None)
+        ctx.dims = (B, Cc, L, h, w)
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        dseg = ctx.dseg * g if ctx.dseg is not None else None
-        dheat = ctx.dheat * g if ctx.dheat is not None else None
-        return dseg, dheat, None, None, None, None, None
+        lib = nat.lib()
+        a = ctx.args
+        B, Cc, L, h, w = ctx.dims
+        dev = ctx.keep[0].device
+        gs = g.detach().to(torch.float32).reshape(1).contiguous()
+        a.stage = 2
+        a.grad_scale = gs.data_ptr()
+        outs = []
+        for want, win, nch, which in ((ctx.want[0], ctx.windows[0], Cc, 'dseg'), (ctx.want[1], ctx.windows[1], L, 'dheat')):
+            ptr, strides, out = None, (0, 0, 0), None
+            if want:
+                if win is not None:
+                    shape, r0, c0 = win
+                    buf = _zero_border_buffer(dev, shape, (r0, c0, h, w))
+                    H, W = shape[2], shape[3]
+                    ptr = buf.data_ptr() + 4 * (r0 * W + c0)
+                    strides = (nch * H * W, H * W, W)
+                    out = buf[..., r0:r0 + h, c0:c0 + w]
+                else:
+                    out = torch.empty((B, nch, h, w), dtype=torch.float32, device=dev)
+                    ptr = out.data_ptr()
+            setattr(a, which, ptr)
+            for name, v in zip(('_sN', '_sC', '_sH'), strides):
+                setattr(a, which + name, v)
+            outs.append(out)
+        if outs[0] is not None or outs[1] is not None:
+            nat.check(lib.dfl_dice_ncc_loss(C.addressof(a), torch.cuda.current_stream().cuda_stream), 'dfl_dice_ncc_loss')
+        return outs[0], outs[1], None, None, None, None, None
 
 
 class DiceLoss2D(torch.nn.modules.loss._Loss):

@@ -28,6 +28,30 @@ def get_device(no_gpu=False):
     return torch.device('cuda', torch.cuda.current_device())
 
 
+class _Crop(torch.autograd.Function):
+    """The centre window as a view, with a backward that knows the loss kernels: `dice._LossFn` writes its gradient
+    straight into the interior of a full-size tensor whose border is (and stays) zero and returns that interior as a
+    view -- which IS the gradient of the uncropped tensor, so no zero fill and no copy are left to do here (autograd's own
+    slice backward spends two passes over the full-size tensor per output and step).  Any other incoming gradient takes
+    the generic path."""
+
+    @staticmethod
+    def forward(ctx, img, r0, c0, h, w):
+        ctx.geom = (tuple(img.shape), r0, c0, h, w)
+        return img[..., r0:r0 + h, c0:c0 + w]
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, r0, c0, h, w = ctx.geom
+        base = g._base
+        if base is not None and tuple(base.shape) == shape and getattr(base, '_dfl_zero_border', None) == (r0, c0, h, w) \
+                and g.stride() == base.stride() and g.storage_offset() == base.storage_offset() + r0 * shape[-1] + c0:
+            return base, None, None, None, None
+        out = g.new_zeros(shape)
+        out[..., r0:r0 + h, c0:c0 + w] = g
+        return out, None, None, None, None
+
+
 def center_crop(img, dst_shape):
     """Centre window of the last two dims as a view; ``img`` itself when the sizes already match (util.py:92-114)."""
     rows, cols = img.shape[-2], img.shape[-1]
@@ -37,6 +61,8 @@ def center_crop(img, dst_shape):
     assert img.dim() in (2, 3, 4)
     r0 = int((rows - want_r) / 2)
     c0 = int((cols - want_c) / 2)
+    if img.dim() == 4 and img.is_cuda and img.requires_grad and torch.is_grad_enabled():
+        return _Crop.apply(img, r0, c0, want_r, want_c)
     return img[..., r0:r0 + want_r, c0:c0 + want_c]
 
 

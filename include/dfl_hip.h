@@ -362,6 +362,15 @@ typedef struct {
   int32_t B, C, L, h, w;
   int32_t skip_bg;
   float dice_wgt, heat_wgt;
+  /* Two-stage use (value in forward, gradient in backward -- what autograd asks for): stage 0 = everything in one call;
+   * stage 1 = sums + value only, the gradient coefficients stay in `sums`; stage 2 = gradient only, from the coefficients a
+   * stage-1 call left in the same `sums` (seg / heat / targets and sizes as then).  In stage 2 the gradients are
+   * multiplied by *grad_scale (a DEVICE scalar: the incoming gradient of the loss; NULL = 1) and may be written as
+   * strided [B,C,h,w] windows (element strides; all 0 = dense) -- e.g. the interior of a zero-bordered full-size tensor,
+   * which is the gradient of the uncropped network output without a padding pass. */
+  const float* grad_scale;
+  int64_t dseg_sN, dseg_sC, dseg_sH, dheat_sN, dheat_sC, dheat_sH;
+  int32_t stage, reserved;
 } dfl_loss_args;
 int dfl_dice_ncc_loss(const dfl_loss_args* a, dfl_stream_t stream);
 int64_t dfl_loss_scratch_doubles(int32_t B, int32_t C, int32_t L);
