@@ -231,3 +231,14 @@ def conv_rel_error(mode_name, dev='cuda'):
     e = _rms(y - ref) / _rms(ref)
     _EPS_CACHE[mode_name] = e
     return e
+
+
+_FLOORS = {}
+
+
+def cached_floor(key, make):
+    """One GradientFloor per test problem and session: the arithmetic modes a test is parametrised over share the oracle's
+    clean and noisy gradients (the spreads at each mode's own noise level are cached inside the object)."""
+    if key not in _FLOORS:
+        _FLOORS[key] = make()
+    return _FLOORS[key]

@@ -57,7 +57,7 @@ def test_config3_736_training_step_matches_oracle(math_mode):
     hs = float(oheat.abs().max())
     np.testing.assert_allclose(heat.detach().cpu().numpy(), oheat.numpy(), rtol=1e-4, atol=1e-4 * hs)
     # gradients and labels against the fp64 oracle: noise-floor bars (tests/noise_floor.py), rounding-margin label mask
-    gf = NF.GradientFloor(oracle64(cfg, onet.state_dict()), oracle_run(x, tseg, theat), seeds=(1, 2, 3))
+    gf = NF.cached_floor('config3', lambda: NF.GradientFloor(oracle64(cfg, onet.state_dict()), oracle_run(x, tseg, theat), seeds=(1, 2, 3)))
     oloss64 = float(R.dice_and_heatmap_loss_2d((R.center_crop(gf.out, tseg.shape), R.center_crop(oheat.double(), theat.shape)),
                                                (tseg.double(), theat.double()), skip_bg=False, heatmap_wgt=0.5))
     assert abs(loss.item() - oloss64) < 2e-5

@@ -649,6 +649,43 @@ def test_loss_on_cropped_views_full_size():
     aclose(hd.grad.cpu().numpy(), hr.grad.numpy(), rtol=1e-3, atol=1e-9)
 
 
+def test_two_losses_on_one_cropped_output_accumulate():
+    """The loss gradient is written into a pooled zero-bordered full-size tensor (dice._zero_border_buffer) and handed to
+    util._Crop's backward as is.  Two losses on the same network output in one backward pass must get two different
+    buffers (a buffer still referenced by autograd is not handed out again) and their gradients must add up."""
+    g = torch.Generator().manual_seed(31)
+    B = 2
+    seg = torch.softmax(torch.randn(B, 7, 48, 48, generator=g), 1)
+    heat = torch.randn(B, 14, 48, 48, generator=g) * 0.01
+    lab1, lab2 = torch.randint(0, 7, (B, 44, 44), generator=g), torch.randint(0, 7, (B, 44, 44), generator=g)
+    t1, t2 = R.one_hot_masks(lab1, 7), R.one_hot_masks(lab2, 7)
+    th = torch.rand(B, 14, 44, 44, generator=g) * 0.02
+    sr, hr = seg.clone().requires_grad_(True), heat.clone().requires_grad_(True)
+    lr = (R.dice_and_heatmap_loss_2d((R.center_crop(sr, t1.shape), R.center_crop(hr, th.shape)), (t1, th), False, 0.5)
+          + 3.0 * R.dice_and_heatmap_loss_2d((R.center_crop(sr, t2.shape), R.center_crop(hr, th.shape)), (t2, th), True, 0.25))
+    lr.backward()
+    sd, hd = seg.to(DEV).requires_grad_(True), heat.to(DEV).requires_grad_(True)
+    s_out, h_out = sd * 1.0, hd * 1.0                                  # non-leaf outputs, as a network's are
+    l1 = dfl_amd.DiceAndHeatMapLoss2D(skip_bg=False, heatmap_wgt=0.5)(
+        (dfl_amd.center_crop(s_out, t1.shape), dfl_amd.center_crop(h_out, th.shape)), (t1.to(DEV), th.to(DEV)))
+    l2 = dfl_amd.DiceAndHeatMapLoss2D(skip_bg=True, heatmap_wgt=0.25)(
+        (dfl_amd.center_crop(s_out, t2.shape), dfl_amd.center_crop(h_out, th.shape)), (t2.to(DEV), th.to(DEV)))
+    (l1 + 3.0 * l2).backward()
+    assert abs((l1 + 3.0 * l2).item() - lr.item()) < 5e-6
+    aclose(sd.grad.cpu().numpy(), sr.grad.numpy(), rtol=1e-3, atol=1e-9)
+    aclose(hd.grad.cpu().numpy(), hr.grad.numpy(), rtol=1e-3, atol=1e-9)
+    # a second pass re-uses the pooled buffers: same result
+    sd.grad = hd.grad = None
+    s_out, h_out = sd * 1.0, hd * 1.0
+    l1 = dfl_amd.DiceAndHeatMapLoss2D(skip_bg=False, heatmap_wgt=0.5)(
+        (dfl_amd.center_crop(s_out, t1.shape), dfl_amd.center_crop(h_out, th.shape)), (t1.to(DEV), th.to(DEV)))
+    l1.backward()
+    sr.grad = hr.grad = None
+    R.dice_and_heatmap_loss_2d((R.center_crop(sr, t1.shape), R.center_crop(hr, th.shape)), (t1, th), False, 0.5).backward()
+    aclose(sd.grad.cpu().numpy(), sr.grad.numpy(), rtol=1e-3, atol=1e-9)
+    aclose(hd.grad.cpu().numpy(), hr.grad.numpy(), rtol=1e-3, atol=1e-9)
+
+
 def test_sgd_step():
     lib = nat.lib()
     g = torch.Generator().manual_seed(6)

@@ -99,7 +99,7 @@ def test_tiny_golden(name, math_mode):
     sd0 = {k[4:]: _t(v) for k, v in g.items() if k.startswith('sd0/')}
     if has_grads:
         loss.backward()
-        gf = NF.GradientFloor(oracle64(cfg, sd0), oracle_run(_t(g['x']), _t(g['tseg']), _t(g['theat']) if nl > 0 else None))
+        gf = NF.cached_floor(('tiny', name), lambda: NF.GradientFloor(oracle64(cfg, sd0), oracle_run(_t(g['x']), _t(g['tseg']), _t(g['theat']) if nl > 0 else None)))
         got = {k: p.grad for k, p in net.named_parameters()}
         gf.check(got, seg, NF.conv_rel_error(math_mode), what=name + ' ')
         # ... and against the REFERENCE's own (fp32) gradients: inside the same bars plus the reference's own distance
@@ -124,7 +124,7 @@ def test_tiny_golden(name, math_mode):
         ol = R.dice_and_heatmap_loss_2d((R.center_crop(oo[0], g['tseg'].shape), R.center_crop(oo[1], g['theat'].shape)),
                                         (_t(g['tseg']), _t(g['theat'])), skip_bg=False, heatmap_wgt=0.5)
         ol.backward()
-        gf = NF.GradientFloor(oracle64(cfg, sd0), oracle_run(_t(g['x']), _t(g['tseg']), _t(g['theat'])))
+        gf = NF.cached_floor(('tiny-nobn', name), lambda: NF.GradientFloor(oracle64(cfg, sd0), oracle_run(_t(g['x']), _t(g['tseg']), _t(g['theat']))))
         gf.check({k: p.grad for k, p in net.named_parameters()}, seg, NF.conv_rel_error(math_mode), what=name + ' ')
     for k in [k for k in g if k.startswith('sd1/')]:
         np.testing.assert_allclose(net.state_dict()[k[4:]].cpu().numpy(), g[k], rtol=1e-4, atol=1e-6, err_msg=k)
@@ -514,7 +514,7 @@ def test_ragged_sizes_match_oracle(hw, max_pool, math_mode):
     assert abs(loss.item() - oloss.item()) < 1e-5
     loss.backward()
     oloss.backward()
-    gf = NF.GradientFloor(oracle64(cfg, onet.state_dict()), oracle_run(x, tseg, theat))
+    gf = NF.cached_floor(('ragged', H, W, bool(max_pool)), lambda: NF.GradientFloor(oracle64(cfg, onet.state_dict()), oracle_run(x, tseg, theat)))
     gf.check({k: p.grad for k, p in net.named_parameters()}, seg, NF.conv_rel_error(math_mode), 'ragged %dx%d ' % (H, W))
 
 
@@ -767,5 +767,5 @@ def test_random_architectures_match_oracle(seed, math_mode):
     assert abs(loss.item() - oloss.item()) < 2e-5 * max(1.0, abs(oloss.item()))
     loss.backward()
     oloss.backward()
-    gf = NF.GradientFloor(oracle64(cfg, onet.state_dict()), oracle_run(x, tseg, theat if L > 0 else None, skip_bg=bool(seed % 2)))
+    gf = NF.cached_floor(('random', seed), lambda: NF.GradientFloor(oracle64(cfg, onet.state_dict()), oracle_run(x, tseg, theat if L > 0 else None, skip_bg=bool(seed % 2))))
     gf.check({k: p.grad for k, p in net.named_parameters()}, seg, NF.conv_rel_error(math_mode), 'random architecture %d ' % seed)

@@ -142,3 +142,45 @@ def test_module_copies_and_pickles_without_its_recorded_programs():
         base = m._param_flat.data_ptr()
         assert all(base <= p.data_ptr() < base + 4 * m._param_flat.numel() for p in m.parameters())
     assert owner_of(next(net.parameters())) is net
+
+
+def test_late_scalars_deliver_every_value_in_order():
+    """util.LateScalars on CPU tensors degenerates to .item(); the queue logic (depth, flush) is device independent."""
+    from dfl_amd.util import LateScalars
+    late = LateScalars(depth=1)
+    got = [late.push(torch.tensor(float(i))) for i in range(4)]
+    assert got == [0.0, 1.0, 2.0, 3.0] and late.flush() == []          # CPU tensors are read at once
+    sync = LateScalars(depth=0)
+    assert sync.push(torch.tensor(2.5)) == 2.5 and sync.flush() == []
+
+
+def test_center_crop_keeps_the_plain_view_off_the_training_path():
+    """Tensors that need no gradient (targets, inference outputs) and CPU tensors get the reference's plain slice; the
+    autograd-aware window (util._Crop) is for GPU tensors that require a gradient."""
+    t = torch.arange(2 * 3 * 8 * 8, dtype=torch.float32).view(2, 3, 8, 8)
+    c = dfl_amd.center_crop(t, (2, 3, 4, 6))
+    assert c.shape == (2, 3, 4, 6) and c._base is not None and c.data_ptr() == t[..., 2:, 1:].data_ptr()      # a view, no copy
+    t.requires_grad_(True)
+    c = dfl_amd.center_crop(t * 1.0, (4, 4))                              # CPU: generic autograd slice
+    c.sum().backward()
+    assert float(t.grad.sum()) == 2 * 3 * 16
+    # the generic branch of the custom backward (a gradient that is not the loss kernels' zero-bordered window)
+    from dfl_amd.util import _Crop
+    x = torch.randn(1, 2, 6, 6, requires_grad=True)
+    y = _Crop.apply(x * 1.0, 1, 2, 3, 3)
+    (y * torch.arange(9.0).view(3, 3)).sum().backward()
+    want = torch.zeros(1, 2, 6, 6)
+    want[..., 1:4, 2:5] = torch.arange(9.0).view(3, 3)
+    assert torch.equal(x.grad, want)
+
+
+def test_loss_stage_and_stride_arguments_are_validated():
+    L = nat.lib()
+    a = nat.LossArgs()
+    a.loss = a.sums = a.seg = a.tseg = 4096
+    a.B, a.C, a.h, a.w = 1, 2, 4, 4
+    a.stage = 3
+    assert L.dfl_dice_ncc_loss(C.addressof(a), None) < 0 and b'stage' in L.dfl_last_error()
+    a.stage = 2
+    a.dseg_sN = 64                                                        # a stride without its partners
+    assert L.dfl_dice_ncc_loss(C.addressof(a), None) < 0 and b'strides' in L.dfl_last_error()
