@@ -35,7 +35,8 @@ CONV_KERNELS = ['conv_gemm_kernel<2,2,2,2>', 'conv_gemm_kernel<2,2,2,1>', 'conv_
                 'conv_gemm_kernel<2,2,1,1>', 'conv_gemm_kernel<1,2,1,1>', 'direct_conv_kernel',
                 'conv_rows_kernel<3,1,2,1>', 'conv_rows_kernel<3,1,1,2>', 'conv_rows_kernel<3,1,1,1>']
 CONVP_TILES = ['4,1,2,1', '4,1,1,1', '2,2,4,1', '2,2,3,1', '2,2,2,1', '1,4,2,1', '1,4,3,1', '1,4,4,1', '1,4,6,1', '1,4,9,1', '2,2,1,1', '1,4,1,1',
-               '4,1,3,1', '4,1,4,1', '2,2,6,1', '2,2,2,2', '2,2,3,2', '2,2,4,2', '4,1,2,2', '4,1,3,2', '1,4,2,2', '1,4,3,2']      # csrc/convp_bf16.hip kTiles: waves M x N, tiles M x N per wave
+               '4,1,3,1', '4,1,4,1', '2,2,6,1', '2,2,2,2', '2,2,3,2', '2,2,4,2', '4,1,2,2', '4,1,3,2', '1,4,2,2', '1,4,3,2',
+               '4,1,1,1', '4,1,2,1', '2,2,1,1', '2,2,2,1', '1,4,1,1', '1,4,2,1', '4,1,1,2', '2,2,1,2']   # (22 ...: the streamed 1x1 forms)      # csrc/convp_bf16.hip kTiles: waves M x N, tiles M x N per wave
 WGRAD_KERNELS = ['wgrad_kernel<2,2,2,2,1>', 'wgrad_kernel<2,2,1,1,1>', 'wgrad_kernel<1,1,1,1,3>',
                  'wgrad_kernel<1,1,1,1,2>', 'wgrad_kernel<1,1,1,1,1>', 'direct_wgrad_kernel', 'wgrad_kernel<2,2,1,1,3>']
 

@@ -49,7 +49,7 @@ __device__ __forceinline__ uint32_t pack_bf2(float a, float b) {
 __device__ __forceinline__ float round_bf(float v) { return (float)(__bf16)v; }
 __device__ __forceinline__ float ld_bf(const __bf16* p) { return (float)*p; }
 
-template <int WM, int WN, int TM, int TN, bool AFF>
+template <int WM, int WN, int TM, int TN, bool AFF, bool GA>
 __global__ void __launch_bounds__(256, (TM * TN >= 6) ? 1 : 2) convp_kernel(const ConvP p) {
   static_assert(WM * WN == 4, "four waves per workgroup");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -147,6 +147,67 @@ __global__ void __launch_bounds__(256, (TM * TN >= 6) ? 1 : 2) convp_kernel(cons
 #define TR(i)
 #define TRACC(i, t0)
 #endif
+  if constexpr (GA) {
+    // ---- 1x1 / stride 1 windows without an affine on load ("global A"): the input pixel of a GEMM row IS its output pixel,
+    //      so the A fragment of a lane -- 8 channels of its row -- is one 16-byte load straight from the tensor, like the B
+    //      fragment.  No LDS image, no staging round trip before the first matrix instruction, no barrier before the
+    //      epilogue; a wave keeps two groups of k-steps (A and B) in flight.  These layers are HBM streams (K = Cin is
+    //      2 ... 64 k-steps): what they need is bytes in flight, not the patch reuse the LDS image exists for.
+    uint32_t a_goff[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int q = (wm * TM + i) * 32 + li;
+      const int img = q / PP;
+      const int r = q - img * PP;
+      const int py = r / p.PW, px = r - py * p.PW;
+      const int n = img0 + img, gy = gy0 + py, gx = gx0 + px;
+      const bool ok = img < p.IPP && n < a.N && gy < p.Hg && gx < p.Wg;
+      a_goff[i] = ok ? (uint32_t)(((n * a.Hin + gy) * a.Win + gx) * a.ldx) * 2u + (uint32_t)lh * 16u : POOB;
+    }
+    constexpr int GG = 2;
+    const int steps = a.Cin >> 4;
+    const int ngr = (steps + GG - 1) / GG;
+    pu32x4 areg[3][GG][TM], bqreg[3][GG][TN];
+    int ls = 0;
+    const uint32_t bstep = (uint32_t)a.Ntot * 32u;
+    auto load_gr = [&](int set) {
+#pragma unroll
+      for (int e = 0; e < GG; ++e) {
+        const bool live = ls < steps;
+        const uint32_t ao = live ? (uint32_t)ls * 32u : 0u, bo = live ? (uint32_t)ls * bstep : 0u;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) areg[set][e][i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, live ? a_goff[i] : POOB, ao, 0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bqreg[set][e][j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, live ? b_voff[j] : POOB, bo, 0);
+        ++ls;
+      }
+    };
+    auto compute_gr = [&](int set) {
+#pragma unroll
+      for (int e = 0; e < GG; ++e)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, bqreg[set][e][j]);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, areg[set][e][i]), bf, acc[i][j], 0, 0, 0);
+        }
+    };
+    load_gr(0);
+    load_gr(1);
+    for (int g = 0; g < ngr; g += 3) {
+      load_gr(2);
+      compute_gr(0);
+      if (g + 1 < ngr) {
+        load_gr(0);
+        compute_gr(1);
+      }
+      if (g + 2 < ngr) {
+        load_gr(1);
+        compute_gr(2);
+      }
+    }
+  } else {
   const int blk_begin = bslice * p.blk_per_slice;
   const int blk_end = min(blk_begin + p.blk_per_slice, p.nblk);
   for (int blk = blk_begin; blk < blk_end; ++blk) {
@@ -275,6 +336,7 @@ __global__ void __launch_bounds__(256, (TM * TN >= 6) ? 1 : 2) convp_kernel(cons
       }
     }
     TRACC(2, tb1)
+  }
   }
   TR(3)
 
@@ -529,13 +591,16 @@ __global__ void __launch_bounds__(256) convp_finish_kernel(const ConvP p, int TX
 
 // ---- host side ------------------------------------------------------------------------------------------------------
 
-struct TileCfg { int WM, WN, TM, TN; };
+struct TileCfg { int WM, WN, TM, TN, GA; };   // GA: A fragments straight from global memory (1x1 windows, see the kernel)
 // value reported by dfl_conv_config for these kernels = 16 + index
-static const TileCfg kTiles[] = {{4, 1, 2, 1}, {4, 1, 1, 1}, {2, 2, 4, 1}, {2, 2, 3, 1}, {2, 2, 2, 1}, {1, 4, 2, 1},
-                                 {1, 4, 3, 1}, {1, 4, 4, 1}, {1, 4, 6, 1}, {1, 4, 9, 1}, {2, 2, 1, 1}, {1, 4, 1, 1},
-                                 {4, 1, 3, 1}, {4, 1, 4, 1}, {2, 2, 6, 1},
+static const TileCfg kTiles[] = {{4, 1, 2, 1, 0}, {4, 1, 1, 1, 0}, {2, 2, 4, 1, 0}, {2, 2, 3, 1, 0}, {2, 2, 2, 1, 0}, {1, 4, 2, 1, 0},
+                                 {1, 4, 3, 1, 0}, {1, 4, 4, 1, 0}, {1, 4, 6, 1, 0}, {1, 4, 9, 1, 0}, {2, 2, 1, 1, 0}, {1, 4, 1, 1, 0},
+                                 {4, 1, 3, 1, 0}, {4, 1, 4, 1, 0}, {2, 2, 6, 1, 0},
                                  // two column tiles per wave: half the LDS fragment reads per matrix instruction
-                                 {2, 2, 2, 2}, {2, 2, 3, 2}, {2, 2, 4, 2}, {4, 1, 2, 2}, {4, 1, 3, 2}, {1, 4, 2, 2}, {1, 4, 3, 2}};
+                                 {2, 2, 2, 2, 0}, {2, 2, 3, 2, 0}, {2, 2, 4, 2, 0}, {4, 1, 2, 2, 0}, {4, 1, 3, 2, 0}, {1, 4, 2, 2, 0}, {1, 4, 3, 2, 0},
+                                 // 1x1 windows streamed from global memory (22 ...): only ever chosen through the measured table
+                                 {4, 1, 1, 1, 1}, {4, 1, 2, 1, 1}, {2, 2, 1, 1, 1}, {2, 2, 2, 1, 1}, {1, 4, 1, 1, 1}, {1, 4, 2, 1, 1},
+                                 {4, 1, 1, 2, 1}, {2, 2, 1, 2, 1}};
 constexpr int kNumTiles = (int)(sizeof(kTiles) / sizeof(kTiles[0]));
 constexpr size_t kLdsSoft = 64 * 1024, kLdsHard = 150 * 1024;
 
@@ -563,6 +628,22 @@ static bool try_geometry(const dfl_conv_args& a, ConvP* p, const TileCfg& t, int
   p->IH = (ph - 1) * a.stride + a.KH;
   p->IW = (pw - 1) * a.stride + a.KW;
   const int64_t npix = (int64_t)ipp * p->IH * p->IW;
+  if (t.GA) {
+    // streamed 1x1 window: no LDS image, no K slices; scored only by measurement (tools/tune_convp.py)
+    if (a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0 || a.in_scale != nullptr || want_splits > 1) return false;
+    p->CK = 16;
+    p->nblk = a.Cin / 16;
+    p->splits = 1;
+    p->blk_per_slice = p->nblk;
+    p->pix_stride = 48;
+    p->upp_shift = 1;
+    p->lds_bytes = 0;
+    p->ntiles = (int)ceil_div(a.Ntot, t.WN * t.TN * 32);
+    p->xcd_mode = 0;
+    p->grid = p->npatch * p->ntiles;
+    *cost = 1e290;
+    return true;
+  }
   // resident channels: the largest power-of-two multiple of 16 (<= 128, dividing Cin) whose image fits
   int ck = 128;
   while (ck > 16 && (a.Cin % ck != 0 || npix * (ck * 2 + 16) > (int64_t)kLdsSoft)) ck >>= 1;
@@ -684,7 +765,7 @@ static void for_each_candidate(const dfl_conv_args& a, const ConvP& base, int fo
     if (wide) {
       if (bn > n32 || (bn < 64 && n32 >= 64) || (t.TN > 1 && bn > a.Ntot)) continue;
     } else {
-      if (t.TN != 1) continue;                       // the model was fitted on the one-column-tile configurations
+      if (t.TN != 1 || t.GA) continue;               // the model was fitted on the one-column-tile configurations
       if (a.Ntot <= 32 && t.WN != 1) continue;
       if (a.Ntot > 32 && a.Ntot <= 64 && t.WN != 2) continue;
       if (a.Ntot > 64 && t.WN != 4) continue;
@@ -808,7 +889,7 @@ int convp_plan(const dfl_conv_args* a, ConvP* p, int force_splits) {
   return DFL_OK;
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool GA = false>
 static int convp_launch_t(const ConvP& p, hipStream_t s) {
   const bool aff = p.a.in_scale != nullptr;
   dim3 grid((unsigned)p.grid);
@@ -818,12 +899,14 @@ static int convp_launch_t(const ConvP& p, hipStream_t s) {
   const size_t red = (size_t)(256 / (BN_ / 8)) * 2 * BN_ * sizeof(float);      // statistics scratch
   if (lds < epi) lds = epi;
   if (lds < red) lds = red;
-  if (aff) {
-    auto k = convp_kernel<WM, WN, TM, TN, true>;
+  if constexpr (GA) {
+    hipLaunchKernelGGL((convp_kernel<WM, WN, TM, TN, false, true>), grid, dim3(256), lds, s, p);
+  } else if (aff) {
+    auto k = convp_kernel<WM, WN, TM, TN, true, false>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, grid, dim3(256), lds, s, p);
   } else {
-    auto k = convp_kernel<WM, WN, TM, TN, false>;
+    auto k = convp_kernel<WM, WN, TM, TN, false, false>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, grid, dim3(256), lds, s, p);
   }
@@ -854,7 +937,15 @@ int convp_launch(const ConvP& p, hipStream_t s) {
     case 18: rc = convp_launch_t<4, 1, 2, 2>(p, s); break;
     case 19: rc = convp_launch_t<4, 1, 3, 2>(p, s); break;
     case 20: rc = convp_launch_t<1, 4, 2, 2>(p, s); break;
-    default: rc = convp_launch_t<1, 4, 3, 2>(p, s); break;
+    case 21: rc = convp_launch_t<1, 4, 3, 2>(p, s); break;
+    case 22: rc = convp_launch_t<4, 1, 1, 1, true>(p, s); break;
+    case 23: rc = convp_launch_t<4, 1, 2, 1, true>(p, s); break;
+    case 24: rc = convp_launch_t<2, 2, 1, 1, true>(p, s); break;
+    case 25: rc = convp_launch_t<2, 2, 2, 1, true>(p, s); break;
+    case 26: rc = convp_launch_t<1, 4, 1, 1, true>(p, s); break;
+    case 27: rc = convp_launch_t<1, 4, 2, 1, true>(p, s); break;
+    case 28: rc = convp_launch_t<4, 1, 1, 2, true>(p, s); break;
+    default: rc = convp_launch_t<2, 2, 1, 2, true>(p, s); break;
   }
   if (rc != DFL_OK || p.splits <= 1) return rc;
   int tx = 1;

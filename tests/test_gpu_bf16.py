@@ -214,7 +214,9 @@ def _candidates(N, Cin, Cout, H, W, K, stride, pad):
 
 
 @pytest.mark.parametrize('case', [(2, 64, 128, 17, 11, 3, 1, 1), (4, 128, 256, 24, 24, 3, 1, 1), (3, 64, 64, 13, 9, 3, 1, 1),
-                                  (2, 32, 32, 24, 20, 3, 1, 1), (16, 256, 256, 6, 6, 3, 1, 1)])
+                                  (2, 32, 32, 24, 20, 3, 1, 1), (16, 256, 256, 6, 6, 3, 1, 1),
+                                  # 1x1 windows: also the configurations that stream A fragments from global memory
+                                  (2, 64, 128, 16, 16, 1, 1, 0), (4, 128, 32, 24, 24, 1, 1, 0), (3, 32, 64, 13, 9, 1, 1, 0)])
 def test_convp_every_tile_configuration(case):
     """The tuning table (dfl_conv_tune_add) may select any candidate of the geometry search: every tile configuration the
     layer admits -- including the two-column-tile ones the cost model never picks -- is forced once per K-slice count
@@ -244,6 +246,58 @@ def test_convp_every_tile_configuration(case):
         yd = y.double().reshape(-1, Cout)
         np.testing.assert_allclose(st[0].numpy(), yd.sum(0).numpy(), rtol=2e-5, atol=2e-5 * float(yd.abs().sum(0).max()))
     assert len(tiles) >= 3, tiles
+
+
+def test_convp_streamed_1x1_forms_with_scatter_and_residual_epilogues():
+    """The global-A configurations (tile index >= 22) under the epilogues 1x1 layers use in the network: the transposed
+    convolution's 2x2 scatter into a channel half of a wider buffer, and bias + '+ BN(other)' + statistics."""
+    lib = nat.lib()
+    g = torch.Generator().manual_seed(77)
+    N, Ci, Co, H, W = 2, 64, 32, 10, 7
+    x = rb(torch.randn(N, Ci, H, W, generator=g))
+    wt = rb(torch.randn(Ci, Co, 2, 2, generator=g) / (4 * Ci) ** 0.5)
+    bt = torch.randn(Co, generator=g)
+    ref_t = nhwc(F.conv_transpose2d(x.double(), wt.double(), bt.double(), stride=2))
+    w1 = rb(torch.randn(Co, Ci, 1, 1, generator=g) / Ci ** 0.5)
+    b1 = torch.randn(Co, generator=g)
+    other = rb(torch.randn(N, Co, H, W, generator=g))
+    asc, ash = torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g) * 0.2
+    ref_1 = nhwc(F.conv2d(x.double(), w1.double(), b1.double()) + other.double() * asc.double().view(1, -1, 1, 1) + ash.double().view(1, -1, 1, 1))
+    a = nat.ConvArgs()
+    a.x = a.w = a.y = 4096
+    a.x_bf16, a.y_bf16, a.w_split = 1, 1, 2
+    a.N, a.Hin, a.Win, a.Cin, a.ldx = N, H, W, Ci, Ci
+    a.KH = a.KW = 1
+    a.stride, a.pad = 1, 0
+    out = (C.c_int32 * (5 * 4096))()
+    seen = 0
+    for scatter in (1, 0):
+        a.scatter2x2 = scatter
+        a.Hout, a.Wout = (2 * H, 2 * W) if scatter else (H, W)
+        a.Ntot, a.ldy = (4 * Co, 2 * Co) if scatter else (Co, Co)
+        n = nat.check(lib.dfl_conv_candidates(C.addressof(a), C.addressof(out), 4096), 'candidates')
+        cands = [tuple(out[5 * i + j] for j in range(5)) for i in range(n)]
+        tiles = {}
+        for c in cands:
+            if c[0] >= 22:
+                tiles.setdefault(c[0], c)
+        assert tiles, 'no streamed configuration among the candidates'
+        for geom in tiles.values():
+            gv = (C.c_int32 * 5)(*geom)
+            nat.check(lib.dfl_conv_force_geometry(C.addressof(gv)), 'force')
+            try:
+                if scatter:
+                    y = conv_bf16(x, pack16(wt, 3), 4 * Co, 1, 1, 1, 0, 2 * H, 2 * W, bias=bt, scatter=1, ldy=2 * Co, force_splits=1)
+                    close_bf16(y, ref_t, 'scatter %s' % (geom,))
+                else:
+                    y, st = conv_bf16(x, pack16(w1, 1), Co, 1, 1, 1, 0, H, W, bias=b1, add=other, add_aff=(asc, ash), stats=True, force_splits=1)
+                    close_bf16(y, ref_1, 'residual %s' % (geom,))
+                    yd = y.double().reshape(-1, Co)
+                    np.testing.assert_allclose(st[0].numpy(), yd.sum(0).numpy(), rtol=2e-5, atol=2e-5 * float(yd.abs().sum(0).max()))
+            finally:
+                lib.dfl_conv_force_geometry(None)
+            seen += 1
+    assert seen >= 4
 
 
 def test_convp_tuning_table_entry_is_used_and_validated():
