@@ -148,9 +148,9 @@ __global__ void __launch_bounds__(256, (TM * TN >= 6) ? 1 : 2) convp_kernel(cons
 #define TRACC(i, t0)
 #endif
   if constexpr (GA) {
-    // ---- 1x1 / stride 1 windows without an affine on load ("global A"): the input pixel of a GEMM row IS its output pixel,
-    //      so the A fragment of a lane -- 8 channels of its row -- is one 16-byte load straight from the tensor, like the B
-    //      fragment.  No LDS image, no staging round trip before the first matrix instruction, no barrier before the
+    // ---- Windows that do not overlap (1x1 / stride 1, 2x2 / stride 2; no padding, no affine on load), "global A": every
+    //      input pixel belongs to ONE GEMM row, so there is nothing to share through LDS and the A fragment of a lane -- 8
+    //      channels of one pixel of its row's window -- is one 16-byte load straight from the tensor, like the B fragment.  No LDS image, no staging round trip before the first matrix instruction, no barrier before the
     //      epilogue; a wave keeps two groups of k-steps (A and B) in flight.  These layers are HBM streams (K = Cin is
     //      2 ... 64 k-steps): what they need is bytes in flight, not the patch reuse the LDS image exists for.
     uint32_t a_goff[TM];
@@ -162,24 +162,37 @@ __global__ void __launch_bounds__(256, (TM * TN >= 6) ? 1 : 2) convp_kernel(cons
       const int py = r / p.PW, px = r - py * p.PW;
       const int n = img0 + img, gy = gy0 + py, gx = gx0 + px;
       const bool ok = img < p.IPP && n < a.N && gy < p.Hg && gx < p.Wg;
-      a_goff[i] = ok ? (uint32_t)(((n * a.Hin + gy) * a.Win + gx) * a.ldx) * 2u + (uint32_t)lh * 16u : POOB;
+      a_goff[i] = ok ? (uint32_t)(((n * a.Hin + gy * a.stride) * a.Win + gx * a.stride) * a.ldx) * 2u + (uint32_t)lh * 16u : POOB;
     }
     constexpr int GG = 2;
-    const int steps = a.Cin >> 4;
+    const int chunks = a.Cin >> 4;
+    const int steps = p.T * chunks;                    // k = tap * Cin + c, as the weights are packed
     const int ngr = (steps + GG - 1) / GG;
     pu32x4 areg[3][GG][TM], bqreg[3][GG][TN];
-    int ls = 0;
+    int ls = 0, lcc = 0, ltx = 0;
+    uint32_t lao = 0;                                  // byte offset of (tap, chunk) from the window's first pixel
     const uint32_t bstep = (uint32_t)a.Ntot * 32u;
+    const uint32_t pixb = (uint32_t)a.ldx * 2u;
+    const uint32_t tap_x = pixb - (uint32_t)chunks * 32u, tap_y = (uint32_t)(a.Win - a.KW) * pixb;
     auto load_gr = [&](int set) {
 #pragma unroll
       for (int e = 0; e < GG; ++e) {
         const bool live = ls < steps;
-        const uint32_t ao = live ? (uint32_t)ls * 32u : 0u, bo = live ? (uint32_t)ls * bstep : 0u;
+        const uint32_t ao = live ? lao : 0u, bo = live ? (uint32_t)ls * bstep : 0u;
 #pragma unroll
         for (int i = 0; i < TM; ++i) areg[set][e][i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, live ? a_goff[i] : POOB, ao, 0);
 #pragma unroll
         for (int j = 0; j < TN; ++j) bqreg[set][e][j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, live ? b_voff[j] : POOB, bo, 0);
         ++ls;
+        lao += 32u;
+        if (++lcc == chunks) {
+          lcc = 0;
+          lao += tap_x;
+          if (++ltx == a.KW) {
+            ltx = 0;
+            lao += tap_y;
+          }
+        }
       }
     };
     auto compute_gr = [&](int set) {
@@ -629,8 +642,9 @@ static bool try_geometry(const dfl_conv_args& a, ConvP* p, const TileCfg& t, int
   p->IW = (pw - 1) * a.stride + a.KW;
   const int64_t npix = (int64_t)ipp * p->IH * p->IW;
   if (t.GA) {
-    // streamed 1x1 window: no LDS image, no K slices; scored only by measurement (tools/tune_convp.py)
-    if (a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0 || a.in_scale != nullptr || want_splits > 1) return false;
+    // streamed non-overlapping window (1x1 / stride 1, 2x2 / stride 2): no LDS image, no K slices; scored only by
+    // measurement (tools/tune_convp.py)
+    if (a.KH != a.KW || a.stride != a.KH || a.KH > 2 || a.pad != 0 || a.in_scale != nullptr || want_splits > 1) return false;
     p->CK = 16;
     p->nblk = a.Cin / 16;
     p->splits = 1;

@@ -216,7 +216,8 @@ def _candidates(N, Cin, Cout, H, W, K, stride, pad):
 @pytest.mark.parametrize('case', [(2, 64, 128, 17, 11, 3, 1, 1), (4, 128, 256, 24, 24, 3, 1, 1), (3, 64, 64, 13, 9, 3, 1, 1),
                                   (2, 32, 32, 24, 20, 3, 1, 1), (16, 256, 256, 6, 6, 3, 1, 1),
                                   # 1x1 windows: also the configurations that stream A fragments from global memory
-                                  (2, 64, 128, 16, 16, 1, 1, 0), (4, 128, 32, 24, 24, 1, 1, 0), (3, 32, 64, 13, 9, 1, 1, 0)])
+                                  (2, 64, 128, 16, 16, 1, 1, 0), (4, 128, 32, 24, 24, 1, 1, 0), (3, 32, 64, 13, 9, 1, 1, 0),
+                                  (2, 32, 64, 12, 10, 2, 2, 0), (3, 64, 64, 7, 9, 2, 2, 0)])      # 2x2 / stride 2 (odd input: last row / column unused)
 def test_convp_every_tile_configuration(case):
     """The tuning table (dfl_conv_tune_add) may select any candidate of the geometry search: every tile configuration the
     layer admits -- including the two-column-tile ones the cost model never picks -- is forced once per K-slice count
