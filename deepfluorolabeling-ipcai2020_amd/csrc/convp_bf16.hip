@@ -47,6 +47,9 @@ __device__ __forceinline__ uint32_t pack_bf2(float a, float b) {
   return __builtin_bit_cast(uint32_t, h);
 }
 __device__ __forceinline__ float round_bf(float v) { return (float)(__bf16)v; }
+// q / d for the small row indices of a patch (q < 65536, d < 65536): one multiply-high with m = ceil(2^32 / d) from the host
+// (the epilogue decodes a patch row into (image, y, x) for every row it stores: two 35-instruction divisions each before)
+__device__ __forceinline__ int pdiv(int q, uint32_t m, int d) { return d == 1 ? q : (int)__umulhi((uint32_t)q, m); }
 __device__ __forceinline__ float ld_bf(const __bf16* p) { return (float)*p; }
 
 template <int WM, int WN, int TM, int TN, bool AFF, bool GA>
@@ -98,9 +101,9 @@ __global__ void __launch_bounds__(256, (TM * TN >= 6) ? 1 : 2) convp_kernel(cons
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     int q = (wm * TM + i) * 32 + li;
-    int img = q / PP;
+    int img = pdiv(q, p.mPP, PP);
     int r = q - img * PP;
-    int py = r / p.PW, px = r - py * p.PW;
+    int py = pdiv(r, p.mPW, p.PW), px = r - py * p.PW;
     if (img >= p.IPP) img = 0, py = 0, px = 0;   // padding rows of the last tile: any valid address, results are dropped
     a_base[i] = (uint32_t)(((img * p.IH + py * a.stride) * p.IW + px * a.stride) * S + lh * 16);
   }
@@ -157,9 +160,9 @@ __global__ void __launch_bounds__(256, (TM * TN >= 6) ? 1 : 2) convp_kernel(cons
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int q = (wm * TM + i) * 32 + li;
-      const int img = q / PP;
+      const int img = pdiv(q, p.mPP, PP);
       const int r = q - img * PP;
-      const int py = r / p.PW, px = r - py * p.PW;
+      const int py = pdiv(r, p.mPW, p.PW), px = r - py * p.PW;
       const int n = img0 + img, gy = gy0 + py, gx = gx0 + px;
       const bool ok = img < p.IPP && n < a.N && gy < p.Hg && gx < p.Wg;
       a_goff[i] = ok ? (uint32_t)(((n * a.Hin + gy * a.stride) * a.Win + gx * a.stride) * a.ldx) * 2u + (uint32_t)lh * 16u : POOB;
@@ -363,9 +366,9 @@ __global__ void __launch_bounds__(256, (TM * TN >= 6) ? 1 : 2) convp_kernel(cons
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int q = (wm * TM + i) * 32 + 8 * g + 4 * lh;
-        int img = q / PP;
+        int img = pdiv(q, p.mPP, PP);
         int r = q - img * PP;
-        int py = r / p.PW, px = r - py * p.PW;
+        int py = pdiv(r, p.mPW, p.PW), px = r - py * p.PW;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const int n = img0 + img, gy = gy0 + py, gx = gx0 + px;
@@ -449,9 +452,9 @@ __global__ void __launch_bounds__(256, (TM * TN >= 6) ? 1 : 2) convp_kernel(cons
 #endif
     for (int rl = urow; rl < WM * 32; rl += RPS) {    // row rl of the image = row (rl / 32) * TM*32 + i*32 + rl % 32 of the patch
       const int q = ((rl >> 5) * TM + i) * 32 + (rl & 31);
-      const int img = q / PP;
+      const int img = pdiv(q, p.mPP, PP);
       const int rr = q - img * PP;
-      const int py = rr / p.PW, px = rr - py * p.PW;
+      const int py = pdiv(rr, p.mPW, p.PW), px = rr - py * p.PW;
       const int n = img0 + img, gy = gy0 + py, gx = gx0 + px;
       if (!(cok && img < p.IPP && n < a.N && gy < p.Hg && gx < p.Wg)) continue;
       const int64_t m = ((int64_t)n * p.Hg + gy) * p.Wg + gx;
@@ -635,6 +638,8 @@ static bool try_geometry(const dfl_conv_args& a, ConvP* p, const TileCfg& t, int
   p->IPP = ipp;
   p->PH = ph;
   p->PW = pw;
+  p->mPP = (uint32_t)(((1ull << 32) + (uint64_t)(ph * pw) - 1) / (uint64_t)(ph * pw));
+  p->mPW = (uint32_t)(((1ull << 32) + (uint64_t)pw - 1) / (uint64_t)pw);
   p->npy = (int)ceil_div(p->Hg, ph);
   p->npx = (int)ceil_div(p->Wg, pw);
   p->npatch = (int)ceil_div(a.N, ipp) * p->npy * p->npx;
