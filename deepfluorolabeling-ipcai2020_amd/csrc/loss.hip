@@ -181,36 +181,62 @@ __global__ void __launch_bounds__(256) loss_finalize_kernel(const dfl_loss_args 
   }
 }
 
+// Gradient stage: blockIdx.x = plane ((image, class) for the Dice part, then (image, landmark)), blockIdx.y = one of LOSS_NS
+// row ranges, a wave per row, a lane per 4 pixels (float4 when the windows are 16-byte aligned) -- no index division per
+// element.  dseg = gs * (a1 * t + a2 * s), dheat = gs * (k1 * y + k2 * x + k0) with the per-plane coefficients of the
+// finalize kernel and gs = the incoming gradient of the loss.
 __global__ void __launch_bounds__(256) loss_grad_kernel(const dfl_loss_args a) {
   const int BC = a.B * a.C, BL = a.B * a.L;
-  const int64_t hw = (int64_t)a.h * a.w;
   const double* dcoef = a.sums + (int64_t)BC * 3 + (int64_t)BL * 5;
   const double* ncoef = dcoef + (int64_t)BC * 2;
-  const int64_t nseg = (a.dseg != nullptr) ? (int64_t)BC * hw : 0;
-  const int64_t nheat = (a.dheat != nullptr && a.L > 0) ? (int64_t)BL * hw : 0;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const float gs = a.grad_scale != nullptr ? *a.grad_scale : 1.f;
-  const bool sdense = a.dseg_sN == 0, hdense = a.dheat_sN == 0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nseg + nheat; i += stride) {
-    if (i < nseg) {
-      const int64_t pc = i / hw;
-      const int64_t rem = i - pc * hw;
-      const int y = (int)(rem / a.w), x = (int)(rem - (int64_t)y * a.w);
-      const int n = (int)(pc / a.C), c = (int)(pc % a.C);
-      const float a1 = (float)dcoef[pc * 2 + 0], a2 = (float)dcoef[pc * 2 + 1];
-      const float sv = a.seg[n * a.seg_sN + c * a.seg_sC + y * a.seg_sH + x];
-      const float tv = a.tseg[n * a.tseg_sN + c * a.tseg_sC + y * a.tseg_sH + x];
-      a.dseg[sdense ? i : (n * a.dseg_sN + c * a.dseg_sC + y * a.dseg_sH + x)] = gs * fmaf(a1, tv, a2 * sv);
-    } else {
-      const int64_t j = i - nseg;
-      const int64_t pc = j / hw;
-      const int64_t rem = j - pc * hw;
-      const int y = (int)(rem / a.w), x = (int)(rem - (int64_t)y * a.w);
-      const int n = (int)(pc / a.L), l = (int)(pc % a.L);
-      const float k1 = (float)ncoef[pc * 3 + 0], k2 = (float)ncoef[pc * 3 + 1], k0 = (float)ncoef[pc * 3 + 2];
-      const float xv = a.heat[n * a.heat_sN + l * a.heat_sC + y * a.heat_sH + x];
-      const float yv = a.theat[n * a.theat_sN + l * a.theat_sC + y * a.theat_sH + x];
-      a.dheat[hdense ? j : (n * a.dheat_sN + l * a.dheat_sC + y * a.dheat_sH + x)] = gs * fmaf(k1, yv, fmaf(k2, xv, k0));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rows = (a.h + LOSS_NS - 1) / LOSS_NS;
+  const int y0 = blockIdx.y * rows, y1 = min(y0 + rows, a.h);
+  const bool dice = (int)blockIdx.x < BC;
+  const float *p, *q;
+  float* o;
+  int64_t pH, qH, oH;
+  float c1, c2, c0;
+  if (dice) {
+    if (a.dseg == nullptr) return;
+    const int pc = blockIdx.x, n = pc / a.C, c = pc % a.C;
+    p = a.seg + n * a.seg_sN + c * a.seg_sC;
+    q = a.tseg + n * a.tseg_sN + c * a.tseg_sC;
+    pH = a.seg_sH; qH = a.tseg_sH;
+    const bool dense = a.dseg_sN == 0;
+    o = a.dseg + (dense ? (int64_t)pc * a.h * a.w : n * a.dseg_sN + c * a.dseg_sC);
+    oH = dense ? a.w : a.dseg_sH;
+    c1 = gs * (float)dcoef[pc * 2 + 1];       // * s
+    c2 = gs * (float)dcoef[pc * 2 + 0];       // * t
+    c0 = 0.f;
+  } else {
+    if (a.dheat == nullptr || a.L == 0) return;
+    const int pc = blockIdx.x - BC, n = pc / a.L, l = pc % a.L;
+    p = a.heat + n * a.heat_sN + l * a.heat_sC;
+    q = a.theat + n * a.theat_sN + l * a.theat_sC;
+    pH = a.heat_sH; qH = a.theat_sH;
+    const bool dense = a.dheat_sN == 0;
+    o = a.dheat + (dense ? (int64_t)pc * a.h * a.w : n * a.dheat_sN + l * a.dheat_sC);
+    oH = dense ? a.w : a.dheat_sH;
+    c1 = gs * (float)ncoef[pc * 3 + 1];       // * x
+    c2 = gs * (float)ncoef[pc * 3 + 0];       // * y
+    c0 = gs * (float)ncoef[pc * 3 + 2];
+  }
+  const bool vec = (a.w & 3) == 0 && (pH & 3) == 0 && (qH & 3) == 0 && (oH & 3) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(o)) & 15) == 0;
+  for (int x = 4 * lane; x < a.w; x += 256) {
+    for (int y = y0 + wave; y < y1; y += 4) {
+      const float* pr = p + y * pH + x;
+      const float* qr = q + y * qH + x;
+      float* orow = o + y * oH + x;
+      if (vec) {
+        const float4 pv = *reinterpret_cast<const float4*>(pr), qv = *reinterpret_cast<const float4*>(qr);
+        *reinterpret_cast<float4*>(orow) = make_float4(fmaf(c2, qv.x, fmaf(c1, pv.x, c0)), fmaf(c2, qv.y, fmaf(c1, pv.y, c0)),
+                                                       fmaf(c2, qv.z, fmaf(c1, pv.z, c0)), fmaf(c2, qv.w, fmaf(c1, pv.w, c0)));
+      } else {
+        for (int e = 0; e < 4 && x + e < a.w; ++e) orow[e] = fmaf(c2, qr[e], fmaf(c1, pr[e], c0));
+      }
     }
   }
 }
@@ -332,12 +358,8 @@ extern "C" int dfl_dice_ncc_loss(const dfl_loss_args* a, dfl_stream_t stream) {
     hipLaunchKernelGGL(loss_sums_kernel, dim3((unsigned)(a->B * (a->C + a->L)), (unsigned)LOSS_NS), dim3(256), 0, s, *a, part);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, *a, part);
   }
-  if (a->stage != 1 && (a->dseg != nullptr || (a->dheat != nullptr && a->L > 0))) {
-    const int64_t total = (int64_t)a->B * (a->C + a->L) * a->h * a->w;
-    int64_t blocks = ceil_div(total, 256);
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(loss_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, s, *a);
-  }
+  if (a->stage != 1 && (a->dseg != nullptr || (a->dheat != nullptr && a->L > 0)))
+    hipLaunchKernelGGL(loss_grad_kernel, dim3((unsigned)(a->B * (a->C + a->L)), (unsigned)LOSS_NS), dim3(256), 0, s, *a);
   return check_launch("dfl_dice_ncc_loss");
 }
 
