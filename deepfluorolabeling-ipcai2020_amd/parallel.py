@@ -175,13 +175,17 @@ class DataParallel:
     def _run_backward(self, plan, stream):
         if not self.active:
             plan.bwd.run(stream)
+            getattr(plan, 'unfold_tail_grads', lambda: None)()
             return
         flat = plan.grad_flat
         inv = 1.0 / self.world
         if not self.overlap or not flat.is_cuda:
             # same segment walk, communication in line (also the path the CPU/gloo tests exercise)
-            for k, (op_start, op_count, ranges) in enumerate(self._segments(plan)):
+            segs = self._segments(plan)
+            for k, (op_start, op_count, ranges) in enumerate(segs):
                 plan.bwd.run(stream, op_start, op_count)
+                if op_start + op_count == len(plan.bwd):
+                    getattr(plan, 'unfold_tail_grads', lambda: None)()      # gradients made after the last op (plan.py)
                 if ranges:
                     self._reduce_bucket(plan, k, ranges, inv)
             return
@@ -192,6 +196,8 @@ class DataParallel:
         events = plan.__dict__.setdefault('_dp_events', {})   # one event per bucket, created once and re-recorded every step
         for k, (op_start, op_count, ranges) in enumerate(self._segments(plan)):
             plan.bwd.run(stream, op_start, op_count)
+            if op_start + op_count == len(plan.bwd):
+                getattr(plan, 'unfold_tail_grads', lambda: None)()
             if ranges:
                 ev = events.get(k)
                 if ev is None:

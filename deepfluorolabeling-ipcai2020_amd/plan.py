@@ -599,6 +599,20 @@ class UNetPlan:
         w_l1 = self.P['lands_1x1.0.weight'] if L > 0 else None
         w_l2 = self.P.get('lands_1x1.1.weight') if L > 0 else None
         NM = w_l1.shape[0] if L > 0 else 0
+        # lands_num_1x1 > 2 (unet.py:146-156): the 1x1 convolutions behind the first one are bias-free and have no
+        # non-linearity between them, i.e. ONE linear map  W_k ... W_2 W_1  (L x NM).  The head kernels run with that product
+        # (fold_tail, re-made whenever weights change) and the gradient they return for it is taken apart afterwards
+        # (unfold_tail_grads):  dW_j = (W_k ... W_{j+1})^T  G  (W_{j-1} ... W_1)^T.
+        self.tail_names = []
+        j = 1
+        while L > 0 and ('lands_1x1.%d.weight' % j) in self.P:
+            self.tail_names.append('lands_1x1.%d.weight' % j)
+            j += 1
+        self.w_l2_eff = self.g_l2_eff = None
+        if len(self.tail_names) > 1:
+            self.w_l2_eff = self._new(L * NM).view(L, NM, 1, 1)
+            self.g_l2_eff = self._new(L * NM).view(L, NM, 1, 1)
+            w_l2 = self.w_l2_eff
         self.head_fwd = HeadFwdArgs(x=u.ptr, w_seg=w_seg.data_ptr(), w_l1=nat.ptr(w_l1), w_l2=nat.ptr(w_l2),
                                     N=N, H=u.H, W=u.W, F=F, ldx=u.ld, NC=NC, NM=NM, L=L,
                                     softmax=1 if cfg['do_soft_max'] else 0, x_bf16=u.bf16)
@@ -643,7 +657,7 @@ class UNetPlan:
             if L > 0:
                 self.head_bwd.dw_l1 = self.G['lands_1x1.0.weight'].data_ptr()
                 if w_l2 is not None:
-                    self.head_bwd.dw_l2 = self.G['lands_1x1.1.weight'].data_ptr()
+                    self.head_bwd.dw_l2 = (self.g_l2_eff if self.g_l2_eff is not None else self.G['lands_1x1.1.weight']).data_ptr()
         else:
             scratch = self._new(M * sld)
             self.head_bwd.scratch = scratch.data_ptr()
@@ -659,7 +673,8 @@ class UNetPlan:
             if L > 0:
                 self._wgrad(bwd, sact(off[0], F + NC), sact(off[2], NM), self.G['lands_1x1.0.weight'], 1, 1, 1, 0, u.H, u.W)
                 if w_l2 is not None:
-                    self._wgrad(bwd, sact(off[3], NM), sact(off[4], L), self.G['lands_1x1.1.weight'], 1, 1, 1, 0, u.H, u.W)
+                    self._wgrad(bwd, sact(off[3], NM), sact(off[4], L),
+                                self.g_l2_eff if self.g_l2_eff is not None else self.G['lands_1x1.1.weight'], 1, 1, 1, 0, u.H, u.W)
 
         # up path, last block first
         # Column sums ride on the kernels that produce the tensors: the conv that completes dcat leaves sum(dy) (the
@@ -744,6 +759,38 @@ class UNetPlan:
                 name = by_ptr.get(d)
                 if name is not None:
                     self.grad_ready_op[name] = max(idx, self.grad_ready_op.get(name, -1))
+        if self.g_l2_eff is not None:            # taken apart after the last op (unfold_tail_grads)
+            for name in self.tail_names:
+                self.grad_ready_op[name] = len(bwd.structs) - 1
+
+    # ------------------------------------------------------------------------------------------ folded 1x1 tail
+    def fold_tail(self):
+        """w_l2_eff = W_k ... W_1 of the landmark 1x1 convolutions behind the first (tiny torch matmuls on the current stream)."""
+        if self.w_l2_eff is None:
+            return
+        mats = [self.P[n].view(self.P[n].shape[0], self.P[n].shape[1]) for n in self.tail_names]
+        eff = mats[0]
+        for m in mats[1:]:
+            eff = m @ eff
+        self.w_l2_eff.view(eff.shape).copy_(eff)
+
+    def unfold_tail_grads(self):
+        """Gradients of the folded 1x1 convolutions from the gradient of their product (see the heads section)."""
+        if self.g_l2_eff is None:
+            return
+        mats = [self.P[n].view(self.P[n].shape[0], self.P[n].shape[1]) for n in self.tail_names]
+        G = self.g_l2_eff.view(mats[-1].shape[0], mats[0].shape[1])
+        k = len(mats)
+        below = [None] * k                       # below[j] = W_{j-1} ... W_1 (None: identity)
+        for j in range(1, k):
+            below[j] = mats[j - 1] if below[j - 1] is None else mats[j - 1] @ below[j - 1]
+        above = None                             # W_k ... W_{j+1}
+        for j in reversed(range(k)):
+            g = G if above is None else above.t() @ G
+            if below[j] is not None:
+                g = g @ below[j].t()
+            self.G[self.tail_names[j]].view(g.shape).copy_(g)
+            above = mats[j] if above is None else above @ mats[j]
 
     # ------------------------------------------------------------------------------------------ run
     def run_pack(self, stream, forward_only=False):

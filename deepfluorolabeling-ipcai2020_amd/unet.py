@@ -134,8 +134,8 @@ class UNet(nn.Module):
             raise NotImplementedError("pad_mode='%s' is not implemented in the HIP path (no reference CLI selects it)" % pad_mode)
         if num_lands > 0 and lands_block_depth > 0:
             raise NotImplementedError('lands_block_depth > 0 is not implemented in the HIP path (no reference CLI selects it)')
-        if num_lands > 0 and lands_num_1x1 not in (1, 2):
-            raise NotImplementedError('lands_num_1x1 must be 1 or 2 in the HIP path')
+        if num_lands > 0 and lands_num_1x1 < 1:
+            raise AssertionError('lands_num_1x1 must be positive')
         self.padding, self.pad_mode, self.depth = padding, pad_mode, depth
         self.do_max_pool, self.num_lands, self.do_soft_max = max_pool, num_lands, do_soft_max
         self._cfg = dict(in_channels=in_channels, n_classes=n_classes, depth=depth, wf=wf, padding=bool(padding),
@@ -165,8 +165,10 @@ class UNet(nn.Module):
             self.lands_block = None
             mid = num_lands + n_classes if lands_num_1x1 > 1 else num_lands
             heads = [nn.Conv2d(ch + n_classes, mid, kernel_size=1, bias=False)]
-            if lands_num_1x1 > 1:
-                heads.append(nn.Conv2d(mid, num_lands, kernel_size=1, bias=False))
+            feats = mid
+            for _ in range(lands_num_1x1 - 1):       # reference unet.py:152-157: mid -> L, then L -> L ...
+                heads.append(nn.Conv2d(feats, num_lands, kernel_size=1, bias=False))
+                feats = num_lands
             self.lands_1x1 = nn.Sequential(*heads)
 
         self._plans = {}
@@ -289,6 +291,7 @@ class UNet(nn.Module):
         ver = sum(p._version for p in self._weight_params)
         if self._pack_version != (id(plan), ver):
             plan.pack.run(stream)                    # weight re-layout for this plan's kernels
+            plan.fold_tail()                         # (lands_num_1x1 > 2: product of the trailing 1x1 convolutions)
             self._pack_version = (id(plan), ver)
 
     def _run_forward(self, plan, x):
@@ -317,6 +320,7 @@ class UNet(nn.Module):
 
     def _run_backward(self, plan, stream):
         plan.bwd.run(stream)
+        plan.unfold_tail_grads()
 
     # ---------------------------------------------------------------------------------------------- forward
     def forward(self, x):

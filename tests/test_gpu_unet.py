@@ -518,6 +518,50 @@ def test_ragged_sizes_match_oracle(hw, max_pool, math_mode):
     gf.check({k: p.grad for k, p in net.named_parameters()}, seg, NF.conv_rel_error(math_mode), 'ragged %dx%d ' % (H, W))
 
 
+@pytest.mark.parametrize('n1x1', [3, 4])
+def test_more_than_two_landmark_1x1_convolutions(n1x1, math_mode):
+    """lands_num_1x1 > 2 (unet.py:146-157: F+NC -> L+NC -> L -> L ...): the trailing bias-free 1x1 convolutions run as their
+    product inside the head kernels (plan.fold_tail) and their gradients are taken apart afterwards (unfold_tail_grads):
+    state_dict layout, forward, loss and every gradient against the oracle; a second step after an optimizer update
+    checks that the product is re-made when the weights change."""
+    cfg = dict(n_classes=5, depth=3, wf=4, batch_norm=True, padding=True, max_pool=False, num_lands=6, do_res=True,
+               block_depth=2, lands_num_1x1=n1x1)
+    torch.manual_seed(77 + n1x1)
+    onet = R.OracleUNet(1, **cfg)
+    net = dfl_amd.UNet(1, **cfg)
+    assert [k for k in net.state_dict()] == [k for k in onet.state_dict()]
+    assert [tuple(v.shape) for v in net.state_dict().values()] == [tuple(v.shape) for v in onet.state_dict().values()]
+    net.load_state_dict(onet.state_dict())
+    net = net.to(DEV)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 1, 40, 48, generator=g)
+    tseg = torch.softmax(torch.randn(2, 5, 36, 44, generator=g), 1)
+    theat = torch.rand(2, 6, 36, 44, generator=g) * 0.02
+    net.train()
+    onet.train()
+    crit = dfl_amd.DiceAndHeatMapLoss2D(skip_bg=False, heatmap_wgt=0.5)
+    opt = dfl_amd.SGD(net.parameters(), lr=0.05, momentum=0.0)
+    oopt = torch.optim.SGD(onet.parameters(), lr=0.05, momentum=0.0)
+    for step in range(2):
+        opt.zero_grad()
+        oopt.zero_grad()
+        oseg, oheat = onet(x)
+        seg, heat = net(x.to(DEV))
+        np.testing.assert_allclose(seg.detach().cpu().numpy(), oseg.detach().numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(heat.detach().cpu().numpy(), oheat.detach().numpy(), rtol=1e-4, atol=1e-4 * float(oheat.detach().abs().max()))
+        loss = crit((dfl_amd.center_crop(seg, tseg.shape), dfl_amd.center_crop(heat, theat.shape)), (tseg.to(DEV), theat.to(DEV)))
+        oloss = R.dice_and_heatmap_loss_2d((R.center_crop(oseg, tseg.shape), R.center_crop(oheat, theat.shape)), (tseg, theat),
+                                           skip_bg=False, heatmap_wgt=0.5)
+        assert abs(loss.item() - oloss.item()) < 1e-5
+        loss.backward()
+        oloss.backward()
+        if step == 0:
+            gf = NF.cached_floor(('n1x1', n1x1), lambda: NF.GradientFloor(oracle64(cfg, onet.state_dict()), oracle_run(x, tseg, theat)))
+            gf.check({k: p.grad for k, p in net.named_parameters()}, seg, NF.conv_rel_error(math_mode), 'lands_num_1x1=%d ' % n1x1)
+        opt.step()
+        oopt.step()
+
+
 @pytest.mark.parametrize('mode', ['fp32', 'bf16x3', 'bf16', 'bf16s'])
 def test_plateau_dice_matches_reference(mode):
     """North-star quality bar: hard Dice within +-0.005 of the REFERENCE.  tests/golden/plateau.npz holds a run of the
