@@ -176,7 +176,7 @@ EXPORTS = ['dfl_version', 'dfl_last_error', 'dfl_sizeof', 'dfl_conv2d', 'dfl_con
            'dfl_reduce_job_blocks', 'dfl_prep_batch', 'dfl_prep_scratch_doubles', 'dfl_est_lands', 'dfl_hard_dice', 'dfl_get_math_mode',
            'dfl_set_math_mode', 'dfl_graph_capture', 'dfl_graph_launch', 'dfl_graph_nodes', 'dfl_graph_destroy',
            'dfl_set_conv_rows_min_tiles', 'dfl_conv_candidates', 'dfl_conv_force_geometry', 'dfl_conv_tune_add',
-           'dfl_head_wgrad_blocks']
+           'dfl_head_wgrad_blocks', 'dfl_head_scratch_ld_for', 'dfl_head_scratch_off_for']
 
 
 class DflError(RuntimeError):
@@ -232,6 +232,8 @@ def lib():
         getattr(L, fn).argtypes = [fp]
     L.dfl_conv_candidates.argtypes = [fp, fp, i32]
     L.dfl_head_wgrad_blocks.argtypes = [i64]
+    L.dfl_head_scratch_ld_for.argtypes = [i32, i32, i32, i32]
+    L.dfl_head_scratch_off_for.argtypes = [i32, i32, i32, i32, i32]
     L.dfl_conv_force_geometry.argtypes = [fp]
     L.dfl_conv_tune_add.argtypes = [fp, fp]
     for k, cls in enumerate(_SIZEOF_ORDER):

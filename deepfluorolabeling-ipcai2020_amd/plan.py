@@ -640,12 +640,12 @@ class UNetPlan:
             self.dead_params.add('downsample_convs.%d.bias' % (depth - 1))
 
         # heads
-        sld = self.lib.dfl_head_scratch_ld(F)
+        sld = self.lib.dfl_head_scratch_ld_for(F, NC, NM, L)
         M = u.M
         dfeat = self._act(N, u.H, u.W, F)
         # bf16 features of the paper's width: the head kernel takes its three weight gradients itself (include/dfl_hip.h);
         # otherwise it leaves a per-pixel scratch row and three 1x1 weight-gradient launches follow
-        fused_head = bool(u.bf16) and F == 32 and os.environ.get('DFL_HEAD_FUSED', '1') != '0'
+        fused_head = bool(u.bf16) and F == 32 and NC <= 8 and NM <= 24 and L <= 16 and os.environ.get('DFL_HEAD_FUSED', '1') != '0'
         self.head_bwd = HeadBwdArgs(x=u.ptr, w_seg=w_seg.data_ptr(), w_l1=nat.ptr(w_l1), w_l2=nat.ptr(w_l2),
                                     dx=dfeat.ptr, N=N, H=u.H, W=u.W, F=F, ldx=u.ld,
                                     lddx=dfeat.ld, NC=NC, NM=NM, L=L, softmax=1 if cfg['do_soft_max'] else 0,
@@ -665,7 +665,7 @@ class UNetPlan:
             bwd.wait(self.EV_PACK_DONE, stream=0)      # data-gradient weight layouts are packed on the side stream
         bwd.add(self.head_bwd)
         if not fused_head:
-            off = [self.lib.dfl_head_scratch_off(F, k) for k in range(5)]
+            off = [self.lib.dfl_head_scratch_off_for(F, NC, NM, L, k) for k in range(5)]
 
             def sact(o, c):
                 return Act(scratch, scratch.data_ptr() + 4 * o, sld, N, u.H, u.W, c)

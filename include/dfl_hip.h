@@ -294,7 +294,7 @@ int dfl_maxpool2x2_bwd(const dfl_pool_args* a, dfl_stream_t stream);
  * Output heads (unet.py:176-191): logits = seg_conv(x) (1x1, no bias); seg = Softmax2d(logits) (or logits);
  * heat = lands_1x1[1](lands_1x1[0](cat(x, logits))) (two bias-free 1x1 convs; the second is optional).
  * x is NHWC; seg and heat are written NCHW (the reference's output layout).
- * Limits: n_classes <= 8, num_lands <= 16, n_mid <= 24.
+ * Limits: n_classes <= 16, num_lands <= 32, n_mid <= 48 (the specialised small-array kernels serve up to 8 / 16 / 24).
  * ------------------------------------------------------------------------------------------------------------ */
 typedef struct {
   const float* x;         /* [M][ldx], F features */
@@ -316,6 +316,11 @@ int dfl_head_fwd(const dfl_head_fwd_args* a, dfl_stream_t stream);
 #define DFL_HEAD_MAX_NC 8
 #define DFL_HEAD_MAX_L 16
 #define DFL_HEAD_MAX_NM 24
+/* Heads beyond those counts (train.py --num-classes is free) run the same kernels compiled with larger per-thread arrays
+ * (generic bounds, no fused weight gradients): up to */
+#define DFL_HEAD_LARGE_NC 16
+#define DFL_HEAD_LARGE_L 32
+#define DFL_HEAD_LARGE_NM 48
 typedef struct {
   const float* x; const float* seg; const float* dseg; const float* dheat;
   const float* w_seg; const float* w_l1; const float* w_l2;
@@ -340,6 +345,9 @@ int dfl_head_wgrad_blocks(int64_t M);  /* workgroups (= partial slots) of the fu
  * dmid (24), mid (24), dheat (16). */
 int dfl_head_scratch_ld(int32_t F);
 int dfl_head_scratch_off(int32_t F, int32_t which); /* which: 0 cat, 1 dlogits, 2 dmid, 3 mid, 4 dheat */
+/* The same for a given head shape: the scratch row of a large head (above) is wider. */
+int dfl_head_scratch_ld_for(int32_t F, int32_t NC, int32_t NM, int32_t L);
+int dfl_head_scratch_off_for(int32_t F, int32_t NC, int32_t NM, int32_t L, int32_t which);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Losses (dice.py:14-86, ncc.py:12-38) with their closed-form gradients.

@@ -518,7 +518,9 @@ def test_affine_copy_window():
 
 
 @pytest.mark.parametrize('NC,L,two,softmax,F_', [(7, 14, True, True, 32), (3, 14, False, True, 8), (5, 0, True, False, 8),
-                                                 (7, 14, True, True, 4)])
+                                                 (7, 14, True, True, 4),
+                                                 # beyond 8 classes / 16 landmarks / 24 mid channels: the large-capacity build of the kernels
+                                                 (12, 20, True, True, 32), (16, 32, True, True, 16), (10, 0, True, True, 8), (3, 30, False, False, 8)])
 def test_heads_forward_backward(NC, L, two, softmax, F_):
     lib = nat.lib()
     g = torch.Generator().manual_seed(NC + L)
@@ -557,7 +559,7 @@ def test_heads_forward_backward(NC, L, two, softmax, F_):
     if L > 0:
         aclose(heatd.cpu().numpy(), heat.detach().numpy(), rtol=1e-5, atol=1e-5)
     # backward
-    sld = lib.dfl_head_scratch_ld(F_)
+    sld = lib.dfl_head_scratch_ld_for(F_, NC, NM, L)
     scratch = torch.full((N * H * W, sld), float('nan'), device=DEV)
     dxd = torch.empty(N, H, W, F_, device=DEV)
     dsegd = dv(gouts[0])
@@ -570,7 +572,7 @@ def test_heads_forward_backward(NC, L, two, softmax, F_):
     aclose(nchw(dxd.cpu()).numpy(), x.grad.numpy(), rtol=1e-4, atol=1e-5)
     sc = scratch.cpu().double()
     assert torch.isfinite(sc).all()
-    off = [lib.dfl_head_scratch_off(F_, k) for k in range(5)]
+    off = [lib.dfl_head_scratch_off_for(F_, NC, NM, L, k) for k in range(5)]
     dwseg = sc[:, off[1]:off[1] + NC].t() @ sc[:, off[0]:off[0] + F_]
     aclose(dwseg.numpy(), wseg.grad[:, :, 0, 0].numpy(), rtol=1e-4, atol=1e-4)
     if L > 0:

@@ -518,6 +518,36 @@ def test_ragged_sizes_match_oracle(hw, max_pool, math_mode):
     gf.check({k: p.grad for k, p in net.named_parameters()}, seg, NF.conv_rel_error(math_mode), 'ragged %dx%d ' % (H, W))
 
 
+def test_head_with_more_classes_and_landmarks_than_the_paper(math_mode):
+    """train.py --num-classes is free and the landmark count comes from the data file: 12 classes and 20 landmarks (beyond
+    the 8 / 16 the specialised head kernels hold in registers) run the large-capacity build of the same kernels: forward,
+    loss and every gradient against the oracle."""
+    cfg = dict(n_classes=12, depth=3, wf=4, batch_norm=True, padding=True, max_pool=False, num_lands=20, do_res=True, block_depth=2)
+    torch.manual_seed(91)
+    onet = R.OracleUNet(1, **cfg)
+    net = dfl_amd.UNet(1, **cfg)
+    net.load_state_dict(onet.state_dict())
+    net = net.to(DEV)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 1, 40, 48, generator=g)
+    tseg = torch.softmax(torch.randn(2, 12, 36, 44, generator=g), 1)
+    theat = torch.rand(2, 20, 36, 44, generator=g) * 0.02
+    net.train()
+    onet.train()
+    oseg, oheat = onet(x)
+    seg, heat = net(x.to(DEV))
+    np.testing.assert_allclose(seg.detach().cpu().numpy(), oseg.detach().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(heat.detach().cpu().numpy(), oheat.detach().numpy(), rtol=1e-4, atol=1e-4 * float(oheat.detach().abs().max()))
+    crit = dfl_amd.DiceAndHeatMapLoss2D(skip_bg=False, heatmap_wgt=0.5)
+    loss = crit((dfl_amd.center_crop(seg, tseg.shape), dfl_amd.center_crop(heat, theat.shape)), (tseg.to(DEV), theat.to(DEV)))
+    oloss = R.dice_and_heatmap_loss_2d((R.center_crop(oseg, tseg.shape), R.center_crop(oheat, theat.shape)), (tseg, theat),
+                                       skip_bg=False, heatmap_wgt=0.5)
+    assert abs(loss.item() - oloss.item()) < 1e-5
+    loss.backward()
+    gf = NF.cached_floor('large-head', lambda: NF.GradientFloor(oracle64(cfg, onet.state_dict()), oracle_run(x, tseg, theat)))
+    gf.check({k: p.grad for k, p in net.named_parameters()}, seg, NF.conv_rel_error(math_mode), 'large head ')
+
+
 @pytest.mark.parametrize('n1x1', [3, 4])
 def test_more_than_two_landmark_1x1_convolutions(n1x1, math_mode):
     """lands_num_1x1 > 2 (unet.py:146-157: F+NC -> L+NC -> L -> L ...): the trailing bias-free 1x1 convolutions run as their
