@@ -613,8 +613,41 @@ class UNetPlan:
             self.w_l2_eff = self._new(L * NM).view(L, NM, 1, 1)
             self.g_l2_eff = self._new(L * NM).view(L, NM, 1, 1)
             w_l2 = self.w_l2_eff
-        self.head_fwd = HeadFwdArgs(x=u.ptr, w_seg=w_seg.data_ptr(), w_l1=nat.ptr(w_l1), w_l2=nat.ptr(w_l2),
-                                    N=N, H=u.H, W=u.W, F=F, ldx=u.ld, NC=NC, NM=NM, L=L,
+        # lands_block_depth > 0 (unet.py:108-137,185-187): bias-only 3x3 convolutions F -> F/2 (-> F/2 ...) in front of the
+        # landmark 1x1.  Their output lb is written next to a copy of the features into ONE wider tensor [u | lb], and the
+        # head kernels run on that with widened weight matrices -- w_seg' = [w_seg | 0], w_l1' = [0 | W1[:, :F/2] | W1[:, F/2:]]
+        # (fold_tail) -- so seg sees u, the landmark branch sees cat(lb, logits), and no kernel changes.  Their gradients come
+        # back as columns of the widened matrices and of dx (unfold_tail_grads; the lb columns of dx feed the convolutions'
+        # backward, the u columns go on into the decoder).
+        lbd = int(cfg.get('lands_block_depth', 0)) if L > 0 else 0
+        self.lb_layers = []
+        self.eff_heads = None
+        head_x, Fh = u, F
+        if lbd > 0:
+            if not cfg['padding']:
+                raise PlanError('lands_block_depth > 0 needs padding=True (unpadded, the landmark maps shrink against the '
+                                'segmentation: not implemented in the HIP path)')
+            F2 = F // 2
+            if F2 % (16 if self.bf16 else 4) != 0:
+                raise PlanError('lands_block_depth > 0 needs F/2 = %d channels to be a multiple of %d in this arithmetic' % (F2, 16 if self.bf16 else 4))
+            Fh = F + F2
+            uw = self._act(N, u.H, u.W, Fh)
+            fwd.add(AffineCopyArgs(x=u.ptr, y=uw.ptr, N=N, H=u.H, W=u.W, C=F, ldx=u.ld, xH=u.H, xW=u.W, ldy=uw.ld, yH=u.H, yW=u.W,
+                                   bf16=u.bf16))
+            src = u
+            for j in range(lbd):
+                wname, bname = 'lands_block.%d.weight' % j, 'lands_block.%d.bias' % j
+                dst = uw.chan_slice(F, F2) if j == lbd - 1 else self._act(N, u.H, u.W, F2)
+                self._conv(fwd, src, self._pack_conv_fwd(self.P[wname]), dst, 3, 3, 1, 1, F2, bias=self.P[bname])
+                self.lb_layers.append((src, dst, wname, bname))
+                src = dst
+            self.eff_heads = dict(F=F, F2=F2, w_seg=self._new(NC * Fh).view(NC, Fh, 1, 1).zero_(),
+                                  w_l1=self._new(NM * (Fh + NC)).view(NM, Fh + NC, 1, 1).zero_(),
+                                  g_seg=self._new(NC * Fh).view(NC, Fh, 1, 1), g_l1=self._new(NM * (Fh + NC)).view(NM, Fh + NC, 1, 1))
+            w_seg, w_l1 = self.eff_heads['w_seg'], self.eff_heads['w_l1']
+            head_x = uw
+        self.head_fwd = HeadFwdArgs(x=head_x.ptr, w_seg=w_seg.data_ptr(), w_l1=nat.ptr(w_l1), w_l2=nat.ptr(w_l2),
+                                    N=N, H=u.H, W=u.W, F=Fh, ldx=head_x.ld, NC=NC, NM=NM, L=L,
                                     softmax=1 if cfg['do_soft_max'] else 0, x_bf16=u.bf16)
         fwd.add(self.head_fwd)
         self.out_hw = (u.H, u.W)
@@ -640,22 +673,26 @@ class UNetPlan:
             self.dead_params.add('downsample_convs.%d.bias' % (depth - 1))
 
         # heads
+        Fdec = F                                  # channels of the decoder output (F below: what the head kernels see)
+        F = Fh
+        g_seg = self.eff_heads['g_seg'] if self.eff_heads is not None else self.G['seg_conv.weight']
+        g_l1 = (self.eff_heads['g_l1'] if self.eff_heads is not None else self.G['lands_1x1.0.weight']) if L > 0 else None
         sld = self.lib.dfl_head_scratch_ld_for(F, NC, NM, L)
         M = u.M
         dfeat = self._act(N, u.H, u.W, F)
         # bf16 features of the paper's width: the head kernel takes its three weight gradients itself (include/dfl_hip.h);
         # otherwise it leaves a per-pixel scratch row and three 1x1 weight-gradient launches follow
         fused_head = bool(u.bf16) and F == 32 and NC <= 8 and NM <= 24 and L <= 16 and os.environ.get('DFL_HEAD_FUSED', '1') != '0'
-        self.head_bwd = HeadBwdArgs(x=u.ptr, w_seg=w_seg.data_ptr(), w_l1=nat.ptr(w_l1), w_l2=nat.ptr(w_l2),
-                                    dx=dfeat.ptr, N=N, H=u.H, W=u.W, F=F, ldx=u.ld,
+        self.head_bwd = HeadBwdArgs(x=head_x.ptr, w_seg=w_seg.data_ptr(), w_l1=nat.ptr(w_l1), w_l2=nat.ptr(w_l2),
+                                    dx=dfeat.ptr, N=N, H=u.H, W=u.W, F=F, ldx=head_x.ld,
                                     lddx=dfeat.ld, NC=NC, NM=NM, L=L, softmax=1 if cfg['do_soft_max'] else 0,
                                     scratch_ld=sld, x_bf16=u.bf16)
         if fused_head:
             part = self._new(4096 * nat.check(self.lib.dfl_head_wgrad_blocks(M), 'dfl_head_wgrad_blocks'))
             self.head_bwd.wg_partial = part.data_ptr()
-            self.head_bwd.dw_seg = self.G['seg_conv.weight'].data_ptr()
+            self.head_bwd.dw_seg = g_seg.data_ptr()
             if L > 0:
-                self.head_bwd.dw_l1 = self.G['lands_1x1.0.weight'].data_ptr()
+                self.head_bwd.dw_l1 = g_l1.data_ptr()
                 if w_l2 is not None:
                     self.head_bwd.dw_l2 = (self.g_l2_eff if self.g_l2_eff is not None else self.G['lands_1x1.1.weight']).data_ptr()
         else:
@@ -669,9 +706,9 @@ class UNetPlan:
 
             def sact(o, c):
                 return Act(scratch, scratch.data_ptr() + 4 * o, sld, N, u.H, u.W, c)
-            self._wgrad(bwd, sact(off[0], F), sact(off[1], NC), self.G['seg_conv.weight'], 1, 1, 1, 0, u.H, u.W)
+            self._wgrad(bwd, sact(off[0], F), sact(off[1], NC), g_seg, 1, 1, 1, 0, u.H, u.W)
             if L > 0:
-                self._wgrad(bwd, sact(off[0], F + NC), sact(off[2], NM), self.G['lands_1x1.0.weight'], 1, 1, 1, 0, u.H, u.W)
+                self._wgrad(bwd, sact(off[0], F + NC), sact(off[2], NM), g_l1, 1, 1, 1, 0, u.H, u.W)
                 if w_l2 is not None:
                     self._wgrad(bwd, sact(off[3], NM), sact(off[4], L),
                                 self.g_l2_eff if self.g_l2_eff is not None else self.G['lands_1x1.1.weight'], 1, 1, 1, 0, u.H, u.W)
@@ -681,6 +718,23 @@ class UNetPlan:
         # transposed conv's bias gradient), the conv that produces du leaves the BatchNorm-backward sums of the block
         # that consumes du, the conv that completes a block-input gradient leaves the down-sampling bias gradient.
         dout = dfeat
+        if self.lb_layers:
+            # backward of the landmark block: the lb columns of dx through the 3x3 convolutions (bias sums, weight gradients,
+            # data gradients), the first one's data gradient added onto the u columns, which then enter the decoder
+            dout = dfeat.chan_slice(0, Fdec)
+            d = dfeat.chan_slice(Fdec, Fh - Fdec)
+            for j in reversed(range(len(self.lb_layers))):
+                src, dst, wname, bname = self.lb_layers[j]
+                self._colsum(bwd, d, self.G[bname])
+                self._wgrad(bwd, src, d, self.G[wname], 3, 3, 1, 1, u.H, u.W)
+                wd = self._pack_conv_dgrad(self.P[wname])
+                if j == 0:
+                    self._conv(bwd, d, wd, dout, 3, 3, 1, 1, Fdec, accumulate=1)
+                else:
+                    dprev = self._act(N, u.H, u.W, Fh - Fdec)
+                    self._conv(bwd, d, wd, dprev, 3, 3, 1, 1, Fh - Fdec)
+                    d = dprev
+        F = Fdec
         dout_sums = None
         for j in reversed(range(len(up_recs))):
             rec = up_recs[j]
@@ -762,10 +816,20 @@ class UNetPlan:
         if self.g_l2_eff is not None:            # taken apart after the last op (unfold_tail_grads)
             for name in self.tail_names:
                 self.grad_ready_op[name] = len(bwd.structs) - 1
+        if self.eff_heads is not None:
+            for name in ('seg_conv.weight', 'lands_1x1.0.weight'):
+                self.grad_ready_op[name] = len(bwd.structs) - 1
 
     # ------------------------------------------------------------------------------------------ folded 1x1 tail
     def fold_tail(self):
         """w_l2_eff = W_k ... W_1 of the landmark 1x1 convolutions behind the first (tiny torch matmuls on the current stream)."""
+        if self.eff_heads is not None:           # lands_block_depth > 0: widened head matrices (see the heads section)
+            e = self.eff_heads
+            F, F2 = e['F'], e['F2']
+            e['w_seg'][:, :F].copy_(self.P['seg_conv.weight'])
+            w1 = self.P['lands_1x1.0.weight']
+            e['w_l1'][:, F:F + F2].copy_(w1[:, :F2])
+            e['w_l1'][:, F + F2:].copy_(w1[:, F2:])
         if self.w_l2_eff is None:
             return
         mats = [self.P[n].view(self.P[n].shape[0], self.P[n].shape[1]) for n in self.tail_names]
@@ -776,6 +840,13 @@ class UNetPlan:
 
     def unfold_tail_grads(self):
         """Gradients of the folded 1x1 convolutions from the gradient of their product (see the heads section)."""
+        if self.eff_heads is not None and self.need_grad:
+            e = self.eff_heads
+            F, F2 = e['F'], e['F2']
+            self.G['seg_conv.weight'].copy_(e['g_seg'][:, :F])
+            g1 = self.G['lands_1x1.0.weight']
+            g1[:, :F2].copy_(e['g_l1'][:, F:F + F2])
+            g1[:, F2:].copy_(e['g_l1'][:, F + F2:])
         if self.g_l2_eff is None:
             return
         mats = [self.P[n].view(self.P[n].shape[0], self.P[n].shape[1]) for n in self.tail_names]

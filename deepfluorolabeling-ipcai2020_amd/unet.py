@@ -132,15 +132,17 @@ class UNet(nn.Module):
             raise AssertionError("up_mode must be 'upconv' or 'upsample'")
         if pad_mode != 'zeros':
             raise NotImplementedError("pad_mode='%s' is not implemented in the HIP path (no reference CLI selects it)" % pad_mode)
-        if num_lands > 0 and lands_block_depth > 0:
-            raise NotImplementedError('lands_block_depth > 0 is not implemented in the HIP path (no reference CLI selects it)')
+        if num_lands > 0 and lands_block_depth > 0 and not padding:
+            raise NotImplementedError('lands_block_depth > 0 needs padding=True in the HIP path (unpadded, the landmark maps '
+                                      'shrink against the segmentation; no reference CLI selects it)')
         if num_lands > 0 and lands_num_1x1 < 1:
             raise AssertionError('lands_num_1x1 must be positive')
         self.padding, self.pad_mode, self.depth = padding, pad_mode, depth
         self.do_max_pool, self.num_lands, self.do_soft_max = max_pool, num_lands, do_soft_max
         self._cfg = dict(in_channels=in_channels, n_classes=n_classes, depth=depth, wf=wf, padding=bool(padding),
                          batch_norm=bool(batch_norm), max_pool=bool(max_pool), num_lands=num_lands, do_res=bool(do_res),
-                         block_depth=block_depth, lands_num_1x1=lands_num_1x1, do_soft_max=bool(do_soft_max))
+                         block_depth=block_depth, lands_num_1x1=lands_num_1x1, lands_block_depth=lands_block_depth,
+                         do_soft_max=bool(do_soft_max))
 
         # registration order: downsample_convs is assigned before down_path (reference unet.py:80-85)
         self.downsample_convs = None if max_pool else nn.ModuleList()
@@ -163,8 +165,15 @@ class UNet(nn.Module):
             self.soft_max = nn.Softmax2d()           # stateless; present so attribute access matches the reference
         if num_lands > 0:
             self.lands_block = None
+            lands_ch = ch
+            if lands_block_depth > 0:             # reference unet.py:118-137: bias-only 3x3 convolutions, no non-linearity
+                lands_ch = ch // 2
+                convs = [nn.Conv2d(ch, lands_ch, kernel_size=3, padding=int(padding))]
+                for _ in range(lands_block_depth - 1):
+                    convs.append(nn.Conv2d(lands_ch, lands_ch, kernel_size=3, padding=int(padding)))
+                self.lands_block = nn.Sequential(*convs)
             mid = num_lands + n_classes if lands_num_1x1 > 1 else num_lands
-            heads = [nn.Conv2d(ch + n_classes, mid, kernel_size=1, bias=False)]
+            heads = [nn.Conv2d(lands_ch + n_classes, mid, kernel_size=1, bias=False)]
             feats = mid
             for _ in range(lands_num_1x1 - 1):       # reference unet.py:152-157: mid -> L, then L -> L ...
                 heads.append(nn.Conv2d(feats, num_lands, kernel_size=1, bias=False))

@@ -548,6 +548,49 @@ def test_head_with_more_classes_and_landmarks_than_the_paper(math_mode):
     gf.check({k: p.grad for k, p in net.named_parameters()}, seg, NF.conv_rel_error(math_mode), 'large head ')
 
 
+@pytest.mark.parametrize('lbd', [1, 2])
+def test_landmark_block_in_front_of_the_1x1(lbd, math_mode):
+    """lands_block_depth > 0 (unet.py:118-137,185-187): bias-only 3x3 convolutions F -> F/2 in front of the landmark 1x1.  The
+    plan writes their output next to a copy of the features and runs the head kernels with widened matrices (plan.py): state
+    dict layout, seeded init, forward, loss and every gradient against the oracle."""
+    cfg = dict(n_classes=5, depth=3, wf=5, batch_norm=True, padding=True, max_pool=False, num_lands=6, do_res=True,
+               block_depth=2, lands_block_depth=lbd)
+    torch.manual_seed(123 + lbd)
+    onet = R.OracleUNet(1, **cfg)
+    torch.manual_seed(123 + lbd)
+    net = dfl_amd.UNet(1, **cfg)
+    assert [k for k in net.state_dict()] == [k for k in onet.state_dict()]
+    for (k, a), b in zip(net.state_dict().items(), onet.state_dict().values()):
+        assert torch.equal(a, b), k                                    # same modules created in the same order: same seeded init
+    net = net.to(DEV)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(3, 1, 72, 80, generator=g)          # (enough pixels that a single ReLU mask flip under the arithmetic's noise
+    tseg = torch.softmax(torch.randn(3, 5, 68, 76, generator=g), 1)     # does not dominate a BatchNorm gradient: tests/noise_floor.py)
+    theat = torch.rand(3, 6, 68, 76, generator=g) * 0.02
+    net.train()
+    onet.train()
+    oseg, oheat = onet(x)
+    seg, heat = net(x.to(DEV))
+    np.testing.assert_allclose(seg.detach().cpu().numpy(), oseg.detach().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(heat.detach().cpu().numpy(), oheat.detach().numpy(), rtol=1e-4, atol=1e-4 * float(oheat.detach().abs().max()))
+    crit = dfl_amd.DiceAndHeatMapLoss2D(skip_bg=False, heatmap_wgt=0.5)
+    loss = crit((dfl_amd.center_crop(seg, tseg.shape), dfl_amd.center_crop(heat, theat.shape)), (tseg.to(DEV), theat.to(DEV)))
+    oloss = R.dice_and_heatmap_loss_2d((R.center_crop(oseg, tseg.shape), R.center_crop(oheat, theat.shape)), (tseg, theat),
+                                       skip_bg=False, heatmap_wgt=0.5)
+    assert abs(loss.item() - oloss.item()) < 1e-5
+    loss.backward()
+    gf = NF.cached_floor(('lands-block', lbd), lambda: NF.GradientFloor(oracle64(cfg, onet.state_dict()), oracle_run(x, tseg, theat)))
+    gf.check({k: p.grad for k, p in net.named_parameters()}, seg, NF.conv_rel_error(math_mode), 'lands_block_depth=%d ' % lbd)
+    # eval-mode forward (its own plan, folded matrices re-made)
+    net.eval()
+    onet.eval()
+    with torch.no_grad():
+        es, eh = net(x.to(DEV))
+        os_, oh = onet(x)
+    np.testing.assert_allclose(es.cpu().numpy(), os_.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(eh.cpu().numpy(), oh.numpy(), rtol=1e-4, atol=1e-4 * float(oh.abs().max()))
+
+
 @pytest.mark.parametrize('n1x1', [3, 4])
 def test_more_than_two_landmark_1x1_convolutions(n1x1, math_mode):
     """lands_num_1x1 > 2 (unet.py:146-157: F+NC -> L+NC -> L -> L ...): the trailing bias-free 1x1 convolutions run as their
