@@ -198,9 +198,14 @@ class Trainer:
         if self.world > 1:
             self.dev = torch.device('cuda', self.local % torch.cuda.device_count())
             torch.cuda.set_device(self.dev)
+        from dfl_amd import _native as nat
         if args.math is not None:
-            from dfl_amd import _native as nat
             nat.check(nat.lib().dfl_set_math_mode(MATH_MODES[args.math]), 'dfl_set_math_mode')
+        mode = nat.lib().dfl_get_math_mode()
+        names = {v: k for k, v in MATH_MODES.items()}
+        # (the library default is fp32 products, the 1e-4 parity mode; BASELINE configs[1] is --math bf16s, 2.4x the speed)
+        self.say('arithmetic: {}{}'.format(names.get(mode, mode), '' if args.math is not None or mode != 0 else
+                                            ' (library default; --math bf16s = bf16 tensors in HBM, see DESIGN.md section 4b)'))
         self._seed(args.seed)
 
         self.cfg = Settings.from_args(args)
