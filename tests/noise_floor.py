@@ -117,12 +117,12 @@ class GradientFloor:
     enough seeds; in the paper-size networks thousands of flips average into the smooth part."""
     EPS_REF = 1.0e-6
     K_TENSOR, K_WHOLE, ABS = 8.0, 4.0, 2.0e-6       # bars: K x spread + fp32 rounding of the result itself (the spread is an
-    # RMS over 4-6 seeds, +-30 % itself; measured error / spread: 0.8-1.1 in the median, <= 2 for GEMM-fed tensors, 6.3 for the
+    # RMS over 2-4 seeds, +-30..50 % itself; measured error / spread: 0.8-1.1 in the median, <= 2 for GEMM-fed tensors, 6.3 for the
     # worst one -- a decoder BatchNorm weight with fp32 products, whose gradient the library forms as invstd * (sum dy r -
     # mean * sum dy), a difference the reference avoids by summing dy * xhat; 8 covers that with the sampling margin; the whole-gradient error is
     # dominated by the one or two worst-conditioned tensors, so its factor follows theirs: 4)
 
-    def __init__(self, onet64, run, seeds=(1, 2, 3, 4, 5, 6)):
+    def __init__(self, onet64, run, seeds=(1, 2, 3, 4)):
         self.net, self.seeds = onet64, tuple(seeds)
         self._box = {}
 
@@ -133,11 +133,9 @@ class GradientFloor:
         self._loss_of = loss_of
         self.clean = noisy_gradients(onet64, loss_of, 0.0, 0)
         self.out = self._box['out']
-        fwd = 0.0
-        for s_ in (101, 102):
-            noisy_gradients(onet64, loss_of, self.EPS_REF, s_)
-            fwd += float((self._box['out'] - self.out).pow(2).sum() / self.out.pow(2).sum().clamp_min(1e-300))
-        self.fwd_spread = (fwd / 2) ** 0.5                                  # forward output deviation per EPS_REF of noise
+        noisy_gradients(onet64, loss_of, self.EPS_REF, 101)              # (one run: the output has 1e5+ elements to average over)
+        fwd = float((self._box['out'] - self.out).pow(2).sum() / self.out.pow(2).sum().clamp_min(1e-300))
+        self.fwd_spread = fwd ** 0.5                                        # forward output deviation per EPS_REF of noise
         # absolute term of the bars: fp32 rounding of the result itself + the random walk of an fp32 accumulation over the
         # P output pixels a weight gradient of the widest level sums (2^-24 sqrt(P): 6.5e-5 at 2 x 768 x 768 pixels; any fp32
         # implementation, the reference's included, carries it -- the injected noise above models the products, not the

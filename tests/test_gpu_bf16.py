@@ -599,7 +599,7 @@ def test_network_bf16_storage_against_fp64_oracle(cfgname):
     plan = [p for ps in net._plans.values() for p in ps][0]
     assert plan.bf16 and plan.feat.t.dtype == torch.bfloat16, 'the recorded program must hold bf16 activations'
     torch.set_num_threads(max(torch.get_num_threads(), 32))
-    gf = NF.GradientFloor(oracle64(cfg, onet.state_dict()), oracle_run(x, tseg, theat), seeds=(1, 2, 3, 4))
+    gf = NF.GradientFloor(oracle64(cfg, onet.state_dict()), oracle_run(x, tseg, theat), seeds=(1, 2, 3))
     dev = float((seg.detach().double().cpu() - gf.out).abs().max())
     assert dev < 5e-2, 'soft-max deviation %.3e from fp64' % dev
     assert dev > 1e-5, 'the bf16 storage mode does not seem to be in effect'
