@@ -315,14 +315,18 @@ class Program:
         self.structs = []      # keeps the argument structs alive
         self.kinds = []
         self.streams = []      # 0 = the caller's stream, 1.. = library side streams (dfl_op.stream)
+        self.volatile = []     # ops whose argument block is rewritten between replays (caller-owned addresses): never captured
         self._ops = None
         self.keep = []         # tensors referenced by raw pointers
+        self._chunks = {}      # (start, count) -> [(first op, count, Graph or None)], see run_graphed
 
-    def add(self, args_struct, kind=None, stream=0):
+    def add(self, args_struct, kind=None, stream=0, volatile=False):
         self.structs.append(args_struct)
         self.kinds.append(kind if kind is not None else _KIND_OF[type(args_struct)])
         self.streams.append(stream)
+        self.volatile.append(bool(volatile))
         self._ops = None
+        self._chunks = {}
         return args_struct
 
     def record(self, event, stream=0):
@@ -337,8 +341,8 @@ class Program:
         return self.add(args_struct, OP_POOL_BWD if backward else OP_POOL_FWD)
 
     def extend(self, other):
-        for s, k, st in zip(other.structs, other.kinds, other.streams):
-            self.add(s, k, st)
+        for s, k, st, v in zip(other.structs, other.kinds, other.streams, other.volatile):
+            self.add(s, k, st, v)
         self.keep.extend(other.keep)
 
     def __len__(self):
@@ -370,6 +374,40 @@ class Program:
         check(lib().dfl_graph_capture(C.addressof(self._ops) + start * C.sizeof(Op), n, stream, C.addressof(h)),
               'dfl_graph_capture')
         return Graph(h.value, self)
+
+    MIN_GRAPH_OPS = 2
+
+    def graph_chunks(self, stream, start=0, count=None):
+        """Cut ops [start, start + count) into maximal runs that one hipGraph can stand for -- main-stream kernels whose
+        argument blocks do not change between replays -- and the ops in between (event record / wait, side-stream work,
+        volatile ops), which stay plain launches in program order.  Graphs are captured here, once per range."""
+        n = len(self.structs) - start if count is None else count
+        key = (start, n)
+        chunks = self._chunks.get(key)
+        if chunks is None:
+            chunks, i, end = [], start, start + n
+            while i < end:
+                plain = self.kinds[i] in (OP_RECORD, OP_WAIT) or self.streams[i] != 0 or self.volatile[i]
+                j = i + 1
+                while j < end and (self.kinds[j] in (OP_RECORD, OP_WAIT) or self.streams[j] != 0 or self.volatile[j]) == plain:
+                    j += 1
+                if not plain and j - i >= self.MIN_GRAPH_OPS:
+                    chunks.append((i, j - i, self.capture(stream, i, j - i)))
+                else:
+                    chunks.append((i, j - i, None))
+                i = j
+            self._chunks[key] = chunks
+        return chunks
+
+    def run_graphed(self, stream, start=0, count=None):
+        """Replay ops [start, start + count): hipGraph launches for the capturable runs, dfl_exec for the rest."""
+        if not self.structs:
+            return
+        for first, cnt, graph in self.graph_chunks(stream, start, count):
+            if graph is not None:
+                graph.launch(stream)
+            else:
+                self.run(stream, first, cnt)
 
     def run(self, stream, start=0, count=None):
         if not self.structs:

@@ -822,7 +822,7 @@ static void for_each_candidate(const dfl_conv_args& a, const ConvP& base, int fo
   }
 }
 
-int convp_plan(const dfl_conv_args* a, ConvP* p, int force_splits) {
+static int convp_plan_search(const dfl_conv_args* a, ConvP* p, int force_splits) {
   DFL_REQUIRE(a->x && a->w && a->y, "dfl_conv2d (bf16): x, w and y are required");
   DFL_REQUIRE(a->N > 0 && a->Hin > 0 && a->Win > 0 && a->Cin > 0 && a->Ntot > 0, "dfl_conv2d (bf16): bad sizes");
   DFL_REQUIRE(a->Ntot % 8 == 0 && a->ldy % 8 == 0 && aligned16(a->y) && (a->add == nullptr || (a->ldadd % 8 == 0 && aligned16(a->add))) &&
@@ -908,6 +908,48 @@ int convp_plan(const dfl_conv_args* a, ConvP* p, int force_splits) {
   return DFL_OK;
 }
 
+// The geometry of an argument block is resolved ONCE: a recorded program replays the same blocks every step (97 convolutions
+// per training step of the paper network), and the search above -- validation, the tuning-table scan under a mutex, for
+// layers the table does not list up to ~1000 try_geometry calls -- is host time the GPU waits for on a slow host
+// (8.4 ms per step observed where the kernels take 5.3).  Keyed by the whole argument block (addresses
+// included: they select alignment-dependent paths and are copied into ConvP) and the requested K slices; a forced
+// geometry (tuners, tests) bypasses it, a changed tuning table clears it.
+struct PlanMemo { dfl_conv_args a; int force_splits; ConvP p; };
+static std::mutex g_memo_mu;
+static std::vector<PlanMemo> g_memo[64];
+static inline unsigned memo_bucket(const dfl_conv_args* a, int force_splits) {
+  uint64_t h = 1469598103934665603ull;
+  const uint64_t* w = reinterpret_cast<const uint64_t*>(a);
+  for (size_t i = 0; i < sizeof(dfl_conv_args) / 8; ++i) h = (h ^ w[i]) * 1099511628211ull;
+  h ^= (uint64_t)force_splits;
+  return (unsigned)((h ^ (h >> 29)) & 63u);
+}
+static void memo_clear() {
+  std::lock_guard<std::mutex> lock(g_memo_mu);
+  for (auto& b : g_memo) b.clear();
+}
+
+int convp_plan(const dfl_conv_args* a, ConvP* p, int force_splits) {
+  static_assert(sizeof(dfl_conv_args) % 8 == 0, "hashed as 64-bit words");
+  DFL_REQUIRE(a != nullptr && p != nullptr, "dfl_conv2d (bf16): null arguments");
+  if (t_force.tile >= 0) return convp_plan_search(a, p, force_splits);
+  const unsigned b = memo_bucket(a, force_splits);
+  {
+    std::lock_guard<std::mutex> lock(g_memo_mu);
+    for (const PlanMemo& m : g_memo[b])
+      if (m.force_splits == force_splits && memcmp(&m.a, a, sizeof(*a)) == 0) {
+        *p = m.p;
+        return DFL_OK;
+      }
+  }
+  const int rc = convp_plan_search(a, p, force_splits);
+  if (rc != DFL_OK) return rc;
+  std::lock_guard<std::mutex> lock(g_memo_mu);
+  if (g_memo[b].size() >= 256) g_memo[b].clear();          // bounded: 16 K argument blocks, then start over
+  g_memo[b].push_back(PlanMemo{*a, force_splits, *p});
+  return DFL_OK;
+}
+
 template <int WM, int WN, int TM, int TN, bool GA = false>
 static int convp_launch_t(const ConvP& p, hipStream_t s) {
   const bool aff = p.a.in_scale != nullptr;
@@ -922,11 +964,13 @@ static int convp_launch_t(const ConvP& p, hipStream_t s) {
     hipLaunchKernelGGL((convp_kernel<WM, WN, TM, TN, false, true>), grid, dim3(256), lds, s, p);
   } else if (aff) {
     auto k = convp_kernel<WM, WN, TM, TN, true, false>;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsHard);
+    (void)attr;                                      // (once per instantiation, not per launch)
     hipLaunchKernelGGL(k, grid, dim3(256), lds, s, p);
   } else {
     auto k = convp_kernel<WM, WN, TM, TN, false, false>;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsHard);
+    (void)attr;
     hipLaunchKernelGGL(k, grid, dim3(256), lds, s, p);
   }
   return check_launch("dfl_conv2d (bf16)");
@@ -1005,6 +1049,7 @@ int convp_force(const int32_t* g) {
 }
 
 int convp_tune_add(const int32_t* key, const int32_t* g) {
+  memo_clear();
   std::lock_guard<std::mutex> lock(g_tune_mu);
   if (key == nullptr) {
     g_tune.clear();

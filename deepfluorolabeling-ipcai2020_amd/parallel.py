@@ -126,6 +126,14 @@ class DataParallel:
         plan._dp_segments = (self.bucket_elems, seg)
         return seg
 
+    def _run_ops(self, plan, stream, start=0, count=None):
+        """A segment of the backward program; on the GPU through the network's replay (hipGraph per segment, unet.run_program)."""
+        run = getattr(self.net, 'run_program', None)
+        if run is not None and plan.grad_flat.is_cuda:
+            run(plan, plan.bwd, stream, start, count)
+        else:
+            plan.bwd.run(stream, start, count)
+
     def _reduce(self, view, inv):
         if self._avg_in_collective:
             dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group)
@@ -174,7 +182,7 @@ class DataParallel:
 
     def _run_backward(self, plan, stream):
         if not self.active:
-            plan.bwd.run(stream)
+            self._run_ops(plan, stream)
             getattr(plan, 'unfold_tail_grads', lambda: None)()
             return
         flat = plan.grad_flat
@@ -183,7 +191,7 @@ class DataParallel:
             # same segment walk, communication in line (also the path the CPU/gloo tests exercise)
             segs = self._segments(plan)
             for k, (op_start, op_count, ranges) in enumerate(segs):
-                plan.bwd.run(stream, op_start, op_count)
+                self._run_ops(plan, stream, op_start, op_count)
                 if op_start + op_count == len(plan.bwd):
                     getattr(plan, 'unfold_tail_grads', lambda: None)()      # gradients made after the last op (plan.py)
                 if ranges:
@@ -195,7 +203,7 @@ class DataParallel:
         comm = self.comm_stream
         events = plan.__dict__.setdefault('_dp_events', {})   # one event per bucket, created once and re-recorded every step
         for k, (op_start, op_count, ranges) in enumerate(self._segments(plan)):
-            plan.bwd.run(stream, op_start, op_count)
+            self._run_ops(plan, stream, op_start, op_count)
             if op_start + op_count == len(plan.bwd):
                 getattr(plan, 'unfold_tail_grads', lambda: None)()
             if ranges:

@@ -77,6 +77,8 @@ class UNetPlan:
         self.adt = torch.bfloat16 if self.bf16 else torch.float32
         self.aesz = 2 if self.bf16 else 4
         self._packed_split = {}         # packed-weight address -> stored as split quads
+        self.relu_out = {}              # nn.ReLU module name -> Act of its output (saved for backward; introspection for tests)
+        self.pool_in = {}               # level -> Act the max-pool of that level reads
         self._build()
 
     # ------------------------------------------------------------------------------------------ memory
@@ -441,6 +443,7 @@ class UNetPlan:
                     aff = (scale, shift)
                     bnrec = (gamma, mean, invstd, bname)
                 convs.append(dict(w=w, wname=wname, inp=cur, inp_aff=cur_aff, r=r, bn=bnrec))
+                self.relu_out['%s.block.%d' % (prefix, d * step + 1)] = r      # (module name of the nn.ReLU: tests read its mask)
                 cur, cur_aff = r, aff
             assert cur.H == Hb and cur.W == Wb
             if do_res:
@@ -564,6 +567,7 @@ class UNetPlan:
                     rec['crop'] = (oy, ox, ch, cw)
                 nxt = self._act(N, hin[i + 1], win[i + 1], Ci)
                 if cfg['max_pool']:
+                    self.pool_in[i] = out
                     fwd.add_pool(PoolArgs(x=out.ptr, y=nxt.ptr, N=N, H=out.H, W=out.W, C=Ci, ldx=out.ld, ldy=nxt.ld,
                                           bf16=out.bf16), backward=False)
                 else:
@@ -649,7 +653,7 @@ class UNetPlan:
         self.head_fwd = HeadFwdArgs(x=head_x.ptr, w_seg=w_seg.data_ptr(), w_l1=nat.ptr(w_l1), w_l2=nat.ptr(w_l2),
                                     N=N, H=u.H, W=u.W, F=Fh, ldx=head_x.ld, NC=NC, NM=NM, L=L,
                                     softmax=1 if cfg['do_soft_max'] else 0, x_bf16=u.bf16)
-        fwd.add(self.head_fwd)
+        fwd.add(self.head_fwd, volatile=True)       # writes the caller-owned outputs: addresses change per call
         self.out_hw = (u.H, u.W)
 
         self._n_fwd_pack = len(self._pack_jobs)
@@ -700,7 +704,7 @@ class UNetPlan:
             self.head_bwd.scratch = scratch.data_ptr()
         if self.PACK_OVERLAP:
             bwd.wait(self.EV_PACK_DONE, stream=0)      # data-gradient weight layouts are packed on the side stream
-        bwd.add(self.head_bwd)
+        bwd.add(self.head_bwd, volatile=True)       # reads the caller-owned seg / dseg / dheat
         if not fused_head:
             off = [self.lib.dfl_head_scratch_off_for(F, NC, NM, L, k) for k in range(5)]
 
@@ -876,3 +880,11 @@ class UNetPlan:
 
     def grads(self):
         return [None if k in self.dead_params else self.G[k] for k in self.grad_names]
+
+    def act_nchw(self, act):
+        """Copy of an internal NHWC activation window as an fp32 NCHW tensor (introspection for tests and diagnosis)."""
+        esz = act.esz
+        base = act.t.view(-1)
+        off = (act.ptr - base.data_ptr()) // esz
+        v = base.as_strided((act.N, act.H, act.W, act.C), (act.H * act.W * act.ld, act.W * act.ld, act.ld, 1), off)
+        return v.permute(0, 3, 1, 2).float().contiguous()

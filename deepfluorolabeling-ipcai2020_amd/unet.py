@@ -189,6 +189,8 @@ class UNet(nn.Module):
         self.direct_grad = True                       # install gradient views as .grad without autograd copies
         # inference forwards replay one hipGraph per recorded plan (DFL_HIPGRAPH=0: launch the ops one by one)
         self.use_graphs = os.environ.get('DFL_HIPGRAPH', '1') != '0'
+        # ... and so do training forwards / backwards (DFL_TRAIN_GRAPH=0: op by op)
+        self.train_graphs = os.environ.get('DFL_TRAIN_GRAPH', '1') != '0'
         self._flatten_parameters()
 
     # ---------------------------------------------------------------------------------------------- plumbing
@@ -314,21 +316,30 @@ class UNet(nn.Module):
         seg, heat = plan.new_outputs()
         plan.head_fwd.seg = seg.data_ptr()
         plan.head_fwd.heat = nat.ptr(heat)
-        n = len(plan.fwd)
-        if self.use_graphs and not plan.training and n > 1:
-            # inference: everything up to the heads is one hipGraph launch (BASELINE configs[4]; the per-image loops of
-            # util.test_dataset / seg_dataset_ensemble replay ~100 small launches per net).  Captured on first use; the
-            # head op writes the caller-owned outputs, whose addresses change per call, so it stays a plain launch.
-            if plan.graph is None:
-                plan.graph = plan.fwd.capture(stream, 0, n - 1)
-            plan.graph.launch(stream)
-            plan.fwd.run(stream, n - 1, 1)
-        else:
-            plan.fwd.run(stream)
+        self.run_program(plan, plan.fwd, stream)
         return seg, heat
 
+    def graphs_on(self, plan):
+        return self.use_graphs and (self.train_graphs or not plan.training)
+
+    def run_program(self, plan, prog, stream, start=0, count=None):
+        """Replay (part of) a recorded program.  With graphs on, every run of main-stream kernels with fixed argument blocks
+        is ONE hipGraph launch (captured on first use): the inference forward up to the heads (BASELINE configs[4]; the
+        per-image loops of util.test_dataset / seg_dataset_ensemble replay ~100 small launches per net) and -- round 3 --
+        the training forward and backward (~250 launches per step: on a slow host the GPU waited for them).
+        The head ops read / write caller-owned tensors whose addresses change per call, event waits order the side-stream
+        weight packing: both stay plain launches in program order (Program.graph_chunks)."""
+        if self.graphs_on(plan):
+            chunks = prog.graph_chunks(stream, start, count)
+            if prog is plan.fwd and plan.graph is None:
+                gs = [g for _, _, g in chunks if g is not None]
+                plan.graph = max(gs, key=lambda g: g.nodes) if gs else None
+            prog.run_graphed(stream, start, count)
+        else:
+            prog.run(stream, start, count)
+
     def _run_backward(self, plan, stream):
-        plan.bwd.run(stream)
+        self.run_program(plan, plan.bwd, stream)
         plan.unfold_tail_grads()
 
     # ---------------------------------------------------------------------------------------------- forward

@@ -113,6 +113,7 @@ class OracleUNet(nn.Module):
         self.do_max_pool = max_pool
         self.num_lands = num_lands
         self.do_soft_max = do_soft_max
+        self.pool_override = None      # tests: callable(level, x) -> pooled x replacing F.max_pool2d (forced arg-max choices)
         # attribute assigned before down_path => registered first
         self.downsample_convs = None
         if not max_pool:
@@ -160,7 +161,7 @@ class OracleUNet(nn.Module):
             if i != len(self.down_path) - 1:
                 bridges.append(x)
                 if self.do_max_pool:
-                    x = F.max_pool2d(x, 2)
+                    x = F.max_pool2d(x, 2) if self.pool_override is None else self.pool_override(i, x)
                 else:
                     x = self.downsample_convs[i](x)
         for i, up in enumerate(self.up_path):

@@ -245,3 +245,59 @@ def cached_floor(key, make):
     if key not in _FLOORS:
         _FLOORS[key] = make()
     return _FLOORS[key]
+
+
+# ---- activation-pattern-aware comparison ------------------------------------------------------------------------------
+# A ReLU whose pre-activation lies within the arithmetic's noise of zero, or a 2x2 pooling window whose two largest values
+# lie that close together, may resolve differently in the HIP run and in the fp64 oracle.  Either choice is a valid
+# rounding of the same network, but the two gradients then differ by a whole element of an upstream gradient, whatever the
+# noise level is -- in a 2 x 32 x 32 test network one such flip moves an 8-element weight gradient by 2e-3 (VERDICT r02:
+# tiny_bd3_nosm, bf16x3, down_path.0.res_conv1x1.weight).  The comparison therefore runs the fp64 oracle ON THE HIP RUN'S
+# ACTIVATION PATTERN: its ReLUs multiply by the masks the HIP run used, its max-pools gather the elements the HIP run
+# chose.  What is left between the two gradients is rounding noise proper, which is smooth in the noise level.
+import contextlib
+import torch.nn.functional as F
+
+
+def hip_choices(plan):
+    """{'relu': {module name: bool mask [N,C,H,W]}, 'pool': {level: int64 flat indices [N,C,H/2,W/2]}} of the forward pass
+    whose activations the plan holds (plan.relu_out / plan.pool_in: the tensors its backward pass reads)."""
+    relu = {k: (plan.act_nchw(a) > 0).cpu() for k, a in plan.relu_out.items()}
+    pool = {}
+    for lvl, a in plan.pool_in.items():
+        pool[lvl] = F.max_pool2d(plan.act_nchw(a), 2, return_indices=True)[1].cpu()
+    return {'relu': relu, 'pool': pool}
+
+
+@contextlib.contextmanager
+def forced_choices(onet, choices):
+    """Run `onet` (oracle/ref_cpu.OracleUNet) with the ReLU masks and pooling choices of `choices` (hip_choices).  Yields a
+    dict that receives the number of ReLU outputs / pooling windows whose natural choice differs from the forced one."""
+    info = {'relu_flips': 0, 'pool_flips': 0, 'relu_total': 0}
+    handles = []
+    mods = dict(onet.named_modules())
+    for name, mask in choices['relu'].items():
+        m = mods[name]
+        assert isinstance(m, nn.ReLU), name
+
+        def hook(mod, inp, out, mask=mask):
+            x = inp[0]
+            assert tuple(x.shape) == tuple(mask.shape), (tuple(x.shape), tuple(mask.shape))
+            info['relu_flips'] += int(((x.detach() > 0) != mask).sum())
+            info['relu_total'] += mask.numel()
+            return x * mask.to(x.dtype)
+        handles.append(m.register_forward_hook(hook))
+    prev = onet.pool_override
+    if choices['pool']:
+        def pool(level, x):
+            idx = choices['pool'][level]
+            nat_idx = F.max_pool2d(x.detach(), 2, return_indices=True)[1]
+            info['pool_flips'] += int((nat_idx != idx).sum())
+            return x.flatten(2).gather(2, idx.flatten(2)).view(idx.shape)
+        onet.pool_override = pool
+    try:
+        yield info
+    finally:
+        onet.pool_override = prev
+        for h in handles:
+            h.remove()
