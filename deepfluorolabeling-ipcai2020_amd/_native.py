@@ -145,6 +145,11 @@ class EstLandsArgs(C.Structure):
                 ('B', i32), ('L', i32), ('H', i32), ('W', i32), ('sigma', f32), ('min_ncc', f32)]
 
 
+class UpsampleArgs(C.Structure):
+    _fields_ = [('x', fp), ('y', fp), ('N', i32), ('H', i32), ('W', i32), ('C', i32), ('ldx', i32), ('ldy', i32),
+                ('bf16', i32), ('accumulate', i32)]
+
+
 class SyncArgs(C.Structure):
     _fields_ = [('event', i32), ('reserved', i32)]
 
@@ -155,7 +160,7 @@ class Op(C.Structure):
 
 OP_CONV, OP_WGRAD, OP_SUM_PARTIALS, OP_PACK, OP_BN_FINALIZE, OP_BN_EVAL, OP_COLSTATS, OP_BN_BWD_FINALIZE, \
     OP_BN_RELU_BWD, OP_REDUCE_PARTIALS, OP_AFFINE_COPY, OP_POOL_FWD, OP_POOL_BWD, OP_HEAD_FWD, OP_HEAD_BWD, \
-    OP_MEMSET, OP_REDUCE_BATCH, OP_RECORD, OP_WAIT = range(1, 20)
+    OP_MEMSET, OP_REDUCE_BATCH, OP_RECORD, OP_WAIT, OP_UPSAMPLE_FWD, OP_UPSAMPLE_BWD = range(1, 22)
 
 _KIND_OF = {ConvArgs: OP_CONV, WgradArgs: OP_WGRAD, SumPartialsArgs: OP_SUM_PARTIALS, PackArgs: OP_PACK,
             BnFinalizeArgs: OP_BN_FINALIZE, BnEvalArgs: OP_BN_EVAL, ColstatsArgs: OP_COLSTATS,
@@ -164,7 +169,8 @@ _KIND_OF = {ConvArgs: OP_CONV, WgradArgs: OP_WGRAD, SumPartialsArgs: OP_SUM_PART
             HeadBwdArgs: OP_HEAD_BWD, MemsetArgs: OP_MEMSET, ReduceBatchArgs: OP_REDUCE_BATCH}
 
 _SIZEOF_ORDER = [ConvArgs, WgradArgs, PackJob, BnFinalizeArgs, ColstatsArgs, BnBwdFinalizeArgs, BnReluBwdArgs,
-                 AffineCopyArgs, PoolArgs, HeadFwdArgs, HeadBwdArgs, LossArgs, EnsembleArgs, Op, ReduceJob, PrepArgs, EstLandsArgs]
+                 AffineCopyArgs, PoolArgs, HeadFwdArgs, HeadBwdArgs, LossArgs, EnsembleArgs, Op, ReduceJob, PrepArgs, EstLandsArgs,
+                 UpsampleArgs]
 
 EXPORTS = ['dfl_version', 'dfl_last_error', 'dfl_sizeof', 'dfl_conv2d', 'dfl_conv_grid_m', 'dfl_conv2d_wgrad',
            'dfl_wgrad_suggest_splits', 'dfl_sum_partials', 'dfl_pack_weights', 'dfl_bn_finalize',
@@ -176,7 +182,8 @@ EXPORTS = ['dfl_version', 'dfl_last_error', 'dfl_sizeof', 'dfl_conv2d', 'dfl_con
            'dfl_reduce_job_blocks', 'dfl_prep_batch', 'dfl_prep_scratch_doubles', 'dfl_est_lands', 'dfl_hard_dice', 'dfl_get_math_mode',
            'dfl_set_math_mode', 'dfl_graph_capture', 'dfl_graph_launch', 'dfl_graph_nodes', 'dfl_graph_destroy',
            'dfl_set_conv_rows_min_tiles', 'dfl_conv_candidates', 'dfl_conv_force_geometry', 'dfl_conv_tune_add',
-           'dfl_head_wgrad_blocks', 'dfl_head_scratch_ld_for', 'dfl_head_scratch_off_for']
+           'dfl_head_wgrad_blocks', 'dfl_head_scratch_ld_for', 'dfl_head_scratch_off_for', 'dfl_upsample2x_fwd',
+           'dfl_upsample2x_bwd']
 
 
 class DflError(RuntimeError):
@@ -226,7 +233,8 @@ def lib():
     L.dfl_wgrad_config.argtypes = [fp]
     for fn in ('dfl_conv2d', 'dfl_conv2d_wgrad', 'dfl_bn_finalize', 'dfl_colstats', 'dfl_bn_bwd_finalize',
                'dfl_bn_relu_bwd_apply', 'dfl_affine_copy', 'dfl_maxpool2x2_fwd', 'dfl_maxpool2x2_bwd',
-               'dfl_head_fwd', 'dfl_head_bwd', 'dfl_dice_ncc_loss', 'dfl_ensemble_reduce'):
+               'dfl_head_fwd', 'dfl_head_bwd', 'dfl_dice_ncc_loss', 'dfl_ensemble_reduce', 'dfl_upsample2x_fwd',
+               'dfl_upsample2x_bwd'):
         getattr(L, fn).argtypes = [fp, fp]
     for fn in ('dfl_conv_grid_m', 'dfl_wgrad_suggest_splits', 'dfl_conv_suggest_splits'):
         getattr(L, fn).argtypes = [fp]
@@ -325,6 +333,16 @@ class Program:
         self.kinds.append(kind if kind is not None else _KIND_OF[type(args_struct)])
         self.streams.append(stream)
         self.volatile.append(bool(volatile))
+        self._ops = None
+        self._chunks = {}
+        return args_struct
+
+    def insert(self, index, args_struct, kind=None, stream=0, volatile=False):
+        """Like add(), in front of op `index`."""
+        self.structs.insert(index, args_struct)
+        self.kinds.insert(index, kind if kind is not None else _KIND_OF[type(args_struct)])
+        self.streams.insert(index, stream)
+        self.volatile.insert(index, bool(volatile))
         self._ops = None
         self._chunks = {}
         return args_struct

@@ -78,7 +78,7 @@ extern "C" int dfl_sizeof(int which) {
       (int)sizeof(dfl_bn_relu_bwd_args), (int)sizeof(dfl_affine_copy_args),    (int)sizeof(dfl_pool_args),
       (int)sizeof(dfl_head_fwd_args),   (int)sizeof(dfl_head_bwd_args),        (int)sizeof(dfl_loss_args),
       (int)sizeof(dfl_ensemble_args),   (int)sizeof(dfl_op),                   (int)sizeof(dfl_reduce_job),
-      (int)sizeof(dfl_prep_args),       (int)sizeof(dfl_est_lands_args)};
+      (int)sizeof(dfl_prep_args),       (int)sizeof(dfl_est_lands_args),       (int)sizeof(dfl_upsample_args)};
   if (which < 0 || which >= (int)(sizeof(sizes) / sizeof(sizes[0]))) return -1;
   return sizes[which];
 }
@@ -256,6 +256,8 @@ static int exec_one(const dfl_op* ops, int i, dfl_stream_t main_stream, bool ser
       case DFL_OP_AFFINE_COPY: rc = dfl_affine_copy(static_cast<const dfl_affine_copy_args*>(p), stream); break;
       case DFL_OP_POOL_FWD: rc = dfl_maxpool2x2_fwd(static_cast<const dfl_pool_args*>(p), stream); break;
       case DFL_OP_POOL_BWD: rc = dfl_maxpool2x2_bwd(static_cast<const dfl_pool_args*>(p), stream); break;
+      case DFL_OP_UPSAMPLE_FWD: rc = dfl_upsample2x_fwd(static_cast<const dfl_upsample_args*>(p), stream); break;
+      case DFL_OP_UPSAMPLE_BWD: rc = dfl_upsample2x_bwd(static_cast<const dfl_upsample_args*>(p), stream); break;
       case DFL_OP_HEAD_FWD: rc = dfl_head_fwd(static_cast<const dfl_head_fwd_args*>(p), stream); break;
       case DFL_OP_HEAD_BWD: rc = dfl_head_bwd(static_cast<const dfl_head_bwd_args*>(p), stream); break;
       case DFL_OP_REDUCE_BATCH: {

@@ -4,7 +4,7 @@ set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 out="$here/../lib"
 mkdir -p "$out"
-srcs=(api.hip conv_gemm.hip conv_rows.hip convp_bf16.hip wgradp_bf16.hip wgrad_gemm.hip direct_small.hip bn_elem.hip head.hip loss.hip prep.hip)
+srcs=(api.hip conv_gemm.hip conv_rows.hip convp_bf16.hip wgradp_bf16.hip wgrad_gemm.hip direct_small.hip bn_elem.hip head.hip loss.hip prep.hip upsample.hip)
 objs=()
 pids=()
 for s in "${srcs[@]}"; do

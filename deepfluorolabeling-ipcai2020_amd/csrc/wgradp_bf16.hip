@@ -366,6 +366,19 @@ static int wgp_plan(const dfl_wgrad_args* a, WgP* p, bool need_out) {
   // workgroup tile and wave roles
   p->CMT = a->Cm > 32 ? 64 : 32;
   p->CGT = a->Cg > 32 ? 64 : 32;
+  {
+    // Layers with many (cm, cg) tiles but not enough of them to fill the chip (levels 3-4 of the paper network: 16 ... 128
+    // tiles of 64 x 64) used to be cut into 16 ... 2 pixel slices, each leaving a full-size fp32 partial gradient (37.7 MB per
+    // 3x3 layer, written here and read back by dfl_reduce_batch: the largest wasted traffic of a step).  With
+    // 32 x 32 tiles the same workgroup count needs a quarter of the slices -- none at all from 256 tiles on; the patch of d /
+    // g is then staged by twice as many workgroups, which these small, L2-resident activations can afford.
+    static const int small_from = [] {
+      const char* e = getenv("DFL_WGP_SMALL_TILES");   // use 32 x 32 tiles from this many 64 x 64 tiles on (0: never)
+      return e ? atoi(e) : 16;
+    }();
+    const int64_t tiles64 = ceil_div(a->Cm, 64) * ceil_div(a->Cg, 64);
+    if (small_from > 0 && a->Cm > 32 && a->Cg > 32 && tiles64 >= small_from && tiles64 < 256) p->CMT = p->CGT = 32;
+  }
   p->pairs = (p->CMT / 32) * (p->CGT / 32);
   p->phases = 4 / p->pairs;
   p->dupp_shift = p->CMT == 64 ? 3 : 2;
@@ -505,11 +518,13 @@ static int wgp_launch_t(const WgP& p, hipStream_t s) {
   const size_t lds = (size_t)p.lds_bytes;
   if (p.a.in_scale != nullptr) {
     auto k = wgradp_kernel<KH, KW, true>;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)attr;                                          // (once per instantiation, not per launch)
     hipLaunchKernelGGL(k, grid, dim3(256 * KH), lds, s, p);
   } else {
     auto k = wgradp_kernel<KH, KW, false>;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)attr;
     hipLaunchKernelGGL(k, grid, dim3(256 * KH), lds, s, p);
   }
   return check_launch("dfl_conv2d_wgrad (bf16)");

@@ -49,15 +49,23 @@ _ZB_POOL = {}
 def _zero_border_buffer(dev, shape, window):
     """A full-size fp32 tensor whose border around `window` = (r0, c0, h, w) is zero: the loss gradient is written into
     its interior.  Buffers are pooled per (device, shape, window) and handed out only while nothing else refers to them
-    (a gradient still held by autograd or by the caller keeps its buffer out of circulation)."""
+    (a gradient still held by autograd or by the caller keeps its buffer out of circulation).  The library writes the
+    interior through a raw pointer, which leaves torch's version counter alone: a counter that HAS moved means some torch
+    op wrote into the buffer in place (a gradient hook scaling or clamping it) and may have dirtied the border,
+    so the buffer is zeroed again before it goes out."""
     key = (str(dev), shape, window)
     pool = _ZB_POOL.setdefault(key, [])
-    for buf in pool:
-        if buf._use_count() == 1:
+    use_count = getattr(torch.Tensor, '_use_count', None)
+    for buf in pool if use_count is not None else ():
+        if use_count(buf) == 1:
+            if buf._version != buf._dfl_version:
+                buf.zero_()
+                buf._dfl_version = buf._version
             return buf
     buf = torch.zeros(shape, dtype=torch.float32, device=dev)
     buf._dfl_zero_border = window
-    if len(pool) < 4:
+    buf._dfl_version = buf._version
+    if len(pool) < 4 and use_count is not None:
         pool.append(buf)
     return buf
 

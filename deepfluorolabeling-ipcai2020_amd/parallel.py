@@ -105,6 +105,16 @@ class DataParallel:
         net._backward_runner = self._run_backward
         net.dp = self
 
+    def sync_buffers(self, src=0):
+        """Broadcast rank `src`'s buffers (BatchNorm running statistics, batch counters).  The statistics follow each replica's
+        own shards during training and drift apart; before anything that READS them on several ranks and must agree with what
+        rank 0 saves -- sharded validation, checkpoints -- every rank takes rank `src`'s."""
+        if not self.active:
+            return
+        with torch.no_grad():
+            for b in self.net.buffers():
+                dist.broadcast(b, src=src, group=self.group)
+
     # -------------------------------------------------------------------------------------------------------
     def _segments(self, plan):
         """[(op_start, op_count, [(start, stop), ...])]: run ops, then reduce those arena ranges."""

@@ -15,7 +15,7 @@ import torch
 
 from . import _native as nat
 from ._native import (ConvArgs, WgradArgs, PackJob, BnFinalizeArgs, ColstatsArgs, BnBwdFinalizeArgs, BnReluBwdArgs,
-                      AffineCopyArgs, PoolArgs, HeadFwdArgs, HeadBwdArgs, SumPartialsArgs, PackArgs, BnEvalArgs,
+                      AffineCopyArgs, PoolArgs, HeadFwdArgs, HeadBwdArgs, SumPartialsArgs, PackArgs, BnEvalArgs, UpsampleArgs,
                       ReducePartialsArgs, MemsetArgs, ReduceJob, ReduceBatchArgs, Program)
 
 BN_EPS = 1.0e-5
@@ -155,24 +155,57 @@ class UNetPlan:
         if not self.PACK_OVERLAP or self.bwd is None or nf in (0, n):
             self.pack.add(PackArgs(jobs_dev=self._jobs_dev.data_ptr(), max_elems=mx, njobs=n))
             return
-        # The layouts only the backward pass reads (flipped / transposed data-gradient operands: half of the traffic) are
-        # built on the side stream while the forward convolutions run -- an HBM-bound kernel next to matrix-bound ones.
-        # Main stream: forward layouts.  Side stream: waits for the main stream (the optimizer step), packs, signals;
-        # the backward program starts by waiting for that signal.
+        # Only what the FIRST forward layers read is packed on the main stream.  The side stream -- forked behind the
+        # optimizer step -- packs the large forward layouts of the deep levels (9/10 of the bytes: the forward program waits
+        # for them in front of its first deep layer, about a millisecond of shallow-level kernels later) and then the layouts
+        # only the backward pass reads (flipped / transposed data-gradient operands; the backward program starts by waiting
+        # for those): an HBM-bound kernel next to latency-bound convolutions.
         def mx_of(jobs):
             return max(A * B * Cc for (_, _, A, B, Cc, _, _, _) in jobs)
-        self.pack.add(PackArgs(jobs_dev=self._jobs_dev.data_ptr(), max_elems=mx_of(self._pack_jobs[:nf]), njobs=nf))
+        jobs = self._pack_jobs
+        nd = self._n_deep_pack
+        ns = nf - nd                         # (_order_pack_jobs: shallow forward jobs, deep forward jobs, backward jobs)
+        sz = C.sizeof(PackJob)
+        base = self._jobs_dev.data_ptr()
         self.pack.record(self.EV_PACK_FORK, stream=0)
         self.pack.wait(self.EV_PACK_FORK, stream=1)
-        self.pack.add(PackArgs(jobs_dev=self._jobs_dev.data_ptr() + nf * C.sizeof(PackJob),
-                               max_elems=mx_of(self._pack_jobs[nf:]), njobs=n - nf), stream=1)
+        if ns > 0:
+            self.pack.add(PackArgs(jobs_dev=base, max_elems=mx_of(jobs[:ns]), njobs=ns))
+        if nd > 0:
+            self.pack.add(PackArgs(jobs_dev=base + ns * sz, max_elems=mx_of(jobs[ns:nf]), njobs=nd), stream=1)
+            self.pack.record(self.EV_PACK_DEEP, stream=1)
+        self.pack.add(PackArgs(jobs_dev=base + nf * sz, max_elems=mx_of(jobs[nf:]), njobs=n - nf), stream=1)
         self.pack.record(self.EV_PACK_DONE, stream=1)
         self._bwd_needs_pack_wait = True
+
+    DEEP_PACK_ELEMS = int(os.environ.get('DFL_PACK_DEEP_ELEMS', str(256 * 1024)))   # forward layouts from this size on are packed on the side stream (0: none)
+
+    def _order_pack_jobs(self):
+        """Forward jobs: small ones first, then -- from the first large one in forward order on -- the rest ("deep": packed on
+        the side stream); a wait for them goes in front of the first forward op that reads one."""
+        nf = self._n_fwd_pack
+        self._n_deep_pack = 0
+        if not self.PACK_OVERLAP or self.bwd is None or self.DEEP_PACK_ELEMS <= 0 or nf == 0:
+            return
+        fwd_jobs = self._pack_jobs[:nf]
+        first = next((i for i, j in enumerate(fwd_jobs) if j[2] * j[3] * j[4] >= self.DEEP_PACK_ELEMS), None)
+        if first is None or first == 0:
+            return
+        deep = {fwd_jobs[i][1].data_ptr() for i in range(first, nf) if fwd_jobs[i][2] * fwd_jobs[i][3] * fwd_jobs[i][4] >= self.DEEP_PACK_ELEMS}
+        # small weights that come later in forward order (decoder levels, heads) stay on the main stream
+        shallow = [j for j in fwd_jobs if j[1].data_ptr() not in deep]
+        deepj = [j for j in fwd_jobs if j[1].data_ptr() in deep]
+        self._pack_jobs[:nf] = shallow + deepj
+        self._n_deep_pack = len(deepj)
+        for idx, st in enumerate(self.fwd.structs):
+            if isinstance(st, ConvArgs) and st.w in deep:
+                self.fwd.insert(idx, nat.SyncArgs(event=self.EV_PACK_DEEP), nat.OP_WAIT, 0)
+                break
 
     PACK_OVERLAP = os.environ.get('DFL_PACK_OVERLAP', '1') != '0'
     WSPLIT = os.environ.get('DFL_WSPLIT', '1') != '0'      # split-bf16 modes: weights split once by the pack kernel
     DSPLIT = os.environ.get('DFL_DSPLIT', '1') != '0'      # ... and the BatchNorm/ReLU backward output split once by its producer
-    EV_PACK_FORK, EV_PACK_DONE = 60000, 60001
+    EV_PACK_FORK, EV_PACK_DONE, EV_PACK_DEEP = 60000, 60001, 60002
 
     # ------------------------------------------------------------------------------------------ op helpers
     def _conv(self, prog, x, w, y, KH, KW, stride, pad, Ntot, bias=None, in_aff=None, relu=0, add=None,
@@ -316,6 +349,45 @@ class UNetPlan:
                               bf16=a.bf16))
         self._defer_sum(prog, part.data_ptr(), out.data_ptr(), a.C, 2 * a.C, nb)
 
+    # ------------------------------------------------------------------------------------------ circular padding
+    # pad_mode='circular' (unet.py:211-212: nn.Conv2d(..., padding=1, padding_mode='circular')).  No reference CLI selects
+    # it, so it is built from what exists rather than as a third addressing mode of every kernel: the input is copied into a
+    # tensor with a one-pixel wrapped frame (9 window copies) and the convolution runs UNPADDED on that; backward, the data
+    # gradient comes out on the framed grid (a "full" correlation) and the frame is folded back onto the pixels it copies
+    # (9 window copies, 8 of them accumulating).  BatchNorm-on-load keeps working: every framed pixel is a real pixel.
+    _WRAP = ((-1, 0, 1), (0, 1, None), (0, None, 1))      # (source start or -1 = last, destination start or None = last, extent or None = all)
+
+    def _wrap_regions(self, H, W):
+        out = []
+        for sy, dy, h in ((H - 1, 0, 1), (0, 1, H), (0, H + 1, 1)):
+            for sx, dx, w in ((W - 1, 0, 1), (0, 1, W), (0, W + 1, 1)):
+                out.append((sy, sx, dy, dx, h, w))
+        return out
+
+    def _wrap_pad(self, prog, x):
+        """Act [N, H+2, W+2, C] holding x with a wrapped one-pixel frame (raw values: an affine-on-load still applies)."""
+        n = x.N * (x.H + 2) * (x.W + 2) * x.C
+        t = self._new(n, torch.bfloat16 if x.esz == 2 else torch.float32)
+        xp = Act(t, t.data_ptr(), x.C, x.N, x.H + 2, x.W + 2, x.C, x.esz)
+        for sy, sx, dy, dx, h, w in self._wrap_regions(x.H, x.W):
+            prog.add(AffineCopyArgs(x=x.ptr, y=xp.ptr, N=x.N, H=h, W=w, C=x.C, ldx=x.ld, xH=x.H, xW=x.W, xoy=sy, xox=sx,
+                                    ldy=xp.ld, yH=xp.H, yW=xp.W, yoy=dy, yox=dx, bf16=x.bf16))
+        return xp
+
+    def _wrap_fold(self, prog, dxp, dx, accumulate=0):
+        """dx (+)= the framed gradient dxp folded back: the adjoint of _wrap_pad."""
+        regs = self._wrap_regions(dx.H, dx.W)
+        regs.sort(key=lambda r: 0 if (r[4] == dx.H and r[5] == dx.W) else 1)     # the interior first: it may overwrite
+        for i, (sy, sx, dy, dx_, h, w) in enumerate(regs):
+            prog.add(AffineCopyArgs(x=dxp.ptr, y=dx.ptr, N=dx.N, H=h, W=w, C=dx.C, ldx=dxp.ld, xH=dxp.H, xW=dxp.W, xoy=dy, xox=dx_,
+                                    ldy=dx.ld, yH=dx.H, yW=dx.W, yoy=sy, yox=sx, accumulate=(accumulate if i == 0 else 1), bf16=dx.bf16))
+
+    def _framed_grad(self, like):
+        """Scratch Act for a data gradient on the framed grid of `like` ([N, H+2, W+2, C])."""
+        n = like.N * (like.H + 2) * (like.W + 2) * like.C
+        t = self._new(n, self.adt)
+        return Act(t, t.data_ptr(), like.C, like.N, like.H + 2, like.W + 2, like.C, self.aesz)
+
     # ------------------------------------------------------------------------------------------ build
     def _build(self):
         cfg = self.cfg
@@ -324,6 +396,9 @@ class UNetPlan:
         bd = cfg['block_depth']
         bn = cfg['batch_norm']
         do_res = cfg['do_res']
+        circ = bool(pad) and cfg.get('pad_mode', 'zeros') == 'circular'
+        upsample = cfg.get('up_mode', 'upconv') == 'upsample'
+        self.circular = circ
         N = self.N
         chans = [2 ** (wf + i) for i in range(depth)]
         for c in chans:
@@ -417,7 +492,8 @@ class UNetPlan:
                 wp = self._pack_conv_fwd(w)
                 Ho, Wo = cur.H - (0 if pad else 2), cur.W - (0 if pad else 2)
                 r = self._act(N, Ho, Wo, Cout)
-                part = self._conv(fwd, cur, wp, r, 3, 3, 1, pad, Cout, bias=b, in_aff=cur_aff, relu=1,
+                gin = self._wrap_pad(fwd, cur) if circ else cur          # what the convolution (and its weight gradient) gathers from
+                part = self._conv(fwd, gin, wp, r, 3, 3, 1, 0 if circ else pad, Cout, bias=b, in_aff=cur_aff, relu=1,
                                    stats=bn and self.training)
                 aff = None
                 bnrec = None
@@ -442,7 +518,7 @@ class UNetPlan:
                                            scale=scale.data_ptr(), shift=shift.data_ptr(), C=Cout, eps=BN_EPS))
                     aff = (scale, shift)
                     bnrec = (gamma, mean, invstd, bname)
-                convs.append(dict(w=w, wname=wname, inp=cur, inp_aff=cur_aff, r=r, bn=bnrec))
+                convs.append(dict(w=w, wname=wname, inp=cur, gin=gin, inp_aff=cur_aff, r=r, bn=bnrec))
                 self.relu_out['%s.block.%d' % (prefix, d * step + 1)] = r      # (module name of the nn.ReLU: tests read its mask)
                 cur, cur_aff = r, aff
             assert cur.H == Hb and cur.W == Wb
@@ -514,9 +590,24 @@ class UNetPlan:
                                           partials=bpart.data_ptr(), M=r.M, C=Cout, lddy=g.ld, ldr=r.ld, ldo=dpre.ld,
                                           nblocks=nb, split_out=dsplit, bf16=r.bf16))
                     self._defer_sum(bwd, bpart.data_ptr(), G[cv['wname'] + '.bias'].data_ptr(), Cout, Cout, nb)
-                    self._wgrad(bwd, inp, dpre, G[cv['wname'] + '.weight'], 3, 3, 1, pad, r.H, r.W,
+                    self._wgrad(bwd, cv['gin'], dpre, G[cv['wname'] + '.weight'], 3, 3, 1, 0 if circ else pad, r.H, r.W,
                                 in_aff=cv['inp_aff'], side=side, side_buf=self._dpre_turn, d_split=dsplit)
-                    if d > 0:
+                    if circ and (d > 0 or dxin is not None):
+                        # data gradient on the framed grid, folded back onto the pixels the frame copies (see _wrap_pad)
+                        wd = self._pack_conv_dgrad(cv['w'])
+                        dzp = self._framed_grad(inp)
+                        self._conv(bwd, dpre, wd, dzp, 3, 3, 1, 2, inp.C, x_split=dsplit)
+                        if d > 0:
+                            dz = self._scratch_act('dz', N, inp.H, inp.W, Cout)
+                            self._wrap_fold(bwd, dzp, dz)
+                            fused = None
+                            g = dz
+                        else:
+                            self._wrap_fold(bwd, dzp, dxin, accumulate=1 if (do_res and not res_dgrad_last) else 0)
+                            if res_dgrad_last:
+                                dxin_part = self._conv(bwd, dout, self._pack_conv_dgrad(rw), dxin, 1, 1, 1, 0, xin.C,
+                                                       accumulate=1, stats=dxin_stats and self.FUSE_COLSUMS)
+                    elif d > 0:
                         wd = self._pack_conv_dgrad(cv['w'])
                         dz = self._scratch_act('dz', N, inp.H, inp.W, Cout)
                         prev = convs[d - 1]
@@ -584,11 +675,21 @@ class UNetPlan:
         for j, i in enumerate(reversed(range(depth - 1))):
             Ci = chans[i]
             name = 'up_path.%d' % j
-            uw_, ub_ = self.P[name + '.up.weight'], self.P[name + '.up.bias']
-            wp = self._pack_convT_fwd(uw_)
             ch, cw = up_hw[j]
             up_half = cat[i].chan_slice(0, Ci)
-            self._conv(fwd, u, wp, up_half, 1, 1, 1, 0, 4 * Ci, bias=ub_, scatter=1, Hout=ch, Wout=cw)
+            if upsample:
+                # up_mode='upsample' (unet.py:242-244): bilinear x2, then a 1x1 convolution.  Both are linear, the convolution is
+                # pointwise and the interpolation weights sum to one: conv(up(x)) = up(conv(x)) with the bias added once -- the 1x1
+                # runs on the small grid, dfl_upsample2x_fwd spreads its result into the up half of the concat buffer
+                uw_, ub_ = self.P[name + '.up.1.weight'], self.P[name + '.up.1.bias']
+                ylow = self._act(N, u.H, u.W, Ci)
+                self._conv(fwd, u, self._pack_conv_fwd(uw_), ylow, 1, 1, 1, 0, Ci, bias=ub_)
+                fwd.add(UpsampleArgs(x=ylow.ptr, y=up_half.ptr, N=N, H=u.H, W=u.W, C=Ci, ldx=ylow.ld, ldy=up_half.ld, bf16=ylow.bf16),
+                        nat.OP_UPSAMPLE_FWD)
+            else:
+                uw_, ub_ = self.P[name + '.up.weight'], self.P[name + '.up.bias']
+                wp = self._pack_convT_fwd(uw_)
+                self._conv(fwd, u, wp, up_half, 1, 1, 1, 0, 4 * Ci, bias=ub_, scatter=1, Hout=ch, Wout=cw)
             out = self._act(N, ch - shrink, cw - shrink, Ci)
             bw = block(name + '.conv_block', cat[i], out)
             up_recs.append(dict(block_bw=bw, out=out, u=u, level=i, name=name, w=uw_))
@@ -627,34 +728,53 @@ class UNetPlan:
         self.lb_layers = []
         self.eff_heads = None
         head_x, Fh = u, F
+        # Unpadded (padding=False) the landmark block's valid 3x3 convolutions shrink lb against the features by lbd pixels per
+        # side; the reference crops the logits to lb (unet.py:185-187), so the heat maps come out SMALLER than the
+        # segmentation.  The head kernels then run twice: on u with the segmentation matrix alone (the full-size seg), and on
+        # [crop(u) | lb] with the widened matrices (heat maps; its soft-max output, a crop of seg, stays in a plan buffer).
+        self.split_heads = lbd > 0 and not cfg['padding']
+        hl, wl = u.H, u.W
         if lbd > 0:
-            if not cfg['padding']:
-                raise PlanError('lands_block_depth > 0 needs padding=True (unpadded, the landmark maps shrink against the '
-                                'segmentation: not implemented in the HIP path)')
             F2 = F // 2
             if F2 % (16 if self.bf16 else 4) != 0:
                 raise PlanError('lands_block_depth > 0 needs F/2 = %d channels to be a multiple of %d in this arithmetic' % (F2, 16 if self.bf16 else 4))
+            lpad = 1 if cfg['padding'] else 0
+            if not lpad:
+                hl, wl = u.H - 2 * lbd, u.W - 2 * lbd
+                if hl < 1 or wl < 1:
+                    raise PlanError('input %dx%d too small for lands_block_depth=%d without padding' % (self.H, self.W, lbd))
             Fh = F + F2
-            uw = self._act(N, u.H, u.W, Fh)
-            fwd.add(AffineCopyArgs(x=u.ptr, y=uw.ptr, N=N, H=u.H, W=u.W, C=F, ldx=u.ld, xH=u.H, xW=u.W, ldy=uw.ld, yH=u.H, yW=u.W,
-                                   bf16=u.bf16))
+            uw = self._act(N, hl, wl, Fh)
+            fwd.add(AffineCopyArgs(x=u.ptr, y=uw.ptr, N=N, H=hl, W=wl, C=F, ldx=u.ld, xH=u.H, xW=u.W, xoy=(u.H - hl) // 2, xox=(u.W - wl) // 2,
+                                   ldy=uw.ld, yH=hl, yW=wl, bf16=u.bf16))
             src = u
             for j in range(lbd):
                 wname, bname = 'lands_block.%d.weight' % j, 'lands_block.%d.bias' % j
-                dst = uw.chan_slice(F, F2) if j == lbd - 1 else self._act(N, u.H, u.W, F2)
-                self._conv(fwd, src, self._pack_conv_fwd(self.P[wname]), dst, 3, 3, 1, 1, F2, bias=self.P[bname])
-                self.lb_layers.append((src, dst, wname, bname))
+                ho_, wo_ = src.H - (0 if lpad else 2), src.W - (0 if lpad else 2)
+                dst = uw.chan_slice(F, F2) if j == lbd - 1 else self._act(N, ho_, wo_, F2)
+                gin = self._wrap_pad(fwd, src) if circ else src
+                self._conv(fwd, gin, self._pack_conv_fwd(self.P[wname]), dst, 3, 3, 1, 0 if (circ or not lpad) else 1, F2, bias=self.P[bname],
+                           Hout=ho_, Wout=wo_)
+                self.lb_layers.append((src, dst, wname, bname, gin, ho_, wo_))
                 src = dst
             self.eff_heads = dict(F=F, F2=F2, w_seg=self._new(NC * Fh).view(NC, Fh, 1, 1).zero_(),
                                   w_l1=self._new(NM * (Fh + NC)).view(NM, Fh + NC, 1, 1).zero_(),
                                   g_seg=self._new(NC * Fh).view(NC, Fh, 1, 1), g_l1=self._new(NM * (Fh + NC)).view(NM, Fh + NC, 1, 1))
-            w_seg, w_l1 = self.eff_heads['w_seg'], self.eff_heads['w_l1']
             head_x = uw
+        sm = 1 if cfg['do_soft_max'] else 0
+        self.head_fwd_seg = None
+        if self.split_heads:
+            self.head_fwd_seg = HeadFwdArgs(x=u.ptr, w_seg=self.P['seg_conv.weight'].data_ptr(), N=N, H=u.H, W=u.W, F=F, ldx=u.ld,
+                                            NC=NC, NM=0, L=0, softmax=sm, x_bf16=u.bf16)
+            fwd.add(self.head_fwd_seg, volatile=True)
+            self.seg_crop = self._new(N * NC * hl * wl)         # soft-max of the landmark call: what its backward recomputes from
+        if self.eff_heads is not None:
+            w_seg, w_l1 = self.eff_heads['w_seg'], self.eff_heads['w_l1']
         self.head_fwd = HeadFwdArgs(x=head_x.ptr, w_seg=w_seg.data_ptr(), w_l1=nat.ptr(w_l1), w_l2=nat.ptr(w_l2),
-                                    N=N, H=u.H, W=u.W, F=Fh, ldx=head_x.ld, NC=NC, NM=NM, L=L,
-                                    softmax=1 if cfg['do_soft_max'] else 0, x_bf16=u.bf16)
+                                    N=N, H=hl, W=wl, F=Fh, ldx=head_x.ld, NC=NC, NM=NM, L=L, softmax=sm, x_bf16=u.bf16)
         fwd.add(self.head_fwd, volatile=True)       # writes the caller-owned outputs: addresses change per call
         self.out_hw = (u.H, u.W)
+        self.heat_hw = (hl, wl)
 
         self._n_fwd_pack = len(self._pack_jobs)
         if not self.need_grad:
@@ -677,45 +797,57 @@ class UNetPlan:
             self.dead_params.add('downsample_convs.%d.bias' % (depth - 1))
 
         # heads
-        Fdec = F                                  # channels of the decoder output (F below: what the head kernels see)
-        F = Fh
+        Fdec = F                                  # channels of the decoder output (Fh: what the landmark head call sees)
         g_seg = self.eff_heads['g_seg'] if self.eff_heads is not None else self.G['seg_conv.weight']
         g_l1 = (self.eff_heads['g_l1'] if self.eff_heads is not None else self.G['lands_1x1.0.weight']) if L > 0 else None
-        sld = self.lib.dfl_head_scratch_ld_for(F, NC, NM, L)
-        M = u.M
-        dfeat = self._act(N, u.H, u.W, F)
-        # bf16 features of the paper's width: the head kernel takes its three weight gradients itself (include/dfl_hip.h);
-        # otherwise it leaves a per-pixel scratch row and three 1x1 weight-gradient launches follow
-        fused_head = bool(u.bf16) and F == 32 and NC <= 8 and NM <= 24 and L <= 16 and os.environ.get('DFL_HEAD_FUSED', '1') != '0'
-        self.head_bwd = HeadBwdArgs(x=head_x.ptr, w_seg=w_seg.data_ptr(), w_l1=nat.ptr(w_l1), w_l2=nat.ptr(w_l2),
-                                    dx=dfeat.ptr, N=N, H=u.H, W=u.W, F=F, ldx=head_x.ld,
-                                    lddx=dfeat.ld, NC=NC, NM=NM, L=L, softmax=1 if cfg['do_soft_max'] else 0,
-                                    scratch_ld=sld, x_bf16=u.bf16)
-        if fused_head:
-            part = self._new(4096 * nat.check(self.lib.dfl_head_wgrad_blocks(M), 'dfl_head_wgrad_blocks'))
-            self.head_bwd.wg_partial = part.data_ptr()
-            self.head_bwd.dw_seg = g_seg.data_ptr()
-            if L > 0:
-                self.head_bwd.dw_l1 = g_l1.data_ptr()
-                if w_l2 is not None:
-                    self.head_bwd.dw_l2 = (self.g_l2_eff if self.g_l2_eff is not None else self.G['lands_1x1.1.weight']).data_ptr()
-        else:
-            scratch = self._new(M * sld)
-            self.head_bwd.scratch = scratch.data_ptr()
+        g_l2 = None
+        if L > 0 and w_l2 is not None:
+            g_l2 = self.g_l2_eff if self.g_l2_eff is not None else self.G['lands_1x1.1.weight']
         if self.PACK_OVERLAP:
             bwd.wait(self.EV_PACK_DONE, stream=0)      # data-gradient weight layouts are packed on the side stream
-        bwd.add(self.head_bwd, volatile=True)       # reads the caller-owned seg / dseg / dheat
-        if not fused_head:
-            off = [self.lib.dfl_head_scratch_off_for(F, NC, NM, L, k) for k in range(5)]
 
-            def sact(o, c):
-                return Act(scratch, scratch.data_ptr() + 4 * o, sld, N, u.H, u.W, c)
-            self._wgrad(bwd, sact(off[0], F), sact(off[1], NC), g_seg, 1, 1, 1, 0, u.H, u.W)
-            if L > 0:
-                self._wgrad(bwd, sact(off[0], F + NC), sact(off[2], NM), g_l1, 1, 1, 1, 0, u.H, u.W)
-                if w_l2 is not None:
-                    self._wgrad(bwd, sact(off[3], NM), sact(off[4], L),
-                                self.g_l2_eff if self.g_l2_eff is not None else self.G['lands_1x1.1.weight'], 1, 1, 1, 0, u.H, u.W)
+        def head_backward(x_act, Fx, H_, W_, ws, w1, w2, nm, nl, gs, g1, g2):
+            """HeadBwdArgs + its weight gradients on x_act [N,H_,W_,Fx]; returns (args, dx Act)."""
+            sld = self.lib.dfl_head_scratch_ld_for(Fx, NC, nm, nl)
+            M_ = N * H_ * W_
+            dx = self._act(N, H_, W_, Fx)
+            fused_head = bool(x_act.bf16) and Fx == 32 and NC <= 8 and nm <= 24 and nl <= 16 and os.environ.get('DFL_HEAD_FUSED', '1') != '0'
+            hb = HeadBwdArgs(x=x_act.ptr, w_seg=ws.data_ptr(), w_l1=nat.ptr(w1), w_l2=nat.ptr(w2), dx=dx.ptr, N=N, H=H_, W=W_, F=Fx,
+                             ldx=x_act.ld, lddx=dx.ld, NC=NC, NM=nm, L=nl, softmax=1 if cfg['do_soft_max'] else 0, scratch_ld=sld,
+                             x_bf16=x_act.bf16)
+            # bf16 features of the paper's width: the head kernel takes its three weight gradients itself (include/dfl_hip.h);
+            # otherwise it leaves a per-pixel scratch row and three 1x1 weight-gradient launches follow
+            if fused_head:
+                part = self._new(4096 * nat.check(self.lib.dfl_head_wgrad_blocks(M_), 'dfl_head_wgrad_blocks'))
+                hb.wg_partial = part.data_ptr()
+                hb.dw_seg = gs.data_ptr()
+                if nl > 0:
+                    hb.dw_l1 = g1.data_ptr()
+                    if w2 is not None:
+                        hb.dw_l2 = g2.data_ptr()
+            else:
+                scratch = self._new(M_ * sld)
+                hb.scratch = scratch.data_ptr()
+            bwd.add(hb, volatile=True)                 # reads the caller-owned seg / dseg / dheat
+            if not fused_head:
+                off = [self.lib.dfl_head_scratch_off_for(Fx, NC, nm, nl, k) for k in range(5)]
+
+                def sact(o, c):
+                    return Act(scratch, scratch.data_ptr() + 4 * o, sld, N, H_, W_, c)
+                self._wgrad(bwd, sact(off[0], Fx), sact(off[1], NC), gs, 1, 1, 1, 0, H_, W_)
+                if nl > 0:
+                    self._wgrad(bwd, sact(off[0], Fx + NC), sact(off[2], nm), g1, 1, 1, 1, 0, H_, W_)
+                    if w2 is not None:
+                        self._wgrad(bwd, sact(off[3], nm), sact(off[4], nl), g2, 1, 1, 1, 0, H_, W_)
+            return hb, dx
+
+        hl, wl = self.heat_hw
+        self.head_bwd_seg = None
+        if self.split_heads:
+            self.g_seg_full = self._new(NC * Fdec).view(NC, Fdec, 1, 1)
+            self.head_bwd_seg, dfeat_a = head_backward(u, Fdec, u.H, u.W, self.P['seg_conv.weight'], None, None, 0, 0, self.g_seg_full, None, None)
+            self.dseg_zero = self._new(N * NC * hl * wl).zero_()
+        self.head_bwd, dfeat = head_backward(head_x, Fh, hl, wl, w_seg, w_l1, w_l2, NM, L, g_seg, g_l1, g_l2)
 
         # up path, last block first
         # Column sums ride on the kernels that produce the tensors: the conv that completes dcat leaves sum(dy) (the
@@ -725,19 +857,30 @@ class UNetPlan:
         if self.lb_layers:
             # backward of the landmark block: the lb columns of dx through the 3x3 convolutions (bias sums, weight gradients,
             # data gradients), the first one's data gradient added onto the u columns, which then enter the decoder
-            dout = dfeat.chan_slice(0, Fdec)
+            lpad = 1 if cfg['padding'] else 0
+            if self.split_heads:
+                # the u columns of the landmark call's dx belong to the centre window of the full-size feature gradient
+                dout = dfeat_a
+                src_u = dfeat.chan_slice(0, Fdec)
+                bwd.add(AffineCopyArgs(x=src_u.ptr, y=dout.ptr, N=N, H=hl, W=wl, C=Fdec, ldx=src_u.ld, xH=hl, xW=wl, ldy=dout.ld,
+                                       yH=u.H, yW=u.W, yoy=(u.H - hl) // 2, yox=(u.W - wl) // 2, accumulate=1, bf16=dout.bf16))
+            else:
+                dout = dfeat.chan_slice(0, Fdec)
             d = dfeat.chan_slice(Fdec, Fh - Fdec)
             for j in reversed(range(len(self.lb_layers))):
-                src, dst, wname, bname = self.lb_layers[j]
+                src, dst, wname, bname, gin, ho_, wo_ = self.lb_layers[j]
                 self._colsum(bwd, d, self.G[bname])
-                self._wgrad(bwd, src, d, self.G[wname], 3, 3, 1, 1, u.H, u.W)
+                self._wgrad(bwd, gin, d, self.G[wname], 3, 3, 1, 0 if (circ or not lpad) else 1, ho_, wo_)
                 wd = self._pack_conv_dgrad(self.P[wname])
-                if j == 0:
-                    self._conv(bwd, d, wd, dout, 3, 3, 1, 1, Fdec, accumulate=1)
+                tgt = dout if j == 0 else self._act(N, src.H, src.W, Fh - Fdec)
+                if circ:
+                    dzp = self._framed_grad(src)
+                    self._conv(bwd, d, wd, dzp, 3, 3, 1, 2, src.C)
+                    self._wrap_fold(bwd, dzp, tgt, accumulate=1 if j == 0 else 0)
                 else:
-                    dprev = self._act(N, u.H, u.W, Fh - Fdec)
-                    self._conv(bwd, d, wd, dprev, 3, 3, 1, 1, Fh - Fdec)
-                    d = dprev
+                    self._conv(bwd, d, wd, tgt, 3, 3, 1, 1 if lpad else 2, src.C, accumulate=1 if j == 0 else 0)
+                if j > 0:
+                    d = tgt
         F = Fdec
         dout_sums = None
         for j in reversed(range(len(up_recs))):
@@ -747,17 +890,27 @@ class UNetPlan:
             st = rec['block_bw'](dout, dcat[i], fused_in=dout_sums, dxin_stats=True)
             dy = dcat[i].chan_slice(0, Ci)                    # gradient of the transposed-conv output
             uin = rec['u']
+            bias_name = rec['name'] + ('.up.1.bias' if upsample else '.up.bias')
             if st is not None:                                # rows of (sum v, sum v^2) over all 2*Ci columns of dcat
-                self._defer_sum(bwd, st[0].data_ptr(), self.G[rec['name'] + '.up.bias'].data_ptr(), Ci, 4 * Ci, st[1])
+                self._defer_sum(bwd, st[0].data_ptr(), self.G[bias_name].data_ptr(), Ci, 4 * Ci, st[1])
             else:
-                self._colsum(bwd, dy, self.G[rec['name'] + '.up.bias'])
-            # dW[ci][co][ab] = sum x[i,j][ci] * dy[2i+a,2j+b][co]
-            self._wgrad(bwd, dy, uin, self.G[rec['name'] + '.up.weight'], 2, 2, 2, 0, uin.H, uin.W)
-            wd = self._pack_convT_dgrad(rec['w'])
+                self._colsum(bwd, dy, self.G[bias_name])          # (upsample: the adjoint preserves column sums)
             du = self._act(N, uin.H, uin.W, uin.C)
             consumer = up_recs[j - 1]['block_bw'] if j > 0 else pending[depth - 1]['block_bw']
             r_last = consumer.last_r if self.FUSE_COLSUMS else None
-            dout_sums = self._conv(bwd, dy, wd, du, 2, 2, 2, 0, uin.C, stats=r_last is not None, stat_other=r_last)
+            if upsample:
+                # gradient of the small-grid 1x1 result = adjoint of the interpolation applied to dy; then an ordinary 1x1 layer
+                dylow = self._act(N, uin.H, uin.W, Ci)
+                bwd.add(UpsampleArgs(x=dylow.ptr, y=dy.ptr, N=N, H=uin.H, W=uin.W, C=Ci, ldx=dylow.ld, ldy=dy.ld, bf16=dy.bf16),
+                        nat.OP_UPSAMPLE_BWD)
+                self._wgrad(bwd, uin, dylow, self.G[rec['name'] + '.up.1.weight'], 1, 1, 1, 0, uin.H, uin.W)
+                dout_sums = self._conv(bwd, dylow, self._pack_conv_dgrad(rec['w']), du, 1, 1, 1, 0, uin.C,
+                                       stats=r_last is not None, stat_other=r_last)
+            else:
+                # dW[ci][co][ab] = sum x[i,j][ci] * dy[2i+a,2j+b][co]
+                self._wgrad(bwd, dy, uin, self.G[rec['name'] + '.up.weight'], 2, 2, 2, 0, uin.H, uin.W)
+                wd = self._pack_convT_dgrad(rec['w'])
+                dout_sums = self._conv(bwd, dy, wd, du, 2, 2, 2, 0, uin.C, stats=r_last is not None, stat_other=r_last)
             dout = du
         # down path, deepest block first
         for i in reversed(range(depth)):
@@ -802,6 +955,7 @@ class UNetPlan:
                 pending[i - 1]['dnxt_sums'] = st
         self._flush_sums(bwd)
         self._side_join(bwd)
+        self._order_pack_jobs()
         self._finish_pack()
         # index of the last backward op that writes each parameter gradient (data-parallel bucket scheduling)
         by_ptr = {self.G[k].data_ptr(): k for k in self.grad_names}
@@ -847,7 +1001,10 @@ class UNetPlan:
         if self.eff_heads is not None and self.need_grad:
             e = self.eff_heads
             F, F2 = e['F'], e['F2']
-            self.G['seg_conv.weight'].copy_(e['g_seg'][:, :F])
+            if self.split_heads:                   # full-size segmentation call + the logits' path into the landmark call
+                torch.add(self.g_seg_full, e['g_seg'][:, :F], out=self.G['seg_conv.weight'])
+            else:
+                self.G['seg_conv.weight'].copy_(e['g_seg'][:, :F])
             g1 = self.G['lands_1x1.0.weight']
             g1[:, :F2].copy_(e['g_l1'][:, F:F + F2])
             g1[:, F2:].copy_(e['g_l1'][:, F + F2:])
@@ -874,9 +1031,28 @@ class UNetPlan:
     def new_outputs(self):
         N = self.N
         h, w = self.out_hw
+        hl, wl = self.heat_hw
         seg = torch.empty((N, self.NC, h, w), dtype=torch.float32, device=self.dev)
-        heat = torch.empty((N, self.L, h, w), dtype=torch.float32, device=self.dev) if self.L > 0 else None
+        heat = torch.empty((N, self.L, hl, wl), dtype=torch.float32, device=self.dev) if self.L > 0 else None
         return seg, heat
+
+    def bind_outputs(self, seg, heat):
+        """Point the head op(s) of the forward program at the caller-owned output tensors."""
+        if self.split_heads:
+            self.head_fwd_seg.seg = seg.data_ptr()
+            self.head_fwd.seg = self.seg_crop.data_ptr()
+        else:
+            self.head_fwd.seg = seg.data_ptr()
+        self.head_fwd.heat = nat.ptr(heat)
+
+    def bind_grads(self, seg, dseg, dheat):
+        """Point the head op(s) of the backward program at the forward's seg and the incoming gradients (dheat may be None)."""
+        if self.split_heads:
+            self.head_bwd_seg.seg, self.head_bwd_seg.dseg = seg.data_ptr(), dseg.data_ptr()
+            self.head_bwd.seg, self.head_bwd.dseg = self.seg_crop.data_ptr(), self.dseg_zero.data_ptr()
+        else:
+            self.head_bwd.seg, self.head_bwd.dseg = seg.data_ptr(), dseg.data_ptr()
+        self.head_bwd.dheat = nat.ptr(dheat)
 
     def grads(self):
         return [None if k in self.dead_params else self.G[k] for k in self.grad_names]

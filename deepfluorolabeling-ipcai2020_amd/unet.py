@@ -53,9 +53,10 @@ class UNetUpBlock(nn.Module):
 
     def __init__(self, in_size, out_size, up_mode, padding, batch_norm, pad_mode, do_res, block_depth):
         super().__init__()
-        if up_mode != 'upconv':
-            raise NotImplementedError("up_mode='upsample' is not implemented in the HIP path (no reference CLI selects it)")
-        self.up = nn.ConvTranspose2d(in_size, out_size, kernel_size=2, stride=2)
+        if up_mode == 'upconv':
+            self.up = nn.ConvTranspose2d(in_size, out_size, kernel_size=2, stride=2)
+        else:                                       # reference unet.py:242-244; keys up.1.weight / up.1.bias
+            self.up = nn.Sequential(nn.Upsample(mode='bilinear', scale_factor=2), nn.Conv2d(in_size, out_size, kernel_size=1))
         self.conv_block = UNetConvBlock(in_size, out_size, padding, batch_norm, pad_mode, do_res, block_depth)
 
     forward = _no_forward('UNetUpBlock')
@@ -91,11 +92,9 @@ class _UNetFn(torch.autograd.Function):
         if dseg is None:
             dseg = torch.zeros_like(seg)
         dseg = dseg.contiguous()
-        hb = plan.head_bwd
-        hb.seg, hb.dseg = seg.data_ptr(), dseg.data_ptr()
         if dheat is not None:
             dheat = dheat.contiguous()
-        hb.dheat = nat.ptr(dheat)
+        plan.bind_grads(seg, dseg, dheat)
         stream = torch.cuda.current_stream().cuda_stream
         params = net._param_list
         # a .grad that still aliases this plan's arena (no zero_grad since the last backward) would be overwritten by
@@ -130,11 +129,9 @@ class UNet(nn.Module):
         super().__init__()
         if up_mode not in ('upconv', 'upsample'):
             raise AssertionError("up_mode must be 'upconv' or 'upsample'")
-        if pad_mode != 'zeros':
-            raise NotImplementedError("pad_mode='%s' is not implemented in the HIP path (no reference CLI selects it)" % pad_mode)
-        if num_lands > 0 and lands_block_depth > 0 and not padding:
-            raise NotImplementedError('lands_block_depth > 0 needs padding=True in the HIP path (unpadded, the landmark maps '
-                                      'shrink against the segmentation; no reference CLI selects it)')
+        if pad_mode not in ('zeros', 'circular'):
+            raise NotImplementedError("pad_mode='%s' is not implemented in the HIP path (the reference's flag values: 'zeros', "
+                                      "'circular')" % pad_mode)
         if num_lands > 0 and lands_num_1x1 < 1:
             raise AssertionError('lands_num_1x1 must be positive')
         self.padding, self.pad_mode, self.depth = padding, pad_mode, depth
@@ -142,7 +139,7 @@ class UNet(nn.Module):
         self._cfg = dict(in_channels=in_channels, n_classes=n_classes, depth=depth, wf=wf, padding=bool(padding),
                          batch_norm=bool(batch_norm), max_pool=bool(max_pool), num_lands=num_lands, do_res=bool(do_res),
                          block_depth=block_depth, lands_num_1x1=lands_num_1x1, lands_block_depth=lands_block_depth,
-                         do_soft_max=bool(do_soft_max))
+                         do_soft_max=bool(do_soft_max), pad_mode=pad_mode, up_mode=up_mode)
 
         # registration order: downsample_convs is assigned before down_path (reference unet.py:80-85)
         self.downsample_convs = None if max_pool else nn.ModuleList()
@@ -168,9 +165,9 @@ class UNet(nn.Module):
             lands_ch = ch
             if lands_block_depth > 0:             # reference unet.py:118-137: bias-only 3x3 convolutions, no non-linearity
                 lands_ch = ch // 2
-                convs = [nn.Conv2d(ch, lands_ch, kernel_size=3, padding=int(padding))]
+                convs = [nn.Conv2d(ch, lands_ch, kernel_size=3, padding=int(padding), padding_mode=pad_mode)]
                 for _ in range(lands_block_depth - 1):
-                    convs.append(nn.Conv2d(lands_ch, lands_ch, kernel_size=3, padding=int(padding)))
+                    convs.append(nn.Conv2d(lands_ch, lands_ch, kernel_size=3, padding=int(padding), padding_mode=pad_mode))
                 self.lands_block = nn.Sequential(*convs)
             mid = num_lands + n_classes if lands_num_1x1 > 1 else num_lands
             heads = [nn.Conv2d(lands_ch + n_classes, mid, kernel_size=1, bias=False)]
@@ -314,8 +311,7 @@ class UNet(nn.Module):
         else:
             plan.x_in.copy_(x.permute(0, 2, 3, 1).reshape(-1))
         seg, heat = plan.new_outputs()
-        plan.head_fwd.seg = seg.data_ptr()
-        plan.head_fwd.heat = nat.ptr(heat)
+        plan.bind_outputs(seg, heat)
         self.run_program(plan, plan.fwd, stream)
         return seg, heat
 

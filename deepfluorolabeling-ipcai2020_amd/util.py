@@ -199,7 +199,9 @@ def _squeeze_heats(heats):
 def test_dataset(ds, net, dev=None, num_lands=0, shard=None):
     """Eval-mode per-image loss; returns (mean, std) over the data set (util.py:116-165).  Leaves the net in eval mode.
     ``shard=(rank, world)`` (data-parallel training): every rank evaluates the images i = rank mod world and the
-    per-image losses are summed over ranks, so all ranks return the same numbers as a single-process call."""
+    per-image losses are summed over ranks, so all ranks return the same numbers -- those of a single-process call on the same
+    model.  With BatchNorm the replicas' running statistics must be made equal first (parallel.DataParallel.sync_buffers;
+    train.py does it before every validation): they follow each rank's own shards during training."""
     dev = dev if dev is not None else next(net.parameters()).device
     crit = DiceAndHeatMapLoss2D(skip_bg=False) if num_lands > 0 else DiceLoss2D(skip_bg=False)
     rank, world = shard if shard is not None else (0, 1)

@@ -280,6 +280,19 @@ typedef struct {
 } dfl_affine_copy_args;
 int dfl_affine_copy(const dfl_affine_copy_args* a, dfl_stream_t stream);
 
+/* Bilinear x2 up-sampling and its adjoint (up_mode='upsample': nn.Upsample(mode='bilinear', scale_factor=2) in front of a 1x1
+ * convolution, train_test_code/unet.py:242-244; align_corners=False as torch's default).  fwd: y[N,2H,2W,C] = up(x[N,H,W,C]).
+ * bwd: x (+)= up^T(y): x receives the gradient of the small tensor from y, the gradient of the large one. */
+typedef struct {
+  const void* x; void* y;       /* NHWC with pixel strides ldx / ldy (elements); fp32 or bf16 (both the same) */
+  int32_t N, H, W, C;           /* SMALL grid: x is H x W, y is 2H x 2W */
+  int32_t ldx, ldy;
+  int32_t bf16;                 /* 1: bf16 tensors (C % 8 == 0, ld % 8 == 0) */
+  int32_t accumulate;           /* bwd only: add to x instead of overwriting it */
+} dfl_upsample_args;
+int dfl_upsample2x_fwd(const dfl_upsample_args* a, dfl_stream_t stream);
+int dfl_upsample2x_bwd(const dfl_upsample_args* a, dfl_stream_t stream);
+
 /* F.max_pool2d(x, 2) (unet.py:169) and its backward (first maximum in scan order wins; gradient is ADDED to dx). */
 typedef struct {
   const float* x; float* y;     /* fwd: x -> y.  bwd: x = saved input, y = dy (read), dx accumulated */
@@ -488,7 +501,7 @@ typedef enum {
   DFL_OP_BN_EVAL = 6, DFL_OP_COLSTATS = 7, DFL_OP_BN_BWD_FINALIZE = 8, DFL_OP_BN_RELU_BWD = 9,
   DFL_OP_REDUCE_PARTIALS = 10, DFL_OP_AFFINE_COPY = 11, DFL_OP_POOL_FWD = 12, DFL_OP_POOL_BWD = 13,
   DFL_OP_HEAD_FWD = 14, DFL_OP_HEAD_BWD = 15, DFL_OP_MEMSET = 16, DFL_OP_REDUCE_BATCH = 17,
-  DFL_OP_RECORD = 18, DFL_OP_WAIT = 19
+  DFL_OP_RECORD = 18, DFL_OP_WAIT = 19, DFL_OP_UPSAMPLE_FWD = 20, DFL_OP_UPSAMPLE_BWD = 21
 } dfl_op_kind;
 
 typedef struct { const float* src; float* dst; int64_t n; int32_t splits; int32_t T; } dfl_sum_partials_args;

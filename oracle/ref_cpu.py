@@ -237,6 +237,51 @@ def ensemble_reduce(seg_list, heat_list, orig_shape):
 
 
 # --------------------------------------------------------------------------------------
+# Validation loops (train_test_code/util.py:116-165 and :167-241)
+# --------------------------------------------------------------------------------------
+def validation_loss(net, items, num_lands):
+    """util.test_dataset: eval mode, batch 1, per-image Dice (+ NCC with the FIXED weight 0.5, util.py:126-129 -- SURVEY D11)
+    on the centre-cropped outputs; returns (mean, std) with torch.std's unbiased estimator.  items: (proj [1,Hp,Wp],
+    mask [C,H,W], lands, heat [L,1,H,W]) tuples."""
+    losses = torch.zeros(len(items))
+    with torch.no_grad():
+        net.eval()
+        for i, (p, m, _, h) in enumerate(items):
+            out = net(p.unsqueeze(0))
+            m = m.unsqueeze(0)
+            if num_lands > 0:
+                h = h.view(1, h.shape[0], h.shape[-2], h.shape[-1])
+                losses[i] = dice_and_heatmap_loss_2d((center_crop(out[0], m.shape), center_crop(out[1], h.shape)), (m, h),
+                                                     skip_bg=False, heatmap_wgt=0.5).item()
+            else:
+                seg = out[0] if isinstance(out, tuple) else out
+                losses[i] = dice_loss_2d(center_crop(seg, m.shape), m, skip_bg=False).item()
+    return torch.mean(losses), torch.std(losses)
+
+
+def validation_loss_ensemble(nets, items, num_lands, dice_only=False):
+    """util.test_dataset_ensemble: the loss of the AVERAGED cropped soft-max (and averaged RAW heat maps -- no min-max
+    normalisation here, unlike seg_dataset_ensemble) per image; Dice only when dice_only or there are no landmarks."""
+    losses = torch.zeros(len(items))
+    use_heat = (not dice_only) and num_lands > 0
+    with torch.no_grad():
+        for n in nets:
+            n.eval()
+        for i, (p, m, _, h) in enumerate(items):
+            m = m.unsqueeze(0)
+            outs = [n(p.unsqueeze(0)) for n in nets]
+            segs = [o[0] if isinstance(o, tuple) else o for o in outs]
+            avg_seg = sum(center_crop(s_, m.shape) for s_ in segs) / len(nets)
+            if use_heat:
+                h = h.view(1, h.shape[0], h.shape[-2], h.shape[-1])
+                avg_heat = sum(center_crop(o[1], h.shape) for o in outs) / len(nets)
+                losses[i] = dice_and_heatmap_loss_2d((avg_seg, avg_heat), (m, h), skip_bg=False, heatmap_wgt=0.5).item()
+            else:
+                losses[i] = dice_loss_2d(avg_seg, m, skip_bg=False).item()
+    return torch.mean(losses), torch.std(losses)
+
+
+# --------------------------------------------------------------------------------------
 # SGDR schedule (train_test_code/warm_restarts_lr.py:14-63) as a pure function trace
 # --------------------------------------------------------------------------------------
 def warm_restart_lr_trace(base_lr, period, growth, lr_min, n_epochs, intra_steps):

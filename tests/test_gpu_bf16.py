@@ -21,7 +21,8 @@ from dfl_amd import _native as nat
 from conftest import PAPER_CFGS
 from oracle import ref_cpu as R
 import noise_floor as NF
-from test_gpu_unet import oracle64, oracle_run, label_mask
+import problems as PR
+from gpu_common import oracle64, label_mask, hip_net, hip_step
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
@@ -576,30 +577,13 @@ def _eps4():
 def test_network_bf16_storage_against_fp64_oracle(cfgname):
     """Paper presets, batch 2: forward deviation at the bf16 level, labels identical outside the margin that deviation
     implies, every gradient tensor inside its noise-floor bar at the mode's own measured convolution error."""
-    seed, cfg = PAPER_CFGS[cfgname]
-    torch.manual_seed(seed)
-    onet = R.OracleUNet(**cfg)
-    net = dfl_amd.UNet(**cfg)
-    net.load_state_dict(onet.state_dict())
-    net = net.to(DEV).train()
-    gen = torch.Generator().manual_seed(seed + 1)
-    x = torch.randn(2, 1, 192, 192, generator=gen)
-    lab = torch.randint(0, 7, (2, 184, 184), generator=gen)
-    tseg = R.one_hot_masks(lab, 7)
-    nl = cfg['num_lands']
-    theat = torch.rand(2, 14, 184, 184, generator=gen) * 0.02 if nl > 0 else None
-    out = net(x.to(DEV))
-    seg = out[0] if nl > 0 else out
-    if nl > 0:
-        loss = dfl_amd.DiceAndHeatMapLoss2D(skip_bg=False, heatmap_wgt=0.5)(
-            (dfl_amd.center_crop(seg, tseg.shape), dfl_amd.center_crop(out[1], theat.shape)), (tseg.to(DEV), theat.to(DEV)))
-    else:
-        loss = dfl_amd.DiceLoss2D(skip_bg=False)(dfl_amd.center_crop(seg, tseg.shape), tseg.to(DEV))
-    loss.backward()
-    plan = [p for ps in net._plans.values() for p in ps][0]
-    assert plan.bf16 and plan.feat.t.dtype == torch.bfloat16, 'the recorded program must hold bf16 activations'
     torch.set_num_threads(max(torch.get_num_threads(), 32))
-    gf = NF.GradientFloor(oracle64(cfg, onet.state_dict()), oracle_run(x, tseg, theat), seeds=(1, 2, 3))
+    gf = NF.cached_check('paper__%s__b2' % cfgname, lambda: PR.paper(cfgname, 2))
+    pr = gf.problem
+    net = hip_net(pr)
+    out, seg, loss = hip_step(pr, net)
+    plan = NF.train_plan(net)
+    assert plan.bf16 and plan.feat.t.dtype == torch.bfloat16, 'the recorded program must hold bf16 activations'
     dev = float((seg.detach().double().cpu() - gf.out).abs().max())
     assert dev < 5e-2, 'soft-max deviation %.3e from fp64' % dev
     assert dev > 1e-5, 'the bf16 storage mode does not seem to be in effect'
@@ -607,8 +591,10 @@ def test_network_bf16_storage_against_fp64_oracle(cfgname):
     sure = (top2[:, 0] - top2[:, 1]) > 2.5 * dev
     assert float(sure.float().mean()) > 0.5
     assert bool((seg.detach().argmax(1).cpu() == gf.out.argmax(1))[sure].all())
-    worst, whole, eps_eff = gf.check({k: p.grad for k, p in net.named_parameters()}, seg, _eps4(), cfgname + ' bf16s ')
-    print('%s bf16 storage: conv noise %.2e, whole-gradient error %.3e, worst per-tensor error / bar %.2f' % (cfgname, eps_eff, whole, worst))
+    res = gf.check(net, seg, _eps4(), cfgname + ' bf16s ')
+    print('%s bf16 storage: conv noise %.2e, whole-gradient error %.3e, worst per-tensor error / bar %.2f, decisions forced %d ReLU / %d pool '
+          '(of %d), largest margin %.2e' % (cfgname, res['eps_eff'], res['whole'], res['worst'], res['info']['relu_flips'],
+                                            res['info']['pool_flips'], res['info']['relu_total'], res['info']['max_margin']))
 
 
 def test_eval_and_inference_graph_bf16_storage():

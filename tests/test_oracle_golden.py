@@ -214,3 +214,35 @@ def test_landmark_extraction():
     assert found.any() and (~found).any()                         # both outcomes are covered ...
     assert float((ncc2 - 0.9).abs().min()) > 2e-4                 # ... and none sits on the 0.9 threshold (fp32 noise ~1e-6)
     assert (g['rc_masked'] != g['rc_plain']).any()                # the mask changes some answers
+
+
+VAL_BASE = dict(n_classes=7, depth=3, wf=2, batch_norm=True, padding=True, max_pool=False, do_res=True, block_depth=2)
+
+
+def validation_items(g):
+    t = lambda a: torch.from_numpy(np.asarray(a))
+    return [(t(g['x'][i]), t(g['masks'][i]), t(g['lands'][i]), t(g['heats'][i])) for i in range(g['x'].shape[0])]
+
+
+def validation_nets(g, tag, num_lands, n, make):
+    nets = []
+    for i in range(n):
+        net = make(**dict(VAL_BASE, num_lands=num_lands))
+        pre = '%s_net%d/' % (tag, i)
+        net.load_state_dict({k[len(pre):]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith(pre)})
+        nets.append(net)
+    return nets
+
+
+def test_validation_loops():
+    """util.test_dataset / util.test_dataset_ensemble (util.py:116-241) of the reference, run by tools/gen_golden.py: the
+    oracle's restatement returns the same (mean, std) -- with and without landmarks, both dice_only values."""
+    g = load_golden('validation')
+    items = validation_items(g)
+    n14 = validation_nets(g, 'l14', 14, 3, R.OracleUNet)
+    n0 = validation_nets(g, 'l0', 0, 2, R.OracleUNet)
+    got = {'single_l14': R.validation_loss(n14[0], items, 14), 'single_l0': R.validation_loss(n0[0], items, 0),
+           'ens_l14': R.validation_loss_ensemble(n14, items, 14), 'ens_l14_dice_only': R.validation_loss_ensemble(n14, items, 14, dice_only=True),
+           'ens_l0': R.validation_loss_ensemble(n0, items, 0)}
+    for k, (m, s) in got.items():
+        np.testing.assert_allclose([float(m), float(s)], g['result/' + k], rtol=0, atol=2e-6, err_msg=k)

@@ -376,6 +376,64 @@ def fixture_ensemble(unet, util):
     print('ensemble labels hist', np.bincount(res['nn_segs'].ravel(), minlength=7))
 
 
+def fixture_validation(unet, util):
+    """util.test_dataset (util.py:116-165) and util.test_dataset_ensemble (util.py:167-241) of the REFERENCE on seeded tiny
+    nets and four toy images: (mean, std) of the per-image losses with and without landmarks (D11: the fixed 0.5 heat-map
+    weight of the validation loss) and both dice_only values."""
+    base = dict(n_classes=7, depth=3, wf=2, batch_norm=True, padding=True, max_pool=False, do_res=True, block_depth=2)
+
+    def make(seed, num_lands):
+        torch.manual_seed(seed)
+        n = unet.UNet(num_lands=num_lands, **base)
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            for b in n.buffers():
+                if b.dtype.is_floating_point:
+                    b.add_(0.2 * torch.rand(b.shape, generator=g))
+        return n
+    nets14 = [make(s, 14) for s in (31, 32, 33)]
+    nets0 = [make(s, 0) for s in (41, 42)]
+    H = W = 28
+    projs, segs, lands = toy_ellipses(4, H, W, seed=77)
+    g = torch.Generator().manual_seed(78)
+    x = torch.nn.functional.pad(projs[:, None], (2, 2, 2, 2), mode='reflect')
+    x = (x - x.mean(dim=(1, 2, 3), keepdim=True)) / x.std(dim=(1, 2, 3), keepdim=True)
+    masks = torch.stack([(segs == c) for c in range(7)], 1).float()
+    Y, X = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing='ij')
+    heats = torch.zeros(4, 14, 1, H, W)
+    for i in range(4):
+        for l in range(14):
+            cx, cy = float(lands[i, 0, l]), float(lands[i, 1, l])
+            if 0 <= cx <= W - 1 and 0 <= cy <= H - 1:
+                heats[i, l, 0] = torch.exp(((X - cx) ** 2 + (Y - cy) ** 2) / (-2 * 2.5 * 2.5)) / (2 * math.pi * 2.5 * 2.5)
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 4
+
+        def __getitem__(self, i):
+            return (x[i], masks[i], lands[i], heats[i])
+
+    res = {'x': x.numpy(), 'masks': masks.numpy(), 'lands': lands.numpy(), 'heats': heats.numpy()}
+    for tag, nets in (('l14', nets14), ('l0', nets0)):
+        for i, n in enumerate(nets):
+            for k, v in n.state_dict().items():
+                res['%s_net%d/%s' % (tag, i, k)] = v.numpy()
+    ds = DS()
+    cpu = torch.device('cpu')       # (with dev=None the reference skips the [B,L,1,H,W] -> [B,L,H,W] view of the heat targets)
+    out = {
+        'single_l14': util.test_dataset(ds, nets14[0], cpu, 14),
+        'single_l0': util.test_dataset(ds, nets0[0], cpu, 0),
+        'ens_l14': util.test_dataset_ensemble(ds, nets14, cpu, 14, dice_only=False),
+        'ens_l14_dice_only': util.test_dataset_ensemble(ds, nets14, cpu, 14, dice_only=True),
+        'ens_l0': util.test_dataset_ensemble(ds, nets0, cpu, 0),
+    }
+    for k, (m, sd) in out.items():
+        res['result/' + k] = np.array([float(m), float(sd)], dtype=np.float64)
+        print('validation %-20s mean %.6f std %.6f' % (k, float(m), float(sd)))
+    np.savez_compressed(os.path.join(OUT, 'validation.npz'), **res)
+
+
 def fixture_trajectory(unet, dice, util):
     """Short SGD trajectory (train.py:405-430 wiring) on the toy-ellipses set, tiny-ish net."""
     import torch.optim as optim
@@ -581,6 +639,9 @@ def main():
         fixture_plateau(unet, dice, util)
         fixture_plateau(unet, dice, util, wf=4, out_name='plateau_wf4.npz')     # 16..64 channels: the bf16 storage mode's minimum
         return
+    if '--only-validation' in sys.argv:
+        fixture_validation(unet, util)
+        return
     if '--only-est-lands' in sys.argv:
         sys.argv.remove('--only-est-lands')
         fixture_est_lands(util)
@@ -602,6 +663,7 @@ def main():
     fixture_sched(wr)
     fixture_dataset(dataset)
     fixture_ensemble(unet, util)
+    fixture_validation(unet, util)
     fixture_trajectory(unet, dice, util)
     fixture_plateau(unet, dice, util)
     fixture_plateau(unet, dice, util, wf=4, out_name='plateau_wf4.npz')

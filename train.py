@@ -328,13 +328,19 @@ class Trainer:
                 self.sched.load_state_dict(resume['scheduler-state-dict'])
 
     # ------------------------------------------------------------------------------------------- one epoch
-    def _mean_over_ranks(self, value):
-        if self.world == 1:
-            return value
+    def _flush_rank_losses(self):
+        """Data parallel: the per-rank minibatch losses of the last report window, kept on the device, are averaged over the
+        ranks with ONE collective and read with one copy -- not one all-reduce + host synchronisation per step."""
+        if not self._rank_losses:
+            return
         import torch.distributed as dist
-        t = torch.tensor([value], dtype=torch.float64, device=self.dev if dist.get_backend() == 'nccl' else 'cpu')
+        t = torch.stack([v.detach().reshape(()).to(torch.float64) for v in self._rank_losses])
+        self._rank_losses = []
+        if dist.get_backend() != 'nccl':
+            t = t.cpu()
         dist.all_reduce(t)
-        return float(t.item()) / self.world
+        for value in (t / self.world).tolist():          # the loss of each global minibatch (mean of equal shards)
+            self._account(value)
 
     def train_epoch(self):
         c, net, opt = self.cfg, self.net, self.optimizer
@@ -346,6 +352,8 @@ class Trainer:
         seen = steps = 0
         self._acc = [0.0, 0, 0.0, 0, report_every]       # total, steps, window sum, window count, window length
         late = util.LateScalars(depth=0 if self.args.sync_loss else 1)   # loss values are read one step late (util.LateScalars)
+        self._rank_losses = []
+        window = max(report_every // max(c['batch-size'] * self.world, 1), 1) if self.world > 1 else 0
         for projs, masks, _, heats in self.train_ds.batches(c['batch-size'], shuffle=True, shard=(self.rank, self.world)):
             opt.zero_grad()
             out = net(projs)
@@ -362,11 +370,18 @@ class Trainer:
                 self.sched.intra_epoch_step(seen / n_images)
             self.last_loss = loss.detach()
             steps += 1
+            if self.world > 1:
+                self._rank_losses.append(loss)
+                if len(self._rank_losses) >= window or self.args.sync_loss:
+                    self._flush_rank_losses()
+                continue
             value = late.push(loss)
             if value is not None:
                 self._account(value)
         for value in late.flush():
             self._account(value)
+        if self.world > 1:
+            self._flush_rank_losses()
         if steps == 0:
             raise ValueError('the training set ({} images) yields no minibatch of {} x {} ranks'.format(
                 n_images, c['batch-size'], self.world))
@@ -374,7 +389,6 @@ class Trainer:
 
     def _account(self, value):
         """One minibatch loss (train.py:430-441): log line, epoch mean, running average every 5 % of the images."""
-        value = self._mean_over_ranks(value)             # the loss of the global minibatch (mean of equal shards)
         if self.main:
             self.train_log.write(value)
         acc = self._acc
@@ -388,6 +402,11 @@ class Trainer:
 
     def validate(self):
         c = self.cfg
+        if self.dp is not None:
+            # BatchNorm running statistics follow each replica's own shards and drift apart; validation is sharded over the
+            # ranks and rank 0 writes the checkpoint, so every rank scores its images with rank 0's statistics -- the logged
+            # validation loss, the best-validation choice and the plateau scheduler then describe the model that is saved
+            self.dp.sync_buffers(src=0)
         mean, std = util.test_dataset(self.valid_ds, self.net, dev=self.dev,
                                       num_lands=0 if c['use-dice-valid'] else c['num-lands'],
                                       shard=(self.rank, self.world))
