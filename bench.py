@@ -203,6 +203,10 @@ def main():
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=16, help='images per GPU')
+    ap.add_argument('--prewarm-seconds', type=float, default=2.0,
+                    help='untimed steps run for this long BEFORE the --warmup steps: a fresh box (cold GPU clocks, cold host caches) '
+                         'runs its first few hundred milliseconds of steps up to 50 %% slower than steady state (measured: first process on a box '
+                         '7.9 ms per step, every later one 5.1; training runs for hours).  0 = off')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--no-fwd', action='store_true', help='skip the eval-forward timings (fwd_ms_per_img)')
@@ -262,6 +266,11 @@ def main():
         opt.step()
         return late.push(loss)      # train.py:430 reads the loss of every step; so do we (all of them, see the flush below)
 
+    prewarm_steps = 0
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < args.prewarm_seconds:
+        step()
+        prewarm_steps += 1
     for _ in range(args.warmup):
         step()
     late.flush()
@@ -286,7 +295,8 @@ def main():
     value = B * world * args.steps / dt
 
     roofline = None
-    extra = {'rccl_ranks': world if (multi and args.backend == 'nccl') else 0}
+    extra = {'rccl_ranks': world if (multi and args.backend == 'nccl') else 0, 'prewarm_steps': prewarm_steps,
+             'prewarm_seconds': args.prewarm_seconds}
     # host time to queue one step when the GPU is idle at its start (nothing to wait for): what a slow host adds to a step once
     # it exceeds the GPU time (8.4 ms per step observed by the driver where the kernels take 5.3)
     nh = 10
@@ -346,34 +356,27 @@ def main():
             except (ValueError, KeyError):
                 pass
         fl_all = sum(v[1] for v in groups.values())
-        # GPU time outside the two programs: weight re-layout + optimizer (opt.step() queues both) and the loss kernels
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
-        other = [0.0, 0.0, 0.0]
-        for _ in range(5):
+        # GPU time of a whole step = steps queued back to back with NO host read in between (the queue never runs dry: the host
+        # queues a step in `host_enqueue_ms_per_step`, a fraction of what the GPU needs for it), losses read at the very end
+        from dfl_amd.util import LateScalars as _LS
+        nq = 10
+        deep = _LS(depth=nq + 1)
+        torch.cuda.synchronize()
+        tq = time.perf_counter()
+        for _ in range(nq):
             opt.zero_grad()
             seg, heat = net(x)
-            torch.cuda.synchronize()
-            ev[0].record()
             loss = crit((dfl_amd.center_crop(seg, tseg.shape), dfl_amd.center_crop(heat, theat.shape)), (tseg, theat))
-            ev[1].record()
-            gl = torch.autograd.grad(loss, [seg, heat], retain_graph=True)       # the loss-gradient kernel alone
-            ev[2].record()
-            del gl
             loss.backward()
-            torch.cuda.synchronize()
-            ev[3].record()
             opt.step()
-            ev[4].record()
-            torch.cuda.synchronize()
-            other[0] += ev[0].elapsed_time(ev[1])
-            other[1] += ev[1].elapsed_time(ev[2])
-            other[2] += ev[3].elapsed_time(ev[4])
-        other = [o / 5 for o in other]
-        gpu_ms = tot_ms + sum(other)
+            deep.push(loss)
+        deep.flush()
+        torch.cuda.synchronize()
+        gpu_ms = (time.perf_counter() - tq) / nq * 1e3
         extra['kernel_time_ms_per_step'] = round(tot_ms, 3)
         extra['gpu_time_ms_per_step'] = round(gpu_ms, 3)
-        extra['gpu_time_outside_programs_ms'] = {'loss_value': round(other[0], 3), 'loss_gradient': round(other[1], 3),
-                                                 'optimizer_and_weight_relayout': round(other[2], 3)}
+        extra['gpu_time_note'] = 'kernel_time = hipEvent pairs around every op of the forward and backward programs; gpu_time = %d whole ' \
+                                 'steps (loss, optimizer, weight re-layout included) queued back to back without a host read' % nq
         extra['gpu_idle_frac'] = round(max(0.0, 1.0 - gpu_ms / ms_per_step), 4)
         extra['program_ops_per_step'] = sum(v[2] for v in groups.values())
         extra['whole_step_tflops'] = round(fl_all / (ms_per_step * 1e-3) / 1e12, 2)

@@ -77,10 +77,11 @@ def ragged(H, W, max_pool):
     g = torch.Generator().manual_seed(5)
     x = torch.randn(3, 1, H, W, generator=g)
     try:
-        with torch.no_grad():
-            ho, wo = onet(x[:1])[0].shape[-2:]
+        with torch.no_grad():            # (eval mode: a probing forward must not move the BatchNorm running statistics)
+            ho, wo = onet.eval()(x[:1])[0].shape[-2:]
     except Exception:
         return None                      # the reference architecture itself rejects this size
+    onet.train()
     tseg = torch.softmax(torch.randn(3, 5, ho - 2, wo - 2, generator=g), 1)
     theat = torch.rand(3, 6, ho - 2, wo - 2, generator=g) * 0.02
     return Problem('ragged__%dx%d__mp%d' % (H, W, int(bool(max_pool))), cfg, onet.state_dict(), x, tseg, theat)
@@ -103,7 +104,8 @@ def lands_block(lbd, padding=True):
     g = torch.Generator().manual_seed(9)
     x = torch.randn(3, 1, 72, 80, generator=g)
     with torch.no_grad():
-        so, ho = onet(x[:1])
+        so, ho = onet.eval()(x[:1])
+    onet.train()
     tseg = torch.softmax(torch.randn(3, 5, ho.shape[-2] - 4, ho.shape[-1] - 4, generator=g), 1)
     theat = torch.rand(3, 6, ho.shape[-2] - 4, ho.shape[-1] - 4, generator=g) * 0.02
     return Problem('landsblock__%d%s' % (lbd, '' if padding else '__valid'), cfg, onet.state_dict(), x, tseg, theat)

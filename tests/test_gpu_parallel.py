@@ -41,10 +41,67 @@ def test_bench_under_torchrun_one_rank_rccl():
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
            '--master-port', '29535', os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1',
-           '--no-cpu-baseline', '--no-profile', '--no-fp32-reference', '--force-dp']
+           '--no-cpu-baseline', '--no-profile', '--no-fp32-reference', '--force-dp', '--prewarm-seconds', '0']
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     import json
     line = [l for l in p.stdout.splitlines() if l.startswith('{')][-1]
     d = json.loads(line)
-    assert d['n_gpus'] == 1 and d['value'] > 100 and d['config']['parallelism'] == 'dp1'
+    assert d['n_gpus'] == 1 and d['value'] > 100 and d['config']['parallelism'] == 'dp1' and d['rccl_ranks'] == 1
+
+
+def test_gradient_readiness_leaves_room_for_overlap():
+    """Data-parallel overlap is only possible if gradients become FINAL early in the backward pass: on the real program of the
+    benchmarked step (paper preset, batch 16, bf16 storage) -- its per-op hipEvent times, the op that last writes each gradient
+    (plan.grad_ready_op, batched sums included) and the bucket cuts DataParallel makes -- at least 75 % of the gradient bytes
+    must be final before the last 25 % of the backward kernel time, and every bucket but the last must have kernel time
+    left behind it to hide its all-reduce.  Prints the per-bucket table DESIGN.md section 6 quotes."""
+    import torch
+    import dfl_amd
+    from dfl_amd import _native as nat
+    from dfl_amd.parallel import DataParallel
+    import bench
+    lib = nat.lib()
+    prev = lib.dfl_get_math_mode()
+    nat.check(lib.dfl_set_math_mode(4), 'dfl_set_math_mode')
+    try:
+        torch.manual_seed(1)
+        net = dfl_amd.UNet(**bench.PAPER).to('cuda').train()
+        x, tseg, theat = bench.synth_batch(16, 7, 'cuda')
+        crit = dfl_amd.DiceAndHeatMapLoss2D(skip_bg=False, heatmap_wgt=0.5)
+        seg, heat = net(x)
+        crit((dfl_amd.center_crop(seg, tseg.shape), dfl_amd.center_crop(heat, theat.shape)), (tseg, theat)).backward()
+        torch.cuda.synchronize()
+        plan = net._last_train_plan()
+        seg, heat = net(x)                                   # fresh activations for the timed replay
+        hold = (torch.randn_like(seg) * 1e-6, torch.randn_like(heat) * 1e-6)
+        plan.bind_grads(seg, hold[0], hold[1])
+        stream = torch.cuda.current_stream().cuda_stream
+        plan.bwd.run(stream)
+        ms = plan.bwd.run_timed(stream)
+        plan.busy = False
+    finally:
+        nat.check(lib.dfl_set_math_mode(prev), 'dfl_set_math_mode')
+    total = sum(ms)
+    done_at, acc = [], 0.0
+    for t in ms:
+        acc += t
+        done_at.append(acc)                                  # time at which op i has finished
+    dp = DataParallel.__new__(DataParallel)                  # the bucket logic only: no process group on this box
+    dp.bucket_elems = int(32.0 * (1 << 20) / 4)
+    segs = dp._segments(plan)
+    nbytes = {k: 4 * plan.P[k].numel() for k in plan.grad_names if k not in plan.dead_params}
+    all_bytes = float(sum(nbytes.values()))
+    early = sum(b for k, b in nbytes.items() if done_at[plan.grad_ready_op[k]] <= 0.75 * total)
+    print('backward kernel time %.3f ms, %d ops; gradient bytes final before 75 %% of it: %.1f %%' % (total, len(ms), 100 * early / all_bytes))
+    ring_ms_per_mb = 2.0 * 7 / 8 / 153e3 * 1e3 * 1.048576       # 8-GPU ring all-reduce, one xGMI link of ~153 GB/s per hop
+    for k, (op0, cnt, ranges) in enumerate(segs):
+        if not ranges:
+            continue
+        mb = sum(e - s for s, e in ranges) * 4 / 2 ** 20
+        t_ready = done_at[op0 + cnt - 1]
+        print('  bucket %d: %6.1f MB ready at %.3f ms (%.0f %% of backward), %.3f ms of kernels behind it, ring all-reduce ~%.2f ms' % (
+            k, mb, t_ready, 100 * t_ready / total, total - t_ready, mb * ring_ms_per_mb))
+    assert early / all_bytes >= 0.75, 'only %.1f %% of the gradient bytes are final before the last quarter of backward' % (100 * early / all_bytes)
+    ready = [done_at[op0 + cnt - 1] for op0, cnt, ranges in segs if ranges]
+    assert all(t < 0.9 * total for t in ready[:-1]), 'a bucket other than the last becomes ready in the last 10 % of backward'
