@@ -32,13 +32,14 @@ F32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, 
 BF16_MFMA_PEAK_TFLOPS = 2500.0        # same guide: dense bf16 MFMA (the 5 PF marketing figure is 2:1 sparse)
 # product arithmetic of the GEMM kernels (include/dfl_hip.h): name -> (mode, bf16 MFMA products per fp32 product)
 MATH = {'fp32': (0, 0), 'bf16x3': (1, 3), 'bf16x6': (2, 6), 'bf16': (3, 1), 'bf16s': (4, 1)}
-TRAFFIC_FILE = 'r02_traffic.json'      # per-kernel HBM bytes from the committed rocprofv3 --pmc passes of this round
+TRAFFIC_FILE = 'r03_traffic.json'      # per-kernel HBM bytes from the committed rocprofv3 --pmc passes of this round
 CONV_KERNELS = ['conv_gemm_kernel<2,2,2,2>', 'conv_gemm_kernel<2,2,2,1>', 'conv_gemm_kernel<4,1,2,1>',
                 'conv_gemm_kernel<2,2,1,1>', 'conv_gemm_kernel<1,2,1,1>', 'direct_conv_kernel',
                 'conv_rows_kernel<3,1,2,1>', 'conv_rows_kernel<3,1,1,2>', 'conv_rows_kernel<3,1,1,1>']
 CONVP_TILES = ['4,1,2,1', '4,1,1,1', '2,2,4,1', '2,2,3,1', '2,2,2,1', '1,4,2,1', '1,4,3,1', '1,4,4,1', '1,4,6,1', '1,4,9,1', '2,2,1,1', '1,4,1,1',
                '4,1,3,1', '4,1,4,1', '2,2,6,1', '2,2,2,2', '2,2,3,2', '2,2,4,2', '4,1,2,2', '4,1,3,2', '1,4,2,2', '1,4,3,2',
-               '4,1,1,1', '4,1,2,1', '2,2,1,1', '2,2,2,1', '1,4,1,1', '1,4,2,1', '4,1,1,2', '2,2,1,2']   # (22 ...: the streamed 1x1 forms)      # csrc/convp_bf16.hip kTiles: waves M x N, tiles M x N per wave
+               '4,1,1,1', '4,1,2,1', '2,2,1,1', '2,2,2,1', '1,4,1,1', '1,4,2,1', '4,1,1,2', '2,2,1,2',   # (22 ...: the streamed 1x1 forms)
+               '1,4,3,1,k2', '1,4,2,1,k2', '1,4,4,1,k2', '2,2,3,1,k2', '2,2,2,1,k2', '1,4,2,2,k2', '2,2,2,2,k2', '4,1,3,1,k2', '4,1,2,1,k2']   # (30 ...: two k-groups, 512 threads)      # csrc/convp_bf16.hip kTiles: waves M x N, tiles M x N per wave
 WGRAD_KERNELS = ['wgrad_kernel<2,2,2,2,1>', 'wgrad_kernel<2,2,1,1,1>', 'wgrad_kernel<1,1,1,1,3>',
                  'wgrad_kernel<1,1,1,1,2>', 'wgrad_kernel<1,1,1,1,1>', 'direct_wgrad_kernel', 'wgrad_kernel<2,2,1,1,3>']
 

@@ -52,12 +52,22 @@ __device__ __forceinline__ float round_bf(float v) { return (float)(__bf16)v; }
 __device__ __forceinline__ int pdiv(int q, uint32_t m, int d) { return d == 1 ? q : (int)__umulhi((uint32_t)q, m); }
 __device__ __forceinline__ float ld_bf(const __bf16* p) { return (float)*p; }
 
-template <int WM, int WN, int TM, int TN, bool AFF, bool GA>
-__global__ void __launch_bounds__(256, (TM * TN >= 6) ? 1 : 2) convp_kernel(const ConvP p) {
-  static_assert(WM * WN == 4, "four waves per workgroup");
+// KS = 2 ("two k-groups"): 512 threads -- the same 4-wave tile layout twice.  Both groups share the staged patch image and
+// take alternate ring groups of k-steps; their accumulators meet in LDS before the epilogue.  Two waves per SIMD instead of
+// one cover each other's fragment-read and weight-load latencies in the k loop (a batch-16 layer of the deep levels has one
+// workgroup per CU, i.e. ONE wave per SIMD: its k loop runs at 35-41 % of the matrix rate), the patch is staged by twice
+// the threads, and -- unlike more K slices -- no partial sums go through HBM.
+template <int WM, int WN, int TM, int TN, bool AFF, bool GA, int KS = 1>
+__global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : 2) convp_kernel(const ConvP p) {
+  static_assert(WM * WN == 4, "four waves per k-group");
+  static_assert(KS == 1 || (KS == 2 && !GA), "two k-groups: LDS-image form only");
+  constexpr int NT = 256 * KS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const dfl_conv_args& a = p.a;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
+  // k-group of this wave: a compile-time 0 for one group, wave-uniform (scalar register) for two -- the k loop's cursors and
+  // liveness tests must stay scalar
+  const int kg = KS == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 8);
   const int wm = wave / WN, wn = wave % WN, li = lane & 31, lh = lane >> 5;
   const int S = p.pix_stride;
   const int PP = p.PH * p.PW;
@@ -129,7 +139,7 @@ __global__ void __launch_bounds__(256, (TM * TN >= 6) ? 1 : 2) convp_kernel(cons
   //      group, its pixel advances by 256 / upp per pass
   const int upp = p.CK >> 3, upp_sh = p.upp_shift;
   const int cg = tid & (upp - 1);
-  const int dpix = 256 >> upp_sh;
+  const int dpix = NT >> upp_sh;
   const int dpix_y = dpix / p.IW, dpix_x = dpix - dpix_y * p.IW;
   const int npix = p.IPP * p.IH * p.IW;
   const int CKC = p.CK >> 4;                       // 16-channel chunks per resident block (a power of two)
@@ -297,13 +307,16 @@ __global__ void __launch_bounds__(256, (TM * TN >= 6) ? 1 : 2) convp_kernel(cons
     // ================================================================ k-steps of this block: s = tap * CKC + chunk
     // B fragments ride a ring of three register sets, loaded two groups (8 k-steps) ahead of their use.
     constexpr int G = TN == 1 ? 4 : 2;             // k-steps per ring set (the ring holds 3 * G * TN fragments)
-    const int ngroups = (S_steps + G - 1) / G;
+    const int ngroups_all = (S_steps + G - 1) / G;
+    // k-group kg takes the ring groups kg, kg + KS, ...: local group gl is global group gl * KS + kg
+    const int ngroups = (ngroups_all - kg + KS - 1) / KS;
     pu32x4 breg[3][G][TN];
-    auto load_group = [&](int g, int set) {
+    auto load_group = [&](int gl, int set) {
+      const int g = gl * KS + kg;
 #pragma unroll
       for (int e = 0; e < G; ++e) {
         const int s = g * G + e;
-        const bool live = g < ngroups && s < S_steps;
+        const bool live = gl < ngroups && s < S_steps;
         const int tap = s >> ckc_sh, cc = s & (CKC - 1);
         const uint32_t soff = live ? (uint32_t)((tap * cin_chunks + blk * CKC + cc)) * (uint32_t)a.Ntot * 32u : 0u;
 #pragma unroll
@@ -321,13 +334,14 @@ __global__ void __launch_bounds__(256, (TM * TN >= 6) ? 1 : 2) convp_kernel(cons
 #pragma unroll
       for (int i = 0; i < TM; ++i) afn[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const pu32x4*>(smem + a_base[i] + aoff));
     };
-    auto compute_group = [&](int g, int set) {
+    auto compute_group = [&](int gl, int set) {
+      const int g = gl * KS + kg;
 #pragma unroll
       for (int e = 0; e < G; ++e) {
         bf16x8_t af[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) af[i] = afn[i];
-        fetch_a(g * G + e + 1);
+        fetch_a(e + 1 < G ? g * G + e + 1 : (g + KS) * G);      // the step this k-group takes next
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, breg[set][e][j]);
@@ -336,7 +350,7 @@ __global__ void __launch_bounds__(256, (TM * TN >= 6) ? 1 : 2) convp_kernel(cons
         }
       }
     };
-    fetch_a(0);
+    fetch_a(kg * G);
     load_group(0, 0);
     load_group(1, 1);
     for (int g = 0; g < ngroups; g += 3) {
@@ -356,9 +370,33 @@ __global__ void __launch_bounds__(256, (TM * TN >= 6) ? 1 : 2) convp_kernel(cons
   }
   TR(3)
 
+  // ==================================================================== the two k-groups add up (through LDS, tile row by tile row)
+  if constexpr (KS == 2) {
+    constexpr int XP = WN * TN * 32 + 4;
+    float* xg = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      __syncthreads();                                // the k loop / the previous tile row is done with this LDS region
+      if (kg == 1) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) xg[(wm * 32 + mfma32_row(r, lane)) * XP + (wn * TN + j) * 32 + li] = acc[i][j][r];
+      }
+      __syncthreads();
+      if (kg == 0) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += xg[(wm * 32 + mfma32_row(r, lane)) * XP + (wn * TN + j) * 32 + li];
+      }
+    }
+  }
+
   // ==================================================================== epilogue
   const bool sliced = p.splits > 1;
   if (sliced) {
+    if (KS == 2 && kg == 1) return;
     // K slices: raw fp32 partial sums, row = GEMM row, 128-byte runs per accumulator row; convp_finish_kernel does the rest
     float* part = a.partial + (int64_t)bslice * p.Mtot * a.Ntot;
 #pragma unroll
@@ -399,8 +437,9 @@ __global__ void __launch_bounds__(256, (TM * TN >= 6) ? 1 : 2) convp_kernel(cons
   constexpr int BN = WN * TN * 32;
   constexpr int EP = BN + 4;                          // row pitch in floats (+4: rows 4 apart on different banks)
   constexpr int UPR = BN / 8;                         // 8-column units per row
-  constexpr int RPS = 256 / UPR;                      // rows per step of the 256 threads
-  static_assert(256 % UPR == 0 && (WM * 32) % RPS == 0, "row phase mapping");
+  constexpr int RPS = (NT / UPR) < WM * 32 ? (NT / UPR) : WM * 32;   // rows per step of the workgroup's threads
+  static_assert(NT % UPR == 0 && (WM * 32) % RPS == 0, "row phase mapping");
+  const bool rowthread = (RPS * UPR == NT) ? true : (tid < RPS * UPR);   // (two k-groups on a narrow tile: more threads than (row, unit) pairs)
   float* ep = reinterpret_cast<float*>(smem);
   const bool do_stats = a.stat_partials != nullptr;
   const bool scat = a.scatter2x2 != 0;
@@ -440,17 +479,19 @@ __global__ void __launch_bounds__(256, (TM * TN >= 6) ? 1 : 2) convp_kernel(cons
 #ifdef DFL_CONVP_TRACE
     const long long te1 = __builtin_amdgcn_s_memtime();
 #endif
+    if (KS == 1 || kg == 0) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        ep[(wm * 32 + mfma32_row(r, lane)) * EP + (wn * TN + j) * 32 + li] = acc[i][j][r];
+        for (int r = 0; r < 16; ++r)
+          ep[(wm * 32 + mfma32_row(r, lane)) * EP + (wn * TN + j) * 32 + li] = acc[i][j][r];
+    }
     __syncthreads();
     TRACC(7, te1)
 #ifdef DFL_CONVP_TRACE
     const long long te2 = __builtin_amdgcn_s_memtime();
 #endif
-    for (int rl = urow; rl < WM * 32; rl += RPS) {    // row rl of the image = row (rl / 32) * TM*32 + i*32 + rl % 32 of the patch
+    for (int rl = rowthread ? urow : WM * 32; rl < WM * 32; rl += RPS) {    // row rl of the image = row (rl / 32) * TM*32 + i*32 + rl % 32 of the patch
       const int q = ((rl >> 5) * TM + i) * 32 + (rl & 31);
       const int img = pdiv(q, p.mPP, PP);
       const int rr = q - img * PP;
@@ -518,13 +559,15 @@ __global__ void __launch_bounds__(256, (TM * TN >= 6) ? 1 : 2) convp_kernel(cons
   // through LDS in a fixed order
   __syncthreads();
   float* red = reinterpret_cast<float*>(smem);        // [RPS][2][BN]
+  if (rowthread) {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    red[(urow * 2 + 0) * BN + ucol + e] = s1[e];
-    red[(urow * 2 + 1) * BN + ucol + e] = s2[e];
+    for (int e = 0; e < 8; ++e) {
+      red[(urow * 2 + 0) * BN + ucol + e] = s1[e];
+      red[(urow * 2 + 1) * BN + ucol + e] = s2[e];
+    }
   }
   __syncthreads();
-  for (int idx = tid; idx < 2 * BN; idx += 256) {
+  for (int idx = tid; idx < 2 * BN; idx += NT) {
     const int which = idx / BN, col = idx - which * BN;
     const int n = n0 + col;
     if (n < a.Ntot) {
@@ -607,16 +650,19 @@ __global__ void __launch_bounds__(256) convp_finish_kernel(const ConvP p, int TX
 
 // ---- host side ------------------------------------------------------------------------------------------------------
 
-struct TileCfg { int WM, WN, TM, TN, GA; };   // GA: A fragments straight from global memory (1x1 windows, see the kernel)
+struct TileCfg { int WM, WN, TM, TN, GA, KS; };   // GA: A fragments straight from global memory (1x1 windows, see the kernel); KS: k-groups (1 or 2)
 // value reported by dfl_conv_config for these kernels = 16 + index
-static const TileCfg kTiles[] = {{4, 1, 2, 1, 0}, {4, 1, 1, 1, 0}, {2, 2, 4, 1, 0}, {2, 2, 3, 1, 0}, {2, 2, 2, 1, 0}, {1, 4, 2, 1, 0},
-                                 {1, 4, 3, 1, 0}, {1, 4, 4, 1, 0}, {1, 4, 6, 1, 0}, {1, 4, 9, 1, 0}, {2, 2, 1, 1, 0}, {1, 4, 1, 1, 0},
-                                 {4, 1, 3, 1, 0}, {4, 1, 4, 1, 0}, {2, 2, 6, 1, 0},
+static const TileCfg kTiles[] = {{4, 1, 2, 1, 0, 1}, {4, 1, 1, 1, 0, 1}, {2, 2, 4, 1, 0, 1}, {2, 2, 3, 1, 0, 1}, {2, 2, 2, 1, 0, 1}, {1, 4, 2, 1, 0, 1},
+                                 {1, 4, 3, 1, 0, 1}, {1, 4, 4, 1, 0, 1}, {1, 4, 6, 1, 0, 1}, {1, 4, 9, 1, 0, 1}, {2, 2, 1, 1, 0, 1}, {1, 4, 1, 1, 0, 1},
+                                 {4, 1, 3, 1, 0, 1}, {4, 1, 4, 1, 0, 1}, {2, 2, 6, 1, 0, 1},
                                  // two column tiles per wave: half the LDS fragment reads per matrix instruction
-                                 {2, 2, 2, 2, 0}, {2, 2, 3, 2, 0}, {2, 2, 4, 2, 0}, {4, 1, 2, 2, 0}, {4, 1, 3, 2, 0}, {1, 4, 2, 2, 0}, {1, 4, 3, 2, 0},
+                                 {2, 2, 2, 2, 0, 1}, {2, 2, 3, 2, 0, 1}, {2, 2, 4, 2, 0, 1}, {4, 1, 2, 2, 0, 1}, {4, 1, 3, 2, 0, 1}, {1, 4, 2, 2, 0, 1}, {1, 4, 3, 2, 0, 1},
                                  // 1x1 windows streamed from global memory (22 ...): only ever chosen through the measured table
-                                 {4, 1, 1, 1, 1}, {4, 1, 2, 1, 1}, {2, 2, 1, 1, 1}, {2, 2, 2, 1, 1}, {1, 4, 1, 1, 1}, {1, 4, 2, 1, 1},
-                                 {4, 1, 1, 2, 1}, {2, 2, 1, 2, 1}};
+                                 {4, 1, 1, 1, 1, 1}, {4, 1, 2, 1, 1, 1}, {2, 2, 1, 1, 1, 1}, {2, 2, 2, 1, 1, 1}, {1, 4, 1, 1, 1, 1}, {1, 4, 2, 1, 1, 1},
+                                 {4, 1, 1, 2, 1, 1}, {2, 2, 1, 2, 1, 1},
+                                 // two k-groups (512 threads, 30 ...): only ever chosen through the measured table
+                                 {1, 4, 3, 1, 0, 2}, {1, 4, 2, 1, 0, 2}, {1, 4, 4, 1, 0, 2}, {2, 2, 3, 1, 0, 2}, {2, 2, 2, 1, 0, 2}, {1, 4, 2, 2, 0, 2},
+                                 {2, 2, 2, 2, 0, 2}, {4, 1, 3, 1, 0, 2}, {4, 1, 2, 1, 0, 2}};
 constexpr int kNumTiles = (int)(sizeof(kTiles) / sizeof(kTiles[0]));
 constexpr size_t kLdsSoft = 64 * 1024, kLdsHard = 150 * 1024;
 
@@ -740,7 +786,7 @@ static bool try_geometry(const dfl_conv_args& a, ConvP* p, const TileCfg& t, int
   const double per_round = busy > lat + loop ? busy : lat + loop;
   double c = (double)rounds * per_round;
   if (splits > 1) c += (double)p->Mtot * a.Ntot * 4.0 * (splits + 1) / 2000.0 + 6000.0;   // partial sums: bytes / (B per cycle of the chip) + the finish launch
-  *cost = c;
+  *cost = t.KS == 2 ? 1e289 : c;                       // (two k-groups: scored only by measurement, tools/tune_convp.py)
   return true;
 }
 
@@ -784,7 +830,7 @@ static void for_each_candidate(const dfl_conv_args& a, const ConvP& base, int fo
     if (wide) {
       if (bn > n32 || (bn < 64 && n32 >= 64) || (t.TN > 1 && bn > a.Ntot)) continue;
     } else {
-      if (t.TN != 1 || t.GA) continue;               // the model was fitted on the one-column-tile configurations
+      if (t.TN != 1 || t.GA || t.KS != 1) continue;   // the model was fitted on the one-column-tile, one-k-group configurations
       if (a.Ntot <= 32 && t.WN != 1) continue;
       if (a.Ntot > 32 && a.Ntot <= 64 && t.WN != 2) continue;
       if (a.Ntot > 64 && t.WN != 4) continue;
@@ -950,28 +996,30 @@ int convp_plan(const dfl_conv_args* a, ConvP* p, int force_splits) {
   return DFL_OK;
 }
 
-template <int WM, int WN, int TM, int TN, bool GA = false>
+template <int WM, int WN, int TM, int TN, bool GA = false, int KS = 1>
 static int convp_launch_t(const ConvP& p, hipStream_t s) {
   const bool aff = p.a.in_scale != nullptr;
   dim3 grid((unsigned)p.grid);
   size_t lds = (size_t)p.lds_bytes;
   constexpr int BN_ = WN * TN * 32;
-  const size_t epi = (size_t)WM * 32 * (BN_ + 4) * sizeof(float);              // epilogue image
-  const size_t red = (size_t)(256 / (BN_ / 8)) * 2 * BN_ * sizeof(float);      // statistics scratch
+  constexpr int NT_ = 256 * KS;
+  constexpr int RPS_ = (NT_ / (BN_ / 8)) < WM * 32 ? (NT_ / (BN_ / 8)) : WM * 32;
+  const size_t epi = (size_t)WM * 32 * (BN_ + 4) * sizeof(float);              // epilogue image (and the k-group exchange)
+  const size_t red = (size_t)RPS_ * 2 * BN_ * sizeof(float);                   // statistics scratch
   if (lds < epi) lds = epi;
   if (lds < red) lds = red;
   if constexpr (GA) {
     hipLaunchKernelGGL((convp_kernel<WM, WN, TM, TN, false, true>), grid, dim3(256), lds, s, p);
   } else if (aff) {
-    auto k = convp_kernel<WM, WN, TM, TN, true, false>;
+    auto k = convp_kernel<WM, WN, TM, TN, true, false, KS>;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsHard);
     (void)attr;                                      // (once per instantiation, not per launch)
-    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL(k, grid, dim3(NT_), lds, s, p);
   } else {
-    auto k = convp_kernel<WM, WN, TM, TN, false, false>;
+    auto k = convp_kernel<WM, WN, TM, TN, false, false, KS>;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsHard);
     (void)attr;
-    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL(k, grid, dim3(NT_), lds, s, p);
   }
   return check_launch("dfl_conv2d (bf16)");
 }
@@ -1008,7 +1056,16 @@ int convp_launch(const ConvP& p, hipStream_t s) {
     case 26: rc = convp_launch_t<1, 4, 1, 1, true>(p, s); break;
     case 27: rc = convp_launch_t<1, 4, 2, 1, true>(p, s); break;
     case 28: rc = convp_launch_t<4, 1, 1, 2, true>(p, s); break;
-    default: rc = convp_launch_t<2, 2, 1, 2, true>(p, s); break;
+    case 29: rc = convp_launch_t<2, 2, 1, 2, true>(p, s); break;
+    case 30: rc = convp_launch_t<1, 4, 3, 1, false, 2>(p, s); break;
+    case 31: rc = convp_launch_t<1, 4, 2, 1, false, 2>(p, s); break;
+    case 32: rc = convp_launch_t<1, 4, 4, 1, false, 2>(p, s); break;
+    case 33: rc = convp_launch_t<2, 2, 3, 1, false, 2>(p, s); break;
+    case 34: rc = convp_launch_t<2, 2, 2, 1, false, 2>(p, s); break;
+    case 35: rc = convp_launch_t<1, 4, 2, 2, false, 2>(p, s); break;
+    case 36: rc = convp_launch_t<2, 2, 2, 2, false, 2>(p, s); break;
+    case 37: rc = convp_launch_t<4, 1, 3, 1, false, 2>(p, s); break;
+    default: rc = convp_launch_t<4, 1, 2, 1, false, 2>(p, s); break;
   }
   if (rc != DFL_OK || p.splits <= 1) return rc;
   int tx = 1;
