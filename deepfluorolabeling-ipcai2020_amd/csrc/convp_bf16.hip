@@ -666,9 +666,21 @@ static const TileCfg kTiles[] = {{4, 1, 2, 1, 0, 1}, {4, 1, 1, 1, 0, 1}, {2, 2, 
 constexpr int kNumTiles = (int)(sizeof(kTiles) / sizeof(kTiles[0]));
 constexpr size_t kLdsSoft = 64 * 1024, kLdsHard = 150 * 1024;
 
+// Row blocks of convp_finish_kernel = rows of stat_partials the following finalize kernel has to read.  Few (<= FIN_ROWS) and
+// the finalize launch reads a few hundred KB instead of up to 4.7 MB (one row per 1-2 GEMM rows on the deep levels: its
+// 10-12 us there against 5-6 us elsewhere); the finish kernel keeps its parallelism through narrow column blocks (FIN_TX).
+static const int FIN_ROWS = [] {
+  const char* e = getenv("DFL_CONVP_FIN_ROWS");
+  return e ? atoi(e) : 128;                    // (measured 2048 / 512 / 256 / 128 rows: 4.89 / 4.88 / 4.865 / 4.85 ms per step)
+}();
+static const int FIN_TX = [] {
+  const char* e = getenv("DFL_CONVP_FIN_TX");
+  return e ? atoi(e) : 32;
+}();
 static int finish_rows_p(int M, int Ntot) {
   int64_t nb = ceil_div((int64_t)M * Ntot, 1024);
   if (nb > 2048) nb = 2048;
+  if (nb > FIN_ROWS) nb = FIN_ROWS;
   if (nb > M) nb = M;
   return nb < 1 ? 1 : (int)nb;
 }
@@ -1069,7 +1081,7 @@ int convp_launch(const ConvP& p, hipStream_t s) {
   }
   if (rc != DFL_OK || p.splits <= 1) return rc;
   int tx = 1;
-  while (tx * 2 <= p.a.Ntot && tx * 2 <= 256) tx *= 2;
+  while (tx * 2 <= p.a.Ntot && tx * 2 <= FIN_TX) tx *= 2;
   const int nb = finish_rows_p(p.Mtot, p.a.Ntot);
   const int rpb = (int)ceil_div(p.Mtot, nb);
   dim3 grid((unsigned)nb, (unsigned)ceil_div(p.a.Ntot, tx));

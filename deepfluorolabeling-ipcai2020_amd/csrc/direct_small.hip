@@ -178,6 +178,190 @@ __global__ void __launch_bounds__(256) direct_conv_kernel(const dfl_conv_args a,
   }
 }
 
+// ---------------------------------------------------------------------------------------------- 3x3 window, ONE input channel: row form
+// The network's first convolution and its weight gradient (unet.py:211: Conv2d(1, 32, 3)) are pure streams: 2.4 MB of image
+// against 37.7 MB of bf16 output / output gradient at batch 16.  The general direct kernels above walk pixels with a cursor,
+// four channels and ONE pixel per thread and iteration: every iteration waits for its own loads (18 dependent round trips per
+// thread in the weight gradient: 69 us where the data take 7 at the HBM rate) and spends more instructions on addresses than on
+// multiply-adds.  Here a workgroup owns RB rows of one image, a thread 8 channels of the pixels x = pl, pl + PL, ... of each
+// row: no divisions, row validity is workgroup-uniform, the loops are short and fully unrolled by the compiler (all loads of a
+// row in flight), stores / loads of the big tensor are 16 bytes, and the weight gradient adds its accumulators up with wave
+// shuffles + one LDS round instead of 36 barrier rounds.
+template <bool BF>
+__device__ __forceinline__ void ld8c(const float* base, int64_t elem, float* v) {
+  if constexpr (BF) {
+    const uint4 w = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(base) + elem);
+    v[0] = __uint_as_float(w.x << 16); v[1] = __uint_as_float(w.x & 0xffff0000u);
+    v[2] = __uint_as_float(w.y << 16); v[3] = __uint_as_float(w.y & 0xffff0000u);
+    v[4] = __uint_as_float(w.z << 16); v[5] = __uint_as_float(w.z & 0xffff0000u);
+    v[6] = __uint_as_float(w.w << 16); v[7] = __uint_as_float(w.w & 0xffff0000u);
+  } else {
+    const float4 a = *reinterpret_cast<const float4*>(base + elem), b = *reinterpret_cast<const float4*>(base + elem + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+}
+// store 8 channels (rounding to bf16 when BF); v receives the values as stored
+template <bool BF>
+__device__ __forceinline__ void st8c(float* base, int64_t elem, float* v) {
+  if constexpr (BF) {
+    uint4 w;
+    w.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){v[0], v[1]}, bf16x2_t));
+    w.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){v[2], v[3]}, bf16x2_t));
+    w.z = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){v[4], v[5]}, bf16x2_t));
+    w.w = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){v[6], v[7]}, bf16x2_t));
+    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(base) + elem) = w;
+    v[0] = __uint_as_float(w.x << 16); v[1] = __uint_as_float(w.x & 0xffff0000u);
+    v[2] = __uint_as_float(w.y << 16); v[3] = __uint_as_float(w.y & 0xffff0000u);
+    v[4] = __uint_as_float(w.z << 16); v[5] = __uint_as_float(w.z & 0xffff0000u);
+    v[6] = __uint_as_float(w.w << 16); v[7] = __uint_as_float(w.w & 0xffff0000u);
+  } else {
+    *reinterpret_cast<float4*>(base + elem) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(base + elem + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+}
+
+constexpr int ROWS_CONV_RB = 2, ROWS_WGRAD_RB = 4;   // (measured against 4 / 6 rows with four pixels in flight per thread and the
+// weights staged through LDS: 37 / 40 us here, 79 / 47 us there -- 184 registers halve the occupancy these short loops live on)
+
+template <bool BF>
+__global__ void __launch_bounds__(256) direct_conv3_rows_kernel(const dfl_conv_args a) {
+  __shared__ float red[2][256][8];
+  const int cq = a.Ntot >> 3, PL = 256 / cq;
+  const int q = threadIdx.x % cq, pl = threadIdx.x / cq;
+  const int n0 = 8 * q;
+  const int bands = (a.Hout + ROWS_CONV_RB - 1) / ROWS_CONV_RB;
+  const int n = blockIdx.x / bands, y0 = (blockIdx.x - n * bands) * ROWS_CONV_RB;
+  float w[9][8], bias[8], s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w[k][j] = a.w[((int64_t)(k >> 2) * a.Ntot + n0 + j) * 4 + (k & 3)];   // quad-packed operand
+    bias[j] = a.bias != nullptr ? a.bias[n0 + j] : 0.f;
+    s1[j] = 0.f;
+    s2[j] = 0.f;
+  }
+  const float* img = a.x + (int64_t)n * a.Hin * a.Win * a.ldx;
+#pragma unroll
+  for (int ry = 0; ry < ROWS_CONV_RB; ++ry) {
+    const int y = y0 + ry;
+    if (y >= a.Hout) break;
+    for (int x = pl; x < a.Wout; x += PL) {
+      float xv[9];
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int iy = y - a.pad + dy, ix = x - a.pad + dx;
+          const bool ok = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+          xv[dy * 3 + dx] = ok ? img[(int64_t)(iy * a.Win + ix) * a.ldx] : 0.f;
+        }
+      float acc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = bias[j];
+#pragma unroll
+      for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv[k], w[k][j], acc[j]);
+      if (a.relu) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaxf(acc[j], 0.f);
+      }
+      st8c<BF>(a.y, ((int64_t)(n * a.Hout + y) * a.Wout + x) * a.ldy + n0, acc);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {   // statistics of the values as stored
+        s1[j] += acc[j];
+        s2[j] = fmaf(acc[j], acc[j], s2[j]);
+      }
+    }
+  }
+  if (a.stat_partials == nullptr) return;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    red[0][threadIdx.x][j] = s1[j];
+    red[1][threadIdx.x][j] = s2[j];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 2 * a.Ntot; idx += 256) {   // fixed order: bit-reproducible
+    const int which = idx / a.Ntot, c = idx - which * a.Ntot;
+    const int qq = c >> 3, j = c & 7;
+    float t = 0.f;
+    for (int p = 0; p < PL; ++p) t += red[which][p * cq + qq][j];
+    a.stat_partials[((int64_t)blockIdx.x * 2 + which) * a.Ntot + c] = t;
+  }
+}
+
+static bool direct_conv_rows_ok(const dfl_conv_args* a) {
+  return a->KH == 3 && a->KW == 3 && a->Cin == 1 && a->stride == 1 && a->add == nullptr && !a->accumulate && a->stat_other == nullptr &&
+         a->in_scale == nullptr && a->Ntot % 8 == 0 && a->Ntot <= 64 && 256 % (a->Ntot / 8) == 0 && a->ldy % 8 == 0 && aligned16(a->y);
+}
+
+// dw[cm][0][t] (or the tap-major partial slot of this workgroup) = sum over its pixels of x(tap t) * d[cm]
+template <bool BF>
+__global__ void __launch_bounds__(256) direct_wgrad3_rows_kernel(const dfl_wgrad_args a) {
+  __shared__ float red[4][8 * 72];              // [wave][q][k][j]
+  const int cq = a.Cm >> 3, PL = 256 / cq;
+  const int q = threadIdx.x % cq, pl = threadIdx.x / cq;
+  const int bands = (a.Hout + ROWS_WGRAD_RB - 1) / ROWS_WGRAD_RB;
+  const int n = blockIdx.x / bands, y0 = (blockIdx.x - n * bands) * ROWS_WGRAD_RB;
+  float acc[9][8];
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
+  const float* img = a.g + (int64_t)n * a.Hin * a.Win * a.ldg;
+#pragma unroll
+  for (int ry = 0; ry < ROWS_WGRAD_RB; ++ry) {
+    const int y = y0 + ry;
+    if (y >= a.Hout) break;
+    for (int x = pl; x < a.Wout; x += PL) {
+      float d[8], xv[9];
+      ld8c<BF>(a.d, ((int64_t)(n * a.Hout + y) * a.Wout + x) * a.ldd + 8 * q, d);
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int iy = y - a.pad + dy, ix = x - a.pad + dx;
+          const bool ok = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+          xv[dy * 3 + dx] = ok ? img[(int64_t)(iy * a.Win + ix) * a.ldg] : 0.f;
+        }
+#pragma unroll
+      for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[k][j] = fmaf(xv[k], d[j], acc[k][j]);
+    }
+  }
+  // lanes of one wave that share q (lane % cq): butterfly over the pixel lanes, then the four waves through LDS -- a fixed tree
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = acc[k][j];
+      for (int off = cq; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+      acc[k][j] = v;
+    }
+  if (lane < cq) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) red[wave][(lane * 9 + k) * 8 + j] = acc[k][j];
+  }
+  __syncthreads();
+  const bool sliced = a.splits > 1;
+  float* out = sliced ? a.partial + (int64_t)blockIdx.x * a.Cm * 9 : a.dw;
+  for (int idx = threadIdx.x; idx < cq * 72; idx += 256) {
+    const float t = ((red[0][idx] + red[1][idx]) + red[2][idx]) + red[3][idx];
+    const int qq = idx / 72, r = idx - qq * 72, k = r >> 3, j = r & 7;
+    const int cm = 8 * qq + j;
+    out[sliced ? (int64_t)k * a.Cm + cm : (int64_t)cm * 9 + k] = t;
+  }
+}
+
+static bool direct_wgrad_rows_ok(const dfl_wgrad_args* a) {
+  return a->KH == 3 && a->KW == 3 && a->Cg == 1 && a->stride == 1 && a->in_scale == nullptr && a->Cm % 8 == 0 && a->Cm <= 64 &&
+         256 % (a->Cm / 8) == 0 && 64 % (a->Cm / 8) == 0 && a->ldd % 8 == 0 && aligned16(a->d) && !a->g_bf16;
+}
+
 // instantiated windows (KH = KW): 3x3 with 1 channel, 2x2 with <= 3, 1x1 with <= 4
 static bool direct_window(int KH, int KW, int C) {
   if (KH != KW) return false;
@@ -195,6 +379,7 @@ bool direct_conv_ok(const dfl_conv_args* a) {
 }
 
 int direct_conv_blocks(const dfl_conv_args* a) {
+  if (direct_conv_rows_ok(a)) return a->N * (int)ceil_div(a->Hout, ROWS_CONV_RB);
   const int64_t M = (int64_t)a->N * a->Hout * a->Wout;
   const int PL = 256 / (a->Ntot / 4);
   int64_t b = ceil_div(M, (int64_t)PL * 8);
@@ -205,6 +390,11 @@ int direct_conv_blocks(const dfl_conv_args* a) {
 int direct_conv_launch(const dfl_conv_args* a, hipStream_t s) {
   const int64_t M = (int64_t)a->N * a->Hout * a->Wout;
   const int blocks = direct_conv_blocks(a);
+  if (direct_conv_rows_ok(a)) {
+    if (a->y_bf16) hipLaunchKernelGGL(direct_conv3_rows_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, *a);
+    else hipLaunchKernelGGL(direct_conv3_rows_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, *a);
+    return check_launch("dfl_conv2d");
+  }
   const int rpb = (int)ceil_div(M, blocks);
 #define DFL_DC(KH_, C_)                                                                                                  \
   {                                                                                                                      \
@@ -303,6 +493,7 @@ bool direct_wgrad_ok(const dfl_wgrad_args* a) {
 }
 
 int direct_wgrad_splits(const dfl_wgrad_args* a) {
+  if (direct_wgrad_rows_ok(a)) return a->N * (int)ceil_div(a->Hout, ROWS_WGRAD_RB);
   const int64_t M = (int64_t)a->N * a->Hout * a->Wout;
   const int PL = 256 / (a->Cm / 4);
   int64_t b = ceil_div(M, (int64_t)PL * 16);
@@ -311,6 +502,11 @@ int direct_wgrad_splits(const dfl_wgrad_args* a) {
 }
 
 int direct_wgrad_launch(const dfl_wgrad_args* a, hipStream_t s) {
+  if (direct_wgrad_rows_ok(a) && a->splits == direct_wgrad_splits(a)) {     // (the row form's slots are its workgroups)
+    if (a->d_bf16) hipLaunchKernelGGL(direct_wgrad3_rows_kernel<true>, dim3((unsigned)a->splits), dim3(256), 0, s, *a);
+    else hipLaunchKernelGGL(direct_wgrad3_rows_kernel<false>, dim3((unsigned)a->splits), dim3(256), 0, s, *a);
+    return check_launch("dfl_conv2d_wgrad");
+  }
   const int64_t M = (int64_t)a->N * a->Hout * a->Wout;
   const int rpb = (int)ceil_div(M, a->splits);
 #define DFL_DW(KH_, C_)                                                                                                  \
