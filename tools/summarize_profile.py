@@ -25,7 +25,8 @@ def short(name):
         return re.sub(r'\(.*', '', name).replace('void ', '').replace('dfl::', '')[:80]
     args = [a.strip() for a in m.group(2).split(',')]
     keep = {'conv_gemm_kernel': 4, 'conv_rows_kernel': 4, 'wgrad_kernel': 5, 'convp_kernel': 4, 'wgradp_kernel': 2}.get(m.group(1), len(args))
-    return '%s<%s>' % (m.group(1), ','.join(args[:keep]))
+    tail = ',k2' if (m.group(1) == 'convp_kernel' and len(args) >= 7 and args[6] == '2') else ''     # two k-groups (512 threads)
+    return '%s<%s%s>' % (m.group(1), ','.join(args[:keep]), tail)
 
 
 def main():
