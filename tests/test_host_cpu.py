@@ -51,7 +51,47 @@ def test_cpu_tensors_are_refused():
     with pytest.raises(RuntimeError):
         dfl_amd.get_device(no_gpu=True)
     with pytest.raises(NotImplementedError):
-        dfl_amd.UNet(up_mode='upsample')
+        dfl_amd.UNet(pad_mode='reflect')              # torch accepts it; the reference's flag values are 'zeros' and 'circular'
+    with pytest.raises(AssertionError):
+        dfl_amd.UNet(up_mode='nearest')               # unet.py:72: assert up_mode in ('upconv', 'upsample')
+
+
+@pytest.mark.parametrize('flags', [dict(up_mode='upsample', padding=True), dict(pad_mode='circular', padding=True),
+                                   dict(padding=False, do_res=False, num_lands=6, lands_block_depth=2),
+                                   dict(padding=True, num_lands=6, lands_block_depth=1, lands_num_1x1=3, up_mode='upsample', pad_mode='circular')])
+def test_every_constructor_flag_builds_the_reference_module_tree(flags):
+    """The constructor values no reference CLI selects (unet.py:41-45: up_mode='upsample', pad_mode='circular', lands_block_depth
+    with and without padding): same state_dict keys, shapes and seeded initialisation as the oracle's module tree, which
+    tests/test_oracle_golden.py pins to the reference."""
+    from oracle import ref_cpu as R
+    cfg = dict(n_classes=5, depth=3, wf=3, batch_norm=True, max_pool=False)
+    cfg.update(flags)
+    torch.manual_seed(11)
+    a = dfl_amd.UNet(1, **cfg).state_dict()
+    torch.manual_seed(11)
+    b = R.OracleUNet(1, **cfg).state_dict()
+    assert list(a.keys()) == list(b.keys())
+    for k in a:
+        assert a[k].shape == b[k].shape and torch.equal(a[k], b[k]), k
+    # ... and the programs record for them (addresses only, nothing is launched), in the fp32 and the bf16 storage arithmetic
+    L = nat.lib()
+    prev = L.dfl_get_math_mode()
+    try:
+        for mode, wf in ((0, 3), (4, 5)):      # (bf16 storage: channel counts, F/2 of the landmark block included, are multiples of 16)
+            nat.check(L.dfl_set_math_mode(mode), 'dfl_set_math_mode')
+            net = dfl_amd.UNet(1, **dict(cfg, wf=wf))
+            P, B = net._state()
+            plan = UNetPlan(net._cfg, P, B, 2, 64, 64, True, True, torch.device('cpu'))
+            seg, heat = plan.new_outputs()
+            with torch.no_grad():
+                o = R.OracleUNet(1, **dict(cfg, wf=wf))(torch.zeros(2, 1, 64, 64))
+            oseg, oheat = (o if isinstance(o, tuple) else (o, None))
+            assert tuple(seg.shape) == tuple(oseg.shape) and (heat is None) == (oheat is None)
+            assert heat is None or tuple(heat.shape) == tuple(oheat.shape)
+            live = [k for k in plan.grad_names if k not in plan.dead_params]
+            assert set(plan.grad_ready_op) == set(live)
+    finally:
+        nat.check(L.dfl_set_math_mode(prev), 'dfl_set_math_mode')
 
 
 @pytest.mark.parametrize('name', sorted(PAPER_CFGS))
