@@ -98,6 +98,7 @@ def large_head():
 
 
 def lands_block(lbd, padding=True):
+    """(wf = 5: F/2 = 16 channels, so the same problems also run in the bf16 storage arithmetic.)"""
     cfg = dict(n_classes=5, depth=3, wf=5, batch_norm=True, padding=padding, max_pool=False, num_lands=6, do_res=bool(padding),
                block_depth=2, lands_block_depth=lbd)
     onet = _seeded_oracle(123 + lbd, cfg, 1)
@@ -166,16 +167,16 @@ def config3():
     return Problem('config3', cfg, onet.state_dict(), x, tseg, theat)
 
 
-def upsample(pad_mode='zeros'):
+def upsample(pad_mode='zeros', wf=4):
     """up_mode='upsample' (unet.py:242-244) and / or pad_mode='circular' (unet.py:211-212): flags no reference CLI selects."""
-    cfg = dict(n_classes=5, depth=3, wf=4, batch_norm=True, padding=True, max_pool=False, num_lands=6, do_res=True,
+    cfg = dict(n_classes=5, depth=3, wf=wf, batch_norm=True, padding=True, max_pool=False, num_lands=6, do_res=True,
                block_depth=2, up_mode='upsample', pad_mode=pad_mode)
     onet = _seeded_oracle(55, cfg, 1)
     g = torch.Generator().manual_seed(12)
     x = torch.randn(2, 1, 48, 64, generator=g)
     tseg = torch.softmax(torch.randn(2, 5, 44, 60, generator=g), 1)
     theat = torch.rand(2, 6, 44, 60, generator=g) * 0.02
-    return Problem('upsample__%s' % pad_mode, cfg, onet.state_dict(), x, tseg, theat)
+    return Problem('upsample__%s' % pad_mode + ('' if wf == 4 else '__wf%d' % wf), cfg, onet.state_dict(), x, tseg, theat)
 
 
 def circular(lbd=0):
@@ -213,5 +214,6 @@ for _l in (0, 1):
     REGISTRY['circular__lb%d' % _l] = (lambda l=_l: circular(l))
 for _m in ('zeros', 'circular'):
     REGISTRY['upsample__%s' % _m] = (lambda m=_m: upsample(m))
+REGISTRY['upsample__circular__wf5'] = lambda: upsample('circular', wf=5)     # (wide enough for the bf16 storage arithmetic)
 
 FLOOR_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'floors')

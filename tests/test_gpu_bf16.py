@@ -597,6 +597,26 @@ def test_network_bf16_storage_against_fp64_oracle(cfgname):
                                             res['info']['pool_flips'], res['info']['relu_total'], res['info']['max_margin']))
 
 
+@pytest.mark.parametrize('key', ['upsample__circular__wf5', 'landsblock__1__valid', 'landsblock__2'])
+def test_constructor_flags_in_bf16_storage(key):
+    """The constructor values no reference CLI selects -- up_mode='upsample' + pad_mode='circular' (bf16 forms of dfl_upsample2x_*
+    and of the frame copies), lands_block_depth with and without padding (two head calls) -- in the
+    bf16 storage arithmetic: forward at bf16 distance from the fp64 oracle, every gradient inside its bar on the run's pattern."""
+    pr = PR.REGISTRY[key]()
+    if any(2 ** (pr.cfg['wf'] + i) % 16 for i in range(pr.cfg['depth'])):
+        pytest.skip('channel counts below 16')
+    gc = NF.cached_check(key, lambda: pr)
+    net = hip_net(gc.problem)
+    out, seg, loss = hip_step(gc.problem, net)
+    assert NF.train_plan(net).bf16
+    dev = float((seg.detach().double().cpu() - gc.out).abs().max())
+    assert 1e-6 < dev < 5e-2, 'soft-max deviation %.3e from fp64' % dev
+    assert float((out[1].detach().double().cpu() - gc.heat).abs().max()) < 5e-2 * float(gc.heat.abs().max())
+    assert abs(loss.item() - gc.loss) < 2e-2 * abs(gc.loss)
+    res = gc.check(net, seg, _eps4(), key + ' bf16s ')
+    print('%s bf16 storage: conv noise %.2e, whole-gradient error %.3e, worst error / bar %.2f' % (key, res['eps_eff'], res['whole'], res['worst']))
+
+
 def test_eval_and_inference_graph_bf16_storage():
     """Eval-mode forward (running statistics) and its hipGraph replay in the bf16 storage mode."""
     seed, cfg = PAPER_CFGS['paper_sc_l14']

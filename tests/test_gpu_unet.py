@@ -145,6 +145,37 @@ def test_repeated_forward_and_grad_accumulation():
             rel_close(p.grad.cpu().numpy(), (ga[k] + gb[k]).cpu().numpy(), 1e-3, 'accumulated grad ' + k)
 
 
+@pytest.mark.parametrize('mode', ['fp32', 'bf16s'])
+def test_training_hipgraph_replay_equals_plain_launches(mode):
+    """Training forwards and backwards replay hipGraphs (round 3: every run of main-stream kernels with fixed argument blocks is
+    one graph launch; head ops and event waits stay plain launches).  Same weights, same batch: outputs, loss and every
+    gradient are bit-identical to op-by-op replay through dfl_exec, over several steps with an optimizer in between (the
+    graphs freeze addresses, not contents)."""
+    from gpu_common import math_mode_set
+    import problems as PR_
+    pr = PR_.n1x1(3) if mode == 'fp32' else PR_.lands_block(1)
+    with math_mode_set(mode):
+        nets = []
+        for graphs in (True, False):
+            net = hip_net(pr)
+            net.train_graphs = graphs
+            opt = dfl_amd.SGD(net.parameters(), lr=0.05, momentum=0.9, nesterov=True)
+            hist = []
+            for step in range(3):
+                opt.zero_grad()
+                out, seg, loss = hip_step(pr, net)
+                hist.append((seg.detach().clone(), out[1].detach().clone(), loss.detach().clone(),
+                             [p.grad.clone() for p in net.parameters() if p.grad is not None]))
+                opt.step()
+            plan = NF.train_plan(net)
+            has_graph = any(g is not None for chunks in plan.bwd._chunks.values() for _, _, g in chunks)
+            assert has_graph == graphs, 'backward %s captured' % ('was not' if graphs else 'was')
+            nets.append(hist)
+    for (s0, h0, l0, g0), (s1, h1, l1, g1) in zip(*nets):
+        assert torch.equal(s0, s1) and torch.equal(h0, h1) and torch.equal(l0, l1)
+        assert len(g0) == len(g1) and all(torch.equal(a, b) for a, b in zip(g0, g1))
+
+
 def test_cpu_input_fails_loudly():
     net = dfl_amd.UNet(n_classes=7, depth=2, wf=2, padding=True, batch_norm=True)
     with pytest.raises(RuntimeError):
