@@ -20,7 +20,8 @@ class ConvArgs(C.Structure):
                 ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32),
                 ('Hout', i32), ('Wout', i32), ('Ntot', i32), ('ldy', i32),
                 ('ldadd', i32), ('ldso', i32), ('relu', i32), ('accumulate', i32), ('scatter2x2', i32),
-                ('splits', i32), ('w_split', i32), ('x_split', i32), ('x_bf16', i32), ('y_bf16', i32)]
+                ('splits', i32), ('w_split', i32), ('x_split', i32), ('x_bf16', i32), ('y_bf16', i32),
+                ('x2', fp), ('ldx2', i32), ('x_mode', i32)]
 
 
 class WgradArgs(C.Structure):
@@ -28,7 +29,8 @@ class WgradArgs(C.Structure):
                 ('N', i32), ('Hin', i32), ('Win', i32), ('Cg', i32), ('ldg', i32),
                 ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32),
                 ('Hout', i32), ('Wout', i32), ('Cm', i32), ('ldd', i32), ('splits', i32), ('d_split', i32),
-                ('g_bf16', i32), ('d_bf16', i32), ('reserved', i32)]
+                ('g_bf16', i32), ('d_bf16', i32), ('d_mode', i32), ('d2', fp), ('coef', fp), ('bias_partial', fp),
+                ('ldd2', i32), ('reserved2', i32)]
 
 
 class PackJob(C.Structure):

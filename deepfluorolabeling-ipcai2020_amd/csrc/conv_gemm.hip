@@ -862,6 +862,7 @@ extern "C" int dfl_conv2d(const dfl_conv_args* a, dfl_stream_t stream) {
     if (rc != DFL_OK) return rc;
     return dfl::convp_launch(p, static_cast<hipStream_t>(stream));
   }
+  DFL_REQUIRE(a == nullptr || a->x_mode == 0, "dfl_conv2d: x_mode (fused BatchNorm + ReLU backward operand) is implemented by the bf16 patch kernels only");
   dfl::ConvK k;
   int rc = dfl::prepare(a, &k);
   if (rc != DFL_OK) return rc;

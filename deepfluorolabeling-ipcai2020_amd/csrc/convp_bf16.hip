@@ -57,10 +57,13 @@ __device__ __forceinline__ float ld_bf(const __bf16* p) { return (float)*p; }
 // one cover each other's fragment-read and weight-load latencies in the k loop (a batch-16 layer of the deep levels has one
 // workgroup per CU, i.e. ONE wave per SIMD: its k loop runs at 35-41 % of the matrix rate), the patch is staged by twice
 // the threads, and -- unlike more K slices -- no partial sums go through HBM.
-template <int WM, int WN, int TM, int TN, bool AFF, bool GA, int KS = 1>
+// AFF: what happens to an input unit on its way into the LDS image -- 0: nothing; 1: BatchNorm affine (scale, shift); 2: BatchNorm +
+// ReLU backward (dfl_conv_args.x_mode): x is dy, x2 the saved ReLU output r, the staged value [r > 0] * (A dy + B r + C).
+template <int WM, int WN, int TM, int TN, int AFF, bool GA, int KS = 1>
 __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : 2) convp_kernel(const ConvP p) {
   static_assert(WM * WN == 4, "four waves per k-group");
   static_assert(KS == 1 || (KS == 2 && !GA), "two k-groups: LDS-image form only");
+  static_assert(AFF != 2 || !GA, "the fused BatchNorm + ReLU backward operand is staged through LDS");
   constexpr int NT = 256 * KS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const dfl_conv_args& a = p.a;
@@ -244,12 +247,23 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : 2) c
     const long long tb0 = __builtin_amdgcn_s_memtime();
 #endif
     {
-      float sc[8], sh[8];
-      if constexpr (AFF) {
+      float sc[8], sh[8], sq[8];
+      if constexpr (AFF == 1) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           sc[e] = a.in_scale[c0 + cg * 8 + e];
           sh[e] = a.in_shift[c0 + cg * 8 + e];
+        }
+      }
+      __amdgpu_buffer_rsrc_t rsR = rsX;
+      if constexpr (AFF == 2) {                    // d(pre-activation) = [r > 0] * (sc dy + sh r + sq); no BatchNorm: 1, 0, 0
+        rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x2), 0, (int)p.x2_bytes, 0x00020000);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = c0 + cg * 8 + e;
+          sc[e] = a.in_scale != nullptr ? a.in_scale[c] : 1.f;
+          sh[e] = a.in_scale != nullptr ? a.in_scale[a.Cin + c] : 0.f;
+          sq[e] = a.in_scale != nullptr ? a.in_scale[2 * a.Cin + c] : 0.f;
         }
       }
       int pix = tid >> upp_sh;
@@ -258,9 +272,9 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : 2) c
       int iy = rem / p.IW, ix = rem - iy * p.IW;
       const int ybase = gy0 * a.stride - a.pad, xbase = gx0 * a.stride - a.pad;
       const uint32_t cbyte = (uint32_t)((c0 + cg * 8) * 2);
-      constexpr int U = 8;                         // loads in flight per thread
+      constexpr int U = AFF == 2 ? 4 : 8;          // loads in flight per thread (two tensors in mode 2)
       for (; pix < npix; pix += U * dpix) {
-        pu32x4 v[U];
+        pu32x4 v[U], v2[AFF == 2 ? U : 1];
         bool ok[U];
         int pixs[U];
 #pragma unroll
@@ -270,6 +284,10 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : 2) c
           ok[u] = pixs[u] < npix && n < a.N && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
           const uint32_t off = (uint32_t)(((n * a.Hin + gy) * a.Win + gx) * a.ldx) * 2u + cbyte;
           v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsX, ok[u] ? off : POOB, 0, 0);
+          if constexpr (AFF == 2) {
+            const uint32_t off2 = (uint32_t)(((n * a.Hin + gy) * a.Win + gx) * a.ldx2) * 2u + cbyte;
+            v2[u] = __builtin_amdgcn_raw_buffer_load_b128(rsR, ok[u] ? off2 : POOB, 0, 0);
+          }
           ix += dpix_x;
           iy += dpix_y;
           if (ix >= p.IW) {
@@ -285,13 +303,21 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : 2) c
         for (int u = 0; u < U; ++u) {
           if (pixs[u] < npix) {
             pu32x4 w = v[u];
-            if constexpr (AFF) {                   // zero padding applies AFTER the BatchNorm affine: outside pixels stay 0
+            if constexpr (AFF == 1) {              // zero padding applies AFTER the BatchNorm affine: outside pixels stay 0
               if (ok[u]) {
                 w.x = pack_bf2(fmaf(bf_lo(w.x), sc[0], sh[0]), fmaf(bf_hi(w.x), sc[1], sh[1]));
                 w.y = pack_bf2(fmaf(bf_lo(w.y), sc[2], sh[2]), fmaf(bf_hi(w.y), sc[3], sh[3]));
                 w.z = pack_bf2(fmaf(bf_lo(w.z), sc[4], sh[4]), fmaf(bf_hi(w.z), sc[5], sh[5]));
                 w.w = pack_bf2(fmaf(bf_lo(w.w), sc[6], sh[6]), fmaf(bf_hi(w.w), sc[7], sh[7]));
               }
+            }
+            if constexpr (AFF == 2) {              // outside pixels were loaded as zeros: r = 0 there, the value stays 0
+              const pu32x4 r = v2[u];
+              auto brb = [](float dy, float rv, float A, float B, float Cc) { return rv > 0.f ? fmaf(A, dy, fmaf(B, rv, Cc)) : 0.f; };
+              w.x = pack_bf2(brb(bf_lo(w.x), bf_lo(r.x), sc[0], sh[0], sq[0]), brb(bf_hi(w.x), bf_hi(r.x), sc[1], sh[1], sq[1]));
+              w.y = pack_bf2(brb(bf_lo(w.y), bf_lo(r.y), sc[2], sh[2], sq[2]), brb(bf_hi(w.y), bf_hi(r.y), sc[3], sh[3], sq[3]));
+              w.z = pack_bf2(brb(bf_lo(w.z), bf_lo(r.z), sc[4], sh[4], sq[4]), brb(bf_hi(w.z), bf_hi(r.z), sc[5], sh[5], sq[5]));
+              w.w = pack_bf2(brb(bf_lo(w.w), bf_lo(r.w), sc[6], sh[6], sq[6]), brb(bf_hi(w.w), bf_hi(r.w), sc[7], sh[7], sq[7]));
             }
             *reinterpret_cast<pu32x4*>(smem + (uint32_t)pixs[u] * (uint32_t)S + (uint32_t)cg * 16u) = w;
           }
@@ -707,7 +733,7 @@ static bool try_geometry(const dfl_conv_args& a, ConvP* p, const TileCfg& t, int
   if (t.GA) {
     // streamed non-overlapping window (1x1 / stride 1, 2x2 / stride 2): no LDS image, no K slices; scored only by
     // measurement (tools/tune_convp.py)
-    if (a.KH != a.KW || a.stride != a.KH || a.KH > 2 || a.pad != 0 || a.in_scale != nullptr || want_splits > 1) return false;
+    if (a.KH != a.KW || a.stride != a.KH || a.KH > 2 || a.pad != 0 || a.in_scale != nullptr || a.x_mode != 0 || want_splits > 1) return false;
     p->CK = 16;
     p->nblk = a.Cin / 16;
     p->splits = 1;
@@ -889,7 +915,7 @@ static int convp_plan_search(const dfl_conv_args* a, ConvP* p, int force_splits)
   DFL_REQUIRE(a->Cin % 16 == 0 && a->ldx % 8 == 0 && aligned16(a->x) && aligned16(a->w),
               "dfl_conv2d (bf16): needs Cin %% 16 == 0, ldx %% 8 == 0 and 16-byte aligned x / w (Cin = %d, ldx = %d)", a->Cin, a->ldx);
   DFL_REQUIRE(a->w_split == 2, "dfl_conv2d (bf16): weights must be packed with dfl_pack_job.split = 2");
-  DFL_REQUIRE((a->in_scale == nullptr) == (a->in_shift == nullptr), "dfl_conv2d: in_scale/in_shift go together");
+  DFL_REQUIRE(a->x_mode != 0 || (a->in_scale == nullptr) == (a->in_shift == nullptr), "dfl_conv2d: in_scale/in_shift go together");
   DFL_REQUIRE((a->add_scale == nullptr) == (a->add_shift == nullptr), "dfl_conv2d: add_scale/add_shift go together");
   DFL_REQUIRE(a->KH * a->KW <= 16 && a->KH > 0 && a->KW > 0 && a->stride > 0 && a->pad >= 0, "dfl_conv2d (bf16): bad window");
   memset(p, 0, sizeof(*p));
@@ -921,6 +947,14 @@ static int convp_plan_search(const dfl_conv_args* a, ConvP* p, int force_splits)
   DFL_REQUIRE(xb < lim && wb < lim, "dfl_conv2d (bf16): tensors must stay below 2 GiB");
   p->x_bytes = (uint32_t)xb;
   p->w_bytes = (uint32_t)wb;
+  if (a->x_mode != 0) {
+    DFL_REQUIRE(a->x_mode == 1 && a->x2 != nullptr && a->in_shift == nullptr && a->ldx2 % 8 == 0 && aligned16(a->x2) &&
+                    (a->in_scale == nullptr || aligned16(a->in_scale)),
+                "dfl_conv2d (bf16): x_mode 1 needs x2 (16-byte aligned, ldx2 %% 8 == 0), coefficients in in_scale and no in_shift");
+    const int64_t x2b = (((int64_t)a->N * a->Hin * a->Win - 1) * a->ldx2 + a->Cin) * 2;
+    DFL_REQUIRE(x2b < lim, "dfl_conv2d (bf16): tensors must stay below 2 GiB");
+    p->x2_bytes = (uint32_t)x2b;
+  }
 
   // a forced geometry (dfl_conv_force_geometry: tuners, tests) or an entry of the tuning table (dfl_conv_tune_add) wins
   // over the cost model, as long as it is valid for this layer and agrees with the caller's K slices
@@ -1021,14 +1055,19 @@ static int convp_launch_t(const ConvP& p, hipStream_t s) {
   if (lds < epi) lds = epi;
   if (lds < red) lds = red;
   if constexpr (GA) {
-    hipLaunchKernelGGL((convp_kernel<WM, WN, TM, TN, false, true>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((convp_kernel<WM, WN, TM, TN, 0, true>), grid, dim3(256), lds, s, p);
+  } else if (p.a.x_mode != 0) {
+    auto k = convp_kernel<WM, WN, TM, TN, 2, false, KS>;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsHard);
+    (void)attr;
+    hipLaunchKernelGGL(k, grid, dim3(NT_), lds, s, p);
   } else if (aff) {
-    auto k = convp_kernel<WM, WN, TM, TN, true, false, KS>;
+    auto k = convp_kernel<WM, WN, TM, TN, 1, false, KS>;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsHard);
     (void)attr;                                      // (once per instantiation, not per launch)
     hipLaunchKernelGGL(k, grid, dim3(NT_), lds, s, p);
   } else {
-    auto k = convp_kernel<WM, WN, TM, TN, false, false, KS>;
+    auto k = convp_kernel<WM, WN, TM, TN, 0, false, KS>;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsHard);
     (void)attr;
     hipLaunchKernelGGL(k, grid, dim3(NT_), lds, s, p);

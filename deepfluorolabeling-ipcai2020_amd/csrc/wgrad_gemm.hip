@@ -657,6 +657,7 @@ extern "C" int dfl_wgrad_suggest_splits(const dfl_wgrad_args* a) {
 
 extern "C" int dfl_conv2d_wgrad(const dfl_wgrad_args* a, dfl_stream_t stream) {
   if (a != nullptr && a->g_bf16 && a->d_bf16) return dfl::wgradp_launch(a, static_cast<hipStream_t>(stream));
+  DFL_REQUIRE(a == nullptr || a->d_mode == 0, "dfl_conv2d_wgrad: d_mode (fused BatchNorm + ReLU backward operand) is implemented by the bf16 patch kernels only");
   dfl::WgK k;
   int rc = dfl::wg_prepare(a, &k, true);
   if (rc != DFL_OK) return rc;

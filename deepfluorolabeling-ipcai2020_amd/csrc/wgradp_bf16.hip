@@ -47,6 +47,7 @@ struct WgP {
   int kpipe;                           // fragments of the next k-step are fetched under the matrix instructions of this one
   long long* trace;                    // diagnosis build only (-DDFL_WGP_TRACE, tools/exp/wgradp_trace.py)
   uint32_t g_bytes, d_bytes;
+  uint32_t d2_bytes, pad0;             // extent of the second dense tensor (dfl_wgrad_args.d_mode)
 };
 
 __device__ __forceinline__ float wbf_lo(uint32_t w) { return __uint_as_float(w << 16); }
@@ -71,10 +72,13 @@ __device__ __forceinline__ bf16x8_t wtr_read8(const unsigned char* base, uint32_
 // Units (16 bytes) of the d / g images a workgroup may hold in flight in registers, per window height: the 3x3 kernel
 // (768 threads) fills a CU alone; the 2x2 and 1x1 kernels (512 / 256 threads) keep their register count at 128 so that
 // two / four workgroups share a CU and cover each other's barriers and load waits.
-__host__ __device__ constexpr int wgp_max_d_units(int KH) { return KH == 3 ? 2304 : 1024; }
-__host__ __device__ constexpr int wgp_max_g_units(int KH) { return KH == 3 ? 4608 : 2048; }
+// (dbrb: the fused BatchNorm + ReLU backward operand keeps TWO tensors of the d patch in flight: smaller patches pay for its registers)
+__host__ __device__ constexpr int wgp_max_d_units(int KH, bool dbrb = false) { return KH == 3 ? (dbrb ? 1536 : 2304) : 1024; }
+__host__ __device__ constexpr int wgp_max_g_units(int KH, bool dbrb = false) { return KH == 3 ? (dbrb ? 3072 : 4608) : 2048; }
 
-template <int KH, int KW, bool AFF>
+// DBRB: the dense operand is the BatchNorm + ReLU backward of (d = dy, d2 = r) formed while the patch is written to LDS
+// (dfl_wgrad_args.d_mode), and the column sums of it -- the layer's bias gradient -- leave with the slice (bias_partial).
+template <int KH, int KW, bool AFF, bool DBRB = false>
 __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const WgP p) {
   constexpr int NT = 256 * KH;
   constexpr int T = KH * KW;
@@ -92,6 +96,8 @@ __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const
 
   __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.d), 0, (int)p.d_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g), 0, (int)p.g_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsD2 = rsD;
+  if constexpr (DBRB) rsD2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.d2), 0, (int)p.d2_bytes, 0x00020000);
 
   f32x16 acc[KW];
 #pragma unroll
@@ -115,14 +121,17 @@ __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const
   // written to LDS after them.  Everything about a unit that does not depend on WHICH patch is staged is worked out once:
   // its position inside the patch (y | x << 12 | image << 24 | live << 31) and its byte offset from the patch origin;
   // per patch a unit costs a bounds test against the image and one add.
-  constexpr int MAXD = wgp_max_d_units(KH) / NT, MAXG = wgp_max_g_units(KH) / NT;   // host: P16 * dupp and npix_g * gupp stay below these
+  constexpr int MAXD = wgp_max_d_units(KH, DBRB) / NT, MAXG = wgp_max_g_units(KH, DBRB) / NT;   // host: P16 * dupp and npix_g * gupp stay below these
   wpu32x4 dreg[MAXD], greg[MAXG];
+  wpu32x4 d2reg[DBRB ? MAXD : 1];
+  float bsum = 0.f;                                               // DBRB: this thread's share of the bias gradient (one channel)
+  const bool bias_on = DBRB && a.bias_partial != nullptr && blockIdx.y == 0;
   uint32_t dpos[MAXD], gpos[MAXG];
   uint32_t gok = 0;
   const int ddk = NT >> p.dupp_shift, gdk = NT >> p.gupp_shift;
   const int dcq = tid & (dupp - 1), gcq = tid & (gupp - 1);
   const int dc = cm0 + dcq * 8, gc = cg0 + gcq * 8;
-  const uint32_t dpitch = (uint32_t)a.ldd * 2u, gpitch = (uint32_t)a.ldg * 2u;
+  const uint32_t dpitch = (uint32_t)a.ldd * 2u, gpitch = (uint32_t)a.ldg * 2u, d2pitch = (uint32_t)a.ldd2 * 2u;
   const int nd = (p.P16 * dupp + NT - 1) / NT, ng = (npix_g * gupp + NT - 1) / NT;   // units per thread actually in use (uniform)
   {
     const int PHW = p.PH * p.PW;
@@ -159,6 +168,16 @@ __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const
       aff[p.CGT + c] = (cg0 + c < a.Cg) ? a.in_shift[cg0 + c] : 0.f;
     }
   }
+  float* dco = aff + 2 * p.CGT;                                             // [3][CMT]: A, B, C of this tile's d channels
+  if constexpr (DBRB) {
+    for (int c = tid; c < p.CMT; c += NT) {
+      const bool live = a.coef != nullptr && cm0 + c < a.Cm;
+      dco[c] = live ? a.coef[cm0 + c] : 1.f;
+      dco[p.CMT + c] = live ? a.coef[a.Cm + cm0 + c] : 0.f;
+      dco[2 * p.CMT + c] = live ? a.coef[2 * a.Cm + cm0 + c] : 0.f;
+    }
+  }
+  if constexpr (AFF || DBRB) __syncthreads();             // the first commit() reads these tables
   auto issue = [&](int patch, bool live) {
     const int pg = patch / per_img, pr = patch - pg * per_img;
     const int ppy = pr / p.npx, ppx = pr - ppy * p.npx;
@@ -166,6 +185,7 @@ __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const
     const int nleft = live ? a.N - img0 : 0;                       // images of this patch that exist
     {   // d: rows = patch pixels in patch order (image, row, column), zeros beyond the patch / image
       const uint32_t base = (uint32_t)(((img0 * a.Hout + oy0) * a.Wout + ox0) * a.ldd + dc) * 2u;
+      const uint32_t base2 = DBRB ? (uint32_t)(((img0 * a.Hout + oy0) * a.Wout + ox0) * a.ldd2 + dc) * 2u : 0u;
 #pragma unroll
       for (int u = 0; u < MAXD; ++u) {
         if (u < nd) {
@@ -174,6 +194,10 @@ __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const
           const bool ok = (int)q < 0 && qi < nleft && oy0 + qy < a.Hout && ox0 + qx < a.Wout;
           const uint32_t rel = (uint32_t)((qi * a.Hout + qy) * a.Wout + qx) * dpitch;
           dreg[u] = __builtin_amdgcn_raw_buffer_load_b128(rsD, ok ? base + rel : WPOOB, 0, 0);
+          if constexpr (DBRB) {
+            const uint32_t rel2 = (uint32_t)((qi * a.Hout + qy) * a.Wout + qx) * d2pitch;
+            d2reg[u] = __builtin_amdgcn_raw_buffer_load_b128(rsD2, ok ? base2 + rel2 : WPOOB, 0, 0);
+          }
         }
       }
     }
@@ -198,7 +222,21 @@ __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const
 #pragma unroll
     for (int u = 0; u < MAXD; ++u) {
       const int k = (tid >> p.dupp_shift) + u * ddk;
-      if (u < nd && k < p.P16) *reinterpret_cast<wpu32x4*>(Ds + (uint32_t)k * (uint32_t)p.sd + (uint32_t)dcq * 16u) = dreg[u];
+      if (u < nd && k < p.P16) {
+        wpu32x4 v = dreg[u];
+        if constexpr (DBRB) {     // [r > 0] * (A dy + B r + C); rows outside the patch / image were loaded as zeros: r = 0, value 0
+          const wpu32x4 r = d2reg[u];
+          const float4 a0 = *reinterpret_cast<const float4*>(dco + dcq * 8), a1 = *reinterpret_cast<const float4*>(dco + dcq * 8 + 4);
+          const float4 b0 = *reinterpret_cast<const float4*>(dco + p.CMT + dcq * 8), b1 = *reinterpret_cast<const float4*>(dco + p.CMT + dcq * 8 + 4);
+          const float4 c0 = *reinterpret_cast<const float4*>(dco + 2 * p.CMT + dcq * 8), c1 = *reinterpret_cast<const float4*>(dco + 2 * p.CMT + dcq * 8 + 4);
+          auto brb = [](float dy, float rv, float A, float B, float Cc) { return rv > 0.f ? fmaf(A, dy, fmaf(B, rv, Cc)) : 0.f; };
+          v.x = wpack_bf2(brb(wbf_lo(v.x), wbf_lo(r.x), a0.x, b0.x, c0.x), brb(wbf_hi(v.x), wbf_hi(r.x), a0.y, b0.y, c0.y));
+          v.y = wpack_bf2(brb(wbf_lo(v.y), wbf_lo(r.y), a0.z, b0.z, c0.z), brb(wbf_hi(v.y), wbf_hi(r.y), a0.w, b0.w, c0.w));
+          v.z = wpack_bf2(brb(wbf_lo(v.z), wbf_lo(r.z), a1.x, b1.x, c1.x), brb(wbf_hi(v.z), wbf_hi(r.z), a1.y, b1.y, c1.y));
+          v.w = wpack_bf2(brb(wbf_lo(v.w), wbf_lo(r.w), a1.z, b1.z, c1.z), brb(wbf_hi(v.w), wbf_hi(r.w), a1.w, b1.w, c1.w));
+        }
+        *reinterpret_cast<wpu32x4*>(Ds + (uint32_t)k * (uint32_t)p.sd + (uint32_t)dcq * 16u) = v;
+      }
     }
 #pragma unroll
     for (int u = 0; u < MAXG; ++u) {
@@ -250,6 +288,15 @@ __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const
     WT0(ti0)
     issue(patch + 1, patch + 1 < pend);
     WTR(3, ti0)
+    if constexpr (DBRB) {
+      // bias gradient: column sums of the d image as stored -- thread t owns channel t % CMT and every (NT / CMT)-th pixel row
+      // (rows beyond the patch are zero); one accumulator register instead of eight in the staging path
+      if (bias_on) {
+        const int bc = tid & (p.CMT - 1), bstride = NT / p.CMT;
+        for (int r = tid / p.CMT; r < p.P16; r += bstride)
+          bsum += __uint_as_float((uint32_t)*reinterpret_cast<const unsigned short*>(Ds + (uint32_t)r * (uint32_t)p.sd + (uint32_t)bc * 2u) << 16);
+      }
+    }
     WT0(tk0)
     // ---- k-steps of this patch (16 pixels each), this wave's phase; this lane's two pixel rows of a step are the
     //      patch pixels j0 = 16 ks + trow and j0 + 4: their d rows are j0 * sd, their g rows come from the offset table
@@ -271,6 +318,21 @@ __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const
 #ifdef DFL_WGP_TRACE
   tr[5] = __builtin_amdgcn_s_memtime();
 #endif
+
+  // ---- bias gradient of this pixel slice (DBRB): the threads that staged the same 8 channels add up through LDS, fixed order
+  if constexpr (DBRB) {
+    if (a.bias_partial != nullptr && blockIdx.y == 0) {
+      __syncthreads();
+      float* bred = reinterpret_cast<float*>(smem);     // [NT]
+      bred[tid] = bsum;
+      __syncthreads();
+      for (int c = tid; c < p.CMT; c += NT) {
+        float t = 0.f;
+        for (int th = c; th < NT; th += p.CMT) t += bred[th];
+        if (cm0 + c < a.Cm) a.bias_partial[(int64_t)blockIdx.z * a.Cm + cm0 + c] = t;
+      }
+    }
+  }
 
   // ---- waves that split the k-steps of the patches (phases > 1) add their accumulators through LDS, tap by tap, in a
   //      fixed order; the waves of phase 0 then own the workgroup's result for their (cm, cg) pair and kernel row
@@ -363,6 +425,13 @@ static int wgp_plan(const dfl_wgrad_args* a, WgP* p, bool need_out) {
   DFL_REQUIRE(gb < lim && db < lim, "dfl_conv2d_wgrad (bf16): tensors must stay below 2 GiB");
   p->g_bytes = (uint32_t)gb;
   p->d_bytes = (uint32_t)db;
+  if (a->d_mode != 0) {
+    DFL_REQUIRE(a->d_mode == 1 && a->KH == 3 && a->d2 != nullptr && a->ldd2 % 8 == 0 && aligned16(a->d2),
+                "dfl_conv2d_wgrad (bf16): d_mode 1 needs a 3x3 window and d2 (16-byte aligned, ldd2 %% 8 == 0)");
+    const int64_t d2b = ((M - 1) * a->ldd2 + a->Cm) * 2;
+    DFL_REQUIRE(d2b < lim, "dfl_conv2d_wgrad (bf16): tensors must stay below 2 GiB");
+    p->d2_bytes = (uint32_t)d2b;
+  }
   // workgroup tile and wave roles
   p->CMT = a->Cm > 32 ? 64 : 32;
   p->CGT = a->Cg > 32 ? 64 : 32;
@@ -389,7 +458,7 @@ static int wgp_plan(const dfl_wgrad_args* a, WgP* p, bool need_out) {
   // (halo and the padding of the last 16-pixel step included) plus a fixed charge per patch for its two barriers and the
   // pipeline bubble -- within what a thread can hold in flight (2048 / 4096 sixteen-byte units of d / g per workgroup)
   // and the LDS budget.  Whole images are grouped while they fit.
-  const int64_t max_du = wgp_max_d_units(a->KH), max_gu = wgp_max_g_units(a->KH);
+  const int64_t max_du = wgp_max_d_units(a->KH, a->d_mode != 0), max_gu = wgp_max_g_units(a->KH, a->d_mode != 0);
   static const int lds_env = [] {
     const char* e = getenv("DFL_WGP_LDS_KB");
     return e ? atoi(e) * 1024 : 0;
@@ -413,7 +482,7 @@ static int wgp_plan(const dfl_wgrad_args* a, WgP* p, bool need_out) {
   struct PatchMemo { int key[8]; int ipp, ph, pw; };
   static std::mutex memo_mu;
   static std::vector<PatchMemo> memo;
-  const int mkey[8] = {a->N, a->Hout, a->Wout, a->stride, a->KH, a->KW, p->CMT, p->CGT};
+  const int mkey[8] = {a->N, a->Hout, a->Wout, a->stride, a->KH + 16 * (a->d_mode != 0 ? 1 : 0), a->KW, p->CMT, p->CGT};
   bool found = false;
   {
     std::lock_guard<std::mutex> lock(memo_mu);
@@ -470,7 +539,8 @@ static int wgp_plan(const dfl_wgrad_args* a, WgP* p, bool need_out) {
   }();
   p->kpipe = kpipe;
   p->tab_off = (p->g_off + ipp * p->IH * p->IW * p->sg + 255) / 256 * 256;
-  p->lds_bytes = p->tab_off + p->P16 * 4 + 2 * p->CGT * 4;
+  p->lds_bytes = p->tab_off + p->P16 * 4 + 2 * p->CGT * 4 + 3 * p->CMT * 4;
+  if (a->d_mode != 0 && p->lds_bytes < 256 * a->KH * 4) p->lds_bytes = 256 * a->KH * 4;   // room for the bias-gradient sums
   const int red_bytes = (p->phases - 1) * p->pairs * a->KH * 16 * 64 * 4;   // room for the cross-phase sums
   if (p->lds_bytes < red_bytes) p->lds_bytes = red_bytes;
   return DFL_OK;
@@ -516,17 +586,22 @@ template <int KH, int KW>
 static int wgp_launch_t(const WgP& p, hipStream_t s) {
   dim3 grid((unsigned)ceil_div(p.a.Cm, p.CMT), (unsigned)ceil_div(p.a.Cg, p.CGT), (unsigned)p.zslices);
   const size_t lds = (size_t)p.lds_bytes;
-  if (p.a.in_scale != nullptr) {
-    auto k = wgradp_kernel<KH, KW, true>;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    (void)attr;                                          // (once per instantiation, not per launch)
-    hipLaunchKernelGGL(k, grid, dim3(256 * KH), lds, s, p);
-  } else {
-    auto k = wgradp_kernel<KH, KW, false>;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    (void)attr;
-    hipLaunchKernelGGL(k, grid, dim3(256 * KH), lds, s, p);
+#define DFL_WGP_LAUNCH(AFF_, DBRB_)                                                                                              \
+  {                                                                                                                              \
+    auto k = wgradp_kernel<KH, KW, AFF_, DBRB_>;                                                                                 \
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+    (void)attr;                                          /* (once per instantiation, not per launch) */                         \
+    hipLaunchKernelGGL(k, grid, dim3(256 * KH), lds, s, p);                                                                      \
   }
+  const bool aff = p.a.in_scale != nullptr;
+  if constexpr (KH == 3) {
+    if (p.a.d_mode != 0) {
+      if (aff) DFL_WGP_LAUNCH(true, true) else DFL_WGP_LAUNCH(false, true)
+      return check_launch("dfl_conv2d_wgrad (bf16)");
+    }
+  }
+  if (aff) DFL_WGP_LAUNCH(true, false) else DFL_WGP_LAUNCH(false, false)
+#undef DFL_WGP_LAUNCH
   return check_launch("dfl_conv2d_wgrad (bf16)");
 }
 

@@ -209,7 +209,7 @@ class UNetPlan:
 
     # ------------------------------------------------------------------------------------------ op helpers
     def _conv(self, prog, x, w, y, KH, KW, stride, pad, Ntot, bias=None, in_aff=None, relu=0, add=None,
-              add_aff=None, accumulate=0, scatter=0, stats=False, stat_other=None, Hout=None, Wout=None, x_split=0):
+              add_aff=None, accumulate=0, scatter=0, stats=False, stat_other=None, Hout=None, Wout=None, x_split=0, brb=None):
         a = ConvArgs()
         a.x, a.w, a.y = x.ptr, w.data_ptr(), y.ptr
         a.w_split = self._packed_split.get(w.data_ptr(), 0)
@@ -220,6 +220,11 @@ class UNetPlan:
         a.bias = nat.ptr(bias)
         if in_aff is not None:
             a.in_scale, a.in_shift = in_aff[0].data_ptr(), in_aff[1].data_ptr()
+        if brb is not None:
+            # the operand is the BatchNorm + ReLU backward of (x = dy, r) formed while the patch is staged (dfl_conv_args.x_mode)
+            r_act, coef = brb
+            a.x_mode, a.x2, a.ldx2 = 1, r_act.ptr, r_act.ld
+            a.in_scale = nat.ptr(coef)
         if add is not None:
             a.add, a.ldadd = add.ptr, add.ld
             if add_aff is not None:
@@ -260,7 +265,8 @@ class UNetPlan:
             e['waited'] = len(prog.structs)
             prog.wait(e['done'], stream=0)
 
-    def _wgrad(self, prog, g, d, dw, KH, KW, stride, pad, Hout, Wout, in_aff=None, side=False, side_buf=None, d_split=0):
+    def _wgrad(self, prog, g, d, dw, KH, KW, stride, pad, Hout, Wout, in_aff=None, side=False, side_buf=None, d_split=0, brb=None,
+               bias_out=None):
         a = WgradArgs()
         a.d_split = d_split
         a.g_bf16, a.d_bf16 = g.bf16, d.bf16
@@ -270,9 +276,17 @@ class UNetPlan:
         a.N, a.Hin, a.Win, a.Cg, a.ldg = g.N, g.H, g.W, g.C, g.ld
         a.KH, a.KW, a.stride, a.pad = KH, KW, stride, pad
         a.Hout, a.Wout, a.Cm, a.ldd = Hout, Wout, d.C, d.ld
+        if brb is not None:
+            r_act, coef = brb                       # d = dy; the operand is formed from (dy, r) while the patch is staged (d_mode)
+            a.d_mode, a.d2, a.ldd2, a.coef = 1, r_act.ptr, r_act.ld, nat.ptr(coef)
         a.splits = 1
         s = nat.check(self.lib.dfl_wgrad_suggest_splits(C.addressof(a)), 'dfl_wgrad_suggest_splits')
         a.splits = s
+        if brb is not None and bias_out is not None:
+            # the column sums of that operand = the layer's bias gradient, one row per pixel slice
+            bpart = self._new(s * d.C)
+            a.bias_partial = bpart.data_ptr()
+            self._defer_sum(prog, bpart.data_ptr(), bias_out.data_ptr(), d.C, d.C, s)
         n = d.C * g.C * KH * KW
         if s > 1:
             big = 4 * n >= self.FLUSH_BYTES
@@ -298,6 +312,7 @@ class UNetPlan:
     # and one dfl_reduce_batch finishes the queue once FLUSH_BYTES of gradient are waiting (and at the end of backward).
     FLUSH_BYTES = int(float(os.environ.get('DFL_FLUSH_MB', '16')) * (1 << 20))   # (4 / 16 / 64 MB measured: 0.414 / 0.373 / 0.367 ms of sums per step)
     FUSE_BWD_STATS = os.environ.get('DFL_FUSE_BWD_STATS', '1') != '0'
+    FUSE_BRB = os.environ.get('DFL_FUSE_BRB', '1') != '0'      # BatchNorm + ReLU backward inside the weight-/data-gradient staging (bf16 storage)
     RES_DGRAD_LAST = os.environ.get('DFL_RES_DGRAD_LAST', '1') != '0'   # residual 1x1 data gradient accumulates onto the 3x3 one (not the reverse)
     FUSE_COLSUMS = FUSE_BWD_STATS and os.environ.get('DFL_FUSE_COLSUMS', '1') != '0'   # sums across block boundaries (see the backward program)
 
@@ -326,6 +341,15 @@ class UNetPlan:
         self._red_flushes.append((len(prog.structs), [j[1] for j in jobs]))
         prog.add(ReduceBatchArgs(jobs_dev=dev.data_ptr(), njobs=len(jobs), total_blocks=blocks))
         self._red_pending, self._red_bytes = [], 0
+
+    def _dz_for(self, g, N, H, W, Cc, fused):
+        """Scratch for the data gradient a layer hands to the layer below.  With the BatchNorm + ReLU backward folded into the
+        data-gradient kernel that kernel READS the incoming gradient g while it writes: never the same buffer -- 'dz' and 'dpre0'
+        (idle in that mode) alternate."""
+        key = 'dz'
+        if fused and g.t is self._scratch.get('dz'):
+            key = 'dpre0'
+        return self._scratch_act(key, N, H, W, Cc)
 
     def _shared_scratch(self, key, nelem):
         t = self._scratch.get(key)
@@ -581,24 +605,35 @@ class UNetPlan:
                                             2 * Cout, prow)
                     elif do_res and d == bd - 1:
                         self._colsum(bwd, g, G[prefix + '.res_conv1x1.bias'])
-                    bpart = self._new(nb * Cout)
                     inp = cv['inp']
-                    # dpre feeds exactly two GEMMs (weight gradient: dense operand; data gradient: gathered operand);
-                    # with split-bf16 products it is written split once here instead of being split by every tile of both
-                    dsplit = int(self.math in (1, 3) and Cout % 16 == 0 and inp.C % 4 == 0 and inp.C * 9 > 12 and self.DSPLIT)
-                    bwd.add(BnReluBwdArgs(dy=g.ptr, r=r.ptr, coef=nat.ptr(coef), dpre=dpre.ptr,
-                                          partials=bpart.data_ptr(), M=r.M, C=Cout, lddy=g.ld, ldr=r.ld, ldo=dpre.ld,
-                                          nblocks=nb, split_out=dsplit, bf16=r.bf16))
-                    self._defer_sum(bwd, bpart.data_ptr(), G[cv['wname'] + '.bias'].data_ptr(), Cout, Cout, nb)
+                    # BatchNorm + ReLU backward folded into its two consumers (bf16 patch kernels; round 3): the weight-gradient
+                    # and data-gradient kernels form [r > 0] * (A dy + B r + C) from (dy, r) while they stage their patches --
+                    # dpre is never written (one tensor pass and one launch per layer less), the bias-gradient sums come out
+                    # of the weight-gradient kernel.  The 1-channel first layer (direct kernels) keeps the materialised form.
+                    fuse_brb = self.FUSE_BRB and not self.SIDE_STREAM and bool(r.bf16) and bool(inp.bf16) and inp.C % 16 == 0 and g.bf16 == r.bf16
+                    brb = (r, coef) if fuse_brb else None
+                    dsplit = 0
+                    if fuse_brb:
+                        dpre = g                          # what the consumers are given as their "d" / "x": dy itself
+                    else:
+                        bpart = self._new(nb * Cout)
+                        # dpre feeds exactly two GEMMs (weight gradient: dense operand; data gradient: gathered operand);
+                        # with split-bf16 products it is written split once here instead of being split by every tile of both
+                        dsplit = int(self.math in (1, 3) and Cout % 16 == 0 and inp.C % 4 == 0 and inp.C * 9 > 12 and self.DSPLIT)
+                        bwd.add(BnReluBwdArgs(dy=g.ptr, r=r.ptr, coef=nat.ptr(coef), dpre=dpre.ptr,
+                                              partials=bpart.data_ptr(), M=r.M, C=Cout, lddy=g.ld, ldr=r.ld, ldo=dpre.ld,
+                                              nblocks=nb, split_out=dsplit, bf16=r.bf16))
+                        self._defer_sum(bwd, bpart.data_ptr(), G[cv['wname'] + '.bias'].data_ptr(), Cout, Cout, nb)
                     self._wgrad(bwd, cv['gin'], dpre, G[cv['wname'] + '.weight'], 3, 3, 1, 0 if circ else pad, r.H, r.W,
-                                in_aff=cv['inp_aff'], side=side, side_buf=self._dpre_turn, d_split=dsplit)
+                                in_aff=cv['inp_aff'], side=side, side_buf=self._dpre_turn, d_split=dsplit, brb=brb,
+                                bias_out=G[cv['wname'] + '.bias'])
                     if circ and (d > 0 or dxin is not None):
                         # data gradient on the framed grid, folded back onto the pixels the frame copies (see _wrap_pad)
                         wd = self._pack_conv_dgrad(cv['w'])
                         dzp = self._framed_grad(inp)
-                        self._conv(bwd, dpre, wd, dzp, 3, 3, 1, 2, inp.C, x_split=dsplit)
+                        self._conv(bwd, dpre, wd, dzp, 3, 3, 1, 2, inp.C, x_split=dsplit, brb=brb)
                         if d > 0:
-                            dz = self._scratch_act('dz', N, inp.H, inp.W, Cout)
+                            dz = self._dz_for(g, N, inp.H, inp.W, Cout, fuse_brb)
                             self._wrap_fold(bwd, dzp, dz)
                             fused = None
                             g = dz
@@ -609,22 +644,22 @@ class UNetPlan:
                                                        accumulate=1, stats=dxin_stats and self.FUSE_COLSUMS)
                     elif d > 0:
                         wd = self._pack_conv_dgrad(cv['w'])
-                        dz = self._scratch_act('dz', N, inp.H, inp.W, Cout)
+                        dz = self._dz_for(g, N, inp.H, inp.W, Cout, fuse_brb)
                         prev = convs[d - 1]
                         if prev['bn'] is not None and self.FUSE_BWD_STATS:
                             # the data-gradient conv leaves sum(dz), sum(dz*r) per channel for the next BN backward
                             fused = self._conv(bwd, dpre, wd, dz, 3, 3, 1, 2 - pad, Cout, stats=True, stat_other=prev['r'],
-                                               x_split=dsplit)
+                                               x_split=dsplit, brb=brb)
                         else:
                             fused = None
-                            self._conv(bwd, dpre, wd, dz, 3, 3, 1, 2 - pad, Cout, x_split=dsplit)
+                            self._conv(bwd, dpre, wd, dz, 3, 3, 1, 2 - pad, Cout, x_split=dsplit, brb=brb)
                         g = dz
                     elif dxin is not None:
                         wd = self._pack_conv_dgrad(cv['w'])
                         want = dxin_stats and self.FUSE_COLSUMS
                         dxin_part = self._conv(bwd, dpre, wd, dxin, 3, 3, 1, 2 - pad, xin.C,
                                                accumulate=1 if (do_res and not res_dgrad_last) else 0,
-                                               x_split=dsplit, stats=want and not res_dgrad_last)
+                                               x_split=dsplit, stats=want and not res_dgrad_last, brb=brb)
                         if res_dgrad_last:
                             dxin_part = self._conv(bwd, dout, self._pack_conv_dgrad(rw), dxin, 1, 1, 1, 0, xin.C,
                                                    accumulate=1, stats=want)

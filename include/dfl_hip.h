@@ -96,6 +96,12 @@ typedef struct {
    * y_bf16: y, add and stat_other are bf16 (values are rounded once, statistics are taken from the rounded values).
    * The direct small-K kernels (Cin <= 4: the network's first layer) take x_bf16 = 0, y_bf16 = 1. */
   int32_t x_bf16, y_bf16;
+  /* BatchNorm + ReLU backward fused into the operand (bf16 patch kernels, x_mode = 1): x is dy, x2 the saved ReLU output r
+   * (same shape, pixel stride ldx2) and the convolution's operand is  [r > 0] * (A*dy + B*r + C)  with A, B, C = in_scale[0..C),
+   * [C..2C), [2C..3C) -- the coefficients dfl_bn_bwd_finalize leaves (in_scale NULL: plain ReLU backward [r > 0] * dy; in_shift
+   * must be NULL).  What dfl_bn_relu_bwd_apply would materialise is never written: one tensor pass and one launch per layer less. */
+  const float* x2;
+  int32_t ldx2, x_mode;
 } dfl_conv_args;
 
 int dfl_conv2d(const dfl_conv_args* a, dfl_stream_t stream);
@@ -143,7 +149,15 @@ typedef struct {
   int32_t d_split;       /* d is a split tensor (see dfl_conv_args.x_split); math mode 1 fast path only */
   int32_t g_bf16, d_bf16;/* g / d are bf16 tensors (math mode 4; csrc/wgradp_bf16.hip when both are; the direct small-K
                             kernels take g_bf16 = 0, d_bf16 = 1) */
-  int32_t reserved;
+  /* BatchNorm + ReLU backward fused into the dense operand (bf16 patch kernels, d_mode = 1): d is dy, d2 the saved ReLU output
+   * r (pixel stride ldd2), coef the [3][Cm] coefficients of dfl_bn_bwd_finalize (NULL: plain ReLU backward) and the operand is
+   * [r > 0] * (A*dy + B*r + C), as dfl_conv_args.x_mode.  bias_partial (optional): [splits][Cm] fp32 -- the column sums of that
+   * operand over each pixel slice, i.e. the partial sums of the layer's BIAS gradient that dfl_bn_relu_bwd_apply used to leave. */
+  int32_t d_mode;
+  const float* d2;
+  const float* coef;
+  float* bias_partial;
+  int32_t ldd2, reserved2;
 } dfl_wgrad_args;
 
 int dfl_conv2d_wgrad(const dfl_wgrad_args* a, dfl_stream_t stream);

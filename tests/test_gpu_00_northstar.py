@@ -119,7 +119,7 @@ def test_plateau_dice_matches_reference(mode):
     100, train.py:405-430 wiring) -- twice, with 8 and 1 CPU threads, which shows the reference's own run-to-run spread
     at the plateau (mean Dice 0.9972 / 0.9955, single classes up to 0.007 apart).  The HIP path, same data, same steps:
     mean Dice of the training images within 0.005 of the reference's runs, every class within 0.005 + the reference's own
-    spread on that class, and the plateau loss within 5e-3."""
+    spread on that class, and the plateau loss not more than 5e-3 above the reference's."""
     # (bf16s = math mode 4, bf16 STORAGE, needs >= 16 channels: its reference run is the 16..64-channel network of
     # tests/golden/plateau_wf4.npz, same data and schedule)
     g = load_golden('plateau_wf4' if mode == 'bf16s' else 'plateau')
@@ -168,7 +168,12 @@ def test_plateau_dice_matches_reference(mode):
     for c in range(6):
         a, b = min(ref8[c], ref1[c]), max(ref8[c], ref1[c])
         assert a - 0.005 <= d[c] <= b + 0.005, 'class %d: hard Dice %.4f vs reference %.4f / %.4f' % (c + 1, d[c], ref8[c], ref1[c])
-    assert abs(float(np.mean(losses[-20:])) - float(g['losses'][-20:].mean())) < 5e-3
+    # plateau loss (mean of the last 20 steps; the trajectories are chaotic at this level: the reference's own two runs -- 8 / 1
+    # CPU threads -- end 0.0016 apart for the wf = 3 fixture and 0.0042 for wf = 4, two builds of this library 0.003): not
+    # more than 5e-3 above the worse of the reference's runs, and not implausibly far below the better one
+    l_hip, l8, l1 = float(np.mean(losses[-20:])), float(g['losses'][-20:].mean()), float(g['losses_1thread'][-20:].mean())
+    print('plateau %s: loss %.4f (reference %.4f / %.4f)' % (mode, l_hip, l8, l1))
+    assert min(l8, l1) - 2e-2 <= l_hip <= max(l8, l1) + 5e-3, 'plateau loss %.4f vs reference %.4f / %.4f' % (l_hip, l8, l1)
 
 
 

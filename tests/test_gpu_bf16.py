@@ -89,7 +89,7 @@ def test_pack_bf16_chunk_layout():
 
 
 def conv_bf16(x, wp, Ntot, KH, KW, stride, pad, Hout, Wout, bias=None, in_aff=None, relu=0, add=None, add_aff=None,
-              y_init=None, accumulate=0, scatter=0, stats=False, stat_other=None, ldy=None, ldx_pad=0, force_splits=None):
+              y_init=None, accumulate=0, scatter=0, stats=False, stat_other=None, ldy=None, ldx_pad=0, force_splits=None, brb=None):
     """x: NCHW fp32 cpu tensor (bf16-representable) -> dfl_conv2d with bf16 tensors -> y NHWC fp32 cpu tensor (+ stats)."""
     lib = nat.lib()
     N, Cin, Hin, Win = x.shape
@@ -126,6 +126,15 @@ def conv_bf16(x, wp, Ntot, KH, KW, stride, pad, Hout, Wout, bias=None, in_aff=No
             asc, ash = add_aff[0].to(DEV), add_aff[1].to(DEV)
             keep += [asc, ash]
             a.add_scale, a.add_shift = asc.data_ptr(), ash.data_ptr()
+    if brb is not None:                                 # x is dy; operand = [r > 0] * (A dy + B r + C) formed in the staging (x_mode)
+        r_, coef = brb
+        rd = F.pad(nhwc(r_), (0, 8)).to(DEV).to(BF).contiguous()       # (its own pixel stride)
+        keep.append(rd)
+        a.x_mode, a.x2, a.ldx2 = 1, rd.data_ptr(), rd.shape[-1]
+        if coef is not None:
+            cd = coef.to(DEV).contiguous()
+            keep.append(cd)
+            a.in_scale = cd.data_ptr()
     a.N, a.Hin, a.Win, a.Cin, a.ldx = N, Hin, Win, Cin, Cin + ldx_pad
     a.KH, a.KW, a.stride, a.pad = KH, KW, stride, pad
     a.Hout, a.Wout, a.Ntot, a.ldy = Hout, Wout, Ntot, ldy
@@ -386,7 +395,7 @@ def test_convp_transposed_scatter_and_data_gradients():
     close_bf16(du, nhwc(ref_du), 'dgrad convT')
 
 
-def wgrad_bf16(gx, d, KH, KW, stride, pad, Hout, Wout, in_aff=None, force_splits=None):
+def wgrad_bf16(gx, d, KH, KW, stride, pad, Hout, Wout, in_aff=None, force_splits=None, brb=None):
     """gx: gathered tensor NCHW, d: dense NCHW (both bf16-representable) -> dw [Cm][Cg][KH][KW] fp32 (cpu)."""
     lib = nat.lib()
     N, Cg, Hin, Win = gx.shape
@@ -405,9 +414,22 @@ def wgrad_bf16(gx, d, KH, KW, stride, pad, Hout, Wout, in_aff=None, force_splits
     a.N, a.Hin, a.Win, a.Cg, a.ldg = N, Hin, Win, Cg, Cg
     a.KH, a.KW, a.stride, a.pad = KH, KW, stride, pad
     a.Hout, a.Wout, a.Cm, a.ldd = Hout, Wout, Cm, Cm
+    if brb is not None:                                 # d is dy; operand = [r > 0] * (A dy + B r + C) formed in the staging (d_mode)
+        r_, coef = brb
+        rd = F.pad(nhwc(r_), (0, 8)).to(DEV).to(BF).contiguous()
+        keep.append(rd)
+        a.d_mode, a.d2, a.ldd2 = 1, rd.data_ptr(), rd.shape[-1]
+        if coef is not None:
+            cd = coef.to(DEV).contiguous()
+            keep.append(cd)
+            a.coef = cd.data_ptr()
     a.splits = 1
     s = force_splits or nat.check(lib.dfl_wgrad_suggest_splits(C.addressof(a)), 'suggest')
     a.splits = s
+    bias_part = None
+    if brb is not None:
+        bias_part = torch.full((s, Cm), float('nan'), device=DEV)
+        a.bias_partial = bias_part.data_ptr()
     n = Cm * Cg * KH * KW
     if s > 1:
         part = torch.full((s * n,), float('nan'), device=DEV)
@@ -418,7 +440,50 @@ def wgrad_bf16(gx, d, KH, KW, stride, pad, Hout, Wout, in_aff=None, force_splits
     if s > 1:
         nat.check(lib.dfl_sum_partials(part.data_ptr(), dw.data_ptr(), n, s, KH * KW, stream()), 'dfl_sum_partials')
     torch.cuda.synchronize()
+    if brb is not None:
+        return dw.cpu(), bias_part.cpu().double().sum(0)
     return dw.cpu()
+
+
+def brb_reference(dy, r, coef):
+    """d(pre-activation) of BatchNorm + ReLU backward as the kernels form it: fp32 arithmetic on bf16 values, rounded to bf16."""
+    if coef is None:
+        return rb(torch.where(r > 0, dy, torch.zeros(())))
+    A, B, Cc = (coef[i].view(1, -1, 1, 1).double() for i in range(3))
+    t = (B * r.double() + Cc).float()                       # fmaf(B, r, C): one rounding (the fp64 sum of an fp32 product is exact here)
+    v = (A * dy.double() + t.double()).float()              # fmaf(A, dy, t)
+    return rb(torch.where(r > 0, v, torch.zeros(())))
+
+
+@pytest.mark.parametrize('case', [(2, 32, 32, 20, 20), (2, 64, 128, 12, 12), (4, 256, 256, 6, 6), (3, 128, 64, 9, 7), (2, 32, 32, 96, 96),
+                                  (2, 32, 32, 192, 192), (2, 64, 64, 96, 96)])
+@pytest.mark.parametrize('with_bn', [True, False])
+def test_fused_bn_relu_backward_operand(case, with_bn):
+    """dfl_conv_args.x_mode / dfl_wgrad_args.d_mode: the data-gradient convolution and the weight gradient form
+    [r > 0] * (A dy + B r + C) from (dy, r) while they stage their patches -- what dfl_bn_relu_bwd_apply would have written to
+    HBM -- and the weight gradient leaves the column sums of it (the bias gradient).  Against fp64 on the bf16-rounded operand."""
+    N, Cin, Cout, H, W = case
+    g = torch.Generator().manual_seed(sum(case) + 5)
+    dy = rb(torch.randn(N, Cin, H, W, generator=g))
+    r = rb(torch.relu(torch.randn(N, Cin, H, W, generator=g)))
+    coef = torch.stack([torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3, torch.randn(Cin, generator=g) * 0.1]) if with_bn else None
+    dpre = brb_reference(dy, r, coef)
+    # data gradient: a 3x3 convolution over dpre (zero padding applies to dpre: outside pixels contribute nothing)
+    w = rb(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)
+    ref = F.conv2d(dpre.double(), w.double(), padding=1)
+    for splits in (None, 2 if Cin >= 128 else None):
+        y = conv_bf16(dy, pack16(w, 1), Cout, 3, 3, 1, 1, H, W, brb=(r, coef), force_splits=splits)
+        close_bf16(y, nhwc(ref), 'x_mode %s splits %s' % (str(case), splits))
+    # weight gradient with dpre as the dense operand + the bias gradient
+    x = rb(torch.randn(N, Cout, H, W, generator=g))                  # the layer input (gathered operand), Cg = Cout here
+    refb = dpre.double().sum(dim=(0, 2, 3))
+    sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.3
+    for in_aff in (None, (sc, sh)):                                   # ... without / with the BatchNorm affine on the gathered operand
+        xa = x if in_aff is None else rb((x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)).float())   # fmaf: one rounding
+        dw, bias = wgrad_bf16(x, dy, 3, 3, 1, 1, H, W, brb=(r, coef), in_aff=in_aff)
+        refw = torch.nn.grad.conv2d_weight(xa.double(), (Cin, Cout, 3, 3), dpre.double(), padding=1)
+        np.testing.assert_allclose(dw.numpy(), refw.numpy(), rtol=2e-5, atol=3e-5 * float(refw.abs().max()))
+        np.testing.assert_allclose(bias.numpy(), refb.numpy(), rtol=2e-5, atol=3e-5 * float(dpre.double().abs().sum(dim=(0, 2, 3)).max()))
 
 
 WCASES = [
