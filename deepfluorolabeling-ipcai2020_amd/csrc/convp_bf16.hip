@@ -38,6 +38,9 @@
 namespace dfl {
 
 constexpr uint32_t POOB = 0x80000000u;
+#ifndef DFL_BRB_U
+#define DFL_BRB_U 4
+#endif
 typedef unsigned int pu32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
@@ -272,7 +275,7 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : 2) c
       int iy = rem / p.IW, ix = rem - iy * p.IW;
       const int ybase = gy0 * a.stride - a.pad, xbase = gx0 * a.stride - a.pad;
       const uint32_t cbyte = (uint32_t)((c0 + cg * 8) * 2);
-      constexpr int U = AFF == 2 ? 4 : 8;          // loads in flight per thread (two tensors in mode 2)
+      constexpr int U = AFF == 2 ? DFL_BRB_U : 8;  // loads in flight per thread (two tensors in mode 2)
       for (; pix < npix; pix += U * dpix) {
         pu32x4 v[U], v2[AFF == 2 ? U : 1];
         bool ok[U];
