@@ -62,6 +62,12 @@ __device__ __forceinline__ float ld_bf(const __bf16* p) { return (float)*p; }
 // the threads, and -- unlike more K slices -- no partial sums go through HBM.
 // AFF: what happens to an input unit on its way into the LDS image -- 0: nothing; 1: BatchNorm affine (scale, shift); 2: BatchNorm +
 // ReLU backward (dfl_conv_args.x_mode): x is dy, x2 the saved ReLU output r, the staged value [r > 0] * (A dy + B r + C).
+#ifndef DFL_CONVP_G1
+#define DFL_CONVP_G1 4
+#endif
+#ifndef DFL_CONVP_PRIME
+#define DFL_CONVP_PRIME 0   // 1: request a block's first two weight groups before its image is staged.  Measured (round 3): 20-30
+#endif                      // more registers live across the staging, 4.75 -> 4.84 ms/step; six k-steps per ring set: 4.87
 template <int WM, int WN, int TM, int TN, int AFF, bool GA, int KS = 1>
 __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : 2) convp_kernel(const ConvP p) {
   static_assert(WM * WN == 4, "four waves per k-group");
@@ -240,10 +246,32 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : 2) c
       }
     }
   } else {
+  // B fragments ride a ring of three register sets, loaded two groups (2 G k-steps) ahead of their use.
+  constexpr int G = TN == 1 ? DFL_CONVP_G1 : 2;    // k-steps per ring set (the ring holds 3 * G * TN fragments)
+  const int ngroups_all = (S_steps + G - 1) / G;
+  // k-group kg takes the ring groups kg, kg + KS, ...: local group gl is global group gl * KS + kg
+  const int ngroups = (ngroups_all - kg + KS - 1) / KS;
+  pu32x4 breg[3][G][TN];
+  auto load_group = [&](int blk, int gl, int set) {
+    const int g = gl * KS + kg;
+#pragma unroll
+    for (int e = 0; e < G; ++e) {
+      const int s = g * G + e;
+      const bool live = gl < ngroups && s < S_steps;
+      const int tap = s >> ckc_sh, cc = s & (CKC - 1);
+      const uint32_t soff = live ? (uint32_t)((tap * cin_chunks + blk * CKC + cc)) * (uint32_t)a.Ntot * 32u : 0u;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) breg[set][e][j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, live ? b_voff[j] : POOB, soff, 0);
+    }
+  };
   const int blk_begin = bslice * p.blk_per_slice;
   const int blk_end = min(blk_begin + p.blk_per_slice, p.nblk);
   for (int blk = blk_begin; blk < blk_end; ++blk) {
     const int c0 = blk * p.CK;
+    if (DFL_CONVP_PRIME) {
+      load_group(blk, 0, 0);
+      load_group(blk, 1, 1);
+    }
     // ================================================================ stage the patch image of channels [c0, c0 + CK)
     if (blk != blk_begin) __syncthreads();         // every wave is done reading the previous image
 #ifdef DFL_CONVP_TRACE
@@ -334,24 +362,6 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : 2) c
 #endif
 
     // ================================================================ k-steps of this block: s = tap * CKC + chunk
-    // B fragments ride a ring of three register sets, loaded two groups (8 k-steps) ahead of their use.
-    constexpr int G = TN == 1 ? 4 : 2;             // k-steps per ring set (the ring holds 3 * G * TN fragments)
-    const int ngroups_all = (S_steps + G - 1) / G;
-    // k-group kg takes the ring groups kg, kg + KS, ...: local group gl is global group gl * KS + kg
-    const int ngroups = (ngroups_all - kg + KS - 1) / KS;
-    pu32x4 breg[3][G][TN];
-    auto load_group = [&](int gl, int set) {
-      const int g = gl * KS + kg;
-#pragma unroll
-      for (int e = 0; e < G; ++e) {
-        const int s = g * G + e;
-        const bool live = gl < ngroups && s < S_steps;
-        const int tap = s >> ckc_sh, cc = s & (CKC - 1);
-        const uint32_t soff = live ? (uint32_t)((tap * cin_chunks + blk * CKC + cc)) * (uint32_t)a.Ntot * 32u : 0u;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) breg[set][e][j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, live ? b_voff[j] : POOB, soff, 0);
-      }
-    };
     // A fragments run one k-step ahead of the matrix instructions that use them: the reads of step s + 1 are issued
     // before the instructions of step s (a fragment read takes 64-128 cycles, an instruction 32)
     bf16x8_t afn[TM];
@@ -380,17 +390,19 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : 2) c
       }
     };
     fetch_a(kg * G);
-    load_group(0, 0);
-    load_group(1, 1);
+    if (!DFL_CONVP_PRIME) {
+      load_group(blk, 0, 0);
+      load_group(blk, 1, 1);
+    }
     for (int g = 0; g < ngroups; g += 3) {
-      load_group(g + 2, 2);
+      load_group(blk, g + 2, 2);
       compute_group(g, 0);
       if (g + 1 < ngroups) {
-        load_group(g + 3, 0);
+        load_group(blk, g + 3, 0);
         compute_group(g + 1, 1);
       }
       if (g + 2 < ngroups) {
-        load_group(g + 4, 1);
+        load_group(blk, g + 4, 1);
         compute_group(g + 2, 2);
       }
     }
@@ -543,8 +555,10 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : 2) c
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += fmaf(o[e], casc[e], cash[e]);
       }
-      const int64_t yo = scat ? ((((int64_t)n * a.Hout + 2 * gy + (cab >> 1)) * a.Wout + 2 * gx + (cab & 1)) * a.ldy + cco)
-                              : (m * a.ldy + ncol);
+      // pixel and column of this unit in y (scatter2x2: the 2x2 position its column group stands for)
+      const int64_t opix = scat ? (((int64_t)n * a.Hout + 2 * gy + (cab >> 1)) * a.Wout + 2 * gx + (cab & 1)) : m;
+      const int ocol = scat ? cco : ncol;
+      const int64_t yo = opix * a.ldy + ocol;
       if (a.accumulate) {
         float o[8];
         unpack(*reinterpret_cast<const pu32x4*>(yp + yo), o);
@@ -561,7 +575,7 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : 2) c
         float vr[8], u[8];
         unpack(w, vr);                                // statistics of the values as stored
         if (sop != nullptr) {
-          unpack(*reinterpret_cast<const pu32x4*>(sop + m * a.ldso + ncol), u);
+          unpack(*reinterpret_cast<const pu32x4*>(sop + opix * a.ldso + ocol), u);
         } else {
 #pragma unroll
           for (int e = 0; e < 8; ++e) u[e] = vr[e];
@@ -602,7 +616,12 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : 2) c
     if (n < a.Ntot) {
       float sum = 0.f;
       for (int w = 0; w < RPS; ++w) sum += red[(w * 2 + which) * BN + col];
-      a.stat_partials[((int64_t)bpatch * 2 + which) * a.Ntot + n] = sum;
+      if (scat) {                                      // rows = (patch, 2x2 position): [.][2][Cout], the sums of y's Cout channels
+        const int ab = n / p.Cout, co = n - ab * p.Cout;
+        a.stat_partials[(((int64_t)bpatch * 4 + ab) * 2 + which) * p.Cout + co] = sum;
+      } else {
+        a.stat_partials[((int64_t)bpatch * 2 + which) * a.Ntot + n] = sum;
+      }
     }
   }
 }
@@ -642,22 +661,20 @@ __global__ void __launch_bounds__(256) convp_finish_kernel(const ConvP p, int TX
       v += bias;
       if (a.relu) v = fmaxf(v, 0.f);
       if (addp != nullptr) v += fmaf(ld_bf(addp + (int64_t)m * a.ldadd + n), asc, ash);
-      __bf16* dst;
+      int64_t opix = m;
       if (a.scatter2x2) {
         const int jx = m % p.Wg;
         const int t = m / p.Wg;
         const int iy = t % p.Hg;
         const int ni = t / p.Hg;
-        const int64_t opix = ((int64_t)ni * a.Hout + 2 * iy + (ab >> 1)) * a.Wout + 2 * jx + (ab & 1);
-        dst = yp + opix * a.ldy + co;
-      } else {
-        dst = yp + (int64_t)m * a.ldy + n;
+        opix = ((int64_t)ni * a.Hout + 2 * iy + (ab >> 1)) * a.Wout + 2 * jx + (ab & 1);
       }
+      __bf16* dst = yp + opix * a.ldy + co;
       if (a.accumulate) v += (float)*dst;
       const __bf16 hv = (__bf16)v;
       *dst = hv;
       const float vr = (float)hv;
-      const float u = (sop != nullptr) ? ld_bf(sop + (int64_t)m * a.ldso + n) : vr;
+      const float u = (sop != nullptr) ? ld_bf(sop + opix * a.ldso + co) : vr;
       s1 += vr;
       s2 = fmaf(vr, u, s2);
     }
@@ -672,8 +689,13 @@ __global__ void __launch_bounds__(256) convp_finish_kernel(const ConvP p, int TX
       t1 += red[0][y * TX + tx];
       t2 += red[1][y * TX + tx];
     }
-    a.stat_partials[((int64_t)blockIdx.x * 2 + 0) * Ntot + n] = t1;
-    a.stat_partials[((int64_t)blockIdx.x * 2 + 1) * Ntot + n] = t2;
+    if (a.scatter2x2) {                                // rows = (row block, 2x2 position), see convp_kernel
+      a.stat_partials[(((int64_t)blockIdx.x * 4 + ab) * 2 + 0) * p.Cout + co] = t1;
+      a.stat_partials[(((int64_t)blockIdx.x * 4 + ab) * 2 + 1) * p.Cout + co] = t2;
+    } else {
+      a.stat_partials[((int64_t)blockIdx.x * 2 + 0) * Ntot + n] = t1;
+      a.stat_partials[((int64_t)blockIdx.x * 2 + 1) * Ntot + n] = t2;
+    }
   }
 }
 
@@ -926,7 +948,7 @@ static int convp_plan_search(const dfl_conv_args* a, ConvP* p, int force_splits)
   if (a->scatter2x2) {
     DFL_REQUIRE(a->KH == 1 && a->KW == 1 && a->stride == 1 && a->pad == 0, "dfl_conv2d: scatter2x2 needs a 1x1 gather");
     DFL_REQUIRE(a->Ntot % 4 == 0 && a->Hout >= 2 * a->Hin && a->Wout >= 2 * a->Win, "dfl_conv2d: scatter2x2 geometry");
-    DFL_REQUIRE(a->add == nullptr && a->stat_partials == nullptr, "dfl_conv2d: scatter2x2 has no add/stats epilogue");
+    DFL_REQUIRE(a->add == nullptr, "dfl_conv2d: scatter2x2 has no add epilogue");
     p->Hg = a->Hin;
     p->Wg = a->Win;
     p->Cout = a->Ntot / 4;

@@ -246,7 +246,7 @@ class UNetPlan:
             a.stat_partials = partials.data_ptr()
             if stat_other is not None:
                 a.stat_other, a.ldso = stat_other.ptr, stat_other.ld
-            partials = (partials, gm)
+            partials = (partials, 4 * gm if scatter else gm)    # scatter2x2: rows = (row block, 2x2 position), Ntot / 4 columns
         prog.add(a)
         return partials
 
@@ -312,6 +312,7 @@ class UNetPlan:
     # and one dfl_reduce_batch finishes the queue once FLUSH_BYTES of gradient are waiting (and at the end of backward).
     FLUSH_BYTES = int(float(os.environ.get('DFL_FLUSH_MB', '16')) * (1 << 20))   # (4 / 16 / 64 MB measured: 0.414 / 0.373 / 0.367 ms of sums per step)
     FUSE_BWD_STATS = os.environ.get('DFL_FUSE_BWD_STATS', '1') != '0'
+    FUSE_DOWN_STATS = os.environ.get('DFL_FUSE_DOWN_STATS', '1') != '0'   # ... and the strided-conv data gradient's scatter (bf16)
     FUSE_BRB = os.environ.get('DFL_FUSE_BRB', '1') != '0'      # BatchNorm + ReLU backward inside the weight-/data-gradient staging (bf16 storage)
     RES_DGRAD_LAST = os.environ.get('DFL_RES_DGRAD_LAST', '1') != '0'   # residual 1x1 data gradient accumulates onto the 3x3 one (not the reverse)
     FUSE_COLSUMS = FUSE_BWD_STATS and os.environ.get('DFL_FUSE_COLSUMS', '1') != '0'   # sums across block boundaries (see the backward program)
@@ -952,6 +953,7 @@ class UNetPlan:
             rec = pending[i]
             out = rec['out']
             Ci = chans[i]
+            down_sums = None
             if i != depth - 1:
                 # dout = bridge gradient (+ crop padding) + down-sampling gradient
                 if direct_bridge[i]:
@@ -977,14 +979,17 @@ class UNetPlan:
                         self._colsum(bwd, dnxt, self.G[wname + '.bias'])
                     self._wgrad(bwd, out, dnxt, self.G[wname + '.weight'], 2, 2, 2, 0, nxt.H, nxt.W)
                     wd = self._pack_down_dgrad(self.P[wname + '.weight'])
-                    self._conv(bwd, dnxt, wd, dout, 1, 1, 1, 0, 4 * Ci, accumulate=1, scatter=1,
-                               Hout=out.H, Wout=out.W)
+                    # the last kernel that writes dout leaves sum(dout), sum(dout * r_last) for the block's first BN backward
+                    r_last = rec['block_bw'].last_r
+                    want = self.FUSE_DOWN_STATS and r_last is not None and bool(dout.bf16) and bool(r_last.bf16)
+                    down_sums = self._conv(bwd, dnxt, wd, dout, 1, 1, 1, 0, 4 * Ci, accumulate=1, scatter=1,
+                                           Hout=out.H, Wout=out.W, stats=want, stat_other=r_last if want else None)
             if i > 0:
                 dxin = self._act(N, rec['xin'].H, rec['xin'].W, rec['xin'].C)
                 pending[i - 1]['dnxt'] = dxin
             else:
                 dxin = None
-            st = rec['block_bw'](dout, dxin, fused_in=dout_sums if i == depth - 1 else None,
+            st = rec['block_bw'](dout, dxin, fused_in=dout_sums if i == depth - 1 else down_sums,
                                  dxin_stats=dxin is not None and not cfg['max_pool'])
             if i > 0:
                 pending[i - 1]['dnxt_sums'] = st

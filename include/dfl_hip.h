@@ -74,7 +74,8 @@ typedef struct {
   const float* add_shift;
   const float* stat_other; /* [M][ldso] or NULL (=> u = v) */
   float* y;              /* output, NHWC, pixel stride ldy */
-  float* stat_partials;  /* [gridM][2][Ntot] or NULL; gridM = dfl_conv_grid_m(args) */
+  float* stat_partials;  /* [gridM][2][Ntot] or NULL; gridM = dfl_conv_grid_m(args).  With scatter2x2 (bf16 tensors only):
+                            [4*gridM][2][Cout], the sums of y's Cout channels (stat_other is then addressed like y) */
   float* partial;        /* split-K scratch [splits][M][Ntot], required when splits > 1 */
   int32_t N, Hin, Win, Cin, ldx;
   int32_t KH, KW, stride, pad;

@@ -148,7 +148,7 @@ def conv_bf16(x, wp, Ntot, KH, KW, stride, pad, Hout, Wout, bias=None, in_aff=No
     part = None
     if stats:
         gm = nat.check(lib.dfl_conv_grid_m(C.addressof(a)), 'grid_m')
-        part = torch.zeros(gm, 2, Ntot, device=DEV)
+        part = torch.zeros(4 * gm, 2, Cout, device=DEV) if scatter else torch.zeros(gm, 2, Ntot, device=DEV)
         a.stat_partials = part.data_ptr()
         if stat_other is not None:
             so = nhwc(stat_other).to(DEV).to(BF).contiguous()
@@ -388,6 +388,18 @@ def test_convp_transposed_scatter_and_data_gradients():
     d0 = rb(torch.randn(N, 32, 12, 10, generator=g))
     dd = conv_bf16(dn, pack16(w2, 3), 4 * 32, 1, 1, 1, 0, 12, 10, scatter=1, y_init=d0, accumulate=1)
     close_bf16(dd, nhwc(d0.double() + F.conv_transpose2d(dn.double(), w2.double(), stride=2)), 'dgrad 2x2 s2')
+    # ... leaving the BatchNorm-backward sums of the finished gradient against a partner tensor (one pass and through K slices)
+    for Cd, sp in ((32, None), (64, None), (64, 2), (128, 2)):
+        dn = rb(torch.randn(N, Cd, 6, 5, generator=g))
+        w2 = rb(torch.randn(Cd, Cd, 2, 2, generator=g) / (4 * Cd) ** 0.5)
+        d0 = rb(torch.randn(N, Cd, 12, 10, generator=g))
+        partner = rb(torch.randn(N, Cd, 12, 10, generator=g))
+        dd, st = conv_bf16(dn, pack16(w2, 3), 4 * Cd, 1, 1, 1, 0, 12, 10, scatter=1, y_init=d0, accumulate=1, stats=True,
+                           stat_other=partner, force_splits=sp)
+        close_bf16(dd, nhwc(d0.double() + F.conv_transpose2d(dn.double(), w2.double(), stride=2)), 'dgrad 2x2 s2 + sums %d' % Cd)
+        yd, pd = dd.double().reshape(-1, Cd), nhwc(partner).double().reshape(-1, Cd)
+        np.testing.assert_allclose(st[0].numpy(), yd.sum(0).numpy(), rtol=2e-5, atol=2e-5 * float(yd.abs().sum(0).max()))
+        np.testing.assert_allclose(st[1].numpy(), (yd * pd).sum(0).numpy(), rtol=2e-5, atol=2e-5 * float((yd * pd).abs().sum(0).max()))
     # data gradient of the transposed conv = conv 2x2 / stride 2 over dy
     dyT = rb(torch.randn(N, Co, 2 * H, 2 * W, generator=g))
     du = conv_bf16(dyT, pack16(w, 1), Ci, 2, 2, 2, 0, H, W)
