@@ -380,6 +380,7 @@ def main():
                                  'steps (loss, optimizer, weight re-layout included) queued back to back without a host read' % nq
         extra['gpu_idle_frac'] = round(max(0.0, 1.0 - gpu_ms / ms_per_step), 4)
         extra['program_ops_per_step'] = sum(v[2] for v in groups.values())
+        extra['partial_sum_mb_per_step'] = round(plan.partial_sum_bytes / 1e6, 1)   # fp32 slices the batched reductions read
         extra['whole_step_tflops'] = round(fl_all / (ms_per_step * 1e-3) / 1e12, 2)
         extra['kernels'] = {k: {'ms': round(v[0], 3), 'tflops': round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[0] > 0 and v[1] > 0 else None,
                                 'launches': v[2]} for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0])}

@@ -279,7 +279,10 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __res
 // weight-gradient and bias job; otherwise four scalar loads), four slices in flight, fp64 accumulation in a fixed order.
 // Many slices (count >= 32): a workgroup takes 32 outputs (one 128-byte line per slice) x 32 slice lanes, eight slices of a
 // lane in flight, and adds the lanes up through LDS.  Few slices: 1024 outputs per workgroup, the slices walked in order.
-constexpr int RB_T = 256, RB_O = 32, RB_S = 32, RB_WIDE_MIN = 32;
+#ifndef DFL_RB_O
+#define DFL_RB_O 32
+#endif
+constexpr int RB_T = 256, RB_O = DFL_RB_O, RB_S = 4 * RB_T / RB_O, RB_WIDE_MIN = 32;
 static inline int reduce_job_blocks(int64_t n, int count) {
   return (int)(count >= RB_WIDE_MIN ? ceil_div(n, RB_O) : ceil_div(n, 4 * RB_T));
 }
@@ -315,7 +318,7 @@ __global__ void __launch_bounds__(RB_T) reduce_batch_kernel(const dfl_reduce_job
   const int b = (int)blockIdx.x - j.first_block;
   const bool vec = (j.n & 3) == 0 && (j.stride & 3) == 0 && (reinterpret_cast<uintptr_t>(j.src) & 15) == 0;
   if (j.count >= RB_WIDE_MIN) {
-    const int o4 = threadIdx.x & 7, sl = threadIdx.x >> 3;
+    const int o4 = threadIdx.x % (RB_O / 4), sl = threadIdx.x / (RB_O / 4);
     const int64_t i = (int64_t)b * RB_O + 4 * o4;
     double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0}, a3[4] = {0, 0, 0, 0};
     if (i < j.n) {

@@ -69,6 +69,7 @@ class UNetPlan:
         self._red_pending = []          # deferred sums (src, dst, n, stride, count), see _defer_sum
         self._red_bytes = 0
         self._red_flushes = []          # (index of the batch op in bwd, [dst pointers])
+        self.partial_sum_bytes = 0      # bytes of fp32 partial sums the batched reductions of one backward pass read
         self._side = []                 # weight gradients running on the side stream: dict(done=event, op=index, waited=index|None)
         self.math = self.lib.dfl_get_math_mode()   # product arithmetic the plan is recorded for (split operand formats)
         # math mode 4, "bf16 storage": internal activations, their gradients and the GEMM copies of the weights are bf16
@@ -340,6 +341,7 @@ class UNetPlan:
         dev = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(self.dev)
         self._keep.append(dev)
         self._red_flushes.append((len(prog.structs), [j[1] for j in jobs]))
+        self.partial_sum_bytes += sum(4 * n * count for (_, _, n, _, count, _) in jobs)
         prog.add(ReduceBatchArgs(jobs_dev=dev.data_ptr(), njobs=len(jobs), total_blocks=blocks))
         self._red_pending, self._red_bytes = [], 0
 
