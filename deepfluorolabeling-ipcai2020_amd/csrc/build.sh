@@ -10,7 +10,7 @@ pids=()
 for s in "${srcs[@]}"; do
   o="$out/${s%.hip}.o"
   objs+=("$o")
-  if [ ! -f "$o" ] || [ "$here/$s" -nt "$o" ] || [ "$here/common.h" -nt "$o" ] || [ "$here/direct_small.h" -nt "$o" ] || [ "$here/conv_epilogue.h" -nt "$o" ] || [ "$here/conv_rows.h" -nt "$o" ] || [ "$here/convp.h" -nt "$o" ] || [ "$here/head_caps.inc" -nt "$o" ] || [ "$here/../../include/dfl_hip.h" -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$here/$s" -nt "$o" ] || [ "$here/common.h" -nt "$o" ] || [ "$here/direct_small.h" -nt "$o" ] || [ "$here/conv_epilogue.h" -nt "$o" ] || [ "$here/conv_rows.h" -nt "$o" ] || [ "$here/convp.h" -nt "$o" ] || [ "$here/head_caps.inc" -nt "$o" ] || [ "$here/head_mfma.inc" -nt "$o" ] || [ "$here/../../include/dfl_hip.h" -nt "$o" ]; then
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -c "$here/$s" -o "$o" &
     pids+=($!)
   fi

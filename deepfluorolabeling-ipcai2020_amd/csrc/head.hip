@@ -16,6 +16,7 @@
 // to LDS as bf16, four waves multiply them on the matrix cores through transposing LDS reads (contraction over pixels,
 // as csrc/wgradp_bf16.hip), workgroups leave 64 x 64 fp32 partials and head_wgrad_finish_kernel adds them up.
 #include "common.h"
+#include <stdlib.h>
 
 
 namespace dfl {
@@ -121,6 +122,17 @@ static unsigned head_wgrad_grid(int64_t M) {
   int64_t b = ceil_div(M, HT);
   if (b > 512) b = 512;                     // two workgroups per CU walk the tiles; one partial each
   return (unsigned)(b < 1 ? 1 : b);
+}
+
+#include "head_mfma.inc"
+
+// bf16 features with F = 32 and a head inside the small capacities (two 1x1 landmark layers, or none): matrix-core kernels
+static bool head_mfma_ok(int x_bf16, int F, int ldx, int L, const void* w_l2, const void* w_seg) {
+  static const bool on = [] {
+    const char* e = getenv("DFL_HEAD_MFMA");
+    return e == nullptr || atoi(e) != 0;
+  }();
+  return on && x_bf16 && F == 32 && ldx % 8 == 0 && (L == 0 || w_l2 != nullptr) && aligned16(w_seg);
 }
 
 // The kernels and their launchers, once per capacity (csrc/head_caps.inc)

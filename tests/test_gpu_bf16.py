@@ -592,20 +592,23 @@ def test_streaming_kernels_bf16():
 
 
 # ---------------------------------------------------------------------------------------------------- whole network
-@pytest.mark.parametrize('NC,L,two', [(7, 14, True), (7, 0, True), (5, 9, False)])
-def test_head_backward_fused_weight_gradients(NC, L, two):
-    """dfl_head_bwd with bf16 features and dw_seg set: dx and the three head weight gradients (unet.py:176-191 under
-    autograd) without the per-pixel scratch.  The matrix-core form rounds [dlogits | dmid | dheat] and [logits | mid] to
-    bf16 (x is bf16 already): 2^-9 relative per product, averaged over the pixels -- the bar is 2^-8 of the largest
-    gradient magnitude of each tensor, dx keeps the bar of a bf16 result."""
+@pytest.mark.parametrize('NC,L,two,softmax', [(7, 14, True, 1), (7, 0, True, 1), (5, 9, False, 1), (5, 9, True, 1), (8, 16, True, 0),
+                                              (3, 0, True, 0), (2, 3, True, 1)])
+def test_head_backward_fused_weight_gradients(NC, L, two, softmax):
+    """dfl_head_fwd / dfl_head_bwd with bf16 features (F = 32; unet.py:176-191 under autograd): outputs, dx and the three head
+    weight gradients without the per-pixel scratch -- on the matrix cores when the head has two landmark layers or none (fp32
+    weights and computed operands as hi + lo bf16 pairs: the outputs keep the fp32 kernels' bar), thread-per-pixel otherwise.
+    The weight gradients round [dlogits | dmid | dheat] and [logits | mid] to bf16 (x is bf16 already): 2^-9 relative per
+    product, averaged over the pixels -- the bar is 2^-8 of the largest gradient magnitude of each tensor, dx keeps the bar
+    of a bf16 result."""
     lib = nat.lib()
     g = torch.Generator().manual_seed(NC + L + 1)
-    N, H, W, F_ = 3, 37, 29, 32                                     # 3219 pixels: 13 tiles, the last one ragged
+    N, H, W, F_ = 3, 37, 29, 32                                     # 3219 pixels: ragged last tile, images that straddle tiles
     x = rb(torch.randn(N, F_, H, W, generator=g)).double().requires_grad_(True)
     wseg = (torch.randn(NC, F_, 1, 1, generator=g, dtype=torch.float64) / 3).float().double().requires_grad_(True)
     NM = (NC + L if two else L) if L > 0 else 0
     logits = F.conv2d(x, wseg)
-    seg = torch.softmax(logits, 1)
+    seg = torch.softmax(logits, 1) if softmax else logits
     outs = [seg]
     w1 = w2 = None
     if L > 0:
@@ -619,8 +622,18 @@ def test_head_backward_fused_weight_gradients(NC, L, two):
     gouts = [torch.randn(o.shape, generator=g, dtype=torch.float64) for o in outs]
     torch.autograd.backward(outs, gouts)
     dv = lambda t: t.detach().float().contiguous().to(DEV)
-    xd = nhwc(x.detach().float()).to(DEV).to(BF).contiguous()
+    xd = F.pad(nhwc(x.detach().float()), (0, 8)).to(DEV).to(BF).contiguous()      # pixel stride 40
     wsd, w1d, w2d = dv(wseg), (dv(w1) if w1 is not None else None), (dv(w2) if w2 is not None else None)
+    seg_out = torch.full((N, NC, H, W), float('nan'), device=DEV)
+    heat_out = torch.full((N, L, H, W), float('nan'), device=DEV) if L > 0 else None
+    nat.call('dfl_head_fwd', nat.HeadFwdArgs(
+        x=xd.data_ptr(), w_seg=wsd.data_ptr(), w_l1=nat.ptr(w1d), w_l2=nat.ptr(w2d), seg=seg_out.data_ptr(), heat=nat.ptr(heat_out),
+        N=N, H=H, W=W, F=F_, ldx=F_ + 8, NC=NC, NM=NM, L=L, softmax=softmax, x_bf16=1), stream())
+    torch.cuda.synchronize()
+    # (three bf16 products per product: 2^-17 of the terms' magnitude -- the bar of the bf16x3 mode)
+    np.testing.assert_allclose(seg_out.cpu().numpy(), seg.detach().numpy(), rtol=1e-4, atol=1e-5 * float(seg.detach().abs().max()))
+    if L > 0:
+        np.testing.assert_allclose(heat_out.cpu().numpy(), outs[1].detach().numpy(), rtol=1e-4, atol=1e-5 * float(outs[1].detach().abs().max()))
     segd = dv(seg)
     dsegd = dv(gouts[0])
     dheatd = dv(gouts[1]) if L > 0 else None
@@ -633,8 +646,8 @@ def test_head_backward_fused_weight_gradients(NC, L, two):
     dw2 = torch.full((L, NM), float('nan'), device=DEV) if (L > 0 and two) else None
     nat.call('dfl_head_bwd', nat.HeadBwdArgs(
         x=xd.data_ptr(), seg=segd.data_ptr(), dseg=dsegd.data_ptr(), dheat=nat.ptr(dheatd), w_seg=wsd.data_ptr(),
-        w_l1=nat.ptr(w1d), w_l2=nat.ptr(w2d), dx=dxd.data_ptr(), N=N, H=H, W=W, F=F_, ldx=F_, lddx=F_, NC=NC, NM=NM, L=L,
-        softmax=1, x_bf16=1, dw_seg=dws.data_ptr(), dw_l1=nat.ptr(dw1), dw_l2=nat.ptr(dw2), wg_partial=part.data_ptr()), stream())
+        w_l1=nat.ptr(w1d), w_l2=nat.ptr(w2d), dx=dxd.data_ptr(), N=N, H=H, W=W, F=F_, ldx=F_ + 8, lddx=F_, NC=NC, NM=NM, L=L,
+        softmax=softmax, x_bf16=1, dw_seg=dws.data_ptr(), dw_l1=nat.ptr(dw1), dw_l2=nat.ptr(dw2), wg_partial=part.data_ptr()), stream())
     torch.cuda.synchronize()
     close_bf16(dxd.float().cpu(), nhwc(x.grad), 'dx')
     for got, ref, name in ((dws, wseg.grad, 'seg_conv'), (dw1, None if w1 is None else w1.grad, 'lands_1x1.0'),

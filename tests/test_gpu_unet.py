@@ -430,9 +430,9 @@ def test_more_than_two_landmark_1x1_convolutions(n1x1, math_mode):
 
 
 def test_training_quality_is_the_same_with_split_bf16_products():
-    """North-star quality bar (Dice within +-0.005 of the reference): 400 SGD steps on the toy-ellipses set with fp32
-    products and with bf16x3 products from the same initial weights -- final loss and mean hard Dice agree, i.e. the
-    2^-16 product noise does not change what the network learns."""
+    """North-star quality bar (Dice within +-0.005 of the reference): 400 SGD steps on the toy-ellipses set (learning rate cut
+    10x for the last 100) with fp32 products and with bf16x3 products from the same initial weights -- plateau loss and mean
+    hard Dice agree, i.e. the 2^-16 product noise does not change what the network learns."""
     g = load_golden('trajectory')
     cfg = dict(n_classes=7, depth=3, wf=3, batch_norm=True, padding=True, max_pool=False, num_lands=14, do_res=True,
                block_depth=2)
@@ -454,6 +454,9 @@ def test_training_quality_is_the_same_with_split_bf16_products():
             net.train()
             tail = []
             for step in range(400):
+                if step == 300:                      # as tests/golden/plateau.npz: the end point is a plateau, not a point of a
+                    for gr in opt.param_groups:      # chaotic trajectory (at a constant 0.05 the final Dice of ONE arithmetic moved
+                        gr['lr'] = 0.005             # by 0.04 between two builds that differ in summation order only)
                 idx = [(step * 4 + j) % 8 for j in range(4)]
                 opt.zero_grad()
                 out = net(P[idx])
