@@ -78,12 +78,18 @@ __host__ __device__ constexpr int wgp_max_g_units(int KH, bool dbrb = false) { r
 
 // DBRB: the dense operand is the BatchNorm + ReLU backward of (d = dy, d2 = r) formed while the patch is written to LDS
 // (dfl_wgrad_args.d_mode), and the column sums of it -- the layer's bias gradient -- leave with the slice (bias_partial).
+#ifndef DFL_WGP_INTERLEAVE
+#define DFL_WGP_INTERLEAVE 0   // 1 / 2 / 4: the next patch's loads requested between this patch's k-steps (spread over all of them / the first
+#endif                         // half / quarter).  Measured (round 3): weight gradients 1.33 -> 1.45 ms per step in every variant -- left off.
 template <int KH, int KW, bool AFF, bool DBRB = false>
 __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const WgP p) {
   constexpr int NT = 256 * KH;
   constexpr int T = KH * KW;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const dfl_wgrad_args& a = p.a;
+#ifdef DFL_WGP_TRACE
+  const long long tr_entry = __builtin_amdgcn_s_memtime();
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int ty = wave % KH, slot = wave / KH;
@@ -178,45 +184,54 @@ __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const
     }
   }
   if constexpr (AFF || DBRB) __syncthreads();             // the first commit() reads these tables
-  auto issue = [&](int patch, bool live) {
+  // issue: the loads of one patch, unit by unit -- issue_setup fixes the patch, issue_d(u) / issue_g(u) request one 16-byte unit each
+  int is_nleft = 0, is_oy0 = 0, is_ox0 = 0, is_ybase = 0, is_xbase = 0;
+  uint32_t is_dbase = 0, is_dbase2 = 0, is_gbase = 0;
+  auto issue_setup = [&](int patch, bool live) {
     const int pg = patch / per_img, pr = patch - pg * per_img;
     const int ppy = pr / p.npx, ppx = pr - ppy * p.npx;
-    const int img0 = pg * p.IPP, oy0 = ppy * p.PH, ox0 = ppx * p.PW;
-    const int nleft = live ? a.N - img0 : 0;                       // images of this patch that exist
-    {   // d: rows = patch pixels in patch order (image, row, column), zeros beyond the patch / image
-      const uint32_t base = (uint32_t)(((img0 * a.Hout + oy0) * a.Wout + ox0) * a.ldd + dc) * 2u;
-      const uint32_t base2 = DBRB ? (uint32_t)(((img0 * a.Hout + oy0) * a.Wout + ox0) * a.ldd2 + dc) * 2u : 0u;
-#pragma unroll
-      for (int u = 0; u < MAXD; ++u) {
-        if (u < nd) {
-          const uint32_t q = dpos[u];
-          const int qy = (int)(q & 0xfffu), qx = (int)((q >> 12) & 0xfffu), qi = (int)((q >> 24) & 127u);
-          const bool ok = (int)q < 0 && qi < nleft && oy0 + qy < a.Hout && ox0 + qx < a.Wout;
-          const uint32_t rel = (uint32_t)((qi * a.Hout + qy) * a.Wout + qx) * dpitch;
-          dreg[u] = __builtin_amdgcn_raw_buffer_load_b128(rsD, ok ? base + rel : WPOOB, 0, 0);
-          if constexpr (DBRB) {
-            const uint32_t rel2 = (uint32_t)((qi * a.Hout + qy) * a.Wout + qx) * d2pitch;
-            d2reg[u] = __builtin_amdgcn_raw_buffer_load_b128(rsD2, ok ? base2 + rel2 : WPOOB, 0, 0);
-          }
-        }
+    const int img0 = pg * p.IPP;
+    is_oy0 = ppy * p.PH;
+    is_ox0 = ppx * p.PW;
+    is_nleft = live ? a.N - img0 : 0;                              // images of this patch that exist
+    // d: rows = patch pixels in patch order (image, row, column), zeros beyond the patch / image
+    is_dbase = (uint32_t)(((img0 * a.Hout + is_oy0) * a.Wout + is_ox0) * a.ldd + dc) * 2u;
+    is_dbase2 = DBRB ? (uint32_t)(((img0 * a.Hout + is_oy0) * a.Wout + is_ox0) * a.ldd2 + dc) * 2u : 0u;
+    // g: the gathered pixels of the patch with their halo, zero outside the image
+    is_ybase = is_oy0 * a.stride - a.pad;
+    is_xbase = is_ox0 * a.stride - a.pad;
+    is_gbase = (uint32_t)(((img0 * a.Hin + is_ybase) * a.Win + is_xbase) * a.ldg + gc) * 2u;   // may wrap: base + rel is what counts
+    gok = 0;
+  };
+  auto issue_d = [&](int u) {
+    if (u < nd) {
+      const uint32_t q = dpos[u];
+      const int qy = (int)(q & 0xfffu), qx = (int)((q >> 12) & 0xfffu), qi = (int)((q >> 24) & 127u);
+      const bool ok = (int)q < 0 && qi < is_nleft && is_oy0 + qy < a.Hout && is_ox0 + qx < a.Wout;
+      const uint32_t rel = (uint32_t)((qi * a.Hout + qy) * a.Wout + qx) * dpitch;
+      dreg[u] = __builtin_amdgcn_raw_buffer_load_b128(rsD, ok ? is_dbase + rel : WPOOB, 0, 0);
+      if constexpr (DBRB) {
+        const uint32_t rel2 = (uint32_t)((qi * a.Hout + qy) * a.Wout + qx) * d2pitch;
+        d2reg[u] = __builtin_amdgcn_raw_buffer_load_b128(rsD2, ok ? is_dbase2 + rel2 : WPOOB, 0, 0);
       }
     }
-    {   // g: the gathered pixels of the patch with their halo, zero outside the image
-      const int ybase = oy0 * a.stride - a.pad, xbase = ox0 * a.stride - a.pad;
-      const uint32_t base = (uint32_t)(((img0 * a.Hin + ybase) * a.Win + xbase) * a.ldg + gc) * 2u;   // may wrap: base + rel is what counts
-      gok = 0;
-#pragma unroll
-      for (int u = 0; u < MAXG; ++u) {
-        if (u < ng) {
-          const uint32_t q = gpos[u];
-          const int qy = (int)(q & 0xfffu), qx = (int)((q >> 12) & 0xfffu), qi = (int)((q >> 24) & 127u);
-          const bool ok = (int)q < 0 && qi < nleft && (unsigned)(ybase + qy) < (unsigned)a.Hin && (unsigned)(xbase + qx) < (unsigned)a.Win;
-          gok |= ok ? (1u << u) : 0u;
-          const uint32_t rel = (uint32_t)((qi * a.Hin + qy) * a.Win + qx) * gpitch;
-          greg[u] = __builtin_amdgcn_raw_buffer_load_b128(rsG, ok ? base + rel : WPOOB, 0, 0);
-        }
-      }
+  };
+  auto issue_g = [&](int u) {
+    if (u < ng) {
+      const uint32_t q = gpos[u];
+      const int qy = (int)(q & 0xfffu), qx = (int)((q >> 12) & 0xfffu), qi = (int)((q >> 24) & 127u);
+      const bool ok = (int)q < 0 && qi < is_nleft && (unsigned)(is_ybase + qy) < (unsigned)a.Hin && (unsigned)(is_xbase + qx) < (unsigned)a.Win;
+      gok |= ok ? (1u << u) : 0u;
+      const uint32_t rel = (uint32_t)((qi * a.Hin + qy) * a.Win + qx) * gpitch;
+      greg[u] = __builtin_amdgcn_raw_buffer_load_b128(rsG, ok ? is_gbase + rel : WPOOB, 0, 0);
     }
+  };
+  auto issue = [&](int patch, bool live) {
+    issue_setup(patch, live);
+#pragma unroll
+    for (int u = 0; u < MAXD; ++u) issue_d(u);
+#pragma unroll
+    for (int u = 0; u < MAXG; ++u) issue_g(u);
   };
   auto commit = [&]() {
 #pragma unroll
@@ -286,7 +301,7 @@ __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const
     __syncthreads();
     WTR(1, tb1)
     WT0(ti0)
-    issue(patch + 1, patch + 1 < pend);
+    if (DFL_WGP_INTERLEAVE) issue_setup(patch + 1, patch + 1 < pend); else issue(patch + 1, patch + 1 < pend);
     WTR(3, ti0)
     if constexpr (DBRB) {
       // bias gradient: column sums of the d image as stored -- thread t owns channel t % CMT and every (NT / CMT)-th pixel row
@@ -302,7 +317,8 @@ __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const
     //      patch pixels j0 = 16 ks + trow and j0 + 4: their d rows are j0 * sd, their g rows come from the offset table
     uint32_t dr0 = (uint32_t)(phase * 16 + trow) * (uint32_t)p.sd + d_col;
     const uint32_t* tp = gtab + phase * 16 + trow;
-    for (int ks = phase; ks < nsteps; ks += p.phases) {
+    int ks = phase;
+    auto kstep = [&]() {
       const uint32_t gr0 = tp[0] + gadd, gr1 = tp[4] + gadd;
       const bf16x8_t df = wtr_read8(Ds, dr0, dr0 + 4u * (uint32_t)p.sd);
       bf16x8_t gf[KW];
@@ -312,7 +328,20 @@ __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const
       for (int t = 0; t < KW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, gf[t], acc[t], 0, 0, 0);
       dr0 += dstep;
       tp += 16 * p.phases;
+      ks += p.phases;
+    };
+    if (DFL_WGP_INTERLEAVE) {
+      // one unit of the next patch, then this wave's share of the k-steps that come between two units
+      const int mine = (nsteps - phase + p.phases - 1) / p.phases;
+      const int per = (mine / (DFL_WGP_INTERLEAVE ? DFL_WGP_INTERLEAVE : 1) + nd + ng - 1) / (nd + ng);   // (2, 4: all units requested within the first half, quarter)
+#pragma unroll
+      for (int u = 0; u < MAXD + MAXG; ++u) {
+        if (u < MAXD) issue_d(u); else issue_g(u - MAXD);
+        if (u < MAXD ? u < nd : u - MAXD < ng)
+          for (int c = 0; c < per && ks < nsteps; ++c) kstep();
+      }
     }
+    while (ks < nsteps) kstep();
     WTR(4, tk0)
   }
 #ifdef DFL_WGP_TRACE
@@ -358,14 +387,7 @@ __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const
     if (phase > 0) return;
   }
 #ifdef DFL_WGP_TRACE
-  if (tid == 0 && p.trace != nullptr) {
-    long long* sink = p.trace + (int64_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 10;
-    for (int i = 0; i < 6; ++i) sink[i] = tr[i];
-    sink[6] = __builtin_amdgcn_s_memtime();
-    sink[7] = tr[6];
-    sink[8] = __builtin_amdgcn_s_memrealtime();
-    sink[9] = 1;
-  }
+  const long long tr_main_end = __builtin_amdgcn_s_memtime();
 #endif
   // ---- output: one partial slot per pixel slice
   const bool sliced = p.zslices > 1;
@@ -383,6 +405,19 @@ __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const
       }
     }
   }
+#ifdef DFL_WGP_TRACE
+  __builtin_amdgcn_s_waitcnt(0);                       // (the stores of this wave have left)
+  if (tid == 0 && p.trace != nullptr) {
+    long long* sink = p.trace + (int64_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 12;
+    for (int i = 0; i < 6; ++i) sink[i] = tr[i];
+    sink[6] = tr_main_end;
+    sink[7] = tr[6];
+    sink[8] = __builtin_amdgcn_s_memrealtime();
+    sink[10] = tr_entry;
+    sink[11] = __builtin_amdgcn_s_memtime();
+    sink[9] = 1;
+  }
+#endif
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------

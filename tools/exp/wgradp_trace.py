@@ -16,7 +16,7 @@ DEV = 'cuda'
 BF = torch.bfloat16
 lib = nat.lib()
 nat.check(lib.dfl_set_math_mode(4), 'mode')
-trace = torch.zeros(10 << 16, dtype=torch.int64, device=DEV)
+trace = torch.zeros(12 << 16, dtype=torch.int64, device=DEV)
 os.environ['DFL_WGP_TRACE_PTR'] = hex(trace.data_ptr())
 
 
@@ -52,16 +52,17 @@ def run(B, Cg, Cm, H, K, stride=1):
     nat.check(lib.dfl_conv2d_wgrad(C.addressof(a), st), 'wgrad')
     e1.record()
     torch.cuda.synchronize()
-    t = trace.cpu().numpy().reshape(-1, 10)
+    t = trace.cpu().numpy().reshape(-1, 12)
     t = t[t[:, 9] != 0]
     us = 1e-2
     tick = ((t[:, 8] - t[:, 7]).sum() * us) / max((t[:, 6] - t[:, 0]).sum(), 1)
     tot = (t[:, 6] - t[:, 0]) * tick
     byts = 2.0 * B * (H * H * Cg + Ho * Ho * Cm)
     print('B%d g %dx%dx%d d %dx%dx%d k%d: %d WGs, kernel %.1f us (%.2f TB/s compulsory); per WG us: total %.1f (max %.1f) = barrier %.1f + LDS commit (incl. load wait) %.1f '
-          '+ issue %.1f + k-steps %.1f + tail %.1f'
+          '+ issue %.1f + k-steps %.1f + tail %.1f; before the first patch %.1f, output %.1f, first start -> last end %.1f us'
           % (B, H, H, Cg, Ho, Ho, Cm, K, len(t), e0.elapsed_time(e1) * 1e3, byts / (e0.elapsed_time(e1) * 1e-3) / 1e12, tot.mean(), tot.max(),
-             t[:, 1].mean() * tick, t[:, 2].mean() * tick, t[:, 3].mean() * tick, t[:, 4].mean() * tick, (t[:, 6] - t[:, 5]).mean() * tick), flush=True)
+             t[:, 1].mean() * tick, t[:, 2].mean() * tick, t[:, 3].mean() * tick, t[:, 4].mean() * tick, (t[:, 6] - t[:, 5]).mean() * tick,
+             (t[:, 0] - t[:, 10]).mean() * tick, (t[:, 11] - t[:, 6]).mean() * tick, (t[:, 8].max() - t[:, 7].min()) * us), flush=True)
 
 
 for (Cg, Cm, H, K, s) in ((32, 32, 192, 3, 1), (64, 32, 192, 3, 1), (64, 32, 192, 1, 1), (64, 64, 96, 3, 1), (128, 64, 96, 3, 1), (128, 64, 96, 1, 1), (128, 128, 48, 3, 1),
