@@ -104,31 +104,38 @@ __device__ __forceinline__ void sum_partials_f64(const float* __restrict__ parti
                                                  double* out1, double* out2, double (*red)[256]) {
   const int cl = threadIdx.x % cpb, rl = threadIdx.x / cpb, lanes = 256 / cpb;
   const int c = blockIdx.x * cpb + cl;
-  double s1 = 0.0, s2 = 0.0, t1 = 0.0, t2 = 0.0;
+  double s1 = 0.0, s2 = 0.0;
   if (c < C) {
+    // four rows (eight loads) in flight per lane: these kernels are one memory round trip after the other, nothing else
     int r = rl;
-    for (; r + lanes < nblocks; r += 2 * lanes) {
-      const float a1 = partials[((int64_t)r * 2 + 0) * C + c], a2 = partials[((int64_t)r * 2 + 1) * C + c];
-      const float b1 = partials[((int64_t)(r + lanes) * 2 + 0) * C + c], b2 = partials[((int64_t)(r + lanes) * 2 + 1) * C + c];
-      s1 += (double)a1; s2 += (double)a2; t1 += (double)b1; t2 += (double)b2;
+    for (; r + 3 * lanes < nblocks; r += 4 * lanes) {
+      float v1[4], v2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        v1[u] = partials[((int64_t)(r + u * lanes) * 2 + 0) * C + c];
+        v2[u] = partials[((int64_t)(r + u * lanes) * 2 + 1) * C + c];
+      }
+      s1 += ((double)v1[0] + (double)v1[1]) + ((double)v1[2] + (double)v1[3]);
+      s2 += ((double)v2[0] + (double)v2[1]) + ((double)v2[2] + (double)v2[3]);
     }
-    if (r < nblocks) {
+    for (; r < nblocks; r += lanes) {
       s1 += (double)partials[((int64_t)r * 2 + 0) * C + c];
       s2 += (double)partials[((int64_t)r * 2 + 1) * C + c];
     }
   }
-  red[0][threadIdx.x] = s1 + t1;
-  red[1][threadIdx.x] = s2 + t2;
-  __syncthreads();
-  for (int off = lanes / 2; off >= 1; off >>= 1) {
-    if (rl < off) {
-      red[0][threadIdx.x] += red[0][threadIdx.x + off * cpb];
-      red[1][threadIdx.x] += red[1][threadIdx.x + off * cpb];
-    }
-    __syncthreads();
+  // lanes of one channel inside a wave (lane = row lane * cpb + channel: xor offsets >= cpb keep the channel), then the four waves
+  for (int off = 32; off >= cpb; off >>= 1) {
+    s1 += __shfl_xor(s1, off, 64);
+    s2 += __shfl_xor(s2, off, 64);
   }
-  *out1 = red[0][cl];
-  *out2 = red[1][cl];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane < cpb) {
+    red[0][wave * 8 + lane] = s1;
+    red[1][wave * 8 + lane] = s2;
+  }
+  __syncthreads();
+  *out1 = (red[0][cl] + red[0][8 + cl]) + (red[0][16 + cl] + red[0][24 + cl]);
+  *out2 = (red[1][cl] + red[1][8 + cl]) + (red[1][16 + cl] + red[1][24 + cl]);
 }
 
 static inline int finalize_cpb(int C) { return C >= 512 ? 8 : (C >= 256 ? 4 : (C >= 128 ? 2 : 1)); }
