@@ -296,7 +296,9 @@ static bool direct_conv_rows_ok(const dfl_conv_args* a) {
 }
 
 // dw[cm][0][t] (or the tap-major partial slot of this workgroup) = sum over its pixels of x(tap t) * d[cm]
-template <bool BF>
+// DB (dfl_wgrad_args.d_mode, bf16 d): d is dy, the operand [r > 0] * (A dy + B r + C) (r = d2, rounded to bf16 as the materialised
+// tensor was) is formed on the way in and its column sums -- the layer's bias gradient -- leave with the slice (bias_partial).
+template <bool BF, bool DB = false>
 __global__ void __launch_bounds__(256) direct_wgrad3_rows_kernel(const dfl_wgrad_args a) {
   __shared__ float red[4][8 * 72];              // [wave][q][k][j]
   const int cq = a.Cm >> 3, PL = 256 / cq;
@@ -309,6 +311,16 @@ __global__ void __launch_bounds__(256) direct_wgrad3_rows_kernel(const dfl_wgrad
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
   const float* img = a.g + (int64_t)n * a.Hin * a.Win * a.ldg;
+  float cA[DB ? 8 : 1], cB[DB ? 8 : 1], cC[DB ? 8 : 1], bsum[DB ? 8 : 1];
+  if constexpr (DB) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      cA[j] = a.coef != nullptr ? a.coef[8 * q + j] : 1.f;
+      cB[j] = a.coef != nullptr ? a.coef[a.Cm + 8 * q + j] : 0.f;
+      cC[j] = a.coef != nullptr ? a.coef[2 * a.Cm + 8 * q + j] : 0.f;
+      bsum[j] = 0.f;
+    }
+  }
 #pragma unroll
   for (int ry = 0; ry < ROWS_WGRAD_RB; ++ry) {
     const int y = y0 + ry;
@@ -316,6 +328,16 @@ __global__ void __launch_bounds__(256) direct_wgrad3_rows_kernel(const dfl_wgrad
     for (int x = pl; x < a.Wout; x += PL) {
       float d[8], xv[9];
       ld8c<BF>(a.d, ((int64_t)(n * a.Hout + y) * a.Wout + x) * a.ldd + 8 * q, d);
+      if constexpr (DB) {
+        float r[8];
+        ld8c<BF>(a.d2, ((int64_t)(n * a.Hout + y) * a.Wout + x) * a.ldd2 + 8 * q, r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float v = r[j] > 0.f ? fmaf(cA[j], d[j], fmaf(cB[j], r[j], cC[j])) : 0.f;
+          d[j] = (float)(__bf16)v;
+          bsum[j] += d[j];
+        }
+      }
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
@@ -354,6 +376,23 @@ __global__ void __launch_bounds__(256) direct_wgrad3_rows_kernel(const dfl_wgrad
     const int qq = idx / 72, r = idx - qq * 72, k = r >> 3, j = r & 7;
     const int cm = 8 * qq + j;
     out[sliced ? (int64_t)k * a.Cm + cm : (int64_t)cm * 9 + k] = t;
+  }
+  if constexpr (DB) {
+    if (a.bias_partial == nullptr) return;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = bsum[j];
+      for (int off = cq; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+      bsum[j] = v;
+    }
+    __syncthreads();                            // (the weight-gradient sums above are read)
+    if (lane < cq) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) red[wave][lane * 8 + j] = bsum[j];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < a.Cm; idx += 256)
+      a.bias_partial[(int64_t)blockIdx.x * a.Cm + idx] = ((red[0][idx] + red[1][idx]) + red[2][idx]) + red[3][idx];
   }
 }
 
@@ -503,10 +542,18 @@ int direct_wgrad_splits(const dfl_wgrad_args* a) {
 
 int direct_wgrad_launch(const dfl_wgrad_args* a, hipStream_t s) {
   if (direct_wgrad_rows_ok(a) && a->splits == direct_wgrad_splits(a)) {     // (the row form's slots are its workgroups)
-    if (a->d_bf16) hipLaunchKernelGGL(direct_wgrad3_rows_kernel<true>, dim3((unsigned)a->splits), dim3(256), 0, s, *a);
-    else hipLaunchKernelGGL(direct_wgrad3_rows_kernel<false>, dim3((unsigned)a->splits), dim3(256), 0, s, *a);
+    if (a->d_mode != 0) {
+      DFL_REQUIRE(a->d_mode == 1 && a->d_bf16 && a->d2 != nullptr && a->ldd2 % 8 == 0 && aligned16(a->d2),
+                  "dfl_conv2d_wgrad (1-channel 3x3): d_mode 1 needs bf16 d / d2 (16-byte aligned, ldd2 %% 8 == 0)");
+      hipLaunchKernelGGL((direct_wgrad3_rows_kernel<true, true>), dim3((unsigned)a->splits), dim3(256), 0, s, *a);
+    } else if (a->d_bf16) {
+      hipLaunchKernelGGL(direct_wgrad3_rows_kernel<true>, dim3((unsigned)a->splits), dim3(256), 0, s, *a);
+    } else {
+      hipLaunchKernelGGL(direct_wgrad3_rows_kernel<false>, dim3((unsigned)a->splits), dim3(256), 0, s, *a);
+    }
     return check_launch("dfl_conv2d_wgrad");
   }
+  DFL_REQUIRE(a->d_mode == 0, "dfl_conv2d_wgrad: d_mode is implemented by the bf16 patch kernels and the 1-channel 3x3 row form only");
   const int64_t M = (int64_t)a->N * a->Hout * a->Wout;
   const int rpb = (int)ceil_div(M, a->splits);
 #define DFL_DW(KH_, C_)                                                                                                  \

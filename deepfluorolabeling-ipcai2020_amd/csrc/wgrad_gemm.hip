@@ -657,7 +657,6 @@ extern "C" int dfl_wgrad_suggest_splits(const dfl_wgrad_args* a) {
 
 extern "C" int dfl_conv2d_wgrad(const dfl_wgrad_args* a, dfl_stream_t stream) {
   if (a != nullptr && a->g_bf16 && a->d_bf16) return dfl::wgradp_launch(a, static_cast<hipStream_t>(stream));
-  DFL_REQUIRE(a == nullptr || a->d_mode == 0, "dfl_conv2d_wgrad: d_mode (fused BatchNorm + ReLU backward operand) is implemented by the bf16 patch kernels only");
   dfl::WgK k;
   int rc = dfl::wg_prepare(a, &k, true);
   if (rc != DFL_OK) return rc;
@@ -667,6 +666,7 @@ extern "C" int dfl_conv2d_wgrad(const dfl_wgrad_args* a, dfl_stream_t stream) {
     return dfl::direct_wgrad_launch(a, s);
   }
   DFL_REQUIRE(!a->g_bf16 && !a->d_bf16, "dfl_conv2d_wgrad: mixed bf16 / fp32 operands only for the direct small-K layers");
+  DFL_REQUIRE(a->d_mode == 0, "dfl_conv2d_wgrad: d_mode (fused BatchNorm + ReLU backward operand) is implemented by the bf16 patch kernels and the 1-channel 3x3 row form only");
   k.cps = (int)dfl::ceil_div(k.nchunks, a->splits);
   const bool f = k.fast;
   DFL_REQUIRE(!a->d_split || (f && (dfl::math_mode() == 1 || dfl::math_mode() == 3) && !dfl::direct_wgrad_ok(a)),

@@ -614,6 +614,11 @@ class UNetPlan:
                     # dpre is never written (one tensor pass and one launch per layer less), the bias-gradient sums come out
                     # of the weight-gradient kernel.  The 1-channel first layer (direct kernels) keeps the materialised form.
                     fuse_brb = self.FUSE_BRB and not self.SIDE_STREAM and bool(r.bf16) and bool(inp.bf16) and inp.C % 16 == 0 and g.bf16 == r.bf16
+                    # ... and the network's first layer (1-channel fp32 input, no data gradient): the row form of the direct
+                    # weight-gradient kernel does the same while it reads its d rows
+                    if (self.FUSE_BRB and not self.SIDE_STREAM and bool(r.bf16) and g.bf16 == r.bf16 and not inp.bf16 and inp.C == 1
+                            and d == 0 and dxin is None and Cout in (8, 16, 32, 64)):
+                        fuse_brb = True
                     brb = (r, coef) if fuse_brb else None
                     dsplit = 0
                     if fuse_brb:

@@ -498,6 +498,51 @@ def test_fused_bn_relu_backward_operand(case, with_bn):
         np.testing.assert_allclose(bias.numpy(), refb.numpy(), rtol=2e-5, atol=3e-5 * float(dpre.double().abs().sum(dim=(0, 2, 3)).max()))
 
 
+@pytest.mark.parametrize('case', [(2, 32, 20, 20, 1), (3, 16, 13, 9, 1), (1, 64, 4, 7, 1), (2, 32, 192, 192, 1), (2, 32, 12, 14, 0)])
+@pytest.mark.parametrize('with_bn', [True, False])
+def test_fused_bn_relu_backward_first_layer(case, with_bn):
+    """The same operand in the network's first layer (1-channel fp32 input, direct 3x3 weight-gradient kernel in its row form):
+    d_mode with a bf16 (dy, r) pair, weight gradient and bias-gradient sums against fp64 on the bf16-rounded operand."""
+    lib = nat.lib()
+    N, Cm, H, W, pad = case
+    Hin, Win = H + 2 - 2 * pad, W + 2 - 2 * pad
+    g = torch.Generator().manual_seed(sum(case) + 3)
+    dy = rb(torch.randn(N, Cm, H, W, generator=g))
+    r = rb(torch.relu(torch.randn(N, Cm, H, W, generator=g)))
+    coef = torch.stack([torch.rand(Cm, generator=g) + 0.5, torch.randn(Cm, generator=g) * 0.3, torch.randn(Cm, generator=g) * 0.1]) if with_bn else None
+    dpre = brb_reference(dy, r, coef)
+    x = torch.randn(N, 1, Hin, Win, generator=g)
+    xd = nhwc(x).to(DEV).contiguous()
+    dyd = nhwc(dy).to(DEV).to(BF).contiguous()
+    rd = F.pad(nhwc(r), (0, 8)).to(DEV).to(BF).contiguous()
+    dw = torch.full((Cm, 1, 3, 3), float('nan'), device=DEV)
+    a = nat.WgradArgs()
+    a.g, a.d, a.dw = xd.data_ptr(), dyd.data_ptr(), dw.data_ptr()
+    a.g_bf16, a.d_bf16 = 0, 1
+    a.N, a.Hin, a.Win, a.Cg, a.ldg = N, Hin, Win, 1, 1
+    a.KH, a.KW, a.stride, a.pad = 3, 3, 1, pad
+    a.Hout, a.Wout, a.Cm, a.ldd = H, W, Cm, Cm
+    a.d_mode, a.d2, a.ldd2 = 1, rd.data_ptr(), rd.shape[-1]
+    cd = coef.to(DEV).contiguous() if coef is not None else None
+    a.coef = nat.ptr(cd)
+    a.splits = 1
+    s = nat.check(lib.dfl_wgrad_suggest_splits(C.addressof(a)), 'suggest')
+    a.splits = s
+    bias_part = torch.full((s, Cm), float('nan'), device=DEV)
+    a.bias_partial = bias_part.data_ptr()
+    part = torch.full((max(s, 2) * Cm * 9,), float('nan'), device=DEV)
+    a.partial = part.data_ptr()
+    nat.check(lib.dfl_conv2d_wgrad(C.addressof(a), stream()), 'dfl_conv2d_wgrad')
+    if s > 1:
+        nat.check(lib.dfl_sum_partials(part.data_ptr(), dw.data_ptr(), Cm * 9, s, 9, stream()), 'dfl_sum_partials')
+    torch.cuda.synchronize()
+    refw = torch.nn.grad.conv2d_weight(x.double(), (Cm, 1, 3, 3), dpre.double(), padding=pad)
+    np.testing.assert_allclose(dw.cpu().numpy(), refw.numpy(), rtol=2e-5, atol=3e-5 * float(refw.abs().max()))
+    refb = dpre.double().sum(dim=(0, 2, 3))
+    np.testing.assert_allclose(bias_part.cpu().double().sum(0).numpy(), refb.numpy(), rtol=2e-5,
+                               atol=3e-5 * float(dpre.double().abs().sum(dim=(0, 2, 3)).max()))
+
+
 WCASES = [
     # N, Cg, Cm, H, W, K, stride, pad
     (2, 32, 32, 24, 20, 3, 1, 1),
