@@ -30,6 +30,7 @@ PAPER = dict(n_classes=7, depth=6, wf=5, batch_norm=True, padding=True, max_pool
              block_depth=2)
 F32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0        # same guide: dense bf16 MFMA (the 5 PF marketing figure is 2:1 sparse)
+HBM_PEAK_GBS = 8000.0                 # same guide: HBM3E, 8 TB/s
 # product arithmetic of the GEMM kernels (include/dfl_hip.h): name -> (mode, bf16 MFMA products per fp32 product)
 MATH = {'fp32': (0, 0), 'bf16x3': (1, 3), 'bf16x6': (2, 6), 'bf16': (3, 1), 'bf16s': (4, 1)}
 TRAFFIC_FILE = 'r03_traffic.json'      # per-kernel HBM bytes from the committed rocprofv3 --pmc passes of this round
@@ -69,11 +70,16 @@ def op_profile(plan, lib, nat, stream, detail=None):
                 fl = 2.0 * M * st.KH * st.KW * st.Cin * st.Ntot
                 esz = 2.0 if st.x_bf16 else 4.0
                 by = esz * (st.N * st.Hin * st.Win * st.Cin + st.KH * st.KW * st.Cin * st.Ntot + M * st.Ntot)
+                if st.x_mode:               # the operand is formed from TWO tensors (dy and the saved ReLU output)
+                    by += esz * st.N * st.Hin * st.Win * st.Cin
             elif isinstance(st, nat.WgradArgs):
                 cfg = lib.dfl_wgrad_config(C.addressof(st))
                 name = WGRAD_KERNELS[cfg] if cfg < 16 else 'wgradp_kernel<%s>' % ('3,3', '2,2', '1,1')[cfg - 16]
                 fl = 2.0 * st.N * st.Hout * st.Wout * st.Cm * st.Cg * st.KH * st.KW
-                by = (2.0 if st.g_bf16 else 4.0) * (st.N * st.Hin * st.Win * st.Cg + st.N * st.Hout * st.Wout * st.Cm) + 4.0 * st.Cm * st.Cg * st.KH * st.KW
+                by = (2.0 if st.g_bf16 else 4.0) * st.N * st.Hin * st.Win * st.Cg + (2.0 if st.d_bf16 else 4.0) * st.N * st.Hout * st.Wout * st.Cm \
+                    + 4.0 * st.Cm * st.Cg * st.KH * st.KW
+                if st.d_mode:               # the dense operand is formed from TWO tensors (dy and the saved ReLU output)
+                    by += (2.0 if st.d_bf16 else 4.0) * st.N * st.Hout * st.Wout * st.Cm
             else:
                 name, fl, by = type(st).__name__, 0.0, 0.0
             if detail is not None:
@@ -335,15 +341,25 @@ def main():
         # the layer), so emulation overhead (3 / 6 bf16 products per fp32 product) shows as a lower fraction, not as a
         # lower roof; `mfma_issue_frac` = achieved * products-per-product / peak is the share of the pipe's issue slots.
         peak = F32_MFMA_PEAK_TFLOPS if nprod == 0 else BF16_MFMA_PEAK_TFLOPS
-        roofline = {'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 2), 'peak': round(peak, 1),
-                    'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': None,
+        # Which roof binds this kernel: the one its algorithmic work needs longer under -- compulsory bytes at the HBM peak or
+        # algorithmic flops at the matrix peak.  (With the BatchNorm + ReLU backward formed inside the weight gradient the
+        # kernel reads three activation tensors per layer: its byte floor now exceeds its flop floor.)
+        gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        mfma_frac, hbm_frac = achieved / peak, gbs / HBM_PEAK_GBS
+        if hbm_frac > mfma_frac:
+            head = {'bound': 'hbm', 'kernel': name, 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(hbm_frac, 4)}
+        else:
+            head = {'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+                    'frac': round(mfma_frac, 4)}
+        roofline = dict(head, **{'traffic': None, 'mfma_tflops': round(achieved, 2), 'mfma_frac': round(mfma_frac, 4),
+                    'hbm_gbs_compulsory': round(gbs, 1), 'hbm_frac_compulsory': round(hbm_frac, 4),
                     'mfma_issue_frac': round(achieved * max(nprod, 1) / peak, 4),
                     'peak_note': ('fp32 MFMA peak (v_mfma_f32_32x32x2_f32)' if nprod == 0 else
                                   'dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16); this mode issues %d bf16 product(s) per '
                                   'algorithmic product' % nprod),
                     'launches_per_step': n, 'avg_launch_ms': round(ms / n, 4),
                     'share_of_kernel_time': round(ms / tot_ms, 3),
-                    'algorithmic_flop_per_launch': round(fl / n), 'compulsory_bytes_per_launch': round(by / n)}
+                    'algorithmic_flop_per_launch': round(fl / n), 'compulsory_bytes_per_launch': round(by / n)})
         # HBM bytes per launch of that kernel come from the separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE;
         # tools/profile_round.sh), which cannot run inside this process; the committed summary is quoted when present
         tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', TRAFFIC_FILE)
@@ -352,6 +368,7 @@ def main():
                 rec = json.load(open(tfile))['kernels'].get(name)
                 if rec:
                     roofline['traffic'] = rec['hbm_bytes_per_launch']
+                    roofline['hbm_frac_traffic'] = round(rec['hbm_bytes_per_launch'] / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                     roofline['traffic_unit'] = 'HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB, rocprofv3 PMC passes of ' \
                                                'the same command (profiles/%s)' % TRAFFIC_FILE
             except (ValueError, KeyError):
