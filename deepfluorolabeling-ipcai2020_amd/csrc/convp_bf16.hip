@@ -69,7 +69,10 @@ __device__ __forceinline__ float ld_bf(const __bf16* p) { return (float)*p; }
 #define DFL_CONVP_PRIME 0   // 1: request a block's first two weight groups before its image is staged.  Measured (round 3): 20-30
 #endif                      // more registers live across the staging, 4.75 -> 4.84 ms/step; six k-steps per ring set: 4.87
 template <int WM, int WN, int TM, int TN, int AFF, bool GA, int KS = 1>
-__global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : 2) convp_kernel(const ConvP p) {
+#ifndef DFL_CONVP_MINW3
+#define DFL_CONVP_MINW3 2
+#endif
+__global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : (TM * TN <= 3 ? DFL_CONVP_MINW3 : 2)) convp_kernel(const ConvP p) {
   static_assert(WM * WN == 4, "four waves per k-group");
   static_assert(KS == 1 || (KS == 2 && !GA), "two k-groups: LDS-image form only");
   static_assert(AFF != 2 || !GA, "the fused BatchNorm + ReLU backward operand is staged through LDS");
@@ -510,6 +513,10 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : 2) c
     f[0] = bf_lo(w.x); f[1] = bf_hi(w.x); f[2] = bf_lo(w.y); f[3] = bf_hi(w.y);
     f[4] = bf_lo(w.z); f[5] = bf_hi(w.z); f[6] = bf_lo(w.w); f[7] = bf_hi(w.w);
   };
+  // The per-column constants above must have ARRIVED before the row loops: with a load still outstanding at the loop header the
+  // compiler covers their first use inside the loop by s_waitcnt vmcnt(0) -- which, on every iteration, also waits for the
+  // previous row's STORE to be acknowledged by memory (measured: 3 us of a workgroup's 13 on a 32-column layer).
+  __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0) only
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #ifdef DFL_CONVP_TRACE
@@ -539,7 +546,9 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : 2) c
       const int py = pdiv(rr, p.mPW, p.PW), px = rr - py * p.PW;
       const int n = img0 + img, gy = gy0 + py, gx = gx0 + px;
       if (!(cok && img < p.IPP && n < a.N && gy < p.Hg && gx < p.Wg)) continue;
-      const int64_t m = ((int64_t)n * p.Hg + gy) * p.Wg + gx;
+      // (32-bit element offsets: the host checks every tensor of the epilogue against 2^32 elements; 64-bit multiplies made this
+      // loop the longest stretch of a workgroup's epilogue)
+      const uint32_t m = (uint32_t)((n * p.Hg + gy) * p.Wg + gx);
       float v[8];
       const float4 v0 = *reinterpret_cast<const float4*>(ep + rl * EP + ucol);
       const float4 v1 = *reinterpret_cast<const float4*>(ep + rl * EP + ucol + 4);
@@ -551,14 +560,14 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : 2) c
       }
       if (addp != nullptr) {
         float o[8];
-        unpack(*reinterpret_cast<const pu32x4*>(addp + m * a.ldadd + ncol), o);
+        unpack(*reinterpret_cast<const pu32x4*>(addp + (m * (uint32_t)a.ldadd + (uint32_t)ncol)), o);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += fmaf(o[e], casc[e], cash[e]);
       }
       // pixel and column of this unit in y (scatter2x2: the 2x2 position its column group stands for)
-      const int64_t opix = scat ? (((int64_t)n * a.Hout + 2 * gy + (cab >> 1)) * a.Wout + 2 * gx + (cab & 1)) : m;
+      const uint32_t opix = scat ? (uint32_t)((n * a.Hout + 2 * gy + (cab >> 1)) * a.Wout + 2 * gx + (cab & 1)) : m;
       const int ocol = scat ? cco : ncol;
-      const int64_t yo = opix * a.ldy + ocol;
+      const uint32_t yo = opix * (uint32_t)a.ldy + (uint32_t)ocol;
       if (a.accumulate) {
         float o[8];
         unpack(*reinterpret_cast<const pu32x4*>(yp + yo), o);
@@ -575,7 +584,7 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : 2) c
         float vr[8], u[8];
         unpack(w, vr);                                // statistics of the values as stored
         if (sop != nullptr) {
-          unpack(*reinterpret_cast<const pu32x4*>(sop + opix * a.ldso + ocol), u);
+          unpack(*reinterpret_cast<const pu32x4*>(sop + (opix * (uint32_t)a.ldso + (uint32_t)ocol)), u);
         } else {
 #pragma unroll
           for (int e = 0; e < 8; ++e) u[e] = vr[e];
@@ -937,6 +946,11 @@ static int convp_plan_search(const dfl_conv_args* a, ConvP* p, int force_splits)
   DFL_REQUIRE(a->Ntot % 8 == 0 && a->ldy % 8 == 0 && aligned16(a->y) && (a->add == nullptr || (a->ldadd % 8 == 0 && aligned16(a->add))) &&
                   (a->stat_other == nullptr || (a->ldso % 8 == 0 && aligned16(a->stat_other))),
               "dfl_conv2d (bf16): output columns and the pixel strides of y / add / stat_other must be multiples of 8, tensors 16-byte aligned");
+  {
+    const int64_t opx = (int64_t)a->N * a->Hout * a->Wout, lim = 1ll << 32;
+    DFL_REQUIRE(opx * a->ldy < lim && (a->add == nullptr || opx * a->ldadd < lim) && (a->stat_other == nullptr || opx * a->ldso < lim),
+                "dfl_conv2d (bf16): y / add / stat_other must stay below 2^32 elements");
+  }
   DFL_REQUIRE(a->Cin % 16 == 0 && a->ldx % 8 == 0 && aligned16(a->x) && aligned16(a->w),
               "dfl_conv2d (bf16): needs Cin %% 16 == 0, ldx %% 8 == 0 and 16-byte aligned x / w (Cin = %d, ldx = %d)", a->Cin, a->ldx);
   DFL_REQUIRE(a->w_split == 2, "dfl_conv2d (bf16): weights must be packed with dfl_pack_job.split = 2");
@@ -1079,6 +1093,13 @@ static int convp_launch_t(const ConvP& p, hipStream_t s) {
   const size_t red = (size_t)RPS_ * 2 * BN_ * sizeof(float);                   // statistics scratch
   if (lds < epi) lds = epi;
   if (lds < red) lds = red;
+  {   // diagnosis: extra LDS per workgroup = fewer workgroups per CU (how does a layer's time scale with the workgroups in flight?)
+    static const size_t pad = [] {
+      const char* e = getenv("DFL_CONVP_LDS_PAD_KB");
+      return e ? (size_t)atoi(e) * 1024 : (size_t)0;
+    }();
+    if (lds + pad <= kLdsHard) lds += pad;
+  }
   if constexpr (GA) {
     hipLaunchKernelGGL((convp_kernel<WM, WN, TM, TN, 0, true>), grid, dim3(256), lds, s, p);
   } else if (p.a.x_mode != 0) {
