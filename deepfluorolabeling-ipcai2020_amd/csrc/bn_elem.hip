@@ -191,7 +191,8 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const dfl_bn_bwd_f
     a.dgamma[c] = (float)sdyx;
     a.dbeta[c] = (float)sdy;
     const double s = g * invstd;
-    const double c1 = sdy / cnt, c2 = sdyx / cnt;
+    // count == 0: the statistics were constants (eval mode, running mean / variance): no batch-mean terms
+    const double c1 = a.count > 0 ? sdy / cnt : 0.0, c2 = a.count > 0 ? sdyx / cnt : 0.0;
     // dr = s*(dy - c1 - xhat*c2),  xhat = (r - mean)*invstd
     a.coef[0 * a.C + c] = (float)s;
     a.coef[1 * a.C + c] = (float)(-s * c2 * invstd);
@@ -927,7 +928,7 @@ extern "C" int dfl_bn_eval_prepare(const float* gamma, const float* beta, const 
 extern "C" int dfl_bn_bwd_finalize(const dfl_bn_bwd_finalize_args* a, dfl_stream_t stream) {
   DFL_REQUIRE(a && a->partials && a->gamma && a->save_mean && a->save_invstd && a->dgamma && a->dbeta && a->coef,
               "dfl_bn_bwd_finalize: missing pointer");
-  DFL_REQUIRE(a->C > 0 && a->nblocks > 0 && a->count > 0, "dfl_bn_bwd_finalize: bad sizes");
+  DFL_REQUIRE(a->C > 0 && a->nblocks > 0 && a->count >= 0, "dfl_bn_bwd_finalize: bad sizes");
   const int cpb = finalize_cpb(a->C);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(a->C, cpb)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), *a, cpb);

@@ -88,6 +88,16 @@ class UNetPlan:
         self._keep.append(t)
         return t
 
+    def _const(self, n, value):
+        """A plan-owned constant vector (shared per (length, value))."""
+        key = ('const', int(n), float(value))
+        t = self._scratch.get(key)
+        if t is None:
+            t = torch.full((int(n),), float(value), dtype=torch.float32, device=self.dev)
+            self._keep.append(t)
+            self._scratch[key] = t
+        return t
+
     def _act(self, N, H, W, C):
         t = self._new(N * H * W * C, self.adt)
         return Act(t, t.data_ptr(), C, N, H, W, C, self.aesz)
@@ -543,6 +553,14 @@ class UNetPlan:
                                            running_mean=self.Bf[bname + '.running_mean'].data_ptr(),
                                            running_var=self.Bf[bname + '.running_var'].data_ptr(),
                                            scale=scale.data_ptr(), shift=shift.data_ptr(), C=Cout, eps=BN_EPS))
+                        if self.need_grad:
+                            # gradients through eval-mode BatchNorm (nn.Module semantics of unet.py:161-193): the statistics
+                            # are the running ones -- mean is the buffer itself, 1/sqrt(var + eps) is the scale of (gamma = 1)
+                            ones, zeros = self._const(Cout, 1.0), self._const(Cout, 0.0)
+                            mean = self.Bf[bname + '.running_mean']
+                            fwd.add(BnEvalArgs(gamma=ones.data_ptr(), beta=zeros.data_ptr(), running_mean=mean.data_ptr(),
+                                               running_var=self.Bf[bname + '.running_var'].data_ptr(),
+                                               scale=invstd.data_ptr(), shift=self._new(Cout).data_ptr(), C=Cout, eps=BN_EPS))
                     aff = (scale, shift)
                     bnrec = (gamma, mean, invstd, bname)
                 convs.append(dict(w=w, wname=wname, inp=cur, gin=gin, inp_aff=cur_aff, r=r, bn=bnrec))
@@ -601,7 +619,8 @@ class UNetPlan:
                                                   save_mean=mean.data_ptr(), save_invstd=invstd.data_ptr(),
                                                   dgamma=G[bname + '.weight'].data_ptr(),
                                                   dbeta=G[bname + '.bias'].data_ptr(), coef=coef.data_ptr(),
-                                                  count=r.M, nblocks=prow, C=Cout))
+                                                  count=r.M if self.training else 0,      # 0: fixed (running) statistics
+                                                  nblocks=prow, C=Cout))
                         if do_res and d == bd - 1:
                             # residual bias gradient = column sums of dout, already in the same partials
                             self._defer_sum(bwd, part.data_ptr(), G[prefix + '.res_conv1x1.bias'].data_ptr(), Cout,

@@ -351,9 +351,6 @@ class UNet(nn.Module):
         x = x.detach().to(torch.float32).contiguous()
         self._state()
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list)
-        if need_grad and self._cfg['batch_norm'] and not self.training:
-            raise NotImplementedError('gradients through eval-mode BatchNorm are not implemented in the HIP path; '
-                                      'call net.train() or wrap the call in torch.no_grad()')
         plan = self._get_plan(x, need_grad)
         # first GPU work of a training step: enqueue it before the autograd bookkeeping below (the GPU sits idle between
         # the previous step's loss.item() and this launch)

@@ -245,7 +245,8 @@ typedef struct {
   const float* gamma; const float* save_mean; const float* save_invstd;
   float* dgamma; float* dbeta;   /* [C] */
   float* coef;                   /* [3][C] */
-  int64_t count;
+  int64_t count;                 /* elements per channel; 0: save_mean / save_invstd are constants (eval mode, running
+                                    statistics): A = gamma * invstd, B = C = 0 */
   int32_t nblocks, C;
 } dfl_bn_bwd_finalize_args;
 int dfl_bn_bwd_finalize(const dfl_bn_bwd_finalize_args* a, dfl_stream_t stream);

@@ -176,6 +176,49 @@ def test_training_hipgraph_replay_equals_plain_launches(mode):
         assert len(g0) == len(g1) and all(torch.equal(a, b) for a, b in zip(g0, g1))
 
 
+@pytest.mark.parametrize('mode,key', [('fp32', 'tiny_sc_l14'), ('fp32', 'tiny_mp_l0'), ('bf16x3', 'tiny_bd3_nosm'), ('bf16s', 'landsblock1')])
+def test_gradients_through_eval_mode_batchnorm(mode, key):
+    """nn.Module semantics of unet.py:161-193: net.eval() with gradients enabled -- BatchNorm normalises with its running
+    statistics and is a fixed affine map in backward (d/dx = gamma / sqrt(var + eps), no batch-mean terms; dgamma / dbeta as
+    usual).  Running statistics moved off their initial values; outputs, loss and every parameter gradient against the fp64
+    oracle in eval mode on the HIP run's activation pattern; the buffers stay untouched."""
+    from gpu_common import math_mode_set
+    pr = PR.lands_block(1) if key == 'landsblock1' else PR.tiny(key)
+    g = torch.Generator().manual_seed(11)
+    sd = dict(pr.sd)
+    for k in list(sd):
+        if k.endswith('running_mean'):
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.2
+        elif k.endswith('running_var'):
+            sd[k] = torch.rand(sd[k].shape, generator=g) + 0.5
+    pr.sd = sd
+    ref = pr.oracle64()
+    ref.eval()
+    tol = {'fp32': 2e-4, 'bf16x3': 1e-3, 'bf16s': 6e-2}[mode]
+    with math_mode_set(mode):
+        net = hip_net(pr).eval()
+        before = {k: v.clone() for k, v in net.state_dict().items() if 'running' in k or 'num_batches' in k}
+        out, seg, loss = hip_step(pr, net)
+        plan = NF.train_plan(net)
+        with NF.forced_choices(ref, NF.hip_choices(plan)):
+            grads, oseg = NF.gradients(ref, pr.run)
+        oloss, _ = pr.run(ref)
+        for k, v in net.state_dict().items():
+            if k in before:
+                assert torch.equal(v, before[k]), 'eval mode changed ' + k
+        assert abs(float(loss.detach()) - float(oloss.detach())) <= tol * max(1.0, abs(float(oloss.detach())))
+        assert NF.rel_l2(seg.detach().double().cpu().numpy(), oseg.numpy()) <= tol
+        gall = sum(float(r.double().pow(2).sum()) for r in grads.values() if r is not None) ** 0.5
+        for k, p_ in net.named_parameters():
+            r = grads[k]
+            if r is None:
+                assert p_.grad is None, k
+                continue
+            err = float((p_.grad.detach().double().cpu() - r.double()).norm())
+            # (+ a share of the whole gradient's norm: the bias of lands_block.0 has an EXACT gradient of zero -- NCC ignores offsets)
+            assert err <= tol * float(r.double().norm()) + 0.02 * tol * gall + 1e-9, (k, err, float(r.double().norm()), gall)
+
+
 def test_cpu_input_fails_loudly():
     net = dfl_amd.UNet(n_classes=7, depth=2, wf=2, padding=True, batch_norm=True)
     with pytest.raises(RuntimeError):
