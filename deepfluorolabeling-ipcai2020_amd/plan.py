@@ -47,7 +47,7 @@ class PlanError(RuntimeError):
 
 
 class UNetPlan:
-    def __init__(self, cfg, params, buffers, N, H, W, training, need_grad, device):
+    def __init__(self, cfg, params, buffers, N, H, W, training, need_grad, device, input_grad=False):
         """cfg: dict of the UNet constructor flags; params / buffers: name -> tensor (module state)."""
         self.cfg = cfg
         self.P = params
@@ -55,6 +55,8 @@ class UNetPlan:
         self.N, self.H, self.W = N, H, W
         self.training = training
         self.need_grad = need_grad
+        self.input_grad = bool(input_grad and need_grad)    # d(loss)/d(input) as well (nn.Module semantics; no reference script asks)
+        self.dx_in = None
         self.dev = device
         self.lib = nat.lib()
         self._keep = []
@@ -1013,10 +1015,16 @@ class UNetPlan:
             if i > 0:
                 dxin = self._act(N, rec['xin'].H, rec['xin'].W, rec['xin'].C)
                 pending[i - 1]['dnxt'] = dxin
+            elif self.input_grad:
+                if self.bf16:
+                    raise PlanError('gradients with respect to the network input are implemented for the fp32-tensor arithmetic '
+                                    'modes only (DFL_MATH=fp32 / bf16x3 / bf16x6 / bf16), not for bf16 storage')
+                dxin = self._act(N, rec['xin'].H, rec['xin'].W, rec['xin'].C)
+                self.dx_in = dxin
             else:
                 dxin = None
             st = rec['block_bw'](dout, dxin, fused_in=dout_sums if i == depth - 1 else down_sums,
-                                 dxin_stats=dxin is not None and not cfg['max_pool'])
+                                 dxin_stats=dxin is not None and i > 0 and not cfg['max_pool'])
             if i > 0:
                 pending[i - 1]['dnxt_sums'] = st
         self._flush_sums(bwd)

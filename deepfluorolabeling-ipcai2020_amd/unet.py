@@ -74,7 +74,8 @@ def owner_of(param):
 class _UNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, plan, x, *params):
-        seg, heat = net._run_forward(plan, x)
+        ctx.x_meta = (x.shape, x.dtype) if plan.input_grad else None
+        seg, heat = net._run_forward(plan, x.detach().to(torch.float32).contiguous())
         ctx.net, ctx.plan, ctx.gen = net, plan, plan.generation
         ctx.save_for_backward(seg)
         ctx.n_params = len(params)
@@ -107,6 +108,11 @@ class _UNetFn(torch.autograd.Function):
         net._backward_runner(plan, stream)
         plan.busy = False
         grads = plan.grads()
+        dx = None
+        if ctx.x_meta is not None:                   # NHWC gradient of the plan -> the caller's [B, C, H, W]
+            shape, dtype = ctx.x_meta
+            d = plan.dx_in
+            dx = d.t.view(d.N, d.H, d.W, d.ld)[..., :d.C].permute(0, 3, 1, 2).to(dtype).contiguous().view(shape)
         # Fast hand-off: the gradients are views of the plan's flat arena.  Returning them makes autograd's
         # AccumulateGrad clone every one (135 small copies per step), so when no parameter has hooks and every .grad
         # is empty (the zero_grad() -> backward() pattern of train.py:405-422) the views are installed as .grad
@@ -115,11 +121,11 @@ class _UNetFn(torch.autograd.Function):
             for g, p in zip(grads, params):
                 if g is not None and p.requires_grad:
                     p.grad = g
-            return (None, None, None) + (None,) * len(params)
+            return (None, None, dx) + (None,) * len(params)
         out = []
         for g, p in zip(grads, params):
             out.append(g if p.requires_grad else None)
-        return (None, None, None) + tuple(out)
+        return (None, None, dx) + tuple(out)
 
 
 class UNet(nn.Module):
@@ -260,10 +266,10 @@ class UNet(nn.Module):
             self._weight_params = [p for p in self._param_list if p.dim() == 4]
         return self._param_dict, self._buffer_dict
 
-    def _get_plan(self, x, need_grad):
+    def _get_plan(self, x, need_grad, input_grad=False):
         P, B = self._state()
         N, _, H, W = x.shape
-        key = (N, H, W, self.training, need_grad, nat.lib().dfl_get_math_mode())   # operand formats depend on the mode
+        key = (N, H, W, self.training, need_grad, nat.lib().dfl_get_math_mode(), bool(input_grad))   # operand formats depend on the mode
         plans = self._plans.setdefault(key, [])
         for p in plans:
             if not p.busy:
@@ -278,7 +284,7 @@ class UNet(nn.Module):
             if p_.device != x.device or p_.dtype != torch.float32 or not p_.is_contiguous():
                 raise RuntimeError('UNet parameters must be contiguous float32 tensors on %s' % x.device)
         try:
-            plan = UNetPlan(self._cfg, P, B, N, H, W, self.training, need_grad, x.device)
+            plan = UNetPlan(self._cfg, P, B, N, H, W, self.training, need_grad, x.device, input_grad=input_grad)
         except PlanError as e:
             raise RuntimeError(str(e))
         plans.append(plan)
@@ -345,13 +351,11 @@ class UNet(nn.Module):
                                'fallback); move the network and its input to the device')
         if x.dim() != 4 or x.shape[1] != self._cfg['in_channels']:
             raise RuntimeError('expected input of shape [B, %d, H, W]' % self._cfg['in_channels'])
-        if x.requires_grad and torch.is_grad_enabled():
-            raise NotImplementedError('gradients with respect to the network INPUT are not implemented in the HIP path (no '
-                                      'reference script asks for them); pass x.detach()')
+        x_src = x if (x.requires_grad and torch.is_grad_enabled()) else None     # d(loss)/d(input) wanted (nn.Module semantics)
         x = x.detach().to(torch.float32).contiguous()
         self._state()
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list)
-        plan = self._get_plan(x, need_grad)
+        need_grad = torch.is_grad_enabled() and (x_src is not None or any(p.requires_grad for p in self._param_list))
+        plan = self._get_plan(x, need_grad, input_grad=x_src is not None)
         # first GPU work of a training step: enqueue it before the autograd bookkeeping below (the GPU sits idle between
         # the previous step's loss.item() and this launch)
         self._ensure_packed(plan, torch.cuda.current_stream().cuda_stream)
@@ -361,4 +365,4 @@ class UNet(nn.Module):
         plan.busy = True
         plan.generation += 1
         self._last_train_plan = weakref.ref(plan)
-        return _UNetFn.apply(self, plan, x, *self._param_list)
+        return _UNetFn.apply(self, plan, x if x_src is None else x_src, *self._param_list)

@@ -219,6 +219,52 @@ def test_gradients_through_eval_mode_batchnorm(mode, key):
             assert err <= tol * float(r.double().norm()) + 0.02 * tol * gall + 1e-9, (k, err, float(r.double().norm()), gall)
 
 
+@pytest.mark.parametrize('mode,key', [('fp32', 'tiny_sc_l14'), ('fp32', 'tiny_mp_l0'), ('bf16x3', 'tiny_bd3_nosm'), ('fp32', 'tiny_valid_nores')])
+def test_gradient_with_respect_to_the_input(mode, key):
+    """nn.Module semantics of unet.py:161-193: an input that requires a gradient gets one (fp32-tensor modes: the first block's
+    3x3 and residual 1x1 data gradients with ONE output channel) -- against the fp64 oracle on the HIP run's activation pattern;
+    the parameter gradients of the same pass stay what they are without it.  The bf16 storage mode refuses, loudly."""
+    from gpu_common import math_mode_set
+    if key not in TINY_CFGS:
+        pytest.skip('no such fixture')
+    pr = PR.tiny(key)
+    ref = pr.oracle64()
+    tol = {'fp32': 2e-4, 'bf16x3': 2e-3}[mode]
+    with math_mode_set(mode):
+        net = hip_net(pr)
+        out, seg, loss = hip_step(pr, net)
+        base = {k: p_.grad.clone() for k, p_ in net.named_parameters() if p_.grad is not None}
+        net2 = hip_net(pr)
+        x = pr.x.clone().to(DEV).requires_grad_(True)
+        keep = pr.x
+        try:
+            pr.x = x
+            hip_step(pr, net2)
+        finally:
+            pr.x = keep
+        assert x.grad is not None and x.grad.shape == x.shape
+        for k, p_ in net2.named_parameters():
+            if p_.grad is not None:
+                assert torch.equal(p_.grad, base[k]), k
+        plan = NF.train_plan(net2)
+        x64 = pr.x.double().clone().requires_grad_(True)
+        with NF.forced_choices(ref, NF.hip_choices(plan)):
+            try:
+                pr.x = x64
+                ref.zero_grad()
+                oloss, _ = pr.run(ref)
+                oloss.backward()
+            finally:
+                pr.x = keep
+        err = float((x.grad.double().cpu() - x64.grad).norm()) / float(x64.grad.norm())
+        assert err <= tol, err
+    with math_mode_set('bf16s'):
+        prb = PR.lands_block(1)
+        netb = hip_net(prb)
+        with pytest.raises(RuntimeError, match='fp32-tensor'):
+            netb(prb.x.clone().to(DEV).requires_grad_(True))
+
+
 def test_cpu_input_fails_loudly():
     net = dfl_amd.UNet(n_classes=7, depth=2, wf=2, padding=True, batch_norm=True)
     with pytest.raises(RuntimeError):
