@@ -220,7 +220,13 @@ __device__ __forceinline__ void st8c(float* base, int64_t elem, float* v) {
   }
 }
 
-constexpr int ROWS_CONV_RB = 2, ROWS_WGRAD_RB = 4;   // (measured against 4 / 6 rows with four pixels in flight per thread and the
+#ifndef DFL_ROWS_CONV_RB
+#define DFL_ROWS_CONV_RB 2
+#endif
+#ifndef DFL_ROWS_WGRAD_RB
+#define DFL_ROWS_WGRAD_RB 4
+#endif
+constexpr int ROWS_CONV_RB = DFL_ROWS_CONV_RB, ROWS_WGRAD_RB = DFL_ROWS_WGRAD_RB;   // (measured against 4 / 6 rows with four pixels in flight per thread and the
 // weights staged through LDS: 37 / 40 us here, 79 / 47 us there -- 184 registers halve the occupancy these short loops live on)
 
 template <bool BF>

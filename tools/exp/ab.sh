@@ -16,9 +16,9 @@ except Exception as e:
 k = d.get('kernels', {})
 def fam(prefix):
     return sum(v['ms'] for n, v in k.items() if n.startswith(prefix))
-print('%-40s %8.1f img/s %6.3f ms/step | gpu %6.3f host %5.2f idle %.3f | convp %.3f wgradp %.3f reduce %.3f bnrelu %.3f bnfin %.3f head %.3f' % (
+print('%-40s %8.1f img/s %6.3f ms/step | gpu %6.3f host %5.2f idle %.3f | convp %.3f wgradp %.3f reduce %.3f bnrelu %.3f bnfin %.3f head %.3f direct %.3f' % (
     sys.argv[1], d['value'], d['ms_per_step'], d.get('gpu_time_ms_per_step', 0), d.get('host_enqueue_ms_per_step', 0), d.get('gpu_idle_frac', 0),
-    fam('convp_kernel'), fam('wgradp_kernel'), fam('ReduceBatch'), fam('BnReluBwd'), fam('BnFinalize') + fam('BnBwdFinalize'), fam('Head')) + ' partial MB %s' % d.get('partial_sum_mb_per_step'))
+    fam('convp_kernel'), fam('wgradp_kernel'), fam('ReduceBatch'), fam('BnReluBwd'), fam('BnFinalize') + fam('BnBwdFinalize'), fam('Head'), fam('direct_')) + ' partial MB %s' % d.get('partial_sum_mb_per_step'))
 PY
 done
 cat $out
