@@ -533,7 +533,11 @@ static int wgp_plan(const dfl_wgrad_args* a, WgP* p, bool need_out) {
     int64_t lds, du, gu;
     geom(ipp_, ph_, pw_, &lds, &du, &gu);
     const double npatch = (double)ceil_div(a->N, ipp_) * (double)ceil_div(a->Hout, ph_) * (double)ceil_div(a->Wout, pw_);
-    const double cost = npatch * ((double)(du + gu) * 16.0 + 24.0 * 1024.0);
+    static const double charge = [] {                 // bytes-equivalent of a patch's fixed costs (barriers, load round trip)
+      const char* e = getenv("DFL_WGP_PATCH_CHARGE_KB");
+      return (e ? atof(e) : 24.0) * 1024.0;
+    }();
+    const double cost = npatch * ((double)(du + gu) * 16.0 + charge);
     if (cost < best_cost) {
       best_cost = cost;
       ipp = ipp_;
