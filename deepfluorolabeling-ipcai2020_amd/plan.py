@@ -364,6 +364,8 @@ class UNetPlan:
         key = 'dz'
         if fused and g.t is self._scratch.get('dz'):
             key = 'dpre0'
+        if fused:
+            self._side_join(self.bwd, buf=key)      # side-stream weight gradients that still read this scratch
         return self._scratch_act(key, N, H, W, Cc)
 
     def _shared_scratch(self, key, nelem):
@@ -634,10 +636,10 @@ class UNetPlan:
                     # and data-gradient kernels form [r > 0] * (A dy + B r + C) from (dy, r) while they stage their patches --
                     # dpre is never written (one tensor pass and one launch per layer less), the bias-gradient sums come out
                     # of the weight-gradient kernel.  The 1-channel first layer (direct kernels) keeps the materialised form.
-                    fuse_brb = self.FUSE_BRB and not self.SIDE_STREAM and bool(r.bf16) and bool(inp.bf16) and inp.C % 16 == 0 and g.bf16 == r.bf16
+                    fuse_brb = self.FUSE_BRB and bool(r.bf16) and bool(inp.bf16) and inp.C % 16 == 0 and g.bf16 == r.bf16
                     # ... and the network's first layer (1-channel fp32 input, no data gradient): the row form of the direct
                     # weight-gradient kernel does the same while it reads its d rows
-                    if (self.FUSE_BRB and not self.SIDE_STREAM and bool(r.bf16) and g.bf16 == r.bf16 and not inp.bf16 and inp.C == 1
+                    if (self.FUSE_BRB and bool(r.bf16) and g.bf16 == r.bf16 and not inp.bf16 and inp.C == 1
                             and d == 0 and dxin is None and Cout in (8, 16, 32, 64)):
                         fuse_brb = True
                     brb = (r, coef) if fuse_brb else None
@@ -653,8 +655,13 @@ class UNetPlan:
                                               partials=bpart.data_ptr(), M=r.M, C=Cout, lddy=g.ld, ldr=r.ld, ldo=dpre.ld,
                                               nblocks=nb, split_out=dsplit, bf16=r.bf16))
                         self._defer_sum(bwd, bpart.data_ptr(), G[cv['wname'] + '.bias'].data_ptr(), Cout, Cout, nb)
+                    side_buf = self._dpre_turn
+                    if fuse_brb:
+                        # (a side-stream weight gradient reads dy itself: the scratch it lives in must not be rewritten --
+                        # by the data gradient one layer further down -- before it is done: _dz_for joins on this key)
+                        side_buf = next((kk for kk in ('dz', 'dpre0') if g.t is self._scratch.get(kk)), None)
                     self._wgrad(bwd, cv['gin'], dpre, G[cv['wname'] + '.weight'], 3, 3, 1, 0 if circ else pad, r.H, r.W,
-                                in_aff=cv['inp_aff'], side=side, side_buf=self._dpre_turn, d_split=dsplit, brb=brb,
+                                in_aff=cv['inp_aff'], side=side, side_buf=side_buf, d_split=dsplit, brb=brb,
                                 bias_out=G[cv['wname'] + '.bias'])
                     if circ and (d > 0 or dxin is not None):
                         # data gradient on the framed grid, folded back onto the pixels the frame copies (see _wrap_pad)
