@@ -69,6 +69,9 @@ __device__ __forceinline__ float ld_bf(const __bf16* p) { return (float)*p; }
 #define DFL_CONVP_PRIME 0   // 1: request a block's first two weight groups before its image is staged.  Measured (round 3): 20-30
 #endif                      // more registers live across the staging, 4.75 -> 4.84 ms/step; six k-steps per ring set: 4.87
 template <int WM, int WN, int TM, int TN, int AFF, bool GA, int KS = 1>
+#ifndef DFL_CONVP_ADEPTH
+#define DFL_CONVP_ADEPTH 1    // k-steps the A fragments run ahead (2, a second register set, measured: no faster)
+#endif
 #ifndef DFL_CONVP_MINW3
 #define DFL_CONVP_MINW3 2
 #endif
@@ -162,6 +165,11 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : (TM 
   const int S_steps = p.T * CKC;                   // k-steps per block
   const int cin_chunks = a.Cin >> 4;
   const int KW = a.KW;
+  // tap / KW without a division: (tap * ceil(256 / KW)) >> 8 is exact for tap < 16 (at most 16 taps), KW <= 16.  The k loop asks for
+  // it once per k-step; the scalar division the compiler emits for it (22 dependent scalar instructions) sat in the chain
+  // cursor -> LDS address -> fragment read -> matrix instruction and made that chain longer than the three matrix instructions
+  // of a k-step (rocprofv3: 15-18 scalar instructions per matrix instruction in these kernels).
+  const int kw_magic = (256 + KW - 1) / KW;
 
 #ifdef DFL_CONVP_TRACE   // diagnosis build (tools/exp/convp_trace.py): shader-clock stamps of wave 0 at the phase boundaries
   long long tr_t[10];
@@ -365,16 +373,19 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : (TM 
 #endif
 
     // ================================================================ k-steps of this block: s = tap * CKC + chunk
-    // A fragments run one k-step ahead of the matrix instructions that use them: the reads of step s + 1 are issued
-    // before the instructions of step s (a fragment read takes 64-128 cycles, an instruction 32)
-    bf16x8_t afn[TM];
-    auto fetch_a = [&](int s) {
+    // A fragments run DFL_CONVP_ADEPTH (1) k-steps ahead of the matrix instructions that use them: the reads of step s + 1 are
+    // issued before the instructions of step s (a fragment read takes 64-128 cycles plus the scalar cursor arithmetic in front of
+    // its address, an instruction 32).  With depth 2 two register sets take turns (G is even: a group always starts on set 0).
+    static_assert(G % 2 == 0 || DFL_CONVP_ADEPTH == 1, "the A-fragment sets alternate inside a group");
+    constexpr int AD = DFL_CONVP_ADEPTH;
+    bf16x8_t afq[AD][TM];
+    auto fetch_a = [&](int s, int slot) {
       s = s < S_steps ? s : S_steps - 1;           // dead steps of the last group: weights were loaded as zeros
       const int tap = s >> ckc_sh, cc = s & (CKC - 1);
-      const int ty = tap / KW, tx = tap - ty * KW;
+      const int ty = (tap * kw_magic) >> 8, tx = tap - ty * KW;
       const uint32_t aoff = (uint32_t)((ty * p.IW + tx) * S + cc * 32);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) afn[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const pu32x4*>(smem + a_base[i] + aoff));
+      for (int i = 0; i < TM; ++i) afq[slot][i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const pu32x4*>(smem + a_base[i] + aoff));
     };
     auto compute_group = [&](int gl, int set) {
       const int g = gl * KS + kg;
@@ -382,8 +393,9 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : (TM 
       for (int e = 0; e < G; ++e) {
         bf16x8_t af[TM];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = afn[i];
-        fetch_a(e + 1 < G ? g * G + e + 1 : (g + KS) * G);      // the step this k-group takes next
+        for (int i = 0; i < TM; ++i) af[i] = afq[e % AD][i];
+        // the step this k-group takes AD steps from now
+        fetch_a(e + AD < G ? g * G + e + AD : (g + KS) * G + (e + AD - G), e % AD);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, breg[set][e][j]);
@@ -392,7 +404,8 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : (TM 
         }
       }
     };
-    fetch_a(kg * G);
+#pragma unroll
+    for (int d = 0; d < AD; ++d) fetch_a(kg * G + d, d);
     if (!DFL_CONVP_PRIME) {
       load_group(blk, 0, 0);
       load_group(blk, 1, 1);
