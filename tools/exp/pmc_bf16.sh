@@ -15,14 +15,16 @@ f = glob.glob(sys.argv[1] + '/**/p_counter_collection.csv', recursive=True)
 d = collections.defaultdict(lambda: collections.defaultdict(list))
 def short(n):
     n = n.replace('void ', '').replace('dfl::', '')
-    m = re.match(r'(convp_kernel<\d+, \d+, \d+, \d+, \d+)', n)
-    if m: return m.group(1) + '>'
+    m = re.match(r'(convp_kernel<\d+, \d+, \d+, \d+, \d+), (true|false)', n)
+    if m: return m.group(1) + (', GA>' if m.group(2) == 'true' else '>')
     m = re.match(r'(wgradp_kernel<\d+, \d+)', n)
     if m: return m.group(1) + '>'
     return n.split('(')[0][:40]
 for r in csv.DictReader(open(f[0])):
     d[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
-keep = [k for k in d if k.startswith('convp_kernel<1, 4, 3, 1') or k.startswith('convp_kernel<4, 1, 3, 1') or k.startswith('wgradp_kernel<3, 3') or k.startswith('convp_kernel<2, 2, 3, 1')]
+import os
+pref = os.environ.get('PMC_KERNELS', 'convp_kernel<1, 4, 3, 1;convp_kernel<4, 1, 3, 1;wgradp_kernel<3, 3;convp_kernel<2, 2, 3, 1').split(';')
+keep = [k for k in d if any(k.startswith(q) for q in pref)]
 for k in sorted(keep):
     print(k, len(next(iter(d[k].values()))), 'launches')
     for c, v in d[k].items():
