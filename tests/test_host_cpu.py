@@ -224,3 +224,26 @@ def test_loss_stage_and_stride_arguments_are_validated():
     a.stage = 2
     a.dseg_sN = 64                                                        # a stride without its partners
     assert L.dfl_dice_ncc_loss(C.addressof(a), None) < 0 and b'strides' in L.dfl_last_error()
+
+
+def test_product_path_never_touches_the_oracle():
+    """oracle/ is test infrastructure: only tests/, tools/ (fixture generation), __graft_entry__.smoke() and bench.py's cpu_baseline
+    leg may import it -- never the package or the host scripts (a product path that routes through the CPU restatement would void
+    every parity claim)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pat = re.compile(r'^\s*(from\s+oracle\b|import\s+oracle\b)', re.M)
+    product = [os.path.join(root, f) for f in ('train.py', 'test_ensemble.py', 'est_lands_csv.py', 'compute_actual_dice_on_test.py', 'dfl_amd.py')]
+    pkg = os.path.join(root, 'deepfluorolabeling-ipcai2020_amd')
+    for d, _, files in os.walk(pkg):
+        product += [os.path.join(d, f) for f in files if f.endswith('.py')]
+    for f in product:
+        if os.path.exists(f):
+            assert not pat.search(open(f).read()), '%s imports the oracle' % f
+    # the two allowed root files use it in exactly one function each
+    for f, fn in (('bench.py', 'cpu_baseline'), ('__graft_entry__.py', 'smoke')):
+        src = open(os.path.join(root, f)).read()
+        hits = [m.start() for m in pat.finditer(src)]
+        assert len(hits) == 1, (f, len(hits))
+        head = src[:hits[0]]
+        assert head.rfind('def ') == head.rfind('def ' + fn), '%s: the oracle import is not inside %s()' % (f, fn)
