@@ -247,3 +247,20 @@ def test_product_path_never_touches_the_oracle():
         assert len(hits) == 1, (f, len(hits))
         head = src[:hits[0]]
         assert head.rfind('def ') == head.rfind('def ' + fn), '%s: the oracle import is not inside %s()' % (f, fn)
+
+
+def test_missing_library_fails_loudly():
+    """No fallback: without libdfl_hip.so the first call into the library raises (a subprocess, so that this process keeps its
+    loaded library)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import dfl_amd\n"
+            "from dfl_amd import _native as nat\n"
+            "try:\n"
+            "    nat.lib()\n"
+            "except nat.DflError as e:\n"
+            "    print('RAISED', e)\n" % root)
+    env = dict(os.environ, DFL_LIB_OVERRIDE='/nonexistent/libdfl_hip.so')
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
+    assert 'RAISED' in out.stdout and 'no fallback' in out.stdout, (out.stdout[-400:], out.stderr[-400:])
