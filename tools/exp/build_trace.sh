@@ -5,8 +5,8 @@ root="$(cd "$(dirname "${BASH_SOURCE[0]}")/../.." && pwd)"
 src="$root/deepfluorolabeling-ipcai2020_amd/csrc"; lib="$root/deepfluorolabeling-ipcai2020_amd/lib"
 bash "$src/build.sh" >/dev/null
 mkdir -p "$root/tools/exp/bin"
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -DDFL_CONVP_TRACE -c "$src/convp_bf16.hip" -o "$root/tools/exp/bin/convp_trace.o" &
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -DDFL_WGP_TRACE -c "$src/wgradp_bf16.hip" -o "$root/tools/exp/bin/wgradp_trace.o" &
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -mllvm -amdgpu-sched-strategy=max-ilp -DDFL_CONVP_TRACE -c "$src/convp_bf16.hip" -o "$root/tools/exp/bin/convp_trace.o" &
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -mllvm -amdgpu-sched-strategy=max-ilp -DDFL_WGP_TRACE -c "$src/wgradp_bf16.hip" -o "$root/tools/exp/bin/wgradp_trace.o" &
 wait
 objs=$(ls "$lib"/*.o | grep -v convp_bf16.o | grep -v wgradp_bf16.o)
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$root/tools/exp/bin/libdfl_trace.so" $objs "$root/tools/exp/bin/convp_trace.o" "$root/tools/exp/bin/wgradp_trace.o"

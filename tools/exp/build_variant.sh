@@ -15,7 +15,9 @@ for o in $lib/*.o; do
   case " $files " in *" $b "*) ;; *) objs="$objs $o";; esac
 done
 for f in $files; do
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function "$@" -c $src/$f.hip -o $out/$f.o &
+  extra=""
+  case "$f" in convp_bf16|wgradp_bf16) extra="-mllvm -amdgpu-sched-strategy=max-ilp";; esac      # as csrc/build.sh
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function $extra "$@" -c $src/$f.hip -o $out/$f.o &
 done
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC -o $out/libdfl_hip.so $objs $out/*.o
