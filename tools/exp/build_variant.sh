@@ -16,7 +16,7 @@ for o in $lib/*.o; do
 done
 for f in $files; do
   extra=""
-  case "$f" in convp_bf16|wgradp_bf16) extra="-mllvm -amdgpu-sched-strategy=max-ilp";; esac      # as csrc/build.sh
+  case "$f" in convp_bf16|wgradp_bf16|bn_elem) extra="-mllvm -amdgpu-sched-strategy=max-ilp";; esac      # as csrc/build.sh
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function $extra "$@" -c $src/$f.hip -o $out/$f.o &
 done
 wait
