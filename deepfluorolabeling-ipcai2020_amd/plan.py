@@ -606,7 +606,9 @@ class UNetPlan:
                     # two dpre buffers alternate, so a side-stream weight gradient may still read one while the next
                     # layer fills the other; the one about to be rewritten must be free
                     self._dpre_turn ^= 1
-                    self._side_join(bwd, buf=self._dpre_turn)
+                    if g.t is self._scratch.get('dpre%d' % self._dpre_turn):
+                        self._dpre_turn ^= 1              # never the buffer the incoming gradient lives in (mixed fused / plain layers)
+                    self._side_join(bwd, buf='dpre%d' % self._dpre_turn)
                     dpre = self._scratch_act('dpre%d' % self._dpre_turn, N, r.H, r.W, Cout)
                     nb = self.lib.dfl_rowblock_count(r.M, Cout)
                     coef = None
@@ -655,7 +657,7 @@ class UNetPlan:
                                               partials=bpart.data_ptr(), M=r.M, C=Cout, lddy=g.ld, ldr=r.ld, ldo=dpre.ld,
                                               nblocks=nb, split_out=dsplit, bf16=r.bf16))
                         self._defer_sum(bwd, bpart.data_ptr(), G[cv['wname'] + '.bias'].data_ptr(), Cout, Cout, nb)
-                    side_buf = self._dpre_turn
+                    side_buf = 'dpre%d' % self._dpre_turn          # (one key space: scratch names, see _side_join / _dz_for)
                     if fuse_brb:
                         # (a side-stream weight gradient reads dy itself: the scratch it lives in must not be rewritten --
                         # by the data gradient one layer further down -- before it is done: _dz_for joins on this key)
@@ -1016,7 +1018,10 @@ class UNetPlan:
                     wd = self._pack_down_dgrad(self.P[wname + '.weight'])
                     # the last kernel that writes dout leaves sum(dout), sum(dout * r_last) for the block's first BN backward
                     r_last = rec['block_bw'].last_r
-                    want = self.FUSE_DOWN_STATS and r_last is not None and bool(dout.bf16) and bool(r_last.bf16)
+                    # (the scatter visits the 2*H' x 2*W' pixels it writes: with an odd out.H / out.W the last row / column of
+                    # dout holds bridge gradient only and would be missing from the sums -- then the separate pass takes them)
+                    want = (self.FUSE_DOWN_STATS and r_last is not None and bool(dout.bf16) and bool(r_last.bf16)
+                            and out.H == 2 * nxt.H and out.W == 2 * nxt.W)
                     down_sums = self._conv(bwd, dnxt, wd, dout, 1, 1, 1, 0, 4 * Ci, accumulate=1, scatter=1,
                                            Hout=out.H, Wout=out.W, stats=want, stat_other=r_last if want else None)
             if i > 0:

@@ -275,6 +275,86 @@ class GradientCheck:
         return {'worst': worst, 'whole': whole, 'eps_eff': eps_eff, 'bars': bars, 'ref': ref, 'info': info, 'd_fwd': d_fwd}
 
 
+# ---- the bf16 STORAGE arithmetic against its own fp64 emulation (oracle/bf16_emu.py) ----------------------------------------
+# The emulation rounds to bf16 wherever the product stores or stages a bf16 value, so what separates a HIP gradient from it
+# (on the HIP run's activation pattern) is fp32 accumulation order plus rare one-ulp bf16 flips -- measured on MI355X at the
+# level of the bf16x3 arithmetic.  Fixed bars, nothing calibrated on the run under test: the forward output has
+# to be within BF16S_FWD_BAR of the emulation's, a flipped ReLU / pooling decision within BF16S_MARGIN_BAR of undecided, and
+# the per-convolution noise level the gradient bars are made of is BF16S_EPS (not derived from the run's own deviation).
+BF16S_FWD_BAR = 1.0e-3
+BF16S_MARGIN_BAR = 1.0e-3
+BF16S_EPS = 3.0e-5
+BF16S_WHOLE_BAR = 1.0e-3
+BF16S_FLIP_FRAC = 1.0e-4
+
+
+def emulated_reference(gc, plan):
+    """oracle/bf16_emu.py on gc.problem with the ReLU masks and pooling choices of the HIP run `plan` holds."""
+    from oracle import bf16_emu as E
+    emu = E.Bf16Emulation(gc.net, dict(gc.problem.cfg), choices=hip_choices(plan))
+    return emu.run(gc.problem.x, gc.problem.loss_of)
+
+
+def check_bf16_storage(gc, net, hip_out, hip_loss=None, hip_heat=None, what='', measure_only=False):
+    """Assert a bf16-storage run of `net` (dfl_amd.UNet after backward) against the fp64 emulation of that arithmetic on the run's
+    own pattern: forward, loss, every gradient tensor, the whole gradient.  Returns the measurements."""
+    plan = train_plan(net)
+    assert plan.bf16, 'not a bf16-storage plan'
+    ref = emulated_reference(gc, plan)
+    info = ref['info']
+    d_fwd = rel_l2(hip_out.detach().double().cpu().numpy(), ref['seg'].numpy())
+    fl = gc.floor
+    bars = {}
+    for k, s in fl['s_conv'].items():
+        kk = K_WHOLE if k == '*' else K_TENSOR
+        bars[k] = kk * ((BF16S_EPS * s) ** 2 + fl['s_bn'][k] ** 2) ** 0.5 + gc.abs_term
+    bars['*'] = min(bars['*'], BF16S_WHOLE_BAR)
+    flip_frac = (info['relu_flips'] + info['pool_flips']) / max(info['relu_total'], 1)
+    res = {'d_fwd': d_fwd, 'info': info, 'bars': bars, 'flip_frac': flip_frac, 'ref': ref}
+    if hip_heat is not None and ref['heat'] is not None:
+        res['d_heat'] = rel_l2(hip_heat.detach().double().cpu().numpy(), ref['heat'].numpy())
+    if hip_loss is not None:
+        res['d_loss'] = abs(float(hip_loss) - ref['loss']) / max(abs(ref['loss']), 1e-12)
+    worst, worst_k, num_all, den_all = 0.0, None, 0.0, 0.0
+    errs = {}
+    for k, p in net.named_parameters():
+        r = ref['grads'][k]
+        if r is None:
+            assert p.grad is None, '%s%s: gradient where the reference has none' % (what, k)
+            continue
+        assert p.grad is not None, '%s%s: no gradient' % (what, k)
+        got = p.grad.detach().double().cpu()
+        num = float((got - r).pow(2).sum())
+        den = max(float(r.pow(2).sum()), 1e-300)
+        gn, gn_all = fl['gnorm'][k], fl['gnorm']['*']
+        num_all += num
+        if den ** 0.5 < 1e-6 * gn_all and gn < 1e-6 * gn_all:        # exact gradient zero (see GradientCheck.check)
+            errs[k] = ('abs', num ** 0.5, bars[k] * gn + 1e-12)
+            continue
+        den_all += den
+        e = (num / den) ** 0.5
+        errs[k] = ('rel', e, bars[k])
+        if e / bars[k] > worst:
+            worst, worst_k = e / bars[k], k
+    res.update(worst=worst, worst_k=worst_k, whole=(num_all / den_all) ** 0.5, errs=errs)
+    if measure_only:
+        return res
+    assert d_fwd <= BF16S_FWD_BAR, '%sforward output %.3e (relative L2) off the bf16 emulation (bar %.1e)' % (what, d_fwd, BF16S_FWD_BAR)
+    if 'd_heat' in res:
+        assert res['d_heat'] <= BF16S_FWD_BAR, '%sheat maps %.3e off the bf16 emulation' % (what, res['d_heat'])
+    if 'd_loss' in res:
+        assert res['d_loss'] <= BF16S_FWD_BAR, '%sloss %.3e off the bf16 emulation' % (what, res['d_loss'])
+    assert info['max_margin'] <= BF16S_MARGIN_BAR, \
+        '%sa decision differs from the emulation where it is not undecided: margin %.3e of the layer rms (bar %.1e; %d ReLU + %d ' \
+        'pooling decisions differ)' % (what, info['max_margin'], BF16S_MARGIN_BAR, info['relu_flips'], info['pool_flips'])
+    assert flip_frac <= BF16S_FLIP_FRAC, '%s%.2e of the decisions differ from the emulation (bar %.1e)' % (what, flip_frac, BF16S_FLIP_FRAC)
+    for k, (kind, e, bar) in errs.items():
+        assert e <= bar, '%s%s: gradient %s error %.3e > bar %.3e against the bf16 emulation (sensitivity %.3g)' % (
+            what, k, 'absolute' if kind == 'abs' else 'relative L2', e, bar, fl['s_conv'][k])
+    assert res['whole'] <= bars['*'], '%swhole gradient: relative L2 error %.3e > bar %.3e against the bf16 emulation' % (what, res['whole'], bars['*'])
+    return res
+
+
 _EPS_CACHE = {}
 
 

@@ -35,6 +35,13 @@ class Problem:
             loss = R.dice_loss_2d(R.center_crop(seg, self.tseg.shape), self.tseg.double(), skip_bg=self.skip_bg)
         return loss, seg
 
+    def loss_of(self, seg, heat):
+        """The same loss from the two network outputs (fp64; oracle/bf16_emu.py drives its own forward)."""
+        if self.theat is not None:
+            return R.dice_and_heatmap_loss_2d((R.center_crop(seg, self.tseg.shape), R.center_crop(heat, self.theat.shape)),
+                                              (self.tseg.double(), self.theat.double()), skip_bg=False, heatmap_wgt=0.5)
+        return R.dice_loss_2d(R.center_crop(seg, self.tseg.shape), self.tseg.double(), skip_bg=self.skip_bg)
+
 
 def _t(a):
     return torch.from_numpy(np.asarray(a))

@@ -371,7 +371,7 @@ class Trainer:
             self.last_loss = loss.detach()
             steps += 1
             if self.world > 1:
-                self._rank_losses.append(loss)
+                self._rank_losses.append(self.last_loss)     # (detached: only the value is used)
                 if len(self._rank_losses) >= window or self.args.sync_loss:
                     self._flush_rank_losses()
                 continue
