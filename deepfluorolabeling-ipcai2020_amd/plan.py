@@ -46,6 +46,11 @@ class PlanError(RuntimeError):
     pass
 
 
+# Diagnosis (tests/test_gpu_bf16_stepwise.py): plans built while this is True give every activation gradient its own buffer
+# instead of the three shared scratch tensors, so that all of them can be read after a backward pass (UNetPlan.dbg names them).
+KEEP_GRADS = False
+
+
 class UNetPlan:
     def __init__(self, cfg, params, buffers, N, H, W, training, need_grad, device, input_grad=False):
         """cfg: dict of the UNet constructor flags; params / buffers: name -> tensor (module state)."""
@@ -81,6 +86,8 @@ class UNetPlan:
         self.aesz = 2 if self.bf16 else 4
         self._packed_split = {}         # packed-weight address -> stored as split quads
         self.relu_out = {}              # nn.ReLU module name -> Act of its output (saved for backward; introspection for tests)
+        self.dbg = {}                   # name -> Act / tensors of intermediate results (introspection for tests, see KEEP_GRADS)
+        self.keep_grads = bool(KEEP_GRADS)
         self.pool_in = {}               # level -> Act the max-pool of that level reads
         self._build()
 
@@ -110,6 +117,8 @@ class UNetPlan:
         t = self._scratch.get(key)
         if t is None or t.numel() < need:
             raise PlanError('scratch %s not sized' % key)
+        if self.keep_grads:
+            return self._act(N, H, W, C)
         return Act(t, t.data_ptr(), C, N, H, W, C, self.aesz)
 
     # ------------------------------------------------------------------------------------------ weights
@@ -567,6 +576,7 @@ class UNetPlan:
                                                scale=invstd.data_ptr(), shift=self._new(Cout).data_ptr(), C=Cout, eps=BN_EPS))
                     aff = (scale, shift)
                     bnrec = (gamma, mean, invstd, bname)
+                    self.dbg['bn:' + bname] = (scale, shift, mean, invstd)
                 convs.append(dict(w=w, wname=wname, inp=cur, gin=gin, inp_aff=cur_aff, r=r, bn=bnrec))
                 self.relu_out['%s.block.%d' % (prefix, d * step + 1)] = r      # (module name of the nn.ReLU: tests read its mask)
                 cur, cur_aff = r, aff
@@ -582,12 +592,18 @@ class UNetPlan:
                     a.scale, a.shift = cur_aff[0].data_ptr(), cur_aff[1].data_ptr()
                 fwd.add(a)
 
+            self.dbg['out:' + prefix] = out
+            self.dbg['xin:' + prefix] = xin
+
             def backward(dout, dxin, fused_in=None, dxin_stats=False):
                 """dout: Act with d(loss)/d(block output); dxin: Act to receive d/d(xin) (None for the net input).
                 fused_in: (partials, rows) with sum(dout), sum(dout * r_last) per channel when the kernel that wrote dout
                 already left them (saves this block's first statistics pass).  dxin_stats: let the LAST kernel that
                 writes dxin leave its column sums; returns them as (partials, rows) -- the caller's bias gradient."""
                 G = self.G
+                self.dbg['dout:' + prefix] = dout
+                if dxin is not None:
+                    self.dbg['dxin:' + prefix] = dxin
                 dxin_part = None
                 if do_res:
                     self._wgrad(bwd, xin, dout, G[prefix + '.res_conv1x1.weight'], 1, 1, 1, 0, xin.H, xin.W)
@@ -612,6 +628,7 @@ class UNetPlan:
                     dpre = self._scratch_act('dpre%d' % self._dpre_turn, N, r.H, r.W, Cout)
                     nb = self.lib.dfl_rowblock_count(r.M, Cout)
                     coef = None
+                    self.dbg['g:%s.block.%d' % (prefix, d * step + 1)] = g
                     if cv['bn'] is not None:
                         gamma, mean, invstd, bname = cv['bn']
                         if fused is not None:
@@ -621,6 +638,7 @@ class UNetPlan:
                             bwd.add(ColstatsArgs(a=g.ptr, b=r.ptr, partials=part.data_ptr(), M=r.M, C=Cout, lda=g.ld,
                                                  ldb=r.ld, nblocks=nb, bf16=r.bf16))
                         coef = self._new(3 * Cout)
+                        self.dbg['coef:%s.block.%d' % (prefix, d * step + 1)] = coef
                         bwd.add(BnBwdFinalizeArgs(partials=part.data_ptr(), gamma=gamma.data_ptr(),
                                                   save_mean=mean.data_ptr(), save_invstd=invstd.data_ptr(),
                                                   dgamma=G[bname + '.weight'].data_ptr(),
@@ -739,6 +757,7 @@ class UNetPlan:
                     wp = self._pack_conv_fwd(dw_)
                     self._conv(fwd, out, wp, nxt, 2, 2, 2, 0, Ci, bias=db_)
                 rec['nxt'] = nxt
+                self.dbg['nxt:%d' % i] = nxt
                 x = nxt
             pending.append(rec)
 
@@ -764,6 +783,7 @@ class UNetPlan:
                 wp = self._pack_convT_fwd(uw_)
                 self._conv(fwd, u, wp, up_half, 1, 1, 1, 0, 4 * Ci, bias=ub_, scatter=1, Hout=ch, Wout=cw)
             out = self._act(N, ch - shrink, cw - shrink, Ci)
+            self.dbg['cat:%d' % j] = cat[i]
             bw = block(name + '.conv_block', cat[i], out)
             up_recs.append(dict(block_bw=bw, out=out, u=u, level=i, name=name, w=uw_))
             u = out
@@ -921,6 +941,7 @@ class UNetPlan:
             self.head_bwd_seg, dfeat_a = head_backward(u, Fdec, u.H, u.W, self.P['seg_conv.weight'], None, None, 0, 0, self.g_seg_full, None, None)
             self.dseg_zero = self._new(N * NC * hl * wl).zero_()
         self.head_bwd, dfeat = head_backward(head_x, Fh, hl, wl, w_seg, w_l1, w_l2, NM, L, g_seg, g_l1, g_l2)
+        self.dbg['dfeat'] = dfeat
 
         # up path, last block first
         # Column sums ride on the kernels that produce the tensors: the conv that completes dcat leaves sum(dy) (the
@@ -969,6 +990,7 @@ class UNetPlan:
             else:
                 self._colsum(bwd, dy, self.G[bias_name])          # (upsample: the adjoint preserves column sums)
             du = self._act(N, uin.H, uin.W, uin.C)
+            self.dbg['du:%d' % j] = du
             consumer = up_recs[j - 1]['block_bw'] if j > 0 else pending[depth - 1]['block_bw']
             r_last = consumer.last_r if self.FUSE_COLSUMS else None
             if upsample:

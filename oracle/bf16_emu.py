@@ -29,6 +29,18 @@ Supported: the architectures the reference's command lines select (zero padding 
 off, max-pool or strided convolution, any block depth, one or two heads with <= 2 landmark 1x1 layers).  `up_mode='upsample'`,
 `pad_mode='circular'`, `lands_block_depth > 0` raise NotImplementedError: those keep the clean-fp64 comparison.
 
+TWO WAYS TO USE IT.  (1) Free running: the emulation computes everything from the network input; this is what the CPU tests
+pin to the oracle (rounding switched off) -- but a free-running comparison with a HIP run CANNOT be tight: rounding to bf16
+is discontinuous, a difference of one fp32 ulp in a sum flips the stored bf16 value with probability (fp32 error / bf16
+ulp), every flipped element perturbs the 9 x Cout sums it enters, and after five or six layers two valid implementations
+that differ in summation order only are a full bf16 rounding (3e-3) apart (measured, tools/exp/emu_layers.py: 1 element of
+72816 differs after the first layer, 14 % after the sixth).  (2) Teacher forced (`teacher=`): every stored tensor and every
+statistics vector the emulation is about to use is replaced by the one the HIP run holds, after the two were compared --
+each step of the HIP pass is then checked against its exact definition applied to the HIP run's OWN inputs: a stored bf16
+tensor must be the correctly rounded result up to rare one-ulp flips, an fp32 result must agree to fp32 accumulation
+accuracy.  The network is the composition of the steps, so this pins the headline arithmetic op by op, with nothing
+calibrated on the run under test (tests/test_gpu_bf16_stepwise.py).
+
 Only tests/ import this.  Citations: the rounding places are csrc/convp_bf16.hip (staging :344-366, epilogue :569-610),
 csrc/wgradp_bf16.hip (:236-275), csrc/bn_elem.hip (bn_finalize_kernel, bn_bwd_finalize_kernel), csrc/head_mfma.inc.
 """
@@ -52,6 +64,31 @@ def _rms(t):
     return float(t.detach().double().pow(2).mean().sqrt())
 
 
+def compare_stored(e, h):
+    """A stored bf16 tensor of the HIP run (h) against the emulation's (e, both fp64 holding bf16 values): relative L2 distance,
+    fraction of differing elements, and the largest difference in units of the bf16 ulp of the larger magnitude -- elements whose
+    difference is below 1e-6 of the tensor's rms are not counted (a ReLU input within fp32 noise of zero)."""
+    d = (e - h).abs()
+    rms = max(_rms(h), 1e-300)
+    big = torch.maximum(e.abs(), h.abs())
+    ulp = torch.exp2(torch.floor(torch.log2(torch.clamp(big, min=1e-300))) - 7.0)
+    live = d > 1e-6 * rms
+    ulps = float((d / ulp)[live].max()) if bool(live.any()) else 0.0
+    # what is left of the largest difference after ONE bf16 ulp of the element is taken off, in units of the tensor's rms: the
+    # fp32 accumulation error of a sum that cancels (its bf16 ulp is small, the error of its terms is not)
+    excess = float(torch.clamp(d - ulp, min=0.0).max()) / rms
+    return {'kind': 'bf16', 'rel_l2': float(d.pow(2).sum().sqrt() / max(float(h.pow(2).sum().sqrt()), 1e-300)),
+            'frac': float(live.double().mean()), 'max_ulps': ulps, 'excess': excess, 'n': h.numel()}
+
+
+def compare_fp32(e, h):
+    """An fp32 result of the HIP run against the emulation's fp64 value: relative L2 and the largest error over the largest value."""
+    e, h = e.double().reshape(-1), h.double().reshape(-1)
+    den = max(float(e.pow(2).sum().sqrt()), 1e-300)
+    return {'kind': 'fp32', 'rel_l2': float((e - h).pow(2).sum().sqrt()) / den, 'max_rel': float((e - h).abs().max()) / max(float(e.abs().max()), 1e-300),
+            'norm': den, 'n': h.numel()}
+
+
 def _conv_bwd(gout, inp, w, stride, padding, transposed=False, want_input=True):
     """(grad_input or None, grad_weight) of a (transposed) convolution in fp64."""
     gi, gw, _ = torch.ops.aten.convolution_backward(gout, inp, w, None, [stride, stride], [padding, padding], [1, 1], transposed,
@@ -65,7 +102,7 @@ class Bf16Emulation:
     cfg: constructor flags; choices: {'relu': {module name: bool mask}, 'pool': {level: flat indices}} (noise_floor.hip_choices)
     or None for the emulation's own pattern.  run(x, loss_fn) -> dict(grads, seg, heat, loss, info)."""
 
-    def __init__(self, onet, cfg, choices=None):
+    def __init__(self, onet, cfg, choices=None, teacher=None):
         if cfg.get('up_mode', 'upconv') != 'upconv' or cfg.get('pad_mode', 'zeros') != 'zeros' or cfg.get('lands_block_depth', 0) > 0:
             raise NotImplementedError('bf16 emulation: upsample / circular / landmark-block architectures are not restated')
         if cfg.get('num_lands', 0) > 0 and cfg.get('lands_num_1x1', 2) > 2:
@@ -73,6 +110,9 @@ class Bf16Emulation:
         self.net, self.cfg, self.choices = onet, cfg, choices
         self.P = dict(onet.named_parameters())
         self.info = {'relu_flips': 0, 'pool_flips': 0, 'relu_total': 0, 'max_margin': 0.0}
+        self.acts = {}                  # nn.ReLU module name -> stored r (diagnosis: compared with plan.relu_out)
+        self.teacher = teacher          # callable(name) -> the HIP run's tensor(s) of that name (fp64, NCHW) or None
+        self.report = {}                # teacher-forced mode: name -> compare_stored / compare_fp32 result
         self.bn = bool(cfg.get('batch_norm', False))
         self.pad = 1 if cfg.get('padding', False) else 0
         self.bd = int(cfg.get('block_depth', 2))
@@ -83,6 +123,33 @@ class Bf16Emulation:
     @staticmethod
     def _wq(w, cin):
         return rb(w) if cin % 16 == 0 else w.detach()
+
+    # ---- teacher forcing ---------------------------------------------------------------------------------------------------
+    def _st(self, name, value, chans=None):
+        """A stored bf16 tensor: compared with the HIP run's and replaced by it (teacher-forced mode); chans: compare / take
+        only this channel range (the rest stays the emulation's own)."""
+        t = self.teacher(name) if self.teacher is not None else None
+        if t is None:
+            return value
+        if chans is not None:
+            lo, hi = chans
+            self.report[name] = compare_stored(value[:, lo:hi], t[:, lo:hi])
+            out = value.clone()
+            out[:, lo:hi] = t[:, lo:hi]
+            return out
+        assert tuple(t.shape) == tuple(value.shape), (name, tuple(t.shape), tuple(value.shape))
+        self.report[name] = compare_stored(value, t)
+        return t
+
+    def _vec(self, name, values):
+        """fp32 statistic vectors (tuple): compared with the HIP run's and replaced by them."""
+        t = self.teacher(name) if self.teacher is not None else None
+        if t is None:
+            return values
+        assert len(t) == len(values), name
+        for i, (e, h) in enumerate(zip(values, t)):
+            self.report['%s[%d]' % (name, i)] = compare_fp32(e, h)
+        return tuple(h.double() for h in t)
 
     # ---- forward -------------------------------------------------------------------------------------------------------
     def _relu(self, name, v):
@@ -109,8 +176,13 @@ class Bf16Emulation:
             op = rb(cur * aff[0].view(1, -1, 1, 1) + aff[1].view(1, -1, 1, 1)) if aff is not None else cur
             wq = self._wq(w, w.shape[1])
             v = F.conv2d(op, wq, b, padding=self.pad)
-            r, mask = self._relu('%s.block.%d' % (prefix, d * self.step + 1), v)
-            rec = dict(wname=wname, op=op, wq=wq, r=r, mask=mask, bn=None)
+            rname = '%s.block.%d' % (prefix, d * self.step + 1)
+            r, mask = self._relu(rname, v)
+            if self.teacher is not None:
+                r = self._st('r:' + rname, r)
+                mask = r > 0                              # what the product's backward tests
+            rec = dict(wname=wname, op=op, wq=wq, r=r, mask=mask, bn=None, rname=rname)
+            self.acts['%s.block.%d' % (prefix, d * self.step + 1)] = r
             naff = None
             if self.bn:
                 bname = '%s.block.%d' % (prefix, d * self.step + 2)
@@ -118,8 +190,9 @@ class Bf16Emulation:
                 mean = r.mean(dim=(0, 2, 3))
                 var = torch.clamp((r * r).mean(dim=(0, 2, 3)) - mean * mean, min=0.0)
                 invstd = 1.0 / torch.sqrt(var + BN_EPS)
-                naff = (f32(gamma * invstd), f32(beta - mean * gamma * invstd))
-                rec['bn'] = dict(name=bname, gamma=gamma, mean=f32(mean), invstd=f32(invstd), count=r.numel() // r.shape[1])
+                sc, sh, mean_, invstd_ = self._vec('bn:' + bname, (f32(gamma * invstd), f32(beta - mean * gamma * invstd), f32(mean), f32(invstd)))
+                naff = (sc, sh)
+                rec['bn'] = dict(name=bname, gamma=gamma, mean=mean_, invstd=invstd_, count=r.numel() // r.shape[1])
             convs.append(rec)
             cur, aff = r, naff
         last = cur * aff[0].view(1, -1, 1, 1) + aff[1].view(1, -1, 1, 1) if aff is not None else cur
@@ -131,6 +204,7 @@ class Bf16Emulation:
             res = dict(wq=rwq)
         else:
             out = rb(last)
+        out = self._st('out:' + prefix, out)
         return out, dict(prefix=prefix, xin=xin, convs=convs, res=res)
 
     def _pool(self, level, x):
@@ -166,7 +240,7 @@ class Bf16Emulation:
                 else:
                     dw, db = P['downsample_convs.%d.weight' % i].detach(), P['downsample_convs.%d.bias' % i].detach()
                     dwq = self._wq(dw, dw.shape[1])
-                    cur = rb(F.conv2d(out, dwq, db, stride=2))
+                    cur = self._st('nxt:%d' % i, rb(F.conv2d(out, dwq, db, stride=2)))
                     drec['dwq'] = dwq
                 drec['nxt_shape'] = cur.shape
             downs.append(drec)
@@ -177,7 +251,7 @@ class Bf16Emulation:
             name = 'up_path.%d' % j
             uw, ub = P[name + '.up.weight'].detach(), P[name + '.up.bias'].detach()
             uwq = self._wq(uw, uw.shape[0])
-            up = rb(F.conv_transpose2d(u, uwq, ub, stride=2))
+            up = self._st('up:%d' % j, rb(F.conv_transpose2d(u, uwq, ub, stride=2)))
             bridge = downs[i]['out']
             th, tw = up.shape[2], up.shape[3]
             oy, ox = (bridge.shape[2] - th) // 2, (bridge.shape[3] - tw) // 2          # unet.py:248-252
@@ -199,13 +273,29 @@ class Bf16Emulation:
         if L > 0:
             mid = F.conv2d(torch.cat((fx, logits), dim=1), w1)
             heat = F.conv2d(mid, w2) if w2 is not None else mid
-        loss = loss_fn(seg, heat)
+        outs = [seg] + ([heat] if L > 0 else [])
+        # the loss and its gradient with respect to the network outputs -- teacher forced: at the HIP run's own outputs
+        t_out = self.teacher('outputs') if self.teacher is not None else None
+        if t_out is not None:
+            self.report['seg'] = compare_fp32(seg.detach(), t_out[0])
+            if L > 0:
+                self.report['heat'] = compare_fp32(heat.detach(), t_out[1])
+            leaf = [t.detach().clone().requires_grad_(True) for t in t_out[:len(outs)]]
+        else:
+            leaf = [o.detach().clone().requires_grad_(True) for o in outs]
+        loss = loss_fn(leaf[0], leaf[1] if L > 0 else None)
+        douts = list(torch.autograd.grad(loss, leaf))
+        t_dout = self.teacher('doutputs') if self.teacher is not None else None
+        if t_dout is not None:
+            for nm, e, h in zip(('dseg', 'dheat'), douts, t_dout):
+                self.report[nm] = compare_fp32(e, h)
+            douts = [h.double() for h in t_dout[:len(outs)]]
         G = {k: None for k in P}
         # the matrix-core head kernels (head.hip: head_mfma_ok -- bf16 features, F = 32, two landmark layers or none, small head)
         mfma_head = Fc == 32 and NC <= 8 and (L == 0 or (w2 is not None and w1.shape[0] <= 24 and L <= 16))
         if mfma_head:
             wanted = [fx, logits] + ([mid, heat] if L > 0 else [])
-            got = torch.autograd.grad(loss, wanted)
+            got = torch.autograd.grad(outs, wanted, grad_outputs=douts)
             dfeat, dlog = got[0], got[1]
             G['seg_conv.weight'] = torch.einsum('nchw,nfhw->cf', rb(dlog), feat).view_as(wseg)
             if L > 0:
@@ -215,27 +305,29 @@ class Bf16Emulation:
                 G['lands_1x1.1.weight'] = torch.einsum('nchw,nfhw->cf', rb(dheat), rb(mid.detach())).view_as(w2)
         else:
             wl = [wseg] + ([w1] if w1 is not None else []) + ([w2] if w2 is not None else [])
-            got = torch.autograd.grad(loss, [fx] + wl)
+            got = torch.autograd.grad(outs, [fx] + wl, grad_outputs=douts)
             dfeat = got[0]
             G['seg_conv.weight'] = got[1]
             if w1 is not None:
                 G['lands_1x1.0.weight'] = got[2]
             if w2 is not None:
                 G['lands_1x1.1.weight'] = got[3]
-        dout = rb(dfeat)
+        dout = self._st('dfeat', rb(dfeat))
         # ---------------------------------------------------------------- backward: up path, last block first
         dbridge = {}
         for j in reversed(range(len(ups))):
             rec = ups[j]
-            dcat = self._block_bwd(rec['block'], dout, G, need_dxin=True)
             Ci = rec['Ci']
+            # (the bridge half of dcat is accumulated onto later -- the down-sampling gradient -- so the HIP run's value of it
+            # is checked where it is final: 'dout:down_path.i' below; until then the emulation's own value stands in)
+            dcat = self._block_bwd(rec['block'], dout, G, need_dxin=True, dxin_chans=(0, Ci))
             dy = dcat[:, :Ci]
             dbridge[rec['level']] = (dcat[:, Ci:], rec['crop'])
             name = rec['name']
             G[name + '.up.bias'] = dy.sum(dim=(0, 2, 3))
             du, gw = _conv_bwd(dy.contiguous(), rec['u'], rec['uwq'], 2, 0, transposed=True)
             G[name + '.up.weight'] = gw
-            dout = rb(du)
+            dout = self._st('du:%d' % j, rb(du))
         # ---------------------------------------------------------------- backward: down path, deepest block first
         dnxt = None
         for i in reversed(range(depth)):
@@ -248,18 +340,19 @@ class Bf16Emulation:
                 if cfg.get('max_pool', True):
                     idx = drec['pool_idx']
                     add = torch.zeros_like(out).flatten(2).scatter_(2, idx.flatten(2), dnxt.flatten(2)).view_as(out)
-                    dout = rb(dout + add)
+                    dout = self._st('dout:down_path.%d' % i, rb(dout + add))
                 else:
                     wname = 'downsample_convs.%d' % i
                     G[wname + '.bias'] = dnxt.sum(dim=(0, 2, 3))
                     di, gw = _conv_bwd(dnxt, out, drec['dwq'], 2, 0)
                     G[wname + '.weight'] = gw
-                    dout = rb(dout + di)
+                    dout = self._st('dout:down_path.%d' % i, rb(dout + di))
             dnxt = self._block_bwd(drec['block'], dout, G, need_dxin=i > 0)
-        return dict(grads=G, seg=seg.detach(), heat=None if heat is None else heat.detach(), loss=float(loss), info=self.info)
+        return dict(grads=G, seg=seg.detach(), heat=None if heat is None else heat.detach(), loss=float(loss.detach()), info=self.info,
+                    report=self.report)
 
     # ---- backward of one block (plan.py: block.backward) -------------------------------------------------------------------
-    def _block_bwd(self, rec, dout, G, need_dxin):
+    def _block_bwd(self, rec, dout, G, need_dxin, dxin_chans=None):
         prefix, xin, convs = rec['prefix'], rec['xin'], rec['convs']
         if self.do_res:
             _, gw = _conv_bwd(dout, xin, rec['res']['wq'], 1, 0, want_input=False)
@@ -280,9 +373,9 @@ class Bf16Emulation:
                 G[bnr['name'] + '.bias'] = sdy
                 s = gamma * invstd
                 c1, c2 = sdy / cnt, sdyx / cnt
-                A, B, Cc = f32(s), f32(-s * c2 * invstd), f32(-s * c1 + s * c2 * invstd * mean)
+                A, B, Cc = self._vec('coef:' + cv['rname'], (f32(s), f32(-s * c2 * invstd), f32(-s * c1 + s * c2 * invstd * mean)))
                 v = lambda t: t.view(1, -1, 1, 1)
-                dpre = rb(mask * (v(A) * g + (v(B) * r + v(Cc))))
+                dpre = rb(mask * f32(v(A) * g + f32(v(B) * r + v(Cc))))       # two fp32 fused multiply-adds, then the bf16 rounding
             else:
                 dpre = mask * g
             G[cv['wname'] + '.bias'] = dpre.sum(dim=(0, 2, 3))
@@ -290,10 +383,11 @@ class Bf16Emulation:
             di, gw = _conv_bwd(dpre, cv['op'], cv['wq'], 1, self.pad, want_input=want_in)
             G[cv['wname'] + '.weight'] = gw
             if d > 0:
-                g = rb(di)
+                g = self._st('g:' + convs[d - 1]['rname'], rb(di))
             elif need_dxin:
                 dxin = rb(di)
                 if self.do_res:
                     dr, _ = _conv_bwd(dout, xin, rec['res']['wq'], 1, 0)
                     dxin = rb(dxin + dr)
+                dxin = self._st('dxin:' + prefix, dxin, chans=dxin_chans)
         return dxin

@@ -98,12 +98,20 @@ def test_paper_batch16_gradient(mode):
                                             res['info']['pool_flips'], res['info']['relu_total'], res['info']['max_margin']))
     dev = float((seg.detach().double().cpu() - gc.out).abs().max())
     if mode == 'bf16s':
+        # THE GATE of this arithmetic is the step-by-step check: every stored bf16 tensor of this very pass the correctly rounded
+        # value, every fp32 result (all parameter gradients) within 1e-4 of its definition on the pass's own inputs
+        # (tests/test_gpu_bf16_stepwise.py, oracle/bf16_emu.py).  What follows it is the free-running distance from the CLEAN fp64
+        # oracle -- bounded by what bf16 rounding of 25 layers amounts to (measured 9.3e-3), a sanity bar, not the parity claim.
+        import test_gpu_bf16_stepwise as SW
+        rep, sres = SW.stepwise(pr, 'batch 16 bf16s ')
+        print('batch 16 bf16s step by step: ' + SW.summarize(rep))
+        SW.assert_report(rep, sum(float(g_.pow(2).sum()) for g_ in sres['grads'].values() if g_ is not None) ** 0.5, 'batch 16 bf16s ')
         assert 1e-5 < dev < 5e-2, 'soft-max deviation %.3e from fp64 in the bf16 storage mode' % dev
         top2 = gc.out.topk(2, dim=1)[0]
         sure = (top2[:, 0] - top2[:, 1]) > 2.5 * dev
         assert float(sure.float().mean()) > 0.5
         assert bool((seg.detach().argmax(1).cpu() == gc.out.argmax(1))[sure].all())
-        assert res['whole'] <= 0.15, 'whole-gradient relative L2 error %.3e at batch 16 (bf16 storage)' % res['whole']
+        assert res['whole'] <= 3e-2, 'whole-gradient relative L2 error %.3e at batch 16 (bf16 storage, against the clean fp64 oracle)' % res['whole']
     else:
         assert dev <= 1e-4 * float(gc.out.abs().max())
         assert res['whole'] <= 1e-2, 'whole-gradient relative L2 error %.3e at batch 16' % res['whole']

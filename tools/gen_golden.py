@@ -554,6 +554,81 @@ def fixture_plateau(unet, dice, util, wf=3, out_name='plateau.npz'):
         l8[0], l8[-20:].mean(), np.round(dtr8, 4), dtr8.mean(), dtr1.mean(), np.round(dva8, 4), dva8.mean(), dva1.mean()))
     print('  per-class |8 threads - 1 thread|: train', np.round(np.abs(dtr8 - dtr1), 4), 'valid', np.round(np.abs(dva8 - dva1), 4))
 
+def fixture_plateau_paper(unet, dice, util, steps=400, cut=300, threads=(8, 1), out_name='plateau_paper.npz'):
+    """The PAPER preset (train_test_code/Readme.md:16: depth 6, 32 initial features, BatchNorm, padding, strided convolutions,
+    14 landmarks, SGD 0.1 / 0.9 / nesterov / 1e-4) trained by the reference to a plateau on toy-ellipses images of the paper's
+    8x-downsampled size (184 x 184 padded to 192; 16 training + 4 held-out images, batch 4, the step body of train.py:405-430,
+    learning rate cut 10x for the last quarter), scored by hard Dice per class (compute_actual_dice_on_test.py:63-93).  The
+    initial weights are NOT stored (152 MB): torch.manual_seed(1234) + the constructor, whose per-tensor SHA-256 is in
+    paper_sc_l14.npz and is checked here.  Two runs (8 threads / 1 thread) record the reference's own spread."""
+    import torch.optim as optim
+    import dataset
+    NTR, NALL, H = 16, 20, 184
+    projs, segs, lands = toy_ellipses(NALL, H, H, seed=21)
+    kw = dict(n_classes=7, depth=6, wf=5, batch_norm=True, padding=True, max_pool=False, num_lands=14, do_res=True, block_depth=2)
+    FAKE_FILES['plateau_paper.h5'] = {'01': {'projs': _FakeDS(projs.numpy()), 'segs': _FakeDS(segs.numpy()),
+                                             'lands': _FakeDS(lands.numpy())},
+                                      'land-names': {'num-lands': _FakeDS(np.array(14))}}
+    ds = dataset.get_dataset('plateau_paper.h5', [1], num_classes=7, pad_img_dim=192)
+    items = [ds[i] for i in range(NALL)]
+    P = torch.stack([it[0] for it in items])
+    S = torch.stack([it[1] for it in items])
+    Hm = torch.stack([it[3] for it in items]).view(NALL, 14, H, H)
+    shas = dict(np.load(os.path.join(OUT, 'paper_sc_l14.npz'), allow_pickle=False))
+
+    def hard_dice(labels, gt):
+        d = []
+        for c in range(1, 7):
+            a, b = labels == c, gt == c
+            den = int(a.sum()) + int(b.sum())
+            d.append(2.0 * int((a & b).sum()) / den if den > 0 else 1.0)
+        return np.array(d)
+
+    def run(nthreads):
+        import time
+        torch.set_num_threads(nthreads)
+        torch.manual_seed(1234)
+        net = unet.UNet(**kw)
+        names = [str(n) for n in shas['sd_names']] if 'sd_names' in shas else None
+        if names is not None:
+            for n_, h_ in zip(names, shas['sd_sha']):
+                assert sha(net.state_dict()[n_]) == str(h_), n_
+        opt = optim.SGD(net.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4, nesterov=True)
+        crit = dice.DiceAndHeatMapLoss2D(skip_bg=False, heatmap_wgt=0.5)
+        net.train()
+        losses = []
+        t0 = time.time()
+        for step in range(steps):
+            if step == cut:
+                for gr in opt.param_groups:
+                    gr['lr'] = 0.01
+            idx = [(step * 4 + j) % NTR for j in range(4)]
+            opt.zero_grad()
+            out = net(P[idx])
+            loss = crit((util.center_crop(out[0], S[idx].shape), util.center_crop(out[1], Hm[idx].shape)), (S[idx], Hm[idx]))
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+            if step % 20 == 0:
+                print('  [%d threads] step %d loss %.4f (%.0f s)' % (nthreads, step, losses[-1], time.time() - t0), flush=True)
+        net.eval()
+        with torch.no_grad():
+            out = torch.cat([net(P[i:i + 4])[0] for i in range(0, NALL, 4)])
+        labels = torch.max(util.center_crop(out, S.shape), dim=1)[1]
+        gt = segs.long()
+        return np.array(losses), hard_dice(labels[:NTR], gt[:NTR]), hard_dice(labels[NTR:], gt[NTR:])
+
+    runs = [run(t) for t in threads]
+    torch.set_num_threads(8)
+    (l8, dtr8, dva8), (l1, dtr1, dva1) = runs[0], runs[-1]
+    res = {'projs': projs.numpy(), 'segs': segs.numpy(), 'lands': lands.numpy(), 'n_train': np.array(NTR), 'steps': np.array(steps),
+           'cut': np.array(cut), 'seed': np.array(1234), 'losses': l8, 'losses_1thread': l1,
+           'dice_train': dtr8, 'dice_valid': dva8, 'dice_train_1thread': dtr1, 'dice_valid_1thread': dva1}
+    np.savez_compressed(os.path.join(OUT, out_name), **res)
+    print('plateau (paper preset): loss %.4f -> %.4f; train dice %s (mean %.4f / %.4f); valid dice %s (mean %.4f / %.4f)' % (
+        l8[0], l8[-20:].mean(), np.round(dtr8, 4), dtr8.mean(), dtr1.mean(), np.round(dva8, 4), dva8.mean(), dva1.mean()))
+    print('  per-class |run A - run B|: train', np.round(np.abs(dtr8 - dtr1), 4), 'valid', np.round(np.abs(dva8 - dva1), 4))
+
 
 EST_LAND_NAMES = ['FH-l', 'FH-r', 'GSN-l', 'GSN-r', 'IOF-l', 'IOF-r', 'MOF-l', 'MOF-r', 'SPS-l', 'SPS-r', 'IPS-l', 'IPS-r',
                   'ASIS-l', 'ASIS-r']
@@ -639,6 +714,12 @@ def main():
         fixture_plateau(unet, dice, util)
         fixture_plateau(unet, dice, util, wf=4, out_name='plateau_wf4.npz')     # 16..64 channels: the bf16 storage mode's minimum
         return
+    if '--only-plateau-paper' in sys.argv:
+        kw = {}
+        if '--quick' in sys.argv:          # (look at the trajectory first: one 8-thread run, nothing kept)
+            kw = dict(threads=(8,), out_name='plateau_paper_quick.npz')
+        fixture_plateau_paper(unet, dice, util, **kw)
+        return
     if '--only-validation' in sys.argv:
         fixture_validation(unet, util)
         return
@@ -670,6 +751,7 @@ def main():
     fixture_est_lands(util)
     fixture_paper(unet, dice, util, 'paper_sc_l14', 1234, max_pool=False, num_lands=14)
     fixture_paper(unet, dice, util, 'paper_mp_l0', 1235, max_pool=True, num_lands=0)
+    fixture_plateau_paper(unet, dice, util)         # (needs paper_sc_l14.npz: the SHA-256 of the seeded initial weights)
 
 
 if __name__ == '__main__':
