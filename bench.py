@@ -33,7 +33,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0        # same guide: dense bf16 MFMA (the 5 PF ma
 HBM_PEAK_GBS = 8000.0                 # same guide: HBM3E, 8 TB/s
 # product arithmetic of the GEMM kernels (include/dfl_hip.h): name -> (mode, bf16 MFMA products per fp32 product)
 MATH = {'fp32': (0, 0), 'bf16x3': (1, 3), 'bf16x6': (2, 6), 'bf16': (3, 1), 'bf16s': (4, 1)}
-TRAFFIC_FILE = 'r03_traffic.json'      # per-kernel HBM bytes from the committed rocprofv3 --pmc passes of this round
+TRAFFIC_FILE = 'r04_traffic.json'      # per-kernel HBM bytes from the committed rocprofv3 --pmc passes of this round
 CONV_KERNELS = ['conv_gemm_kernel<2,2,2,2>', 'conv_gemm_kernel<2,2,2,1>', 'conv_gemm_kernel<4,1,2,1>',
                 'conv_gemm_kernel<2,2,1,1>', 'conv_gemm_kernel<1,2,1,1>', 'direct_conv_kernel',
                 'conv_rows_kernel<3,1,2,1>', 'conv_rows_kernel<3,1,1,2>', 'conv_rows_kernel<3,1,1,1>']
@@ -103,6 +103,98 @@ def op_profile(plan, lib, nat, stream, detail=None):
         detail.append('---- backward ----')
     account(plan.bwd, plan.bwd.run_timed(stream))
     return groups
+
+
+def roofline_of(groups, math_name):
+    """`roofline` object of the dominant kernel of an op profile (op_profile): achieved = ALGORITHMIC flops (or compulsory bytes)
+    per launch / its average launch time (hipEvent pairs on the launch stream), against the binding roof."""
+    tot_ms = sum(v[0] for v in groups.values())
+    name, (ms, fl, n, by) = max(groups.items(), key=lambda kv: kv[1][0])
+    achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    nprod = MATH[math_name][1]
+    # peak = the guide's hardware peak of the matrix instruction this kernel issues (MI355X_MICROARCH.md): dense bf16
+    # MFMA for every bf16-product mode, fp32 MFMA for fp32 products.  `achieved` counts ALGORITHMIC flops (2 * MACs of
+    # the layer), so emulation overhead (3 / 6 bf16 products per fp32 product) shows as a lower fraction, not as a
+    # lower roof; `mfma_issue_frac` = achieved * products-per-product / peak is the share of the pipe's issue slots.
+    peak = F32_MFMA_PEAK_TFLOPS if nprod == 0 else BF16_MFMA_PEAK_TFLOPS
+    # Which roof binds this kernel: the one its algorithmic work needs longer under -- compulsory bytes at the HBM peak or
+    # algorithmic flops at the matrix peak.  (With the BatchNorm + ReLU backward formed inside the weight gradient the
+    # kernel reads three activation tensors per layer: its byte floor can exceed its flop floor.)
+    gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    mfma_frac, hbm_frac = achieved / peak, gbs / HBM_PEAK_GBS
+    if hbm_frac > mfma_frac:
+        head = {'bound': 'hbm', 'kernel': name, 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(hbm_frac, 4)}
+    else:
+        head = {'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+                'frac': round(mfma_frac, 4)}
+    return dict(head, **{'traffic': None, 'mfma_tflops': round(achieved, 2), 'mfma_frac': round(mfma_frac, 4),
+                'hbm_gbs_compulsory': round(gbs, 1), 'hbm_frac_compulsory': round(hbm_frac, 4),
+                'mfma_issue_frac': round(achieved * max(nprod, 1) / peak, 4),
+                'peak_note': ('fp32 MFMA peak (v_mfma_f32_32x32x2_f32)' if nprod == 0 else
+                              'dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16); this mode issues %d bf16 product(s) per '
+                              'algorithmic product' % nprod),
+                'launches_per_step': n, 'avg_launch_ms': round(ms / n, 4),
+                'share_of_kernel_time': round(ms / tot_ms, 3),
+                'algorithmic_flop_per_launch': round(fl / n), 'compulsory_bytes_per_launch': round(by / n)})
+
+
+def profile_plan(net, x, lib, nat, detail=None):
+    """op_profile of the training plan `net` last ran on (one more forward + backward, replayed op by op)."""
+    plan = net._last_train_plan()
+    seg, heat = net(x)
+    hold = (torch.randn_like(seg) * 1e-6, torch.randn_like(heat) * 1e-6)
+    plan.bind_grads(seg, hold[0], hold[1])
+    stream = torch.cuda.current_stream().cuda_stream
+    plan.bwd.run(stream)
+    torch.cuda.synchronize()
+    groups = op_profile(plan, lib, nat, stream, detail)
+    plan.busy = False
+    return plan, groups
+
+
+def configs3(B=8, H=736, P=768, steps=8, warmup=3):
+    """BASELINE configs[3]: 2x-downsampled 736x736 padded to 768, paper U-Net with both heads, batch 8, one MI355X: the same
+    step body (train.py:405-430), every loss read; images/s and ms/step in the arithmetic that is current."""
+    import dfl_amd
+    from dfl_amd.util import LateScalars
+    dev = torch.device('cuda', torch.cuda.current_device())
+    torch.manual_seed(1)
+    net = dfl_amd.UNet(**PAPER).to(dev)
+    opt = dfl_amd.SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4, nesterov=True)
+    crit = dfl_amd.DiceAndHeatMapLoss2D(skip_bg=False, heatmap_wgt=0.5)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, 1, P, P, generator=g).to(dev)
+    lab = torch.randint(0, 7, (B, H, H), generator=g)
+    tseg = torch.stack([(lab == c) for c in range(7)], 1).float().to(dev)
+    theat = (torch.rand(B, 14, H, H, generator=g) * 0.02).to(dev)
+    net.train()
+    late = LateScalars(depth=1)
+
+    def step():
+        opt.zero_grad()
+        seg, heat = net(x)
+        loss = crit((dfl_amd.center_crop(seg, tseg.shape), dfl_amd.center_crop(heat, theat.shape)), (tseg, theat))
+        loss.backward()
+        opt.step()
+        return late.push(loss)
+    torch.cuda.reset_peak_memory_stats()
+    for _ in range(warmup):
+        step()
+    late.flush()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    late.flush()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    flop = 54.5e9 * (P * P) / (192 * 192) * B
+    out = {'workload': 'BASELINE configs[3]: 2x-downsampled 736x736 (padded 768), paper U-Net dual head, batch %d, 1 MI355X' % B,
+           'images_per_sec': round(B * steps / dt, 2), 'ms_per_step': round(dt / steps * 1e3, 2), 'steps': steps, 'warmup': warmup,
+           'tflops': round(flop / (dt / steps) / 1e12, 1), 'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+    del net, opt, x, tseg, theat
+    torch.cuda.empty_cache()
+    return out
 
 
 def _cpu_steps(net, opt, x, tseg, theat, warm, steps, R):
@@ -217,6 +309,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--no-fwd', action='store_true', help='skip the eval-forward timings (fwd_ms_per_img)')
+    ap.add_argument('--no-configs3', action='store_true', help='skip the 768x768 batch-8 training timing (configs3)')
     ap.add_argument('--detail', action='store_true', help='per-op table on stderr')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' for a self-test)")
     ap.add_argument('--optimizer', default='dfl', choices=['dfl', 'torch'],
@@ -319,47 +412,13 @@ def main():
     extra['host_enqueue_ms_per_step'] = round(host / nh * 1e3, 3)
     if rank == 0 and not args.no_profile:
         # one more forward/backward, replayed op by op with hipEvents on the launch stream
-        plan = [p for plans in net._plans.values() for p in plans if p.need_grad][0]
-        seg, heat = net(x)
-        hold = (torch.randn_like(seg) * 1e-6, torch.randn_like(heat) * 1e-6)
-        plan.bind_grads(seg, hold[0], hold[1])
-        stream = torch.cuda.current_stream().cuda_stream
-        plan.bwd.run(stream)
-        torch.cuda.synchronize()
         detail = [] if args.detail else None
-        groups = op_profile(plan, lib, nat, stream, detail)
+        plan, groups = profile_plan(net, x, lib, nat, detail)
         if detail:
             sys.stderr.write('\n'.join(detail) + '\n')
-        plan.busy = False
         tot_ms = sum(v[0] for v in groups.values())
-        dom = max(groups.items(), key=lambda kv: kv[1][0])
-        name, (ms, fl, n, by) = dom
-        achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        nprod = MATH[args.math][1]
-        # peak = the guide's hardware peak of the matrix instruction this kernel issues (MI355X_MICROARCH.md): dense bf16
-        # MFMA for every bf16-product mode, fp32 MFMA for fp32 products.  `achieved` counts ALGORITHMIC flops (2 * MACs of
-        # the layer), so emulation overhead (3 / 6 bf16 products per fp32 product) shows as a lower fraction, not as a
-        # lower roof; `mfma_issue_frac` = achieved * products-per-product / peak is the share of the pipe's issue slots.
-        peak = F32_MFMA_PEAK_TFLOPS if nprod == 0 else BF16_MFMA_PEAK_TFLOPS
-        # Which roof binds this kernel: the one its algorithmic work needs longer under -- compulsory bytes at the HBM peak or
-        # algorithmic flops at the matrix peak.  (With the BatchNorm + ReLU backward formed inside the weight gradient the
-        # kernel reads three activation tensors per layer: its byte floor now exceeds its flop floor.)
-        gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        mfma_frac, hbm_frac = achieved / peak, gbs / HBM_PEAK_GBS
-        if hbm_frac > mfma_frac:
-            head = {'bound': 'hbm', 'kernel': name, 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(hbm_frac, 4)}
-        else:
-            head = {'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
-                    'frac': round(mfma_frac, 4)}
-        roofline = dict(head, **{'traffic': None, 'mfma_tflops': round(achieved, 2), 'mfma_frac': round(mfma_frac, 4),
-                    'hbm_gbs_compulsory': round(gbs, 1), 'hbm_frac_compulsory': round(hbm_frac, 4),
-                    'mfma_issue_frac': round(achieved * max(nprod, 1) / peak, 4),
-                    'peak_note': ('fp32 MFMA peak (v_mfma_f32_32x32x2_f32)' if nprod == 0 else
-                                  'dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16); this mode issues %d bf16 product(s) per '
-                                  'algorithmic product' % nprod),
-                    'launches_per_step': n, 'avg_launch_ms': round(ms / n, 4),
-                    'share_of_kernel_time': round(ms / tot_ms, 3),
-                    'algorithmic_flop_per_launch': round(fl / n), 'compulsory_bytes_per_launch': round(by / n)})
+        roofline = roofline_of(groups, args.math)
+        name, (ms, fl, n, by) = max(groups.items(), key=lambda kv: kv[1][0])
         # HBM bytes per launch of that kernel come from the separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE;
         # tools/profile_round.sh), which cannot run inside this process; the committed summary is quoted when present
         tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', TRAFFIC_FILE)
@@ -422,10 +481,20 @@ def main():
             torch.cuda.synchronize()
             dside = time.perf_counter() - t0
             extra[key] = {'value': round(B * n32 / dside, 2), 'ms_per_step': round(dside / n32 * 1e3, 3), 'steps': n32}
+            if mode == 'fp32':
+                # the parity gate's own roofline: dominant kernel of the fp32-MFMA mode, same fields as `roofline`
+                late.flush()
+                _, g32 = profile_plan(net, x, lib, nat)
+                extra['roofline_fp32'] = roofline_of(g32, 'fp32')
+                extra['roofline_fp32']['kernel_time_ms_per_step'] = round(sum(v[0] for v in g32.values()), 3)
         nat.check(lib.dfl_set_math_mode(MATH[args.math][0]), 'dfl_set_math_mode')
 
     if rank == 0 and world == 1 and not args.no_profile and not args.no_fwd:
         extra['fwd_ms_per_img'] = fwd_ms_per_img(lib, nat, dev, args.math)
+    if rank == 0 and world == 1 and not args.no_profile and not args.no_configs3:
+        del net, opt, x, tseg, theat
+        torch.cuda.empty_cache()
+        extra['configs3'] = dict(configs3(), math=args.math)
     nat.check(lib.dfl_set_math_mode(mode_before), 'dfl_set_math_mode')
 
     cpu = None

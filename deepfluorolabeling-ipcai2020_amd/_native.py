@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get('DFL_LIB_OVERRIDE') or os.path.join(_HERE, 'lib', 'libdfl_hip.so')   # override: tools/exp variant builds
+LIB_PATH = os.environ.get('DFL_LIB_OVERRIDE') or os.path.join(_HERE, 'lib', 'libdfl_hip.so')   # override: docs/experiments variant builds
 
 i32, i64, f32 = C.c_int32, C.c_int64, C.c_float
 fp = C.c_void_p   # every device pointer is passed as a plain address

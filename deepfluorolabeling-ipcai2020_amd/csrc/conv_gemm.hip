@@ -16,7 +16,7 @@
 //     4 quads; b64: 4 rows x 4 quads per lane group) touch every bank once: no conflict cycles (the padded row-major
 //     layout this replaces spent a third of its LDS cycles on write conflicts, SQ_LDS_BANK_CONFLICT).
 //   * the matrix pipe issues one 32x32x2 per 64 cycles per SIMD and a SIMD has only ~12 other issue slots in that time
-//     (tools/exp/exp_mfma.cpp: the bare loop reaches 100-125 TFLOP/s), so the fast path (MODE 1) is written to spend as
+//     (docs/experiments/exp_mfma.cpp: the bare loop reaches 100-125 TFLOP/s), so the fast path (MODE 1) is written to spend as
 //     few VALU/SALU instructions per MFMA as possible:
 //       - buffer loads with hardware bounds checking: an invalid tap/row/column gets an out-of-range offset and the load
 //         returns 0 -- no clamped address, no select, no branch (a load under a condition would make hipcc branch and
@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
   // Straight-line code: a chunk past the end of the slice is fetched with out-of-range offsets (reads zeros), so the
   // main loop has no conditional loads and the compiler can keep the younger set in flight across the LDS write.
   auto load_AB = [&](int ch, int set) {
-#ifdef DFL_EXP_NOLOAD   // diagnosis builds (tools/exp/loop_bounds.sh): which resource the loop waits for; results are wrong
+#ifdef DFL_EXP_NOLOAD   // diagnosis builds (docs/experiments/loop_bounds.sh): which resource the loop waits for; results are wrong
     const bool live = ch < ch_end && ch < ch_begin + 2;   // later chunks: out-of-range offsets, no memory traffic
 #else
     const bool live = ch < ch_end;
@@ -431,7 +431,7 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
   // multiplies one all-zero chunk at the end.  The sched_barriers pin the order loads | MFMAs | affine + LDS writes:
   // otherwise hipcc hoists part of store_AB() (and its vmcnt waits) above the MFMA block.
 #ifdef DFL_CONV_TRACE
-  // Diagnosis build only (tools/exp/conv_phase_trace.sh): shader-clock time the first wave of every workgroup spends in
+  // Diagnosis build only (docs/experiments/conv_phase_trace.sh): shader-clock time the first wave of every workgroup spends in
   // the four phases of the first half-iteration of each loop trip, summed over the loop, plus the whole-kernel time.
   long long tr[5] = {0, 0, 0, 0, 0};
   const long long tk0 = __builtin_amdgcn_s_memtime();

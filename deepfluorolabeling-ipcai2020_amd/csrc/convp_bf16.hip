@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : (TM 
   // of a k-step (rocprofv3: 15-18 scalar instructions per matrix instruction in these kernels).
   const int kw_magic = (256 + KW - 1) / KW;
 
-#ifdef DFL_CONVP_TRACE   // diagnosis build (tools/exp/convp_trace.py): shader-clock stamps of wave 0 at the phase boundaries
+#ifdef DFL_CONVP_TRACE   // diagnosis build (docs/experiments/convp_trace.py): shader-clock stamps of wave 0 at the phase boundaries
   long long tr_t[10];
   tr_t[6] = tr_t[7] = tr_t[8] = 0;
   tr_t[0] = __builtin_amdgcn_s_memtime();

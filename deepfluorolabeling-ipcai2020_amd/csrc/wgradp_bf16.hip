@@ -45,7 +45,7 @@ struct WgP {
   int tab_off;                         // byte offset of the gathered-pixel offset table (P16 words) behind the g image
   int lds_bytes;
   int kpipe;                           // fragments of the next k-step are fetched under the matrix instructions of this one
-  long long* trace;                    // diagnosis build only (-DDFL_WGP_TRACE, tools/exp/wgradp_trace.py)
+  long long* trace;                    // diagnosis build only (-DDFL_WGP_TRACE, docs/experiments/wgradp_trace.py)
   uint32_t g_bytes, d_bytes;
   uint32_t d2_bytes, pad0;             // extent of the second dense tensor (dfl_wgrad_args.d_mode)
 };

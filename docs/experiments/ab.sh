@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of environment switches on the default bench workload, inside ONE gpurun call (boxes differ by a few percent).
-# Usage: tools/exp/ab.sh "VAR=1 VAR2=x" "VAR=0" ...   -> gpurun_out/ab.txt
+# Usage: docs/experiments/ab.sh "VAR=1 VAR2=x" "VAR=0" ...   -> gpurun_out/ab.txt
 out=gpurun_out/ab.txt
 : > $out
 i=0

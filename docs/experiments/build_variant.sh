@@ -1,13 +1,13 @@
 #!/bin/bash
 # Build a variant of libdfl_hip.so: the named sources recompiled with extra -D flags, every other object taken from the
 # regular build (csrc/build.sh must have run).  The output lives in-tree (git-ignored) so that it travels to the GPU box:
-#   tools/exp/build_variant.sh NAME "convp_bf16 wgradp_bf16" -DFOO=1 ...  ->  tools/exp/bin/NAME/libdfl_hip.so
-# Use with DFL_LIB_OVERRIDE=$GRAFT_REPO_ROOT/tools/exp/bin/NAME/libdfl_hip.so
+#   docs/experiments/build_variant.sh NAME "convp_bf16 wgradp_bf16" -DFOO=1 ...  ->  docs/experiments/bin/NAME/libdfl_hip.so
+# Use with DFL_LIB_OVERRIDE=$GRAFT_REPO_ROOT/docs/experiments/bin/NAME/libdfl_hip.so
 set -e
 name=$1; files=$2; shift 2
 root=$(cd "$(dirname "$0")/../.." && pwd)
 src=$root/deepfluorolabeling-ipcai2020_amd/csrc; lib=$root/deepfluorolabeling-ipcai2020_amd/lib
-out=$root/tools/exp/bin/$name
+out=$root/docs/experiments/bin/$name
 mkdir -p $out
 objs=""
 for o in $lib/*.o; do

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Geometry the host cost model picks for the convolution shapes of the paper network (no GPU needed: planning is host code).
-DFL_CONVP_DEBUG=1 python tools/exp/convp_geom.py"""
+DFL_CONVP_DEBUG=1 python docs/experiments/convp_geom.py"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

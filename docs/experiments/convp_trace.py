@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Phase clocks of the patch-resident convolution kernel (diagnosis build: csrc/convp_bf16.hip with -DDFL_CONVP_TRACE,
-see tools/exp/build_trace.sh): per workgroup the shader-clock time in staging, in the k-loop and in the epilogue, for
-the 3x3 layer shapes of the paper network at batch 16.   DFL_LIB_OVERRIDE=tools/exp/bin/libdfl_trace.so python tools/exp/convp_trace.py"""
+see docs/experiments/build_trace.sh): per workgroup the shader-clock time in staging, in the k-loop and in the epilogue, for
+the 3x3 layer shapes of the paper network at batch 16.   DFL_LIB_OVERRIDE=docs/experiments/bin/libdfl_trace.so python docs/experiments/convp_trace.py"""
 import ctypes as C
 import os
 import sys

@@ -1,6 +1,6 @@
 #!/bin/bash
 # LDS / issue / wait counters of the bf16 kernels inside the default bench workload, three rocprofv3 --pmc passes (counters only).
-# Usage (on the GPU box): tools/exp/pmc_bf16.sh   -> gpurun_out/pmc_bf16.txt  (per kernel: average counter value per launch)
+# Usage (on the GPU box): docs/experiments/pmc_bf16.sh   -> gpurun_out/pmc_bf16.txt  (per kernel: average counter value per launch)
 root=$(pwd); cd /tmp && export TMPDIR=/tmp
 out=$root/gpurun_out/pmc_bf16.txt; : > $out
 i=0

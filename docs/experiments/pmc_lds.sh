@@ -1,5 +1,5 @@
 # LDS / issue counters of one conv layer (level 2 of the paper net) per kernel variant.  Usage (on the GPU box):
-#   DFL_MATH=bf16x3 bash tools/exp/pmc_lds.sh "sbrW sabrW WX"        (KIND=wgrad SHAPE="16 48 48 128 128 3" for the weight gradient)
+#   DFL_MATH=bf16x3 bash docs/experiments/pmc_lds.sh "sbrW sabrW WX"        (KIND=wgrad SHAPE="16 48 48 128 128 3" for the weight gradient)
 cd /tmp && export TMPDIR=/tmp
 root=$GRAFT_REPO_ROOT
 for flags in ${1:-sabr}; do

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Phase clocks of the patch-resident weight-gradient kernel (diagnosis build: tools/exp/build_trace.sh).
-DFL_LIB_OVERRIDE=tools/exp/bin/libdfl_trace.so python tools/exp/wgradp_trace.py"""
+"""Phase clocks of the patch-resident weight-gradient kernel (diagnosis build: docs/experiments/build_trace.sh).
+DFL_LIB_OVERRIDE=docs/experiments/bin/libdfl_trace.so python docs/experiments/wgradp_trace.py"""
 import ctypes as C
 import os
 import sys

@@ -33,7 +33,7 @@ TWO WAYS TO USE IT.  (1) Free running: the emulation computes everything from th
 pin to the oracle (rounding switched off) -- but a free-running comparison with a HIP run CANNOT be tight: rounding to bf16
 is discontinuous, a difference of one fp32 ulp in a sum flips the stored bf16 value with probability (fp32 error / bf16
 ulp), every flipped element perturbs the 9 x Cout sums it enters, and after five or six layers two valid implementations
-that differ in summation order only are a full bf16 rounding (3e-3) apart (measured, tools/exp/emu_layers.py: 1 element of
+that differ in summation order only are a full bf16 rounding (3e-3) apart (measured, docs/experiments/emu_layers.py: 1 element of
 72816 differs after the first layer, 14 % after the sixth).  (2) Teacher forced (`teacher=`): every stored tensor and every
 statistics vector the emulation is about to use is replaced by the one the HIP run holds, after the two were compared --
 each step of the HIP pass is then checked against its exact definition applied to the HIP run's OWN inputs: a stored bf16

@@ -43,7 +43,15 @@ PAPER_CFGS = {
                                 num_lands=14, do_res=True, block_depth=2)),
     'paper_mp_l0': (1235, dict(n_classes=7, depth=6, wf=5, batch_norm=True, padding=True, max_pool=True,
                                num_lands=0, do_res=True, block_depth=2)),
+    # BASELINE configs[0]'s program (train.py:326-327: strided convolutions, segmentation head only, DiceLoss2D alone) at its batch 4
+    'paper_sc_l0': (1236, dict(n_classes=7, depth=6, wf=5, batch_norm=True, padding=True, max_pool=False,
+                               num_lands=0, do_res=True, block_depth=2)),
 }
+PAPER_BATCH = {'paper_sc_l0': 4}          # batch of each paper fixture (default 2)
+
+
+def paper_key(name):
+    return 'paper__%s__b%d' % (name, PAPER_BATCH.get(name, 2))
 
 
 # ---- product arithmetic of the GEMM kernels (include/dfl_hip.h: dfl_set_math_mode) -------------------------------------

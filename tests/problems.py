@@ -9,7 +9,7 @@ import os
 import numpy as np
 import torch
 
-from conftest import TINY_CFGS, PAPER_CFGS, load_golden
+from conftest import TINY_CFGS, PAPER_CFGS, PAPER_BATCH, paper_key, load_golden
 from oracle import ref_cpu as R
 
 
@@ -203,7 +203,7 @@ REGISTRY = {}
 for _n in sorted(TINY_CFGS):
     REGISTRY['tiny__' + _n] = (lambda n=_n: tiny(n))
 for _n in sorted(PAPER_CFGS):
-    REGISTRY['paper__%s__b2' % _n] = (lambda n=_n: paper(n, 2))
+    REGISTRY[paper_key(_n)] = (lambda n=_n: paper(n, PAPER_BATCH.get(n, 2)))
 REGISTRY['paper__paper_sc_l14__b16'] = lambda: paper('paper_sc_l14', 16)
 for _hw in ((50, 70), (37, 41), (64, 96)):
     for _mp in (False, True):

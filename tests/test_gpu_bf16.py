@@ -710,8 +710,9 @@ def _eps4():
 
 @pytest.mark.parametrize('cfgname', ['paper_sc_l14', 'paper_mp_l0'])
 def test_network_bf16_storage_against_fp64_oracle(cfgname):
-    """Paper presets, batch 2: forward deviation at the bf16 level, labels identical outside the margin that deviation
-    implies, every gradient tensor inside its noise-floor bar at the mode's own measured convolution error."""
+    """Paper presets, batch 2, free running against the CLEAN fp64 oracle: forward deviation at the bf16 level, labels identical
+    outside the margin that deviation implies, whole gradient within what bf16 rounding of 25 layers amounts to (a sanity bar:
+    the parity gate of this arithmetic is the step-by-step check of the same problems, tests/test_gpu_bf16_stepwise.py)."""
     torch.set_num_threads(max(torch.get_num_threads(), 32))
     gf = NF.cached_check('paper__%s__b2' % cfgname, lambda: PR.paper(cfgname, 2))
     pr = gf.problem
@@ -726,10 +727,11 @@ def test_network_bf16_storage_against_fp64_oracle(cfgname):
     sure = (top2[:, 0] - top2[:, 1]) > 2.5 * dev
     assert float(sure.float().mean()) > 0.5
     assert bool((seg.detach().argmax(1).cpu() == gf.out.argmax(1))[sure].all())
-    res = gf.check(net, seg, _eps4(), cfgname + ' bf16s ')
-    print('%s bf16 storage: conv noise %.2e, whole-gradient error %.3e, worst per-tensor error / bar %.2f, decisions forced %d ReLU / %d pool '
-          '(of %d), largest margin %.2e' % (cfgname, res['eps_eff'], res['whole'], res['worst'], res['info']['relu_flips'],
-                                            res['info']['pool_flips'], res['info']['relu_total'], res['info']['max_margin']))
+    res = gf.whole_error(net, seg)
+    print('%s bf16 storage against clean fp64: forward %.3e, whole-gradient error %.3e, decisions forced %d ReLU / %d pool (of %d), largest '
+          'margin %.2e' % (cfgname, res['d_fwd'], res['whole'], res['info']['relu_flips'], res['info']['pool_flips'], res['info']['relu_total'],
+                           res['info']['max_margin']))
+    assert res['whole'] <= 5e-2 and res['d_fwd'] <= 2.4e-2
 
 
 @pytest.mark.parametrize('key', ['upsample__circular__wf5', 'landsblock__1__valid', 'landsblock__2'])
@@ -748,7 +750,7 @@ def test_constructor_flags_in_bf16_storage(key):
     assert 1e-6 < dev < 5e-2, 'soft-max deviation %.3e from fp64' % dev
     assert float((out[1].detach().double().cpu() - gc.heat).abs().max()) < 5e-2 * float(gc.heat.abs().max())
     assert abs(loss.item() - gc.loss) < 2e-2 * abs(gc.loss)
-    res = gc.check(net, seg, _eps4(), key + ' bf16s ')
+    res = gc.check(net, seg, _eps4(), key + ' bf16s ', margin_cap=1.0)     # (free running at bf16 distance: these flags are not restated by the emulation)
     print('%s bf16 storage: conv noise %.2e, whole-gradient error %.3e, worst error / bar %.2f' % (key, res['eps_eff'], res['whole'], res['worst']))
 
 

@@ -134,7 +134,7 @@ def assert_report(rep, gnorm_all, what):
 
 
 KEYS = ['ragged__37x41__mp0', 'ragged__37x41__mp1', 'ragged__50x70__mp0', 'ragged__50x70__mp1', 'ragged__64x96__mp0', 'ragged__64x96__mp1',
-        'paper__paper_sc_l14__b2', 'paper__paper_mp_l0__b2', 'config3']       # (batch 16 of the paper preset: tests/test_gpu_00_northstar.py)
+        'paper__paper_sc_l14__b2', 'paper__paper_mp_l0__b2', 'paper__paper_sc_l0__b4', 'config3']       # (batch 16 of the paper preset: tests/test_gpu_00_northstar.py)
 
 
 @pytest.mark.parametrize('key', KEYS)

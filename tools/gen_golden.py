@@ -170,7 +170,7 @@ def fixture_tiny(unet, dice, util, name, seed, hp=24, bwd=True, **kw):
     print(name, 'loss', loss.item(), 'keys', len(res))
 
 
-def fixture_paper(unet, dice, util, name, seed, max_pool, num_lands):
+def fixture_paper(unet, dice, util, name, seed, max_pool, num_lands, batch=2):
     """Paper preset: init hashes, strided output samples, argmax map, loss, grad norms (fp32 + fp64)."""
     kw = dict(n_classes=7, depth=6, wf=5, batch_norm=True, padding=True, max_pool=max_pool,
               num_lands=num_lands, do_res=True, block_depth=2)
@@ -180,11 +180,11 @@ def fixture_paper(unet, dice, util, name, seed, max_pool, num_lands):
     names = list(net.state_dict().keys())
     res['sd_names'] = np.array(names)
     res['sd_sha'] = np.array([sha(v) for v in net.state_dict().values()])
-    g = torch.Generator().manual_seed(seed + 1)
-    x = torch.randn(2, 1, 192, 192, generator=g)
-    lab = torch.randint(0, 7, (2, 184, 184), generator=g)
+    g = torch.Generator().manual_seed(seed + (1 if batch == 2 else batch))       # (as tests/problems.py: paper())
+    x = torch.randn(batch, 1, 192, 192, generator=g)
+    lab = torch.randint(0, 7, (batch, 184, 184), generator=g)
     tseg = torch.stack([(lab == c) for c in range(7)], 1).float()
-    theat = torch.rand(2, 14, 184, 184, generator=g) * 0.02
+    theat = torch.rand(batch, 14, 184, 184, generator=g) * 0.02
     res['x_sha'] = np.array(sha(x))
     res['lab'] = lab.to(torch.uint8).numpy()
     res['theat_sha'] = np.array(sha(theat))
@@ -720,6 +720,9 @@ def main():
             kw = dict(threads=(8,), out_name='plateau_paper_quick.npz')
         fixture_plateau_paper(unet, dice, util, **kw)
         return
+    if '--only-paper-sc-l0' in sys.argv:
+        fixture_paper(unet, dice, util, 'paper_sc_l0', 1236, max_pool=False, num_lands=0, batch=4)
+        return
     if '--only-validation' in sys.argv:
         fixture_validation(unet, util)
         return
@@ -751,6 +754,7 @@ def main():
     fixture_est_lands(util)
     fixture_paper(unet, dice, util, 'paper_sc_l14', 1234, max_pool=False, num_lands=14)
     fixture_paper(unet, dice, util, 'paper_mp_l0', 1235, max_pool=True, num_lands=0)
+    fixture_paper(unet, dice, util, 'paper_sc_l0', 1236, max_pool=False, num_lands=0, batch=4)     # BASELINE configs[0]'s program
     fixture_plateau_paper(unet, dice, util)         # (needs paper_sc_l14.npz: the SHA-256 of the seeded initial weights)
 
 

@@ -11,7 +11,7 @@ root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-bench="python $root/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-fp32-reference --no-fwd $extra"
+bench="python $root/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-fp32-reference --no-fwd --no-configs3 $extra"
 rocprofv3 --kernel-trace --stats -d "$out/trace" -o t --output-format csv -- $bench > "$out/bench_under_rocprof.json" 2> "$out/trace.err"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c -d "$out/pmc_$c" -o p --output-format csv -- $bench --no-profile > /dev/null 2> "$out/pmc_$c.err"
