@@ -158,6 +158,10 @@ def configs3(B=8, H=736, P=768, steps=8, warmup=3):
     import dfl_amd
     from dfl_amd.util import LateScalars
     dev = torch.device('cuda', torch.cuda.current_device())
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    base = torch.cuda.memory_allocated()
     torch.manual_seed(1)
     net = dfl_amd.UNet(**PAPER).to(dev)
     opt = dfl_amd.SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4, nesterov=True)
@@ -191,7 +195,7 @@ def configs3(B=8, H=736, P=768, steps=8, warmup=3):
     flop = 54.5e9 * (P * P) / (192 * 192) * B
     out = {'workload': 'BASELINE configs[3]: 2x-downsampled 736x736 (padded 768), paper U-Net dual head, batch %d, 1 MI355X' % B,
            'images_per_sec': round(B * steps / dt, 2), 'ms_per_step': round(dt / steps * 1e3, 2), 'steps': steps, 'warmup': warmup,
-           'tflops': round(flop / (dt / steps) / 1e12, 1), 'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+           'tflops': round(flop / (dt / steps) / 1e12, 1), 'peak_mem_gb': round((torch.cuda.max_memory_allocated() - base) / 2 ** 30, 2)}
     del net, opt, x, tseg, theat
     torch.cuda.empty_cache()
     return out

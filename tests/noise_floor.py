@@ -262,9 +262,9 @@ class GradientCheck:
         # may loosen itself on the deviation of the run under test)
         assert d_fwd <= max(1.0e-4, FWD_CAP * eps_conv), '%sforward output %.3e (relative L2, same pattern) off the oracle: more than %g x the ' \
             'arithmetic\'s convolution error %.2e' % (what, d_fwd, FWD_CAP, eps_conv)
-        flips = (info['relu_flips'] + info['pool_flips']) / max(info['relu_total'], 1)
-        assert flips <= max(1.0e-5, FLIP_CAP * eps_conv), '%s%.2e of the ReLU / pooling decisions differ from the oracle (convolution error %.2e)' % (
-            what, flips, eps_conv)
+        nflip, ndec = info['relu_flips'] + info['pool_flips'], max(info['relu_total'], 1)
+        assert nflip <= max(3, max(1.0e-5, FLIP_CAP * eps_conv) * ndec), '%s%d of %d ReLU / pooling decisions differ from the oracle (convolution error ' \
+            '%.2e)' % (what, nflip, ndec, eps_conv)
         assert info['max_margin'] <= margin_bar(eps_eff, margin_cap), \
             '%sa decision differs from the oracle where the oracle is not undecided: margin %.3e of the layer rms (bar %.3e at ' \
             'conv noise %.2e; %d ReLU + %d pooling decisions differ)' % (what, info['max_margin'], margin_bar(eps_eff, margin_cap), eps_eff,
