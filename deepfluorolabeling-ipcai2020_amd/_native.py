@@ -21,7 +21,9 @@ class ConvArgs(C.Structure):
                 ('Hout', i32), ('Wout', i32), ('Ntot', i32), ('ldy', i32),
                 ('ldadd', i32), ('ldso', i32), ('relu', i32), ('accumulate', i32), ('scatter2x2', i32),
                 ('splits', i32), ('w_split', i32), ('x_split', i32), ('x_bf16', i32), ('y_bf16', i32),
-                ('x2', fp), ('ldx2', i32), ('x_mode', i32)]
+                ('x2', fp), ('ldx2', i32), ('x_mode', i32),
+                ('stat_totals', fp), ('in_tot', fp), ('in_gamma', fp), ('in_beta', fp), ('add_tot', fp), ('add_gamma', fp),
+                ('add_beta', fp), ('in_count', C.c_double), ('add_count', C.c_double), ('bn_eps', f32), ('reserved3', i32)]
 
 
 class WgradArgs(C.Structure):
@@ -36,6 +38,16 @@ class WgradArgs(C.Structure):
 class PackJob(C.Structure):
     _fields_ = [('src', fp), ('dst', fp), ('A', i32), ('B', i32), ('C', i32), ('kind', i32), ('flip', i32),
                 ('split', i32)]
+
+
+class BnLiveJob(C.Structure):
+    _fields_ = [('totals', fp), ('gamma', fp), ('beta', fp), ('running_mean', fp), ('running_var', fp), ('num_batches_tracked', fp),
+                ('scale', fp), ('shift', fp), ('save_mean', fp), ('save_invstd', fp), ('count', i64), ('C', i32), ('eps', f32),
+                ('momentum', f32), ('reserved', i32)]
+
+
+class BnLiveArgs(C.Structure):
+    _fields_ = [('jobs_dev', fp), ('njobs', i32), ('max_C', i32)]
 
 
 class BnFinalizeArgs(C.Structure):
@@ -162,13 +174,13 @@ class Op(C.Structure):
 
 OP_CONV, OP_WGRAD, OP_SUM_PARTIALS, OP_PACK, OP_BN_FINALIZE, OP_BN_EVAL, OP_COLSTATS, OP_BN_BWD_FINALIZE, \
     OP_BN_RELU_BWD, OP_REDUCE_PARTIALS, OP_AFFINE_COPY, OP_POOL_FWD, OP_POOL_BWD, OP_HEAD_FWD, OP_HEAD_BWD, \
-    OP_MEMSET, OP_REDUCE_BATCH, OP_RECORD, OP_WAIT, OP_UPSAMPLE_FWD, OP_UPSAMPLE_BWD = range(1, 22)
+    OP_MEMSET, OP_REDUCE_BATCH, OP_RECORD, OP_WAIT, OP_UPSAMPLE_FWD, OP_UPSAMPLE_BWD, OP_BN_FINALIZE_LIVE = range(1, 23)
 
 _KIND_OF = {ConvArgs: OP_CONV, WgradArgs: OP_WGRAD, SumPartialsArgs: OP_SUM_PARTIALS, PackArgs: OP_PACK,
             BnFinalizeArgs: OP_BN_FINALIZE, BnEvalArgs: OP_BN_EVAL, ColstatsArgs: OP_COLSTATS,
             BnBwdFinalizeArgs: OP_BN_BWD_FINALIZE, BnReluBwdArgs: OP_BN_RELU_BWD,
             ReducePartialsArgs: OP_REDUCE_PARTIALS, AffineCopyArgs: OP_AFFINE_COPY, HeadFwdArgs: OP_HEAD_FWD,
-            HeadBwdArgs: OP_HEAD_BWD, MemsetArgs: OP_MEMSET, ReduceBatchArgs: OP_REDUCE_BATCH}
+            HeadBwdArgs: OP_HEAD_BWD, MemsetArgs: OP_MEMSET, ReduceBatchArgs: OP_REDUCE_BATCH, BnLiveArgs: OP_BN_FINALIZE_LIVE}
 
 _SIZEOF_ORDER = [ConvArgs, WgradArgs, PackJob, BnFinalizeArgs, ColstatsArgs, BnBwdFinalizeArgs, BnReluBwdArgs,
                  AffineCopyArgs, PoolArgs, HeadFwdArgs, HeadBwdArgs, LossArgs, EnsembleArgs, Op, ReduceJob, PrepArgs, EstLandsArgs,
@@ -185,7 +197,7 @@ EXPORTS = ['dfl_version', 'dfl_last_error', 'dfl_sizeof', 'dfl_conv2d', 'dfl_con
            'dfl_set_math_mode', 'dfl_graph_capture', 'dfl_graph_launch', 'dfl_graph_nodes', 'dfl_graph_destroy',
            'dfl_set_conv_rows_min_tiles', 'dfl_conv_candidates', 'dfl_conv_force_geometry', 'dfl_conv_tune_add',
            'dfl_head_wgrad_blocks', 'dfl_head_scratch_ld_for', 'dfl_head_scratch_off_for', 'dfl_upsample2x_fwd',
-           'dfl_upsample2x_bwd']
+           'dfl_upsample2x_bwd', 'dfl_bn_finalize_live']
 
 
 class DflError(RuntimeError):
@@ -216,6 +228,7 @@ def lib():
     L.dfl_bn_eval_prepare.argtypes = [fp, fp, fp, fp, fp, fp, i32, f32, fp]
     L.dfl_reduce_partials.argtypes = [fp, fp, i32, i32, i32, fp]
     L.dfl_reduce_batch.argtypes = [fp, i32, i32, fp]
+    L.dfl_bn_finalize_live.argtypes = [fp, i32, i32, fp]
     L.dfl_reduce_job_blocks.argtypes = [i64, i32]
     L.dfl_prep_scratch_doubles.restype = i64
     L.dfl_prep_scratch_doubles.argtypes = [i32]

@@ -166,6 +166,28 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const dfl_bn_finalize_
   if (blockIdx.x == 0 && threadIdx.x == 0 && a.num_batches_tracked != nullptr) *a.num_batches_tracked += 1;
 }
 
+// All "live" BatchNorm layers of a forward pass in one launch (dfl_bn_finalize_live): blockIdx.y = layer, a thread = a channel.
+__global__ void __launch_bounds__(256) bn_finalize_live_kernel(const dfl_bn_live_job* __restrict__ jobs) {
+  const dfl_bn_live_job j = jobs[blockIdx.y];
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < j.C) {
+    float scale, shift;
+    double mean, var;
+    bn_live_affine(j.totals, j.gamma, j.beta, (double)j.count, j.eps, j.C, c, &scale, &shift, &mean, &var);
+    j.scale[c] = scale;
+    j.shift[c] = shift;
+    j.save_mean[c] = (float)mean;
+    j.save_invstd[c] = (float)(1.0 / sqrt(var + (double)j.eps));
+    if (j.running_mean != nullptr) {
+      const double mom = (double)j.momentum, cnt = (double)j.count;
+      const double unbiased = (cnt > 1.0) ? var * cnt / (cnt - 1.0) : var;
+      j.running_mean[c] = (float)((1.0 - mom) * (double)j.running_mean[c] + mom * mean);
+      j.running_var[c] = (float)((1.0 - mom) * (double)j.running_var[c] + mom * unbiased);
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && j.num_batches_tracked != nullptr) *j.num_batches_tracked += 1;
+}
+
 __global__ void bn_eval_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
                                const float* __restrict__ rm, const float* __restrict__ rv, float* __restrict__ scale,
                                float* __restrict__ shift, int C, float eps) {
@@ -914,6 +936,13 @@ extern "C" int dfl_bn_finalize(const dfl_bn_finalize_args* a, dfl_stream_t strea
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(a->C, cpb)), dim3(256), 0, static_cast<hipStream_t>(stream), *a,
                      cpb);
   return check_launch("dfl_bn_finalize");
+}
+
+extern "C" int dfl_bn_finalize_live(const dfl_bn_live_job* jobs_dev, int32_t njobs, int32_t max_C, dfl_stream_t stream) {
+  DFL_REQUIRE(jobs_dev && njobs > 0 && max_C > 0, "dfl_bn_finalize_live: bad args");
+  hipLaunchKernelGGL(bn_finalize_live_kernel, dim3((unsigned)ceil_div(max_C, 256), (unsigned)njobs), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), jobs_dev);
+  return check_launch("dfl_bn_finalize_live");
 }
 
 extern "C" int dfl_bn_eval_prepare(const float* gamma, const float* beta, const float* running_mean,

@@ -63,4 +63,29 @@ __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); 
 // Row of accumulator register r (0..15) of a 32x32 MFMA tile for this lane; the column is lane & 31.
 __device__ __forceinline__ int mfma32_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+// ---- "live" BatchNorm statistics (dfl_conv_args.stat_totals / in_tot / add_tot, include/dfl_hip.h) ----------------------
+// One addend of a workgroup into the totals [DFL_BN_R][2][C]: the hardware fp64 atomic, no return value (fire and forget)
+__device__ __forceinline__ void bn_live_add(double* tot, int row, int which, int C, int c, float v) {
+  (void)__builtin_amdgcn_global_atomic_fadd_f64(tot + ((int64_t)((row & (DFL_BN_R - 1)) * 2 + which)) * C + c, (double)v);
+}
+// scale / shift (and mean, 1/std) of channel c from the totals: the arithmetic of bn_finalize_kernel, word for word
+__device__ __forceinline__ void bn_live_affine(const double* tot, const float* gamma, const float* beta, double count, float eps,
+                                               int C, int c, float* scale, float* shift, double* mean_out = nullptr,
+                                               double* var_out = nullptr) {
+  double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int r = 0; r < DFL_BN_R; ++r) {
+    s1 += tot[(int64_t)(r * 2 + 0) * C + c];
+    s2 += tot[(int64_t)(r * 2 + 1) * C + c];
+  }
+  const double mean = s1 / count;
+  double var = s2 / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double invstd = 1.0 / sqrt(var + (double)eps);
+  *scale = (float)((double)gamma[c] * invstd);
+  *shift = (float)((double)beta[c] - mean * (double)gamma[c] * invstd);
+  if (mean_out != nullptr) *mean_out = mean;
+  if (var_out != nullptr) *var_out = var;
+}
+
 }  // namespace dfl

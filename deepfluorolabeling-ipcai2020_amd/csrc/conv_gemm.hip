@@ -863,6 +863,8 @@ extern "C" int dfl_conv2d(const dfl_conv_args* a, dfl_stream_t stream) {
     return dfl::convp_launch(p, static_cast<hipStream_t>(stream));
   }
   DFL_REQUIRE(a == nullptr || a->x_mode == 0, "dfl_conv2d: x_mode (fused BatchNorm + ReLU backward operand) is implemented by the bf16 patch kernels only");
+  DFL_REQUIRE(a == nullptr || (a->stat_totals == nullptr && a->in_tot == nullptr && a->add_tot == nullptr),
+              "dfl_conv2d: live BatchNorm statistics (stat_totals / in_tot / add_tot) are implemented by the bf16 patch kernels only");
   dfl::ConvK k;
   int rc = dfl::prepare(a, &k);
   if (rc != DFL_OK) return rc;

@@ -20,6 +20,7 @@ struct ConvP {
   uint32_t x_bytes, w_bytes;
   uint32_t x2_bytes, pad0;      // extent of the second input tensor (dfl_conv_args.x_mode)
   uint32_t mPP, mPW;            // ceil(2^32 / (PH * PW)), ceil(2^32 / PW): divisions of patch row indices by multiply-high
+  int tab_off, pad1;            // LDS offset of the live-BatchNorm tables (set at launch)
 };
 
 // Chooses the geometry for these arguments.  force_splits: 0 = free choice, else the K-slice count to plan for.

@@ -153,6 +153,21 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : (TM 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // ---- "live" BatchNorm statistics (dfl_conv_args.in_tot / add_tot): scale / shift are derived here, one channel per thread,
+  //      into two small LDS tables behind everything else the kernel keeps in LDS ([2][128] for the input channels of the
+  //      resident block, [2][BN] for the epilogue's "+ BN(add)")
+  float* in_tab = reinterpret_cast<float*>(smem + p.tab_off);
+  float* add_tab = in_tab + 256;
+  if (a.add != nullptr && a.add_tot != nullptr) {
+    constexpr int BN0 = WN * TN * 32;
+    for (int col = tid; col < BN0; col += NT) {
+      float sc_ = 1.f, sh_ = 0.f;
+      if (n0 + col < a.Ntot) bn_live_affine(a.add_tot, a.add_gamma, a.add_beta, a.add_count, a.bn_eps, a.Ntot, n0 + col, &sc_, &sh_);
+      add_tab[col] = sc_;
+      add_tab[BN0 + col] = sh_;
+    }
+  }
+
   // ---- staging geometry: 16-byte units (8 channels) of the patch image, `upp` per pixel; a thread keeps its channel
   //      group, its pixel advances by 256 / upp per pass
   const int upp = p.CK >> 3, upp_sh = p.upp_shift;
@@ -291,10 +306,20 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : (TM 
     {
       float sc[8], sh[8], sq[8];
       if constexpr (AFF == 1) {
+        if (a.in_tot != nullptr) {                   // live statistics: this block's channels, one per thread, through LDS
+          if (tid < p.CK) bn_live_affine(a.in_tot, a.in_gamma, a.in_beta, a.in_count, a.bn_eps, a.Cin, c0 + tid, in_tab + tid, in_tab + 128 + tid);
+          __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          sc[e] = a.in_scale[c0 + cg * 8 + e];
-          sh[e] = a.in_shift[c0 + cg * 8 + e];
+          for (int e = 0; e < 8; ++e) {
+            sc[e] = in_tab[cg * 8 + e];
+            sh[e] = in_tab[128 + cg * 8 + e];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            sc[e] = a.in_scale[c0 + cg * 8 + e];
+            sh[e] = a.in_shift[c0 + cg * 8 + e];
+          }
         }
       }
       __amdgpu_buffer_rsrc_t rsR = rsX;
@@ -498,7 +523,7 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : (TM 
   static_assert(NT % UPR == 0 && (WM * 32) % RPS == 0, "row phase mapping");
   const bool rowthread = (RPS * UPR == NT) ? true : (tid < RPS * UPR);   // (two k-groups on a narrow tile: more threads than (row, unit) pairs)
   float* ep = reinterpret_cast<float*>(smem);
-  const bool do_stats = a.stat_partials != nullptr;
+  const bool do_stats = a.stat_partials != nullptr || a.stat_totals != nullptr;
   const bool scat = a.scatter2x2 != 0;
   const unsigned short* addp = reinterpret_cast<const unsigned short*>(a.add);
   const unsigned short* sop = reinterpret_cast<const unsigned short*>(a.stat_other);
@@ -518,6 +543,9 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : (TM 
     if (addp != nullptr && a.add_scale != nullptr && cok) {
       casc[e] = a.add_scale[ncol + e];
       cash[e] = a.add_shift[ncol + e];
+    } else if (addp != nullptr && a.add_tot != nullptr && cok) {      // (filled at kernel start; barriers passed since)
+      casc[e] = add_tab[ucol + e];
+      cash[e] = add_tab[BN + ucol + e];
     }
     s1[e] = 0.f;
     s2[e] = 0.f;
@@ -641,6 +669,8 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : (TM 
       if (scat) {                                      // rows = (patch, 2x2 position): [.][2][Cout], the sums of y's Cout channels
         const int ab = n / p.Cout, co = n - ab * p.Cout;
         a.stat_partials[(((int64_t)bpatch * 4 + ab) * 2 + which) * p.Cout + co] = sum;
+      } else if (a.stat_totals != nullptr) {           // live statistics: added to the layer's totals (hardware fp64 atomics)
+        bn_live_add(a.stat_totals, bpatch, which, a.Ntot, n, sum);
       } else {
         a.stat_partials[((int64_t)bpatch * 2 + which) * a.Ntot + n] = sum;
       }
@@ -667,6 +697,8 @@ __global__ void __launch_bounds__(256) convp_finish_kernel(const ConvP p, int TX
   if (a.add != nullptr && a.add_scale != nullptr && nok) {
     asc = a.add_scale[n];
     ash = a.add_shift[n];
+  } else if (a.add != nullptr && a.add_tot != nullptr && nok) {
+    bn_live_affine(a.add_tot, a.add_gamma, a.add_beta, a.add_count, a.bn_eps, Ntot, n, &asc, &ash);
   }
   const __bf16* addp = reinterpret_cast<const __bf16*>(a.add);
   const __bf16* sop = reinterpret_cast<const __bf16*>(a.stat_other);
@@ -701,7 +733,7 @@ __global__ void __launch_bounds__(256) convp_finish_kernel(const ConvP p, int TX
       s2 = fmaf(vr, u, s2);
     }
   }
-  if (a.stat_partials == nullptr) return;
+  if (a.stat_partials == nullptr && a.stat_totals == nullptr) return;
   red[0][threadIdx.x] = s1;
   red[1][threadIdx.x] = s2;
   __syncthreads();
@@ -714,6 +746,9 @@ __global__ void __launch_bounds__(256) convp_finish_kernel(const ConvP p, int TX
     if (a.scatter2x2) {                                // rows = (row block, 2x2 position), see convp_kernel
       a.stat_partials[(((int64_t)blockIdx.x * 4 + ab) * 2 + 0) * p.Cout + co] = t1;
       a.stat_partials[(((int64_t)blockIdx.x * 4 + ab) * 2 + 1) * p.Cout + co] = t2;
+    } else if (a.stat_totals != nullptr) {
+      bn_live_add(a.stat_totals, (int)blockIdx.x, 0, Ntot, n, t1);
+      bn_live_add(a.stat_totals, (int)blockIdx.x, 1, Ntot, n, t2);
     } else {
       a.stat_partials[((int64_t)blockIdx.x * 2 + 0) * Ntot + n] = t1;
       a.stat_partials[((int64_t)blockIdx.x * 2 + 1) * Ntot + n] = t2;
@@ -780,7 +815,7 @@ static bool try_geometry(const dfl_conv_args& a, ConvP* p, const TileCfg& t, int
   if (t.GA) {
     // streamed non-overlapping window (1x1 / stride 1, 2x2 / stride 2): no LDS image, no K slices; scored only by
     // measurement (tools/tune_convp.py)
-    if (a.KH != a.KW || a.stride != a.KH || a.KH > 2 || a.pad != 0 || a.in_scale != nullptr || a.x_mode != 0 || want_splits > 1) return false;
+    if (a.KH != a.KW || a.stride != a.KH || a.KH > 2 || a.pad != 0 || a.in_scale != nullptr || a.in_tot != nullptr || a.x_mode != 0 || want_splits > 1) return false;
     p->CK = 16;
     p->nblk = a.Cin / 16;
     p->splits = 1;
@@ -968,6 +1003,12 @@ static int convp_plan_search(const dfl_conv_args* a, ConvP* p, int force_splits)
               "dfl_conv2d (bf16): needs Cin %% 16 == 0, ldx %% 8 == 0 and 16-byte aligned x / w (Cin = %d, ldx = %d)", a->Cin, a->ldx);
   DFL_REQUIRE(a->w_split == 2, "dfl_conv2d (bf16): weights must be packed with dfl_pack_job.split = 2");
   DFL_REQUIRE(a->x_mode != 0 || (a->in_scale == nullptr) == (a->in_shift == nullptr), "dfl_conv2d: in_scale/in_shift go together");
+  DFL_REQUIRE(a->in_tot == nullptr || (a->in_scale == nullptr && a->x_mode == 0 && a->in_gamma != nullptr && a->in_beta != nullptr && a->in_count > 0),
+              "dfl_conv2d (bf16): in_tot replaces in_scale / in_shift and needs in_gamma, in_beta, in_count");
+  DFL_REQUIRE(a->add_tot == nullptr || (a->add != nullptr && a->add_scale == nullptr && a->add_gamma != nullptr && a->add_beta != nullptr && a->add_count > 0),
+              "dfl_conv2d (bf16): add_tot replaces add_scale / add_shift and needs add, add_gamma, add_beta, add_count");
+  DFL_REQUIRE(a->stat_totals == nullptr || (!a->scatter2x2 && a->stat_other == nullptr),
+              "dfl_conv2d (bf16): stat_totals takes the sums (v, v*v) of a plain store");
   DFL_REQUIRE((a->add_scale == nullptr) == (a->add_shift == nullptr), "dfl_conv2d: add_scale/add_shift go together");
   DFL_REQUIRE(a->KH * a->KW <= 16 && a->KH > 0 && a->KW > 0 && a->stride > 0 && a->pad >= 0, "dfl_conv2d (bf16): bad window");
   memset(p, 0, sizeof(*p));
@@ -1096,7 +1137,7 @@ int convp_plan(const dfl_conv_args* a, ConvP* p, int force_splits) {
 
 template <int WM, int WN, int TM, int TN, bool GA = false, int KS = 1>
 static int convp_launch_t(const ConvP& p, hipStream_t s) {
-  const bool aff = p.a.in_scale != nullptr;
+  const bool aff = p.a.in_scale != nullptr || p.a.in_tot != nullptr;
   dim3 grid((unsigned)p.grid);
   size_t lds = (size_t)p.lds_bytes;
   constexpr int BN_ = WN * TN * 32;
@@ -1113,23 +1154,29 @@ static int convp_launch_t(const ConvP& p, hipStream_t s) {
     }();
     if (lds + pad <= kLdsHard) lds += pad;
   }
+  ConvP pl = p;                                       // the "live" BatchNorm tables sit behind everything else in LDS
+  pl.tab_off = (int)((lds + 15) / 16 * 16);
+  if (p.a.in_tot != nullptr || p.a.add_tot != nullptr) lds = (size_t)pl.tab_off + (256 + 2 * BN_) * sizeof(float);
+  const ConvP& p_ = pl;
   if constexpr (GA) {
-    hipLaunchKernelGGL((convp_kernel<WM, WN, TM, TN, 0, true>), grid, dim3(256), lds, s, p);
+    static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(convp_kernel<WM, WN, TM, TN, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsHard);
+    (void)attr0;
+    hipLaunchKernelGGL((convp_kernel<WM, WN, TM, TN, 0, true>), grid, dim3(256), lds, s, p_);
   } else if (p.a.x_mode != 0) {
     auto k = convp_kernel<WM, WN, TM, TN, 2, false, KS>;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsHard);
     (void)attr;
-    hipLaunchKernelGGL(k, grid, dim3(NT_), lds, s, p);
+    hipLaunchKernelGGL(k, grid, dim3(NT_), lds, s, p_);
   } else if (aff) {
     auto k = convp_kernel<WM, WN, TM, TN, 1, false, KS>;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsHard);
     (void)attr;                                      // (once per instantiation, not per launch)
-    hipLaunchKernelGGL(k, grid, dim3(NT_), lds, s, p);
+    hipLaunchKernelGGL(k, grid, dim3(NT_), lds, s, p_);
   } else {
     auto k = convp_kernel<WM, WN, TM, TN, 0, false, KS>;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsHard);
     (void)attr;
-    hipLaunchKernelGGL(k, grid, dim3(NT_), lds, s, p);
+    hipLaunchKernelGGL(k, grid, dim3(NT_), lds, s, p_);
   }
   return check_launch("dfl_conv2d (bf16)");
 }

@@ -15,7 +15,7 @@ import torch
 
 from . import _native as nat
 from ._native import (ConvArgs, WgradArgs, PackJob, BnFinalizeArgs, ColstatsArgs, BnBwdFinalizeArgs, BnReluBwdArgs,
-                      AffineCopyArgs, PoolArgs, HeadFwdArgs, HeadBwdArgs, SumPartialsArgs, PackArgs, BnEvalArgs, UpsampleArgs,
+                      AffineCopyArgs, PoolArgs, HeadFwdArgs, HeadBwdArgs, SumPartialsArgs, PackArgs, BnEvalArgs, UpsampleArgs, BnLiveJob, BnLiveArgs,
                       ReducePartialsArgs, MemsetArgs, ReduceJob, ReduceBatchArgs, Program)
 
 BN_EPS = 1.0e-5
@@ -86,6 +86,7 @@ class UNetPlan:
         self.aesz = 2 if self.bf16 else 4
         self._packed_split = {}         # packed-weight address -> stored as split quads
         self.relu_out = {}              # nn.ReLU module name -> Act of its output (saved for backward; introspection for tests)
+        self._tot_arena, self._tot_used, self._live_jobs = None, 0, []
         self.dbg = {}                   # name -> Act / tensors of intermediate results (introspection for tests, see KEEP_GRADS)
         self.keep_grads = bool(KEEP_GRADS)
         self.pool_in = {}               # level -> Act the max-pool of that level reads
@@ -231,7 +232,10 @@ class UNetPlan:
 
     # ------------------------------------------------------------------------------------------ op helpers
     def _conv(self, prog, x, w, y, KH, KW, stride, pad, Ntot, bias=None, in_aff=None, relu=0, add=None,
-              add_aff=None, accumulate=0, scatter=0, stats=False, stat_other=None, Hout=None, Wout=None, x_split=0, brb=None):
+              add_aff=None, accumulate=0, scatter=0, stats=False, stat_other=None, Hout=None, Wout=None, x_split=0, brb=None,
+              in_live=None, add_live=None, stat_totals=None):
+        """in_live / add_live: (totals, gamma, beta, count) of a live BatchNorm instead of the (scale, shift) vectors of in_aff /
+        add_aff; stat_totals: the producer adds its statistics there instead of leaving partial rows (include/dfl_hip.h)."""
         a = ConvArgs()
         a.x, a.w, a.y = x.ptr, w.data_ptr(), y.ptr
         a.w_split = self._packed_split.get(w.data_ptr(), 0)
@@ -242,6 +246,12 @@ class UNetPlan:
         a.bias = nat.ptr(bias)
         if in_aff is not None:
             a.in_scale, a.in_shift = in_aff[0].data_ptr(), in_aff[1].data_ptr()
+        if in_live is not None:
+            a.in_tot, a.in_gamma, a.in_beta, a.in_count = in_live[0], in_live[1].data_ptr(), in_live[2].data_ptr(), float(in_live[3])
+            a.bn_eps = BN_EPS
+        if add_live is not None:
+            a.add_tot, a.add_gamma, a.add_beta, a.add_count = add_live[0], add_live[1].data_ptr(), add_live[2].data_ptr(), float(add_live[3])
+            a.bn_eps = BN_EPS
         if brb is not None:
             # the operand is the BatchNorm + ReLU backward of (x = dy, r) formed while the patch is staged (dfl_conv_args.x_mode)
             r_act, coef = brb
@@ -262,7 +272,9 @@ class UNetPlan:
             a.splits = sp
             a.partial = self._shared_scratch('conv_partial', sp * M * Ntot).data_ptr()
         partials = None
-        if stats:
+        if stat_totals is not None:
+            a.stat_totals = stat_totals
+        elif stats:
             gm = nat.check(self.lib.dfl_conv_grid_m(C.addressof(a)), 'dfl_conv_grid_m')
             partials = self._new(gm * 2 * Ntot)
             a.stat_partials = partials.data_ptr()
@@ -376,6 +388,41 @@ class UNetPlan:
         if fused:
             self._side_join(self.bwd, buf=key)      # side-stream weight gradients that still read this scratch
         return self._scratch_act(key, N, H, W, Cc)
+
+    LIVE_BN = os.environ.get('DFL_LIVE_BN', '1') != '0'     # BatchNorm statistics completed by their consumers (bf16 patch kernels)
+    BN_R = 8                                                # include/dfl_hip.h: DFL_BN_R
+
+    def _bn_totals(self, Cc):
+        """Address of [BN_R][2][C] doubles inside the plan's totals arena (zeroed by one memset at the start of the forward program)."""
+        need = self.BN_R * 2 * Cc
+        if self._tot_arena is None:
+            cfg = self.cfg
+            chans = [2 ** (cfg['wf'] + i) for i in range(cfg['depth'])]
+            total = sum(chans) * cfg['block_depth'] * 2 * self.BN_R * 2
+            self._tot_arena = self._new(total, torch.float64)
+            self._tot_used = 0
+        assert self._tot_used + need <= self._tot_arena.numel()
+        ptr = self._tot_arena.data_ptr() + 8 * self._tot_used
+        self._tot_used += need
+        return ptr
+
+    def _finish_live_bn(self, fwd, index=None):
+        """The zero fill in front of the forward program and the one batched finalize behind its last BatchNorm layer."""
+        if not self._live_jobs:
+            return
+        arr = (BnLiveJob * len(self._live_jobs))()
+        for i, j in enumerate(self._live_jobs):
+            a = arr[i]
+            a.totals, a.gamma, a.beta = j['totals'], j['gamma'].data_ptr(), j['beta'].data_ptr()
+            a.running_mean = self.Bf[j['bname'] + '.running_mean'].data_ptr()
+            a.running_var = self.Bf[j['bname'] + '.running_var'].data_ptr()
+            a.num_batches_tracked = self.Bf[j['bname'] + '.num_batches_tracked'].data_ptr()
+            a.scale, a.shift, a.save_mean, a.save_invstd = (j[k].data_ptr() for k in ('scale', 'shift', 'mean', 'invstd'))
+            a.count, a.C, a.eps, a.momentum = j['count'], j['C'], BN_EPS, BN_MOMENTUM
+        dev = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(self.dev)
+        self._keep.append(dev)
+        fwd.add(BnLiveArgs(jobs_dev=dev.data_ptr(), njobs=len(self._live_jobs), max_C=max(j['C'] for j in self._live_jobs)))
+        fwd.insert(0, MemsetArgs(ptr=self._tot_arena.data_ptr(), bytes=8 * self._tot_used))
 
     def _shared_scratch(self, key, nelem):
         t = self._scratch.get(key)
@@ -534,8 +581,9 @@ class UNetPlan:
             Cout = out.C
             Hb, Wb = xin.H - shrink, xin.W - shrink
             convs = []
-            cur, cur_aff = xin, None
+            cur, cur_aff, cur_live = xin, None, None
             step = 3 if bn else 2
+            patch_in = lambda t: bool(t.bf16) and t.C % 16 == 0            # a convolution reading t runs the bf16 patch kernels
             for d in range(bd):
                 wname = '%s.block.%d' % (prefix, d * step)
                 w, b = P[wname + '.weight'], P[wname + '.bias']
@@ -543,8 +591,16 @@ class UNetPlan:
                 Ho, Wo = cur.H - (0 if pad else 2), cur.W - (0 if pad else 2)
                 r = self._act(N, Ho, Wo, Cout)
                 gin = self._wrap_pad(fwd, cur) if circ else cur          # what the convolution (and its weight gradient) gathers from
-                part = self._conv(fwd, gin, wp, r, 3, 3, 1, 0 if circ else pad, Cout, bias=b, in_aff=cur_aff, relu=1,
-                                   stats=bn and self.training)
+                # Live statistics (round 4): this layer's BatchNorm is not finalised by a launch between producer and consumer --
+                # the producing patch kernel adds its sums to the layer's totals, the consuming patch kernel (next 3x3, or the
+                # residual 1x1 whose epilogue adds BN(r)) derives scale / shift itself; ONE batched launch at the end of the forward
+                # pass leaves the vectors the backward pass and the module state need.  Both kernels must be patch kernels.
+                live = (self.LIVE_BN and bn and self.training and self.bf16 and not circ and patch_in(gin)
+                        and (d < bd - 1 or (do_res and patch_in(xin))))
+                tot = self._bn_totals(Cout) if live else None
+                part = self._conv(fwd, gin, wp, r, 3, 3, 1, 0 if circ else pad, Cout, bias=b,
+                                   in_aff=None if cur_live is not None else cur_aff, in_live=cur_live, relu=1,
+                                   stats=bn and self.training, stat_totals=tot)
                 aff = None
                 bnrec = None
                 if bn:
@@ -552,7 +608,10 @@ class UNetPlan:
                     gamma, beta = P[bname + '.weight'], P[bname + '.bias']
                     scale, shift = self._new(Cout), self._new(Cout)
                     mean, invstd = self._new(Cout), self._new(Cout)
-                    if self.training:
+                    if self.training and live:
+                        self._live_jobs.append(dict(totals=tot, gamma=gamma, beta=beta, bname=bname, scale=scale, shift=shift, mean=mean,
+                                                    invstd=invstd, count=N * Ho * Wo, C=Cout))
+                    elif self.training:
                         fa = BnFinalizeArgs(partials=part[0].data_ptr(), gamma=gamma.data_ptr(), beta=beta.data_ptr(),
                                             running_mean=self.Bf[bname + '.running_mean'].data_ptr(),
                                             running_var=self.Bf[bname + '.running_var'].data_ptr(),
@@ -580,11 +639,13 @@ class UNetPlan:
                 convs.append(dict(w=w, wname=wname, inp=cur, gin=gin, inp_aff=cur_aff, r=r, bn=bnrec))
                 self.relu_out['%s.block.%d' % (prefix, d * step + 1)] = r      # (module name of the nn.ReLU: tests read its mask)
                 cur, cur_aff = r, aff
+                cur_live = (tot, gamma, beta, N * Ho * Wo) if (bn and self.training and live) else None
             assert cur.H == Hb and cur.W == Wb
             if do_res:
                 rw, rb = P[prefix + '.res_conv1x1.weight'], P[prefix + '.res_conv1x1.bias']
                 rwp = self._pack_conv_fwd(rw)
-                self._conv(fwd, xin, rwp, out, 1, 1, 1, 0, Cout, bias=rb, add=cur, add_aff=cur_aff)
+                self._conv(fwd, xin, rwp, out, 1, 1, 1, 0, Cout, bias=rb, add=cur, add_aff=None if cur_live is not None else cur_aff,
+                           add_live=cur_live)
             else:
                 a = AffineCopyArgs(x=cur.ptr, y=out.ptr, N=N, H=Hb, W=Wb, C=Cout, ldx=cur.ld, xH=Hb, xW=Wb,
                                    ldy=out.ld, yH=out.H, yW=out.W, bf16=cur.bf16)
@@ -788,6 +849,7 @@ class UNetPlan:
             up_recs.append(dict(block_bw=bw, out=out, u=u, level=i, name=name, w=uw_))
             u = out
         self.feat = u
+        self._finish_live_bn(fwd)
 
         # ------------------------------------------------------------------ heads
         NC, L = cfg['n_classes'], cfg['num_lands']

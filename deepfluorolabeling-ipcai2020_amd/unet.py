@@ -186,6 +186,7 @@ class UNet(nn.Module):
         self._plans = {}
         self._param_list = None
         self._pack_version = None
+        self._bn_epoch = 0
         self._last_train_plan = None
         self._backward_runner = self._run_backward
         self.dp = None                                # set by parallel.DataParallel
@@ -303,6 +304,11 @@ class UNet(nn.Module):
 
     def _ensure_packed(self, plan, stream):
         ver = sum(p._version for p in self._weight_params)
+        if not plan.training and not plan.need_grad:
+            # inference plans also prepare the eval-mode BatchNorm scale / shift there: every parameter, every buffer (in-place
+            # torch edits, load_state_dict) and the training forwards of this network (they update the running statistics
+            # through raw pointers) count
+            ver = (ver, sum(p._version for p in self._param_list), sum(b._version for b in self._buffer_dict.values()), self._bn_epoch)
         if self._pack_version != (id(plan), ver):
             plan.pack.run(stream)                    # weight re-layout for this plan's kernels
             plan.fold_tail()                         # (lands_num_1x1 > 2: product of the trailing 1x1 convolutions)
@@ -356,6 +362,8 @@ class UNet(nn.Module):
         self._state()
         need_grad = torch.is_grad_enabled() and (x_src is not None or any(p.requires_grad for p in self._param_list))
         plan = self._get_plan(x, need_grad, input_grad=x_src is not None)
+        if plan.training:
+            self._bn_epoch += 1                      # running statistics move: inference plans re-derive their scale / shift
         # first GPU work of a training step: enqueue it before the autograd bookkeeping below (the GPU sits idle between
         # the previous step's loss.item() and this launch)
         self._ensure_packed(plan, torch.cuda.current_stream().cuda_stream)

@@ -103,7 +103,31 @@ typedef struct {
    * must be NULL).  What dfl_bn_relu_bwd_apply would materialise is never written: one tensor pass and one launch per layer less. */
   const float* x2;
   int32_t ldx2, x_mode;
+  /* "Live" BatchNorm statistics (bf16 patch kernels, training; round 4).  Between a convolution and the next one stands
+   * nn.BatchNorm2d in training mode (unet.py:214-222): the consumer needs scale / shift made of the producer's batch statistics.
+   * dfl_bn_finalize between the two is a 5 us launch in the dependency chain, 44 times per step.  Instead:
+   *   stat_totals  the producer ADDS its workgroups' column sums (sum v, sum v*v of the stored values) into [DFL_BN_R][2][Ntot]
+   *                doubles with hardware fp64 atomics (row = workgroup % DFL_BN_R spreads the contention; the addends are fp32
+   *                values of similar magnitude, their fp64 sum is exact -- independent of the order -- unless one of them is below
+   *                2^-29 of the total).  The caller zeroes the rows before the producer runs.  stat_partials may be NULL then.
+   *   in_tot       (instead of in_scale / in_shift) the consumer derives scale / shift of its input channels itself, with the
+   *                arithmetic of dfl_bn_finalize: mean = s1 / count, var = s2 / count - mean^2 (biased, >= 0),
+   *                scale = gamma / sqrt(var + eps), shift = beta - mean * scale, from in_tot [DFL_BN_R][2][Cin], in_gamma, in_beta.
+   *   add_tot      the same for the epilogue's "+ add * add_scale + add_shift" (add_gamma, add_beta, [DFL_BN_R][2][Ntot]).
+   * dfl_bn_finalize_live (one batched launch per forward pass) turns the totals into the vectors the backward pass and the
+   * module state need (scale, shift, mean, invstd, running statistics). */
+  double* stat_totals;
+  const double* in_tot;
+  const float* in_gamma;
+  const float* in_beta;
+  const double* add_tot;
+  const float* add_gamma;
+  const float* add_beta;
+  double in_count, add_count;
+  float bn_eps;
+  int32_t reserved3;
 } dfl_conv_args;
+#define DFL_BN_R 8
 
 int dfl_conv2d(const dfl_conv_args* a, dfl_stream_t stream);
 /* Number of row blocks whose statistics dfl_conv2d will write for these args (= first dim of stat_partials);
@@ -216,6 +240,23 @@ typedef struct {
 } dfl_bn_finalize_args;
 
 int dfl_bn_finalize(const dfl_bn_finalize_args* a, dfl_stream_t stream);
+
+/* The same for "live" statistics (dfl_conv_args.stat_totals): ONE launch for all BatchNorm layers of a forward pass, after the
+ * last of them -- the convolutions in between derived their scale / shift from the totals themselves.  Each job turns
+ * totals [DFL_BN_R][2][C] into scale / shift / save_mean / save_invstd (what the backward pass and tests read) and updates the
+ * running statistics (momentum, unbiased variance, num_batches_tracked += 1: nn.BatchNorm2d in training mode, unet.py:215,222).
+ * `jobs_dev` lives in device memory. */
+typedef struct {
+  const double* totals;
+  const float* gamma; const float* beta;
+  float* running_mean; float* running_var; int64_t* num_batches_tracked;   /* all three NULL: no module state to update */
+  float* scale; float* shift; float* save_mean; float* save_invstd;
+  int64_t count;
+  int32_t C;
+  float eps, momentum;
+  int32_t reserved;
+} dfl_bn_live_job;
+int dfl_bn_finalize_live(const dfl_bn_live_job* jobs_dev, int32_t njobs, int32_t max_C, dfl_stream_t stream);
 int dfl_bn_eval_prepare(const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float* scale, float* shift, int32_t C, float eps,
                         dfl_stream_t stream);
@@ -517,7 +558,8 @@ typedef enum {
   DFL_OP_BN_EVAL = 6, DFL_OP_COLSTATS = 7, DFL_OP_BN_BWD_FINALIZE = 8, DFL_OP_BN_RELU_BWD = 9,
   DFL_OP_REDUCE_PARTIALS = 10, DFL_OP_AFFINE_COPY = 11, DFL_OP_POOL_FWD = 12, DFL_OP_POOL_BWD = 13,
   DFL_OP_HEAD_FWD = 14, DFL_OP_HEAD_BWD = 15, DFL_OP_MEMSET = 16, DFL_OP_REDUCE_BATCH = 17,
-  DFL_OP_RECORD = 18, DFL_OP_WAIT = 19, DFL_OP_UPSAMPLE_FWD = 20, DFL_OP_UPSAMPLE_BWD = 21
+  DFL_OP_RECORD = 18, DFL_OP_WAIT = 19, DFL_OP_UPSAMPLE_FWD = 20, DFL_OP_UPSAMPLE_BWD = 21,
+  DFL_OP_BN_FINALIZE_LIVE = 22
 } dfl_op_kind;
 
 typedef struct { const float* src; float* dst; int64_t n; int32_t splits; int32_t T; } dfl_sum_partials_args;
@@ -527,6 +569,7 @@ typedef struct { const float* gamma; const float* beta; const float* running_mea
 typedef struct { const float* partials; float* out; int32_t nblocks, stride, C, reserved; } dfl_reduce_partials_args;
 typedef struct { void* ptr; int64_t bytes; } dfl_memset_args; /* zero fill */
 typedef struct { const dfl_reduce_job* jobs_dev; int32_t njobs, total_blocks; } dfl_reduce_batch_args;
+typedef struct { const dfl_bn_live_job* jobs_dev; int32_t njobs, max_C; } dfl_bn_live_args;
 
 /* DFL_OP_RECORD: record library event `event` on the op's stream; DFL_OP_WAIT: make the op's stream wait for it.
  * Events are library-owned, identified by small integers the program chooses (0..65535). */

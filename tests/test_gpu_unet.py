@@ -671,3 +671,55 @@ def test_random_architectures_match_oracle(seed, math_mode):
         pytest.skip('the reference architecture itself rejects the flags / size of seed %d' % seed)
     gc = NF.cached_check('random__%d' % seed, lambda: pr)
     _forward_loss_gradients(gc, math_mode, 'random architecture %d ' % seed)
+
+
+def test_inference_scale_shift_follow_every_change_of_the_batchnorm_state():
+    """Inference plans derive the eval-mode BatchNorm scale / shift in their pack program, not in every forward (round 4): they have
+    to notice (a) a training forward (running statistics move through raw pointers), (b) an optimizer step, (c) an in-place
+    edit of a buffer, (d) load_state_dict -- each time the next eval forward must equal the oracle's (unet.py:161-193 in eval mode)."""
+    cfg = dict(n_classes=7, depth=3, wf=3, batch_norm=True, padding=True, max_pool=False, num_lands=14, do_res=True, block_depth=2)
+    torch.manual_seed(5)
+    net = dfl_amd.UNet(**cfg).to(DEV)
+    onet = R.OracleUNet(**cfg)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 1, 48, 48, generator=g)
+    xt = torch.randn(4, 1, 48, 48, generator=g)
+
+    def same(what):
+        onet.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+        onet.eval()
+        net.eval()
+        with torch.no_grad():
+            s, h = net(x.to(DEV))
+            s2, h2 = net(x.to(DEV))
+            os_, oh = onet(x)
+        assert torch.equal(s, s2) and torch.equal(h, h2), what
+        np.testing.assert_allclose(s.cpu().numpy(), os_.numpy(), rtol=1e-4, atol=1e-5, err_msg=what)
+        np.testing.assert_allclose(h.cpu().numpy(), oh.numpy(), rtol=1e-4, atol=1e-4 * float(oh.abs().max()), err_msg=what)
+
+    same('fresh network')
+    net.train()
+    with torch.no_grad():
+        net(xt.to(DEV))                                   # (a) running statistics move, nothing else
+    same('after a training forward without gradients')
+    net.train()
+    opt = dfl_amd.SGD(net.parameters(), lr=0.05, momentum=0.9)
+    out = net(xt.to(DEV))
+    (out[0].square().mean() + out[1].square().mean()).backward()
+    opt.step()                                            # (b)
+    same('after an optimizer step')
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_var.mul_(1.7)                   # (c)
+                m.bias.add_(0.1)
+    same('after in-place edits of a buffer and a BatchNorm parameter')
+    torch.manual_seed(9)
+    other = R.OracleUNet(**cfg)
+    with torch.no_grad():
+        for m in other.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 2.0)
+    net.load_state_dict(other.state_dict())               # (d)
+    same('after load_state_dict')

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import TINY_CFGS, PAPER_CFGS, load_golden
+from conftest import PAPER_BATCH, TINY_CFGS, PAPER_CFGS, load_golden
 from oracle import ref_cpu as R
 
 
@@ -77,13 +77,14 @@ def test_paper_init_and_forward(name):
     sd = net.state_dict()
     assert list(sd.keys()) == list(g['sd_names'])
     assert [_sha(v) for v in sd.values()] == list(g['sd_sha'])       # identical seeded init
-    gen = torch.Generator().manual_seed(seed + 1)
-    x = torch.randn(2, 1, 192, 192, generator=gen)
+    B = PAPER_BATCH.get(name, 2)
+    gen = torch.Generator().manual_seed(seed + (1 if B == 2 else B))
+    x = torch.randn(B, 1, 192, 192, generator=gen)
     assert _sha(x) == str(g['x_sha'])
-    lab = torch.randint(0, 7, (2, 184, 184), generator=gen)
+    lab = torch.randint(0, 7, (B, 184, 184), generator=gen)
     assert np.array_equal(lab.numpy().astype(np.uint8), g['lab'])
     tseg = R.one_hot_masks(lab, 7)
-    theat = torch.rand(2, 14, 184, 184, generator=gen) * 0.02
+    theat = torch.rand(B, 14, 184, 184, generator=gen) * 0.02
     net.train()
     out = net(x)
     nl = cfg['num_lands']
