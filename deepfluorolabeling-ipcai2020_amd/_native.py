@@ -23,7 +23,8 @@ class ConvArgs(C.Structure):
                 ('splits', i32), ('w_split', i32), ('x_split', i32), ('x_bf16', i32), ('y_bf16', i32),
                 ('x2', fp), ('ldx2', i32), ('x_mode', i32),
                 ('stat_totals', fp), ('in_tot', fp), ('in_gamma', fp), ('in_beta', fp), ('add_tot', fp), ('add_gamma', fp),
-                ('add_beta', fp), ('in_count', C.c_double), ('add_count', C.c_double), ('bn_eps', f32), ('reserved3', i32)]
+                ('add_beta', fp), ('in_count', C.c_double), ('add_count', C.c_double), ('bn_eps', f32), ('reserved3', i32),
+                ('in_mean', fp), ('in_invstd', fp)]
 
 
 class WgradArgs(C.Structure):
@@ -32,7 +33,8 @@ class WgradArgs(C.Structure):
                 ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32),
                 ('Hout', i32), ('Wout', i32), ('Cm', i32), ('ldd', i32), ('splits', i32), ('d_split', i32),
                 ('g_bf16', i32), ('d_bf16', i32), ('d_mode', i32), ('d2', fp), ('coef', fp), ('bias_partial', fp),
-                ('ldd2', i32), ('reserved2', i32)]
+                ('ldd2', i32), ('reserved2', i32), ('coef_tot', fp), ('bn_gamma', fp), ('bn_mean', fp), ('bn_invstd', fp),
+                ('bn_count', C.c_double)]
 
 
 class PackJob(C.Structure):
@@ -44,6 +46,15 @@ class BnLiveJob(C.Structure):
     _fields_ = [('totals', fp), ('gamma', fp), ('beta', fp), ('running_mean', fp), ('running_var', fp), ('num_batches_tracked', fp),
                 ('scale', fp), ('shift', fp), ('save_mean', fp), ('save_invstd', fp), ('count', i64), ('C', i32), ('eps', f32),
                 ('momentum', f32), ('reserved', i32)]
+
+
+class BnBwdLiveJob(C.Structure):
+    _fields_ = [('totals', fp), ('save_mean', fp), ('save_invstd', fp), ('dgamma', fp), ('dbeta', fp), ('sum_out', fp), ('C', i32),
+                ('reserved', i32)]
+
+
+class BnBwdLiveArgs(C.Structure):
+    _fields_ = [('jobs_dev', fp), ('njobs', i32), ('max_C', i32)]
 
 
 class BnLiveArgs(C.Structure):
@@ -174,13 +185,13 @@ class Op(C.Structure):
 
 OP_CONV, OP_WGRAD, OP_SUM_PARTIALS, OP_PACK, OP_BN_FINALIZE, OP_BN_EVAL, OP_COLSTATS, OP_BN_BWD_FINALIZE, \
     OP_BN_RELU_BWD, OP_REDUCE_PARTIALS, OP_AFFINE_COPY, OP_POOL_FWD, OP_POOL_BWD, OP_HEAD_FWD, OP_HEAD_BWD, \
-    OP_MEMSET, OP_REDUCE_BATCH, OP_RECORD, OP_WAIT, OP_UPSAMPLE_FWD, OP_UPSAMPLE_BWD, OP_BN_FINALIZE_LIVE = range(1, 23)
+    OP_MEMSET, OP_REDUCE_BATCH, OP_RECORD, OP_WAIT, OP_UPSAMPLE_FWD, OP_UPSAMPLE_BWD, OP_BN_FINALIZE_LIVE, OP_BN_BWD_FINALIZE_LIVE = range(1, 24)
 
 _KIND_OF = {ConvArgs: OP_CONV, WgradArgs: OP_WGRAD, SumPartialsArgs: OP_SUM_PARTIALS, PackArgs: OP_PACK,
             BnFinalizeArgs: OP_BN_FINALIZE, BnEvalArgs: OP_BN_EVAL, ColstatsArgs: OP_COLSTATS,
             BnBwdFinalizeArgs: OP_BN_BWD_FINALIZE, BnReluBwdArgs: OP_BN_RELU_BWD,
             ReducePartialsArgs: OP_REDUCE_PARTIALS, AffineCopyArgs: OP_AFFINE_COPY, HeadFwdArgs: OP_HEAD_FWD,
-            HeadBwdArgs: OP_HEAD_BWD, MemsetArgs: OP_MEMSET, ReduceBatchArgs: OP_REDUCE_BATCH, BnLiveArgs: OP_BN_FINALIZE_LIVE}
+            HeadBwdArgs: OP_HEAD_BWD, MemsetArgs: OP_MEMSET, ReduceBatchArgs: OP_REDUCE_BATCH, BnLiveArgs: OP_BN_FINALIZE_LIVE, BnBwdLiveArgs: OP_BN_BWD_FINALIZE_LIVE}
 
 _SIZEOF_ORDER = [ConvArgs, WgradArgs, PackJob, BnFinalizeArgs, ColstatsArgs, BnBwdFinalizeArgs, BnReluBwdArgs,
                  AffineCopyArgs, PoolArgs, HeadFwdArgs, HeadBwdArgs, LossArgs, EnsembleArgs, Op, ReduceJob, PrepArgs, EstLandsArgs,
@@ -197,7 +208,7 @@ EXPORTS = ['dfl_version', 'dfl_last_error', 'dfl_sizeof', 'dfl_conv2d', 'dfl_con
            'dfl_set_math_mode', 'dfl_graph_capture', 'dfl_graph_launch', 'dfl_graph_nodes', 'dfl_graph_destroy',
            'dfl_set_conv_rows_min_tiles', 'dfl_conv_candidates', 'dfl_conv_force_geometry', 'dfl_conv_tune_add',
            'dfl_head_wgrad_blocks', 'dfl_head_scratch_ld_for', 'dfl_head_scratch_off_for', 'dfl_upsample2x_fwd',
-           'dfl_upsample2x_bwd', 'dfl_bn_finalize_live']
+           'dfl_upsample2x_bwd', 'dfl_bn_finalize_live', 'dfl_bn_bwd_finalize_live']
 
 
 class DflError(RuntimeError):
@@ -229,6 +240,7 @@ def lib():
     L.dfl_reduce_partials.argtypes = [fp, fp, i32, i32, i32, fp]
     L.dfl_reduce_batch.argtypes = [fp, i32, i32, fp]
     L.dfl_bn_finalize_live.argtypes = [fp, i32, i32, fp]
+    L.dfl_bn_bwd_finalize_live.argtypes = [fp, i32, i32, fp]
     L.dfl_reduce_job_blocks.argtypes = [i64, i32]
     L.dfl_prep_scratch_doubles.restype = i64
     L.dfl_prep_scratch_doubles.argtypes = [i32]

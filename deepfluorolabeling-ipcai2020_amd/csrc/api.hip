@@ -270,6 +270,11 @@ static int exec_one(const dfl_op* ops, int i, dfl_stream_t main_stream, bool ser
         rc = dfl_bn_finalize_live(a->jobs_dev, a->njobs, a->max_C, stream);
         break;
       }
+      case DFL_OP_BN_BWD_FINALIZE_LIVE: {
+        const dfl_bn_bwd_live_args* a = static_cast<const dfl_bn_bwd_live_args*>(p);
+        rc = dfl_bn_bwd_finalize_live(a->jobs_dev, a->njobs, a->max_C, stream);
+        break;
+      }
       case DFL_OP_MEMSET: {
         const dfl_memset_args* a = static_cast<const dfl_memset_args*>(p);
         if (a->bytes > 0 && hipMemsetAsync(a->ptr, 0, (size_t)a->bytes, static_cast<hipStream_t>(stream)) != hipSuccess) {

@@ -188,6 +188,22 @@ __global__ void __launch_bounds__(256) bn_finalize_live_kernel(const dfl_bn_live
   if (blockIdx.x == 0 && threadIdx.x == 0 && j.num_batches_tracked != nullptr) *j.num_batches_tracked += 1;
 }
 
+__global__ void __launch_bounds__(256) bn_bwd_finalize_live_kernel(const dfl_bn_bwd_live_job* __restrict__ jobs) {
+  const dfl_bn_bwd_live_job j = jobs[blockIdx.y];
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= j.C) return;
+  double sdy = 0.0, sdyr = 0.0;
+#pragma unroll
+  for (int r = 0; r < DFL_BN_R; ++r) {
+    sdy += j.totals[(int64_t)(r * 2 + 0) * j.C + c];
+    sdyr += j.totals[(int64_t)(r * 2 + 1) * j.C + c];
+  }
+  const double mean = (double)j.save_mean[c], invstd = (double)j.save_invstd[c];
+  j.dgamma[c] = (float)(invstd * (sdyr - mean * sdy));
+  j.dbeta[c] = (float)sdy;
+  if (j.sum_out != nullptr) j.sum_out[c] = (float)sdy;
+}
+
 __global__ void bn_eval_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
                                const float* __restrict__ rm, const float* __restrict__ rv, float* __restrict__ scale,
                                float* __restrict__ shift, int C, float eps) {
@@ -943,6 +959,13 @@ extern "C" int dfl_bn_finalize_live(const dfl_bn_live_job* jobs_dev, int32_t njo
   hipLaunchKernelGGL(bn_finalize_live_kernel, dim3((unsigned)ceil_div(max_C, 256), (unsigned)njobs), dim3(256), 0,
                      static_cast<hipStream_t>(stream), jobs_dev);
   return check_launch("dfl_bn_finalize_live");
+}
+
+extern "C" int dfl_bn_bwd_finalize_live(const dfl_bn_bwd_live_job* jobs_dev, int32_t njobs, int32_t max_C, dfl_stream_t stream) {
+  DFL_REQUIRE(jobs_dev && njobs > 0 && max_C > 0, "dfl_bn_bwd_finalize_live: bad args");
+  hipLaunchKernelGGL(bn_bwd_finalize_live_kernel, dim3((unsigned)ceil_div(max_C, 256), (unsigned)njobs), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), jobs_dev);
+  return check_launch("dfl_bn_bwd_finalize_live");
 }
 
 extern "C" int dfl_bn_eval_prepare(const float* gamma, const float* beta, const float* running_mean,

@@ -88,4 +88,23 @@ __device__ __forceinline__ void bn_live_affine(const double* tot, const float* g
   if (var_out != nullptr) *var_out = var;
 }
 
+// A, B, C of  d(pre-activation) = [r > 0] * (A dy + B r + C)  for channel c from the totals (sum dy, sum dy*r): the arithmetic of
+// bn_bwd_finalize_kernel (training mode), word for word
+__device__ __forceinline__ void bn_live_coef(const double* tot, const float* gamma, const float* save_mean, const float* save_invstd,
+                                             double count, int C, int c, float* A, float* B, float* Cc) {
+  double sdy = 0.0, sdyr = 0.0;
+#pragma unroll
+  for (int r = 0; r < DFL_BN_R; ++r) {
+    sdy += tot[(int64_t)(r * 2 + 0) * C + c];
+    sdyr += tot[(int64_t)(r * 2 + 1) * C + c];
+  }
+  const double mean = (double)save_mean[c], invstd = (double)save_invstd[c], g = (double)gamma[c];
+  const double sdyx = invstd * (sdyr - mean * sdy);
+  const double s = g * invstd;
+  const double c1 = sdy / count, c2 = sdyx / count;
+  *A = (float)s;
+  *B = (float)(-s * c2 * invstd);
+  *Cc = (float)(-s * c1 + s * c2 * invstd * mean);
+}
+
 }  // namespace dfl

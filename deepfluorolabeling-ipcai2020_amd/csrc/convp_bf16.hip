@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : (TM 
   //      into two small LDS tables behind everything else the kernel keeps in LDS ([2][128] for the input channels of the
   //      resident block, [2][BN] for the epilogue's "+ BN(add)")
   float* in_tab = reinterpret_cast<float*>(smem + p.tab_off);
-  float* add_tab = in_tab + 256;
+  float* add_tab = in_tab + 384;                      // (in_tab: [3][128] -- scale, shift, or the three backward coefficients)
   if (a.add != nullptr && a.add_tot != nullptr) {
     constexpr int BN0 = WN * TN * 32;
     for (int col = tid; col < BN0; col += NT) {
@@ -325,12 +325,24 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : (TM 
       __amdgpu_buffer_rsrc_t rsR = rsX;
       if constexpr (AFF == 2) {                    // d(pre-activation) = [r > 0] * (sc dy + sh r + sq); no BatchNorm: 1, 0, 0
         rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x2), 0, (int)p.x2_bytes, 0x00020000);
+        if (a.in_tot != nullptr) {                   // live statistics: A, B, C of this block's channels, one per thread, through LDS
+          if (tid < p.CK)
+            bn_live_coef(a.in_tot, a.in_gamma, a.in_mean, a.in_invstd, a.in_count, a.Cin, c0 + tid, in_tab + tid, in_tab + 128 + tid, in_tab + 256 + tid);
+          __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int c = c0 + cg * 8 + e;
-          sc[e] = a.in_scale != nullptr ? a.in_scale[c] : 1.f;
-          sh[e] = a.in_scale != nullptr ? a.in_scale[a.Cin + c] : 0.f;
-          sq[e] = a.in_scale != nullptr ? a.in_scale[2 * a.Cin + c] : 0.f;
+          for (int e = 0; e < 8; ++e) {
+            sc[e] = in_tab[cg * 8 + e];
+            sh[e] = in_tab[128 + cg * 8 + e];
+            sq[e] = in_tab[256 + cg * 8 + e];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int c = c0 + cg * 8 + e;
+            sc[e] = a.in_scale != nullptr ? a.in_scale[c] : 1.f;
+            sh[e] = a.in_scale != nullptr ? a.in_scale[a.Cin + c] : 0.f;
+            sq[e] = a.in_scale != nullptr ? a.in_scale[2 * a.Cin + c] : 0.f;
+          }
         }
       }
       int pix = tid >> upp_sh;
@@ -668,7 +680,8 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : (TM 
       for (int w = 0; w < RPS; ++w) sum += red[(w * 2 + which) * BN + col];
       if (scat) {                                      // rows = (patch, 2x2 position): [.][2][Cout], the sums of y's Cout channels
         const int ab = n / p.Cout, co = n - ab * p.Cout;
-        a.stat_partials[(((int64_t)bpatch * 4 + ab) * 2 + which) * p.Cout + co] = sum;
+        if (a.stat_totals != nullptr) bn_live_add(a.stat_totals, bpatch * 4 + ab, which, p.Cout, co, sum);
+        else a.stat_partials[(((int64_t)bpatch * 4 + ab) * 2 + which) * p.Cout + co] = sum;
       } else if (a.stat_totals != nullptr) {           // live statistics: added to the layer's totals (hardware fp64 atomics)
         bn_live_add(a.stat_totals, bpatch, which, a.Ntot, n, sum);
       } else {
@@ -743,7 +756,10 @@ __global__ void __launch_bounds__(256) convp_finish_kernel(const ConvP p, int TX
       t1 += red[0][y * TX + tx];
       t2 += red[1][y * TX + tx];
     }
-    if (a.scatter2x2) {                                // rows = (row block, 2x2 position), see convp_kernel
+    if (a.scatter2x2 && a.stat_totals != nullptr) {
+      bn_live_add(a.stat_totals, (int)blockIdx.x * 4 + ab, 0, p.Cout, co, t1);
+      bn_live_add(a.stat_totals, (int)blockIdx.x * 4 + ab, 1, p.Cout, co, t2);
+    } else if (a.scatter2x2) {                         // rows = (row block, 2x2 position), see convp_kernel
       a.stat_partials[(((int64_t)blockIdx.x * 4 + ab) * 2 + 0) * p.Cout + co] = t1;
       a.stat_partials[(((int64_t)blockIdx.x * 4 + ab) * 2 + 1) * p.Cout + co] = t2;
     } else if (a.stat_totals != nullptr) {
@@ -1003,12 +1019,12 @@ static int convp_plan_search(const dfl_conv_args* a, ConvP* p, int force_splits)
               "dfl_conv2d (bf16): needs Cin %% 16 == 0, ldx %% 8 == 0 and 16-byte aligned x / w (Cin = %d, ldx = %d)", a->Cin, a->ldx);
   DFL_REQUIRE(a->w_split == 2, "dfl_conv2d (bf16): weights must be packed with dfl_pack_job.split = 2");
   DFL_REQUIRE(a->x_mode != 0 || (a->in_scale == nullptr) == (a->in_shift == nullptr), "dfl_conv2d: in_scale/in_shift go together");
-  DFL_REQUIRE(a->in_tot == nullptr || (a->in_scale == nullptr && a->x_mode == 0 && a->in_gamma != nullptr && a->in_beta != nullptr && a->in_count > 0),
-              "dfl_conv2d (bf16): in_tot replaces in_scale / in_shift and needs in_gamma, in_beta, in_count");
+  DFL_REQUIRE(a->in_tot == nullptr || (a->in_scale == nullptr && a->in_gamma != nullptr && a->in_count > 0 &&
+                                       (a->x_mode == 0 ? a->in_beta != nullptr : (a->in_mean != nullptr && a->in_invstd != nullptr))),
+              "dfl_conv2d (bf16): in_tot replaces in_scale / in_shift and needs in_gamma, in_count and in_beta (x_mode 0) or in_mean, in_invstd (x_mode 1)");
   DFL_REQUIRE(a->add_tot == nullptr || (a->add != nullptr && a->add_scale == nullptr && a->add_gamma != nullptr && a->add_beta != nullptr && a->add_count > 0),
               "dfl_conv2d (bf16): add_tot replaces add_scale / add_shift and needs add, add_gamma, add_beta, add_count");
-  DFL_REQUIRE(a->stat_totals == nullptr || (!a->scatter2x2 && a->stat_other == nullptr),
-              "dfl_conv2d (bf16): stat_totals takes the sums (v, v*v) of a plain store");
+
   DFL_REQUIRE((a->add_scale == nullptr) == (a->add_shift == nullptr), "dfl_conv2d: add_scale/add_shift go together");
   DFL_REQUIRE(a->KH * a->KW <= 16 && a->KH > 0 && a->KW > 0 && a->stride > 0 && a->pad >= 0, "dfl_conv2d (bf16): bad window");
   memset(p, 0, sizeof(*p));
@@ -1156,7 +1172,7 @@ static int convp_launch_t(const ConvP& p, hipStream_t s) {
   }
   ConvP pl = p;                                       // the "live" BatchNorm tables sit behind everything else in LDS
   pl.tab_off = (int)((lds + 15) / 16 * 16);
-  if (p.a.in_tot != nullptr || p.a.add_tot != nullptr) lds = (size_t)pl.tab_off + (256 + 2 * BN_) * sizeof(float);
+  if (p.a.in_tot != nullptr || p.a.add_tot != nullptr) lds = (size_t)pl.tab_off + (384 + 2 * BN_) * sizeof(float);
   const ConvP& p_ = pl;
   if constexpr (GA) {
     static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(convp_kernel<WM, WN, TM, TN, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsHard);

@@ -178,9 +178,12 @@ __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const
   if constexpr (DBRB) {
     for (int c = tid; c < p.CMT; c += NT) {
       const bool live = a.coef != nullptr && cm0 + c < a.Cm;
-      dco[c] = live ? a.coef[cm0 + c] : 1.f;
-      dco[p.CMT + c] = live ? a.coef[a.Cm + cm0 + c] : 0.f;
-      dco[2 * p.CMT + c] = live ? a.coef[2 * a.Cm + cm0 + c] : 0.f;
+      float A = live ? a.coef[cm0 + c] : 1.f, B = live ? a.coef[a.Cm + cm0 + c] : 0.f, Cc = live ? a.coef[2 * a.Cm + cm0 + c] : 0.f;
+      if (a.coef_tot != nullptr && cm0 + c < a.Cm)      // live statistics (include/dfl_hip.h): derived here
+        bn_live_coef(a.coef_tot, a.bn_gamma, a.bn_mean, a.bn_invstd, a.bn_count, a.Cm, cm0 + c, &A, &B, &Cc);
+      dco[c] = A;
+      dco[p.CMT + c] = B;
+      dco[2 * p.CMT + c] = Cc;
     }
   }
   if constexpr (AFF || DBRB) __syncthreads();             // the first commit() reads these tables
@@ -461,6 +464,8 @@ static int wgp_plan(const dfl_wgrad_args* a, WgP* p, bool need_out) {
   p->g_bytes = (uint32_t)gb;
   p->d_bytes = (uint32_t)db;
   if (a->d_mode != 0) {
+    DFL_REQUIRE(a->coef_tot == nullptr || (a->coef == nullptr && a->bn_gamma && a->bn_mean && a->bn_invstd && a->bn_count > 0),
+                "dfl_conv2d_wgrad (bf16): coef_tot replaces coef and needs bn_gamma, bn_mean, bn_invstd, bn_count");
     DFL_REQUIRE(a->d_mode == 1 && a->KH == 3 && a->d2 != nullptr && a->ldd2 % 8 == 0 && aligned16(a->d2),
                 "dfl_conv2d_wgrad (bf16): d_mode 1 needs a 3x3 window and d2 (16-byte aligned, ldd2 %% 8 == 0)");
     const int64_t d2b = ((M - 1) * a->ldd2 + a->Cm) * 2;

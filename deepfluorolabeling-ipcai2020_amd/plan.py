@@ -15,7 +15,7 @@ import torch
 
 from . import _native as nat
 from ._native import (ConvArgs, WgradArgs, PackJob, BnFinalizeArgs, ColstatsArgs, BnBwdFinalizeArgs, BnReluBwdArgs,
-                      AffineCopyArgs, PoolArgs, HeadFwdArgs, HeadBwdArgs, SumPartialsArgs, PackArgs, BnEvalArgs, UpsampleArgs, BnLiveJob, BnLiveArgs,
+                      AffineCopyArgs, PoolArgs, HeadFwdArgs, HeadBwdArgs, SumPartialsArgs, PackArgs, BnEvalArgs, UpsampleArgs, BnLiveJob, BnLiveArgs, BnBwdLiveJob, BnBwdLiveArgs,
                       ReducePartialsArgs, MemsetArgs, ReduceJob, ReduceBatchArgs, Program)
 
 BN_EPS = 1.0e-5
@@ -86,7 +86,7 @@ class UNetPlan:
         self.aesz = 2 if self.bf16 else 4
         self._packed_split = {}         # packed-weight address -> stored as split quads
         self.relu_out = {}              # nn.ReLU module name -> Act of its output (saved for backward; introspection for tests)
-        self._tot_arena, self._tot_used, self._live_jobs = None, 0, []
+        self._tot_fwd, self._tot_bwd, self._live_jobs, self._live_bwd_pending = [None, 0], [None, 0], [], []
         self.dbg = {}                   # name -> Act / tensors of intermediate results (introspection for tests, see KEEP_GRADS)
         self.keep_grads = bool(KEEP_GRADS)
         self.pool_in = {}               # level -> Act the max-pool of that level reads
@@ -256,7 +256,11 @@ class UNetPlan:
             # the operand is the BatchNorm + ReLU backward of (x = dy, r) formed while the patch is staged (dfl_conv_args.x_mode)
             r_act, coef = brb
             a.x_mode, a.x2, a.ldx2 = 1, r_act.ptr, r_act.ld
-            a.in_scale = nat.ptr(coef)
+            if isinstance(coef, dict):               # live statistics: the kernel derives A, B, C from the totals itself
+                a.in_tot, a.in_gamma, a.in_mean, a.in_invstd = coef['tot'], coef['gamma'].data_ptr(), coef['mean'].data_ptr(), coef['invstd'].data_ptr()
+                a.in_count = float(coef['count'])
+            else:
+                a.in_scale = nat.ptr(coef)
         if add is not None:
             a.add, a.ldadd = add.ptr, add.ld
             if add_aff is not None:
@@ -274,6 +278,9 @@ class UNetPlan:
         partials = None
         if stat_totals is not None:
             a.stat_totals = stat_totals
+            if stat_other is not None:
+                a.stat_other, a.ldso = stat_other.ptr, stat_other.ld
+            partials = ('live', stat_totals)
         elif stats:
             gm = nat.check(self.lib.dfl_conv_grid_m(C.addressof(a)), 'dfl_conv_grid_m')
             partials = self._new(gm * 2 * Ntot)
@@ -312,7 +319,12 @@ class UNetPlan:
         a.Hout, a.Wout, a.Cm, a.ldd = Hout, Wout, d.C, d.ld
         if brb is not None:
             r_act, coef = brb                       # d = dy; the operand is formed from (dy, r) while the patch is staged (d_mode)
-            a.d_mode, a.d2, a.ldd2, a.coef = 1, r_act.ptr, r_act.ld, nat.ptr(coef)
+            a.d_mode, a.d2, a.ldd2 = 1, r_act.ptr, r_act.ld
+            if isinstance(coef, dict):               # live statistics (include/dfl_hip.h)
+                a.coef_tot, a.bn_gamma, a.bn_mean, a.bn_invstd = coef['tot'], coef['gamma'].data_ptr(), coef['mean'].data_ptr(), coef['invstd'].data_ptr()
+                a.bn_count = float(coef['count'])
+            else:
+                a.coef = nat.ptr(coef)
         a.splits = 1
         s = nat.check(self.lib.dfl_wgrad_suggest_splits(C.addressof(a)), 'dfl_wgrad_suggest_splits')
         a.splits = s
@@ -361,6 +373,7 @@ class UNetPlan:
             self._flush_sums(prog)
 
     def _flush_sums(self, prog):
+        self._flush_live_bwd(prog)
         jobs = self._red_pending
         if not jobs:
             return
@@ -392,19 +405,36 @@ class UNetPlan:
     LIVE_BN = os.environ.get('DFL_LIVE_BN', '1') != '0'     # BatchNorm statistics completed by their consumers (bf16 patch kernels)
     BN_R = 8                                                # include/dfl_hip.h: DFL_BN_R
 
-    def _bn_totals(self, Cc):
-        """Address of [BN_R][2][C] doubles inside the plan's totals arena (zeroed by one memset at the start of the forward program)."""
+    def _bn_totals(self, Cc, bwd=False):
+        """Address of [BN_R][2][C] doubles inside the plan's totals arena of the forward (backward) pass, zeroed by one memset at
+        the start of that program."""
         need = self.BN_R * 2 * Cc
-        if self._tot_arena is None:
+        ar = self._tot_bwd if bwd else self._tot_fwd
+        if ar[0] is None:
             cfg = self.cfg
             chans = [2 ** (cfg['wf'] + i) for i in range(cfg['depth'])]
-            total = sum(chans) * cfg['block_depth'] * 2 * self.BN_R * 2
-            self._tot_arena = self._new(total, torch.float64)
-            self._tot_used = 0
-        assert self._tot_used + need <= self._tot_arena.numel()
-        ptr = self._tot_arena.data_ptr() + 8 * self._tot_used
-        self._tot_used += need
+            ar[0] = self._new(sum(chans) * cfg['block_depth'] * 2 * self.BN_R * 2, torch.float64)
+        assert ar[1] + need <= ar[0].numel()
+        ptr = ar[0].data_ptr() + 8 * ar[1]
+        ar[1] += need
         return ptr
+
+    def _flush_live_bwd(self, prog):
+        """One batched launch for the BatchNorm parameter gradients (and residual bias gradients) of the live layers queued so far."""
+        jobs = self._live_bwd_pending
+        if not jobs:
+            return
+        arr = (BnBwdLiveJob * len(jobs))()
+        for i, j in enumerate(jobs):
+            a = arr[i]
+            a.totals, a.save_mean, a.save_invstd = j['tot'], j['mean'].data_ptr(), j['invstd'].data_ptr()
+            a.dgamma, a.dbeta, a.sum_out, a.C = j['dgamma'].data_ptr(), j['dbeta'].data_ptr(), nat.ptr(j['sum_out']), j['C']
+        dev = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(self.dev)
+        self._keep.append(dev)
+        dsts = [j[k].data_ptr() for j in jobs for k in ('dgamma', 'dbeta', 'sum_out') if j[k] is not None]
+        self._red_flushes.append((len(prog.structs), dsts))
+        prog.add(BnBwdLiveArgs(jobs_dev=dev.data_ptr(), njobs=len(jobs), max_C=max(j['C'] for j in jobs)))
+        self._live_bwd_pending = []
 
     def _finish_live_bn(self, fwd, index=None):
         """The zero fill in front of the forward program and the one batched finalize behind its last BatchNorm layer."""
@@ -422,7 +452,7 @@ class UNetPlan:
         dev = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(self.dev)
         self._keep.append(dev)
         fwd.add(BnLiveArgs(jobs_dev=dev.data_ptr(), njobs=len(self._live_jobs), max_C=max(j['C'] for j in self._live_jobs)))
-        fwd.insert(0, MemsetArgs(ptr=self._tot_arena.data_ptr(), bytes=8 * self._tot_used))
+        fwd.insert(0, MemsetArgs(ptr=self._tot_fwd[0].data_ptr(), bytes=8 * self._tot_fwd[1]))
 
     def _shared_scratch(self, key, nelem):
         t = self._scratch.get(key)
@@ -598,6 +628,8 @@ class UNetPlan:
                 live = (self.LIVE_BN and bn and self.training and self.bf16 and not circ and patch_in(gin)
                         and (d < bd - 1 or (do_res and patch_in(xin))))
                 tot = self._bn_totals(Cout) if live else None
+                live_bwd = (self.LIVE_BN and bn and self.training and self.bf16 and self.FUSE_BRB and self.FUSE_BWD_STATS and not circ
+                            and patch_in(cur) and self.need_grad)        # this layer's backward can take live (sum dy, sum dy*r)
                 part = self._conv(fwd, gin, wp, r, 3, 3, 1, 0 if circ else pad, Cout, bias=b,
                                    in_aff=None if cur_live is not None else cur_aff, in_live=cur_live, relu=1,
                                    stats=bn and self.training, stat_totals=tot)
@@ -636,7 +668,7 @@ class UNetPlan:
                     aff = (scale, shift)
                     bnrec = (gamma, mean, invstd, bname)
                     self.dbg['bn:' + bname] = (scale, shift, mean, invstd)
-                convs.append(dict(w=w, wname=wname, inp=cur, gin=gin, inp_aff=cur_aff, r=r, bn=bnrec))
+                convs.append(dict(w=w, wname=wname, inp=cur, gin=gin, inp_aff=cur_aff, r=r, bn=bnrec, live_bwd=live_bwd))
                 self.relu_out['%s.block.%d' % (prefix, d * step + 1)] = r      # (module name of the nn.ReLU: tests read its mask)
                 cur, cur_aff = r, aff
                 cur_live = (tot, gamma, beta, N * Ho * Wo) if (bn and self.training and live) else None
@@ -692,24 +724,33 @@ class UNetPlan:
                     self.dbg['g:%s.block.%d' % (prefix, d * step + 1)] = g
                     if cv['bn'] is not None:
                         gamma, mean, invstd, bname = cv['bn']
-                        if fused is not None:
-                            part, prow = fused
+                        if fused is not None and fused[0] == 'live':
+                            # live statistics: the producer of g added (sum g, sum g*r) to this layer's totals; the two consumers
+                            # below derive A, B, C themselves, the parameter gradients leave with the next batched launch
+                            assert cv['live_bwd']
+                            coef = dict(tot=fused[1], gamma=gamma, mean=mean, invstd=invstd, count=r.M)
+                            self._live_bwd_pending.append(dict(tot=fused[1], mean=mean, invstd=invstd, dgamma=G[bname + '.weight'],
+                                                               dbeta=G[bname + '.bias'], C=Cout,
+                                                               sum_out=G[prefix + '.res_conv1x1.bias'] if (do_res and d == bd - 1) else None))
                         else:
-                            part, prow = self._new(nb * 2 * Cout), nb
-                            bwd.add(ColstatsArgs(a=g.ptr, b=r.ptr, partials=part.data_ptr(), M=r.M, C=Cout, lda=g.ld,
-                                                 ldb=r.ld, nblocks=nb, bf16=r.bf16))
-                        coef = self._new(3 * Cout)
-                        self.dbg['coef:%s.block.%d' % (prefix, d * step + 1)] = coef
-                        bwd.add(BnBwdFinalizeArgs(partials=part.data_ptr(), gamma=gamma.data_ptr(),
-                                                  save_mean=mean.data_ptr(), save_invstd=invstd.data_ptr(),
-                                                  dgamma=G[bname + '.weight'].data_ptr(),
-                                                  dbeta=G[bname + '.bias'].data_ptr(), coef=coef.data_ptr(),
-                                                  count=r.M if self.training else 0,      # 0: fixed (running) statistics
-                                                  nblocks=prow, C=Cout))
-                        if do_res and d == bd - 1:
-                            # residual bias gradient = column sums of dout, already in the same partials
-                            self._defer_sum(bwd, part.data_ptr(), G[prefix + '.res_conv1x1.bias'].data_ptr(), Cout,
-                                            2 * Cout, prow)
+                            if fused is not None:
+                                part, prow = fused
+                            else:
+                                part, prow = self._new(nb * 2 * Cout), nb
+                                bwd.add(ColstatsArgs(a=g.ptr, b=r.ptr, partials=part.data_ptr(), M=r.M, C=Cout, lda=g.ld,
+                                                     ldb=r.ld, nblocks=nb, bf16=r.bf16))
+                            coef = self._new(3 * Cout)
+                            self.dbg['coef:%s.block.%d' % (prefix, d * step + 1)] = coef
+                            bwd.add(BnBwdFinalizeArgs(partials=part.data_ptr(), gamma=gamma.data_ptr(),
+                                                      save_mean=mean.data_ptr(), save_invstd=invstd.data_ptr(),
+                                                      dgamma=G[bname + '.weight'].data_ptr(),
+                                                      dbeta=G[bname + '.bias'].data_ptr(), coef=coef.data_ptr(),
+                                                      count=r.M if self.training else 0,      # 0: fixed (running) statistics
+                                                      nblocks=prow, C=Cout))
+                            if do_res and d == bd - 1:
+                                # residual bias gradient = column sums of dout, already in the same partials
+                                self._defer_sum(bwd, part.data_ptr(), G[prefix + '.res_conv1x1.bias'].data_ptr(), Cout,
+                                                2 * Cout, prow)
                     elif do_res and d == bd - 1:
                         self._colsum(bwd, g, G[prefix + '.res_conv1x1.bias'])
                     inp = cv['inp']
@@ -766,7 +807,8 @@ class UNetPlan:
                         if prev['bn'] is not None and self.FUSE_BWD_STATS:
                             # the data-gradient conv leaves sum(dz), sum(dz*r) per channel for the next BN backward
                             fused = self._conv(bwd, dpre, wd, dz, 3, 3, 1, 2 - pad, Cout, stats=True, stat_other=prev['r'],
-                                               x_split=dsplit, brb=brb)
+                                               x_split=dsplit, brb=brb,
+                                               stat_totals=self._bn_totals(Cout, bwd=True) if prev['live_bwd'] else None)
                         else:
                             fused = None
                             self._conv(bwd, dpre, wd, dz, 3, 3, 1, 2 - pad, Cout, x_split=dsplit, brb=brb)
@@ -784,6 +826,7 @@ class UNetPlan:
                 return dxin_part
             # pre-BatchNorm output of the block's last conv: what a producer of this block's dout needs for fused_in
             backward.last_r = convs[-1]['r'] if convs[-1]['bn'] is not None else None
+            backward.last_live = bool(convs[-1]['bn'] is not None and convs[-1]['live_bwd'])    # ... and may leave them as live totals
             return backward
 
         # ------------------------------------------------------------------ down path
@@ -1062,12 +1105,14 @@ class UNetPlan:
                         nat.OP_UPSAMPLE_BWD)
                 self._wgrad(bwd, uin, dylow, self.G[rec['name'] + '.up.1.weight'], 1, 1, 1, 0, uin.H, uin.W)
                 dout_sums = self._conv(bwd, dylow, self._pack_conv_dgrad(rec['w']), du, 1, 1, 1, 0, uin.C,
-                                       stats=r_last is not None, stat_other=r_last)
+                                       stats=r_last is not None, stat_other=r_last,
+                                       stat_totals=self._bn_totals(uin.C, bwd=True) if (r_last is not None and consumer.last_live) else None)
             else:
                 # dW[ci][co][ab] = sum x[i,j][ci] * dy[2i+a,2j+b][co]
                 self._wgrad(bwd, dy, uin, self.G[rec['name'] + '.up.weight'], 2, 2, 2, 0, uin.H, uin.W)
                 wd = self._pack_convT_dgrad(rec['w'])
-                dout_sums = self._conv(bwd, dy, wd, du, 2, 2, 2, 0, uin.C, stats=r_last is not None, stat_other=r_last)
+                dout_sums = self._conv(bwd, dy, wd, du, 2, 2, 2, 0, uin.C, stats=r_last is not None, stat_other=r_last,
+                                       stat_totals=self._bn_totals(uin.C, bwd=True) if (r_last is not None and consumer.last_live) else None)
             dout = du
         # down path, deepest block first
         for i in reversed(range(depth)):
@@ -1107,7 +1152,8 @@ class UNetPlan:
                     want = (self.FUSE_DOWN_STATS and r_last is not None and bool(dout.bf16) and bool(r_last.bf16)
                             and out.H == 2 * nxt.H and out.W == 2 * nxt.W)
                     down_sums = self._conv(bwd, dnxt, wd, dout, 1, 1, 1, 0, 4 * Ci, accumulate=1, scatter=1,
-                                           Hout=out.H, Wout=out.W, stats=want, stat_other=r_last if want else None)
+                                           Hout=out.H, Wout=out.W, stats=want, stat_other=r_last if want else None,
+                                           stat_totals=self._bn_totals(Ci, bwd=True) if (want and rec['block_bw'].last_live) else None)
             if i > 0:
                 dxin = self._act(N, rec['xin'].H, rec['xin'].W, rec['xin'].C)
                 pending[i - 1]['dnxt'] = dxin
@@ -1125,6 +1171,8 @@ class UNetPlan:
                 pending[i - 1]['dnxt_sums'] = st
         self._flush_sums(bwd)
         self._side_join(bwd)
+        if self._tot_bwd[0] is not None:
+            bwd.insert(0, MemsetArgs(ptr=self._tot_bwd[0].data_ptr(), bytes=8 * self._tot_bwd[1]))
         self._order_pack_jobs()
         self._finish_pack()
         # index of the last backward op that writes each parameter gradient (data-parallel bucket scheduling)

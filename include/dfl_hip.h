@@ -126,6 +126,12 @@ typedef struct {
   double in_count, add_count;
   float bn_eps;
   int32_t reserved3;
+  /* ... and for the BatchNorm + ReLU backward operand (x_mode = 1): with in_tot the three coefficients are not read from
+   * in_scale but derived from the totals (sum dy, sum dy*r) [DFL_BN_R][2][Cin] left by the kernel that produced dy
+   * (stat_totals together with stat_other), in_gamma, the layer's saved mean / 1/std (in_mean, in_invstd) and in_count -- the
+   * arithmetic of dfl_bn_bwd_finalize. */
+  const float* in_mean;
+  const float* in_invstd;
 } dfl_conv_args;
 #define DFL_BN_R 8
 
@@ -183,6 +189,13 @@ typedef struct {
   const float* coef;
   float* bias_partial;
   int32_t ldd2, reserved2;
+  /* Live statistics (dfl_conv_args.stat_totals; round 4): instead of `coef` the kernel derives A, B, C itself from coef_tot
+   * [DFL_BN_R][2][Cm] = totals of (sum dy, sum dy*r), bn_gamma, the saved mean / 1/std and bn_count (dfl_bn_bwd_finalize's arithmetic). */
+  const double* coef_tot;
+  const float* bn_gamma;
+  const float* bn_mean;
+  const float* bn_invstd;
+  double bn_count;
 } dfl_wgrad_args;
 
 int dfl_conv2d_wgrad(const dfl_wgrad_args* a, dfl_stream_t stream);
@@ -257,6 +270,16 @@ typedef struct {
   int32_t reserved;
 } dfl_bn_live_job;
 int dfl_bn_finalize_live(const dfl_bn_live_job* jobs_dev, int32_t njobs, int32_t max_C, dfl_stream_t stream);
+/* Backward counterpart: what dfl_bn_bwd_finalize writes besides the coefficients (which the consumers derive themselves) --
+ * dgamma = invstd * (sum dy*r - mean * sum dy), dbeta = sum dy, and optionally `sum_out` = sum dy (the bias gradient of the
+ * residual 1x1 convolution that shares the block's output gradient) -- for a batch of layers in one launch. */
+typedef struct {
+  const double* totals;
+  const float* save_mean; const float* save_invstd;
+  float* dgamma; float* dbeta; float* sum_out;     /* sum_out may be NULL */
+  int32_t C, reserved;
+} dfl_bn_bwd_live_job;
+int dfl_bn_bwd_finalize_live(const dfl_bn_bwd_live_job* jobs_dev, int32_t njobs, int32_t max_C, dfl_stream_t stream);
 int dfl_bn_eval_prepare(const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float* scale, float* shift, int32_t C, float eps,
                         dfl_stream_t stream);
@@ -559,7 +582,7 @@ typedef enum {
   DFL_OP_REDUCE_PARTIALS = 10, DFL_OP_AFFINE_COPY = 11, DFL_OP_POOL_FWD = 12, DFL_OP_POOL_BWD = 13,
   DFL_OP_HEAD_FWD = 14, DFL_OP_HEAD_BWD = 15, DFL_OP_MEMSET = 16, DFL_OP_REDUCE_BATCH = 17,
   DFL_OP_RECORD = 18, DFL_OP_WAIT = 19, DFL_OP_UPSAMPLE_FWD = 20, DFL_OP_UPSAMPLE_BWD = 21,
-  DFL_OP_BN_FINALIZE_LIVE = 22
+  DFL_OP_BN_FINALIZE_LIVE = 22, DFL_OP_BN_BWD_FINALIZE_LIVE = 23
 } dfl_op_kind;
 
 typedef struct { const float* src; float* dst; int64_t n; int32_t splits; int32_t T; } dfl_sum_partials_args;
@@ -570,6 +593,7 @@ typedef struct { const float* partials; float* out; int32_t nblocks, stride, C, 
 typedef struct { void* ptr; int64_t bytes; } dfl_memset_args; /* zero fill */
 typedef struct { const dfl_reduce_job* jobs_dev; int32_t njobs, total_blocks; } dfl_reduce_batch_args;
 typedef struct { const dfl_bn_live_job* jobs_dev; int32_t njobs, max_C; } dfl_bn_live_args;
+typedef struct { const dfl_bn_bwd_live_job* jobs_dev; int32_t njobs, max_C; } dfl_bn_bwd_live_args;
 
 /* DFL_OP_RECORD: record library event `event` on the op's stream; DFL_OP_WAIT: make the op's stream wait for it.
  * Events are library-owned, identified by small integers the program chooses (0..65535). */

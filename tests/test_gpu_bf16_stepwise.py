@@ -54,6 +54,8 @@ def teacher_of(plan, outs, douts):
         if kind == 'bn':
             return [t.detach().double().cpu() for t in plan.dbg[name]]
         if kind == 'coef':
+            if name not in plan.dbg:              # live statistics: the consumers derive the coefficients themselves (nothing is stored)
+                return None
             c = plan.dbg[name].detach().double().cpu()
             return list(c.view(3, -1))
         if kind == 'up':
