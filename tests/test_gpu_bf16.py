@@ -786,3 +786,109 @@ def test_small_channel_counts_are_refused():
     net = dfl_amd.UNet(n_classes=3, depth=2, wf=3, padding=True, batch_norm=True).to(DEV)
     with pytest.raises(RuntimeError, match='multiples of 16'):
         net(torch.zeros(1, 1, 16, 16, device=DEV))
+
+
+def _jobs_dev(arr):
+    return torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(DEV)
+
+
+@pytest.mark.parametrize('C_,rows', [(32, 1536), (256, 36), (1024, 8)])
+def test_live_batchnorm_batched_finalize_equals_the_per_layer_kernels(C_, rows):
+    """dfl_bn_finalize_live / dfl_bn_bwd_finalize_live (one launch for a batch of layers, statistics as [DFL_BN_R][2][C] fp64 totals)
+    against dfl_bn_finalize / dfl_bn_bwd_finalize on the partial rows the totals were added up from: bit for bit (the fp64 sum of
+    fp32 addends of similar size is exact, so its order does not matter)."""
+    lib = nat.lib()
+    g = torch.Generator().manual_seed(C_ + rows)
+    R_ = 8
+    count = rows * 384
+    part = torch.rand(rows, 2, C_, generator=g) * 300.0 + 50.0                 # sums of 384 non-negative values, and of their squares
+    part[:, 1] *= 2.0
+    gamma, beta = torch.rand(C_, generator=g) + 0.5, torch.randn(C_, generator=g)
+    rm, rv = torch.randn(C_, generator=g), torch.rand(C_, generator=g) + 0.5
+    tot = torch.zeros(R_, 2, C_, dtype=torch.float64)
+    for r_ in range(rows):
+        tot[r_ % R_] += part[r_].double()
+    dev = lambda t: t.clone().to(DEV)
+    outs = {}
+    for which in ('old', 'live'):
+        d = dict(gamma=dev(gamma), beta=dev(beta), rm=dev(rm), rv=dev(rv), nbt=torch.tensor(3, dtype=torch.int64, device=DEV),
+                 scale=torch.empty(C_, device=DEV), shift=torch.empty(C_, device=DEV), mean=torch.empty(C_, device=DEV),
+                 invstd=torch.empty(C_, device=DEV))
+        if which == 'old':
+            pd = dev(part)
+            nat.call('dfl_bn_finalize', nat.BnFinalizeArgs(
+                partials=pd.data_ptr(), gamma=d['gamma'].data_ptr(), beta=d['beta'].data_ptr(), running_mean=d['rm'].data_ptr(),
+                running_var=d['rv'].data_ptr(), num_batches_tracked=d['nbt'].data_ptr(), scale=d['scale'].data_ptr(), shift=d['shift'].data_ptr(),
+                save_mean=d['mean'].data_ptr(), save_invstd=d['invstd'].data_ptr(), count=count, nblocks=rows, C=C_, eps=1e-5, momentum=0.1), stream())
+        else:
+            td = dev(tot)
+            job = (nat.BnLiveJob * 1)()
+            job[0].totals, job[0].gamma, job[0].beta = td.data_ptr(), d['gamma'].data_ptr(), d['beta'].data_ptr()
+            job[0].running_mean, job[0].running_var, job[0].num_batches_tracked = d['rm'].data_ptr(), d['rv'].data_ptr(), d['nbt'].data_ptr()
+            job[0].scale, job[0].shift, job[0].save_mean, job[0].save_invstd = (d[k].data_ptr() for k in ('scale', 'shift', 'mean', 'invstd'))
+            job[0].count, job[0].C, job[0].eps, job[0].momentum = count, C_, 1e-5, 0.1
+            jd = _jobs_dev(job)
+            nat.check(lib.dfl_bn_finalize_live(jd.data_ptr(), 1, C_, stream()), 'dfl_bn_finalize_live')
+        torch.cuda.synchronize()
+        outs[which] = {k: d[k].cpu() for k in ('scale', 'shift', 'mean', 'invstd', 'rm', 'rv', 'nbt')}
+    for k in outs['old']:
+        assert torch.equal(outs['old'][k], outs['live'][k]), k
+    # backward: (sum dy, sum dy*r) partials of mixed sign
+    part2 = torch.randn(rows, 2, C_, generator=g) * 3.0
+    tot2 = torch.zeros(R_, 2, C_, dtype=torch.float64)
+    for r_ in range(rows):
+        tot2[r_ % R_] += part2[r_].double()
+    mean, invstd = dev(outs['old']['mean']), dev(outs['old']['invstd'])
+    gd = dev(gamma)
+    dgo, dbo, coef = torch.empty(C_, device=DEV), torch.empty(C_, device=DEV), torch.empty(3, C_, device=DEV)
+    p2 = dev(part2)
+    nat.call('dfl_bn_bwd_finalize', nat.BnBwdFinalizeArgs(partials=p2.data_ptr(), gamma=gd.data_ptr(), save_mean=mean.data_ptr(),
+                                                          save_invstd=invstd.data_ptr(), dgamma=dgo.data_ptr(), dbeta=dbo.data_ptr(),
+                                                          coef=coef.data_ptr(), count=count, nblocks=rows, C=C_), stream())
+    dgl, dbl, sm = torch.empty(C_, device=DEV), torch.empty(C_, device=DEV), torch.empty(C_, device=DEV)
+    t2 = dev(tot2)
+    job = (nat.BnBwdLiveJob * 1)()
+    job[0].totals, job[0].save_mean, job[0].save_invstd = t2.data_ptr(), mean.data_ptr(), invstd.data_ptr()
+    job[0].dgamma, job[0].dbeta, job[0].sum_out, job[0].C = dgl.data_ptr(), dbl.data_ptr(), sm.data_ptr(), C_
+    jd = _jobs_dev(job)
+    nat.check(lib.dfl_bn_bwd_finalize_live(jd.data_ptr(), 1, C_, stream()), 'dfl_bn_bwd_finalize_live')
+    torch.cuda.synchronize()
+    # (signed partials: the fp64 sums agree to the last bit unless a partial is tiny against the total -- allow one fp32 ulp)
+    np.testing.assert_allclose(dgl.cpu().numpy(), dgo.cpu().numpy(), rtol=2e-7, atol=1e-6)
+    np.testing.assert_allclose(dbl.cpu().numpy(), dbo.cpu().numpy(), rtol=2e-7, atol=1e-6)
+    assert torch.equal(dbl, sm)
+
+
+@pytest.mark.parametrize('key', ['paper__paper_sc_l14__b2', 'ragged__37x41__mp1'])
+def test_live_batchnorm_statistics_change_nothing(key):
+    """A training step with the BatchNorm statistics completed by their consumers (dfl_conv_args.stat_totals / in_tot / add_tot,
+    dfl_wgrad_args.coef_tot: the default) against the same step with a dfl_bn_finalize / dfl_bn_bwd_finalize launch per layer
+    (UNetPlan.LIVE_BN = False): outputs, loss, running statistics and EVERY gradient -- equal to fp32 rounding of a sum's last
+    bit (bit-identical whenever the fp64 totals are exact, which the test reports)."""
+    from dfl_amd import plan as P_
+    pr = PR.REGISTRY[key]()
+    res = {}
+    for live in (True, False):
+        prev = P_.UNetPlan.LIVE_BN
+        P_.UNetPlan.LIVE_BN = live
+        try:
+            net = hip_net(pr)
+            out, seg, loss = hip_step(pr, net)
+            plan = NF.train_plan(net)
+            nfin = sum(1 for st in plan.fwd.structs + plan.bwd.structs if isinstance(st, (nat.BnFinalizeArgs, nat.BnBwdFinalizeArgs)))
+        finally:
+            P_.UNetPlan.LIVE_BN = prev
+        res[live] = dict(seg=seg.detach().clone(), loss=loss.item(), nfin=nfin,
+                         grads={k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None},
+                         bufs={k: v.clone() for k, v in net.named_buffers()})
+    a, b = res[True], res[False]
+    assert a['nfin'] <= 4 or a['nfin'] * 3 <= b['nfin'], (a['nfin'], b['nfin'])     # (max-pool boundaries keep a statistics pass)
+    exact = torch.equal(a['seg'], b['seg']) and all(torch.equal(a['grads'][k], b['grads'][k]) for k in a['grads'])
+    print('%s: %d -> %d finalize launches per step; bit-identical: %s' % (key, b['nfin'], a['nfin'], exact))
+    np.testing.assert_allclose(a['seg'].cpu().numpy(), b['seg'].cpu().numpy(), rtol=1e-5, atol=1e-6)
+    assert abs(a['loss'] - b['loss']) <= 1e-6 * abs(b['loss'])
+    for k, v in b['bufs'].items():
+        np.testing.assert_allclose(a['bufs'][k].cpu().numpy(), v.cpu().numpy(), rtol=1e-6, atol=1e-7, err_msg=k)
+    for k, v in b['grads'].items():
+        sc = float(v.abs().max())
+        np.testing.assert_allclose(a['grads'][k].cpu().numpy(), v.cpu().numpy(), rtol=1e-4, atol=1e-5 * sc + 1e-9, err_msg=k)
