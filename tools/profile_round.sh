@@ -23,10 +23,26 @@ for c in 3 4; do
   mkdir -p "$out/cfg$c"
   DFL_MATH=${DFL_MATH_OTHER:-bf16s} rocprofv3 --kernel-trace --stats -d "$out/cfg$c/trace" -o t --output-format csv -- python $root/tools/bench_other.py $c > "$out/cfg$c/bench_other.json" 2> "$out/cfg$c/trace.err"
 done
+# 5. the parity-holding arithmetics (fp32 MFMA = the 1e-4 gate, bf16x3): kernel trace + stats of the same workload
+for m in fp32 bf16x3; do
+  mkdir -p "$out/$m"
+  rocprofv3 --kernel-trace --stats -d "$out/$m/trace" -o t --output-format csv -- $bench --math $m > "$out/$m/bench_under_rocprof.json" 2> "$out/$m/trace.err"
+done
 cd "$root"
 python tools/summarize_profile.py "$out" "$tag"
+for m in fp32 bf16x3; do
+  python tools/summarize_profile.py "$out/$m" "${tag}_$m"
+  cp "$out/$m/${tag}_${m}_kernel_stats.csv" "$out/"
+  cp "$out/$m/bench_under_rocprof.json" "$out/${tag}_${m}_bench_under_rocprof.json"
+done
 for c in 3 4; do
   python tools/summarize_profile.py "$out/cfg$c" "${tag}_cfg$c"
   cp "$out/cfg$c/bench_other.json" "$out/${tag}_cfg${c}_bench.json"
   cp "$out/cfg$c/${tag}_cfg${c}_kernel_stats.csv" "$out/"
 done
+# gpurun copies at most 64 MiB back: keep the summaries and the raw --stats tables, drop the per-dispatch traces and counter dumps
+cp "$(find "$out/trace" -name '*kernel_stats.csv' | head -1)" "$out/${tag}_rocprofv3_kernel_stats_raw.csv" 2>/dev/null || true
+find "$out" -name '*kernel_trace.csv' -delete 2>/dev/null || true
+find "$out" -name '*counter_collection.csv' -delete 2>/dev/null || true
+find "$out" -name '*.db' -delete 2>/dev/null || true
+du -sh "$out" || true
