@@ -39,7 +39,7 @@ class WgradArgs(C.Structure):
 
 class PackJob(C.Structure):
     _fields_ = [('src', fp), ('dst', fp), ('A', i32), ('B', i32), ('C', i32), ('kind', i32), ('flip', i32),
-                ('split', i32)]
+                ('split', i32), ('dst2', fp), ('kind2', i32), ('flip2', i32), ('first_tile', i32), ('reserved', i32)]
 
 
 class BnLiveJob(C.Structure):
@@ -134,7 +134,7 @@ class SumPartialsArgs(C.Structure):
 
 
 class PackArgs(C.Structure):
-    _fields_ = [('jobs_dev', fp), ('max_elems', i64), ('njobs', i32), ('reserved', i32)]
+    _fields_ = [('jobs_dev', fp), ('max_elems', i64), ('njobs', i32), ('tiled', i32)]
 
 
 class BnEvalArgs(C.Structure):
@@ -208,7 +208,7 @@ EXPORTS = ['dfl_version', 'dfl_last_error', 'dfl_sizeof', 'dfl_conv2d', 'dfl_con
            'dfl_set_math_mode', 'dfl_graph_capture', 'dfl_graph_launch', 'dfl_graph_nodes', 'dfl_graph_destroy',
            'dfl_set_conv_rows_min_tiles', 'dfl_conv_candidates', 'dfl_conv_force_geometry', 'dfl_conv_tune_add',
            'dfl_head_wgrad_blocks', 'dfl_head_scratch_ld_for', 'dfl_head_scratch_off_for', 'dfl_upsample2x_fwd',
-           'dfl_upsample2x_bwd', 'dfl_bn_finalize_live', 'dfl_bn_bwd_finalize_live']
+           'dfl_upsample2x_bwd', 'dfl_bn_finalize_live', 'dfl_bn_bwd_finalize_live', 'dfl_pack_weights_tiled']
 
 
 class DflError(RuntimeError):
@@ -236,6 +236,7 @@ def lib():
     L.dfl_rowblock_count.argtypes = [i64, i32]
     L.dfl_sum_partials.argtypes = [fp, fp, i64, i32, i32, fp]
     L.dfl_pack_weights.argtypes = [fp, i32, i64, fp]
+    L.dfl_pack_weights_tiled.argtypes = [fp, i32, i32, fp]
     L.dfl_bn_eval_prepare.argtypes = [fp, fp, fp, fp, fp, fp, i32, f32, fp]
     L.dfl_reduce_partials.argtypes = [fp, fp, i32, i32, i32, fp]
     L.dfl_reduce_batch.argtypes = [fp, i32, i32, fp]

@@ -236,7 +236,8 @@ static int exec_one(const dfl_op* ops, int i, dfl_stream_t main_stream, bool ser
       }
       case DFL_OP_PACK: {
         const dfl_pack_args* a = static_cast<const dfl_pack_args*>(p);
-        rc = dfl_pack_weights(a->jobs_dev, a->njobs, a->max_elems, stream);
+        rc = a->tiled ? dfl_pack_weights_tiled(a->jobs_dev, a->njobs, (int32_t)a->max_elems, stream)
+                      : dfl_pack_weights(a->jobs_dev, a->njobs, a->max_elems, stream);
         break;
       }
       case DFL_OP_BN_FINALIZE: rc = dfl_bn_finalize(static_cast<const dfl_bn_finalize_args*>(p), stream); break;

@@ -890,6 +890,62 @@ __global__ void __launch_bounds__(256) pack_kernel(const dfl_pack_job* __restric
   }
 }
 
+// ---- tiled dual-layout pack (dfl_pack_weights_tiled; round 4) ------------------------------------------------------------
+// One workgroup per 32(A) x 32(B) x C tile of ALL jobs of the launch (flat list: no idle blocks for the small layers, which a
+// (1024, jobs) grid spends 9 of 10 blocks on), the tile read with 16-byte loads, and BOTH bf16 chunk layouts of the parameter --
+// the forward operand and the data-gradient operand -- written from the same LDS tile: the fp32 master is read once.
+__device__ __forceinline__ void pack_emit_cells(const float (*tile)[PK_T * PK_CMAX + 1], unsigned short* dst16, int kind, int flip,
+                                                int A, int B, int Cc, int a0, int b0) {
+  const int N = (kind == 1) ? A : (kind == 2 ? B : Cc * B);
+  for (int e = threadIdx.x; e < 64 * Cc; e += 256) {           // cells of this tile: 32 columns x 2 blocks of 16 k x C taps
+    const int x = e & 31, blk = (e >> 5) & 1, cp = e >> 6;
+    float f[16];
+    int64_t cell;
+    if (kind == 1) {                // k = c*B + b (16 consecutive b), n = a
+#pragma unroll
+      for (int r = 0; r < 16; ++r) f[r] = tile[x][(16 * blk + r) * Cc + cp];
+      cell = (int64_t)((cp * B + b0) / 16 + blk) * N + a0 + x;
+    } else if (kind == 2) {         // k = c'*A + a (16 consecutive a), n = b
+      const int c = flip ? (Cc - 1 - cp) : cp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) f[r] = tile[16 * blk + r][x * Cc + c];
+      cell = (int64_t)((cp * A + a0) / 16 + blk) * N + b0 + x;
+    } else {                        // k = a (16 consecutive a), n = c*B + b
+#pragma unroll
+      for (int r = 0; r < 16; ++r) f[r] = tile[16 * blk + r][x * Cc + cp];
+      cell = (int64_t)(a0 / 16 + blk) * N + cp * B + b0 + x;
+    }
+    bu32x4* d = reinterpret_cast<bu32x4*>(dst16 + cell * 16);
+    d[0] = pack8(f);
+    d[1] = pack8(f + 8);
+  }
+}
+
+__global__ void __launch_bounds__(256) pack_tiles_kernel(const dfl_pack_job* __restrict__ jobs, int njobs) {
+  __shared__ float tile[PK_T][PK_T * PK_CMAX + 1];
+  // which job: the last one whose first_tile <= blockIdx.x (binary search; the few records stay in the scalar cache)
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].first_tile <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const dfl_pack_job j = jobs[lo];
+  const int A = j.A, B = j.B, Cc = j.C;
+  const int tb = B / PK_T;
+  const int tidx = (int)blockIdx.x - j.first_tile;
+  const int a0 = (tidx / tb) * PK_T, b0 = (tidx % tb) * PK_T;
+  const int run4 = 8 * Cc;                                     // float4 per tile row (32 * C floats)
+  for (int e = threadIdx.x; e < PK_T * run4; e += 256) {
+    const int ar = e / run4, q4 = e - ar * run4;
+    const float4 v = *reinterpret_cast<const float4*>(j.src + ((int64_t)(a0 + ar) * B + b0) * Cc + 4 * q4);
+    float* t = &tile[ar][4 * q4];
+    t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+  }
+  __syncthreads();
+  pack_emit_cells(tile, reinterpret_cast<unsigned short*>(j.dst), j.kind, j.flip, A, B, Cc, a0, b0);
+  if (j.dst2 != nullptr) pack_emit_cells(tile, reinterpret_cast<unsigned short*>(j.dst2), j.kind2, j.flip2, A, B, Cc, a0, b0);
+}
+
 // ------------------------------------------------------------------------------------------------ SGD
 __global__ void __launch_bounds__(256) sgd_kernel(float* __restrict__ p, const float* __restrict__ grad,
                                                  float* __restrict__ buf, int64_t n, float lr, float mom, float wd,
@@ -1116,6 +1172,12 @@ extern "C" int dfl_pack_weights(const dfl_pack_job* jobs_dev, int32_t njobs, int
   if (bx < 1) bx = 1;
   hipLaunchKernelGGL(pack_kernel, dim3((unsigned)bx, (unsigned)njobs), dim3(256), 0, static_cast<hipStream_t>(stream), jobs_dev);
   return check_launch("dfl_pack_weights");
+}
+
+extern "C" int dfl_pack_weights_tiled(const dfl_pack_job* jobs_dev, int32_t njobs, int32_t total_tiles, dfl_stream_t stream) {
+  DFL_REQUIRE(jobs_dev && njobs > 0 && total_tiles > 0, "dfl_pack_weights_tiled: bad args");
+  hipLaunchKernelGGL(pack_tiles_kernel, dim3((unsigned)total_tiles), dim3(256), 0, static_cast<hipStream_t>(stream), jobs_dev, (int)njobs);
+  return check_launch("dfl_pack_weights_tiled");
 }
 
 extern "C" int dfl_sgd_step(float* p, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,

@@ -67,6 +67,7 @@ class UNetPlan:
         self._keep = []
         self.fwd = Program()
         self.bwd = Program() if need_grad else None
+        self._prep = Program()          # eval-mode BatchNorm scale / shift of an inference plan: part of its pack program
         self._pack_jobs = []
         self._pack_dsts = []
         self.busy = False
@@ -163,7 +164,11 @@ class UNetPlan:
     def _finish_pack(self):
         n = len(self._pack_jobs)
         self.pack = Program()
+        self.pack.extend(self._prep)
         if n == 0:
+            return
+        if not self.PACK_OVERLAP and self.bf16 and self.PACK_TILED:
+            self._finish_pack_tiled()
             return
         arr = (PackJob * n)()
         mx = 0
@@ -201,6 +206,49 @@ class UNetPlan:
         self.pack.record(self.EV_PACK_DONE, stream=1)
         self._bwd_needs_pack_wait = True
 
+    PACK_TILED = os.environ.get('DFL_PACK_TILED', '1') != '0'
+
+    def _finish_pack_tiled(self):
+        """One-stream pack (round 4): the bf16 chunk layouts of parameters that tile into 32 x 32 x C blocks go through
+        dfl_pack_weights_tiled -- a flat list of tiles over all jobs, BOTH layouts of a parameter (forward operand and data-gradient
+        operand) from one read of the fp32 master --, everything else (the first layer, heads, odd sizes) through dfl_pack_weights."""
+        tiled, rest, by_src = [], [], {}
+        for job in self._pack_jobs:
+            src, dst, A, B, Cc, kind, flip, split = job
+            if split == 2 and A % 32 == 0 and B % 32 == 0 and Cc <= 9:
+                k = src.data_ptr()
+                if k in by_src and len(by_src[k]) == 1:
+                    by_src[k].append(job)
+                else:
+                    by_src[k] = [job]
+                    tiled.append(by_src[k])
+            else:
+                rest.append(job)
+        def to_dev(arr):
+            t = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(self.dev)
+            self._keep.append(t)
+            return t
+        if tiled:
+            arr = (PackJob * len(tiled))()
+            tiles = 0
+            for i, group in enumerate(tiled):
+                src, dst, A, B, Cc, kind, flip, split = group[0]
+                a = arr[i]
+                a.src, a.dst, a.A, a.B, a.C, a.kind, a.flip, a.split = src.data_ptr(), dst.data_ptr(), A, B, Cc, kind, flip, 2
+                if len(group) > 1:
+                    a.dst2, a.kind2, a.flip2 = group[1][1].data_ptr(), group[1][5], group[1][6]
+                a.first_tile = tiles
+                tiles += (A // 32) * (B // 32)
+            self.pack.add(PackArgs(jobs_dev=to_dev(arr).data_ptr(), max_elems=tiles, njobs=len(tiled), tiled=1))
+        if rest:
+            arr = (PackJob * len(rest))()
+            mx = 0
+            for i, (src, dst, A, B, Cc, kind, flip, split) in enumerate(rest):
+                arr[i].src, arr[i].dst = src.data_ptr(), dst.data_ptr()
+                arr[i].A, arr[i].B, arr[i].C, arr[i].kind, arr[i].flip, arr[i].split = A, B, Cc, kind, flip, split
+                mx = max(mx, A * B * Cc)
+            self.pack.add(PackArgs(jobs_dev=to_dev(arr).data_ptr(), max_elems=mx, njobs=len(rest)))
+
     DEEP_PACK_ELEMS = int(os.environ.get('DFL_PACK_DEEP_ELEMS', str(256 * 1024)))   # forward layouts from this size on are packed on the side stream (0: none)
 
     def _order_pack_jobs(self):
@@ -225,7 +273,7 @@ class UNetPlan:
                 self.fwd.insert(idx, nat.SyncArgs(event=self.EV_PACK_DEEP), nat.OP_WAIT, 0)
                 break
 
-    PACK_OVERLAP = os.environ.get('DFL_PACK_OVERLAP', '1') != '0'
+    PACK_OVERLAP = os.environ.get('DFL_PACK_OVERLAP', '0') != '0'     # (round 4: off -- with the BatchNorm launches gone the one-stream form is 1.2 % faster)
     WSPLIT = os.environ.get('DFL_WSPLIT', '1') != '0'      # split-bf16 modes: weights split once by the pack kernel
     DSPLIT = os.environ.get('DFL_DSPLIT', '1') != '0'      # ... and the BatchNorm/ReLU backward output split once by its producer
     EV_PACK_FORK, EV_PACK_DONE, EV_PACK_DEEP = 60000, 60001, 60002
@@ -653,10 +701,15 @@ class UNetPlan:
                                             count=N * Ho * Wo, nblocks=part[1], C=Cout, eps=BN_EPS, momentum=BN_MOMENTUM)
                         fwd.add(fa)
                     else:
-                        fwd.add(BnEvalArgs(gamma=gamma.data_ptr(), beta=beta.data_ptr(),
-                                           running_mean=self.Bf[bname + '.running_mean'].data_ptr(),
-                                           running_var=self.Bf[bname + '.running_var'].data_ptr(),
-                                           scale=scale.data_ptr(), shift=shift.data_ptr(), C=Cout, eps=BN_EPS))
+                        # eval mode: scale / shift depend on parameters and running statistics only -- constants between two
+                        # forwards of an inference loop (util.test_dataset, seg_dataset_ensemble: one image after the other).
+                        # Inference plans compute them in the PACK program (re-run when a parameter, a buffer or a training
+                        # forward has touched them, UNet._ensure_packed) instead of 22 launches in every forward (round 4).
+                        (fwd if self.need_grad else self._prep).add(
+                            BnEvalArgs(gamma=gamma.data_ptr(), beta=beta.data_ptr(),
+                                       running_mean=self.Bf[bname + '.running_mean'].data_ptr(),
+                                       running_var=self.Bf[bname + '.running_var'].data_ptr(),
+                                       scale=scale.data_ptr(), shift=shift.data_ptr(), C=Cout, eps=BN_EPS))
                         if self.need_grad:
                             # gradients through eval-mode BatchNorm (nn.Module semantics of unet.py:161-193): the statistics
                             # are the running ones -- mean is the buffer itself, 1/sqrt(var + eps) is the scale of (gamma = 1)

@@ -224,10 +224,19 @@ typedef struct {
   int32_t split;         /* 1: write split quads (4 hi bf16 | 4 lo bf16) instead of 4 floats (dfl_conv_args.w_split);
                             2: bf16 chunk layout w[(k/16)*Ntot*16 + n*16 + k%16] (K rounded up to 16 with zeros): one MFMA B
                             fragment of 32 columns is 1 KiB contiguous; dst holds ceil(K/16)*Ntot*16 bf16 */
+  /* dfl_pack_weights_tiled only (round 4): a SECOND layout of the same parameter written from the same read of it (the
+   * forward operand and the data-gradient operand of a layer: the fp32 master is read once instead of twice), and the job's
+   * first tile in the launch's flat tile list (tiles of 32 x 32 x C; a job has (A/32)*(B/32) of them). */
+  float* dst2;           /* NULL: one layout */
+  int32_t kind2, flip2;
+  int32_t first_tile, reserved;
 } dfl_pack_job;
 
 /* jobs: DEVICE pointer to njobs dfl_pack_job records; max_elems = max over jobs of A*B*C. */
 int dfl_pack_weights(const dfl_pack_job* jobs_dev, int32_t njobs, int64_t max_elems, dfl_stream_t stream);
+/* The bf16 chunk layouts (split = 2) of parameters with A % 32 == 0, B % 32 == 0, C <= 9: one workgroup per 32 x 32 x C tile of
+ * all jobs (first_tile: ascending prefix sums, total_tiles their sum), 16-byte loads, both layouts of a job from one LDS tile. */
+int dfl_pack_weights_tiled(const dfl_pack_job* jobs_dev, int32_t njobs, int32_t total_tiles, dfl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * BatchNorm2d (unet.py:215,222; torch defaults eps 1e-5, momentum 0.1).
@@ -586,7 +595,7 @@ typedef enum {
 } dfl_op_kind;
 
 typedef struct { const float* src; float* dst; int64_t n; int32_t splits; int32_t T; } dfl_sum_partials_args;
-typedef struct { const dfl_pack_job* jobs_dev; int64_t max_elems; int32_t njobs; int32_t reserved; } dfl_pack_args;
+typedef struct { const dfl_pack_job* jobs_dev; int64_t max_elems; int32_t njobs; int32_t tiled; } dfl_pack_args;   /* tiled: max_elems = total tiles, dfl_pack_weights_tiled */
 typedef struct { const float* gamma; const float* beta; const float* running_mean; const float* running_var;
                  float* scale; float* shift; int32_t C; float eps; } dfl_bn_eval_args;
 typedef struct { const float* partials; float* out; int32_t nblocks, stride, C, reserved; } dfl_reduce_partials_args;
