@@ -247,6 +247,18 @@ __global__ void __launch_bounds__(256) direct_conv3_rows_kernel(const dfl_conv_a
     s2[j] = 0.f;
   }
   const float* img = a.x + (int64_t)n * a.Hin * a.Win * a.ldx;
+  // the band's input rows (its output rows + the window's halo, zero outside the image) go to LDS once, coalesced: the per-pixel
+  // gathers below then never wait for global memory (round 4: nine dependent 4-byte loads per pixel had made this 0.3 GFLOP kernel
+  // 39 us long)
+  extern __shared__ float img_rows[];                 // [ROWS_CONV_RB + 2][Wout + 2]
+  const int RW = a.Wout + 2;
+  for (int idx = threadIdx.x; idx < (ROWS_CONV_RB + 2) * RW; idx += 256) {
+    const int r = idx / RW, c = idx - r * RW;
+    const int iy = y0 - a.pad + r, ix = c - a.pad;
+    const bool ok = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+    img_rows[idx] = ok ? img[(int64_t)(iy * a.Win + ix) * a.ldx] : 0.f;
+  }
+  __syncthreads();
 #pragma unroll
   for (int ry = 0; ry < ROWS_CONV_RB; ++ry) {
     const int y = y0 + ry;
@@ -256,11 +268,7 @@ __global__ void __launch_bounds__(256) direct_conv3_rows_kernel(const dfl_conv_a
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const int iy = y - a.pad + dy, ix = x - a.pad + dx;
-          const bool ok = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
-          xv[dy * 3 + dx] = ok ? img[(int64_t)(iy * a.Win + ix) * a.ldx] : 0.f;
-        }
+        for (int dx = 0; dx < 3; ++dx) xv[dy * 3 + dx] = img_rows[(ry + dy) * RW + x + dx];
       float acc[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] = bias[j];
@@ -281,6 +289,7 @@ __global__ void __launch_bounds__(256) direct_conv3_rows_kernel(const dfl_conv_a
     }
   }
   if (a.stat_partials == nullptr) return;
+  __syncthreads();
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     red[0][threadIdx.x][j] = s1[j];
@@ -317,6 +326,15 @@ __global__ void __launch_bounds__(256) direct_wgrad3_rows_kernel(const dfl_wgrad
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
   const float* img = a.g + (int64_t)n * a.Hin * a.Win * a.ldg;
+  extern __shared__ float img_rows[];                 // [ROWS_WGRAD_RB + 2][Wout + 2]: the band's input rows with halo (as the forward kernel)
+  const int RW = a.Wout + 2;
+  for (int idx = threadIdx.x; idx < (ROWS_WGRAD_RB + 2) * RW; idx += 256) {
+    const int r = idx / RW, c = idx - r * RW;
+    const int iy = y0 - a.pad + r, ix = c - a.pad;
+    const bool ok = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+    img_rows[idx] = ok ? img[(int64_t)(iy * a.Win + ix) * a.ldg] : 0.f;
+  }
+  __syncthreads();
   float cA[DB ? 8 : 1], cB[DB ? 8 : 1], cC[DB ? 8 : 1], bsum[DB ? 8 : 1];
   if constexpr (DB) {
 #pragma unroll
@@ -347,11 +365,7 @@ __global__ void __launch_bounds__(256) direct_wgrad3_rows_kernel(const dfl_wgrad
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const int iy = y - a.pad + dy, ix = x - a.pad + dx;
-          const bool ok = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
-          xv[dy * 3 + dx] = ok ? img[(int64_t)(iy * a.Win + ix) * a.ldg] : 0.f;
-        }
+        for (int dx = 0; dx < 3; ++dx) xv[dy * 3 + dx] = img_rows[(ry + dy) * RW + x + dx];
 #pragma unroll
       for (int k = 0; k < 9; ++k)
 #pragma unroll
@@ -436,8 +450,9 @@ int direct_conv_launch(const dfl_conv_args* a, hipStream_t s) {
   const int64_t M = (int64_t)a->N * a->Hout * a->Wout;
   const int blocks = direct_conv_blocks(a);
   if (direct_conv_rows_ok(a)) {
-    if (a->y_bf16) hipLaunchKernelGGL(direct_conv3_rows_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, *a);
-    else hipLaunchKernelGGL(direct_conv3_rows_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, *a);
+    const size_t lds = (size_t)(ROWS_CONV_RB + 2) * (a->Wout + 2) * sizeof(float);
+    if (a->y_bf16) hipLaunchKernelGGL(direct_conv3_rows_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, s, *a);
+    else hipLaunchKernelGGL(direct_conv3_rows_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, s, *a);
     return check_launch("dfl_conv2d");
   }
   const int rpb = (int)ceil_div(M, blocks);
@@ -548,14 +563,15 @@ int direct_wgrad_splits(const dfl_wgrad_args* a) {
 
 int direct_wgrad_launch(const dfl_wgrad_args* a, hipStream_t s) {
   if (direct_wgrad_rows_ok(a) && a->splits == direct_wgrad_splits(a)) {     // (the row form's slots are its workgroups)
+    const size_t rows_lds = (size_t)(ROWS_WGRAD_RB + 2) * (a->Wout + 2) * sizeof(float);
     if (a->d_mode != 0) {
       DFL_REQUIRE(a->d_mode == 1 && a->d_bf16 && a->d2 != nullptr && a->ldd2 % 8 == 0 && aligned16(a->d2),
                   "dfl_conv2d_wgrad (1-channel 3x3): d_mode 1 needs bf16 d / d2 (16-byte aligned, ldd2 %% 8 == 0)");
-      hipLaunchKernelGGL((direct_wgrad3_rows_kernel<true, true>), dim3((unsigned)a->splits), dim3(256), 0, s, *a);
+      hipLaunchKernelGGL((direct_wgrad3_rows_kernel<true, true>), dim3((unsigned)a->splits), dim3(256), rows_lds, s, *a);
     } else if (a->d_bf16) {
-      hipLaunchKernelGGL(direct_wgrad3_rows_kernel<true>, dim3((unsigned)a->splits), dim3(256), 0, s, *a);
+      hipLaunchKernelGGL(direct_wgrad3_rows_kernel<true>, dim3((unsigned)a->splits), dim3(256), rows_lds, s, *a);
     } else {
-      hipLaunchKernelGGL(direct_wgrad3_rows_kernel<false>, dim3((unsigned)a->splits), dim3(256), 0, s, *a);
+      hipLaunchKernelGGL(direct_wgrad3_rows_kernel<false>, dim3((unsigned)a->splits), dim3(256), rows_lds, s, *a);
     }
     return check_launch("dfl_conv2d_wgrad");
   }
