@@ -107,7 +107,8 @@ class HeadBwdArgs(C.Structure):
                 ('dx', fp), ('scratch', fp),
                 ('N', i32), ('H', i32), ('W', i32), ('F', i32), ('ldx', i32), ('lddx', i32),
                 ('NC', i32), ('NM', i32), ('L', i32), ('softmax', i32), ('scratch_ld', i32), ('x_bf16', i32),
-                ('dw_seg', fp), ('dw_l1', fp), ('dw_l2', fp), ('wg_partial', fp)]
+                ('dw_seg', fp), ('dw_l1', fp), ('dw_l2', fp), ('wg_partial', fp),
+                ('stat_other', fp), ('stat_totals', fp), ('ldso', i32), ('reserved4', i32)]
 
 
 class LossArgs(C.Structure):

@@ -863,8 +863,16 @@ extern "C" int dfl_conv2d(const dfl_conv_args* a, dfl_stream_t stream) {
     return dfl::convp_launch(p, static_cast<hipStream_t>(stream));
   }
   DFL_REQUIRE(a == nullptr || a->x_mode == 0, "dfl_conv2d: x_mode (fused BatchNorm + ReLU backward operand) is implemented by the bf16 patch kernels only");
-  DFL_REQUIRE(a == nullptr || (a->stat_totals == nullptr && a->in_tot == nullptr && a->add_tot == nullptr),
-              "dfl_conv2d: live BatchNorm statistics (stat_totals / in_tot / add_tot) are implemented by the bf16 patch kernels only");
+  {
+    // live statistics outside the bf16 patch kernels: the 1-channel direct kernels only (3x3 row form: stat_totals; 1x1: add_tot)
+    const bool any = a != nullptr && (a->stat_totals != nullptr || a->in_tot != nullptr || a->add_tot != nullptr);
+    const bool direct_ok = any && dfl::direct_conv_ok(a) && a->in_tot == nullptr &&
+                           (a->stat_totals == nullptr || (dfl::direct_conv_rows_usable(a) && a->stat_other == nullptr)) &&
+                           (a->add_tot == nullptr || (a->add != nullptr && a->add_scale == nullptr && a->add_gamma && a->add_beta && a->add_count > 0 &&
+                                                      !dfl::direct_conv_rows_usable(a)));
+    DFL_REQUIRE(!any || direct_ok,
+                "dfl_conv2d: live BatchNorm statistics (stat_totals / in_tot / add_tot) are implemented by the bf16 patch kernels and the 1-channel direct kernels only");
+  }
   dfl::ConvK k;
   int rc = dfl::prepare(a, &k);
   if (rc != DFL_OK) return rc;

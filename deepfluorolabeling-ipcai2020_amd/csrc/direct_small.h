@@ -9,6 +9,7 @@ constexpr int DIRECT_MAX_K = 12;
 constexpr int CFG_DIRECT = 5;   // value dfl_conv_config / dfl_wgrad_config report for these kernels
 
 bool direct_conv_ok(const dfl_conv_args* a);
+bool direct_conv_rows_usable(const dfl_conv_args* a);   // the 1-channel 3x3 row form will run
 int direct_conv_blocks(const dfl_conv_args* a);   // workgroups = rows of stat_partials
 int direct_conv_launch(const dfl_conv_args* a, hipStream_t s);
 

@@ -94,6 +94,8 @@ __global__ void __launch_bounds__(256) direct_conv_kernel(const dfl_conv_args a,
     if (a.add_scale != nullptr) {
       asc[j] = a.add_scale[n0 + j];
       ash[j] = a.add_shift[n0 + j];
+    } else if (a.add != nullptr && a.add_tot != nullptr) {     // live statistics: derived here (include/dfl_hip.h)
+      bn_live_affine(a.add_tot, a.add_gamma, a.add_beta, a.add_count, a.bn_eps, a.Ntot, n0 + j, &asc[j], &ash[j]);
     }
   }
   float isc[CIN], ish[CIN];
@@ -288,7 +290,7 @@ __global__ void __launch_bounds__(256) direct_conv3_rows_kernel(const dfl_conv_a
       }
     }
   }
-  if (a.stat_partials == nullptr) return;
+  if (a.stat_partials == nullptr && a.stat_totals == nullptr) return;
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -301,7 +303,8 @@ __global__ void __launch_bounds__(256) direct_conv3_rows_kernel(const dfl_conv_a
     const int qq = c >> 3, j = c & 7;
     float t = 0.f;
     for (int p = 0; p < PL; ++p) t += red[which][p * cq + qq][j];
-    a.stat_partials[((int64_t)blockIdx.x * 2 + which) * a.Ntot + c] = t;
+    if (a.stat_totals != nullptr) bn_live_add(a.stat_totals, (int)blockIdx.x, which, a.Ntot, c, t);     // live statistics (include/dfl_hip.h)
+    else a.stat_partials[((int64_t)blockIdx.x * 2 + which) * a.Ntot + c] = t;
   }
 }
 
@@ -337,12 +340,28 @@ __global__ void __launch_bounds__(256) direct_wgrad3_rows_kernel(const dfl_wgrad
   __syncthreads();
   float cA[DB ? 8 : 1], cB[DB ? 8 : 1], cC[DB ? 8 : 1], bsum[DB ? 8 : 1];
   if constexpr (DB) {
+    if (a.coef_tot != nullptr) {            // live statistics: one channel per thread into LDS (red is free until the end)
+      float* ctab = &red[0][0];             // [3][Cm], Cm <= 64
+      if ((int)threadIdx.x < a.Cm)
+        bn_live_coef(a.coef_tot, a.bn_gamma, a.bn_mean, a.bn_invstd, a.bn_count, a.Cm, (int)threadIdx.x, ctab + threadIdx.x, ctab + 64 + threadIdx.x,
+                     ctab + 128 + threadIdx.x);
+      __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      cA[j] = a.coef != nullptr ? a.coef[8 * q + j] : 1.f;
-      cB[j] = a.coef != nullptr ? a.coef[a.Cm + 8 * q + j] : 0.f;
-      cC[j] = a.coef != nullptr ? a.coef[2 * a.Cm + 8 * q + j] : 0.f;
-      bsum[j] = 0.f;
+      for (int j = 0; j < 8; ++j) {
+        cA[j] = ctab[8 * q + j];
+        cB[j] = ctab[64 + 8 * q + j];
+        cC[j] = ctab[128 + 8 * q + j];
+        bsum[j] = 0.f;
+      }
+      __syncthreads();
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        cA[j] = a.coef != nullptr ? a.coef[8 * q + j] : 1.f;
+        cB[j] = a.coef != nullptr ? a.coef[a.Cm + 8 * q + j] : 0.f;
+        cC[j] = a.coef != nullptr ? a.coef[2 * a.Cm + 8 * q + j] : 0.f;
+        bsum[j] = 0.f;
+      }
     }
   }
 #pragma unroll
@@ -426,6 +445,8 @@ static bool direct_window(int KH, int KW, int C) {
   if (KH != KW) return false;
   return (KH == 3 && C == 1) || (KH == 2 && C >= 1 && C <= 3) || (KH == 1 && C >= 1 && C <= 4);
 }
+
+bool direct_conv_rows_usable(const dfl_conv_args* a) { return direct_conv_rows_ok(a); }
 
 bool direct_conv_ok(const dfl_conv_args* a) {
   if (!direct_window(a->KH, a->KW, a->Cin) || a->scatter2x2 || a->splits > 1) return false;
@@ -564,6 +585,8 @@ int direct_wgrad_splits(const dfl_wgrad_args* a) {
 int direct_wgrad_launch(const dfl_wgrad_args* a, hipStream_t s) {
   if (direct_wgrad_rows_ok(a) && a->splits == direct_wgrad_splits(a)) {     // (the row form's slots are its workgroups)
     const size_t rows_lds = (size_t)(ROWS_WGRAD_RB + 2) * (a->Wout + 2) * sizeof(float);
+    DFL_REQUIRE(a->coef_tot == nullptr || (a->d_mode == 1 && a->coef == nullptr && a->bn_gamma && a->bn_mean && a->bn_invstd && a->bn_count > 0),
+                "dfl_conv2d_wgrad (1-channel 3x3): coef_tot replaces coef (d_mode 1) and needs bn_gamma, bn_mean, bn_invstd, bn_count");
     if (a->d_mode != 0) {
       DFL_REQUIRE(a->d_mode == 1 && a->d_bf16 && a->d2 != nullptr && a->ldd2 % 8 == 0 && aligned16(a->d2),
                   "dfl_conv2d_wgrad (1-channel 3x3): d_mode 1 needs bf16 d / d2 (16-byte aligned, ldd2 %% 8 == 0)");

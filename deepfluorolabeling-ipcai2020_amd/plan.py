@@ -451,6 +451,7 @@ class UNetPlan:
         return self._scratch_act(key, N, H, W, Cc)
 
     LIVE_BN = os.environ.get('DFL_LIVE_BN', '1') != '0'     # BatchNorm statistics completed by their consumers (bf16 patch kernels)
+    LIVE_HEAD = os.environ.get('DFL_LIVE_HEAD', '1') != '0'   # ... and the head's backward kernel adds the sums of its dx itself (no colstats pass)
     BN_R = 8                                                # include/dfl_hip.h: DFL_BN_R
 
     def _bn_totals(self, Cc, bwd=False):
@@ -673,11 +674,15 @@ class UNetPlan:
                 # the producing patch kernel adds its sums to the layer's totals, the consuming patch kernel (next 3x3, or the
                 # residual 1x1 whose epilogue adds BN(r)) derives scale / shift itself; ONE batched launch at the end of the forward
                 # pass leaves the vectors the backward pass and the module state need.  Both kernels must be patch kernels.
-                live = (self.LIVE_BN and bn and self.training and self.bf16 and not circ and patch_in(gin)
-                        and (d < bd - 1 or (do_res and patch_in(xin))))
+                # (the network's first block: its 1-channel layers run the direct kernels, which take part as well -- the 3x3 row
+                # form as a producer, the 1x1 form as the consumer of "+ BN(r)", the 3x3 weight gradient as a consumer of A, B, C)
+                one_ch = lambda t: (not t.bf16) and t.C == 1 and Cout in (8, 16, 32, 64) and pad == 1
+                live = (self.LIVE_BN and bn and self.training and self.bf16 and not circ and (patch_in(gin) or one_ch(gin))
+                        and (d < bd - 1 or (do_res and (patch_in(xin) or one_ch(xin)))))
                 tot = self._bn_totals(Cout) if live else None
                 live_bwd = (self.LIVE_BN and bn and self.training and self.bf16 and self.FUSE_BRB and self.FUSE_BWD_STATS and not circ
-                            and patch_in(cur) and self.need_grad)        # this layer's backward can take live (sum dy, sum dy*r)
+                            and self.need_grad and (patch_in(cur) or (one_ch(cur) and d == 0 and first and not self.input_grad)))
+                # (this layer's backward can take live (sum dy, sum dy*r): its consumers derive the coefficients)
                 part = self._conv(fwd, gin, wp, r, 3, 3, 1, 0 if circ else pad, Cout, bias=b,
                                    in_aff=None if cur_live is not None else cur_aff, in_live=cur_live, relu=1,
                                    stats=bn and self.training, stat_totals=tot)
@@ -1057,8 +1062,10 @@ class UNetPlan:
         if self.PACK_OVERLAP:
             bwd.wait(self.EV_PACK_DONE, stream=0)      # data-gradient weight layouts are packed on the side stream
 
-        def head_backward(x_act, Fx, H_, W_, ws, w1, w2, nm, nl, gs, g1, g2):
-            """HeadBwdArgs + its weight gradients on x_act [N,H_,W_,Fx]; returns (args, dx Act)."""
+        def head_backward(x_act, Fx, H_, W_, ws, w1, w2, nm, nl, gs, g1, g2, live_r=None):
+            """HeadBwdArgs + its weight gradients on x_act [N,H_,W_,Fx]; returns (args, dx Act).  live_r: the saved ReLU output behind
+            the BatchNorm dx enters -- the matrix-core kernel then adds (sum dx, sum dx*r) to that layer's live totals itself
+            (self._head_live: ('live', totals) or None)."""
             sld = self.lib.dfl_head_scratch_ld_for(Fx, NC, nm, nl)
             M_ = N * H_ * W_
             dx = self._act(N, H_, W_, Fx)
@@ -1068,6 +1075,12 @@ class UNetPlan:
                              x_bf16=x_act.bf16)
             # bf16 features of the paper's width: the head kernel takes its three weight gradients itself (include/dfl_hip.h);
             # otherwise it leaves a per-pixel scratch row and three 1x1 weight-gradient launches follow
+            self._head_live = None
+            mfma_head = fused_head and nm <= 24 and (nl == 0 or w2 is not None) and x_act.ld % 8 == 0 and os.environ.get('DFL_HEAD_MFMA', '1') != '0'
+            if mfma_head and live_r is not None and Fx == 32:
+                tot = self._bn_totals(Fx, bwd=True)
+                hb.stat_other, hb.ldso, hb.stat_totals = live_r.ptr, live_r.ld, tot
+                self._head_live = ('live', tot)
             if fused_head:
                 part = self._new(4096 * nat.check(self.lib.dfl_head_wgrad_blocks(M_), 'dfl_head_wgrad_blocks'))
                 hb.wg_partial = part.data_ptr()
@@ -1098,7 +1111,11 @@ class UNetPlan:
             self.g_seg_full = self._new(NC * Fdec).view(NC, Fdec, 1, 1)
             self.head_bwd_seg, dfeat_a = head_backward(u, Fdec, u.H, u.W, self.P['seg_conv.weight'], None, None, 0, 0, self.g_seg_full, None, None)
             self.dseg_zero = self._new(N * NC * hl * wl).zero_()
-        self.head_bwd, dfeat = head_backward(head_x, Fh, hl, wl, w_seg, w_l1, w_l2, NM, L, g_seg, g_l1, g_l2)
+        last_bw = up_recs[-1]['block_bw'] if up_recs else pending[depth - 1]['block_bw']
+        head_live_r = (last_bw.last_r if (self.LIVE_BN and self.LIVE_HEAD and self.FUSE_COLSUMS and not self.lb_layers and not self.split_heads
+                                          and last_bw.last_live) else None)
+        self.head_bwd, dfeat = head_backward(head_x, Fh, hl, wl, w_seg, w_l1, w_l2, NM, L, g_seg, g_l1, g_l2, live_r=head_live_r)
+        head_sums = self._head_live
         self.dbg['dfeat'] = dfeat
 
         # up path, last block first
@@ -1134,7 +1151,7 @@ class UNetPlan:
                 if j > 0:
                     d = tgt
         F = Fdec
-        dout_sums = None
+        dout_sums = head_sums if not self.lb_layers else None
         for j in reversed(range(len(up_recs))):
             rec = up_recs[j]
             i = rec['level']

@@ -440,6 +440,13 @@ typedef struct {
    * dw_seg [NC][F], dw_l1 [NM][F+NC] and dw_l2 [L][NM] (NULL where the head has no such layer).  `scratch` is then
    * neither read nor written and may be NULL. */
   float* dw_seg; float* dw_l1; float* dw_l2; float* wg_partial;
+  /* Live statistics (matrix-core kernels only; round 4): dx is the gradient entering the BatchNorm of the decoder's last
+   * convolution.  With stat_totals the kernel adds (sum dx, sum dx * r) of the values it stores -- r = stat_other, the saved ReLU
+   * output of that convolution, [M][ldso] bf16 -- to the layer's totals [DFL_BN_R][2][F] (dfl_conv_args.stat_totals): the
+   * dfl_colstats pass over dx and r and its finalize launch are not needed. */
+  const float* stat_other;
+  double* stat_totals;
+  int32_t ldso, reserved4;
 } dfl_head_bwd_args;
 int dfl_head_bwd(const dfl_head_bwd_args* a, dfl_stream_t stream);
 int dfl_head_wgrad_blocks(int64_t M);  /* workgroups (= partial slots) of the fused form for M pixels */

@@ -863,32 +863,38 @@ def test_live_batchnorm_batched_finalize_equals_the_per_layer_kernels(C_, rows):
 def test_live_batchnorm_statistics_change_nothing(key):
     """A training step with the BatchNorm statistics completed by their consumers (dfl_conv_args.stat_totals / in_tot / add_tot,
     dfl_wgrad_args.coef_tot: the default) against the same step with a dfl_bn_finalize / dfl_bn_bwd_finalize launch per layer
-    (UNetPlan.LIVE_BN = False): outputs, loss, running statistics and EVERY gradient -- equal to fp32 rounding of a sum's last
-    bit (bit-identical whenever the fp64 totals are exact, which the test reports)."""
+    (UNetPlan.LIVE_BN = False): outputs, loss, running statistics and EVERY gradient are BIT-IDENTICAL -- the producers add the
+    same fp32 workgroup sums, and their fp64 total is exact whatever the order.  (The head's backward kernel is the one producer
+    that groups its fp32 sums differently from the pass it replaces, dfl_colstats: with it on -- the default -- the forward pass
+    is still bit-identical and the gradients are a second valid bf16 rounding of the same step, compared loosely here and step
+    by step in tests/test_gpu_bf16_stepwise.py.)"""
     from dfl_amd import plan as P_
     pr = PR.REGISTRY[key]()
     res = {}
-    for live in (True, False):
-        prev = P_.UNetPlan.LIVE_BN
-        P_.UNetPlan.LIVE_BN = live
+    for mode in ('live', 'live_nohead', 'off'):
+        prev = (P_.UNetPlan.LIVE_BN, P_.UNetPlan.LIVE_HEAD)
+        P_.UNetPlan.LIVE_BN, P_.UNetPlan.LIVE_HEAD = mode != 'off', mode == 'live'
         try:
             net = hip_net(pr)
             out, seg, loss = hip_step(pr, net)
             plan = NF.train_plan(net)
             nfin = sum(1 for st in plan.fwd.structs + plan.bwd.structs if isinstance(st, (nat.BnFinalizeArgs, nat.BnBwdFinalizeArgs)))
         finally:
-            P_.UNetPlan.LIVE_BN = prev
-        res[live] = dict(seg=seg.detach().clone(), loss=loss.item(), nfin=nfin,
+            P_.UNetPlan.LIVE_BN, P_.UNetPlan.LIVE_HEAD = prev
+        res[mode] = dict(seg=seg.detach().clone(), loss=loss.item(), nfin=nfin,
                          grads={k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None},
                          bufs={k: v.clone() for k, v in net.named_buffers()})
-    a, b = res[True], res[False]
-    assert a['nfin'] <= 4 or a['nfin'] * 3 <= b['nfin'], (a['nfin'], b['nfin'])     # (max-pool boundaries keep a statistics pass)
-    exact = torch.equal(a['seg'], b['seg']) and all(torch.equal(a['grads'][k], b['grads'][k]) for k in a['grads'])
-    print('%s: %d -> %d finalize launches per step; bit-identical: %s' % (key, b['nfin'], a['nfin'], exact))
-    np.testing.assert_allclose(a['seg'].cpu().numpy(), b['seg'].cpu().numpy(), rtol=1e-5, atol=1e-6)
-    assert abs(a['loss'] - b['loss']) <= 1e-6 * abs(b['loss'])
+    a, a2, b = res['live'], res['live_nohead'], res['off']
+    print('%s: %d -> %d finalize launches per step (%d without the head kernel\'s sums)' % (key, b['nfin'], a['nfin'], a2['nfin']))
+    assert a['nfin'] <= 2 or a['nfin'] * 3 <= b['nfin'], (a['nfin'], b['nfin'])     # (max-pool boundaries keep a statistics pass)
+    # same workgroup sums, exact totals: bit-identical
+    assert torch.equal(a2['seg'], b['seg']) and a2['loss'] == b['loss']
     for k, v in b['bufs'].items():
-        np.testing.assert_allclose(a['bufs'][k].cpu().numpy(), v.cpu().numpy(), rtol=1e-6, atol=1e-7, err_msg=k)
+        assert torch.equal(a2['bufs'][k], v), k
     for k, v in b['grads'].items():
-        sc = float(v.abs().max())
-        np.testing.assert_allclose(a['grads'][k].cpu().numpy(), v.cpu().numpy(), rtol=1e-4, atol=1e-5 * sc + 1e-9, err_msg=k)
+        assert torch.equal(a2['grads'][k], v), k
+    # with the head kernel's own sums: identical forward pass, gradients at bf16 distance (whole gradient, relative L2)
+    assert torch.equal(a['seg'], b['seg']) and a['loss'] == b['loss']
+    num = sum(float((a['grads'][k] - v).double().pow(2).sum()) for k, v in b['grads'].items())
+    den = sum(float(v.double().pow(2).sum()) for v in b['grads'].values())
+    assert (num / den) ** 0.5 <= 3e-2, (num / den) ** 0.5
