@@ -94,8 +94,19 @@ __global__ void __launch_bounds__(256) direct_conv_kernel(const dfl_conv_args a,
     if (a.add_scale != nullptr) {
       asc[j] = a.add_scale[n0 + j];
       ash[j] = a.add_shift[n0 + j];
-    } else if (a.add != nullptr && a.add_tot != nullptr) {     // live statistics: derived here (include/dfl_hip.h)
-      bn_live_affine(a.add_tot, a.add_gamma, a.add_beta, a.add_count, a.bn_eps, a.Ntot, n0 + j, &asc[j], &ash[j]);
+    }
+  }
+  if (a.add != nullptr && a.add_scale == nullptr && a.add_tot != nullptr) {
+    // live statistics (include/dfl_hip.h): derived here, one channel per thread through LDS (four fp64 derivations per thread
+    // made this 19 us kernel 32 us long)
+    __shared__ float atab[2][1024];
+    for (int c = threadIdx.x; c < a.Ntot; c += 256)
+      bn_live_affine(a.add_tot, a.add_gamma, a.add_beta, a.add_count, a.bn_eps, a.Ntot, c, &atab[0][c], &atab[1][c]);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      asc[j] = atab[0][n0 + j];
+      ash[j] = atab[1][n0 + j];
     }
   }
   float isc[CIN], ish[CIN];
