@@ -42,6 +42,14 @@ class PackJob(C.Structure):
                 ('split', i32), ('dst2', fp), ('kind2', i32), ('flip2', i32), ('first_tile', i32), ('reserved', i32)]
 
 
+PACK_PLAIN, SGD_PLAIN_TILE = 100, 4096       # include/dfl_hip.h: DFL_PACK_PLAIN, DFL_SGD_PLAIN_TILE
+
+
+class SgdPackArgs(C.Structure):
+    _fields_ = [('jobs_dev', fp), ('grad_delta', i64), ('buf_delta', i64), ('njobs', i32), ('total_tiles', i32), ('lr', f32),
+                ('momentum', f32), ('weight_decay', f32), ('grad_scale', f32), ('nesterov', i32), ('reserved', i32)]
+
+
 class BnLiveJob(C.Structure):
     _fields_ = [('totals', fp), ('gamma', fp), ('beta', fp), ('running_mean', fp), ('running_var', fp), ('num_batches_tracked', fp),
                 ('scale', fp), ('shift', fp), ('save_mean', fp), ('save_invstd', fp), ('count', i64), ('C', i32), ('eps', f32),
@@ -209,7 +217,8 @@ EXPORTS = ['dfl_version', 'dfl_last_error', 'dfl_sizeof', 'dfl_conv2d', 'dfl_con
            'dfl_set_math_mode', 'dfl_graph_capture', 'dfl_graph_launch', 'dfl_graph_nodes', 'dfl_graph_destroy',
            'dfl_set_conv_rows_min_tiles', 'dfl_conv_candidates', 'dfl_conv_force_geometry', 'dfl_conv_tune_add',
            'dfl_head_wgrad_blocks', 'dfl_head_scratch_ld_for', 'dfl_head_scratch_off_for', 'dfl_upsample2x_fwd',
-           'dfl_upsample2x_bwd', 'dfl_bn_finalize_live', 'dfl_bn_bwd_finalize_live', 'dfl_pack_weights_tiled']
+           'dfl_upsample2x_bwd', 'dfl_bn_finalize_live', 'dfl_bn_bwd_finalize_live', 'dfl_pack_weights_tiled',
+           'dfl_sgd_pack_tiled']
 
 
 class DflError(RuntimeError):
@@ -238,6 +247,7 @@ def lib():
     L.dfl_sum_partials.argtypes = [fp, fp, i64, i32, i32, fp]
     L.dfl_pack_weights.argtypes = [fp, i32, i64, fp]
     L.dfl_pack_weights_tiled.argtypes = [fp, i32, i32, fp]
+    L.dfl_sgd_pack_tiled.argtypes = [fp, fp]
     L.dfl_bn_eval_prepare.argtypes = [fp, fp, fp, fp, fp, fp, i32, f32, fp]
     L.dfl_reduce_partials.argtypes = [fp, fp, i32, i32, i32, fp]
     L.dfl_reduce_batch.argtypes = [fp, i32, i32, fp]

@@ -963,6 +963,67 @@ __global__ void __launch_bounds__(256) sgd_kernel(float* __restrict__ p, const f
   }
 }
 
+__device__ __forceinline__ float sgd_update(float w, float gr, float* b, float lr, float mom, float wd, float gscale, int nesterov) {
+  float g = fmaf(wd, w, gr * gscale);                          // (the arithmetic of sgd_kernel, word for word)
+  if (mom != 0.f) {
+    const float nb = fmaf(mom, *b, g);
+    *b = nb;
+    g = nesterov ? fmaf(mom, nb, g) : nb;
+  }
+  return fmaf(-lr, g, w);
+}
+
+// dfl_sgd_pack_tiled: pack_tiles_kernel whose workgroups update their tile of the master before they emit its layouts -- the
+// weights are read once per step (sgd_kernel + pack_tiles_kernel: twice) and one launch goes.
+__global__ void __launch_bounds__(256) sgd_pack_tiles_kernel(dfl_sgd_pack_args a) {
+  __shared__ float tile[PK_T][PK_T * PK_CMAX + 1];
+  const dfl_pack_job* __restrict__ jobs = a.jobs_dev;
+  int lo = 0, hi = a.njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].first_tile <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const dfl_pack_job j = jobs[lo];
+  const int tidx = (int)blockIdx.x - j.first_tile;
+  float* __restrict__ P = const_cast<float*>(j.src);
+  const float* __restrict__ G = j.src + a.grad_delta;
+  float* __restrict__ Bf = const_cast<float*>(j.src) + a.buf_delta;
+  const bool hasb = a.momentum != 0.f;
+  if (j.kind == DFL_PACK_PLAIN) {
+    const int64_t i0 = (int64_t)tidx * DFL_SGD_PLAIN_TILE;
+    const int64_t i1 = min((int64_t)j.A, i0 + DFL_SGD_PLAIN_TILE);
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+      float b = hasb ? Bf[i] : 0.f;
+      P[i] = sgd_update(P[i], G[i], &b, a.lr, a.momentum, a.weight_decay, a.grad_scale, a.nesterov);
+      if (hasb) Bf[i] = b;
+    }
+    return;
+  }
+  const int A = j.A, B = j.B, Cc = j.C;
+  const int tb = B / PK_T;
+  const int a0 = (tidx / tb) * PK_T, b0 = (tidx % tb) * PK_T;
+  const int run4 = 8 * Cc;
+  for (int e = threadIdx.x; e < PK_T * run4; e += 256) {
+    const int ar = e / run4, q4 = e - ar * run4;
+    const int64_t o = ((int64_t)(a0 + ar) * B + b0) * Cc + 4 * q4;
+    const float4 w = *reinterpret_cast<const float4*>(P + o);
+    const float4 g = *reinterpret_cast<const float4*>(G + o);
+    float4 b = hasb ? *reinterpret_cast<const float4*>(Bf + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 v;
+    v.x = sgd_update(w.x, g.x, &b.x, a.lr, a.momentum, a.weight_decay, a.grad_scale, a.nesterov);
+    v.y = sgd_update(w.y, g.y, &b.y, a.lr, a.momentum, a.weight_decay, a.grad_scale, a.nesterov);
+    v.z = sgd_update(w.z, g.z, &b.z, a.lr, a.momentum, a.weight_decay, a.grad_scale, a.nesterov);
+    v.w = sgd_update(w.w, g.w, &b.w, a.lr, a.momentum, a.weight_decay, a.grad_scale, a.nesterov);
+    *reinterpret_cast<float4*>(P + o) = v;
+    if (hasb) *reinterpret_cast<float4*>(Bf + o) = b;
+    float* t = &tile[ar][4 * q4];
+    t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+  }
+  __syncthreads();
+  pack_emit_cells(tile, reinterpret_cast<unsigned short*>(j.dst), j.kind, j.flip, A, B, Cc, a0, b0);
+  if (j.dst2 != nullptr) pack_emit_cells(tile, reinterpret_cast<unsigned short*>(j.dst2), j.kind2, j.flip2, A, B, Cc, a0, b0);
+}
+
 static unsigned stream_grid(int64_t units) {
   int64_t b = ceil_div(units, 256);
   if (b > 8192) b = 8192;
@@ -1178,6 +1239,14 @@ extern "C" int dfl_pack_weights_tiled(const dfl_pack_job* jobs_dev, int32_t njob
   DFL_REQUIRE(jobs_dev && njobs > 0 && total_tiles > 0, "dfl_pack_weights_tiled: bad args");
   hipLaunchKernelGGL(pack_tiles_kernel, dim3((unsigned)total_tiles), dim3(256), 0, static_cast<hipStream_t>(stream), jobs_dev, (int)njobs);
   return check_launch("dfl_pack_weights_tiled");
+}
+
+extern "C" int dfl_sgd_pack_tiled(const dfl_sgd_pack_args* a, dfl_stream_t stream) {
+  DFL_REQUIRE(a != nullptr && a->jobs_dev != nullptr && a->njobs > 0 && a->total_tiles > 0, "dfl_sgd_pack_tiled: empty job list");
+  DFL_REQUIRE(a->grad_delta % 4 == 0 && a->buf_delta % 4 == 0, "dfl_sgd_pack_tiled: gradient / momentum arenas not 16-byte congruent with the parameters");
+  DFL_REQUIRE(a->momentum >= 0.f && (!a->nesterov || a->momentum > 0.f), "dfl_sgd_pack_tiled: nesterov needs a momentum");
+  hipLaunchKernelGGL(sgd_pack_tiles_kernel, dim3((unsigned)a->total_tiles), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  return check_launch("dfl_sgd_pack_tiled");
 }
 
 extern "C" int dfl_sgd_step(float* p, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,

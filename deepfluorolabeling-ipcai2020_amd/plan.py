@@ -228,6 +228,7 @@ class UNetPlan:
             t = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(self.dev)
             self._keep.append(t)
             return t
+        self._tiled_host, self._tiled_index = None, None      # what sgd.SGD needs to update the weights inside this launch
         if tiled:
             arr = (PackJob * len(tiled))()
             tiles = 0
@@ -239,7 +240,11 @@ class UNetPlan:
                     a.dst2, a.kind2, a.flip2 = group[1][1].data_ptr(), group[1][5], group[1][6]
                 a.first_tile = tiles
                 tiles += (A // 32) * (B // 32)
+            self._tiled_index = len(self.pack)
             self.pack.add(PackArgs(jobs_dev=to_dev(arr).data_ptr(), max_elems=tiles, njobs=len(tiled), tiled=1))
+            srcs = [g[0][0].data_ptr() for g in tiled]
+            if len(set(srcs)) == len(srcs):                   # (a parameter with a third layout: its second record would read
+                self._tiled_host = (bytes(arr), len(tiled), tiles, {g[0][0].data_ptr(): g[0][0].numel() for g in tiled})   # what the first one writes)
         if rest:
             arr = (PackJob * len(rest))()
             mx = 0
@@ -1315,6 +1320,15 @@ class UNetPlan:
     # ------------------------------------------------------------------------------------------ run
     def run_pack(self, stream, forward_only=False):
         self.pack.run(stream)
+
+    def run_pack_rest(self, stream):
+        """The pack program without its tiled launch: what is left to do after dfl_sgd_pack_tiled (sgd.SGD.step) has written the
+        tiled layouts together with the update."""
+        i, n = self._tiled_index, len(self.pack)
+        if i > 0:
+            self.pack.run(stream, 0, i)
+        if n - i - 1 > 0:
+            self.pack.run(stream, i + 1, n - i - 1)
 
     def new_outputs(self):
         N = self.N

@@ -8,6 +8,11 @@ is one dfl_sgd_step launch per contiguous run of live parameters (two runs for t
 Parameters whose tensors do not line up (foreign modules, accumulated gradients) are updated tensor by tensor with
 the same kernel.  CPU tensors are refused: there is no fallback path.
 """
+import ctypes as C
+import os
+import weakref
+
+import numpy as np
 import torch
 from torch.optim.optimizer import Optimizer, required
 
@@ -30,6 +35,7 @@ class SGD(Optimizer):
         super().__init__(params, defaults)
         self.grad_scale = 1.0          # parallel.DataParallel leaves SUMMED gradients when asked to; see there
         self._lib = nat.lib()
+        self._fused_cache = {}         # dfl_sgd_pack_tiled job lists, see _fused_pack
 
     def _momentum_buffers(self, group):
         """Zero momentum buffers for parameters that have none (torch's first step, buf = g, is mom*0 + g).  When the
@@ -73,6 +79,53 @@ class SGD(Optimizer):
                     view.copy_(self.state[p]['momentum_buffer'])
                     self.state[p]['momentum_buffer'] = view
 
+    FUSE_PACK = os.environ.get('DFL_SGD_PACK', '1') != '0'
+
+    def _fused_pack(self, net, live, runs, mom):
+        """(plan, device job list, jobs, tiles, gradient delta, buffer delta) for dfl_sgd_pack_tiled, or None when the update
+        cannot run inside the tiled weight re-layout of the network's training plan: every tiled parameter must be updated by
+        this step, and parameters, gradients and momentum buffers must share one layout (one delta for all runs)."""
+        plan = net.plan_for_fused_update()
+        if plan is None:
+            return None
+        gd = {gp - pp for pp, gp, bp, n in runs}
+        bd = {bp - pp for pp, gp, bp, n in runs} if mom != 0 else {0}
+        if len(gd) != 1 or len(bd) != 1:
+            return None
+        gdelta, bdelta = gd.pop(), bd.pop()
+        if gdelta % 16 or bdelta % 16:
+            return None
+        key = (id(plan), gdelta, bdelta, tuple(p.data_ptr() for p in live))
+        hit = self._fused_cache.get(key)
+        if hit is not None and hit[0]() is plan:
+            return (plan,) + hit[1:]
+        raw, ntiled, tiles, tiled_src = plan._tiled_host
+        ptrs = {p.data_ptr(): p.numel() for p in live}
+        if any(ptrs.get(s) != n for s, n in tiled_src.items()):
+            return None                      # a tiled parameter without a gradient (or a view of one): not this path
+        plain, cur = [], None                # what has no tiled layout, adjacent slices merged (alignment padding absorbed)
+        for p in live:
+            pp, n = p.data_ptr(), p.numel()
+            if pp in tiled_src:
+                cur = None
+                continue
+            if cur is not None and 0 <= pp - cur[0] - 4 * cur[1] <= 12:
+                cur[1] = (pp - cur[0]) // 4 + n
+            else:
+                cur = [pp, n]
+                plain.append(cur)
+        arr = (nat.PackJob * (ntiled + len(plain)))()
+        C.memmove(arr, raw, len(raw))
+        for i, (pp, n) in enumerate(plain):
+            a = arr[ntiled + i]
+            a.src, a.A, a.B, a.C, a.kind, a.first_tile = pp, n, 1, 1, nat.PACK_PLAIN, tiles
+            tiles += -(-n // nat.SGD_PLAIN_TILE)
+        jobs_dev = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(live[0].device)
+        if len(self._fused_cache) >= 4:
+            self._fused_cache.clear()
+        self._fused_cache[key] = (weakref.ref(plan), jobs_dev, len(arr), tiles, gdelta // 4, bdelta // 4)
+        return (plan,) + self._fused_cache[key][1:]
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -104,14 +157,24 @@ class SGD(Optimizer):
                 else:
                     cur = [pp, gp, bp, n]
                     runs.append(cur)
+            from .unet import owner_of
+            net = owner_of(live[0])
+            fused = self._fused_pack(net, live, runs, mom) if (net is not None and self.FUSE_PACK and len(self.param_groups) == 1) else None
+            if fused is not None:
+                # one pass over the weights: the workgroups of the tiled re-layout update their tile first (dfl_sgd_pack_tiled)
+                plan, jobs_dev, njobs, tiles, gdelta, bdelta = fused
+                a = nat.SgdPackArgs(jobs_dev=jobs_dev.data_ptr(), grad_delta=gdelta, buf_delta=bdelta, njobs=njobs, total_tiles=tiles,
+                                    lr=lr, momentum=mom, weight_decay=wd, grad_scale=self.grad_scale, nesterov=int(nest))
+                nat.check(lib.dfl_sgd_pack_tiled(C.addressof(a), stream), 'dfl_sgd_pack_tiled')
+                torch.autograd.graph.increment_version(live)
+                net.after_fused_update(plan, stream)
+                continue
             for pp, gp, bp, n in runs:
                 nat.check(lib.dfl_sgd_step(pp, gp, bp or None, n, lr, mom, wd, self.grad_scale, int(nest), 0, stream),
                           'dfl_sgd_step')
             # the kernel wrote behind autograd's back: bump the version counters like an in-place torch op would (the
             # network re-packs its weights when they move, and autograd must see saved tensors as modified)
             torch.autograd.graph.increment_version(live)
-            from .unet import owner_of
-            net = owner_of(live[0])
             if net is not None:
                 net.prepack()            # next step's weight re-layout starts now, behind the update kernels
         return loss

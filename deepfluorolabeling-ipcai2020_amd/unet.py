@@ -302,6 +302,22 @@ class UNet(nn.Module):
             return
         self._ensure_packed(plan, torch.cuda.current_stream(plan.dev).cuda_stream)
 
+    def plan_for_fused_update(self):
+        """The training plan whose tiled weight re-layout sgd.SGD.step() may run inside its update kernel (dfl_sgd_pack_tiled), or
+        None: the same conditions as prepack() + a tiled pack list without aliases."""
+        plan = self._last_train_plan() if self._last_train_plan is not None else None
+        if plan is None or self._param_list is None or not any(plan is q for ps in self._plans.values() for q in ps):
+            return None
+        if plan.math != nat.lib().dfl_get_math_mode() or getattr(plan, '_tiled_host', None) is None:
+            return None
+        return plan
+
+    def after_fused_update(self, plan, stream):
+        """The tiled layouts of `plan` were written with the update: run what else its pack program holds and mark it packed."""
+        plan.run_pack_rest(stream)
+        plan.fold_tail()
+        self._pack_version = (id(plan), sum(p._version for p in self._weight_params))
+
     def _ensure_packed(self, plan, stream):
         ver = sum(p._version for p in self._weight_params)
         if not plan.training and not plan.need_grad:

@@ -517,6 +517,24 @@ int dfl_ensemble_reduce(const dfl_ensemble_args* a, dfl_stream_t stream);
 int dfl_sgd_step(float* p, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
                  float weight_decay, float grad_scale, int32_t nesterov, int32_t first_step, dfl_stream_t stream);
 
+/* The same update AND the bf16 weight re-layout of the next step in one pass over the weights (round 4; optimizer.step() followed
+ * by the re-layout the next forward needs, train.py:333-334,424): the jobs of dfl_pack_weights_tiled, whose workgroups update
+ * their 32 x 32 x C tile of the fp32 master (p, momentum buffer written back) before they emit its layouts from LDS, followed by
+ * "plain" jobs (kind = DFL_PACK_PLAIN: src, A = element count, no layouts; DFL_SGD_PLAIN_TILE elements per workgroup) for what
+ * has no tiled layout -- biases, BatchNorm parameters, the first layer, the heads.  Gradient and momentum buffer of an element
+ * live at src + grad_delta and src + buf_delta (ELEMENTS; the three arenas share one layout; multiples of 4 for the tiled
+ * jobs' 16-byte accesses).  No job may share elements with another one. */
+#define DFL_PACK_PLAIN 100
+#define DFL_SGD_PLAIN_TILE 4096
+typedef struct {
+  const dfl_pack_job* jobs_dev;
+  int64_t grad_delta, buf_delta;
+  int32_t njobs, total_tiles;
+  float lr, momentum, weight_decay, grad_scale;
+  int32_t nesterov, reserved;
+} dfl_sgd_pack_args;
+int dfl_sgd_pack_tiled(const dfl_sgd_pack_args* a, dfl_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * GPU-side input pipeline: the deterministic part of the reference loader (train_test_code/dataset.py) from raw
  * device arrays, for a whole batch in two launches.

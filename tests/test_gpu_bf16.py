@@ -898,3 +898,65 @@ def test_live_batchnorm_statistics_change_nothing(key):
     num = sum(float((a['grads'][k] - v).double().pow(2).sum()) for k, v in b['grads'].items())
     den = sum(float(v.double().pow(2).sum()) for v in b['grads'].values())
     assert (num / den) ** 0.5 <= 3e-2, (num / den) ** 0.5
+
+
+@pytest.mark.parametrize('key', ['paper__paper_sc_l14__b2', 'ragged__37x41__mp1'])
+def test_update_inside_the_weight_relayout_changes_nothing(key):
+    """optimizer.step() of dfl_amd.SGD in the bf16 storage mode (train.py:333-334,424): the update runs INSIDE the tiled weight
+    re-layout (dfl_sgd_pack_tiled: one pass over the weights, no dfl_sgd_step launch) -- parameters, momentum buffers and the
+    next forward passes (which read the bf16 layouts written there) are BIT-IDENTICAL to update launches followed by the
+    re-layout (SGD.FUSE_PACK = False), and within fp32 rounding of torch.optim.SGD."""
+    pr = PR.REGISTRY[key]()
+    nets, opts, outs = [], [], []
+    for fuse in (True, False, None):
+        net = hip_net(pr)
+        if fuse is None:
+            opt = torch.optim.SGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-3, nesterov=True)
+        else:
+            opt = dfl_amd.SGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-3, nesterov=True)
+            opt.FUSE_PACK = fuse
+        calls = {'dfl_sgd_step': 0, 'dfl_sgd_pack_tiled': 0}
+        if fuse is not None:
+            real = opt._lib
+
+            class Spy:
+                def __getattr__(self, k, real=real, calls=calls):
+                    f = getattr(real, k)
+                    if k in calls:
+                        def counted(*a):
+                            calls[k] += 1
+                            return f(*a)
+                        return counted
+                    return f
+            opt._lib = Spy()
+        seq = []
+        for step in range(3):
+            opt.zero_grad()
+            out, seg, loss = hip_step(pr, net)
+            seq.append((seg.detach().clone(), loss.item()))
+            opt.step()
+            if step == 0:
+                first = [p.detach().clone() for p in net.parameters()]
+                opt.param_groups[0]['lr'] = 0.02          # schedulers write the group between steps
+        net.eval()
+        with torch.no_grad():
+            o = net(pr.x.to(DEV))
+        seq.append(((o[0] if isinstance(o, tuple) else o).clone(), 0.0))
+        torch.cuda.synchronize()
+        nets.append(net); opts.append(opt); outs.append((seq, calls, first))
+    (sa, ca, fa), (sb, cb, _), (sc, _, fc) = outs
+    plan = NF.train_plan(nets[0])
+    assert plan._tiled_host is not None, 'no tiled layouts in this problem: nothing was tested'
+    assert ca == {'dfl_sgd_step': 0, 'dfl_sgd_pack_tiled': 3}, ca
+    assert cb['dfl_sgd_pack_tiled'] == 0 and cb['dfl_sgd_step'] >= 3, cb
+    for (s1, l1), (s2, l2) in zip(sa, sb):
+        assert torch.equal(s1, s2) and l1 == l2
+    for (k, pa), pb in zip(nets[0].named_parameters(), nets[1].parameters()):
+        assert torch.equal(pa, pb), k
+        if pa.grad is not None:
+            assert torch.equal(opts[0].state[pa]['momentum_buffer'], opts[1].state[pb]['momentum_buffer']), k
+    # torch's multi-tensor kernels round a*b+c twice where the HIP update uses fma: the first update (same gradients) agrees
+    # within fp32 rounding; later steps read bf16 layouts of slightly different masters and are not comparable bit by bit
+    for (k, _), pa, pc in zip(nets[0].named_parameters(), fa, fc):
+        d = (pa - pc).abs().max().item()
+        assert d <= 2e-6 * max(1.0, pc.abs().max().item()), (k, d)
