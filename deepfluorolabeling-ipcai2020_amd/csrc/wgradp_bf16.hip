@@ -47,7 +47,8 @@ struct WgP {
   int kpipe;                           // fragments of the next k-step are fetched under the matrix instructions of this one
   long long* trace;                    // diagnosis build only (-DDFL_WGP_TRACE, docs/experiments/wgradp_trace.py)
   uint32_t g_bytes, d_bytes;
-  uint32_t d2_bytes, pad0;             // extent of the second dense tensor (dfl_wgrad_args.d_mode)
+  uint32_t d2_bytes;                   // extent of the second dense tensor (dfl_wgrad_args.d_mode)
+  int xcd_map;                         // workgroup -> (tile, slice) map, see the kernel
 };
 
 __device__ __forceinline__ float wbf_lo(uint32_t w) { return __uint_as_float(w << 16); }
@@ -96,7 +97,25 @@ __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const
   const int pair = slot % p.pairs, phase = slot / p.pairs;
   const int pairs_n = p.CGT >> 5;                       // pairs along cg
   const int pm = pair / pairs_n, pn = pair - pm * pairs_n;
-  const int cm0 = blockIdx.x * p.CMT, cg0 = blockIdx.y * p.CGT;
+  // ---- which tile, which pixel slice.  Workgroup L of the linear dispatch order runs on XCD L % 8 (observed; convp_bf16.hip),
+  //      and each XCD has an L2 of its own.  With the hardware's order (cm tile fastest, then cg tile, then slice) the 8 XCDs
+  //      share every slice: an XCD sees one or two cm tiles and ALL cg tiles, so the gathered tensor is fetched by all eight
+  //      L2s.  xcd_map = 1 gives every XCD a contiguous run of the (slice, cm tile, cg tile) order instead: with 8 slices or
+  //      more an XCD keeps whole slices -- both tensors are fetched once, by the L2 whose workgroups read them.
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (p.xcd_map) {
+    const int gx = gridDim.x, gy = gridDim.y, nt = gx * gy;
+    const int total = nt * (int)gridDim.z, per = total >> 3;
+    const int L = bx + gx * (by + gy * bz);
+    if (L < (per << 3)) {
+      const int Lp = (L & 7) * per + (L >> 3);
+      bz = Lp / nt;
+      const int t = Lp - bz * nt;
+      bx = t / gy;                                            // cg tile fastest: the (larger) d patch stays in L2 across them
+      by = t - bx * gy;
+    }
+  }
+  const int cm0 = bx * p.CMT, cg0 = by * p.CGT;
   unsigned char* Ds = smem;
   unsigned char* Gs = smem + p.g_off;
 
@@ -131,7 +150,7 @@ __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const
   wpu32x4 dreg[MAXD], greg[MAXG];
   wpu32x4 d2reg[DBRB ? MAXD : 1];
   float bsum = 0.f;                                               // DBRB: this thread's share of the bias gradient (one channel)
-  const bool bias_on = DBRB && a.bias_partial != nullptr && blockIdx.y == 0;
+  const bool bias_on = DBRB && a.bias_partial != nullptr && by == 0;
   uint32_t dpos[MAXD], gpos[MAXG];
   uint32_t gok = 0;
   const int ddk = NT >> p.dupp_shift, gdk = NT >> p.gupp_shift;
@@ -277,7 +296,7 @@ __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const
     }
   };
 
-  const int pbegin = blockIdx.z * p.patches_per_slice;
+  const int pbegin = bz * p.patches_per_slice;
   const int pend = min(pbegin + p.patches_per_slice, p.npatch);
   const int nsteps = p.P16 >> 4;
   const uint32_t gadd = g_col + (uint32_t)(ty * p.IW) * (uint32_t)p.sg;     // this wave's kernel row, this lane's channels
@@ -353,7 +372,7 @@ __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const
 
   // ---- bias gradient of this pixel slice (DBRB): the threads that staged the same 8 channels add up through LDS, fixed order
   if constexpr (DBRB) {
-    if (a.bias_partial != nullptr && blockIdx.y == 0) {
+    if (a.bias_partial != nullptr && by == 0) {
       __syncthreads();
       float* bred = reinterpret_cast<float*>(smem);     // [NT]
       bred[tid] = bsum;
@@ -361,7 +380,7 @@ __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const
       for (int c = tid; c < p.CMT; c += NT) {
         float t = 0.f;
         for (int th = c; th < NT; th += p.CMT) t += bred[th];
-        if (cm0 + c < a.Cm) a.bias_partial[(int64_t)blockIdx.z * a.Cm + cm0 + c] = t;
+        if (cm0 + c < a.Cm) a.bias_partial[(int64_t)bz * a.Cm + cm0 + c] = t;
       }
     }
   }
@@ -394,7 +413,7 @@ __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const
 #endif
   // ---- output: one partial slot per pixel slice
   const bool sliced = p.zslices > 1;
-  float* out = sliced ? a.partial + (int64_t)blockIdx.z * a.Cm * a.Cg * T : a.dw;
+  float* out = sliced ? a.partial + (int64_t)bz * a.Cm * a.Cg * T : a.dw;
   const int cg = cg0 + pn * 32 + li;
 #pragma unroll
   for (int tx = 0; tx < KW; ++tx) {
@@ -627,8 +646,14 @@ int wgradp_config(const dfl_wgrad_args* a) {
 }
 
 template <int KH, int KW>
-static int wgp_launch_t(const WgP& p, hipStream_t s) {
+static int wgp_launch_t(const WgP& p_in, hipStream_t s) {
+  WgP p = p_in;
   dim3 grid((unsigned)ceil_div(p.a.Cm, p.CMT), (unsigned)ceil_div(p.a.Cg, p.CGT), (unsigned)p.zslices);
+  static const int xcd_env = [] {
+    const char* e = getenv("DFL_WGP_XCD");          // 0: the hardware's order (A/B measurements)
+    return e ? atoi(e) : 1;
+  }();
+  p.xcd_map = (xcd_env != 0 && grid.x * grid.y > 1 && grid.x * grid.y * grid.z >= 16) ? 1 : 0;
   const size_t lds = (size_t)p.lds_bytes;
 #define DFL_WGP_LAUNCH(AFF_, DBRB_)                                                                                              \
   {                                                                                                                              \
