@@ -862,7 +862,7 @@ extern "C" int dfl_conv2d(const dfl_conv_args* a, dfl_stream_t stream) {
     if (rc != DFL_OK) return rc;
     return dfl::convp_launch(p, static_cast<hipStream_t>(stream));
   }
-  DFL_REQUIRE(a == nullptr || a->x_mode == 0, "dfl_conv2d: x_mode (fused BatchNorm + ReLU backward operand) is implemented by the bf16 patch kernels only");
+  DFL_REQUIRE(a == nullptr || (a->x_mode == 0 && a->x_out == nullptr), "dfl_conv2d: x_mode (fused BatchNorm + ReLU backward operand) and x_out are implemented by the bf16 patch kernels only");
   {
     // live statistics outside the bf16 patch kernels: the 1-channel direct kernels only (3x3 row form: stat_totals; 1x1: add_tot)
     const bool any = a != nullptr && (a->stat_totals != nullptr || a->in_tot != nullptr || a->add_tot != nullptr);

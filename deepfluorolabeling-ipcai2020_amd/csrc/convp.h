@@ -18,7 +18,7 @@ struct ConvP {
   int lds_bytes, tile;          // staged image size, index into the tile configuration table
   int ntiles, grid, xcd_mode;   // column tiles; workgroups launched (linear grid); workgroup -> (patch, tile, slice) map
   uint32_t x_bytes, w_bytes;
-  uint32_t x2_bytes, pad0;      // extent of the second input tensor (dfl_conv_args.x_mode)
+  uint32_t x2_bytes, xo_bytes;  // extent of the second input tensor (dfl_conv_args.x_mode) and of x_out
   uint32_t mPP, mPW;            // ceil(2^32 / (PH * PW)), ceil(2^32 / PW): divisions of patch row indices by multiply-high
   int tab_off, pad1;            // LDS offset of the live-BatchNorm tables (set at launch)
 };

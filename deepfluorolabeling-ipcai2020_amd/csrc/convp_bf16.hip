@@ -322,9 +322,12 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : (TM 
           }
         }
       }
-      __amdgpu_buffer_rsrc_t rsR = rsX;
+      __amdgpu_buffer_rsrc_t rsR = rsX, rsO = rsX;
+      bool store_on = false;                       // x_out: this workgroup writes the interior of its patch (column tile 0 only)
       if constexpr (AFF == 2) {                    // d(pre-activation) = [r > 0] * (sc dy + sh r + sq); no BatchNorm: 1, 0, 0
         rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x2), 0, (int)p.x2_bytes, 0x00020000);
+        store_on = a.x_out != nullptr && btile == 0;
+        if (store_on) rsO = __builtin_amdgcn_make_buffer_rsrc(a.x_out, 0, (int)p.xo_bytes, 0x00020000);
         if (a.in_tot != nullptr) {                   // live statistics: A, B, C of this block's channels, one per thread, through LDS
           if (tid < p.CK)
             bn_live_coef(a.in_tot, a.in_gamma, a.in_mean, a.in_invstd, a.in_count, a.Cin, c0 + tid, in_tab + tid, in_tab + 128 + tid, in_tab + 256 + tid);
@@ -354,6 +357,7 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : (TM 
       constexpr int U = AFF == 2 ? DFL_BRB_U : 8;  // loads in flight per thread (two tensors in mode 2)
       for (; pix < npix; pix += U * dpix) {
         pu32x4 v[U], v2[AFF == 2 ? U : 1];
+        uint32_t offo[AFF == 2 ? U : 1];
         bool ok[U];
         int pixs[U];
 #pragma unroll
@@ -366,6 +370,9 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : (TM 
           if constexpr (AFF == 2) {
             const uint32_t off2 = (uint32_t)(((n * a.Hin + gy) * a.Win + gx) * a.ldx2) * 2u + cbyte;
             v2[u] = __builtin_amdgcn_raw_buffer_load_b128(rsR, ok[u] ? off2 : POOB, 0, 0);
+            // (stride 1: gathered pixel (iy, ix) is output pixel (iy - pad, ix - pad) of the patch)
+            const bool own = store_on && ok[u] && (unsigned)(iy - a.pad) < (unsigned)p.PH && (unsigned)(ix - a.pad) < (unsigned)p.PW;
+            offo[u] = own ? (uint32_t)(((n * a.Hin + gy) * a.Win + gx) * a.ldxo) * 2u + cbyte : POOB;
           }
           ix += dpix_x;
           iy += dpix_y;
@@ -397,6 +404,7 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : (TM 
               w.y = pack_bf2(brb(bf_lo(w.y), bf_lo(r.y), sc[2], sh[2], sq[2]), brb(bf_hi(w.y), bf_hi(r.y), sc[3], sh[3], sq[3]));
               w.z = pack_bf2(brb(bf_lo(w.z), bf_lo(r.z), sc[4], sh[4], sq[4]), brb(bf_hi(w.z), bf_hi(r.z), sc[5], sh[5], sq[5]));
               w.w = pack_bf2(brb(bf_lo(w.w), bf_lo(r.w), sc[6], sh[6], sq[6]), brb(bf_hi(w.w), bf_hi(r.w), sc[7], sh[7], sq[7]));
+              if (store_on) __builtin_amdgcn_raw_buffer_store_b128(w, rsO, offo[u], 0, 0);     // (outside the interior: out of range, dropped)
             }
             *reinterpret_cast<pu32x4*>(smem + (uint32_t)pixs[u] * (uint32_t)S + (uint32_t)cg * 16u) = w;
           }
@@ -1063,6 +1071,16 @@ static int convp_plan_search(const dfl_conv_args* a, ConvP* p, int force_splits)
     const int64_t x2b = (((int64_t)a->N * a->Hin * a->Win - 1) * a->ldx2 + a->Cin) * 2;
     DFL_REQUIRE(x2b < lim, "dfl_conv2d (bf16): tensors must stay below 2 GiB");
     p->x2_bytes = (uint32_t)x2b;
+  }
+  p->xo_bytes = 0;
+  if (a->x_out != nullptr) {
+    DFL_REQUIRE(a->x_mode == 1 && a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && a->Hout == a->Hin && a->Wout == a->Win,
+                "dfl_conv2d (bf16): x_out goes with x_mode 1 of a 3x3 stride-1 pad-1 layer");
+    DFL_REQUIRE(a->ldxo % 8 == 0 && a->ldxo >= a->Cin && aligned16(a->x_out) && a->x_out != a->x && a->x_out != a->x2,
+                "dfl_conv2d (bf16): x_out must be 16-byte aligned with ldxo %% 8 == 0, ldxo >= Cin, and a tensor of its own");
+    const int64_t xob = (((int64_t)a->N * a->Hin * a->Win - 1) * a->ldxo + a->Cin) * 2;
+    DFL_REQUIRE(xob < lim, "dfl_conv2d (bf16): tensors must stay below 2 GiB");
+    p->xo_bytes = (uint32_t)xob;
   }
 
   // a forced geometry (dfl_conv_force_geometry: tuners, tests) or an entry of the tuning table (dfl_conv_tune_add) wins

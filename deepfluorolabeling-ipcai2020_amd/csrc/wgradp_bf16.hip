@@ -82,7 +82,8 @@ __host__ __device__ constexpr int wgp_max_g_units(int KH, bool dbrb = false) { r
 #ifndef DFL_WGP_INTERLEAVE
 #define DFL_WGP_INTERLEAVE 0   // 1 / 2 / 4: the next patch's loads requested between this patch's k-steps (spread over all of them / the first
 #endif                         // half / quarter).  Measured (round 3): weight gradients 1.33 -> 1.45 ms per step in every variant -- left off.
-template <int KH, int KW, bool AFF, bool DBRB = false>
+// BIAS: the column sums also leave when d is a plain tensor (the operand materialised by dfl_conv_args.x_out).
+template <int KH, int KW, bool AFF, bool DBRB = false, bool BIAS = DBRB>
 __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const WgP p) {
   constexpr int NT = 256 * KH;
   constexpr int T = KH * KW;
@@ -150,7 +151,7 @@ __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const
   wpu32x4 dreg[MAXD], greg[MAXG];
   wpu32x4 d2reg[DBRB ? MAXD : 1];
   float bsum = 0.f;                                               // DBRB: this thread's share of the bias gradient (one channel)
-  const bool bias_on = DBRB && a.bias_partial != nullptr && by == 0;
+  const bool bias_on = BIAS && a.bias_partial != nullptr && by == 0;
   uint32_t dpos[MAXD], gpos[MAXG];
   uint32_t gok = 0;
   const int ddk = NT >> p.dupp_shift, gdk = NT >> p.gupp_shift;
@@ -325,7 +326,7 @@ __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const
     WT0(ti0)
     if (DFL_WGP_INTERLEAVE) issue_setup(patch + 1, patch + 1 < pend); else issue(patch + 1, patch + 1 < pend);
     WTR(3, ti0)
-    if constexpr (DBRB) {
+    if constexpr (BIAS) {
       // bias gradient: column sums of the d image as stored -- thread t owns channel t % CMT and every (NT / CMT)-th pixel row
       // (rows beyond the patch are zero); one accumulator register instead of eight in the staging path
       if (bias_on) {
@@ -371,7 +372,7 @@ __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const
 #endif
 
   // ---- bias gradient of this pixel slice (DBRB): the threads that staged the same 8 channels add up through LDS, fixed order
-  if constexpr (DBRB) {
+  if constexpr (BIAS) {
     if (a.bias_partial != nullptr && by == 0) {
       __syncthreads();
       float* bred = reinterpret_cast<float*>(smem);     // [NT]
@@ -491,6 +492,7 @@ static int wgp_plan(const dfl_wgrad_args* a, WgP* p, bool need_out) {
     DFL_REQUIRE(d2b < lim, "dfl_conv2d_wgrad (bf16): tensors must stay below 2 GiB");
     p->d2_bytes = (uint32_t)d2b;
   }
+  DFL_REQUIRE(a->bias_partial == nullptr || a->KH == 3, "dfl_conv2d_wgrad (bf16): bias_partial is implemented by the 3x3 kernel");
   // workgroup tile and wave roles
   p->CMT = a->Cm > 32 ? 64 : 32;
   p->CGT = a->Cg > 32 ? 64 : 32;
@@ -603,7 +605,7 @@ static int wgp_plan(const dfl_wgrad_args* a, WgP* p, bool need_out) {
   p->kpipe = kpipe;
   p->tab_off = (p->g_off + ipp * p->IH * p->IW * p->sg + 255) / 256 * 256;
   p->lds_bytes = p->tab_off + p->P16 * 4 + 2 * p->CGT * 4 + 3 * p->CMT * 4;
-  if (a->d_mode != 0 && p->lds_bytes < 256 * a->KH * 4) p->lds_bytes = 256 * a->KH * 4;   // room for the bias-gradient sums
+  if ((a->d_mode != 0 || a->bias_partial != nullptr) && p->lds_bytes < 256 * a->KH * 4) p->lds_bytes = 256 * a->KH * 4;   // room for the bias-gradient sums
   const int red_bytes = (p->phases - 1) * p->pairs * a->KH * 16 * 64 * 4;   // room for the cross-phase sums
   if (p->lds_bytes < red_bytes) p->lds_bytes = red_bytes;
   return DFL_OK;
@@ -655,9 +657,9 @@ static int wgp_launch_t(const WgP& p_in, hipStream_t s) {
   }();
   p.xcd_map = (xcd_env != 0 && grid.x * grid.y > 1 && grid.x * grid.y * grid.z >= 16) ? 1 : 0;
   const size_t lds = (size_t)p.lds_bytes;
-#define DFL_WGP_LAUNCH(AFF_, DBRB_)                                                                                              \
+#define DFL_WGP_LAUNCH(AFF_, DBRB_, BIAS_)                                                                                       \
   {                                                                                                                              \
-    auto k = wgradp_kernel<KH, KW, AFF_, DBRB_>;                                                                                 \
+    auto k = wgradp_kernel<KH, KW, AFF_, DBRB_, BIAS_>;                                                                          \
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
     (void)attr;                                          /* (once per instantiation, not per launch) */                         \
     hipLaunchKernelGGL(k, grid, dim3(256 * KH), lds, s, p);                                                                      \
@@ -665,11 +667,15 @@ static int wgp_launch_t(const WgP& p_in, hipStream_t s) {
   const bool aff = p.a.in_scale != nullptr;
   if constexpr (KH == 3) {
     if (p.a.d_mode != 0) {
-      if (aff) DFL_WGP_LAUNCH(true, true) else DFL_WGP_LAUNCH(false, true)
+      if (aff) DFL_WGP_LAUNCH(true, true, true) else DFL_WGP_LAUNCH(false, true, true)
+      return check_launch("dfl_conv2d_wgrad (bf16)");
+    }
+    if (p.a.bias_partial != nullptr) {               // the operand is a tensor of its own (dfl_conv_args.x_out)
+      if (aff) DFL_WGP_LAUNCH(true, false, true) else DFL_WGP_LAUNCH(false, false, true)
       return check_launch("dfl_conv2d_wgrad (bf16)");
     }
   }
-  if (aff) DFL_WGP_LAUNCH(true, false) else DFL_WGP_LAUNCH(false, false)
+  if (aff) DFL_WGP_LAUNCH(true, false, false) else DFL_WGP_LAUNCH(false, false, false)
 #undef DFL_WGP_LAUNCH
   return check_launch("dfl_conv2d_wgrad (bf16)");
 }

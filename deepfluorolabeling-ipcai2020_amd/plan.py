@@ -286,7 +286,7 @@ class UNetPlan:
     # ------------------------------------------------------------------------------------------ op helpers
     def _conv(self, prog, x, w, y, KH, KW, stride, pad, Ntot, bias=None, in_aff=None, relu=0, add=None,
               add_aff=None, accumulate=0, scatter=0, stats=False, stat_other=None, Hout=None, Wout=None, x_split=0, brb=None,
-              in_live=None, add_live=None, stat_totals=None):
+              in_live=None, add_live=None, stat_totals=None, x_out=None):
         """in_live / add_live: (totals, gamma, beta, count) of a live BatchNorm instead of the (scale, shift) vectors of in_aff /
         add_aff; stat_totals: the producer adds its statistics there instead of leaving partial rows (include/dfl_hip.h)."""
         a = ConvArgs()
@@ -314,6 +314,8 @@ class UNetPlan:
                 a.in_count = float(coef['count'])
             else:
                 a.in_scale = nat.ptr(coef)
+            if x_out is not None:
+                a.x_out, a.ldxo = x_out.ptr, x_out.ld
         if add is not None:
             a.add, a.ldadd = add.ptr, add.ld
             if add_aff is not None:
@@ -360,7 +362,9 @@ class UNetPlan:
             prog.wait(e['done'], stream=0)
 
     def _wgrad(self, prog, g, d, dw, KH, KW, stride, pad, Hout, Wout, in_aff=None, side=False, side_buf=None, d_split=0, brb=None,
-               bias_out=None):
+               bias_out=None, bias_plain=False):
+        """bias_plain: d is the operand itself (materialised through dfl_conv_args.x_out) and the kernel still leaves its column
+        sums -- the bias gradient -- per pixel slice."""
         a = WgradArgs()
         a.d_split = d_split
         a.g_bf16, a.d_bf16 = g.bf16, d.bf16
@@ -381,7 +385,7 @@ class UNetPlan:
         a.splits = 1
         s = nat.check(self.lib.dfl_wgrad_suggest_splits(C.addressof(a)), 'dfl_wgrad_suggest_splits')
         a.splits = s
-        if brb is not None and bias_out is not None:
+        if (brb is not None or bias_plain) and bias_out is not None:
             # the column sums of that operand = the layer's bias gradient, one row per pixel slice
             bpart = self._new(s * d.C)
             a.bias_partial = bpart.data_ptr()
@@ -413,6 +417,9 @@ class UNetPlan:
     FUSE_BWD_STATS = os.environ.get('DFL_FUSE_BWD_STATS', '1') != '0'
     FUSE_DOWN_STATS = os.environ.get('DFL_FUSE_DOWN_STATS', '1') != '0'   # ... and the strided-conv data gradient's scatter (bf16)
     FUSE_BRB = os.environ.get('DFL_FUSE_BRB', '1') != '0'      # BatchNorm + ReLU backward inside the weight-/data-gradient staging (bf16 storage)
+    # the data-gradient kernel also WRITES the operand it forms (dfl_conv_args.x_out) for layers whose tensor is at most this large:
+    # the weight gradient then reads one plain tensor instead of forming the operand again in each of its (cm, cg) tiles
+    DPRE_OUT_BYTES = int(float(os.environ.get('DFL_DPRE_OUT_MB', '12')) * (1 << 20))
     RES_DGRAD_LAST = os.environ.get('DFL_RES_DGRAD_LAST', '1') != '0'   # residual 1x1 data gradient accumulates onto the 3x3 one (not the reverse)
     FUSE_COLSUMS = FUSE_BWD_STATS and os.environ.get('DFL_FUSE_COLSUMS', '1') != '0'   # sums across block boundaries (see the backward program)
 
@@ -624,6 +631,8 @@ class UNetPlan:
             self._scratch['dpre1'] = self._new(mx, self.adt)
             self._dpre_turn = 0
             self._scratch['dz'] = self._new(mx, self.adt)
+            if self.bf16 and self.FUSE_BRB and self.DPRE_OUT_BYTES > 0:
+                self._scratch['dmat'] = self._new(mx, self.adt)   # operand materialised by the data-gradient kernel (x_out)
 
         fwd, bwd = self.fwd, self.bwd
         Cin0 = cfg['in_channels']
@@ -845,9 +854,24 @@ class UNetPlan:
                         # (a side-stream weight gradient reads dy itself: the scratch it lives in must not be rewritten --
                         # by the data gradient one layer further down -- before it is done: _dz_for joins on this key)
                         side_buf = next((kk for kk in ('dz', 'dpre0') if g.t is self._scratch.get(kk)), None)
-                    self._wgrad(bwd, cv['gin'], dpre, G[cv['wname'] + '.weight'], 3, 3, 1, 0 if circ else pad, r.H, r.W,
-                                in_aff=cv['inp_aff'], side=side, side_buf=side_buf, d_split=dsplit, brb=brb,
-                                bias_out=G[cv['wname'] + '.bias'])
+                    # Small tensors (deep levels: many (cm, cg) tiles, each of which would form the operand again): the data-gradient
+                    # kernel, which forms it anyway, writes it once (x_out) and the weight gradient -- emitted BEHIND it -- reads it
+                    dmat = None
+                    if (fuse_brb and bool(inp.bf16) and not circ and not side and (d > 0 or dxin is not None)
+                            and 'dmat' in self._scratch and r.M * Cout * 2 <= self.DPRE_OUT_BYTES):
+                        dmat = self._scratch_act('dmat', N, r.H, r.W, Cout)
+                        self.dbg['dmat:%s.block.%d' % (prefix, d * step + 1)] = dmat
+
+                    def emit_wgrad():
+                        if dmat is not None:
+                            self._wgrad(bwd, cv['gin'], dmat, G[cv['wname'] + '.weight'], 3, 3, 1, pad, r.H, r.W, in_aff=cv['inp_aff'],
+                                        bias_out=G[cv['wname'] + '.bias'], bias_plain=True)
+                        else:
+                            self._wgrad(bwd, cv['gin'], dpre, G[cv['wname'] + '.weight'], 3, 3, 1, 0 if circ else pad, r.H, r.W,
+                                        in_aff=cv['inp_aff'], side=side, side_buf=side_buf, d_split=dsplit, brb=brb,
+                                        bias_out=G[cv['wname'] + '.bias'])
+                    if dmat is None:
+                        emit_wgrad()
                     if circ and (d > 0 or dxin is not None):
                         # data gradient on the framed grid, folded back onto the pixels the frame copies (see _wrap_pad)
                         wd = self._pack_conv_dgrad(cv['w'])
@@ -870,21 +894,25 @@ class UNetPlan:
                         if prev['bn'] is not None and self.FUSE_BWD_STATS:
                             # the data-gradient conv leaves sum(dz), sum(dz*r) per channel for the next BN backward
                             fused = self._conv(bwd, dpre, wd, dz, 3, 3, 1, 2 - pad, Cout, stats=True, stat_other=prev['r'],
-                                               x_split=dsplit, brb=brb,
+                                               x_split=dsplit, brb=brb, x_out=dmat,
                                                stat_totals=self._bn_totals(Cout, bwd=True) if prev['live_bwd'] else None)
                         else:
                             fused = None
-                            self._conv(bwd, dpre, wd, dz, 3, 3, 1, 2 - pad, Cout, x_split=dsplit, brb=brb)
+                            self._conv(bwd, dpre, wd, dz, 3, 3, 1, 2 - pad, Cout, x_split=dsplit, brb=brb, x_out=dmat)
+                        if dmat is not None:
+                            emit_wgrad()
                         g = dz
                     elif dxin is not None:
                         wd = self._pack_conv_dgrad(cv['w'])
                         want = dxin_stats and self.FUSE_COLSUMS
                         dxin_part = self._conv(bwd, dpre, wd, dxin, 3, 3, 1, 2 - pad, xin.C,
                                                accumulate=1 if (do_res and not res_dgrad_last) else 0,
-                                               x_split=dsplit, stats=want and not res_dgrad_last, brb=brb)
+                                               x_split=dsplit, stats=want and not res_dgrad_last, brb=brb, x_out=dmat)
                         if res_dgrad_last:
                             dxin_part = self._conv(bwd, dout, self._pack_conv_dgrad(rw), dxin, 1, 1, 1, 0, xin.C,
                                                    accumulate=1, stats=want)
+                        if dmat is not None:
+                            emit_wgrad()
                     self._maybe_flush(bwd)
                 return dxin_part
             # pre-BatchNorm output of the block's last conv: what a producer of this block's dout needs for fused_in

@@ -20,7 +20,7 @@ trace = torch.zeros(12 << 16, dtype=torch.int64, device=DEV)
 os.environ['DFL_WGP_TRACE_PTR'] = hex(trace.data_ptr())
 
 
-def run(B, Cg, Cm, H, K, stride=1):
+def run(B, Cg, Cm, H, K, stride=1, fused=False):
     Ho = H if stride == 1 else H // 2
     pad = K // 2 if stride == 1 else 0
     g = torch.Generator().manual_seed(1)
@@ -33,6 +33,15 @@ def run(B, Cg, Cm, H, K, stride=1):
     a.N, a.Hin, a.Win, a.Cg, a.ldg = B, H, H, Cg, Cg
     a.KH, a.KW, a.stride, a.pad = K, K, stride, pad
     a.Hout, a.Wout, a.Cm, a.ldd = Ho, Ho, Cm, Cm
+    keep = []
+    if fused:            # the operand of the training step: BatchNorm + ReLU backward of (dy, r) formed in the staging path, affine on g
+        r = torch.randn(B, Ho, Ho, Cm, generator=g).to(DEV).to(BF)
+        coef = torch.randn(3 * Cm, generator=g).to(DEV)
+        bias = torch.empty(4096 * Cm, device=DEV)
+        sc, sh = torch.rand(Cg, generator=g).to(DEV) + 0.5, torch.randn(Cg, generator=g).to(DEV)
+        a.d2, a.ldd2, a.d_mode, a.coef, a.bias_partial = r.data_ptr(), Cm, 1, coef.data_ptr(), bias.data_ptr()
+        a.in_scale, a.in_shift = sc.data_ptr(), sh.data_ptr()
+        keep += [r, coef, bias, sc, sh]
     a.splits = 1
     s = nat.check(lib.dfl_wgrad_suggest_splits(C.addressof(a)), 'suggest')
     a.splits = s
@@ -58,7 +67,7 @@ def run(B, Cg, Cm, H, K, stride=1):
     tick = ((t[:, 8] - t[:, 7]).sum() * us) / max((t[:, 6] - t[:, 0]).sum(), 1)
     tot = (t[:, 6] - t[:, 0]) * tick
     byts = 2.0 * B * (H * H * Cg + Ho * Ho * Cm)
-    print('B%d g %dx%dx%d d %dx%dx%d k%d: %d WGs, kernel %.1f us (%.2f TB/s compulsory); per WG us: total %.1f (max %.1f) = barrier %.1f + LDS commit (incl. load wait) %.1f '
+    print(('fused ' if fused else 'plain ') + 'B%d g %dx%dx%d d %dx%dx%d k%d: %d WGs, kernel %.1f us (%.2f TB/s compulsory); per WG us: total %.1f (max %.1f) = barrier %.1f + LDS commit (incl. load wait) %.1f '
           '+ issue %.1f + k-steps %.1f + tail %.1f; before the first patch %.1f, output %.1f, first start -> last end %.1f us'
           % (B, H, H, Cg, Ho, Ho, Cm, K, len(t), e0.elapsed_time(e1) * 1e3, byts / (e0.elapsed_time(e1) * 1e-3) / 1e12, tot.mean(), tot.max(),
              t[:, 1].mean() * tick, t[:, 2].mean() * tick, t[:, 3].mean() * tick, t[:, 4].mean() * tick, (t[:, 6] - t[:, 5]).mean() * tick,
@@ -69,3 +78,5 @@ for (Cg, Cm, H, K, s) in ((32, 32, 192, 3, 1), (64, 32, 192, 3, 1), (64, 32, 192
                           (256, 128, 48, 3, 1), (256, 256, 24, 3, 1), (512, 256, 24, 3, 1), (512, 512, 12, 3, 1), (1024, 1024, 6, 3, 1), (32, 64, 192, 2, 2),
                           (256, 512, 24, 2, 2)):
     run(16, Cg, Cm, H, K, s)
+    if K == 3:
+        run(16, Cg, Cm, H, K, s, fused=True)

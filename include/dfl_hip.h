@@ -132,6 +132,13 @@ typedef struct {
    * arithmetic of dfl_bn_bwd_finalize. */
   const float* in_mean;
   const float* in_invstd;
+  /* x_mode = 1, 3x3 stride 1 (round 4): the operand the kernel forms while it stages its patches is ALSO written to x_out
+   * (bf16 [N][Hin][Win] pixels of ldxo elements, Cin channels; every element exactly once: a workgroup stores the interior of
+   * its patch, its K slice's channels, column tile 0 only) -- the layer's weight gradient then reads one plain tensor
+   * (dfl_wgrad_args.d_mode = 0 with bias_partial) instead of forming the same values again from (dy, r) in every (cm, cg) tile.
+   * NULL: nothing is written. */
+  void* x_out;
+  int32_t ldxo, reserved4;
 } dfl_conv_args;
 #define DFL_BN_R 8
 
@@ -182,7 +189,8 @@ typedef struct {
                             kernels take g_bf16 = 0, d_bf16 = 1) */
   /* BatchNorm + ReLU backward fused into the dense operand (bf16 patch kernels, d_mode = 1): d is dy, d2 the saved ReLU output
    * r (pixel stride ldd2), coef the [3][Cm] coefficients of dfl_bn_bwd_finalize (NULL: plain ReLU backward) and the operand is
-   * [r > 0] * (A*dy + B*r + C), as dfl_conv_args.x_mode.  bias_partial (optional): [splits][Cm] fp32 -- the column sums of that
+   * [r > 0] * (A*dy + B*r + C), as dfl_conv_args.x_mode.  bias_partial (optional; 3x3 bf16 patch kernel: with d_mode 0 as well --
+   * d is then the operand itself, materialised by dfl_conv_args.x_out): [splits][Cm] fp32 -- the column sums of the
    * operand over each pixel slice, i.e. the partial sums of the layer's BIAS gradient that dfl_bn_relu_bwd_apply used to leave. */
   int32_t d_mode;
   const float* d2;

@@ -89,8 +89,9 @@ def test_pack_bf16_chunk_layout():
 
 
 def conv_bf16(x, wp, Ntot, KH, KW, stride, pad, Hout, Wout, bias=None, in_aff=None, relu=0, add=None, add_aff=None,
-              y_init=None, accumulate=0, scatter=0, stats=False, stat_other=None, ldy=None, ldx_pad=0, force_splits=None, brb=None):
-    """x: NCHW fp32 cpu tensor (bf16-representable) -> dfl_conv2d with bf16 tensors -> y NHWC fp32 cpu tensor (+ stats)."""
+              y_init=None, accumulate=0, scatter=0, stats=False, stat_other=None, ldy=None, ldx_pad=0, force_splits=None, brb=None, x_out=False):
+    """x: NCHW fp32 cpu tensor (bf16-representable) -> dfl_conv2d with bf16 tensors -> y NHWC fp32 cpu tensor (+ stats).
+    x_out (with brb): also returns the operand tensor the kernel wrote (dfl_conv_args.x_out; NHWC with 8 channels of padding)."""
     lib = nat.lib()
     N, Cin, Hin, Win = x.shape
     xh = nhwc(x)
@@ -135,6 +136,10 @@ def conv_bf16(x, wp, Ntot, KH, KW, stride, pad, Hout, Wout, bias=None, in_aff=No
             cd = coef.to(DEV).contiguous()
             keep.append(cd)
             a.in_scale = cd.data_ptr()
+        if x_out:
+            xo = torch.full((N, Hin, Win, Cin + 8), float('nan'), device=DEV, dtype=BF)
+            keep.append(xo)
+            a.x_out, a.ldxo = xo.data_ptr(), Cin + 8
     a.N, a.Hin, a.Win, a.Cin, a.ldx = N, Hin, Win, Cin, Cin + ldx_pad
     a.KH, a.KW, a.stride, a.pad = KH, KW, stride, pad
     a.Hout, a.Wout, a.Ntot, a.ldy = Hout, Wout, Ntot, ldy
@@ -159,6 +164,8 @@ def conv_bf16(x, wp, Ntot, KH, KW, stride, pad, Hout, Wout, bias=None, in_aff=No
     nat.check(lib.dfl_conv2d(C.addressof(a), stream()), 'dfl_conv2d')
     torch.cuda.synchronize()
     y = yd.float().cpu()[..., :Cout]
+    if x_out:
+        return y, xo.float().cpu()
     return (y, part.cpu().double().sum(0)) if stats else y
 
 
@@ -407,7 +414,7 @@ def test_convp_transposed_scatter_and_data_gradients():
     close_bf16(du, nhwc(ref_du), 'dgrad convT')
 
 
-def wgrad_bf16(gx, d, KH, KW, stride, pad, Hout, Wout, in_aff=None, force_splits=None, brb=None):
+def wgrad_bf16(gx, d, KH, KW, stride, pad, Hout, Wout, in_aff=None, force_splits=None, brb=None, bias_plain=False):
     """gx: gathered tensor NCHW, d: dense NCHW (both bf16-representable) -> dw [Cm][Cg][KH][KW] fp32 (cpu)."""
     lib = nat.lib()
     N, Cg, Hin, Win = gx.shape
@@ -439,7 +446,7 @@ def wgrad_bf16(gx, d, KH, KW, stride, pad, Hout, Wout, in_aff=None, force_splits
     s = force_splits or nat.check(lib.dfl_wgrad_suggest_splits(C.addressof(a)), 'suggest')
     a.splits = s
     bias_part = None
-    if brb is not None:
+    if brb is not None or bias_plain:                   # (bias_plain: d is the operand itself, its column sums leave all the same)
         bias_part = torch.full((s, Cm), float('nan'), device=DEV)
         a.bias_partial = bias_part.data_ptr()
     n = Cm * Cg * KH * KW
@@ -452,7 +459,7 @@ def wgrad_bf16(gx, d, KH, KW, stride, pad, Hout, Wout, in_aff=None, force_splits
     if s > 1:
         nat.check(lib.dfl_sum_partials(part.data_ptr(), dw.data_ptr(), n, s, KH * KW, stream()), 'dfl_sum_partials')
     torch.cuda.synchronize()
-    if brb is not None:
+    if bias_part is not None:
         return dw.cpu(), bias_part.cpu().double().sum(0)
     return dw.cpu()
 
@@ -486,6 +493,12 @@ def test_fused_bn_relu_backward_operand(case, with_bn):
     for splits in (None, 2 if Cin >= 128 else None):
         y = conv_bf16(dy, pack16(w, 1), Cout, 3, 3, 1, 1, H, W, brb=(r, coef), force_splits=splits)
         close_bf16(y, nhwc(ref), 'x_mode %s splits %s' % (str(case), splits))
+        # x_out: the operand itself, written once by the kernel that forms it -- every element, BIT-EXACT, nothing beyond Cin
+        y2, xo = conv_bf16(dy, pack16(w, 1), Cout, 3, 3, 1, 1, H, W, brb=(r, coef), force_splits=splits, x_out=True)
+        assert torch.equal(y2, y)
+        assert torch.equal(xo[..., :Cin], nhwc(dpre)), 'x_out %s splits %s: %d elements differ' % (
+            str(case), splits, int((xo[..., :Cin] != nhwc(dpre)).sum()))
+        assert bool(torch.isnan(xo[..., Cin:]).all())
     # weight gradient with dpre as the dense operand + the bias gradient
     x = rb(torch.randn(N, Cout, H, W, generator=g))                  # the layer input (gathered operand), Cg = Cout here
     refb = dpre.double().sum(dim=(0, 2, 3))
@@ -496,6 +509,10 @@ def test_fused_bn_relu_backward_operand(case, with_bn):
         refw = torch.nn.grad.conv2d_weight(xa.double(), (Cin, Cout, 3, 3), dpre.double(), padding=1)
         np.testing.assert_allclose(dw.numpy(), refw.numpy(), rtol=2e-5, atol=3e-5 * float(refw.abs().max()))
         np.testing.assert_allclose(bias.numpy(), refb.numpy(), rtol=2e-5, atol=3e-5 * float(dpre.double().abs().sum(dim=(0, 2, 3)).max()))
+        # ... and from the materialised operand (d_mode 0 + bias_partial: what follows a data gradient with x_out)
+        dw2, bias2 = wgrad_bf16(x, dpre, 3, 3, 1, 1, H, W, in_aff=in_aff, bias_plain=True)
+        np.testing.assert_allclose(dw2.numpy(), refw.numpy(), rtol=2e-5, atol=3e-5 * float(refw.abs().max()))
+        np.testing.assert_allclose(bias2.numpy(), refb.numpy(), rtol=2e-5, atol=3e-5 * float(dpre.double().abs().sum(dim=(0, 2, 3)).max()))
 
 
 @pytest.mark.parametrize('case', [(2, 32, 20, 20, 1), (3, 16, 13, 9, 1), (1, 64, 4, 7, 1), (2, 32, 192, 192, 1), (2, 32, 12, 14, 0)])
@@ -960,3 +977,36 @@ def test_update_inside_the_weight_relayout_changes_nothing(key):
     for (k, _), pa, pc in zip(nets[0].named_parameters(), fa, fc):
         d = (pa - pc).abs().max().item()
         assert d <= 2e-6 * max(1.0, pc.abs().max().item()), (k, d)
+
+
+@pytest.mark.parametrize('key', ['paper__paper_sc_l14__b2', 'ragged__37x41__mp1', 'ragged__50x70__mp0'])
+def test_operand_written_by_the_data_gradient_changes_nothing(key):
+    """dfl_conv_args.x_out: the data-gradient kernel of a 3x3 layer writes the BatchNorm + ReLU backward operand it forms in its
+    staging path (every element once: patch interiors, K slices, column tile 0; bit-exact, test_fused_bn_relu_backward_operand)
+    and the layer's weight gradient reads that tensor (d_mode 0 + bias_partial) instead of forming the same bf16 values again
+    from (dy, r).  Same operands, same products; what differs is the ORDER of the fp32 sums over pixels (a plain operand
+    allows larger patches): the loss and every data gradient are bit-identical, the parameter gradients agree within fp32
+    summation noise -- with the switch at 'every layer', at its default (small tensors only) and off (SURVEY Appendix F:
+    unet.py:211-222 backward)."""
+    from dfl_amd import plan as P_
+    pr = PR.REGISTRY[key]()
+    res = {}
+    for name, mb in (('all', 1 << 40), ('default', None), ('off', 0)):
+        prev = P_.UNetPlan.DPRE_OUT_BYTES
+        if mb is not None:
+            P_.UNetPlan.DPRE_OUT_BYTES = mb
+        try:
+            net = hip_net(pr)
+            out, seg, loss = hip_step(pr, net)
+            plan = NF.train_plan(net)
+            nout = sum(1 for st in plan.bwd.structs if isinstance(st, nat.ConvArgs) and st.x_out)
+        finally:
+            P_.UNetPlan.DPRE_OUT_BYTES = prev
+        res[name] = dict(loss=loss.item(), nout=nout, grads={k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+    print('%s: layers whose data gradient writes the operand: all %d, default %d, off %d' % (key, res['all']['nout'], res['default']['nout'], res['off']['nout']))
+    assert res['off']['nout'] == 0 and res['all']['nout'] >= 2 and res['all']['nout'] >= res['default']['nout']
+    for name in ('all', 'default'):
+        assert res[name]['loss'] == res['off']['loss']
+        for k, v in res['off']['grads'].items():
+            d = float((res[name]['grads'][k] - v).double().norm()) / max(float(v.double().norm()), 1e-30)
+            assert d <= 2e-6, (name, k, d)
