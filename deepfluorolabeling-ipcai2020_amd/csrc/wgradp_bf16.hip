@@ -506,8 +506,13 @@ static int wgp_plan(const dfl_wgrad_args* a, WgP* p, bool need_out) {
       const char* e = getenv("DFL_WGP_SMALL_TILES");   // use 32 x 32 tiles from this many 64 x 64 tiles on (0: never)
       return e ? atoi(e) : 4;                          // (round 4: 16 -> 4, the same step time with 140 MB less partial sums per step)
     }();
+    static const int small_from21 = [] {
+      const char* e = getenv("DFL_WGP_SMALL_TILES21"); // ... for the 2x2 / 1x1 windows
+      return e ? atoi(e) : 4;
+    }();
     const int64_t tiles64 = ceil_div(a->Cm, 64) * ceil_div(a->Cg, 64);
-    if (small_from > 0 && a->Cm > 32 && a->Cg > 32 && tiles64 >= small_from && tiles64 < 256) p->CMT = p->CGT = 32;
+    const int from = a->KH == 3 ? small_from : small_from21;
+    if (from > 0 && a->Cm > 32 && a->Cg > 32 && tiles64 >= from && tiles64 < 256) p->CMT = p->CGT = 32;
   }
   p->pairs = (p->CMT / 32) * (p->CGT / 32);
   p->phases = 4 / p->pairs;
