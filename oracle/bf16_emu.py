@@ -378,6 +378,8 @@ class Bf16Emulation:
                 dpre = rb(mask * f32(v(A) * g + f32(v(B) * r + v(Cc))))       # two fp32 fused multiply-adds, then the bf16 rounding
             else:
                 dpre = mask * g
+            # (where the data-gradient kernel writes this operand for the weight gradient -- dfl_conv_args.x_out -- it is a stored tensor)
+            dpre = self._st('dmat:' + cv['rname'], dpre)
             G[cv['wname'] + '.bias'] = dpre.sum(dim=(0, 2, 3))
             want_in = d > 0 or need_dxin
             di, gw = _conv_bwd(dpre, cv['op'], cv['wq'], 1, self.pad, want_input=want_in)

@@ -26,6 +26,7 @@ import torch
 
 import dfl_amd
 from dfl_amd import plan as P
+from dfl_amd import _native as nat
 import noise_floor as NF
 import problems as PR
 from oracle import bf16_emu as E
@@ -93,6 +94,9 @@ def stepwise(pr, what=''):
         emu = E.Bf16Emulation(gc_net, dict(pr.cfg), teacher=teacher_of(plan, outs, [o.grad for o in outs]))
         res = emu.run(pr.x, pr.loss_of)
     rep = res['report']
+    # every operand tensor a data-gradient kernel wrote for its layer's weight gradient (dfl_conv_args.x_out) was compared
+    nout = sum(1 for st in plan.bwd.structs if isinstance(st, nat.ConvArgs) and st.x_out)
+    assert sum(1 for k in rep if k.startswith('dmat:')) == nout, (nout, [k for k in rep if k.startswith('dmat:')])
     rep['loss'] = {'kind': 'fp32', 'rel_l2': abs(loss.item() - res['loss']) / max(abs(res['loss']), 1e-12), 'max_rel': 0.0, 'n': 1}
     for k, p in net.named_parameters():
         e = res['grads'][k]
