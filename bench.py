@@ -72,6 +72,8 @@ def op_profile(plan, lib, nat, stream, detail=None):
                 by = esz * (st.N * st.Hin * st.Win * st.Cin + st.KH * st.KW * st.Cin * st.Ntot + M * st.Ntot)
                 if st.x_mode:               # the operand is formed from TWO tensors (dy and the saved ReLU output)
                     by += esz * st.N * st.Hin * st.Win * st.Cin
+                if st.x_out:                # ... and written once for the layer's weight gradient (dfl_conv_args.x_out)
+                    by += esz * st.N * st.Hin * st.Win * st.Cin
             elif isinstance(st, nat.WgradArgs):
                 cfg = lib.dfl_wgrad_config(C.addressof(st))
                 name = WGRAD_KERNELS[cfg] if cfg < 16 else 'wgradp_kernel<%s>' % ('3,3', '2,2', '1,1')[cfg - 16]

@@ -857,7 +857,7 @@ class UNetPlan:
                     # Small tensors (deep levels: many (cm, cg) tiles, each of which would form the operand again): the data-gradient
                     # kernel, which forms it anyway, writes it once (x_out) and the weight gradient -- emitted BEHIND it -- reads it
                     dmat = None
-                    if (fuse_brb and bool(inp.bf16) and not circ and not side and (d > 0 or dxin is not None)
+                    if (fuse_brb and bool(inp.bf16) and not circ and pad == 1 and not side and (d > 0 or dxin is not None)
                             and 'dmat' in self._scratch and r.M * Cout * 2 <= self.DPRE_OUT_BYTES):
                         dmat = self._scratch_act('dmat', N, r.H, r.W, Cout)
                         self.dbg['dmat:%s.block.%d' % (prefix, d * step + 1)] = dmat

@@ -979,7 +979,7 @@ def test_update_inside_the_weight_relayout_changes_nothing(key):
         assert d <= 2e-6 * max(1.0, pc.abs().max().item()), (k, d)
 
 
-@pytest.mark.parametrize('key', ['paper__paper_sc_l14__b2', 'ragged__37x41__mp1', 'ragged__50x70__mp0'])
+@pytest.mark.parametrize('key', ['paper__paper_sc_l14__b2', 'paper__paper_sc_l0__b4', 'ragged__37x41__mp1', 'ragged__50x70__mp0'])
 def test_operand_written_by_the_data_gradient_changes_nothing(key):
     """dfl_conv_args.x_out: the data-gradient kernel of a 3x3 layer writes the BatchNorm + ReLU backward operand it forms in its
     staging path (every element once: patch interiors, K slices, column tile 0; bit-exact, test_fused_bn_relu_backward_operand)
