@@ -239,6 +239,16 @@ __device__ __forceinline__ void st8c(float* base, int64_t elem, float* v) {
 #ifndef DFL_ROWS_WGRAD_RB
 #define DFL_ROWS_WGRAD_RB 4
 #endif
+#ifndef DFL_ROWS_CONV_BPB
+#define DFL_ROWS_CONV_BPB 3
+#endif
+#ifndef DFL_ROWS_WGRAD_BPB
+#define DFL_ROWS_WGRAD_BPB 1
+#endif
+// bands per workgroup of the 3x3 row forms (round 4).  Forward: 1 / 2 / 3 / 6 / 12 bands: 35 / 25 / 25 / 29 / 44 us (the 72 weights
+// of a thread are fetched once per workgroup).  Weight gradient: 1 / 2 / 3 / 4 / 6 bands: 40 / 47 / 55 / 66 / 83 us, and 2 / 3 rows per
+// band instead of 4: 64 / 63 us -- its threads wait for their own d / r loads pixel by pixel, workgroups are its parallelism
+constexpr int ROWS_CONV_BPB = DFL_ROWS_CONV_BPB, ROWS_WGRAD_BPB = DFL_ROWS_WGRAD_BPB;
 constexpr int ROWS_CONV_RB = DFL_ROWS_CONV_RB, ROWS_WGRAD_RB = DFL_ROWS_WGRAD_RB;   // (measured against 4 / 6 rows with four pixels in flight per thread and the
 // weights staged through LDS: 37 / 40 us here, 79 / 47 us there -- 184 registers halve the occupancy these short loops live on)
 
@@ -249,7 +259,6 @@ __global__ void __launch_bounds__(256) direct_conv3_rows_kernel(const dfl_conv_a
   const int q = threadIdx.x % cq, pl = threadIdx.x / cq;
   const int n0 = 8 * q;
   const int bands = (a.Hout + ROWS_CONV_RB - 1) / ROWS_CONV_RB;
-  const int n = blockIdx.x / bands, y0 = (blockIdx.x - n * bands) * ROWS_CONV_RB;
   float w[9][8], bias[8], s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -259,12 +268,19 @@ __global__ void __launch_bounds__(256) direct_conv3_rows_kernel(const dfl_conv_a
     s1[j] = 0.f;
     s2[j] = 0.f;
   }
+  // a workgroup walks ROWS_CONV_BPB bands: the 72 weights of a thread (73 dependent-free but serial scalar loads in front of
+  // six pixels of work) are fetched once for all of them
+  extern __shared__ float img_rows[];                 // [ROWS_CONV_RB + 2][Wout + 2]
+  const int RW = a.Wout + 2;
+  for (int bb = 0; bb < ROWS_CONV_BPB; ++bb) {
+  const int band = (int)blockIdx.x * ROWS_CONV_BPB + bb;
+  if (band >= a.N * bands) break;
+  const int n = band / bands, y0 = (band - n * bands) * ROWS_CONV_RB;
   const float* img = a.x + (int64_t)n * a.Hin * a.Win * a.ldx;
+  if (bb > 0) __syncthreads();                        // the previous band's rows have been read
   // the band's input rows (its output rows + the window's halo, zero outside the image) go to LDS once, coalesced: the per-pixel
   // gathers below then never wait for global memory (round 4: nine dependent 4-byte loads per pixel had made this 0.3 GFLOP kernel
   // 39 us long)
-  extern __shared__ float img_rows[];                 // [ROWS_CONV_RB + 2][Wout + 2]
-  const int RW = a.Wout + 2;
   for (int idx = threadIdx.x; idx < (ROWS_CONV_RB + 2) * RW; idx += 256) {
     const int r = idx / RW, c = idx - r * RW;
     const int iy = y0 - a.pad + r, ix = c - a.pad;
@@ -301,21 +317,26 @@ __global__ void __launch_bounds__(256) direct_conv3_rows_kernel(const dfl_conv_a
       }
     }
   }
-  if (a.stat_partials == nullptr && a.stat_totals == nullptr) return;
-  __syncthreads();
+  // statistics: one row per BAND (as when a workgroup took one band: the same sums in the same order, whatever ROWS_CONV_BPB)
+  if (a.stat_partials != nullptr || a.stat_totals != nullptr) {
+    __syncthreads();
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    red[0][threadIdx.x][j] = s1[j];
-    red[1][threadIdx.x][j] = s2[j];
+    for (int j = 0; j < 8; ++j) {
+      red[0][threadIdx.x][j] = s1[j];
+      red[1][threadIdx.x][j] = s2[j];
+      s1[j] = 0.f;
+      s2[j] = 0.f;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 2 * a.Ntot; idx += 256) {   // fixed order: bit-reproducible
+      const int which = idx / a.Ntot, c = idx - which * a.Ntot;
+      const int qq = c >> 3, j = c & 7;
+      float t = 0.f;
+      for (int p = 0; p < PL; ++p) t += red[which][p * cq + qq][j];
+      if (a.stat_totals != nullptr) bn_live_add(a.stat_totals, band, which, a.Ntot, c, t);     // live statistics (include/dfl_hip.h)
+      else a.stat_partials[((int64_t)band * 2 + which) * a.Ntot + c] = t;
+    }
   }
-  __syncthreads();
-  for (int idx = threadIdx.x; idx < 2 * a.Ntot; idx += 256) {   // fixed order: bit-reproducible
-    const int which = idx / a.Ntot, c = idx - which * a.Ntot;
-    const int qq = c >> 3, j = c & 7;
-    float t = 0.f;
-    for (int p = 0; p < PL; ++p) t += red[which][p * cq + qq][j];
-    if (a.stat_totals != nullptr) bn_live_add(a.stat_totals, (int)blockIdx.x, which, a.Ntot, c, t);     // live statistics (include/dfl_hip.h)
-    else a.stat_partials[((int64_t)blockIdx.x * 2 + which) * a.Ntot + c] = t;
   }
 }
 
@@ -333,22 +354,13 @@ __global__ void __launch_bounds__(256) direct_wgrad3_rows_kernel(const dfl_wgrad
   const int cq = a.Cm >> 3, PL = 256 / cq;
   const int q = threadIdx.x % cq, pl = threadIdx.x / cq;
   const int bands = (a.Hout + ROWS_WGRAD_RB - 1) / ROWS_WGRAD_RB;
-  const int n = blockIdx.x / bands, y0 = (blockIdx.x - n * bands) * ROWS_WGRAD_RB;
   float acc[9][8];
 #pragma unroll
   for (int k = 0; k < 9; ++k)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
-  const float* img = a.g + (int64_t)n * a.Hin * a.Win * a.ldg;
   extern __shared__ float img_rows[];                 // [ROWS_WGRAD_RB + 2][Wout + 2]: the band's input rows with halo (as the forward kernel)
   const int RW = a.Wout + 2;
-  for (int idx = threadIdx.x; idx < (ROWS_WGRAD_RB + 2) * RW; idx += 256) {
-    const int r = idx / RW, c = idx - r * RW;
-    const int iy = y0 - a.pad + r, ix = c - a.pad;
-    const bool ok = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
-    img_rows[idx] = ok ? img[(int64_t)(iy * a.Win + ix) * a.ldg] : 0.f;
-  }
-  __syncthreads();
   float cA[DB ? 8 : 1], cB[DB ? 8 : 1], cC[DB ? 8 : 1], bsum[DB ? 8 : 1];
   if constexpr (DB) {
     if (a.coef_tot != nullptr) {            // live statistics: one channel per thread into LDS (red is free until the end)
@@ -375,6 +387,21 @@ __global__ void __launch_bounds__(256) direct_wgrad3_rows_kernel(const dfl_wgrad
       }
     }
   }
+  // a workgroup walks ROWS_WGRAD_BPB bands (round 4): one coefficient table, one 72-value reduction tree and one partial slot
+  // for all of them
+  for (int bb = 0; bb < ROWS_WGRAD_BPB; ++bb) {
+  const int band = (int)blockIdx.x * ROWS_WGRAD_BPB + bb;
+  if (band >= a.N * bands) break;
+  const int n = band / bands, y0 = (band - n * bands) * ROWS_WGRAD_RB;
+  const float* img = a.g + (int64_t)n * a.Hin * a.Win * a.ldg;
+  if (bb > 0) __syncthreads();                        // the previous band's rows have been read
+  for (int idx = threadIdx.x; idx < (ROWS_WGRAD_RB + 2) * RW; idx += 256) {
+    const int r = idx / RW, c = idx - r * RW;
+    const int iy = y0 - a.pad + r, ix = c - a.pad;
+    const bool ok = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+    img_rows[idx] = ok ? img[(int64_t)(iy * a.Win + ix) * a.ldg] : 0.f;
+  }
+  __syncthreads();
 #pragma unroll
   for (int ry = 0; ry < ROWS_WGRAD_RB; ++ry) {
     const int y = y0 + ry;
@@ -401,6 +428,7 @@ __global__ void __launch_bounds__(256) direct_wgrad3_rows_kernel(const dfl_wgrad
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[k][j] = fmaf(xv[k], d[j], acc[k][j]);
     }
+  }
   }
   // lanes of one wave that share q (lane % cq): butterfly over the pixel lanes, then the four waves through LDS -- a fixed tree
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -470,7 +498,7 @@ bool direct_conv_ok(const dfl_conv_args* a) {
 }
 
 int direct_conv_blocks(const dfl_conv_args* a) {
-  if (direct_conv_rows_ok(a)) return a->N * (int)ceil_div(a->Hout, ROWS_CONV_RB);
+  if (direct_conv_rows_ok(a)) return a->N * (int)ceil_div(a->Hout, ROWS_CONV_RB);      // (bands: rows of stat_partials; ROWS_CONV_BPB of them per workgroup)
   const int64_t M = (int64_t)a->N * a->Hout * a->Wout;
   const int PL = 256 / (a->Ntot / 4);
   int64_t b = ceil_div(M, (int64_t)PL * 8);
@@ -483,8 +511,9 @@ int direct_conv_launch(const dfl_conv_args* a, hipStream_t s) {
   const int blocks = direct_conv_blocks(a);
   if (direct_conv_rows_ok(a)) {
     const size_t lds = (size_t)(ROWS_CONV_RB + 2) * (a->Wout + 2) * sizeof(float);
-    if (a->y_bf16) hipLaunchKernelGGL(direct_conv3_rows_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, s, *a);
-    else hipLaunchKernelGGL(direct_conv3_rows_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, s, *a);
+    const unsigned wgs = (unsigned)ceil_div(blocks, ROWS_CONV_BPB);
+    if (a->y_bf16) hipLaunchKernelGGL(direct_conv3_rows_kernel<true>, dim3(wgs), dim3(256), lds, s, *a);
+    else hipLaunchKernelGGL(direct_conv3_rows_kernel<false>, dim3(wgs), dim3(256), lds, s, *a);
     return check_launch("dfl_conv2d");
   }
   const int rpb = (int)ceil_div(M, blocks);
@@ -585,7 +614,7 @@ bool direct_wgrad_ok(const dfl_wgrad_args* a) {
 }
 
 int direct_wgrad_splits(const dfl_wgrad_args* a) {
-  if (direct_wgrad_rows_ok(a)) return a->N * (int)ceil_div(a->Hout, ROWS_WGRAD_RB);
+  if (direct_wgrad_rows_ok(a)) return (int)ceil_div((int64_t)a->N * ceil_div(a->Hout, ROWS_WGRAD_RB), ROWS_WGRAD_BPB);
   const int64_t M = (int64_t)a->N * a->Hout * a->Wout;
   const int PL = 256 / (a->Cm / 4);
   int64_t b = ceil_div(M, (int64_t)PL * 16);
