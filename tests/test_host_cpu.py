@@ -264,3 +264,19 @@ def test_missing_library_fails_loudly():
     env = dict(os.environ, DFL_LIB_OVERRIDE='/nonexistent/libdfl_hip.so')
     out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
     assert 'RAISED' in out.stdout and 'no fallback' in out.stdout, (out.stdout[-400:], out.stderr[-400:])
+
+
+def test_integration_doc_binding_matches_the_header_mirror():
+    """INTEGRATION.md shows the ctypes mirror of dfl_conv_args a maintainer of the reference would write: it has to be the
+    struct include/dfl_hip.h declares (same fields, same order, same size as dfl_amd._native.ConvArgs, whose size the library's
+    dfl_sizeof pins on the GPU box)."""
+    import ctypes as C
+    from dfl_amd import _native as nat
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    i = text.index('class ConvArgs(C.Structure)')
+    j = text.index('lib = C.CDLL', i)
+    ns = {'C': C}
+    exec(text[i:j], ns)
+    doc = ns['ConvArgs']
+    assert [f[0] for f in doc._fields_] == [f[0] for f in nat.ConvArgs._fields_]
+    assert C.sizeof(doc) == C.sizeof(nat.ConvArgs)
