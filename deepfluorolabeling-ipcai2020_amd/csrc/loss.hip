@@ -242,33 +242,49 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(const dfl_loss_args a) {
 }
 
 // ------------------------------------------------------------------------------------------------ ensemble
-__global__ void __launch_bounds__(256) ens_minmax_partial(const dfl_ensemble_args a, float* part, int nblk) {
-  __shared__ float rmin[256], rmax[256];
+// (round 4: one thread walked 1764 elements with two 64-bit divisions and ONE load in flight each -- 1.1 ms for the 577 MB of a
+// 1436 x 1436 five-net image.  Now a wave takes whole rows of the cropped window, eight 256-byte loads in flight per wave.)
+__global__ void __launch_bounds__(1024) ens_minmax_partial(const dfl_ensemble_args a, float* part, int nblk) {
+  __shared__ float rmin[16], rmax[16];
   const int net = blockIdx.y;
   const float* hp = a.heat_ptrs[net];
-  const int64_t hw = (int64_t)a.h * a.w, total = (int64_t)a.L * hw;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  const int rows = a.L * a.h;
   float mn = INFINITY, mx = -INFINITY;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)nblk * 256) {
-    const int l = (int)(i / hw);
-    const int64_t rem = i - (int64_t)l * hw;
-    const int y = (int)(rem / a.w), x = (int)(rem - (int64_t)y * a.w);
-    const float v = hp[((int64_t)l * a.Hp + a.oy + y) * a.Wp + a.ox + x];
-    mn = fminf(mn, v);
-    mx = fmaxf(mx, v);
-  }
-  rmin[threadIdx.x] = mn;
-  rmax[threadIdx.x] = mx;
-  __syncthreads();
-  for (int off = 128; off >= 1; off >>= 1) {
-    if ((int)threadIdx.x < off) {
-      rmin[threadIdx.x] = fminf(rmin[threadIdx.x], rmin[threadIdx.x + off]);
-      rmax[threadIdx.x] = fmaxf(rmax[threadIdx.x], rmax[threadIdx.x + off]);
+  for (int r = (int)blockIdx.x * nwave + wave; r < rows; r += nblk * nwave) {
+    const int l = r / a.h, y = r - l * a.h;
+    const float* row = hp + ((int64_t)l * a.Hp + a.oy + y) * a.Wp + a.ox;
+    for (int x0 = 0; x0 < a.w; x0 += 8 * 64) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int x = x0 + u * 64 + lane;
+        v[u] = x < a.w ? row[x] : row[0];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        mn = fminf(mn, v[u]);
+        mx = fmaxf(mx, v[u]);
+      }
     }
-    __syncthreads();
   }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    mn = fminf(mn, __shfl_xor(mn, off, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  }
+  if (lane == 0) {
+    rmin[wave] = mn;
+    rmax[wave] = mx;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
-    part[((int64_t)net * nblk + blockIdx.x) * 2 + 0] = rmin[0];
-    part[((int64_t)net * nblk + blockIdx.x) * 2 + 1] = rmax[0];
+    for (int w = 1; w < nwave; ++w) {
+      mn = fminf(mn, rmin[w]);
+      mx = fmaxf(mx, rmax[w]);
+    }
+    part[((int64_t)net * nblk + blockIdx.x) * 2 + 0] = mn;
+    part[((int64_t)net * nblk + blockIdx.x) * 2 + 1] = mx;
   }
 }
 
@@ -298,18 +314,44 @@ __global__ void __launch_bounds__(256) ens_minmax_final(const float* part, float
 
 // One thread per output pixel: mean over nets (summed in net order, then one division, as util.py:340-343,359),
 // first-maximum argmax (torch.max(dim=1), util.py:361), min-max normalised heat maps (util.py:348-356,370).
+constexpr int ENS_NU = 8;
 __global__ void __launch_bounds__(256) ens_final(const dfl_ensemble_args a) {
   const int64_t hw = (int64_t)a.h * a.w;
   const int64_t pHW = (int64_t)a.Hp * a.Wp;
   const float fn = (float)a.nnets;
+  const bool fast = a.nnets <= ENS_NU;
+  const float* sp[ENS_NU];
+  const float* hp[ENS_NU];
+  float hmn[ENS_NU], hmx[ENS_NU];
+#pragma unroll
+  for (int u = 0; u < ENS_NU; ++u) {                  // (nets beyond nnets alias the last one: loaded, never added)
+    const int k = u < a.nnets ? u : a.nnets - 1;
+    sp[u] = a.seg_ptrs[k];
+    hp[u] = a.heat_out != nullptr ? a.heat_ptrs[k] : nullptr;
+    hmn[u] = (a.heat_out != nullptr && !a.raw_heat) ? a.minmax[k * 2 + 0] : 0.f;
+    hmx[u] = (a.heat_out != nullptr && !a.raw_heat) ? a.minmax[k * 2 + 1] : 1.f;
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += (int64_t)gridDim.x * blockDim.x) {
     const int y = (int)(i / a.w), x = (int)(i - (int64_t)y * a.w);
     const int64_t po = (int64_t)(a.oy + y) * a.Wp + a.ox + x;
+    // (nnets <= ENS_NU, the scripts' case: the nets' base pointers sit in registers and the values of all nets are requested
+    // before the first is used -- with a run-time net count in the inner loop ONE load was in flight per thread.  Sums stay in net order.)
     float best = 0.f;
     int arg = 0;
     for (int c = 0; c < a.C; ++c) {
-      float s = a.seg_ptrs[0][c * pHW + po];
-      for (int k = 1; k < a.nnets; ++k) s += a.seg_ptrs[k][c * pHW + po];
+      float s;
+      if (fast) {
+        float v[ENS_NU];
+#pragma unroll
+        for (int u = 0; u < ENS_NU; ++u) v[u] = sp[u][c * pHW + po];
+        s = v[0];
+#pragma unroll
+        for (int u = 1; u < ENS_NU; ++u)
+          if (u < a.nnets) s += v[u];
+      } else {
+        s = a.seg_ptrs[0][c * pHW + po];
+        for (int k = 1; k < a.nnets; ++k) s += a.seg_ptrs[k][c * pHW + po];
+      }
       s = s / fn;
       if (a.avg_seg != nullptr) a.avg_seg[c * hw + i] = s;
       if (c == 0 || s > best) {
@@ -321,13 +363,27 @@ __global__ void __launch_bounds__(256) ens_final(const dfl_ensemble_args a) {
     if (a.heat_out != nullptr) {
       for (int l = 0; l < a.L; ++l) {
         float s = 0.f;
-        for (int k = 0; k < a.nnets; ++k) {
-          float v = a.heat_ptrs[k][l * pHW + po];
-          if (!a.raw_heat) {
-            const float mn = a.minmax[k * 2 + 0], mx = a.minmax[k * 2 + 1];
-            v = (v - mn) / (mx - mn);
+        if (fast) {
+          float v[ENS_NU];
+#pragma unroll
+          for (int u = 0; u < ENS_NU; ++u) v[u] = hp[u][l * pHW + po];
+#pragma unroll
+          for (int u = 0; u < ENS_NU; ++u) {
+            if (u < a.nnets) {
+              float t = v[u];
+              if (!a.raw_heat) t = (t - hmn[u]) / (hmx[u] - hmn[u]);
+              s = (u == 0) ? t : s + t;
+            }
           }
-          s = (k == 0) ? v : s + v;
+        } else {
+          for (int k = 0; k < a.nnets; ++k) {
+            float v = a.heat_ptrs[k][l * pHW + po];
+            if (!a.raw_heat) {
+              const float mn = a.minmax[k * 2 + 0], mx = a.minmax[k * 2 + 1];
+              v = (v - mn) / (mx - mn);
+            }
+            s = (k == 0) ? v : s + v;
+          }
         }
         a.heat_out[l * hw + i] = s / fn;
       }
@@ -373,7 +429,7 @@ extern "C" int dfl_ensemble_reduce(const dfl_ensemble_args* a, dfl_stream_t stre
     // the partial min/max rows live behind the final [nnets][2] table in the same scratch
     const int nblk = 64;
     float* part = a->minmax + 2 * a->nnets;
-    hipLaunchKernelGGL(ens_minmax_partial, dim3(nblk, (unsigned)a->nnets), dim3(256), 0, s, *a, part, nblk);
+    hipLaunchKernelGGL(ens_minmax_partial, dim3(nblk, (unsigned)a->nnets), dim3(1024), 0, s, *a, part, nblk);
     hipLaunchKernelGGL(ens_minmax_final, dim3((unsigned)a->nnets), dim3(256), 0, s, part, a->minmax, nblk);
   }
   int64_t blocks = ceil_div((int64_t)a->h * a->w, 256);
