@@ -122,11 +122,12 @@ class LateScalars:
         t = t.detach()
         if self.depth <= 0 or not t.is_cuda:
             return float(t.item())
-        if self._free:
-            buf, ev = self._free.pop()
+        hit = next((k for k, (b, _) in enumerate(self._free) if b.dtype == t.dtype), None)
+        if hit is not None:
+            buf, ev = self._free.pop(hit)
         else:
-            buf, ev = torch.empty(1, dtype=torch.float64).pin_memory(), torch.cuda.Event()
-        buf.copy_(t.reshape(1), non_blocking=True)      # dtype conversion on the device, then one 8-byte copy
+            buf, ev = torch.empty(1, dtype=t.dtype).pin_memory(), torch.cuda.Event()
+        buf.copy_(t.reshape(1), non_blocking=True)      # same dtype on both sides: one small device-to-host copy, no conversion kernel
         ev.record()
         self._slots.append((buf, ev))
         if len(self._slots) > self.depth:
