@@ -145,42 +145,66 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
   return r;
 }
 
-__global__ void __launch_bounds__(256) est_lands_kernel(const dfl_est_lands_args a) {
-  __shared__ double red[256];
-  __shared__ float bv[256];
-  __shared__ int bi[256];
-  const int l = blockIdx.x, b = blockIdx.y;
-  const int H = a.H, W = a.W;
-  const int64_t hw = (int64_t)H * W;
+// The arg-max pass (round 4: ONE workgroup per map walked it with one load in flight per thread -- 4.5 ms for the fourteen
+// 1436 x 1436 maps of an image on 14 of 256 CUs).  LM_SCAN_NB workgroups per map now, and the map's (row, col) output slot --
+// 8 bytes, zeroed by the launcher -- doubles as the meeting point: an unsigned 64-bit atomic max over
+// (order-preserving bits of the value) << 32 | (2^32 - 1 - flat index) keeps the largest value and, among equals, the lowest
+// index, exactly what the one-workgroup loop kept.  est_lands_kernel decodes the slot before it writes its answer there.
+constexpr int LM_SCAN_NB = 64;
+__device__ __forceinline__ unsigned lm_key(float v) {          // monotone in v (no NaN); +0 and -0 are the same value
+  if (v == 0.f) v = 0.f;
+  const unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float lm_unkey(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+__global__ void __launch_bounds__(256) est_lands_scan_kernel(const dfl_est_lands_args a) {
+  const int l = blockIdx.y, b = blockIdx.z;
+  const int64_t hw = (int64_t)a.H * a.W;
   const float* heat = a.heats + ((int64_t)b * a.L + l) * hw;
   const int want = (a.segs != nullptr && a.label_for_land != nullptr) ? a.label_for_land[l] : -1;
   const unsigned char* seg = (want >= 0) ? a.segs + (int64_t)b * hw : nullptr;
   float best = -INFINITY;
   int besti = 0x7fffffff;
-  for (int i = threadIdx.x; i < hw; i += 256) {
-    const float v = (seg == nullptr || seg[i] == want) ? heat[i] : -INFINITY;
-    if (v > best || (v == best && i < besti)) {
-      best = v;
-      besti = i;
+  constexpr int U = 8;
+  for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < hw; i0 += (int64_t)LM_SCAN_NB * 256 * U) {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + (int64_t)u * LM_SCAN_NB * 256;
+      v[u] = -INFINITY;
+      if (i < hw && (seg == nullptr || seg[i] == want)) v[u] = heat[i];
     }
-  }
-  bv[threadIdx.x] = best;
-  bi[threadIdx.x] = besti;
-  __syncthreads();
-  for (int off = 128; off >= 1; off >>= 1) {
-    if ((int)threadIdx.x < off) {
-      const float v = bv[threadIdx.x + off];
-      const int i = bi[threadIdx.x + off];
-      if (v > bv[threadIdx.x] || (v == bv[threadIdx.x] && i < bi[threadIdx.x])) {
-        bv[threadIdx.x] = v;
-        bi[threadIdx.x] = i;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = (int)(i0 + (int64_t)u * LM_SCAN_NB * 256);   // (ascending within a thread: '>' keeps the lowest index of equals)
+      if (v[u] > best) {
+        best = v[u];
+        besti = i;
       }
     }
-    __syncthreads();
   }
-  best = bv[0];
-  besti = bi[0];
-  __syncthreads();
+  // (every lane takes part in the butterflies: a lane without a candidate -- all of its values -inf or NaN -- carries key 0)
+  unsigned long long m = 0ull;
+  if (best > -INFINITY) m = ((unsigned long long)lm_key(best) << 32) | (unsigned long long)(0xffffffffu - (unsigned)besti);
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned long long o = __shfl_xor(m, off, 64);
+    m = o > m ? o : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m != 0ull) atomicMax(reinterpret_cast<unsigned long long*>(a.rowcol) + (int64_t)b * a.L + l, m);
+}
+
+__global__ void __launch_bounds__(256) est_lands_kernel(const dfl_est_lands_args a) {
+  __shared__ double red[256];
+  const int l = blockIdx.x, b = blockIdx.y;
+  const int H = a.H, W = a.W;
+  const int64_t hw = (int64_t)H * W;
+  const float* heat = a.heats + ((int64_t)b * a.L + l) * hw;
+  const unsigned long long key = reinterpret_cast<const unsigned long long*>(a.rowcol)[(int64_t)b * a.L + l];
+  const float best = key != 0ull ? lm_unkey((unsigned)(key >> 32)) : -INFINITY;
+  const int besti = key != 0ull ? (int)(0xffffffffu - (unsigned)(key & 0xffffffffull)) : 0x7fffffff;
+  __syncthreads();                                     // (every thread has read the slot before thread 0 writes the answer into it)
   int* out = a.rowcol + ((int64_t)b * a.L + l) * 2;
   float* ncc_out = (a.ncc != nullptr) ? a.ncc + (int64_t)b * a.L + l : nullptr;
   if (!(best > -INFINITY)) {   // nothing inside the label (or an all -inf / NaN map)
@@ -242,8 +266,14 @@ extern "C" int dfl_est_lands(const dfl_est_lands_args* a, dfl_stream_t stream) {
   DFL_REQUIRE(a->B > 0 && a->L > 0 && a->H > dfl::LM_R && a->W > dfl::LM_R, "dfl_est_lands: maps must be larger than the 12-pixel reflect border");
   DFL_REQUIRE((int64_t)a->H * a->W < (1ll << 31), "dfl_est_lands: map too large");
   DFL_REQUIRE(a->sigma > 0.f, "dfl_est_lands: sigma");
-  hipLaunchKernelGGL(dfl::est_lands_kernel, dim3((unsigned)a->L, (unsigned)a->B), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), *a);
+  DFL_REQUIRE((reinterpret_cast<uintptr_t>(a->rowcol) & 7) == 0, "dfl_est_lands: rowcol must be 8-byte aligned");
+  hipStream_t hs = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(a->rowcol, 0, (size_t)a->B * a->L * 8, hs) != hipSuccess) {
+    dfl::set_error("dfl_est_lands: hipMemsetAsync failed");
+    return DFL_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(dfl::est_lands_scan_kernel, dim3((unsigned)dfl::LM_SCAN_NB, (unsigned)a->L, (unsigned)a->B), dim3(256), 0, hs, *a);
+  hipLaunchKernelGGL(dfl::est_lands_kernel, dim3((unsigned)a->L, (unsigned)a->B), dim3(256), 0, hs, *a);
   return dfl::check_launch("dfl_est_lands");
 }
 
