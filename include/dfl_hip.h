@@ -578,7 +578,7 @@ typedef struct {
   const float* heats;             /* [B][L][H][W] */
   const unsigned char* segs;      /* [B][H][W] labels or NULL */
   const int32_t* label_for_land;  /* [L] or NULL */
-  int32_t* rowcol;                /* [B][L][2] */
+  int32_t* rowcol;                /* [B][L][2], 8-byte aligned: a map's slot is also where the workgroups of its arg-max pass meet (64-bit atomic max) before the answer is written there */
   float* ncc;                     /* [B][L] correlation at the arg-max (0 where none), or NULL */
   int32_t B, L, H, W;
   float sigma, min_ncc;
