@@ -206,7 +206,9 @@ def test_dataset(ds, net, dev=None, num_lands=0, shard=None):
     dev = dev if dev is not None else next(net.parameters()).device
     crit = DiceAndHeatMapLoss2D(skip_bg=False) if num_lands > 0 else DiceLoss2D(skip_bg=False)
     rank, world = shard if shard is not None else (0, 1)
-    losses = torch.zeros(len(ds))
+    # (the reference reads loss.item() per image, util.py:156: a host round trip with the GPU idle behind every image; the
+    # values are kept on the device and read once after the loop -- same numbers, same order)
+    losses_dev = torch.zeros(len(ds), dtype=torch.float32, device=dev)
     count = 0
     with torch.no_grad():
         net.eval()
@@ -220,8 +222,9 @@ def test_dataset(ds, net, dev=None, num_lands=0, shard=None):
                 loss = crit((seg, center_crop(heat, heats.shape)), (masks, heats))
             else:
                 loss = crit(seg, masks)
-            losses[i] = loss.item()
+            losses_dev[i] = loss
             count += 1
+    losses = losses_dev.cpu()
     assert count == len(range(rank, len(ds), world))
     if world > 1:
         import torch.distributed as dist
@@ -247,7 +250,7 @@ def test_dataset_ensemble(ds, nets, dev=None, num_lands=0, dice_only=False):
     dev = dev if dev is not None else next(nets[0].parameters()).device
     use_heat = (not dice_only) and num_lands > 0
     crit = DiceAndHeatMapLoss2D(skip_bg=False) if use_heat else DiceLoss2D(skip_bg=False)
-    losses = torch.zeros(len(ds))
+    losses_dev = torch.zeros(len(ds), dtype=torch.float32, device=dev)      # (read once after the loop, see test_dataset)
     count = 0
     with torch.no_grad():
         for n_ in nets:
@@ -263,8 +266,9 @@ def test_dataset_ensemble(ds, nets, dev=None, num_lands=0, dice_only=False):
                 loss = crit((avg_seg.unsqueeze(0), avg_heat.unsqueeze(0)), (masks, heats))
             else:
                 loss = crit(avg_seg.unsqueeze(0), masks)
-            losses[i] = loss.item()
+            losses_dev[i] = loss
             count += 1
+    losses = losses_dev.cpu()
     assert count == len(ds)
     return torch.mean(losses), torch.std(losses)
 
