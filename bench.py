@@ -33,7 +33,22 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0        # same guide: dense bf16 MFMA (the 5 PF ma
 HBM_PEAK_GBS = 8000.0                 # same guide: HBM3E, 8 TB/s
 # product arithmetic of the GEMM kernels (include/dfl_hip.h): name -> (mode, bf16 MFMA products per fp32 product)
 MATH = {'fp32': (0, 0), 'bf16x3': (1, 3), 'bf16x6': (2, 6), 'bf16': (3, 1), 'bf16s': (4, 1)}
-TRAFFIC_FILE = 'r04_traffic.json'      # per-kernel HBM bytes from the committed rocprofv3 --pmc passes of this round
+TRAFFIC_FILES = ['r05_traffic.json', 'r04_traffic.json']   # per-kernel HBM bytes from committed rocprofv3 --pmc passes, newest first
+
+
+def csrc_sha16():
+    """Hash of the kernel sources: a committed traffic figure is quoted as current only when the kernels it was measured on
+    are the kernels of this tree (the line must not quote stale bytes silently)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'deepfluorolabeling-ipcai2020_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.h', '.inc')):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
 CONV_KERNELS = ['conv_gemm_kernel<2,2,2,2>', 'conv_gemm_kernel<2,2,2,1>', 'conv_gemm_kernel<4,1,2,1>',
                 'conv_gemm_kernel<2,2,1,1>', 'conv_gemm_kernel<1,2,1,1>', 'direct_conv_kernel',
                 'conv_rows_kernel<3,1,2,1>', 'conv_rows_kernel<3,1,1,2>', 'conv_rows_kernel<3,1,1,1>']
@@ -215,7 +230,7 @@ def _cpu_steps(net, opt, x, tseg, theat, warm, steps, R):
 def cpu_baseline(B):
     """The oracle (CPU restatement of the reference, checked against it in tests/test_oracle_golden.py) on this box's
     host cores: the same step body (train.py:405-430), PyTorch CPU fp32.  Thread count: swept over 8 / 16 / 32 / 64
-    threads on short runs of BASELINE configs[0] (batch 4, segmentation head only), the best one is used for 10 timed steps
+    threads on short runs of BASELINE configs[0] (batch 4, segmentation head only), the best one is used for 5 timed steps
     of configs[0] and for a bounded sample of the batch-`B` dual-head workload the GPU line is quoted on."""
     from oracle import ref_cpu as R
     prev = torch.get_num_threads()
@@ -335,6 +350,19 @@ def main():
                     help='keep the collective path on in a one-rank group (self-test of the RCCL path on a 1-GPU box)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and 'RANK' not in os.environ:
+        # `python bench.py --gpus N` as typed: become the launcher the contract names (one rank per GPU, rendezvous on
+        # 127.0.0.1); rank 0 of the relaunched job prints the one JSON line on this process's stdout
+        import socket
+        with socket.socket() as so:
+            so.bind(('127.0.0.1', 0))
+            port = so.getsockname()[1]
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
+
     import dfl_amd
     from dfl_amd import _native as nat
     from dfl_amd.parallel import DataParallel, init_process_group_from_env
@@ -344,7 +372,7 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit('--gpus %d does not match WORLD_SIZE %d' % (args.gpus, world))
     if args.gpus > 1 and world == 1:
-        raise SystemExit('launch with torch.distributed.run for --gpus > 1')
+        raise SystemExit('--gpus %d inside a one-rank group (WORLD_SIZE / RANK are set: launched by hand?)' % args.gpus)
     dev = torch.device('cuda', local % torch.cuda.device_count())   # (gloo self-test: several ranks may share a GPU)
     torch.cuda.set_device(dev)
     lib = nat.lib()
@@ -427,15 +455,22 @@ def main():
         name, (ms, fl, n, by) = max(groups.items(), key=lambda kv: kv[1][0])
         # HBM bytes per launch of that kernel come from the separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE;
         # tools/profile_round.sh), which cannot run inside this process; the committed summary is quoted when present
-        tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', TRAFFIC_FILE)
-        if os.path.exists(tfile):
+        for tname in TRAFFIC_FILES:
+            tfile = os.path.join(ROOT, 'profiles', tname)
+            if not os.path.exists(tfile):
+                continue
             try:
-                rec = json.load(open(tfile))['kernels'].get(name)
+                tj = json.load(open(tfile))
+                rec = tj['kernels'].get(name)
                 if rec:
+                    current = tj.get('csrc_sha16') == csrc_sha16()
                     roofline['traffic'] = rec['hbm_bytes_per_launch']
                     roofline['hbm_frac_traffic'] = round(rec['hbm_bytes_per_launch'] / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                     roofline['traffic_unit'] = 'HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB, rocprofv3 PMC passes of ' \
-                                               'the same command (profiles/%s)' % TRAFFIC_FILE
+                                               'the same command (profiles/%s)' % tname
+                    roofline['traffic_measured_in'] = tj.get('round', tname.split('_')[0])
+                    roofline['traffic_kernels_unchanged_since'] = bool(current)   # False: csrc/ changed after the PMC passes
+                    break
             except (ValueError, KeyError):
                 pass
         fl_all = sum(v[1] for v in groups.values())

@@ -159,10 +159,6 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
 #pragma unroll
     for (int r = 0; r < QA; ++r)
       a_rowb[r] = (uint32_t)((((int64_t)a_base[r] + (int64_t)a_iy0[r] * Win + a_ix0[r]) * a.ldx + 4 * aq) * 4);
-#ifdef DFL_EXP_SMALLA   // diagnosis: every gather row inside one small window (L2- or L1-resident), same access shape
-#pragma unroll
-    for (int r = 0; r < QA; ++r) a_rowb[r] = (a_rowb[r] & (uint32_t)(DFL_EXP_SMALLA - 1)) + 65536u;
-#endif
 #pragma unroll
     for (int r = 0; r < QB; ++r) {
       const int idx = tid + r * NT;
@@ -185,11 +181,7 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
   // Straight-line code: a chunk past the end of the slice is fetched with out-of-range offsets (reads zeros), so the
   // main loop has no conditional loads and the compiler can keep the younger set in flight across the LDS write.
   auto load_AB = [&](int ch, int set) {
-#ifdef DFL_EXP_NOLOAD   // diagnosis builds (docs/experiments/loop_bounds.sh): which resource the loop waits for; results are wrong
-    const bool live = ch < ch_end && ch < ch_begin + 2;   // later chunks: out-of-range offsets, no memory traffic
-#else
     const bool live = ch < ch_end;
-#endif
     if constexpr (MODE == 1) {
       // must be called once per chunk, in order: uses and advances the uniform cursor
       const bool kvalid = live && cur_tap < T;
@@ -313,9 +305,6 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
       }
     }
     float* Bb = Bs + buf * IMB;
-#ifdef DFL_EXP_BDIRECT   // diagnosis: what the loop would cost if the weight fragments never went through LDS
-    if constexpr (MATH != 0) return;
-#endif
 #pragma unroll
     for (int r = 0; r < QB; ++r) {
       const int idx = tid + r * NT;
@@ -363,11 +352,7 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
           ap[i][q] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Ab + i * 256 + q * PLA));
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-#ifdef DFL_EXP_BDIRECT
-          bp[j][q] = __builtin_bit_cast(bf16x8_t, rb[buf ^ 1][0]);
-#else
           bp[j][q] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Bb + j * 256 + q * PLB));
-#endif
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -377,11 +362,7 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
           for (int o = NP - 1; o >= 0; --o)   // order o = qa + qb, small terms first
 #pragma unroll
             for (int qa = 0; qa <= o; ++qa)
-#ifdef DFL_EXP_NOMFMA
-              acc[i][j][0] += (float)ap[i][qa][0] + (float)bp[j][o - qa][0];   // keeps the fragment reads alive
-#else
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][qa], bp[j][o - qa], acc[i][j], 0, 0, 0);
-#endif
       return;
     }
 #pragma unroll
@@ -444,11 +425,7 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
 #else
 #define TR_MARK(i)
 #endif
-#ifdef DFL_EXP_NOBAR
-#define LOOP_SYNC()
-#else
 #define LOOP_SYNC() __syncthreads()
-#endif
   for (int ch = ch_begin; ch < ch_end; ch += 2) {
 #ifdef DFL_CONV_TRACE
     long long tlast = __builtin_amdgcn_s_memtime();

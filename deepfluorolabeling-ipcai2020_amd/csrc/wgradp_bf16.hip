@@ -108,13 +108,13 @@ __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const
     const int gx = gridDim.x, gy = gridDim.y, nt = gx * gy;
     const int total = nt * (int)gridDim.z, per = total >> 3;
     const int L = bx + gx * (by + gy * bz);
-    if (L < (per << 3)) {
-      const int Lp = (L & 7) * per + (L >> 3);
-      bz = Lp / nt;
-      const int t = Lp - bz * nt;
-      bx = t / gy;                                            // cg tile fastest: the (larger) d patch stays in L2 across them
-      by = t - bx * gy;
-    }
+    // (the tail L >= 8 * per keeps its number but is decoded like the rest: with the hardware's decode there the map was
+    //  not a bijection for gx, gy > 1 and total % 8 != 0 -- ADVICE r04)
+    const int Lp = L < (per << 3) ? (L & 7) * per + (L >> 3) : L;
+    bz = Lp / nt;
+    const int t = Lp - bz * nt;
+    bx = t / gy;                                              // cg tile fastest: the (larger) d patch stays in L2 across them
+    by = t - bx * gy;
   }
   const int cm0 = bx * p.CMT, cg0 = by * p.CGT;
   unsigned char* Ds = smem;

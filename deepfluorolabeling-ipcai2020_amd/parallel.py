@@ -114,6 +114,10 @@ class DataParallel:
         with torch.no_grad():
             for b in self.net.buffers():
                 dist.broadcast(b, src=src, group=self.group)
+        # collectives write the buffers without a version bump: inference plans keep scale / shift derived from them in
+        # their pack program and must derive them again
+        if hasattr(self.net, '_bn_epoch'):
+            self.net._bn_epoch += 1
 
     # -------------------------------------------------------------------------------------------------------
     def _segments(self, plan):

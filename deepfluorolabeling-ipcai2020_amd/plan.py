@@ -1276,6 +1276,13 @@ class UNetPlan:
         self._side_join(bwd)
         if self._tot_bwd[0] is not None:
             bwd.insert(0, MemsetArgs(ptr=self._tot_bwd[0].data_ptr(), bytes=8 * self._tot_bwd[1]))
+            # every op index recorded while the program was emitted moved up by one (the flushes' indices
+            # stayed behind and data-parallel buckets were cut one op early)
+            self._red_flushes = [(idx + 1, dsts) for idx, dsts in self._red_flushes]
+            for e in self._side:
+                e['op'] += 1
+                if e['waited'] is not None:
+                    e['waited'] += 1
         self._order_pack_jobs()
         self._finish_pack()
         # index of the last backward op that writes each parameter gradient (data-parallel bucket scheduling)

@@ -104,13 +104,19 @@ class SGD(Optimizer):
         if any(ptrs.get(s) != n for s, n in tiled_src.items()):
             return None                      # a tiled parameter without a gradient (or a view of one): not this path
         plain, cur = [], None                # what has no tiled layout, adjacent slices merged (alignment padding absorbed)
+        flat = getattr(net, '_param_flat', None)
+        lo = flat.data_ptr() if flat is not None else 0
+        hi = lo + 4 * flat.numel() if flat is not None else 0
+
+        def in_arena(ptr):                   # only slices of the network's own flat arena are merged across a gap
+            return lo <= ptr < hi
         for p in live:
             pp, n = p.data_ptr(), p.numel()
             if pp in tiled_src:
                 cur = None
                 continue
-            if cur is not None and 0 <= pp - cur[0] - 4 * cur[1] <= 12:
-                cur[1] = (pp - cur[0]) // 4 + n
+            if cur is not None and 0 <= pp - cur[0] - 4 * cur[1] <= 12 and in_arena(cur[0]) and in_arena(pp):
+                cur[1] = (pp - cur[0]) // 4 + n          # (the gap is the arena's alignment padding: nobody else's memory)
             else:
                 cur = [pp, n]
                 plain.append(cur)

@@ -1,5 +1,6 @@
 # What does the bf16x3 GEMM loop wait for?  Times one level-2 layer with diagnosis builds that remove one resource each
-# (results are wrong, only the time matters).  Build first (CPU box):
+# (results are wrong, only the time matters).  The DFL_EXP_* branches left csrc/conv_gemm.hip in round 5: apply
+# docs/experiments/conv_gemm_loop_bounds_r02.diff (patch -p0 -R style: it is product -> diagnosis) first.  Build (CPU box):
 #   for v in NOLOAD NOMFMA NOBAR; do docs/experiments/build_variant.sh $v -DDFL_EXP_$v; done
 #   docs/experiments/build_variant.sh NOLOAD_NOBAR -DDFL_EXP_NOLOAD -DDFL_EXP_NOBAR ; ... (any combination)
 # Run (GPU box): bash docs/experiments/loop_bounds.sh

@@ -572,6 +572,7 @@ WCASES = [
     (2, 32, 64, 12, 10, 2, 2, 0),      # 2x2 stride 2
     (2, 32, 32, 96, 96, 3, 1, 1),      # wide image: row patches, many pixel slices
     (2, 64, 64, 40, 300, 3, 1, 1),     # rows longer than a patch
+    (2, 96, 96, 12, 12, 3, 1, 1),      # 3 x 3 tiles: with 2 slices the XCD-aware order has a tail (18 workgroups)
 ]
 
 
@@ -587,7 +588,7 @@ def test_wgradp(case):
     scale = float(ref.abs().max())
     np.testing.assert_allclose(dw.numpy(), ref.numpy(), rtol=2e-5, atol=3e-5 * scale)
     if K == 3:      # one slot (direct torch-order store) and an explicit slice count
-        for s in (1, 3):
+        for s in (1, 2, 3):
             if Cm > 32 and Cg > 32 or s > 1:
                 dws = wgrad_bf16(x, d, K, K, stride, pad, Ho, Wo, force_splits=s)
                 np.testing.assert_allclose(dws.numpy(), ref.numpy(), rtol=2e-5, atol=3e-5 * scale)
