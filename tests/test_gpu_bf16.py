@@ -594,16 +594,33 @@ def test_wgradp(case):
                 np.testing.assert_allclose(dws.numpy(), ref.numpy(), rtol=2e-5, atol=3e-5 * scale)
 
 
-def test_wgradp_affine_on_load():
-    g = torch.Generator().manual_seed(4)
-    N, Cg, Cm, H, W = 2, 64, 32, 14, 10
+@pytest.mark.parametrize('case', [
+    # N, Cg, Cm, H, W
+    (2, 64, 32, 14, 10),
+    (3, 32, 64, 9, 21),        # ragged: width not a multiple of 8, odd height
+    (2, 128, 64, 24, 24),      # several cg tiles, whole-image patches
+    (16, 64, 64, 6, 6),        # several images per patch, every pixel on a border
+    (1, 32, 32, 70, 40),       # interior patches, border patches of all nine kinds
+    (2, 96, 96, 12, 12),
+])
+def test_wgradp_affine_on_load(case):
+    """BatchNorm affine of the gathered operand, applied while the patch is staged: the operand is bf16(fma(x, scale, shift)) inside
+    the image and zero outside (the padding is applied to the BatchNorm output, unet.py:214-222) -- ragged widths, whole-image
+    patches, images that are all border."""
+    N, Cg, Cm, H, W = case
+    g = torch.Generator().manual_seed(4 + sum(case))
     x = rb(torch.randn(N, Cg, H, W, generator=g))
-    d = rb(torch.randn(N, Cm, H, W, generator=g))
+    d = rb(torch.randn(N, Cm, H, W, generator=g) + 0.25)
     sc, sh = torch.rand(Cg, generator=g) + 0.5, torch.randn(Cg, generator=g) * 0.3
-    xa = rb(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
-    dw = wgrad_bf16(x, d, 3, 3, 1, 1, H, W, in_aff=(sc, sh))
+    xa = rb((x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)).float())     # fmaf: one rounding to fp32, then bf16
     ref = torch.nn.grad.conv2d_weight(xa.double(), (Cm, Cg, 3, 3), d.double(), padding=1)
+    for s in (None, 1, 3):
+        dw = wgrad_bf16(x, d, 3, 3, 1, 1, H, W, in_aff=(sc, sh), force_splits=s)
+        np.testing.assert_allclose(dw.numpy(), ref.numpy(), rtol=2e-5, atol=3e-5 * float(ref.abs().max()))
+    dw, bias = wgrad_bf16(x, d, 3, 3, 1, 1, H, W, in_aff=(sc, sh), bias_plain=True)
     np.testing.assert_allclose(dw.numpy(), ref.numpy(), rtol=2e-5, atol=3e-5 * float(ref.abs().max()))
+    refb = d.double().sum(dim=(0, 2, 3))
+    np.testing.assert_allclose(bias.double().numpy(), refb.numpy(), rtol=2e-5, atol=3e-5 * float(d.double().abs().sum(dim=(0, 2, 3)).max()))
 
 
 def test_streaming_kernels_bf16():
