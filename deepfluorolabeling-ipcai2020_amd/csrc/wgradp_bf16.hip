@@ -407,25 +407,47 @@ __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const
         }
       }
     }
-    if (phase > 0) return;
+    if (phase > 0 && p.zslices > 1) return;
   }
 #ifdef DFL_WGP_TRACE
   const long long tr_main_end = __builtin_amdgcn_s_memtime();
 #endif
-  // ---- output: one partial slot per pixel slice
+  // ---- output
   const bool sliced = p.zslices > 1;
-  float* out = sliced ? a.partial + (int64_t)bz * a.Cm * a.Cg * T : a.dw;
-  const int cg = cg0 + pn * 32 + li;
+  const int cgl = pn * 32 + li, cg = cg0 + cgl;
+  if (sliced) {
+    // one partial slot per pixel slice, tap-major [t][cm][cg]: every accumulator row is a 128-byte store
+    float* out = a.partial + (int64_t)bz * a.Cm * a.Cg * T;
 #pragma unroll
-  for (int tx = 0; tx < KW; ++tx) {
-    const int t = ty * KW + tx;
+    for (int tx = 0; tx < KW; ++tx) {
+      const int t = ty * KW + tx;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int cm = cm0 + pm * 32 + mfma32_row(r, lane);
-      if (cm < a.Cm && cg < a.Cg) {
-        const int64_t o = sliced ? ((int64_t)t * a.Cm + cm) * a.Cg + cg : ((int64_t)cm * a.Cg + cg) * T + t;
-        out[o] = acc[tx][r];
+      for (int r = 0; r < 16; ++r) {
+        const int cm = cm0 + pm * 32 + mfma32_row(r, lane);
+        if (cm < a.Cm && cg < a.Cg) out[((int64_t)t * a.Cm + cm) * a.Cg + cg] = acc[tx][r];
       }
+    }
+  } else {
+    // a single slot writes dw in torch's order [cm][cg][t] (a 4-byte store every T * 4 bytes from the accumulators: 13 - 17 us for
+    // a 64 x 64 x 9 tile, round 5 phase clocks): the tile goes through LDS ([cm][cg][T] floats -- the T * CGT floats of a cm row are
+    // contiguous in dw as well) and leaves in 16-byte stores by all threads
+    __syncthreads();                                      // images and reduction scratch have been read
+    float* tile = reinterpret_cast<float*>(smem);
+    if (phase == 0) {
+#pragma unroll
+      for (int tx = 0; tx < KW; ++tx) {
+        const int t = ty * KW + tx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tile[((pm * 32 + mfma32_row(r, lane)) * p.CGT + cgl) * T + t] = acc[tx][r];
+      }
+    }
+    __syncthreads();
+    const int row4 = p.CGT * T / 4;                       // float4 per cm row of the tile
+    const int valid4 = min(p.CGT, a.Cg - cg0) * T / 4;    // (Cg % 8 == 0: whole float4)
+    for (int idx = tid; idx < p.CMT * row4; idx += NT) {
+      const int row = idx / row4, c4 = idx - row * row4;
+      if (cm0 + row < a.Cm && c4 < valid4)
+        *reinterpret_cast<float4*>(a.dw + ((int64_t)(cm0 + row) * a.Cg + cg0) * T + c4 * 4) = *reinterpret_cast<const float4*>(tile + (row * p.CGT) * T + c4 * 4);
     }
   }
 #ifdef DFL_WGP_TRACE
@@ -691,6 +713,7 @@ int wgradp_launch(const dfl_wgrad_args* a, hipStream_t s) {
   if (rc != DFL_OK) return rc;
   p.zslices = a->splits;                     // partial slots = pixel slices
   p.patches_per_slice = (int)ceil_div(p.npatch, p.zslices);
+  if (p.zslices == 1 && p.lds_bytes < p.CMT * p.CGT * p.T * 4) p.lds_bytes = p.CMT * p.CGT * p.T * 4;   // the output tile of the torch-order store
 #ifdef DFL_WGP_TRACE
   {
     const char* e = getenv("DFL_WGP_TRACE_PTR");
