@@ -801,14 +801,8 @@ constexpr size_t kLdsSoft = 64 * 1024, kLdsHard = 150 * 1024;
 // Row blocks of convp_finish_kernel = rows of stat_partials the following finalize kernel has to read.  Few (<= FIN_ROWS) and
 // the finalize launch reads a few hundred KB instead of up to 4.7 MB (one row per 1-2 GEMM rows on the deep levels: its
 // 10-12 us there against 5-6 us elsewhere); the finish kernel keeps its parallelism through narrow column blocks (FIN_TX).
-static const int FIN_ROWS = [] {
-  const char* e = getenv("DFL_CONVP_FIN_ROWS");
-  return e ? atoi(e) : 128;                    // (measured 2048 / 512 / 256 / 128 rows: 4.89 / 4.88 / 4.865 / 4.85 ms per step)
-}();
-static const int FIN_TX = [] {
-  const char* e = getenv("DFL_CONVP_FIN_TX");
-  return e ? atoi(e) : 32;
-}();
+constexpr int FIN_ROWS = 128;                  // (measured 2048 / 512 / 256 / 128 rows: 4.89 / 4.88 / 4.865 / 4.85 ms per step)
+constexpr int FIN_TX = 32;
 static int finish_rows_p(int M, int Ntot) {
   int64_t nb = ceil_div((int64_t)M * Ntot, 1024);
   if (nb > 2048) nb = 2048;
@@ -1181,13 +1175,6 @@ static int convp_launch_t(const ConvP& p, hipStream_t s) {
   const size_t red = (size_t)RPS_ * 2 * BN_ * sizeof(float);                   // statistics scratch
   if (lds < epi) lds = epi;
   if (lds < red) lds = red;
-  {   // diagnosis: extra LDS per workgroup = fewer workgroups per CU (how does a layer's time scale with the workgroups in flight?)
-    static const size_t pad = [] {
-      const char* e = getenv("DFL_CONVP_LDS_PAD_KB");
-      return e ? (size_t)atoi(e) * 1024 : (size_t)0;
-    }();
-    if (lds + pad <= kLdsHard) lds += pad;
-  }
   ConvP pl = p;                                       // the "live" BatchNorm tables sit behind everything else in LDS
   pl.tab_off = (int)((lds + 15) / 16 * 16);
   if (p.a.in_tot != nullptr || p.a.add_tot != nullptr) lds = (size_t)pl.tab_off + (384 + 2 * BN_) * sizeof(float);

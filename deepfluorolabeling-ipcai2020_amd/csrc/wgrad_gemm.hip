@@ -531,10 +531,7 @@ enum WgCfg { WG_128 = 0, WG_64, WG_ROW3, WG_ROW2, WG_32, WG_64ROW = 6 };   // (5
 
 // the shared-halo form of the kernel-row variant: chunks of 16 output pixels never leave their image row
 static bool wg_halo_ok(const dfl_wgrad_args* a) {
-  static const bool on = [] {
-    const char* e = getenv("DFL_WGRAD_HALO");
-    return e == nullptr || atoi(e) != 0;
-  }();
+  constexpr bool on = true;       // (against three stagings: -11 ... 14 % per launch, round 1)
   // (chunks of 16 output pixels may span up to four image rows)
   return on && a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && a->Wout >= 6 &&
          ((int64_t)a->N * a->Hout * a->Wout) % KP == 0 && WG_WS == 1;
@@ -551,11 +548,8 @@ static WgCfg pick_wg(const dfl_wgrad_args* a) {
   if (a->Cm >= 256 && a->Cg >= 256 && (int64_t)a->Cm * a->Cg * T >= 128ll * 128 * 1024) return WG_128;
   // 64 x 64 tiles with a kernel row of taps per workgroup and the shared halo (three accumulators per wave): a third of
   // the loads per matrix instruction; the workgroup count is kept by three times the pixel slices (the extra partial-sum
-  // traffic costs less than the loads saved: 0.080 -> 0.051 + 0.008 ms at 48 x 48 x 128 x 128).  DFL_WGRAD_ROW64=0: off.
-  static const int row64 = [] {
-    const char* e = getenv("DFL_WGRAD_ROW64");
-    return e ? atoi(e) : 1;
-  }();
+  // traffic costs less than the loads saved: 0.080 -> 0.051 + 0.008 ms at 48 x 48 x 128 x 128).
+  constexpr int row64 = 1;
   // Only where chunks stay inside an image row (W % 16 == 0), i.e. the wide levels: below that the layers are the deep
   // ones, whose slices are megabytes each -- measured on the 192 x 192 network the extra partial sums eat the gain there
   // (1876-1897 vs 1890-1918 images/s), while the 768 x 768 configuration gains 4 %.

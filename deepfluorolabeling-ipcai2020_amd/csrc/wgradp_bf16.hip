@@ -44,7 +44,6 @@ struct WgP {
   int g_off;                           // byte offset of the g image behind the d image
   int tab_off;                         // byte offset of the gathered-pixel offset table (P16 words) behind the g image
   int lds_bytes;
-  int kpipe;                           // fragments of the next k-step are fetched under the matrix instructions of this one
   long long* trace;                    // diagnosis build only (-DDFL_WGP_TRACE, docs/experiments/wgradp_trace.py)
   uint32_t g_bytes, d_bytes;
   uint32_t d2_bytes;                   // extent of the second dense tensor (dfl_wgrad_args.d_mode)
@@ -79,9 +78,6 @@ __host__ __device__ constexpr int wgp_max_g_units(int KH, bool dbrb = false) { r
 
 // DBRB: the dense operand is the BatchNorm + ReLU backward of (d = dy, d2 = r) formed while the patch is written to LDS
 // (dfl_wgrad_args.d_mode), and the column sums of it -- the layer's bias gradient -- leave with the slice (bias_partial).
-#ifndef DFL_WGP_INTERLEAVE
-#define DFL_WGP_INTERLEAVE 0   // 1 / 2 / 4: the next patch's loads requested between this patch's k-steps (spread over all of them / the first
-#endif                         // half / quarter).  Measured (round 3): weight gradients 1.33 -> 1.45 ms per step in every variant -- left off.
 // BIAS: the column sums also leave when d is a plain tensor (the operand materialised by dfl_conv_args.x_out).
 template <int KH, int KW, bool AFF, bool DBRB = false, bool BIAS = DBRB>
 __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const WgP p) {
@@ -324,7 +320,7 @@ __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const
     __syncthreads();
     WTR(1, tb1)
     WT0(ti0)
-    if (DFL_WGP_INTERLEAVE) issue_setup(patch + 1, patch + 1 < pend); else issue(patch + 1, patch + 1 < pend);
+    issue(patch + 1, patch + 1 < pend);
     WTR(3, ti0)
     if constexpr (BIAS) {
       // bias gradient: column sums of the d image as stored -- thread t owns channel t % CMT and every (NT / CMT)-th pixel row
@@ -353,17 +349,6 @@ __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const
       tp += 16 * p.phases;
       ks += p.phases;
     };
-    if (DFL_WGP_INTERLEAVE) {
-      // one unit of the next patch, then this wave's share of the k-steps that come between two units
-      const int mine = (nsteps - phase + p.phases - 1) / p.phases;
-      const int per = (mine / (DFL_WGP_INTERLEAVE ? DFL_WGP_INTERLEAVE : 1) + nd + ng - 1) / (nd + ng);   // (2, 4: all units requested within the first half, quarter)
-#pragma unroll
-      for (int u = 0; u < MAXD + MAXG; ++u) {
-        if (u < MAXD) issue_d(u); else issue_g(u - MAXD);
-        if (u < MAXD ? u < nd : u - MAXD < ng)
-          for (int c = 0; c < per && ks < nsteps; ++c) kstep();
-      }
-    }
     while (ks < nsteps) kstep();
     WTR(4, tk0)
   }
@@ -528,10 +513,7 @@ static int wgp_plan(const dfl_wgrad_args* a, WgP* p, bool need_out) {
       const char* e = getenv("DFL_WGP_SMALL_TILES");   // use 32 x 32 tiles from this many 64 x 64 tiles on (0: never)
       return e ? atoi(e) : 4;                          // (round 4: 16 -> 4, the same step time with 140 MB less partial sums per step)
     }();
-    static const int small_from21 = [] {
-      const char* e = getenv("DFL_WGP_SMALL_TILES21"); // ... for the 2x2 / 1x1 windows
-      return e ? atoi(e) : 4;
-    }();
+    constexpr int small_from21 = 4;                    // ... for the 2x2 / 1x1 windows (64 x 64 tiles there: kernels 0.437 -> 0.395 ms, batched sums 0.14 -> 0.21: equal, round 4)
     const int64_t tiles64 = ceil_div(a->Cm, 64) * ceil_div(a->Cg, 64);
     const int from = a->KH == 3 ? small_from : small_from21;
     if (from > 0 && a->Cm > 32 && a->Cg > 32 && tiles64 >= from && tiles64 < 256) p->CMT = p->CGT = 32;
@@ -547,11 +529,7 @@ static int wgp_plan(const dfl_wgrad_args* a, WgP* p, bool need_out) {
   // pipeline bubble -- within what a thread can hold in flight (2048 / 4096 sixteen-byte units of d / g per workgroup)
   // and the LDS budget.  Whole images are grouped while they fit.
   const int64_t max_du = wgp_max_d_units(a->KH, a->d_mode != 0), max_gu = wgp_max_g_units(a->KH, a->d_mode != 0);
-  static const int lds_env = [] {
-    const char* e = getenv("DFL_WGP_LDS_KB");
-    return e ? atoi(e) * 1024 : 0;
-  }();
-  const int lds_cap = lds_env ? lds_env : (a->KH == 3 ? 120 * 1024 : (a->KH == 2 ? 72 * 1024 : 52 * 1024));
+  const int lds_cap = a->KH == 3 ? 120 * 1024 : (a->KH == 2 ? 72 * 1024 : 52 * 1024);   // (100 / 140 KB for the 3x3 window: flat or slower, round 3)
   auto geom = [&](int ipp_, int ph_, int pw_, int64_t* lds, int64_t* du, int64_t* gu) {
     const int p16 = (ipp_ * ph_ * pw_ + 15) / 16 * 16;
     const int ih = (ph_ - 1) * a->stride + a->KH, iw = (pw_ - 1) * a->stride + a->KW;
@@ -586,10 +564,7 @@ static int wgp_plan(const dfl_wgrad_args* a, WgP* p, bool need_out) {
     int64_t lds, du, gu;
     geom(ipp_, ph_, pw_, &lds, &du, &gu);
     const double npatch = (double)ceil_div(a->N, ipp_) * (double)ceil_div(a->Hout, ph_) * (double)ceil_div(a->Wout, pw_);
-    static const double charge = [] {                 // bytes-equivalent of a patch's fixed costs (barriers, load round trip)
-      const char* e = getenv("DFL_WGP_PATCH_CHARGE_KB");
-      return (e ? atof(e) : 24.0) * 1024.0;
-    }();
+    constexpr double charge = 24.0 * 1024.0;          // bytes-equivalent of a patch's fixed costs (barriers, load round trip; 4 ... 128 KB measured: flat, round 3)
     const double cost = npatch * ((double)(du + gu) * 16.0 + charge);
     if (cost < best_cost) {
       best_cost = cost;
@@ -625,11 +600,6 @@ static int wgp_plan(const dfl_wgrad_args* a, WgP* p, bool need_out) {
   p->IH = (ph - 1) * a->stride + a->KH;
   p->IW = (pw - 1) * a->stride + a->KW;
   p->g_off = (p->P16 * p->sd + 255) / 256 * 256;
-  static const int kpipe = [] {
-    const char* e = getenv("DFL_WGP_KPIPE");
-    return e ? atoi(e) : 1;
-  }();
-  p->kpipe = kpipe;
   p->tab_off = (p->g_off + ipp * p->IH * p->IW * p->sg + 255) / 256 * 256;
   p->lds_bytes = p->tab_off + p->P16 * 4 + 2 * p->CGT * 4 + 3 * p->CMT * 4;
   if ((a->d_mode != 0 || a->bias_partial != nullptr) && p->lds_bytes < 256 * a->KH * 4) p->lds_bytes = 256 * a->KH * 4;   // room for the bias-gradient sums
@@ -642,14 +612,8 @@ static int wgp_plan(const dfl_wgrad_args* a, WgP* p, bool need_out) {
 // gradients per step and 0.43 / 0.74 / 1.10 ms of partial sums)
 static int wgp_slices(const WgP& p) {
   const int64_t tiles = ceil_div(p.a.Cm, p.CMT) * ceil_div(p.a.Cg, p.CGT);
-  static const int target3 = [] {
-    const char* e = getenv("DFL_WGP_WGS");
-    return e ? atoi(e) : 256;
-  }();
-  static const int target21 = [] {                    // 2x2 / 1x1 windows: several workgroups per CU
-    const char* e = getenv("DFL_WGP_WGS21");
-    return e ? atoi(e) : 512;
-  }();
+  constexpr int target3 = 256;                        // (192 / 128: +1 % / +5 % step time, round 3)
+  constexpr int target21 = 512;                       // 2x2 / 1x1 windows: several workgroups per CU
   const int target = p.a.KH == 3 ? target3 : target21;
   int64_t z = ceil_div(target, tiles);
   if (z > p.npatch) z = p.npatch;
@@ -678,11 +642,7 @@ template <int KH, int KW>
 static int wgp_launch_t(const WgP& p_in, hipStream_t s) {
   WgP p = p_in;
   dim3 grid((unsigned)ceil_div(p.a.Cm, p.CMT), (unsigned)ceil_div(p.a.Cg, p.CGT), (unsigned)p.zslices);
-  static const int xcd_env = [] {
-    const char* e = getenv("DFL_WGP_XCD");          // 0: the hardware's order (A/B measurements)
-    return e ? atoi(e) : 1;
-  }();
-  p.xcd_map = (xcd_env != 0 && grid.x * grid.y > 1 && grid.x * grid.y * grid.z >= 16) ? 1 : 0;
+  p.xcd_map = (grid.x * grid.y > 1 && grid.x * grid.y * grid.z >= 16) ? 1 : 0;   // (against the hardware's order: 1.330 -> 1.315 ms of weight gradients per step, round 4)
   const size_t lds = (size_t)p.lds_bytes;
 #define DFL_WGP_LAUNCH(AFF_, DBRB_, BIAS_)                                                                                       \
   {                                                                                                                              \

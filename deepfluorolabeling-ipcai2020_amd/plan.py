@@ -254,7 +254,7 @@ class UNetPlan:
                 mx = max(mx, A * B * Cc)
             self.pack.add(PackArgs(jobs_dev=to_dev(arr).data_ptr(), max_elems=mx, njobs=len(rest)))
 
-    DEEP_PACK_ELEMS = int(os.environ.get('DFL_PACK_DEEP_ELEMS', str(256 * 1024)))   # forward layouts from this size on are packed on the side stream (0: none)
+    DEEP_PACK_ELEMS = 256 * 1024   # forward layouts from this size on are packed on the side stream (0: none)
 
     def _order_pack_jobs(self):
         """Forward jobs: small ones first, then -- from the first large one in forward order on -- the rest ("deep": packed on
@@ -278,9 +278,9 @@ class UNetPlan:
                 self.fwd.insert(idx, nat.SyncArgs(event=self.EV_PACK_DEEP), nat.OP_WAIT, 0)
                 break
 
-    PACK_OVERLAP = os.environ.get('DFL_PACK_OVERLAP', '0') != '0'     # (round 4: off -- with the BatchNorm launches gone the one-stream form is 1.2 % faster)
-    WSPLIT = os.environ.get('DFL_WSPLIT', '1') != '0'      # split-bf16 modes: weights split once by the pack kernel
-    DSPLIT = os.environ.get('DFL_DSPLIT', '1') != '0'      # ... and the BatchNorm/ReLU backward output split once by its producer
+    PACK_OVERLAP = False     # (round 4: off -- with the BatchNorm launches gone the one-stream form is 1.2 % faster)
+    WSPLIT = True      # split-bf16 modes: weights split once by the pack kernel
+    DSPLIT = True      # ... and the BatchNorm/ReLU backward output split once by its producer
     EV_PACK_FORK, EV_PACK_DONE, EV_PACK_DEEP = 60000, 60001, 60002
 
     # ------------------------------------------------------------------------------------------ op helpers
@@ -351,7 +351,7 @@ class UNetPlan:
     # (fork after dpre is written; joined before dpre's buffer is rewritten two layers later, before a batched sum
     # reads its slices, and at the end of backward).  Measured: +10 % on an isolated pair for 24x24..96x96 layers, -8 % at
     # 192x192 -- but nothing inside the real backward pass (both kernels just run slower side by side), so it is off by default.
-    SIDE_STREAM = os.environ.get('DFL_SIDE_STREAM', '0') != '0'     # off: inside the whole backward pass the pair runs no faster (r01)
+    SIDE_STREAM = False     # off: inside the whole backward pass the pair runs no faster (r01)
     SIDE_MAX_PIXELS = 16 * 96 * 96
 
     def _side_join(self, prog, buf=None):
@@ -414,14 +414,14 @@ class UNetPlan:
     # Small sums (bias gradients, pixel-slice partials of narrow layers) are not launched one by one: they queue up
     # and one dfl_reduce_batch finishes the queue once FLUSH_BYTES of gradient are waiting (and at the end of backward).
     FLUSH_BYTES = int(float(os.environ.get('DFL_FLUSH_MB', '16')) * (1 << 20))   # (4 / 16 / 64 MB measured: 0.414 / 0.373 / 0.367 ms of sums per step)
-    FUSE_BWD_STATS = os.environ.get('DFL_FUSE_BWD_STATS', '1') != '0'
+    FUSE_BWD_STATS = True
     FUSE_DOWN_STATS = os.environ.get('DFL_FUSE_DOWN_STATS', '1') != '0'   # ... and the strided-conv data gradient's scatter (bf16)
     FUSE_BRB = os.environ.get('DFL_FUSE_BRB', '1') != '0'      # BatchNorm + ReLU backward inside the weight-/data-gradient staging (bf16 storage)
     # the data-gradient kernel also WRITES the operand it forms (dfl_conv_args.x_out) for layers whose tensor is at most this large:
     # the weight gradient then reads one plain tensor instead of forming the operand again in each of its (cm, cg) tiles
     DPRE_OUT_BYTES = int(float(os.environ.get('DFL_DPRE_OUT_MB', '12')) * (1 << 20))
-    RES_DGRAD_LAST = os.environ.get('DFL_RES_DGRAD_LAST', '1') != '0'   # residual 1x1 data gradient accumulates onto the 3x3 one (not the reverse)
-    FUSE_COLSUMS = FUSE_BWD_STATS and os.environ.get('DFL_FUSE_COLSUMS', '1') != '0'   # sums across block boundaries (see the backward program)
+    RES_DGRAD_LAST = True   # residual 1x1 data gradient accumulates onto the 3x3 one (not the reverse)
+    FUSE_COLSUMS = True   # sums across block boundaries (see the backward program)
 
     def _defer_sum(self, prog, src, dst, n, stride, count, T=1):
         self._red_pending.append((src, dst, n, stride, count, T))

@@ -174,6 +174,13 @@ def config3():
     return Problem('config3', cfg, onet.state_dict(), x, tseg, theat)
 
 
+def config3_one():
+    """The first image of config3 alone: the step-by-step check of the bf16 storage arithmetic at 768x768 (half the emulation time;
+    every geometry decision of the kernels depends on the image size, not on the image count)."""
+    pr = config3()
+    return Problem('config3__b1', pr.cfg, pr.sd, pr.x[:1].clone(), pr.tseg[:1].clone(), pr.theat[:1].clone())
+
+
 def upsample(pad_mode='zeros', wf=4):
     """up_mode='upsample' (unet.py:242-244) and / or pad_mode='circular' (unet.py:211-212): flags no reference CLI selects."""
     cfg = dict(n_classes=5, depth=3, wf=wf, batch_norm=True, padding=True, max_pool=False, num_lands=6, do_res=True,
@@ -205,6 +212,7 @@ for _n in sorted(TINY_CFGS):
 for _n in sorted(PAPER_CFGS):
     REGISTRY[paper_key(_n)] = (lambda n=_n: paper(n, PAPER_BATCH.get(n, 2)))
 REGISTRY['paper__paper_sc_l14__b16'] = lambda: paper('paper_sc_l14', 16)
+REGISTRY['paper__paper_sc_l14__b5'] = lambda: paper('paper_sc_l14', 5)     # the paper's own batch (train_test_code/Readme.md:16): 180 pixels at level 5
 for _hw in ((50, 70), (37, 41), (64, 96)):
     for _mp in (False, True):
         REGISTRY['ragged__%dx%d__mp%d' % (_hw[0], _hw[1], int(_mp))] = (lambda hw=_hw, mp=_mp: ragged(hw[0], hw[1], mp))

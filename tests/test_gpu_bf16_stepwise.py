@@ -140,13 +140,13 @@ def assert_report(rep, gnorm_all, what):
 
 
 KEYS = ['ragged__37x41__mp0', 'ragged__37x41__mp1', 'ragged__50x70__mp0', 'ragged__50x70__mp1', 'ragged__64x96__mp0', 'ragged__64x96__mp1',
-        'paper__paper_sc_l14__b2', 'paper__paper_mp_l0__b2', 'paper__paper_sc_l0__b4', 'config3']       # (batch 16 of the paper preset: tests/test_gpu_00_northstar.py)
+        'paper__paper_sc_l14__b2', 'paper__paper_mp_l0__b2', 'paper__paper_sc_l0__b4', 'config3__b1']       # (batch 16 of the paper preset: tests/test_gpu_00_northstar.py)
 
 
 @pytest.mark.parametrize('key', KEYS)
 def test_every_step_of_a_bf16_storage_pass_is_its_definition(key):
     torch.set_num_threads(max(torch.get_num_threads(), min(64, os.cpu_count() or 32)))
-    pr = PR.REGISTRY[key]()
+    pr = PR.config3_one() if key == 'config3__b1' else PR.REGISTRY[key]()
     if pr is None:
         pytest.skip('rejected architecture')
     rep, res = stepwise(pr, key + ' ')
