@@ -65,6 +65,13 @@ __device__ __forceinline__ bf16x8_t wtr_read8(const unsigned char* base, uint32_
   return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
+typedef unsigned int wpu32x2 __attribute__((ext_vector_type(2)));
+// 4 consecutive pixel rows of one channel (one transposing read), as two dwords
+__device__ __forceinline__ wpu32x2 wtr_read4(const unsigned char* base, uint32_t r0) {
+  typedef __attribute__((address_space(3))) ws16x4_t* lds_p;
+  return __builtin_bit_cast(wpu32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + r0)));
+}
+
 // KH x KW window.  4 * KH waves: wave w owns kernel row w % KH (KW taps, KW accumulator tiles) of "slot" w / KH; a slot is
 // a (cm32, cg32) pair of the workgroup tile and, when the tile has fewer than 4 pairs, a phase of the k-steps.  12 waves of
 // 48 accumulator registers (3x3) instead of 4 waves of 144: three waves per SIMD cover each other's LDS latency, the patch
@@ -298,6 +305,7 @@ __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const
   const int nsteps = p.P16 >> 4;
   const uint32_t gadd = g_col + (uint32_t)(ty * p.IW) * (uint32_t)p.sg;     // this wave's kernel row, this lane's channels
   const uint32_t dstep = (uint32_t)(16 * p.phases) * (uint32_t)p.sd;
+  const bool al8 = KW == 3 && a.stride == 1 && (p.PW & 7) == 0;          // (uniform)
 #ifdef DFL_WGP_TRACE
   long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   tr[0] = __builtin_amdgcn_s_memtime();
@@ -341,8 +349,19 @@ __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const
       const uint32_t gr0 = tp[0] + gadd, gr1 = tp[4] + gadd;
       const bf16x8_t df = wtr_read8(Ds, dr0, dr0 + 4u * (uint32_t)p.sd);
       bf16x8_t gf[KW];
+      if (KW == 3 && al8) {
+        // the 8 pixels of this lane's half of the k-step are consecutive pixels of one image row (PW % 8 == 0, stride 1): 12
+        // consecutive gathered pixels -- three transposing reads -- hold all three taps of the kernel row; tap 1 is the same
+        // registers shifted by one pixel (v_alignbit).  3 LDS reads instead of 6 in a loop that is bound by them (round 5)
+        const wpu32x2 g0 = wtr_read4(Gs, gr0), g1 = wtr_read4(Gs, gr1), g2 = wtr_read4(Gs, gr0 + 8u * (uint32_t)p.sg);
+        gf[0] = __builtin_bit_cast(bf16x8_t, (wpu32x4){g0.x, g0.y, g1.x, g1.y});
+        gf[1] = __builtin_bit_cast(bf16x8_t, (wpu32x4){__builtin_amdgcn_alignbit(g0.y, g0.x, 16), __builtin_amdgcn_alignbit(g1.x, g0.y, 16),
+                                                        __builtin_amdgcn_alignbit(g1.y, g1.x, 16), __builtin_amdgcn_alignbit(g2.x, g1.y, 16)});
+        gf[KW - 1] = __builtin_bit_cast(bf16x8_t, (wpu32x4){g0.y, g1.x, g1.y, g2.x});
+      } else {
 #pragma unroll
-      for (int t = 0; t < KW; ++t) gf[t] = wtr_read8(Gs, gr0 + (uint32_t)(t * p.sg), gr1 + (uint32_t)(t * p.sg));
+        for (int t = 0; t < KW; ++t) gf[t] = wtr_read8(Gs, gr0 + (uint32_t)(t * p.sg), gr1 + (uint32_t)(t * p.sg));
+      }
 #pragma unroll
       for (int t = 0; t < KW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, gf[t], acc[t], 0, 0, 0);
       dr0 += dstep;
@@ -565,7 +584,8 @@ static int wgp_plan(const dfl_wgrad_args* a, WgP* p, bool need_out) {
     geom(ipp_, ph_, pw_, &lds, &du, &gu);
     const double npatch = (double)ceil_div(a->N, ipp_) * (double)ceil_div(a->Hout, ph_) * (double)ceil_div(a->Wout, pw_);
     constexpr double charge = 24.0 * 1024.0;          // bytes-equivalent of a patch's fixed costs (barriers, load round trip; 4 ... 128 KB measured: flat, round 3)
-    const double cost = npatch * ((double)(du + gu) * 16.0 + charge);
+    double cost = npatch * ((double)(du + gu) * 16.0 + charge);
+    if (a->KH == 3 && a->stride == 1 && pw_ % 8 == 0) cost *= 0.92;   // (runs of 8 pixels: the three taps of a kernel row from one set of reads)
     if (cost < best_cost) {
       best_cost = cost;
       ipp = ipp_;
@@ -600,7 +620,7 @@ static int wgp_plan(const dfl_wgrad_args* a, WgP* p, bool need_out) {
   p->IH = (ph - 1) * a->stride + a->KH;
   p->IW = (pw - 1) * a->stride + a->KW;
   p->g_off = (p->P16 * p->sd + 255) / 256 * 256;
-  p->tab_off = (p->g_off + ipp * p->IH * p->IW * p->sg + 255) / 256 * 256;
+  p->tab_off = (p->g_off + (ipp * p->IH * p->IW + 2) * p->sg + 255) / 256 * 256;   // (+ 2 pixels: the third read of a row's last run of 8)
   p->lds_bytes = p->tab_off + p->P16 * 4 + 2 * p->CGT * 4 + 3 * p->CMT * 4;
   if ((a->d_mode != 0 || a->bias_partial != nullptr) && p->lds_bytes < 256 * a->KH * 4) p->lds_bytes = 256 * a->KH * 4;   // room for the bias-gradient sums
   const int red_bytes = (p->phases - 1) * p->pairs * a->KH * 16 * 64 * 4;   // room for the cross-phase sums
