@@ -39,7 +39,7 @@ class WgradArgs(C.Structure):
 
 class PackJob(C.Structure):
     _fields_ = [('src', fp), ('dst', fp), ('A', i32), ('B', i32), ('C', i32), ('kind', i32), ('flip', i32),
-                ('split', i32), ('dst2', fp), ('kind2', i32), ('flip2', i32), ('first_tile', i32), ('reserved', i32)]
+                ('split', i32), ('dst2', fp), ('kind2', i32), ('flip2', i32), ('first_tile', i32), ('split2', i32)]
 
 
 PACK_PLAIN, SGD_PLAIN_TILE = 100, 4096       # include/dfl_hip.h: DFL_PACK_PLAIN, DFL_SGD_PLAIN_TILE

@@ -921,6 +921,33 @@ __device__ __forceinline__ void pack_emit_cells(const float (*tile)[PK_T * PK_CM
   }
 }
 
+// ... and the quad layouts of the fp32-tensor arithmetics (4 floats, or 4 hi | 4 lo bf16: pack_put) from the same tile -- the
+// element order of pack_kernel's tiled branch for a full 32 x 32 tile (round 5: the parity modes take the one-pass update too)
+__device__ __forceinline__ void pack_emit_quads(const float (*tile)[PK_T * PK_CMAX + 1], float* dst, int kind, int flip, int split,
+                                                int A, int B, int Cc, int a0, int b0) {
+  const int N = (kind == 1) ? A : (kind == 2 ? B : Cc * B);
+  const int run = PK_T * Cc;
+  for (int e = threadIdx.x; e < PK_T * run; e += 256) {
+    const int r = e & 3, x = (e >> 2) & 31, rest = e >> 7;   // rest in [0, 8*C)
+    if (kind == 1) {            // k = c*B + b, n = a: quads run along b, columns along a
+      const int c = rest >> 3, bq = rest & 7, bb = 4 * bq + r, ar = x;
+      pack_put(dst, (int64_t)((c * B + b0) / 4 + bq) * N + a0 + ar, r, tile[ar][bb * Cc + c], split);
+    } else if (kind == 2) {     // k = c'*A + a, n = b: quads along a, columns along b
+      const int cp = rest >> 3, aq = rest & 7, ar = 4 * aq + r, bb = x;
+      const int c = flip ? (Cc - 1 - cp) : cp;
+      pack_put(dst, (int64_t)((cp * A + a0) / 4 + aq) * N + b0 + bb, r, tile[ar][bb * Cc + c], split);
+    } else {                    // k = a, n = c*B + b
+      const int c = rest >> 3, aq = rest & 7, ar = 4 * aq + r, bb = x;
+      pack_put(dst, (int64_t)(a0 / 4 + aq) * N + c * B + b0 + bb, r, tile[ar][bb * Cc + c], split);
+    }
+  }
+}
+__device__ __forceinline__ void pack_emit(const float (*tile)[PK_T * PK_CMAX + 1], float* dst, int kind, int flip, int split, int A, int B,
+                                          int Cc, int a0, int b0) {
+  if (split == 2) pack_emit_cells(tile, reinterpret_cast<unsigned short*>(dst), kind, flip, A, B, Cc, a0, b0);
+  else pack_emit_quads(tile, dst, kind, flip, split, A, B, Cc, a0, b0);
+}
+
 __global__ void __launch_bounds__(256) pack_tiles_kernel(const dfl_pack_job* __restrict__ jobs, int njobs) {
   __shared__ float tile[PK_T][PK_T * PK_CMAX + 1];
   // which job: the last one whose first_tile <= blockIdx.x (binary search; the few records stay in the scalar cache)
@@ -942,8 +969,8 @@ __global__ void __launch_bounds__(256) pack_tiles_kernel(const dfl_pack_job* __r
     t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
   }
   __syncthreads();
-  pack_emit_cells(tile, reinterpret_cast<unsigned short*>(j.dst), j.kind, j.flip, A, B, Cc, a0, b0);
-  if (j.dst2 != nullptr) pack_emit_cells(tile, reinterpret_cast<unsigned short*>(j.dst2), j.kind2, j.flip2, A, B, Cc, a0, b0);
+  pack_emit(tile, j.dst, j.kind, j.flip, j.split, A, B, Cc, a0, b0);
+  if (j.dst2 != nullptr) pack_emit(tile, j.dst2, j.kind2, j.flip2, j.split2, A, B, Cc, a0, b0);
 }
 
 // ------------------------------------------------------------------------------------------------ SGD
@@ -1020,8 +1047,8 @@ __global__ void __launch_bounds__(256) sgd_pack_tiles_kernel(dfl_sgd_pack_args a
     t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
   }
   __syncthreads();
-  pack_emit_cells(tile, reinterpret_cast<unsigned short*>(j.dst), j.kind, j.flip, A, B, Cc, a0, b0);
-  if (j.dst2 != nullptr) pack_emit_cells(tile, reinterpret_cast<unsigned short*>(j.dst2), j.kind2, j.flip2, A, B, Cc, a0, b0);
+  pack_emit(tile, j.dst, j.kind, j.flip, j.split, A, B, Cc, a0, b0);
+  if (j.dst2 != nullptr) pack_emit(tile, j.dst2, j.kind2, j.flip2, j.split2, A, B, Cc, a0, b0);
 }
 
 static unsigned stream_grid(int64_t units) {

@@ -167,7 +167,7 @@ class UNetPlan:
         self.pack.extend(self._prep)
         if n == 0:
             return
-        if not self.PACK_OVERLAP and self.bf16 and self.PACK_TILED:
+        if not self.PACK_OVERLAP and self.PACK_TILED:
             self._finish_pack_tiled()
             return
         arr = (PackJob * n)()
@@ -209,13 +209,13 @@ class UNetPlan:
     PACK_TILED = os.environ.get('DFL_PACK_TILED', '1') != '0'
 
     def _finish_pack_tiled(self):
-        """One-stream pack (round 4): the bf16 chunk layouts of parameters that tile into 32 x 32 x C blocks go through
+        """One-stream pack (round 4; round 5: every arithmetic, not only bf16 storage): the layouts of parameters that tile into 32 x 32 x C blocks go through
         dfl_pack_weights_tiled -- a flat list of tiles over all jobs, BOTH layouts of a parameter (forward operand and data-gradient
         operand) from one read of the fp32 master --, everything else (the first layer, heads, odd sizes) through dfl_pack_weights."""
         tiled, rest, by_src = [], [], {}
         for job in self._pack_jobs:
             src, dst, A, B, Cc, kind, flip, split = job
-            if split == 2 and A % 32 == 0 and B % 32 == 0 and Cc <= 9:
+            if A % 32 == 0 and B % 32 == 0 and Cc <= 9:
                 k = src.data_ptr()
                 if k in by_src and len(by_src[k]) == 1:
                     by_src[k].append(job)
@@ -235,9 +235,9 @@ class UNetPlan:
             for i, group in enumerate(tiled):
                 src, dst, A, B, Cc, kind, flip, split = group[0]
                 a = arr[i]
-                a.src, a.dst, a.A, a.B, a.C, a.kind, a.flip, a.split = src.data_ptr(), dst.data_ptr(), A, B, Cc, kind, flip, 2
+                a.src, a.dst, a.A, a.B, a.C, a.kind, a.flip, a.split = src.data_ptr(), dst.data_ptr(), A, B, Cc, kind, flip, split
                 if len(group) > 1:
-                    a.dst2, a.kind2, a.flip2 = group[1][1].data_ptr(), group[1][5], group[1][6]
+                    a.dst2, a.kind2, a.flip2, a.split2 = group[1][1].data_ptr(), group[1][5], group[1][6], group[1][7]
                 a.first_tile = tiles
                 tiles += (A // 32) * (B // 32)
             self._tiled_index = len(self.pack)

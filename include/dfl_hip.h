@@ -237,13 +237,15 @@ typedef struct {
    * first tile in the launch's flat tile list (tiles of 32 x 32 x C; a job has (A/32)*(B/32) of them). */
   float* dst2;           /* NULL: one layout */
   int32_t kind2, flip2;
-  int32_t first_tile, reserved;
+  int32_t first_tile;
+  int32_t split2;        /* format of dst2 (as split; round 5: the tiled launches write every format, not only the bf16 chunks) */
 } dfl_pack_job;
 
 /* jobs: DEVICE pointer to njobs dfl_pack_job records; max_elems = max over jobs of A*B*C. */
 int dfl_pack_weights(const dfl_pack_job* jobs_dev, int32_t njobs, int64_t max_elems, dfl_stream_t stream);
-/* The bf16 chunk layouts (split = 2) of parameters with A % 32 == 0, B % 32 == 0, C <= 9: one workgroup per 32 x 32 x C tile of
- * all jobs (first_tile: ascending prefix sums, total_tiles their sum), 16-byte loads, both layouts of a job from one LDS tile. */
+/* The layouts of parameters with A % 32 == 0, B % 32 == 0, C <= 9 (any format: fp32 quads, split quads, bf16 chunks): one workgroup
+ * per 32 x 32 x C tile of all jobs (first_tile: ascending prefix sums, total_tiles their sum), 16-byte loads, both layouts of a job
+ * from one LDS tile. */
 int dfl_pack_weights_tiled(const dfl_pack_job* jobs_dev, int32_t njobs, int32_t total_tiles, dfl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------

@@ -153,6 +153,33 @@ def test_pack_weights_layout(shape):
         assert np.array_equal(got, ref), (shape, kind, flip)
 
 
+@pytest.mark.parametrize('shape', [(64, 32, 3), (32, 64, 1), (128, 96, 2), (64, 64, 3)])
+@pytest.mark.parametrize('split', [0, 1])
+def test_pack_weights_tiled_quad_layouts(shape, split):
+    """dfl_pack_weights_tiled writes the fp32 quad layouts (and the split hi | lo bf16 quads) too (round 5: the update inside the
+    weight re-layout for the parity arithmetics): both layouts of a job, bit for bit what dfl_pack_weights writes."""
+    lib = nat.lib()
+    A, B, KK = shape
+    w = torch.randn(A, B, KK, KK, generator=torch.Generator().manual_seed(A * B + KK))
+    src = w.to(DEV).contiguous()
+    Cc = KK * KK
+    for (k1, f1), (k2, f2) in (((1, 0), (2, 1)), ((3, 0), (1, 0)), ((2, 0), (3, 0))):
+        def size(kind):
+            K = {1: Cc * B, 2: Cc * A, 3: A}[kind]
+            N = {1: A, 2: B, 3: Cc * B}[kind]
+            return (K + 3) // 4 * N * 4
+        d1 = torch.full((size(k1),), float('nan'), device=DEV)
+        d2 = torch.full((size(k2),), float('nan'), device=DEV)
+        job = nat.PackJob(src=src.data_ptr(), dst=d1.data_ptr(), A=A, B=B, C=Cc, kind=k1, flip=f1, split=split, dst2=d2.data_ptr(),
+                          kind2=k2, flip2=f2, first_tile=0, split2=split)
+        jobs = torch.from_numpy(np.frombuffer(bytes(job), dtype=np.uint8).copy()).to(DEV)
+        nat.check(lib.dfl_pack_weights_tiled(jobs.data_ptr(), 1, (A // 32) * (B // 32), stream()), 'dfl_pack_weights_tiled')
+        torch.cuda.synchronize()
+        r1, r2 = pack(w, k1, f1, split), pack(w, k2, f2, split)
+        assert torch.equal(d1.view(torch.int32), r1.view(torch.int32)), (shape, split, k1, f1)
+        assert torch.equal(d2.view(torch.int32), r2.view(torch.int32)), (shape, split, k2, f2)
+
+
 CONV_CASES = [
     # N, Cin, Cout, H, W, K, stride, pad
     (2, 8, 16, 12, 12, 3, 1, 1),

@@ -281,6 +281,7 @@ def test_fused_sgd_matches_torch_sgd():
     nb.load_state_dict(na.state_dict())
     assert na._param_flat is not None and na._param_flat.is_cuda
     oa = dfl_amd.SGD(na.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-3, nesterov=True)
+    oa.FUSE_PACK = False                    # the update launches themselves (the update inside the tiled re-layout: the next test)
     ob = torch.optim.SGD(nb.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-3, nesterov=True)
     x = torch.randn(2, 1, 32, 32, device=DEV)
     calls = []
@@ -312,6 +313,53 @@ def test_fused_sgd_matches_torch_sgd():
     assert len(calls) == 2 and sum(calls) >= sum(p.numel() for p in na.parameters() if p.grad is not None)
     sd = oa.state_dict()
     assert len(sd['state']) == len([p for p in na.parameters() if p.grad is not None])
+
+
+def test_update_inside_the_weight_relayout_in_the_parity_arithmetics(math_mode):
+    """dfl_amd.SGD.step() with fp32 tensors (fp32 / bf16x3 products): the update runs inside the tiled weight re-layout as in the
+    bf16 storage mode (dfl_sgd_pack_tiled writes the fp32 quad / split quad layouts too, round 5) -- parameters, momentum buffers
+    and the following forward passes BIT-IDENTICAL to update launches followed by the re-layout."""
+    import problems as PR
+    from gpu_common import hip_net, hip_step
+    pr = PR.REGISTRY['paper__paper_sc_l14__b2']()
+    res = []
+    for fuse in (True, False):
+        net = hip_net(pr)
+        opt = dfl_amd.SGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-3, nesterov=True)
+        opt.FUSE_PACK = fuse
+        calls = {'dfl_sgd_step': 0, 'dfl_sgd_pack_tiled': 0}
+        real = opt._lib
+
+        class Spy:
+            def __getattr__(self, k, real=real, calls=calls):
+                f = getattr(real, k)
+                if k in calls:
+                    def counted(*a):
+                        calls[k] += 1
+                        return f(*a)
+                    return counted
+                return f
+        opt._lib = Spy()
+        seq = []
+        for step in range(3):
+            opt.zero_grad()
+            out, seg, loss = hip_step(pr, net)
+            seq.append((seg.detach().clone(), loss.item()))
+            opt.step()
+        net.eval()
+        with torch.no_grad():
+            seq.append((net(pr.x.to(DEV))[0].clone(), 0.0))
+        torch.cuda.synchronize()
+        res.append((net, opt, seq, calls))
+    (na, oa, sa, ca), (nb, ob, sb, cb) = res
+    assert ca == {'dfl_sgd_step': 0, 'dfl_sgd_pack_tiled': 3}, ca
+    assert cb['dfl_sgd_pack_tiled'] == 0 and cb['dfl_sgd_step'] >= 3, cb
+    for (s1, l1), (s2, l2) in zip(sa, sb):
+        assert torch.equal(s1, s2) and l1 == l2
+    for (k, pa), pb in zip(na.named_parameters(), nb.parameters()):
+        assert torch.equal(pa, pb), k
+        if pa.grad is not None:
+            assert torch.equal(oa.state[pa]['momentum_buffer'], ob.state[pb]['momentum_buffer']), k
 
 
 def test_fused_sgd_refuses_cpu():
