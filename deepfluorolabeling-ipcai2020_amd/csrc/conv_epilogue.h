@@ -137,7 +137,8 @@ __device__ __forceinline__ void conv_stats_tail(const ConvK& p, const float (&s1
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < WM; ++w) s += red[(w * 2 + which) * BN + col];
-      a.stat_partials[((int64_t)blockIdx.x * 2 + which) * Ntot + n] = s;
+      if (a.stat_totals != nullptr) bn_live_add(a.stat_totals, (int)blockIdx.x, which, Ntot, n, s);     // live statistics (include/dfl_hip.h)
+      else a.stat_partials[((int64_t)blockIdx.x * 2 + which) * Ntot + n] = s;
     }
   }
 }

@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
   const int Ktot = p.Ktot, Ntot = a.Ntot;
   const int T = a.KH * KW;
   const int aq = tid & 3;
-  const bool has_aff = a.in_scale != nullptr;
+  const bool has_aff = a.in_scale != nullptr || a.in_tot != nullptr;
 
   // ---- per-thread gather rows: position of tap (0,0) and the set of taps that fall inside the image ----------------
   int a_iy0[QA], a_ix0[QA], a_base[QA];
@@ -151,8 +151,12 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
     rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)p.w_bytes, 0x00020000);
     if constexpr (AFF) {
       for (int c = tid; c < Cin; c += NT) {
-        Ssc[c] = a.in_scale[c];
-        Ssh[c] = a.in_shift[c];
+        if (a.in_tot != nullptr) {      // live statistics: scale / shift of the input channels from the producer's totals (include/dfl_hip.h)
+          bn_live_affine(a.in_tot, a.in_gamma, a.in_beta, a.in_count, a.bn_eps, Cin, c, Ssc + c, Ssh + c);
+        } else {
+          Ssc[c] = a.in_scale[c];
+          Ssh[c] = a.in_shift[c];
+        }
       }
       __syncthreads();
     }
@@ -478,7 +482,7 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
   }
 
   // ---- epilogue ------------------------------------------------------------------------------------------------------
-  const bool do_stats = a.stat_partials != nullptr;
+  const bool do_stats = a.stat_partials != nullptr || a.stat_totals != nullptr;
   float s1[TN], s2[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -509,6 +513,8 @@ __global__ void __launch_bounds__(WM* WN * 64, conv_occ(TM* TN)) conv_gemm_kerne
       if (has_add && a.add_scale != nullptr) {
         casc[j] = a.add_scale[cn[j]];
         cash[j] = a.add_shift[cn[j]];
+      } else if (has_add && a.add_tot != nullptr) {      // "+ BN(add)" with live statistics
+        bn_live_affine(a.add_tot, a.add_gamma, a.add_beta, a.add_count, a.bn_eps, Ntot, cn[j], &casc[j], &cash[j]);
       }
     }
 #pragma unroll
@@ -595,6 +601,8 @@ __global__ void __launch_bounds__(256) conv_finish_kernel(const ConvK p, int TX,
   if (a.add != nullptr && a.add_scale != nullptr && nok) {
     asc = a.add_scale[n];
     ash = a.add_shift[n];
+  } else if (a.add != nullptr && a.add_tot != nullptr && nok) {      // "+ BN(add)" with live statistics (include/dfl_hip.h)
+    bn_live_affine(a.add_tot, a.add_gamma, a.add_beta, a.add_count, a.bn_eps, Ntot, n, &asc, &ash);
   }
   const int64_t slice = (int64_t)p.Mtot * Ntot;
   const int r0 = blockIdx.x * rows_per_block;
@@ -626,7 +634,7 @@ __global__ void __launch_bounds__(256) conv_finish_kernel(const ConvK p, int TX,
       s2 = fmaf(v, u, s2);
     }
   }
-  if (a.stat_partials == nullptr) return;
+  if (a.stat_partials == nullptr && a.stat_totals == nullptr) return;
   red[0][threadIdx.x] = s1;
   red[1][threadIdx.x] = s2;
   __syncthreads();
@@ -636,8 +644,13 @@ __global__ void __launch_bounds__(256) conv_finish_kernel(const ConvK p, int TX,
       t1 += red[0][y * TX + tx];
       t2 += red[1][y * TX + tx];
     }
-    a.stat_partials[((int64_t)blockIdx.x * 2 + 0) * Ntot + n] = t1;
-    a.stat_partials[((int64_t)blockIdx.x * 2 + 1) * Ntot + n] = t2;
+    if (a.stat_totals != nullptr) {
+      bn_live_add(a.stat_totals, (int)blockIdx.x, 0, Ntot, n, t1);
+      bn_live_add(a.stat_totals, (int)blockIdx.x, 1, Ntot, n, t2);
+    } else {
+      a.stat_partials[((int64_t)blockIdx.x * 2 + 0) * Ntot + n] = t1;
+      a.stat_partials[((int64_t)blockIdx.x * 2 + 1) * Ntot + n] = t2;
+    }
   }
 }
 
@@ -841,14 +854,24 @@ extern "C" int dfl_conv2d(const dfl_conv_args* a, dfl_stream_t stream) {
   }
   DFL_REQUIRE(a == nullptr || (a->x_mode == 0 && a->x_out == nullptr), "dfl_conv2d: x_mode (fused BatchNorm + ReLU backward operand) and x_out are implemented by the bf16 patch kernels only");
   {
-    // live statistics outside the bf16 patch kernels: the 1-channel direct kernels only (3x3 row form: stat_totals; 1x1: add_tot)
+    // live statistics outside the bf16 patch kernels: the 1-channel direct kernels (3x3 row form: stat_totals; 1x1: add_tot) and,
+    // round 5, the fp32-tensor GEMM kernels -- producer (stat_totals: plain statistics of the stored values), consumer of an input
+    // (in_tot: the fast gather, whose scale / shift table lives in LDS) and of "+ BN(add)" (add_tot)
     const bool any = a != nullptr && (a->stat_totals != nullptr || a->in_tot != nullptr || a->add_tot != nullptr);
-    const bool direct_ok = any && dfl::direct_conv_ok(a) && a->in_tot == nullptr &&
+    const bool direct = any && dfl::direct_conv_ok(a);
+    const bool direct_ok = direct && a->in_tot == nullptr &&
                            (a->stat_totals == nullptr || (dfl::direct_conv_rows_usable(a) && a->stat_other == nullptr)) &&
                            (a->add_tot == nullptr || (a->add != nullptr && a->add_scale == nullptr && a->add_gamma && a->add_beta && a->add_count > 0 &&
                                                       !dfl::direct_conv_rows_usable(a)));
-    DFL_REQUIRE(!any || direct_ok,
-                "dfl_conv2d: live BatchNorm statistics (stat_totals / in_tot / add_tot) are implemented by the bf16 patch kernels and the 1-channel direct kernels only");
+    DFL_REQUIRE(!direct || direct_ok, "dfl_conv2d: live BatchNorm statistics: this form is not implemented by the 1-channel direct kernels");
+    if (any && !direct) {
+      DFL_REQUIRE(a->x_mode == 0 && !a->scatter2x2 && (a->stat_totals == nullptr || (a->stat_other == nullptr && a->stat_partials == nullptr)),
+                  "dfl_conv2d (fp32 tensors): stat_totals takes the plain statistics of a non-scatter layer");
+      DFL_REQUIRE(a->in_tot == nullptr || (a->in_scale == nullptr && a->in_gamma && a->in_beta && a->in_count > 0 && a->Cin % 16 == 0 && !a->x_split),
+                  "dfl_conv2d (fp32 tensors): in_tot replaces in_scale / in_shift, needs in_gamma, in_beta, in_count and the fast gather (Cin %% 16 == 0)");
+      DFL_REQUIRE(a->add_tot == nullptr || (a->add != nullptr && a->add_scale == nullptr && a->add_gamma && a->add_beta && a->add_count > 0),
+                  "dfl_conv2d (fp32 tensors): add_tot replaces add_scale / add_shift and needs add, add_gamma, add_beta, add_count");
+    }
   }
   dfl::ConvK k;
   int rc = dfl::prepare(a, &k);
@@ -872,7 +895,8 @@ extern "C" int dfl_conv2d(const dfl_conv_args* a, dfl_stream_t stream) {
     DFL_REQUIRE(!a->x_split || a->in_scale == nullptr, "dfl_conv2d: a split input cannot take an affine on load");
   }
   const bool general = a->add != nullptr || a->accumulate || a->scatter2x2 || (a->stat_other != nullptr && !k.so_simple);
-  const bool aff = a->in_scale != nullptr;
+  const bool aff = a->in_scale != nullptr || a->in_tot != nullptr;
+  DFL_REQUIRE(a->in_tot == nullptr || k.fast, "dfl_conv2d (fp32 tensors): in_tot needs the fast gather (aligned tensors below 2 GiB)");
   if (dfl::conv_rows_tile(k)) {   // 3x3 layers in whole row segments (it checks the epilogue / slices it can take)
     rc = dfl::conv_rows_launch(k, s);
   } else if (!k.fast) {

@@ -89,8 +89,12 @@ __global__ void __launch_bounds__(WM* WN * 64, DFL_ROWS_OCC) conv_rows_kernel(co
   }
   if constexpr (AFF) {
     for (int c = tid; c < Cin; c += NT) {
-      Ssc[c] = a.in_scale[c];
-      Ssh[c] = a.in_shift[c];
+      if (a.in_tot != nullptr) {        // live statistics (include/dfl_hip.h)
+        bn_live_affine(a.in_tot, a.in_gamma, a.in_beta, a.in_count, a.bn_eps, Cin, c, Ssc + c, Ssh + c);
+      } else {
+        Ssc[c] = a.in_scale[c];
+        Ssh[c] = a.in_shift[c];
+      }
     }
     __syncthreads();
   }
@@ -265,7 +269,7 @@ __global__ void __launch_bounds__(WM* WN * 64, DFL_ROWS_OCC) conv_rows_kernel(co
     s2[j] = 0.f;
   }
   conv_epilogue_simple<WM, WN, TM, TN>(p, acc, s1, s2, m0, n0, wm, wn, li, lh);
-  if (a.stat_partials != nullptr) conv_stats_tail<WM, WN, TM, TN>(p, s1, s2, smem, tid, n0, wm, wn, li, lh);
+  if (a.stat_partials != nullptr || a.stat_totals != nullptr) conv_stats_tail<WM, WN, TM, TN>(p, s1, s2, smem, tid, n0, wm, wn, li, lh);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
@@ -301,8 +305,9 @@ int conv_rows_tile(const ConvK& k) {
   // bf16x3 / bf16 products with the weights split by the pack kernel.  (fp32 products are bound by the matrix pipe, not by
   // the load path: measured there, these tiles lose 3-5 % of the step against the generic kernel's, so that mode keeps it.)
   if ((math_mode() != 1 && math_mode() != 3) || a.w_split != 1) return 0;
-  if (a.x_split && a.in_scale != nullptr) return 0;
-  if (a.in_scale != nullptr && (size_t)2 * a.Cin * sizeof(float) > 16 * 1024) return 0;
+  const bool has_aff = a.in_scale != nullptr || a.in_tot != nullptr;
+  if (a.x_split && has_aff) return 0;
+  if (has_aff && (size_t)2 * a.Cin * sizeof(float) > 16 * 1024) return 0;
   // whole row segments per tile: a piece of one image row, or up to 16 complete image rows; enough tiles for 256 CUs
   // (there is no split-K form of this kernel)
   auto fits = [&](int bm, int bn) {
@@ -339,7 +344,7 @@ static int rows_launch(const ConvK& k, hipStream_t s) {
 
 template <int WM, int WN, int TM, int TN>
 static int rows_dispatch(const ConvK& k, hipStream_t s) {
-  const bool aff = k.a.in_scale != nullptr;
+  const bool aff = k.a.in_scale != nullptr || k.a.in_tot != nullptr;
   if (math_mode() == 3) {
     if (k.a.x_split) return rows_launch<WM, WN, TM, TN, false, 6>(k, s);
     return aff ? rows_launch<WM, WN, TM, TN, true, 5>(k, s) : rows_launch<WM, WN, TM, TN, false, 5>(k, s);

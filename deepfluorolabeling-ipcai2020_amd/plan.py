@@ -693,6 +693,12 @@ class UNetPlan:
                 one_ch = lambda t: (not t.bf16) and t.C == 1 and Cout in (8, 16, 32, 64) and pad == 1
                 live = (self.LIVE_BN and bn and self.training and self.bf16 and not circ and (patch_in(gin) or one_ch(gin))
                         and (d < bd - 1 or (do_res and (patch_in(xin) or one_ch(xin)))))
+                # (round 5) fp32 tensors: the GEMM kernels take part as well -- producer: any of them (statistics tail, K-slice finish
+                # kernel); consumers: the fast gather of the next 3x3 (its scale / shift table in LDS) and the residual 1x1's "+ BN(r)"
+                gemm_in = lambda t: (not t.bf16) and t.C % 16 == 0
+                if (self.LIVE_BN and bn and self.training and not self.bf16 and not circ and gemm_in(gin) and Cout % 16 == 0
+                        and (d < bd - 1 or do_res)):
+                    live = True
                 tot = self._bn_totals(Cout) if live else None
                 live_bwd = (self.LIVE_BN and bn and self.training and self.bf16 and self.FUSE_BRB and self.FUSE_BWD_STATS and not circ
                             and self.need_grad and (patch_in(cur) or (one_ch(cur) and d == 0 and first and not self.input_grad)))

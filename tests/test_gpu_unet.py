@@ -362,6 +362,41 @@ def test_update_inside_the_weight_relayout_in_the_parity_arithmetics(math_mode):
             assert torch.equal(oa.state[pa]['momentum_buffer'], ob.state[pb]['momentum_buffer']), k
 
 
+@pytest.mark.parametrize('key', ['paper__paper_sc_l14__b2', 'ragged__37x41__mp1'])
+def test_live_batchnorm_statistics_in_the_parity_arithmetics(math_mode, key):
+    """fp32 tensors (round 5): the forward BatchNorm statistics of the layers between two GEMM kernels are completed by their
+    consumers (dfl_conv_args.stat_totals / in_tot / add_tot in conv_gemm / conv_rows / the K-slice finish kernel) instead of a
+    dfl_bn_finalize launch per layer: fewer launches, and outputs, loss, running statistics and every gradient BIT-IDENTICAL to
+    the plan with the launches (the same fp32 workgroup sums, an exact fp64 total)."""
+    import problems as PR
+    import noise_floor as NF
+    from gpu_common import hip_net, hip_step
+    from dfl_amd import plan as P_, _native as nat_
+    pr = PR.REGISTRY[key]()
+    res = {}
+    for live in (True, False):
+        prev = P_.UNetPlan.LIVE_BN
+        P_.UNetPlan.LIVE_BN = live
+        try:
+            net = hip_net(pr)
+            out, seg, loss = hip_step(pr, net)
+            plan = NF.train_plan(net)
+            nfin = sum(1 for st in plan.fwd.structs if isinstance(st, nat_.BnFinalizeArgs))
+        finally:
+            P_.UNetPlan.LIVE_BN = prev
+        res[live] = dict(seg=seg.detach().clone(), loss=loss.item(), nfin=nfin,
+                         grads={k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None},
+                         bufs={k: v.clone() for k, v in net.named_buffers()})
+    a, b = res[True], res[False]
+    print('%s %s: %d -> %d forward finalize launches' % (key, math_mode, b['nfin'], a['nfin']))
+    assert a['nfin'] * 3 <= b['nfin'], (a['nfin'], b['nfin'])
+    assert torch.equal(a['seg'], b['seg']) and a['loss'] == b['loss']
+    for k, v in b['bufs'].items():
+        assert torch.equal(a['bufs'][k], v), k
+    for k, v in b['grads'].items():
+        assert torch.equal(a['grads'][k], v), k
+
+
 def test_fused_sgd_refuses_cpu():
     p = torch.nn.Parameter(torch.zeros(4))
     p.grad = torch.ones(4)
