@@ -64,7 +64,8 @@ def main():
             fe, wr = v['FETCH_SIZE'][0] / v['FETCH_SIZE'][1], v['WRITE_SIZE'][0] / v['WRITE_SIZE'][1]
             traffic[k] = {'fetch_kb_raw': round(fe, 1), 'write_kb_raw': round(wr, 1),
                           'hbm_bytes_per_launch': round((2 * fe + wr) * 1024)}
-    import bench as _bench                                 # (repo root on sys.path: the hash bench.py compares with)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench as _bench                                 # (the hash bench.py compares with)
     json.dump({'note': 'bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024, averaged over the launches of each kernel in '
                        'bench.py --steps 6 --warmup 2; see tools/summarize_profile.py', 'round': tag.split('_')[0],
                'csrc_sha16': _bench.csrc_sha16(), 'kernels': traffic},
