@@ -385,11 +385,13 @@ class UNetPlan:
         a.splits = 1
         s = nat.check(self.lib.dfl_wgrad_suggest_splits(C.addressof(a)), 'dfl_wgrad_suggest_splits')
         a.splits = s
+        bias_job = None
         if (brb is not None or bias_plain) and bias_out is not None:
             # the column sums of that operand = the layer's bias gradient, one row per pixel slice
             bpart = self._new(s * d.C)
             a.bias_partial = bpart.data_ptr()
-            self._defer_sum(prog, bpart.data_ptr(), bias_out.data_ptr(), d.C, d.C, s)
+            bias_job = (bpart.data_ptr(), bias_out.data_ptr(), d.C, d.C, s, 1)    # queued BEHIND the launch that writes the rows (below): a
+                                                                                  # batched sum flushed from here would read them unwritten
         n = d.C * g.C * KH * KW
         if s > 1:
             big = 4 * n >= self.FLUSH_BYTES
@@ -404,6 +406,9 @@ class UNetPlan:
             prog.record(2 * k + 1, stream=1)
         else:
             prog.add(a)
+        if bias_job is not None:
+            self._red_pending.append(bias_job)
+            self._red_bytes += 4 * d.C
         if s > 1:
             # the caller flushes (self._maybe_flush) once the main-stream work that may overlap has been emitted
             self._red_pending.append((part.data_ptr(), dw.data_ptr(), n, n, s, KH * KW))
