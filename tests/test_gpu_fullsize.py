@@ -39,7 +39,8 @@ def _pair(cfg, seed, randomize_bn=False):
     return net.to(DEV), onet
 
 
-@pytest.mark.parametrize('mode', ['fp32', 'bf16x3', 'bf16s'])
+@pytest.mark.parametrize('mode', ['fp32', 'bf16s'])      # (bf16x3 at this size: 43 s of fp64 oracle for the row-tiled kernels that the 192x192
+                                                         #  and ragged tests cover in that arithmetic; dropped in round 5 to keep the suite's time)
 def test_config3_736_training_step_matches_oracle(mode):
     """2x-downsampled 736x736 padded to 768 (configs[3]), paper U-Net, dual head: forward, loss and gradients, in the two
     parity modes and in the bf16 storage mode profiles/ quotes this configuration in."""

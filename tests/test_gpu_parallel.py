@@ -181,4 +181,5 @@ def test_bench_launches_itself_for_more_than_one_gpu():
     lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, p.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d['n_gpus'] == 2 and d['config']['parallelism'] == 'dp2' and d['value'] > 100 and d['scaling'] == 'weak'
+    # (the value is whatever two ranks sharing one GPU and all-reducing 152 MB through gloo's host buffers reach: not a measurement)
+    assert d['n_gpus'] == 2 and d['config']['parallelism'] == 'dp2' and d['value'] > 0 and d['scaling'] == 'weak' and d['steps'] == 3
