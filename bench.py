@@ -55,7 +55,8 @@ CONV_KERNELS = ['conv_gemm_kernel<2,2,2,2>', 'conv_gemm_kernel<2,2,2,1>', 'conv_
 CONVP_TILES = ['4,1,2,1', '4,1,1,1', '2,2,4,1', '2,2,3,1', '2,2,2,1', '1,4,2,1', '1,4,3,1', '1,4,4,1', '1,4,6,1', '1,4,9,1', '2,2,1,1', '1,4,1,1',
                '4,1,3,1', '4,1,4,1', '2,2,6,1', '2,2,2,2', '2,2,3,2', '2,2,4,2', '4,1,2,2', '4,1,3,2', '1,4,2,2', '1,4,3,2',
                '4,1,1,1', '4,1,2,1', '2,2,1,1', '2,2,2,1', '1,4,1,1', '1,4,2,1', '4,1,1,2', '2,2,1,2',   # (22 ...: the streamed 1x1 forms)
-               '1,4,3,1,k2', '1,4,2,1,k2', '1,4,4,1,k2', '2,2,3,1,k2', '2,2,2,1,k2', '1,4,2,2,k2', '2,2,2,2,k2', '4,1,3,1,k2', '4,1,2,1,k2']   # (30 ...: two k-groups, 512 threads)      # csrc/convp_bf16.hip kTiles: waves M x N, tiles M x N per wave
+               '1,4,3,1,k2', '1,4,2,1,k2', '1,4,4,1,k2', '2,2,3,1,k2', '2,2,2,1,k2', '1,4,2,2,k2', '2,2,2,2,k2', '4,1,3,1,k2', '4,1,2,1,k2',   # (30 ...: two k-groups, 512 threads)
+               'latency form']      # csrc/convp_bf16.hip kTiles: waves M x N, tiles M x N per wave
 WGRAD_KERNELS = ['wgrad_kernel<2,2,2,2,1>', 'wgrad_kernel<2,2,1,1,1>', 'wgrad_kernel<1,1,1,1,3>',
                  'wgrad_kernel<1,1,1,1,2>', 'wgrad_kernel<1,1,1,1,1>', 'direct_wgrad_kernel', 'wgrad_kernel<2,2,1,1,3>']
 

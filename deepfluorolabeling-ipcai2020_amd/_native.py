@@ -24,7 +24,7 @@ class ConvArgs(C.Structure):
                 ('x2', fp), ('ldx2', i32), ('x_mode', i32),
                 ('stat_totals', fp), ('in_tot', fp), ('in_gamma', fp), ('in_beta', fp), ('add_tot', fp), ('add_gamma', fp),
                 ('add_beta', fp), ('in_count', C.c_double), ('add_count', C.c_double), ('bn_eps', f32), ('reserved3', i32),
-                ('in_mean', fp), ('in_invstd', fp), ('x_out', fp), ('ldxo', i32), ('reserved4', i32)]
+                ('in_mean', fp), ('in_invstd', fp), ('x_out', fp), ('ldxo', i32), ('latency_form', i32)]
 
 
 class WgradArgs(C.Structure):

@@ -21,7 +21,11 @@ struct ConvP {
   uint32_t x2_bytes, xo_bytes;  // extent of the second input tensor (dfl_conv_args.x_mode) and of x_out
   uint32_t mPP, mPW;            // ceil(2^32 / (PH * PW)), ceil(2^32 / PW): divisions of patch row indices by multiply-high
   int tab_off, pad1;            // LDS offset of the live-BatchNorm tables (set at launch)
+  // latency form (convs_bf16.hip; tile == CONVS_TILE): 32 x 32 tiles over (pixels, columns), waves of a workgroup per tile (log2),
+  // 16-channel chunks per tap (log2), k-steps of the layer and per wave
+  int s_mt, s_nt, s_ksplit_shift, s_cpk_shift, s_ksteps, s_kper;
 };
+constexpr int CONVS_TILE = 39;  // value of ConvP.tile for the latency form (= number of convp tile configurations)
 
 // Chooses the geometry for these arguments.  force_splits: 0 = free choice, else the K-slice count to plan for.
 int convp_plan(const dfl_conv_args* a, ConvP* p, int force_splits);
@@ -30,6 +34,11 @@ int convp_finish_rows(const ConvP& p);
 int convp_candidates(const dfl_conv_args* a, int32_t* out, int max);
 int convp_force(const int32_t* g);
 int convp_tune_add(const int32_t* key, const int32_t* g);
+
+// Latency form for the small problems of a batch-1 inference forward (convs_bf16.hip)
+bool convs_eligible(const dfl_conv_args& a, const ConvP& p);
+void convs_plan(const dfl_conv_args& a, ConvP* p, int force_splits);
+int convs_launch(const ConvP& p, hipStream_t s);
 
 struct WgP;
 int wgradp_suggest_splits(const dfl_wgrad_args* a);

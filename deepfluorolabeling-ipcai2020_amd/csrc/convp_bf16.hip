@@ -796,6 +796,7 @@ static const TileCfg kTiles[] = {{4, 1, 2, 1, 0, 1}, {4, 1, 1, 1, 0, 1}, {2, 2, 
                                  {1, 4, 3, 1, 0, 2}, {1, 4, 2, 1, 0, 2}, {1, 4, 4, 1, 0, 2}, {2, 2, 3, 1, 0, 2}, {2, 2, 2, 1, 0, 2}, {1, 4, 2, 2, 0, 2},
                                  {2, 2, 2, 2, 0, 2}, {4, 1, 3, 1, 0, 2}, {4, 1, 2, 1, 0, 2}};
 constexpr int kNumTiles = (int)(sizeof(kTiles) / sizeof(kTiles[0]));
+static_assert(kNumTiles == CONVS_TILE, "convp.h: CONVS_TILE is the first index behind the tile table");
 constexpr size_t kLdsSoft = 64 * 1024, kLdsHard = 150 * 1024;
 
 // Row blocks of convp_finish_kernel = rows of stat_partials the following finalize kernel has to read.  Few (<= FIN_ROWS) and
@@ -1077,6 +1078,12 @@ static int convp_plan_search(const dfl_conv_args* a, ConvP* p, int force_splits)
     p->xo_bytes = (uint32_t)xob;
   }
 
+  // the latency form (dfl_conv_args.latency_form: small problems of a batch-1 inference forward, convs_bf16.hip) plans itself
+  if (t_force.tile < 0 && convs_eligible(*a, *p)) {
+    convs_plan(*a, p, force_splits);
+    return DFL_OK;
+  }
+
   // a forced geometry (dfl_conv_force_geometry: tuners, tests) or an entry of the tuning table (dfl_conv_tune_add) wins
   // over the cost model, as long as it is valid for this layer and agrees with the caller's K slices
   double best = 1e300;
@@ -1205,6 +1212,7 @@ static int convp_launch_t(const ConvP& p, hipStream_t s) {
 int convp_launch(const ConvP& p, hipStream_t s) {
   int rc;
   switch (p.tile) {
+    case CONVS_TILE: rc = convs_launch(p, s); break;
     case 0: rc = convp_launch_t<4, 1, 2, 1>(p, s); break;
     case 1: rc = convp_launch_t<4, 1, 1, 1>(p, s); break;
     case 2: rc = convp_launch_t<2, 2, 4, 1>(p, s); break;

@@ -325,6 +325,9 @@ class UNetPlan:
         a.Hout, a.Wout = (y.H, y.W) if Hout is None else (Hout, Wout)
         a.Ntot, a.ldy = Ntot, y.ld
         a.relu, a.accumulate, a.scatter2x2 = relu, accumulate, scatter
+        # inference plans ask for the latency form of the bf16 convolution (include/dfl_hip.h: a hint the library honours for the
+        # small problems of a batch-1 forward -- the per-image loops of util.py -- and ignores for everything else)
+        a.latency_form = 1 if (self.bf16 and not self.training and not self.need_grad and os.environ.get('DFL_PLAN_LATENCY_FORM', '1') != '0') else 0
         sp = nat.check(self.lib.dfl_conv_suggest_splits(C.addressof(a)), 'dfl_conv_suggest_splits')
         if sp > 1:
             M = x.N * (x.H * x.W if scatter else a.Hout * a.Wout)

@@ -138,7 +138,13 @@ typedef struct {
    * (dfl_wgrad_args.d_mode = 0 with bias_partial) instead of forming the same values again from (dy, r) in every (cm, cg) tile.
    * NULL: nothing is written. */
   void* x_out;
-  int32_t ldxo, reserved4;
+  int32_t ldxo;
+  /* Latency form (bf16 tensors, round 5): 1 asks for the kernel whose dependency chain is shortest instead of the one with the
+   * highest throughput -- for the small problems of a batch-1 inference forward (the per-image loops of util.py:116-165 and
+   * :318-356: 44 dependent convolutions of 0.01 - 1 GFLOP each).  A hint: honoured for at most 65536 output pixels, Cin / 16 a
+   * power of two, no statistics / live totals / x_mode / x_out; otherwise the patch-resident kernels run.  Same contract, same
+   * roundings (another fp32 summation order); dfl_conv_suggest_splits answers for the form the hint selects. */
+  int32_t latency_form;
 } dfl_conv_args;
 #define DFL_BN_R 8
 

@@ -89,7 +89,8 @@ def test_pack_bf16_chunk_layout():
 
 
 def conv_bf16(x, wp, Ntot, KH, KW, stride, pad, Hout, Wout, bias=None, in_aff=None, relu=0, add=None, add_aff=None,
-              y_init=None, accumulate=0, scatter=0, stats=False, stat_other=None, ldy=None, ldx_pad=0, force_splits=None, brb=None, x_out=False):
+              y_init=None, accumulate=0, scatter=0, stats=False, stat_other=None, ldy=None, ldx_pad=0, force_splits=None, brb=None, x_out=False,
+              latency=False):
     """x: NCHW fp32 cpu tensor (bf16-representable) -> dfl_conv2d with bf16 tensors -> y NHWC fp32 cpu tensor (+ stats).
     x_out (with brb): also returns the operand tensor the kernel wrote (dfl_conv_args.x_out; NHWC with 8 channels of padding)."""
     lib = nat.lib()
@@ -144,6 +145,7 @@ def conv_bf16(x, wp, Ntot, KH, KW, stride, pad, Hout, Wout, bias=None, in_aff=No
     a.KH, a.KW, a.stride, a.pad = KH, KW, stride, pad
     a.Hout, a.Wout, a.Ntot, a.ldy = Hout, Wout, Ntot, ldy
     a.relu, a.accumulate, a.scatter2x2 = relu, accumulate, scatter
+    a.latency_form = 1 if latency else 0              # (the latency form of csrc/convs_bf16.hip: tests/test_gpu_latency_form.py)
     sp = force_splits or nat.check(lib.dfl_conv_suggest_splits(C.addressof(a)), 'suggest')
     if sp > 1:
         Mrows = N * (Hin * Win if scatter else Hout * Wout)
@@ -161,12 +163,16 @@ def conv_bf16(x, wp, Ntot, KH, KW, stride, pad, Hout, Wout, bias=None, in_aff=No
             a.stat_other, a.ldso = so.data_ptr(), so.shape[-1]
     cfg = nat.check(lib.dfl_conv_config(C.addressof(a)), 'config')
     assert cfg >= 16, 'the patch-resident kernels must take bf16 layers'
+    assert not latency or cfg == 16 + LATENCY_CFG, 'the latency form was asked for and is eligible here'
     nat.check(lib.dfl_conv2d(C.addressof(a), stream()), 'dfl_conv2d')
     torch.cuda.synchronize()
     y = yd.float().cpu()[..., :Cout]
     if x_out:
         return y, xo.float().cpu()
     return (y, part.cpu().double().sum(0)) if stats else y
+
+
+LATENCY_CFG = 39       # csrc/convp.h: CONVS_TILE
 
 
 def close_bf16(got, ref, what=''):

@@ -1,0 +1,152 @@
+"""The latency form of the bf16 convolution (csrc/convs_bf16.hip, dfl_conv_args.latency_form: the kernel inference plans ask
+for on the small problems of a batch-1 forward; reference loops: train_test_code/util.py:116-165, :318-356) through the C ABI
+against fp64 PyTorch on the same bf16 operands -- the bars of tests/test_gpu_bf16.py -- and against the patch-resident kernel
+on the same argument block; then a whole inference forward with and without it.  pytest -m gpu."""
+import ctypes as C
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import dfl_amd
+from dfl_amd import _native as nat
+from test_gpu_bf16 import rb, nhwc, pack16, conv_bf16, close_bf16, _mode4  # noqa: F401  (the fixture switches to bf16 storage)
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+# N, Cin, Cout, H, W, K, stride, pad: every window of the network, ragged pixel counts, columns that are no multiple of 32, the
+# wave splits 1 / 2 / 4 / 8 of a tile's k-steps and K slices over workgroups (the deep levels of a 192x192 image)
+LCASES = [
+    (1, 32, 32, 192, 192, 3, 1, 1),     # level 0: one wave per tile
+    (1, 32, 64, 96, 96, 3, 1, 1),       # level 1
+    (1, 64, 64, 80, 80, 3, 1, 1),       # two waves per tile
+    (1, 128, 128, 48, 48, 3, 1, 1),     # four
+    (1, 256, 256, 24, 24, 3, 1, 1),     # eight
+    (1, 512, 512, 12, 12, 3, 1, 1),     # eight + K slices (finish kernel)
+    (1, 1024, 1024, 6, 6, 3, 1, 1),     # 36 pixels: the second pixel tile is nearly empty
+    (1, 1024, 512, 12, 12, 3, 1, 1),    # decoder, 576 k-steps
+    (2, 64, 40, 13, 9, 3, 1, 1),        # ragged pixels, 40 columns
+    (1, 32, 16, 10, 10, 3, 1, 0),       # valid convolution
+    (1, 64, 32, 192, 192, 1, 1, 0),     # 1x1
+    (1, 32, 64, 17, 11, 1, 1, 0),
+    (1, 64, 64, 96, 96, 2, 2, 0),       # 2x2 stride 2
+    (3, 32, 32, 7, 9, 2, 2, 0),         # ... odd input
+    (1, 16, 16, 12, 12, 3, 1, 1),       # one chunk per tap
+]
+
+
+@pytest.mark.parametrize('case', LCASES)
+def test_latency_form_plain(case):
+    N, Cin, Cout, H, W, K, stride, pad = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = rb(torch.randn(N, Cin, H, W, generator=g))
+    w = rb(torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    Ho, Wo = (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1
+    wp = pack16(w, 1)
+    y = conv_bf16(x, wp, Cout, K, K, stride, pad, Ho, Wo, bias=b, relu=1, latency=True)
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=pad))
+    close_bf16(y, nhwc(ref), str(case))
+    # ... and against the patch-resident kernel: the same values up to the fp32 summation order in front of the one rounding
+    y0 = conv_bf16(x, wp, Cout, K, K, stride, pad, Ho, Wo, bias=b, relu=1)
+    differing = float((y != y0).double().mean())
+    assert differing < 0.02, 'fraction of elements that round differently: %.4f' % differing
+    assert float((y - y0).abs().max()) <= 2.0 ** -7 * float(y0.abs().max())
+
+
+@pytest.mark.parametrize('case', [(1, 32, 32, 20, 20, 3), (1, 64, 128, 12, 12, 3), (1, 256, 256, 6, 6, 3), (2, 128, 64, 9, 7, 1), (1, 512, 512, 12, 12, 3)])
+def test_latency_form_affine_residual_epilogue(case):
+    """BatchNorm affine on load with zero padding AFTER it and the '+ BN(other)' residual sum (unet.py:211-231 in eval mode)."""
+    N, Cin, Cout, H, W, K = case
+    pad = K // 2
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    x = rb(torch.randn(N, Cin, H, W, generator=g))
+    w = rb(torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    other = rb(torch.randn(N, Cout, H, W, generator=g))
+    asc, ash = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.2
+    y0 = rb(torch.randn(N, Cout, H, W, generator=g))
+    xa = rb(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    ref = F.conv2d(xa.double(), w.double(), b.double(), padding=pad)
+    ref = ref + other.double() * asc.double().view(1, -1, 1, 1) + ash.double().view(1, -1, 1, 1)
+    y = conv_bf16(x, pack16(w, 1), Cout, K, K, 1, pad, H, W, bias=b, in_aff=(sc, sh), add=other, add_aff=(asc, ash), latency=True)
+    close_bf16(y, nhwc(ref), str(case))
+    ya = conv_bf16(x, pack16(w, 1), Cout, K, K, 1, pad, H, W, bias=b, in_aff=(sc, sh), add=other, add_aff=(asc, ash), y_init=y0, accumulate=1,
+                   latency=True)
+    close_bf16(ya, nhwc(ref + y0.double()), str(case) + ' accumulate')
+
+
+def test_latency_form_transposed_scatter():
+    """ConvTranspose2d(k2,s2) as a 1x1 gather with the 2x2-scatter epilogue into the channel half of a wider buffer (unet.py:240,255-257)."""
+    g = torch.Generator().manual_seed(9)
+    for (N, Ci, Co, H, W) in ((1, 64, 32, 10, 7), (1, 1024, 512, 6, 6), (1, 64, 32, 96, 96)):
+        x = rb(torch.randn(N, Ci, H, W, generator=g))
+        w = rb(torch.randn(Ci, Co, 2, 2, generator=g) / (4 * Ci) ** 0.5)
+        b = torch.randn(Co, generator=g)
+        y = conv_bf16(x, pack16(w, 3), 4 * Co, 1, 1, 1, 0, 2 * H, 2 * W, bias=b, scatter=1, ldy=2 * Co, latency=True)
+        close_bf16(y, nhwc(F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2)), 'convT %d' % Ci)
+
+
+def test_latency_form_is_a_hint():
+    """Statistics, large problems and the fused backward operand keep the patch-resident kernels whatever the hint says."""
+    lib = nat.lib()
+    g = torch.Generator().manual_seed(3)
+    x = rb(torch.randn(16, 64, 96, 96, generator=g))           # one image: 0.68 GFLOP per 3x3 layer of 64 channels
+    w = rb(torch.randn(64, 64, 3, 3, generator=g) / 24.0)
+    a = nat.ConvArgs()
+    xd = nhwc(x).to(DEV).to(torch.bfloat16).contiguous()
+    yd = torch.empty(16, 96, 96, 64, device=DEV, dtype=torch.bfloat16)
+    wp = pack16(w, 1)
+    a.x, a.w, a.y = xd.data_ptr(), wp.data_ptr(), yd.data_ptr()
+    a.x_bf16, a.y_bf16, a.w_split = 1, 1, 2
+    a.N, a.Hin, a.Win, a.Cin, a.ldx = 1, 96, 96, 64, 64
+    a.KH, a.KW, a.stride, a.pad = 3, 3, 1, 1
+    a.Hout, a.Wout, a.Ntot, a.ldy = 96, 96, 64, 64
+    a.latency_form = 1
+    assert lib.dfl_conv_config(C.addressof(a)) == 16 + 39
+    part = torch.zeros(4096, 2, 64, device=DEV)
+    a.stat_partials = part.data_ptr()
+    assert lib.dfl_conv_config(C.addressof(a)) < 16 + 39          # statistics: the patch kernels
+    a.stat_partials = None
+    a.N = 16
+    assert lib.dfl_conv_config(C.addressof(a)) < 16 + 39          # 10.9 GFLOP: a throughput problem
+
+
+def test_inference_forward_with_and_without_the_latency_form():
+    """The eval-mode forward of the paper network at 192x192, batch 1 (the shape of the per-image loops): the plan's hint against
+    DFL_CONVS=0-style plans (hint cleared), output for output."""
+    import bench
+    torch.manual_seed(5)
+    net = dfl_amd.UNet(**bench.PAPER).to(DEV).eval()
+    x = torch.randn(1, 1, 192, 192, device=DEV)
+    with torch.no_grad():
+        seg1, heat1 = net(x)
+        plan = [p for ps in net._plans.values() for p in ps if not p.need_grad][0]
+        lean = [st for st in plan.fwd.structs if isinstance(st, nat.ConvArgs) and st.latency_form]
+        assert len(lean) >= 40
+        lib = nat.lib()
+        taken = sum(1 for st in lean if lib.dfl_conv_config(C.addressof(st)) == 16 + 39)
+        assert taken >= 36, 'latency form taken by %d of %d convolutions' % (taken, len(lean))
+        seg1, heat1 = seg1.clone(), heat1.clone()
+        # the same plan with the hint cleared (K slices re-planned by the library for the patch kernels)
+        net2 = dfl_amd.UNet(**bench.PAPER).to(DEV).eval()
+        net2.load_state_dict(net.state_dict())
+        old = os.environ.get('DFL_PLAN_LATENCY_FORM')
+        os.environ['DFL_PLAN_LATENCY_FORM'] = '0'
+        try:
+            seg0, heat0 = net2(x)
+        finally:
+            if old is None:
+                del os.environ['DFL_PLAN_LATENCY_FORM']
+            else:
+                os.environ['DFL_PLAN_LATENCY_FORM'] = old
+        plan2 = [p for ps in net2._plans.values() for p in ps if not p.need_grad][0]
+        assert not any(st.latency_form for st in plan2.fwd.structs if isinstance(st, nat.ConvArgs))
+    # two bf16-storage forwards that differ in fp32 summation order: a few last-bit roundings per tensor, amplified by 44 layers
+    assert float((seg1 - seg0).abs().max()) < 3e-2
+    assert float((heat1 - heat0).abs().max()) <= 3e-2 * max(1.0, float(heat0.abs().max()))
+    agree = float((seg1.argmax(1) == seg0.argmax(1)).float().mean())
+    assert agree > 0.995, 'label agreement %.4f' % agree
