@@ -24,7 +24,7 @@ class ConvArgs(C.Structure):
                 ('x2', fp), ('ldx2', i32), ('x_mode', i32),
                 ('stat_totals', fp), ('in_tot', fp), ('in_gamma', fp), ('in_beta', fp), ('add_tot', fp), ('add_gamma', fp),
                 ('add_beta', fp), ('in_count', C.c_double), ('add_count', C.c_double), ('bn_eps', f32), ('reserved3', i32),
-                ('in_mean', fp), ('in_invstd', fp), ('x_out', fp), ('ldxo', i32), ('latency_form', i32)]
+                ('in_mean', fp), ('in_invstd', fp), ('x_out', fp), ('ldxo', i32), ('latency_form', i32), ('out_scale', fp), ('out_shift', fp)]
 
 
 class WgradArgs(C.Structure):
@@ -188,19 +188,28 @@ class SyncArgs(C.Structure):
     _fields_ = [('event', i32), ('reserved', i32)]
 
 
+CONV_CFG_LATENCY = 39      # dfl_conv_config: 16 + this = the latency form (csrc/convp.h: CONVS_TILE)
+
+
+class ConvPairArgs(C.Structure):
+    _fields_ = [('a', fp), ('b', fp)]
+
+
 class Op(C.Structure):
     _fields_ = [('kind', i32), ('stream', i32), ('args', fp)]
 
 
 OP_CONV, OP_WGRAD, OP_SUM_PARTIALS, OP_PACK, OP_BN_FINALIZE, OP_BN_EVAL, OP_COLSTATS, OP_BN_BWD_FINALIZE, \
     OP_BN_RELU_BWD, OP_REDUCE_PARTIALS, OP_AFFINE_COPY, OP_POOL_FWD, OP_POOL_BWD, OP_HEAD_FWD, OP_HEAD_BWD, \
-    OP_MEMSET, OP_REDUCE_BATCH, OP_RECORD, OP_WAIT, OP_UPSAMPLE_FWD, OP_UPSAMPLE_BWD, OP_BN_FINALIZE_LIVE, OP_BN_BWD_FINALIZE_LIVE = range(1, 24)
+    OP_MEMSET, OP_REDUCE_BATCH, OP_RECORD, OP_WAIT, OP_UPSAMPLE_FWD, OP_UPSAMPLE_BWD, OP_BN_FINALIZE_LIVE, OP_BN_BWD_FINALIZE_LIVE, \
+    OP_CONV_PAIR = range(1, 25)
 
 _KIND_OF = {ConvArgs: OP_CONV, WgradArgs: OP_WGRAD, SumPartialsArgs: OP_SUM_PARTIALS, PackArgs: OP_PACK,
             BnFinalizeArgs: OP_BN_FINALIZE, BnEvalArgs: OP_BN_EVAL, ColstatsArgs: OP_COLSTATS,
             BnBwdFinalizeArgs: OP_BN_BWD_FINALIZE, BnReluBwdArgs: OP_BN_RELU_BWD,
             ReducePartialsArgs: OP_REDUCE_PARTIALS, AffineCopyArgs: OP_AFFINE_COPY, HeadFwdArgs: OP_HEAD_FWD,
-            HeadBwdArgs: OP_HEAD_BWD, MemsetArgs: OP_MEMSET, ReduceBatchArgs: OP_REDUCE_BATCH, BnLiveArgs: OP_BN_FINALIZE_LIVE, BnBwdLiveArgs: OP_BN_BWD_FINALIZE_LIVE}
+            HeadBwdArgs: OP_HEAD_BWD, MemsetArgs: OP_MEMSET, ReduceBatchArgs: OP_REDUCE_BATCH, BnLiveArgs: OP_BN_FINALIZE_LIVE, BnBwdLiveArgs: OP_BN_BWD_FINALIZE_LIVE,
+            ConvPairArgs: OP_CONV_PAIR}
 
 _SIZEOF_ORDER = [ConvArgs, WgradArgs, PackJob, BnFinalizeArgs, ColstatsArgs, BnBwdFinalizeArgs, BnReluBwdArgs,
                  AffineCopyArgs, PoolArgs, HeadFwdArgs, HeadBwdArgs, LossArgs, EnsembleArgs, Op, ReduceJob, PrepArgs, EstLandsArgs,
@@ -218,7 +227,7 @@ EXPORTS = ['dfl_version', 'dfl_last_error', 'dfl_sizeof', 'dfl_conv2d', 'dfl_con
            'dfl_set_conv_rows_min_tiles', 'dfl_conv_candidates', 'dfl_conv_force_geometry', 'dfl_conv_tune_add',
            'dfl_head_wgrad_blocks', 'dfl_head_scratch_ld_for', 'dfl_head_scratch_off_for', 'dfl_upsample2x_fwd',
            'dfl_upsample2x_bwd', 'dfl_bn_finalize_live', 'dfl_bn_bwd_finalize_live', 'dfl_pack_weights_tiled',
-           'dfl_sgd_pack_tiled']
+           'dfl_sgd_pack_tiled', 'dfl_conv2d_pair', 'dfl_conv_pair_ok']
 
 
 class DflError(RuntimeError):
@@ -283,6 +292,8 @@ def lib():
     L.dfl_head_scratch_off_for.argtypes = [i32, i32, i32, i32, i32]
     L.dfl_conv_force_geometry.argtypes = [fp]
     L.dfl_conv_tune_add.argtypes = [fp, fp]
+    L.dfl_conv2d_pair.argtypes = [fp, fp, fp]
+    L.dfl_conv_pair_ok.argtypes = [fp, fp]
     for k, cls in enumerate(_SIZEOF_ORDER):
         if L.dfl_sizeof(k) != C.sizeof(cls):
             raise DflError('struct mirror %s has size %d, library says %d' % (cls.__name__, C.sizeof(cls), L.dfl_sizeof(k)))
@@ -385,6 +396,15 @@ class Program:
         self._ops = None
         self._chunks = {}
         return args_struct
+
+    def pop(self):
+        """Take the last op back (its argument struct is returned)."""
+        self.kinds.pop()
+        self.streams.pop()
+        self.volatile.pop()
+        self._ops = None
+        self._chunks = {}
+        return self.structs.pop()
 
     def record(self, event, stream=0):
         """Record library event `event` on `stream` (DFL_OP_RECORD)."""

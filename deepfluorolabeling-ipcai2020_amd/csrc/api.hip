@@ -228,6 +228,11 @@ static int exec_one(const dfl_op* ops, int i, dfl_stream_t main_stream, bool ser
         break;
       }
       case DFL_OP_CONV: rc = dfl_conv2d(static_cast<const dfl_conv_args*>(p), stream); break;
+      case DFL_OP_CONV_PAIR: {
+        const dfl_conv_pair_args* a = static_cast<const dfl_conv_pair_args*>(p);
+        rc = dfl_conv2d_pair(a->a, a->b, stream);
+        break;
+      }
       case DFL_OP_WGRAD: rc = dfl_conv2d_wgrad(static_cast<const dfl_wgrad_args*>(p), stream); break;
       case DFL_OP_SUM_PARTIALS: {
         const dfl_sum_partials_args* a = static_cast<const dfl_sum_partials_args*>(p);

@@ -838,9 +838,19 @@ extern "C" int dfl_conv_config(const dfl_conv_args* a) {
   dfl::ConvK k;
   int rc = dfl::prepare(a, &k);
   if (rc != DFL_OK) return rc;
+  if (dfl::convs_first_ok(a)) return 16 + dfl::CONVS_TILE;
   if (dfl::direct_conv_ok(a)) return dfl::CFG_DIRECT;
   if (const int t = dfl::conv_rows_tile(k)) return t;
   return (int)dfl::pick_cfg(k.Mtot, a->Ntot, k.fast);
+}
+
+extern "C" int dfl_conv_pair_ok(const dfl_conv_args* a, const dfl_conv_args* b) { return dfl::convs_pair_ok(a, b); }
+
+extern "C" int dfl_conv2d_pair(const dfl_conv_args* a, const dfl_conv_args* b, dfl_stream_t stream) {
+  DFL_REQUIRE(a != nullptr && b != nullptr, "dfl_conv2d_pair: null arguments");
+  if (dfl::convs_pair_ok(a, b)) return dfl::convs_pair_launch(a, b, static_cast<hipStream_t>(stream));
+  const int rc = dfl_conv2d(a, stream);
+  return rc != DFL_OK ? rc : dfl_conv2d(b, stream);
 }
 
 extern "C" int dfl_conv2d(const dfl_conv_args* a, dfl_stream_t stream) {
@@ -852,6 +862,8 @@ extern "C" int dfl_conv2d(const dfl_conv_args* a, dfl_stream_t stream) {
     if (rc != DFL_OK) return rc;
     return dfl::convp_launch(p, static_cast<hipStream_t>(stream));
   }
+  if (a != nullptr && a->x != nullptr && a->w != nullptr && a->y != nullptr && dfl::convs_first_ok(a)) return dfl::convs_first_launch(a, static_cast<hipStream_t>(stream));
+  DFL_REQUIRE(a == nullptr || a->out_scale == nullptr, "dfl_conv2d: out_scale / out_shift are implemented by the latency form only (dfl_conv_config tells)");
   DFL_REQUIRE(a == nullptr || (a->x_mode == 0 && a->x_out == nullptr), "dfl_conv2d: x_mode (fused BatchNorm + ReLU backward operand) and x_out are implemented by the bf16 patch kernels only");
   {
     // live statistics outside the bf16 patch kernels: the 1-channel direct kernels (3x3 row form: stat_totals; 1x1: add_tot) and,

@@ -39,6 +39,10 @@ int convp_tune_add(const int32_t* key, const int32_t* g);
 bool convs_eligible(const dfl_conv_args& a, const ConvP& p);
 void convs_plan(const dfl_conv_args& a, ConvP* p, int force_splits);
 int convs_launch(const ConvP& p, hipStream_t s);
+bool convs_first_ok(const dfl_conv_args* a);                              // the 1-channel 3x3 first layer
+int convs_first_launch(const dfl_conv_args* a, hipStream_t s);
+int convs_pair_ok(const dfl_conv_args* a, const dfl_conv_args* b);     // dfl_conv_pair_ok
+int convs_pair_launch(const dfl_conv_args* a, const dfl_conv_args* b, hipStream_t s);
 
 struct WgP;
 int wgradp_suggest_splits(const dfl_wgrad_args* a);

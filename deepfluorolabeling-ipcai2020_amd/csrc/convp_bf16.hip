@@ -724,6 +724,7 @@ __global__ void __launch_bounds__(256) convp_finish_kernel(const ConvP p, int TX
   const __bf16* addp = reinterpret_cast<const __bf16*>(a.add);
   const __bf16* sop = reinterpret_cast<const __bf16*>(a.stat_other);
   __bf16* yp = reinterpret_cast<__bf16*>(a.y);
+  const float osc = (a.out_scale != nullptr && nok) ? a.out_scale[co] : 1.f, osh = (a.out_scale != nullptr && nok) ? a.out_shift[co] : 0.f;
   const int64_t slice = (int64_t)p.Mtot * Ntot;
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(r0 + rows_per_block, p.Mtot);
@@ -746,7 +747,8 @@ __global__ void __launch_bounds__(256) convp_finish_kernel(const ConvP p, int TX
       }
       __bf16* dst = yp + opix * a.ldy + co;
       if (a.accumulate) v += (float)*dst;
-      const __bf16 hv = (__bf16)v;
+      __bf16 hv = (__bf16)v;
+      if (a.out_scale != nullptr) hv = (__bf16)fmaf((float)hv, osc, osh);       // (latency form with K slices: the consumer's BatchNorm, include/dfl_hip.h)
       *dst = hv;
       const float vr = (float)hv;
       const float u = (sop != nullptr) ? ld_bf(sop + opix * a.ldso + co) : vr;
@@ -1084,6 +1086,7 @@ static int convp_plan_search(const dfl_conv_args* a, ConvP* p, int force_splits)
     return DFL_OK;
   }
 
+  DFL_REQUIRE(a->out_scale == nullptr, "dfl_conv2d (bf16): out_scale / out_shift are implemented by the latency form only (dfl_conv_config tells)");
   // a forced geometry (dfl_conv_force_geometry: tuners, tests) or an entry of the tuning table (dfl_conv_tune_add) wins
   // over the cost model, as long as it is valid for this layer and agrees with the caller's K slices
   double best = 1e300;

@@ -20,6 +20,14 @@
 //     18 ... 576 k-steps still is a few k-steps deep per wave, and over workgroups (fp32 partial slices + convp_finish_kernel)
 //     only for the weight-heavy levels whose 5 - 19 MB of weights need every CU's memory pipe.
 // Same arithmetic as convp_kernel: bf16 products, fp32 accumulation (another summation order), values rounded to bf16 once.
+//
+// PAIR form (dfl_conv2d_pair): the last 3x3 convolution of a residual block and the block's 1x1 convolution -- y1 = ReLU(conv(x) +
+// bias), y2 = conv1x1(x3) + bias3 + BN(y1) (unet.py:218-231) -- as ONE launch: the waves of a tile take the k-steps of the second
+// product behind their share of the first (a second accumulator tile), the epilogue rounds y1 to bf16, stores it and forms y2 from
+// the rounded value exactly as the two launches do.  11 of the 44 launches of a forward.
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 #include "convp.h"
 
@@ -36,13 +44,29 @@ __device__ __forceinline__ uint32_t spack_bf2(float a, float b) {
   return __builtin_bit_cast(uint32_t, h);
 }
 
-constexpr int SU = 8;              // k-steps per register set
+constexpr int SU = 9;              // k-steps per register set
+constexpr int SU2 = 4;             // k-steps per wave of a pair's second product (registers of their own)
 constexpr int SWAVES = 8;          // waves per workgroup
-constexpr int SRED_FLOATS = SWAVES * 16 * 64;
+constexpr int SCONST_FLOATS = SWAVES * 6 * 32;     // per wave: bias, add_scale, add_shift, bias3, out_scale, out_shift of its tile's 32 columns
 
-template <bool AFF>
-__global__ void __launch_bounds__(64 * SWAVES, 1) convs_kernel(const ConvP p) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];      // [8][16][64] partial tiles, then [2][Cin] scale / shift
+// second convolution of a pair (1x1, stride 1, no affine on load): y2 = x3 * w3 + bias3 + add_scale * y1 + add_shift
+struct ConvPair {
+  const void* x3;
+  const void* w3;
+  const float* bias3;
+  const float* add_scale;
+  const float* add_shift;
+  void* y2;
+  int ldx3, ldy2, ksteps2, kper2;
+  int x3_fp32;                     // the network's first block: x3 is the 1-channel fp32 image, w3 the fp32 quad-packed weights
+  uint32_t x3_bytes, w3_bytes;
+};
+
+template <bool AFF, bool PAIR>
+__global__ void __launch_bounds__(64 * SWAVES, 1) convs_kernel(const ConvP p, const ConvPair q) {
+  constexpr int NACC = PAIR ? 2 : 1;
+  constexpr int SRED = SWAVES * NACC * 16 * 64;          // floats: partial tiles of the workgroup's waves
+  extern __shared__ __attribute__((aligned(16))) float sm[];      // [8][NACC*16][64] partial tiles, [8][6][32] constants, [2][Cin] scale / shift
   const dfl_conv_args& a = p.a;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -69,22 +93,34 @@ __global__ void __launch_bounds__(64 * SWAVES, 1) convs_kernel(const ConvP p) {
 
   __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)p.x_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)p.w_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsX3 = rsX, rsW3 = rsW;
+  if constexpr (PAIR) {
+    rsX3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q.x3), 0, (int)q.x3_bytes, 0x00020000);
+    rsW3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q.w3), 0, (int)q.w3_bytes, 0x00020000);
+  }
 
-  // k-steps of this wave: slice (blockIdx.y, kw) of the layer's T * Cin / 16 steps, s = tap * cpk + chunk
+  // k-steps of this wave: slice (blockIdx.y, kw) of the layer's T * Cin / 16 steps, s = tap * cpk + chunk, walked as v = 0 .. n1 - 1.
+  // The second product of a PAIR has at most SU2 k-steps per wave (host): their fragments get registers of their own, are requested
+  // with the first ones and used last -- no branch per step in the main loop
   const int cpk_sh = p.s_cpk_shift, cpk = 1 << cpk_sh;
   const int KW = a.KW, kw_magic = (256 + KW - 1) / KW;
   const int slice = (int)blockIdx.y * ksplit + kw;
   const int s_begin = slice * p.s_kper;
-  const int s_end = min(p.s_ksteps, s_begin + p.s_kper);
+  const int n1 = max(0, min(p.s_ksteps, s_begin + p.s_kper) - s_begin);
+  const int t_begin = PAIR ? kw * q.kper2 : 0;
+  const int n2 = PAIR ? max(0, min(q.ksteps2, t_begin + q.kper2) - t_begin) : 0;
+  const int nv = n1;
+  const uint32_t x3off = PAIR ? (uint32_t)pix * (uint32_t)q.ldx3 * 2u + lh16 : 0u;
 
   su32x4 xb[2][SU], wb[2][SU];
   uint32_t okm[2] = {0u, 0u};
-  auto load_group = [&](int buf, int s0) {
+  auto load_group = [&](int buf, int v0) {
     uint32_t m = 0;
 #pragma unroll
     for (int u = 0; u < SU; ++u) {
-      const int s = s0 + u;                              // (wave-uniform)
-      const bool live = s < s_end;
+      const int v = v0 + u;                              // (wave-uniform)
+      const int s = s_begin + v;
+      const bool live = v < n1;
       const int tap = s >> cpk_sh, cc = s & (cpk - 1);
       const int ty = (tap * kw_magic) >> 8, tx = tap - ty * KW;
       const bool ok = pok && live && (unsigned)(iy0 + ty) < (unsigned)a.Hin && (unsigned)(ix0 + tx) < (unsigned)a.Win;
@@ -95,17 +131,19 @@ __global__ void __launch_bounds__(64 * SWAVES, 1) convs_kernel(const ConvP p) {
     }
     okm[buf] = m;
   };
+  su32x4 x2b[PAIR ? SU2 : 1], w2b[PAIR ? SU2 : 1];
 
-  f32x16 acc;
+  f32x16 acc, acc2;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  float* tab = sm + SRED_FLOATS;                         // [2][Cin]
-  auto compute_group = [&](int buf, int s0) {
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f, acc2[r] = 0.f;
+  float* cst = sm + SRED + wave * 192;                   // this wave's [6][32] epilogue constants
+  float* tab = sm + SRED + SCONST_FLOATS;                // [2][Cin]
+  auto compute_group = [&](int buf, int v0) {
 #pragma unroll
     for (int u = 0; u < SU; ++u) {
       su32x4 x = xb[buf][u];
       if constexpr (AFF) {                               // BatchNorm affine of the input; zero padding applies AFTER it
-        const int cc = (s0 + u) & (cpk - 1);
+        const int cc = (s_begin + v0 + u) & (cpk - 1);
         const float* sc = tab + cc * 16 + lh * 8;
         const float* sh = sc + a.Cin;
         const float4 s0v = *reinterpret_cast<const float4*>(sc), s1v = *reinterpret_cast<const float4*>(sc + 4);
@@ -122,48 +160,79 @@ __global__ void __launch_bounds__(64 * SWAVES, 1) convs_kernel(const ConvP p) {
     }
   };
 
-  // ---- everything the epilogue needs from memory is requested before the k-steps as well: this wave finishes the accumulator
-  //      groups g = kw, kw + ksplit, ... (< 4) of its tile: channels ni*32 + 8 g + 4 lh + 0..3 of the lane's pixel
+  // ---- what the epilogue needs from memory is requested FIRST (loads return in order: the LDS copies below then wait for these
+  //      few loads only, the fragments behind them land meanwhile): per wave the constants of its tile's 32 columns (lane l < 32:
+  //      column ni*32 + l) and, AFF, the scale / shift table of the input channels
   const bool sliced = p.splits > 1;
   const bool scat = a.scatter2x2 != 0;
-  float4 cbias[4], casc[4], cash[4];
-  su32x2 addv[4];
   const unsigned short* addp = reinterpret_cast<const unsigned short*>(a.add);
-  // (AFF) the scale / shift table is requested FIRST: loads return in order, so the wait in front of its LDS copy and barrier does
-  // not wait for the fragments behind it -- they land while the table is written
+  const float* asc_p = PAIR ? q.add_scale : a.add_scale;
+  const float* ash_p = PAIR ? q.add_shift : a.add_shift;
+  float k0 = 0.f, k1 = 1.f, k2 = 0.f, k3 = 0.f, k4 = 1.f, k5 = 0.f;
+  {
+    const int c = ni * 32 + li;
+    const bool on = tok && c < a.Ntot && lh == 0;
+    const int cco = scat ? c % p.Cout : c;
+    if (on && a.bias != nullptr) k0 = a.bias[cco];
+    if (on && asc_p != nullptr) k1 = asc_p[c], k2 = ash_p[c];
+    if (PAIR && on && q.bias3 != nullptr) k3 = q.bias3[c];
+    if (!PAIR && on && a.out_scale != nullptr) k4 = a.out_scale[cco], k5 = a.out_shift[cco];
+  }
   float tsc[2] = {1.f, 1.f}, tsh[2] = {0.f, 0.f};
   if constexpr (AFF) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int c = tid + q * 64 * SWAVES;
+    for (int e = 0; e < 2; ++e) {
+      const int c = tid + e * 64 * SWAVES;
       if (c < a.Cin) {
-        tsc[q] = a.in_scale[c];
-        tsh[q] = a.in_shift[c];
+        tsc[e] = a.in_scale[c];
+        tsh[e] = a.in_shift[c];
       }
     }
   }
-  load_group(0, s_begin);
-  if (s_begin + SU < s_end) load_group(1, s_begin + SU);
-  // (which wave finishes which group: one wave of the tile -> all four; two -> g = kw, kw + 2; four -> g = kw; eight -> the even
-  //  wave 2g finishes group g, see below)
+  load_group(0, 0);
+  if (SU < nv) load_group(1, SU);
+  if constexpr (PAIR) {
+#pragma unroll
+    for (int u = 0; u < SU2; ++u) {
+      const int t = t_begin + u;
+      const bool live = u < n2;
+      x2b[u] = __builtin_amdgcn_raw_buffer_load_b128(rsX3, (pok && live) ? x3off + (uint32_t)(t * 32) : SOOB, 0, 0);
+      w2b[u] = __builtin_amdgcn_raw_buffer_load_b128(rsW3, (live && nok) ? (uint32_t)t * wrow + wcol : SOOB, 0, 0);
+    }
+  }
+  // (which wave finishes which accumulator group -- channels ni*32 + 8 g + 4 lh + 0..3 of the lane's pixel: one wave of the tile ->
+  //  all four; two -> g = kw, kw + 2; four -> g = kw; eight -> the even wave 2g finishes group g, see below)
   auto owns = [&](int g) { return ksplit == 8 ? ((kw >> 1) == g && (kw & 1) == 0) : ((g & (ksplit - 1)) == kw); };
+  su32x2 addv[4];
+  float x3v = 0.f;
+  float4 w3v[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int c = ni * 32 + 8 * g + 4 * lh;
     const bool on = !sliced && owns(g) && pok && c < a.Ntot;
-    const int cco = scat ? c % p.Cout : c;
-    cbias[g] = (on && a.bias != nullptr) ? *reinterpret_cast<const float4*>(a.bias + cco) : make_float4(0.f, 0.f, 0.f, 0.f);
-    casc[g] = (on && addp != nullptr && a.add_scale != nullptr) ? *reinterpret_cast<const float4*>(a.add_scale + c) : make_float4(1.f, 1.f, 1.f, 1.f);
-    cash[g] = (on && addp != nullptr && a.add_scale != nullptr) ? *reinterpret_cast<const float4*>(a.add_shift + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    addv[g] = (on && addp != nullptr) ? *reinterpret_cast<const su32x2*>(addp + ((uint32_t)pix * (uint32_t)a.ldadd + (uint32_t)c)) : (su32x2){0u, 0u};
+    addv[g] = (!PAIR && on && addp != nullptr) ? *reinterpret_cast<const su32x2*>(addp + ((uint32_t)pix * (uint32_t)a.ldadd + (uint32_t)c)) : (su32x2){0u, 0u};
+    w3v[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (PAIR && q.x3_fp32 && on) {                       // fp32 quad-packed weights of a 1-channel 1x1 window: w[n][0]
+      const float* wq = reinterpret_cast<const float*>(q.w3) + (int64_t)c * 4;
+      w3v[g] = make_float4(wq[0], wq[4], wq[8], wq[12]);
+    }
+  }
+  if (PAIR && q.x3_fp32 && pok) x3v = reinterpret_cast<const float*>(q.x3)[(int64_t)pix * q.ldx3];
+  if (lh == 0) {
+    cst[li] = k0;
+    cst[32 + li] = k1;
+    cst[64 + li] = k2;
+    cst[96 + li] = k3;
+    cst[128 + li] = k4;
+    cst[160 + li] = k5;
   }
   if constexpr (AFF) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int c = tid + q * 64 * SWAVES;
+    for (int e = 0; e < 2; ++e) {
+      const int c = tid + e * 64 * SWAVES;
       if (c < a.Cin) {
-        tab[c] = tsc[q];
-        tab[a.Cin + c] = tsh[q];
+        tab[c] = tsc[e];
+        tab[a.Cin + c] = tsh[e];
       }
     }
     __syncthreads();
@@ -171,43 +240,55 @@ __global__ void __launch_bounds__(64 * SWAVES, 1) convs_kernel(const ConvP p) {
 
   // ---- k-steps
   {
-    int s0 = s_begin;
+    int v0 = 0;
     while (true) {
-      compute_group(0, s0);
-      s0 += SU;
-      if (s0 >= s_end) break;
-      if (s0 + SU < s_end) load_group(0, s0 + SU);
-      compute_group(1, s0);
-      s0 += SU;
-      if (s0 >= s_end) break;
-      if (s0 + SU < s_end) load_group(1, s0 + SU);
+      compute_group(0, v0);
+      v0 += SU;
+      if (v0 >= nv) break;
+      if (v0 + SU < nv) load_group(0, v0 + SU);
+      compute_group(1, v0);
+      v0 += SU;
+      if (v0 >= nv) break;
+      if (v0 + SU < nv) load_group(1, v0 + SU);
     }
+  }
+  if constexpr (PAIR) {
+#pragma unroll
+    for (int u = 0; u < SU2; ++u)
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w2b[u]), __builtin_bit_cast(bf16x8_t, x2b[u]), acc2, 0, 0, 0);
   }
 
   // ---- the waves of a tile add up through LDS (fixed order), each finishing its share of the accumulator groups
   if (ksplit > 1) {
-    float* mine = sm + (wave * 16) * 64 + lane;
+    float* mine = sm + (wave * NACC * 16) * 64 + lane;
 #pragma unroll
     for (int r = 0; r < 16; ++r) mine[r * 64] = acc[r];
+    if constexpr (PAIR) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mine[(16 + r) * 64] = acc2[r];
+    }
     __syncthreads();
   }
   unsigned short* yp = reinterpret_cast<unsigned short*>(a.y);
-  auto finish_group = [&](int g, float4 v) {
+  auto finish_group = [&](int g, float4 v, float4 v2) {
     const int c = ni * 32 + 8 * g + 4 * lh;
     if (!pok || c >= a.Ntot) return;
     if (sliced) {                                        // raw sums of this K slice: convp_finish_kernel does the rest
       *reinterpret_cast<float4*>(a.partial + ((int64_t)blockIdx.y * p.Mtot + pix) * a.Ntot + c) = v;
       return;
     }
-    v.x += cbias[g].x; v.y += cbias[g].y; v.z += cbias[g].z; v.w += cbias[g].w;
+    const float4 cb = *reinterpret_cast<const float4*>(cst + 8 * g + 4 * lh);
+    const float4 cs = *reinterpret_cast<const float4*>(cst + 32 + 8 * g + 4 * lh);
+    const float4 ch = *reinterpret_cast<const float4*>(cst + 64 + 8 * g + 4 * lh);
+    v.x += cb.x; v.y += cb.y; v.z += cb.z; v.w += cb.w;
     if (a.relu) {
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     }
-    if (addp != nullptr) {
-      v.x += fmaf(sbf_lo(addv[g].x), casc[g].x, cash[g].x);
-      v.y += fmaf(sbf_hi(addv[g].x), casc[g].y, cash[g].y);
-      v.z += fmaf(sbf_lo(addv[g].y), casc[g].z, cash[g].z);
-      v.w += fmaf(sbf_hi(addv[g].y), casc[g].w, cash[g].w);
+    if (!PAIR && addp != nullptr) {
+      v.x += fmaf(sbf_lo(addv[g].x), cs.x, ch.x);
+      v.y += fmaf(sbf_hi(addv[g].x), cs.y, ch.y);
+      v.z += fmaf(sbf_lo(addv[g].y), cs.z, ch.z);
+      v.w += fmaf(sbf_hi(addv[g].y), cs.w, ch.w);
     }
     uint32_t opix = (uint32_t)pix;
     int ocol = c;
@@ -224,44 +305,90 @@ __global__ void __launch_bounds__(64 * SWAVES, 1) convs_kernel(const ConvP p) {
     su32x2 w;
     w.x = spack_bf2(v.x, v.y);
     w.y = spack_bf2(v.z, v.w);
+    if (!PAIR && a.out_scale != nullptr) {               // the consumer's BatchNorm, applied to the ROUNDED value and rounded as the consumer would
+      const float4 os = *reinterpret_cast<const float4*>(cst + 128 + 8 * g + 4 * lh);
+      const float4 oh = *reinterpret_cast<const float4*>(cst + 160 + 8 * g + 4 * lh);
+      const su32x2 t = w;
+      w.x = spack_bf2(fmaf(sbf_lo(t.x), os.x, oh.x), fmaf(sbf_hi(t.x), os.y, oh.y));
+      w.y = spack_bf2(fmaf(sbf_lo(t.y), os.z, oh.z), fmaf(sbf_hi(t.y), os.w, oh.w));
+    }
     *reinterpret_cast<su32x2*>(dst) = w;
+    if constexpr (PAIR) {
+      // the second convolution's epilogue, as its own launch performs it: product + bias3, then + BN(y1) of the ROUNDED y1
+      const float4 c3 = *reinterpret_cast<const float4*>(cst + 96 + 8 * g + 4 * lh);
+      float4 o;
+      if (q.x3_fp32) {                                   // (direct_conv_kernel<1,1,1>: acc = bias; acc = fma(x, w, acc))
+        o.x = fmaf(x3v, w3v[g].x, c3.x); o.y = fmaf(x3v, w3v[g].y, c3.y); o.z = fmaf(x3v, w3v[g].z, c3.z); o.w = fmaf(x3v, w3v[g].w, c3.w);
+      } else {
+        o.x = v2.x + c3.x; o.y = v2.y + c3.y; o.z = v2.z + c3.z; o.w = v2.w + c3.w;
+      }
+      o.x += fmaf(sbf_lo(w.x), cs.x, ch.x);
+      o.y += fmaf(sbf_hi(w.x), cs.y, ch.y);
+      o.z += fmaf(sbf_lo(w.y), cs.z, ch.z);
+      o.w += fmaf(sbf_hi(w.y), cs.w, ch.w);
+      su32x2 w2;
+      w2.x = spack_bf2(o.x, o.y);
+      w2.y = spack_bf2(o.z, o.w);
+      *reinterpret_cast<su32x2*>(reinterpret_cast<unsigned short*>(q.y2) + ((uint32_t)pix * (uint32_t)q.ldy2 + (uint32_t)c)) = w2;
+    }
   };
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (ksplit == 1) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) finish_group(g, make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]));
+    for (int g = 0; g < 4; ++g)
+      finish_group(g, make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]),
+                   PAIR ? make_float4(acc2[4 * g], acc2[4 * g + 1], acc2[4 * g + 2], acc2[4 * g + 3]) : zero4);
   } else if (ksplit <= 4) {
     // wave kw of the tile's ksplit waves takes the groups g = kw, kw + ksplit, ...
-    const float* base = sm + ((grp << ksh) * 16) * 64 + lane;
+    const float* base = sm + ((grp << ksh) * NACC * 16) * 64 + lane;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       if ((g & (ksplit - 1)) != kw) continue;
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int q = 0; q < ksplit; ++q)
+      float v[4] = {0.f, 0.f, 0.f, 0.f}, v2[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int w_ = 0; w_ < ksplit; ++w_) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += base[(q * 16 + 4 * g + j) * 64];
-      finish_group(g, make_float4(v[0], v[1], v[2], v[3]));
+        for (int j = 0; j < 4; ++j) v[j] += base[(w_ * NACC * 16 + 4 * g + j) * 64];
+        if constexpr (PAIR) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v2[j] += base[(w_ * NACC * 16 + 16 + 4 * g + j) * 64];
+        }
+      }
+      finish_group(g, make_float4(v[0], v[1], v[2], v[3]), make_float4(v2[0], v2[1], v2[2], v2[3]));
     }
   } else {
     // eight waves: the even ones finish one group each (g = kw / 2); the sums are formed by ALL lanes of waves 2g and 2g + 1 --
     // wave 2g adds the partial tiles 0..3, wave 2g + 1 the tiles 4..7 -- and meet in LDS once more
     const float* base = sm + lane;
     const int g = kw >> 1, half = kw & 1;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int q = 4 * half; q < 4 * half + 4; ++q)
+    float v[4] = {0.f, 0.f, 0.f, 0.f}, v2[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int w_ = 4 * half; w_ < 4 * half + 4; ++w_) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] += base[(q * 16 + 4 * g + j) * 64];
+      for (int j = 0; j < 4; ++j) v[j] += base[(w_ * NACC * 16 + 4 * g + j) * 64];
+      if constexpr (PAIR) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v2[j] += base[(w_ * NACC * 16 + 16 + 4 * g + j) * 64];
+      }
+    }
     __syncthreads();                                     // every partial tile has been read
     if (half) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) sm[(g * 4 + j) * 64 + lane] = v[j];
+      for (int j = 0; j < 4; ++j) sm[(g * 8 + j) * 64 + lane] = v[j];
+      if constexpr (PAIR) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sm[(g * 8 + 4 + j) * 64 + lane] = v2[j];
+      }
     }
     __syncthreads();
     if (!half) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] += sm[(g * 4 + j) * 64 + lane];
+      for (int j = 0; j < 4; ++j) v[j] += sm[(g * 8 + j) * 64 + lane];
+      if constexpr (PAIR) {
 #pragma unroll
-      for (int gg = 0; gg < 4; ++gg)                     // (static register indices: a run-time g would put the epilogue constants in scratch)
-        if (gg == g) finish_group(gg, make_float4(v[0], v[1], v[2], v[3]));
+        for (int j = 0; j < 4; ++j) v2[j] += sm[(g * 8 + 4 + j) * 64 + lane];
+      }
+#pragma unroll
+      for (int gg = 0; gg < 4; ++gg)                     // (static register indices: a run-time g would put per-group registers in scratch)
+        if (gg == g) finish_group(gg, make_float4(v[0], v[1], v[2], v[3]), make_float4(v2[0], v2[1], v2[2], v2[3]));
     }
   }
 }
@@ -281,6 +408,7 @@ bool convs_eligible(const dfl_conv_args& a, const ConvP& p) {
   if (!a.latency_form || !convs_switch()) return false;
   if (a.x_mode != 0 || a.x_out != nullptr || a.stat_partials != nullptr || a.stat_totals != nullptr || a.stat_other != nullptr) return false;
   if (a.in_tot != nullptr || a.add_tot != nullptr) return false;
+  if (a.out_scale != nullptr && a.accumulate) return false;
   const int cpk = a.Cin / 16;
   if (cpk < 1 || (cpk & (cpk - 1)) != 0 || a.Cin > 1024) return false;
   if (a.KW > 16 || a.Ntot % 8 != 0 || p.Mtot > (1 << 16)) return false;
@@ -292,8 +420,6 @@ bool convs_eligible(const dfl_conv_args& a, const ConvP& p) {
   // channels -- 36 or more k-steps on 288+ pixel tiles, i.e. three dependent load rounds per wave here -- stay with the patch kernels
   // (14 -> 17, 13 -> 15, 15 -> 17 us with this form); everything else of a 192x192 forward is 1 - 7 us shorter
   if (p.Mtot >= 9216 && p.T * (a.Cin / 16) >= 36) return false;
-  if (a.bias != nullptr && (reinterpret_cast<uintptr_t>(a.bias) & 15u) != 0) return false;
-  if (a.add != nullptr && a.add_scale != nullptr && ((reinterpret_cast<uintptr_t>(a.add_scale) & 15u) != 0 || (reinterpret_cast<uintptr_t>(a.add_shift) & 15u) != 0)) return false;
   if (a.ldadd % 4 != 0 || a.ldy % 4 != 0) return false;
   return true;
 }
@@ -327,18 +453,164 @@ void convs_plan(const dfl_conv_args& a, ConvP* p, int force_splits) {
   p->splits = zs;
   p->tile = CONVS_TILE;
   p->grid = (int)ceil_div(tiles, SWAVES >> ksh);
-  p->lds_bytes = SRED_FLOATS * 4 + 2 * a.Cin * 4;
+  p->lds_bytes = (SWAVES * 16 * 64 + SCONST_FLOATS + 2 * a.Cin) * 4;
 }
 
 int convs_launch(const ConvP& p, hipStream_t s) {
   dim3 grid((unsigned)p.grid, (unsigned)p.splits);
   const size_t lds = (size_t)p.lds_bytes;
+  ConvPair none;
+  memset(&none, 0, sizeof(none));
   if (p.a.in_scale != nullptr) {
-    hipLaunchKernelGGL(convs_kernel<true>, grid, dim3(64 * SWAVES), lds, s, p);
+    hipLaunchKernelGGL((convs_kernel<true, false>), grid, dim3(64 * SWAVES), lds, s, p, none);
   } else {
-    hipLaunchKernelGGL(convs_kernel<false>, grid, dim3(64 * SWAVES), lds, s, p);
+    hipLaunchKernelGGL((convs_kernel<false, false>), grid, dim3(64 * SWAVES), lds, s, p, none);
   }
   return check_launch("dfl_conv2d (bf16, latency form)");
+}
+
+// ---- pairs (dfl_conv2d_pair): conditions under which (a, b) run as one launch; pa = a's plan in latency form
+static bool pair_ok(const dfl_conv_args* a, const dfl_conv_args* b, const ConvP& pa) {
+  if (pa.tile != CONVS_TILE || pa.splits > 1) return false;
+  if (a->scatter2x2 || a->accumulate || a->add != nullptr || a->out_scale != nullptr || a->in_scale != nullptr) return false;
+  if (b->x_bf16 && ceil_div(b->Cin / 16, 1 << pa.s_ksplit_shift) > SU2) return false;
+  if (!b->latency_form || !b->y_bf16 || b->KH != 1 || b->KW != 1 || b->stride != 1 || b->pad != 0 || b->scatter2x2 || b->accumulate || b->relu) return false;
+  if (b->in_scale != nullptr || b->in_tot != nullptr || b->add_tot != nullptr || b->x_mode != 0 || b->x_out != nullptr || b->out_scale != nullptr) return false;
+  if (b->stat_partials != nullptr || b->stat_totals != nullptr || b->stat_other != nullptr || b->splits > 1) return false;
+  if (b->add != a->y || b->ldadd != a->ldy || b->add_scale == nullptr || b->add_shift == nullptr) return false;
+  if (b->N != a->N || b->Hout != a->Hout || b->Wout != a->Wout || b->Hin != a->Hout || b->Win != a->Wout || b->Ntot != a->Ntot) return false;
+  if (b->y == a->y || b->y == nullptr || b->ldy % 4 != 0 || b->x == nullptr || b->w == nullptr) return false;
+  if (b->x_bf16) {
+    if (b->w_split != 2 || b->Cin % 16 != 0 || b->ldx % 8 != 0 || !aligned16(b->x) || !aligned16(b->w)) return false;
+    const int64_t xb = (((int64_t)b->N * b->Hin * b->Win - 1) * b->ldx + b->Cin) * 2, wb = (int64_t)b->Cin * b->Ntot * 2;
+    if (xb >= (1ll << 31) - 4096 || wb >= (1ll << 31) - 4096) return false;
+  } else {
+    if (b->Cin != 1 || b->w_split != 0 || b->x_split != 0) return false;          // the network's first block: 1-channel fp32 image
+  }
+  return true;
+}
+
+int convs_pair_ok(const dfl_conv_args* a, const dfl_conv_args* b) {
+  if (a == nullptr || b == nullptr || !a->x_bf16 || !a->latency_form) return 0;
+  ConvP pa;
+  if (convp_plan(a, &pa, a->splits > 1 ? a->splits : 1) != DFL_OK) return 0;
+  return pair_ok(a, b, pa) ? 1 : 0;
+}
+
+// a then b as ONE launch (the caller has checked convs_pair_ok)
+int convs_pair_launch(const dfl_conv_args* a, const dfl_conv_args* b, hipStream_t s) {
+  ConvP p;
+  int rc = convp_plan(a, &p, 1);
+  if (rc != DFL_OK) return rc;
+  DFL_REQUIRE(pair_ok(a, b, p), "dfl_conv2d_pair: these two convolutions do not form a pair");
+  ConvPair q;
+  memset(&q, 0, sizeof(q));
+  q.x3 = b->x;
+  q.w3 = b->w;
+  q.bias3 = b->bias;
+  q.add_scale = b->add_scale;
+  q.add_shift = b->add_shift;
+  q.y2 = b->y;
+  q.ldx3 = b->ldx;
+  q.ldy2 = b->ldy;
+  q.x3_fp32 = b->x_bf16 ? 0 : 1;
+  if (b->x_bf16) {
+    q.ksteps2 = b->Cin / 16;
+    q.kper2 = (int)ceil_div(q.ksteps2, 1 << p.s_ksplit_shift);
+    q.x3_bytes = (uint32_t)((((int64_t)b->N * b->Hin * b->Win - 1) * b->ldx + b->Cin) * 2);
+    q.w3_bytes = (uint32_t)((int64_t)b->Cin * b->Ntot * 2);
+  }
+  dim3 grid((unsigned)p.grid, 1);
+  const size_t lds = (size_t)(SWAVES * 2 * 16 * 64 + SCONST_FLOATS + 2 * a->Cin) * 4;
+  auto k = convs_kernel<false, true>;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  (void)attr;
+  hipLaunchKernelGGL(k, grid, dim3(64 * SWAVES), lds, s, p, q);
+  return check_launch("dfl_conv2d_pair");
+}
+
+
+// ---- the network's first convolution in the same spirit (1-channel fp32 image, 3x3 window, stride 1: unet.py:211 with in_channels = 1):
+// direct_conv3_rows_kernel walks bands of rows, three per workgroup -- 32 workgroups for one 192x192 image, 13 us.  Here a thread owns
+// one pixel and 8 channels (a wave: 64 consecutive pixels of one channel group): 9 loads of the image, the 9 x 8 weights from LDS,
+// the multiply-adds in direct_conv3_rows_kernel's order (bit-identical results), one 16-byte store.
+__global__ void __launch_bounds__(256) convs_first_kernel(const dfl_conv_args a, int M) {
+  __shared__ __attribute__((aligned(16))) float wl[9 * 64 + 3 * 64];          // [9][Ntot] weights, bias, out_scale, out_shift
+  const int ncg = a.Ntot >> 3;                            // channel groups of 8
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wpb = 4;                                      // waves per block
+  const int gw = (int)blockIdx.x * wpb + wave;            // global wave: (pixel block of 64, channel group)
+  const int cg = gw % ncg, pb = gw / ncg;
+  const int pix = pb * 64 + lane;
+  const bool pok = pix < M;
+  const int HW = a.Hout * a.Wout;
+  const int img = pix / HW, rem = pix - img * HW;
+  const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
+  float xv[9];
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int iy = oy - a.pad + dy, ix = ox - a.pad + dx;
+      const bool ok = pok && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+      xv[dy * 3 + dx] = ok ? a.x[((int64_t)(img * a.Hin + iy) * a.Win + ix) * a.ldx] : 0.f;
+    }
+  const int Nt = a.Ntot;
+  for (int i = threadIdx.x; i < 9 * Nt; i += 256) {
+    const int k = i / Nt, nn = i - k * Nt;
+    wl[i] = a.w[((int64_t)(k >> 2) * Nt + nn) * 4 + (k & 3)];                 // quad-packed operand
+  }
+  for (int i = threadIdx.x; i < Nt; i += 256) {
+    wl[9 * Nt + i] = a.bias != nullptr ? a.bias[i] : 0.f;
+    wl[10 * Nt + i] = a.out_scale != nullptr ? a.out_scale[i] : 1.f;
+    wl[11 * Nt + i] = a.out_scale != nullptr ? a.out_shift[i] : 0.f;
+  }
+  __syncthreads();
+  const int n0 = cg * 8;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = wl[9 * Nt + n0 + j];
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv[k], wl[k * Nt + n0 + j], acc[j]);
+  if (a.relu) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = fmaxf(acc[j], 0.f);
+  }
+  su32x4 w;
+  w.x = spack_bf2(acc[0], acc[1]);
+  w.y = spack_bf2(acc[2], acc[3]);
+  w.z = spack_bf2(acc[4], acc[5]);
+  w.w = spack_bf2(acc[6], acc[7]);
+  if (a.out_scale != nullptr) {
+    const float* os = wl + 10 * Nt + n0;
+    const float* oh = wl + 11 * Nt + n0;
+    const su32x4 t = w;
+    w.x = spack_bf2(fmaf(sbf_lo(t.x), os[0], oh[0]), fmaf(sbf_hi(t.x), os[1], oh[1]));
+    w.y = spack_bf2(fmaf(sbf_lo(t.y), os[2], oh[2]), fmaf(sbf_hi(t.y), os[3], oh[3]));
+    w.z = spack_bf2(fmaf(sbf_lo(t.z), os[4], oh[4]), fmaf(sbf_hi(t.z), os[5], oh[5]));
+    w.w = spack_bf2(fmaf(sbf_lo(t.w), os[6], oh[6]), fmaf(sbf_hi(t.w), os[7], oh[7]));
+  }
+  if (pok) *reinterpret_cast<su32x4*>(reinterpret_cast<unsigned short*>(a.y) + ((int64_t)pix * a.ldy + n0)) = w;
+}
+
+bool convs_first_ok(const dfl_conv_args* a) {
+  if (!a->latency_form || !convs_switch()) return false;
+  if (a->x_bf16 || !a->y_bf16 || a->Cin != 1 || a->KH != 3 || a->KW != 3 || a->stride != 1) return false;
+  if (a->Ntot % 8 != 0 || a->Ntot > 64 || a->ldy % 8 != 0 || !aligned16(a->y)) return false;
+  if (a->add != nullptr || a->accumulate || a->scatter2x2 || a->splits > 1 || a->in_scale != nullptr || a->in_tot != nullptr) return false;
+  if (a->stat_partials != nullptr || a->stat_totals != nullptr || a->stat_other != nullptr || a->x_mode != 0) return false;
+  const int ho = a->Hin + 2 * a->pad - 2, wo = a->Win + 2 * a->pad - 2;
+  if (ho != a->Hout || wo != a->Wout) return false;
+  return (int64_t)a->N * a->Hout * a->Wout <= (1 << 16);
+}
+
+int convs_first_launch(const dfl_conv_args* a, hipStream_t s) {
+  const int M = a->N * a->Hout * a->Wout;
+  const int waves = (int)ceil_div(M, 64) * (a->Ntot / 8);
+  hipLaunchKernelGGL(convs_first_kernel, dim3((unsigned)ceil_div(waves, 4)), dim3(256), 0, s, *a, M);
+  return check_launch("dfl_conv2d (first layer, latency form)");
 }
 
 }  // namespace dfl

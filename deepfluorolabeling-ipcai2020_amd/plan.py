@@ -286,7 +286,7 @@ class UNetPlan:
     # ------------------------------------------------------------------------------------------ op helpers
     def _conv(self, prog, x, w, y, KH, KW, stride, pad, Ntot, bias=None, in_aff=None, relu=0, add=None,
               add_aff=None, accumulate=0, scatter=0, stats=False, stat_other=None, Hout=None, Wout=None, x_split=0, brb=None,
-              in_live=None, add_live=None, stat_totals=None, x_out=None):
+              in_live=None, add_live=None, stat_totals=None, x_out=None, out_aff=None):
         """in_live / add_live: (totals, gamma, beta, count) of a live BatchNorm instead of the (scale, shift) vectors of in_aff /
         add_aff; stat_totals: the producer adds its statistics there instead of leaving partial rows (include/dfl_hip.h)."""
         a = ConvArgs()
@@ -328,6 +328,14 @@ class UNetPlan:
         # inference plans ask for the latency form of the bf16 convolution (include/dfl_hip.h: a hint the library honours for the
         # small problems of a batch-1 forward -- the per-image loops of util.py -- and ignores for everything else)
         a.latency_form = 1 if (self.bf16 and not self.training and not self.need_grad and os.environ.get('DFL_PLAN_LATENCY_FORM', '1') != '0') else 0
+        self._out_aff_taken = False
+        if out_aff is not None:
+            # the consumer's eval-mode BatchNorm applied by this (producing) kernel: only the latency form does that
+            a.out_scale, a.out_shift = out_aff[0].data_ptr(), out_aff[1].data_ptr()
+            if self.lib.dfl_conv_config(C.addressof(a)) == 16 + nat.CONV_CFG_LATENCY:
+                self._out_aff_taken = True
+            else:
+                a.out_scale, a.out_shift = None, None
         sp = nat.check(self.lib.dfl_conv_suggest_splits(C.addressof(a)), 'dfl_conv_suggest_splits')
         if sp > 1:
             M = x.N * (x.H * x.W if scatter else a.Hout * a.Wout)
@@ -354,6 +362,8 @@ class UNetPlan:
     # (fork after dpre is written; joined before dpre's buffer is rewritten two layers later, before a batched sum
     # reads its slices, and at the end of backward).  Measured: +10 % on an isolated pair for 24x24..96x96 layers, -8 % at
     # 192x192 -- but nothing inside the real backward pass (both kernels just run slower side by side), so it is off by default.
+    OUT_AFF = os.environ.get('DFL_PLAN_OUT_AFF', '1') != '0'  # (0: A/B against the BatchNorm affine on load)
+    PAIRS = os.environ.get('DFL_PLAN_PAIRS', '1') != '0'      # (0: A/B against two launches per residual block end)
     SIDE_STREAM = False     # off: inside the whole backward pass the pair runs no faster (r01)
     SIDE_MAX_PIXELS = 16 * 96 * 96
 
@@ -711,15 +721,22 @@ class UNetPlan:
                 live_bwd = (self.LIVE_BN and bn and self.training and self.bf16 and self.FUSE_BRB and self.FUSE_BWD_STATS and not circ
                             and self.need_grad and (patch_in(cur) or (one_ch(cur) and d == 0 and first and not self.input_grad)))
                 # (this layer's backward can take live (sum dy, sum dy*r): its consumers derive the coefficients)
+                # inference: the BatchNorm between this convolution and the block's next one is applied by THIS kernel where it runs in
+                # latency form (dfl_conv_args.out_scale: the consumer's two roundings, bit for bit) -- the consumer then reads its operand
+                # plain instead of converting 8 channels per lane and k-step on its way into the matrix instruction
+                pre_aff = None
+                if (bn and self.OUT_AFF and self.bf16 and not self.training and not self.need_grad and not circ and pad == 1 and d < bd - 1):
+                    pre_aff = (self._new(Cout), self._new(Cout))
                 part = self._conv(fwd, gin, wp, r, 3, 3, 1, 0 if circ else pad, Cout, bias=b,
                                    in_aff=None if cur_live is not None else cur_aff, in_live=cur_live, relu=1,
-                                   stats=bn and self.training, stat_totals=tot)
+                                   stats=bn and self.training, stat_totals=tot, out_aff=pre_aff)
+                out_aff_taken = pre_aff is not None and self._out_aff_taken
                 aff = None
                 bnrec = None
                 if bn:
                     bname = '%s.block.%d' % (prefix, d * step + 2)
                     gamma, beta = P[bname + '.weight'], P[bname + '.bias']
-                    scale, shift = self._new(Cout), self._new(Cout)
+                    scale, shift = pre_aff if out_aff_taken else (self._new(Cout), self._new(Cout))
                     mean, invstd = self._new(Cout), self._new(Cout)
                     if self.training and live:
                         self._live_jobs.append(dict(totals=tot, gamma=gamma, beta=beta, bname=bname, scale=scale, shift=shift, mean=mean,
@@ -756,7 +773,7 @@ class UNetPlan:
                     self.dbg['bn:' + bname] = (scale, shift, mean, invstd)
                 convs.append(dict(w=w, wname=wname, inp=cur, gin=gin, inp_aff=cur_aff, r=r, bn=bnrec, live_bwd=live_bwd))
                 self.relu_out['%s.block.%d' % (prefix, d * step + 1)] = r      # (module name of the nn.ReLU: tests read its mask)
-                cur, cur_aff = r, aff
+                cur, cur_aff = r, (None if out_aff_taken else aff)       # (out_aff_taken: r holds BN(ReLU(.)) already)
                 cur_live = (tot, gamma, beta, N * Ho * Wo) if (bn and self.training and live) else None
             assert cur.H == Hb and cur.W == Wb
             if do_res:
@@ -764,6 +781,14 @@ class UNetPlan:
                 rwp = self._pack_conv_fwd(rw)
                 self._conv(fwd, xin, rwp, out, 1, 1, 1, 0, Cout, bias=rb, add=cur, add_aff=None if cur_live is not None else cur_aff,
                            add_live=cur_live)
+                # inference: the block's last 3x3 convolution and this 1x1 run as ONE launch where the library can (dfl_conv2d_pair:
+                # the latency form of a batch-1 forward -- 11 launches less in its chain of 44)
+                if (self.PAIRS and not self.training and not self.need_grad and len(fwd) >= 2 and isinstance(fwd.structs[-2], ConvArgs)
+                        and self.lib.dfl_conv_pair_ok(C.addressof(fwd.structs[-2]), C.addressof(fwd.structs[-1])) == 1):
+                    b_ = fwd.pop()
+                    a_ = fwd.pop()
+                    fwd.keep += [a_, b_]
+                    fwd.add(nat.ConvPairArgs(a=C.addressof(a_), b=C.addressof(b_)))
             else:
                 a = AffineCopyArgs(x=cur.ptr, y=out.ptr, N=N, H=Hb, W=Wb, C=Cout, ldx=cur.ld, xH=Hb, xW=Wb,
                                    ldy=out.ld, yH=out.H, yW=out.W, bf16=cur.bf16)

@@ -145,10 +145,24 @@ typedef struct {
    * power of two, no statistics / live totals / x_mode / x_out; otherwise the patch-resident kernels run.  Same contract, same
    * roundings (another fp32 summation order); dfl_conv_suggest_splits answers for the form the hint selects. */
   int32_t latency_form;
+  /* Output affine (latency form only, inference): the stored value becomes bf16(out_scale[n] * bf16(v) + out_shift[n]) with v what
+   * the epilogue would have stored -- the eval-mode BatchNorm between this convolution and the next one (unet.py:214-218) applied by
+   * the PRODUCER with the consumer's two roundings, so that the consumer reads its operand plain (no affine on load; zero padding
+   * after BatchNorm stays zero).  Rejected by every other kernel: ask dfl_conv_config (16 + 39 = latency form) before relying on it. */
+  const float* out_scale;
+  const float* out_shift;
 } dfl_conv_args;
 #define DFL_BN_R 8
 
 int dfl_conv2d(const dfl_conv_args* a, dfl_stream_t stream);
+/* The last 3x3 convolution of a residual block and the block's 1x1 convolution (unet.py:218-231) as ONE launch.  Defined as
+ * dfl_conv2d(a) followed by dfl_conv2d(b) -- both outputs are written, same roundings (y1 is rounded to bf16 before b's epilogue
+ * adds its BatchNorm) -- and performed as one kernel when dfl_conv_pair_ok(a, b) says 1: a in latency form without K slices, add
+ * or scatter; b a 1x1 / stride-1 convolution over the same pixels and columns with add == a->y, add_scale / add_shift, no ReLU,
+ * no statistics, its input bf16 (Cin % 16 == 0) or the 1-channel fp32 image of the network's first block.  Otherwise the two
+ * launches run one after the other.  A batch-1 forward has 11 such pairs among its 44 dependent convolutions. */
+int dfl_conv2d_pair(const dfl_conv_args* a, const dfl_conv_args* b, dfl_stream_t stream);
+int dfl_conv_pair_ok(const dfl_conv_args* a, const dfl_conv_args* b);
 /* Number of row blocks whose statistics dfl_conv2d will write for these args (= first dim of stat_partials);
  * depends on a->splits, so set that first. */
 int dfl_conv_grid_m(const dfl_conv_args* a);
@@ -632,7 +646,7 @@ typedef enum {
   DFL_OP_REDUCE_PARTIALS = 10, DFL_OP_AFFINE_COPY = 11, DFL_OP_POOL_FWD = 12, DFL_OP_POOL_BWD = 13,
   DFL_OP_HEAD_FWD = 14, DFL_OP_HEAD_BWD = 15, DFL_OP_MEMSET = 16, DFL_OP_REDUCE_BATCH = 17,
   DFL_OP_RECORD = 18, DFL_OP_WAIT = 19, DFL_OP_UPSAMPLE_FWD = 20, DFL_OP_UPSAMPLE_BWD = 21,
-  DFL_OP_BN_FINALIZE_LIVE = 22, DFL_OP_BN_BWD_FINALIZE_LIVE = 23
+  DFL_OP_BN_FINALIZE_LIVE = 22, DFL_OP_BN_BWD_FINALIZE_LIVE = 23, DFL_OP_CONV_PAIR = 24
 } dfl_op_kind;
 
 typedef struct { const float* src; float* dst; int64_t n; int32_t splits; int32_t T; } dfl_sum_partials_args;
@@ -644,6 +658,7 @@ typedef struct { void* ptr; int64_t bytes; } dfl_memset_args; /* zero fill */
 typedef struct { const dfl_reduce_job* jobs_dev; int32_t njobs, total_blocks; } dfl_reduce_batch_args;
 typedef struct { const dfl_bn_live_job* jobs_dev; int32_t njobs, max_C; } dfl_bn_live_args;
 typedef struct { const dfl_bn_bwd_live_job* jobs_dev; int32_t njobs, max_C; } dfl_bn_bwd_live_args;
+typedef struct { const dfl_conv_args* a; const dfl_conv_args* b; } dfl_conv_pair_args;   /* dfl_conv2d_pair */
 
 /* DFL_OP_RECORD: record library event `event` on the op's stream; DFL_OP_WAIT: make the op's stream wait for it.
  * Events are library-owned, identified by small integers the program chooses (0..65535). */

@@ -90,11 +90,158 @@ def test_latency_form_transposed_scatter():
         close_bf16(y, nhwc(F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2)), 'convT %d' % Ci)
 
 
+def test_output_affine_is_the_consumers_affine_on_load():
+    """dfl_conv_args.out_scale: producer applies the next layer's eval-mode BatchNorm -- conv(a) with out_scale, then conv(b) plain,
+    against conv(a), then conv(b) with the affine on load: the same bits (the same k-step split in b)."""
+    lib = nat.lib()
+    BF = torch.bfloat16
+    st = torch.cuda.current_stream().cuda_stream
+    for (Cin, C_, H, W) in ((32, 64, 40, 40), (128, 128, 24, 20), (256, 512, 12, 12)):
+        g = torch.Generator().manual_seed(Cin + H)
+        x = nhwc(rb(torch.randn(1, Cin, H, W, generator=g))).to(DEV).to(BF).contiguous()
+        wa = pack16(rb(torch.randn(C_, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5), 1)
+        wb = pack16(rb(torch.randn(C_, C_, 3, 3, generator=g) / (9 * C_) ** 0.5), 1)
+        ba, bb = torch.randn(C_, generator=g).to(DEV), torch.randn(C_, generator=g).to(DEV)
+        sc, sh = (torch.rand(C_, generator=g) + 0.5).to(DEV), (torch.randn(C_, generator=g) * 0.3).to(DEV)
+
+        def run(producer_side):
+            r = torch.full((1, H, W, C_), float('nan'), device=DEV, dtype=BF)
+            y = torch.full((1, H, W, C_), float('nan'), device=DEV, dtype=BF)
+            a = _conv_args(x, wa, r, 1, H, W, Cin, C_, 3, 1)
+            a.bias, a.relu = ba.data_ptr(), 1
+            b = _conv_args(r, wb, y, 1, H, W, C_, C_, 3, 1)
+            b.bias, b.relu = bb.data_ptr(), 1
+            if producer_side:
+                a.out_scale, a.out_shift = sc.data_ptr(), sh.data_ptr()
+                assert lib.dfl_conv_config(C.addressof(a)) == 16 + 39
+            else:
+                b.in_scale, b.in_shift = sc.data_ptr(), sh.data_ptr()
+            for q in (a, b):
+                sp = nat.check(lib.dfl_conv_suggest_splits(C.addressof(q)), 'suggest')
+                if sp > 1:
+                    q.splits = sp
+                    q._part = torch.empty(sp * H * W * C_, device=DEV)
+                    q.partial = q._part.data_ptr()
+                nat.check(lib.dfl_conv2d(C.addressof(q), st), 'conv')
+            torch.cuda.synchronize()
+            return y.float().cpu()
+        assert torch.equal(run(True), run(False)), (Cin, C_, H, W)
+
+
+def test_first_layer_latency_form_is_the_row_kernel():
+    """1-channel 3x3 first layer (unet.py:211, in_channels = 1): the latency form against direct_conv3_rows_kernel, bit for bit."""
+    lib = nat.lib()
+    BF = torch.bfloat16
+    st = torch.cuda.current_stream().cuda_stream
+    for (N, H, W, C_) in ((1, 192, 192, 32), (2, 37, 41, 16), (1, 64, 48, 64)):
+        g = torch.Generator().manual_seed(H + C_)
+        x = torch.randn(N, H, W, 1, generator=g).to(DEV).contiguous()
+        w = torch.randn(C_, 1, 3, 3, generator=g)
+        wq = torch.zeros(3, C_, 4)                            # quad-packed fp32 operand [ceil(9/4)][N][4]
+        for k in range(9):
+            wq[k >> 2, :, k & 3] = w.reshape(C_, 9)[:, k]
+        wq = wq.to(DEV).contiguous()
+        b = torch.randn(C_, generator=g).to(DEV)
+        outs = []
+        for hint in (1, 0):
+            y = torch.full((N, H, W, C_), float('nan'), device=DEV, dtype=BF)
+            a = nat.ConvArgs()
+            a.x, a.w, a.y, a.bias = x.data_ptr(), wq.data_ptr(), y.data_ptr(), b.data_ptr()
+            a.x_bf16, a.y_bf16 = 0, 1
+            a.N, a.Hin, a.Win, a.Cin, a.ldx = N, H, W, 1, 1
+            a.KH, a.KW, a.stride, a.pad = 3, 3, 1, 1
+            a.Hout, a.Wout, a.Ntot, a.ldy = H, W, C_, C_
+            a.relu, a.latency_form = 1, hint
+            assert (lib.dfl_conv_config(C.addressof(a)) == 16 + 39) == bool(hint)
+            nat.check(lib.dfl_conv2d(C.addressof(a), st), 'conv')
+            torch.cuda.synchronize()
+            outs.append(y.float().cpu())
+        assert torch.equal(outs[0], outs[1]), (N, H, W, C_)
+        ref = F.relu(F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.double(), b.double().cpu(), padding=1))
+        close_bf16(outs[0], nhwc(ref), 'first layer')
+
+
+def _conv_args(x_dev, w_dev, y_dev, N, H, W, Cin, Cout, K, pad, ldx=None, ldy=None):
+    a = nat.ConvArgs()
+    a.x, a.w, a.y = x_dev.data_ptr(), w_dev.data_ptr(), y_dev.data_ptr()
+    a.x_bf16, a.y_bf16, a.w_split = 1, 1, 2
+    a.N, a.Hin, a.Win, a.Cin, a.ldx = N, H, W, Cin, ldx or Cin
+    a.KH, a.KW, a.stride, a.pad = K, K, 1, pad
+    a.Hout, a.Wout, a.Ntot, a.ldy = H, W, Cout, ldy or Cout
+    a.latency_form = 1
+    return a
+
+
+@pytest.mark.parametrize('case', [(1, 32, 32, 40, 40), (1, 64, 128, 48, 48), (1, 128, 256, 24, 24), (1, 256, 512, 12, 12), (2, 96, 64, 13, 9), (1, 0, 32, 48, 40)])
+def test_pair_is_the_two_launches(case):
+    """dfl_conv2d_pair(a, b) -- the last 3x3 convolution of a residual block (ReLU) and the block's 1x1
+    convolution with '+ BN(y1)' (unet.py:218-231) -- against dfl_conv2d(a); dfl_conv2d(b): y1 bit for bit (same k-step split), y2 up
+    to the summation order of the 1x1 product; Cres = 0: the first block's 1-channel fp32 image (direct 1x1 kernel)."""
+    N, Cres, C_, H, W = case
+    lib = nat.lib()
+    BF = torch.bfloat16
+    g = torch.Generator().manual_seed(sum(case))
+    r1 = rb(torch.randn(N, C_, H, W, generator=g))
+    w = rb(torch.randn(C_, C_, 3, 3, generator=g) / (9 * C_) ** 0.5)
+    b1, b3 = torch.randn(C_, generator=g).to(DEV), torch.randn(C_, generator=g).to(DEV)
+    sc, sh = (torch.rand(C_, generator=g) + 0.5).to(DEV), (torch.randn(C_, generator=g) * 0.3).to(DEV)
+    asc, ash = (torch.rand(C_, generator=g) + 0.5).to(DEV), (torch.randn(C_, generator=g) * 0.2).to(DEV)
+    r1d = nhwc(r1).to(DEV).to(BF).contiguous()
+    wp = pack16(w, 1)
+    if Cres:
+        xin = rb(torch.randn(N, Cres, H, W, generator=g))
+        w3 = rb(torch.randn(C_, Cres, 1, 1, generator=g) / Cres ** 0.5)
+        xind = nhwc(xin).to(DEV).to(BF).contiguous()
+        w3p = pack16(w3, 1)
+    else:
+        xin = torch.randn(N, 1, H, W, generator=g)
+        w3 = torch.randn(C_, 1, 1, 1, generator=g)
+        xind = nhwc(xin).to(DEV).contiguous()
+        w3p = torch.zeros(C_, 4, device=DEV)                 # quad-packed fp32 operand [ceil(K/4)][N][4], K = 1
+        w3p[:, 0] = w3.reshape(-1).to(DEV)
+
+    def run(paired):
+        y1 = torch.full((N, H, W, C_), float('nan'), device=DEV, dtype=BF)
+        y2 = torch.full((N, H, W, 2 * C_), float('nan'), device=DEV, dtype=BF)        # (the concat buffer's half: ldy = 2 C)
+        a = _conv_args(r1d, wp, y1, N, H, W, C_, C_, 3, 1)
+        a.bias, a.relu = b1.data_ptr(), 1                    # (its operand is plain: the producer applied the BatchNorm, out_scale)
+        if Cres:
+            b = _conv_args(xind, w3p, y2, N, H, W, Cres, C_, 1, 0, ldy=2 * C_)
+        else:
+            b = _conv_args(xind, w3p, y2, N, H, W, 1, C_, 1, 0, ldy=2 * C_)
+            b.x_bf16, b.w_split = 0, 0
+        b.bias, b.add, b.ldadd, b.add_scale, b.add_shift = b3.data_ptr(), y1.data_ptr(), C_, asc.data_ptr(), ash.data_ptr()
+        ok = lib.dfl_conv_pair_ok(C.addressof(a), C.addressof(b))
+        st = torch.cuda.current_stream().cuda_stream
+        if paired:
+            assert ok == 1, 'these two convolutions form a pair'
+            nat.check(lib.dfl_conv2d_pair(C.addressof(a), C.addressof(b), st), 'pair')
+        else:
+            nat.check(lib.dfl_conv2d(C.addressof(a), st), 'a')
+            nat.check(lib.dfl_conv2d(C.addressof(b), st), 'b')
+        torch.cuda.synchronize()
+        return y1.float().cpu(), y2.float().cpu()[..., :C_]
+    y1p, y2p = run(True)
+    y1s, y2s = run(False)
+    assert torch.equal(y1p, y1s)
+    if not Cres:
+        assert torch.equal(y2p, y2s)                         # fp32 multiply-adds in the same order
+    else:
+        assert float((y2p != y2s).double().mean()) < 0.02
+    # and against fp64 on the same operands
+    y1ref = F.relu(F.conv2d(r1.double(), w.double(), b1.cpu().double(), padding=1))
+    close_bf16(y1p, nhwc(y1ref), 'y1 %s' % (case,))
+    y1r = nhwc(y1p).permute(0, 1, 2, 3)                      # NHWC values as stored
+    y2ref = F.conv2d(xin.double(), w3.double(), b3.cpu().double()) + y1p.permute(0, 3, 1, 2).double() * asc.cpu().double().view(1, -1, 1, 1) + \
+        ash.cpu().double().view(1, -1, 1, 1)
+    close_bf16(y2p, nhwc(y2ref), 'y2 %s' % (case,))
+
+
 def test_latency_form_is_a_hint():
     """Statistics, large problems and the fused backward operand keep the patch-resident kernels whatever the hint says."""
     lib = nat.lib()
     g = torch.Generator().manual_seed(3)
-    x = rb(torch.randn(16, 64, 96, 96, generator=g))           # one image: 0.68 GFLOP per 3x3 layer of 64 channels
+    x = rb(torch.randn(16, 64, 96, 96, generator=g))
     w = rb(torch.randn(64, 64, 3, 3, generator=g) / 24.0)
     a = nat.ConvArgs()
     xd = nhwc(x).to(DEV).to(torch.bfloat16).contiguous()
@@ -102,15 +249,17 @@ def test_latency_form_is_a_hint():
     wp = pack16(w, 1)
     a.x, a.w, a.y = xd.data_ptr(), wp.data_ptr(), yd.data_ptr()
     a.x_bf16, a.y_bf16, a.w_split = 1, 1, 2
-    a.N, a.Hin, a.Win, a.Cin, a.ldx = 1, 96, 96, 64, 64
+    a.N, a.Hin, a.Win, a.Cin, a.ldx = 1, 48, 48, 64, 64
     a.KH, a.KW, a.stride, a.pad = 3, 3, 1, 1
-    a.Hout, a.Wout, a.Ntot, a.ldy = 96, 96, 64, 64
+    a.Hout, a.Wout, a.Ntot, a.ldy = 48, 48, 64, 64
     a.latency_form = 1
     assert lib.dfl_conv_config(C.addressof(a)) == 16 + 39
     part = torch.zeros(4096, 2, 64, device=DEV)
     a.stat_partials = part.data_ptr()
     assert lib.dfl_conv_config(C.addressof(a)) < 16 + 39          # statistics: the patch kernels
     a.stat_partials = None
+    a.Hin = a.Win = a.Hout = a.Wout = 96
+    assert lib.dfl_conv_config(C.addressof(a)) < 16 + 39          # measured: 36 k-steps on 9216 pixels stay with the patch kernels
     a.N = 16
     assert lib.dfl_conv_config(C.addressof(a)) < 16 + 39          # 10.9 GFLOP: a throughput problem
 
@@ -125,11 +274,13 @@ def test_inference_forward_with_and_without_the_latency_form():
     with torch.no_grad():
         seg1, heat1 = net(x)
         plan = [p for ps in net._plans.values() for p in ps if not p.need_grad][0]
-        lean = [st for st in plan.fwd.structs if isinstance(st, nat.ConvArgs) and st.latency_form]
+        convs = [st for st in plan.fwd.structs if isinstance(st, nat.ConvArgs)] + [st for st in plan.fwd.keep if isinstance(st, nat.ConvArgs)]
+        lean = [st for st in convs if st.latency_form]
         assert len(lean) >= 40
         lib = nat.lib()
         taken = sum(1 for st in lean if lib.dfl_conv_config(C.addressof(st)) == 16 + 39)
         assert taken >= 36, 'latency form taken by %d of %d convolutions' % (taken, len(lean))
+        assert sum(1 for st in plan.fwd.structs if isinstance(st, nat.ConvPairArgs)) >= 5
         seg1, heat1 = seg1.clone(), heat1.clone()
         # the same plan with the hint cleared (K slices re-planned by the library for the patch kernels)
         net2 = dfl_amd.UNet(**bench.PAPER).to(DEV).eval()
@@ -144,7 +295,7 @@ def test_inference_forward_with_and_without_the_latency_form():
             else:
                 os.environ['DFL_PLAN_LATENCY_FORM'] = old
         plan2 = [p for ps in net2._plans.values() for p in ps if not p.need_grad][0]
-        assert not any(st.latency_form for st in plan2.fwd.structs if isinstance(st, nat.ConvArgs))
+        assert not any(st.latency_form for st in plan2.fwd.structs if isinstance(st, nat.ConvArgs)) and not any(isinstance(st, nat.ConvPairArgs) for st in plan2.fwd.structs)
     # two bf16-storage forwards that differ in fp32 summation order: a few last-bit roundings per tensor, amplified by 44 layers
     assert float((seg1 - seg0).abs().max()) < 3e-2
     assert float((heat1 - heat0).abs().max()) <= 3e-2 * max(1.0, float(heat0.abs().max()))
