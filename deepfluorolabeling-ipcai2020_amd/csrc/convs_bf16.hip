@@ -416,11 +416,9 @@ bool convs_eligible(const dfl_conv_args& a, const ConvP& p) {
   // a latency problem, not a throughput problem: the largest layer of a 192x192 image is 1.4 GFLOP (operands are not reused
   // across tiles here: beyond this the patch-resident kernels win)
   if (2.0 * p.Mtot * a.Ntot * (double)(p.T * a.Cin) > 1.5e9) return false;
-  // measured (tools/kbench_infer.py 192 1, both forms in one call): the 3x3 layers of the two widest levels with 64 or more input
-  // channels -- 36 or more k-steps on 288+ pixel tiles, i.e. three dependent load rounds per wave here -- stay with the patch kernels
-  // (14 -> 17, 13 -> 15, 15 -> 17 us with this form); everything else of a 192x192 forward is 1 - 7 us shorter
-  if (p.Mtot >= 9216 && p.T * (a.Cin / 16) >= 36) return false;
-  if (a.ldadd % 4 != 0 || a.ldy % 4 != 0) return false;
+  // (round 5, measured with tools/kbench_infer.py 192 1 and docs/experiments/infer192_r05: with 8 k-steps per register set and the
+  //  BatchNorm affine on load the 3x3 layers of the two widest levels were 2 - 3 us slower in this form; with 9 k-steps and the affine
+  //  moved into the producer every layer of a 192x192 forward is faster here: 0.335 -> 0.320 ms without an exception)
   return true;
 }
 
@@ -439,9 +437,11 @@ void convs_plan(const dfl_conv_args& a, ConvP* p, int force_splits) {
   int want = 2048 / tiles;
   if (want > p->s_ksteps / 6) want = p->s_ksteps / 6;
   if (want < 1) want = 1;
+  // K slices over workgroups (a finish launch, 4.7 us) only where the eight waves of a tile would be left with more than two
+  // register sets of k-steps each
   int zs = 1;
   if (force_splits > 0) zs = force_splits;
-  else if (want > 8) zs = want / 8;
+  else if (want > 8 && p->s_ksteps > 8 * 2 * SU) zs = want / 8;
   if (zs > 16) zs = 16;
   if (zs > p->s_ksteps) zs = p->s_ksteps;
   int per = want / zs;

@@ -259,7 +259,6 @@ def test_latency_form_is_a_hint():
     assert lib.dfl_conv_config(C.addressof(a)) < 16 + 39          # statistics: the patch kernels
     a.stat_partials = None
     a.Hin = a.Win = a.Hout = a.Wout = 96
-    assert lib.dfl_conv_config(C.addressof(a)) < 16 + 39          # measured: 36 k-steps on 9216 pixels stay with the patch kernels
     a.N = 16
     assert lib.dfl_conv_config(C.addressof(a)) < 16 + 39          # 10.9 GFLOP: a throughput problem
 
@@ -279,8 +278,8 @@ def test_inference_forward_with_and_without_the_latency_form():
         assert len(lean) >= 40
         lib = nat.lib()
         taken = sum(1 for st in lean if lib.dfl_conv_config(C.addressof(st)) == 16 + 39)
-        assert taken >= 36, 'latency form taken by %d of %d convolutions' % (taken, len(lean))
-        assert sum(1 for st in plan.fwd.structs if isinstance(st, nat.ConvPairArgs)) >= 5
+        assert taken >= 42, 'latency form taken by %d of %d convolutions' % (taken, len(lean))
+        assert sum(1 for st in plan.fwd.structs if isinstance(st, nat.ConvPairArgs)) >= 8
         seg1, heat1 = seg1.clone(), heat1.clone()
         # the same plan with the hint cleared (K slices re-planned by the library for the patch kernels)
         net2 = dfl_amd.UNet(**bench.PAPER).to(DEV).eval()
