@@ -46,8 +46,10 @@ __device__ __forceinline__ uint32_t spack_bf2(float a, float b) {
 
 constexpr int SU = 9;              // k-steps per register set
 constexpr int SU2 = 4;             // k-steps per wave of a pair's second product (registers of their own)
-constexpr int SWAVES = 8;          // waves per workgroup
-constexpr int SCONST_FLOATS = SWAVES * 6 * 32;     // per wave: bias, add_scale, add_shift, bias3, out_scale, out_shift of its tile's 32 columns
+// Waves per workgroup, a template parameter: 8 (512 threads, one workgroup per CU) where eight waves share a tile's k-steps, 4 (256
+// threads, two workgroups per CU) otherwise -- a layer of 1152 wave tasks then is 288 workgroups over all 256 CUs instead of 144 on 144
+// (the fragments of this form are not reused across waves: a CU's L1 fill is what a 36-k-step layer waits for).
+constexpr int SCONST_PER_WAVE = 6 * 32;            // per wave: bias, add_scale, add_shift, bias3, out_scale, out_shift of its tile's 32 columns
 
 // second convolution of a pair (1x1, stride 1, no affine on load): y2 = x3 * w3 + bias3 + add_scale * y1 + add_shift
 struct ConvPair {
@@ -62,9 +64,11 @@ struct ConvPair {
   uint32_t x3_bytes, w3_bytes;
 };
 
-template <bool AFF, bool PAIR>
-__global__ void __launch_bounds__(64 * SWAVES, 1) convs_kernel(const ConvP p, const ConvPair q) {
+template <bool AFF, bool PAIR, int SWAVES>
+__global__ void __launch_bounds__(64 * SWAVES, SWAVES == 8 ? 1 : 2) convs_kernel(const ConvP p, const ConvPair q) {
   constexpr int NACC = PAIR ? 2 : 1;
+  constexpr int SCONST_FLOATS = SWAVES * SCONST_PER_WAVE;
+  constexpr int TABQ = 1024 / (64 * SWAVES);            // table entries per thread (Cin <= 1024)
   constexpr int SRED = SWAVES * NACC * 16 * 64;          // floats: partial tiles of the workgroup's waves
   extern __shared__ __attribute__((aligned(16))) float sm[];      // [8][NACC*16][64] partial tiles, [8][6][32] constants, [2][Cin] scale / shift
   const dfl_conv_args& a = p.a;
@@ -178,10 +182,12 @@ __global__ void __launch_bounds__(64 * SWAVES, 1) convs_kernel(const ConvP p, co
     if (PAIR && on && q.bias3 != nullptr) k3 = q.bias3[c];
     if (!PAIR && on && a.out_scale != nullptr) k4 = a.out_scale[cco], k5 = a.out_shift[cco];
   }
-  float tsc[2] = {1.f, 1.f}, tsh[2] = {0.f, 0.f};
+  float tsc[TABQ], tsh[TABQ];
   if constexpr (AFF) {
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
+    for (int e = 0; e < TABQ; ++e) {
+      tsc[e] = 1.f;
+      tsh[e] = 0.f;
       const int c = tid + e * 64 * SWAVES;
       if (c < a.Cin) {
         tsc[e] = a.in_scale[c];
@@ -228,7 +234,7 @@ __global__ void __launch_bounds__(64 * SWAVES, 1) convs_kernel(const ConvP p, co
   }
   if constexpr (AFF) {
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
+    for (int e = 0; e < TABQ; ++e) {
       const int c = tid + e * 64 * SWAVES;
       if (c < a.Cin) {
         tab[c] = tsc[e];
@@ -422,6 +428,12 @@ bool convs_eligible(const dfl_conv_args& a, const ConvP& p) {
   return true;
 }
 
+static int convs_waves(int ksplit_shift) {
+  static const int force = [] { const char* e = getenv("DFL_CONVS_WAVES"); return e ? atoi(e) : 0; }();      // (A/B: 8 = always eight waves)
+  if (force == 8) return 8;
+  return ksplit_shift == 3 ? 8 : 4;
+}
+
 // Work split: 32 x 32 tiles, `ksplit` waves of a workgroup per tile, `splits` K slices over workgroups.  Aim: about one wave
 // per SIMD-slot pair of the chip (2048 waves) and at least 6 k-steps per wave; cross-workgroup slices only when the eight waves
 // of a workgroup leave more than ~36 k-steps each.
@@ -452,8 +464,9 @@ void convs_plan(const dfl_conv_args& a, ConvP* p, int force_splits) {
   if (force_splits <= 0) zs = (int)ceil_div(p->s_ksteps, (int64_t)p->s_kper << ksh);      // (no empty slices when the choice is free)
   p->splits = zs;
   p->tile = CONVS_TILE;
-  p->grid = (int)ceil_div(tiles, SWAVES >> ksh);
-  p->lds_bytes = (SWAVES * 16 * 64 + SCONST_FLOATS + 2 * a.Cin) * 4;
+  const int W = convs_waves(ksh);
+  p->grid = (int)ceil_div(tiles, W >> ksh);
+  p->lds_bytes = (W * 16 * 64 + W * SCONST_PER_WAVE + 2 * a.Cin) * 4;
 }
 
 int convs_launch(const ConvP& p, hipStream_t s) {
@@ -461,10 +474,13 @@ int convs_launch(const ConvP& p, hipStream_t s) {
   const size_t lds = (size_t)p.lds_bytes;
   ConvPair none;
   memset(&none, 0, sizeof(none));
+  const int W = convs_waves(p.s_ksplit_shift);
   if (p.a.in_scale != nullptr) {
-    hipLaunchKernelGGL((convs_kernel<true, false>), grid, dim3(64 * SWAVES), lds, s, p, none);
+    if (W == 8) hipLaunchKernelGGL((convs_kernel<true, false, 8>), grid, dim3(512), lds, s, p, none);
+    else hipLaunchKernelGGL((convs_kernel<true, false, 4>), grid, dim3(256), lds, s, p, none);
   } else {
-    hipLaunchKernelGGL((convs_kernel<false, false>), grid, dim3(64 * SWAVES), lds, s, p, none);
+    if (W == 8) hipLaunchKernelGGL((convs_kernel<false, false, 8>), grid, dim3(512), lds, s, p, none);
+    else hipLaunchKernelGGL((convs_kernel<false, false, 4>), grid, dim3(256), lds, s, p, none);
   }
   return check_launch("dfl_conv2d (bf16, latency form)");
 }
@@ -521,11 +537,16 @@ int convs_pair_launch(const dfl_conv_args* a, const dfl_conv_args* b, hipStream_
     q.w3_bytes = (uint32_t)((int64_t)b->Cin * b->Ntot * 2);
   }
   dim3 grid((unsigned)p.grid, 1);
-  const size_t lds = (size_t)(SWAVES * 2 * 16 * 64 + SCONST_FLOATS + 2 * a->Cin) * 4;
-  auto k = convs_kernel<false, true>;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-  (void)attr;
-  hipLaunchKernelGGL(k, grid, dim3(64 * SWAVES), lds, s, p, q);
+  const int W = convs_waves(p.s_ksplit_shift);
+  const size_t lds = (size_t)(W * 2 * 16 * 64 + W * SCONST_PER_WAVE + 2 * a->Cin) * 4;
+  if (W == 8) {
+    auto k = convs_kernel<false, true, 8>;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)attr;
+    hipLaunchKernelGGL(k, grid, dim3(512), lds, s, p, q);
+  } else {
+    hipLaunchKernelGGL((convs_kernel<false, true, 4>), grid, dim3(256), lds, s, p, q);
+  }
   return check_launch("dfl_conv2d_pair");
 }
 
