@@ -848,7 +848,7 @@ extern "C" int dfl_conv_pair_ok(const dfl_conv_args* a, const dfl_conv_args* b) 
 
 extern "C" int dfl_conv2d_pair(const dfl_conv_args* a, const dfl_conv_args* b, dfl_stream_t stream) {
   DFL_REQUIRE(a != nullptr && b != nullptr, "dfl_conv2d_pair: null arguments");
-  if (dfl::convs_pair_ok(a, b)) return dfl::convs_pair_launch(a, b, static_cast<hipStream_t>(stream));
+  if (dfl::convs_pair_ok(a, b) > 0) return dfl::convs_pair_launch(a, b, static_cast<hipStream_t>(stream));
   const int rc = dfl_conv2d(a, stream);
   return rc != DFL_OK ? rc : dfl_conv2d(b, stream);
 }

@@ -64,6 +64,8 @@ struct ConvPair {
   uint32_t x3_bytes, w3_bytes;
 };
 
+__global__ void convs_pair_finish_kernel(const ConvP p, const ConvPair q);       // (K-sliced pairs, below)
+
 template <bool AFF, bool PAIR, int SWAVES>
 __global__ void __launch_bounds__(64 * SWAVES, SWAVES == 8 ? 1 : 2) convs_kernel(const ConvP p, const ConvPair q) {
   constexpr int NACC = PAIR ? 2 : 1;
@@ -111,7 +113,7 @@ __global__ void __launch_bounds__(64 * SWAVES, SWAVES == 8 ? 1 : 2) convs_kernel
   const int slice = (int)blockIdx.y * ksplit + kw;
   const int s_begin = slice * p.s_kper;
   const int n1 = max(0, min(p.s_ksteps, s_begin + p.s_kper) - s_begin);
-  const int t_begin = PAIR ? kw * q.kper2 : 0;
+  const int t_begin = PAIR ? slice * q.kper2 : 0;       // (the second product's k-steps are shared out over all K slices and waves as well)
   const int n2 = PAIR ? max(0, min(q.ksteps2, t_begin + q.kper2) - t_begin) : 0;
   const int nv = n1;
   const uint32_t x3off = PAIR ? (uint32_t)pix * (uint32_t)q.ldx3 * 2u + lh16 : 0u;
@@ -279,8 +281,9 @@ __global__ void __launch_bounds__(64 * SWAVES, SWAVES == 8 ? 1 : 2) convs_kernel
   auto finish_group = [&](int g, float4 v, float4 v2) {
     const int c = ni * 32 + 8 * g + 4 * lh;
     if (!pok || c >= a.Ntot) return;
-    if (sliced) {                                        // raw sums of this K slice: convp_finish_kernel does the rest
+    if (sliced) {                                        // raw sums of this K slice: convp_finish_kernel / convs_pair_finish_kernel do the rest
       *reinterpret_cast<float4*>(a.partial + ((int64_t)blockIdx.y * p.Mtot + pix) * a.Ntot + c) = v;
+      if constexpr (PAIR) *reinterpret_cast<float4*>(a.partial + ((int64_t)(p.splits + blockIdx.y) * p.Mtot + pix) * a.Ntot + c) = v2;
       return;
     }
     const float4 cb = *reinterpret_cast<const float4*>(cst + 8 * g + 4 * lh);
@@ -487,9 +490,10 @@ int convs_launch(const ConvP& p, hipStream_t s) {
 
 // ---- pairs (dfl_conv2d_pair): conditions under which (a, b) run as one launch; pa = a's plan in latency form
 static bool pair_ok(const dfl_conv_args* a, const dfl_conv_args* b, const ConvP& pa) {
-  if (pa.tile != CONVS_TILE || pa.splits > 1) return false;
+  if (pa.tile != CONVS_TILE) return false;
+  if (pa.splits > 1 && (!b->x_bf16 || a->partial == nullptr)) return false;
   if (a->scatter2x2 || a->accumulate || a->add != nullptr || a->out_scale != nullptr || a->in_scale != nullptr) return false;
-  if (b->x_bf16 && ceil_div(b->Cin / 16, 1 << pa.s_ksplit_shift) > SU2) return false;
+  if (b->x_bf16 && ceil_div(b->Cin / 16, (int64_t)pa.splits << pa.s_ksplit_shift) > SU2) return false;
   if (!b->latency_form || !b->y_bf16 || b->KH != 1 || b->KW != 1 || b->stride != 1 || b->pad != 0 || b->scatter2x2 || b->accumulate || b->relu) return false;
   if (b->in_scale != nullptr || b->in_tot != nullptr || b->add_tot != nullptr || b->x_mode != 0 || b->x_out != nullptr || b->out_scale != nullptr) return false;
   if (b->stat_partials != nullptr || b->stat_totals != nullptr || b->stat_other != nullptr || b->splits > 1) return false;
@@ -510,13 +514,14 @@ int convs_pair_ok(const dfl_conv_args* a, const dfl_conv_args* b) {
   if (a == nullptr || b == nullptr || !a->x_bf16 || !a->latency_form) return 0;
   ConvP pa;
   if (convp_plan(a, &pa, a->splits > 1 ? a->splits : 1) != DFL_OK) return 0;
-  return pair_ok(a, b, pa) ? 1 : 0;
+  if (!pair_ok(a, b, pa)) return 0;
+  return pa.splits > 1 ? 2 : 1;            // 2: K slices -- a->partial holds [2][splits][M][Ntot] floats
 }
 
 // a then b as ONE launch (the caller has checked convs_pair_ok)
 int convs_pair_launch(const dfl_conv_args* a, const dfl_conv_args* b, hipStream_t s) {
   ConvP p;
-  int rc = convp_plan(a, &p, 1);
+  int rc = convp_plan(a, &p, a->splits > 1 ? a->splits : 1);
   if (rc != DFL_OK) return rc;
   DFL_REQUIRE(pair_ok(a, b, p), "dfl_conv2d_pair: these two convolutions do not form a pair");
   ConvPair q;
@@ -532,11 +537,11 @@ int convs_pair_launch(const dfl_conv_args* a, const dfl_conv_args* b, hipStream_
   q.x3_fp32 = b->x_bf16 ? 0 : 1;
   if (b->x_bf16) {
     q.ksteps2 = b->Cin / 16;
-    q.kper2 = (int)ceil_div(q.ksteps2, 1 << p.s_ksplit_shift);
+    q.kper2 = (int)ceil_div(q.ksteps2, (int64_t)p.splits << p.s_ksplit_shift);
     q.x3_bytes = (uint32_t)((((int64_t)b->N * b->Hin * b->Win - 1) * b->ldx + b->Cin) * 2);
     q.w3_bytes = (uint32_t)((int64_t)b->Cin * b->Ntot * 2);
   }
-  dim3 grid((unsigned)p.grid, 1);
+  dim3 grid((unsigned)p.grid, (unsigned)p.splits);
   const int W = convs_waves(p.s_ksplit_shift);
   const size_t lds = (size_t)(W * 2 * 16 * 64 + W * SCONST_PER_WAVE + 2 * a->Cin) * 4;
   if (W == 8) {
@@ -547,9 +552,48 @@ int convs_pair_launch(const dfl_conv_args* a, const dfl_conv_args* b, hipStream_
   } else {
     hipLaunchKernelGGL((convs_kernel<false, true, 4>), grid, dim3(256), lds, s, p, q);
   }
+  if (p.splits > 1) {
+    rc = check_launch("dfl_conv2d_pair");
+    if (rc != DFL_OK) return rc;
+    hipLaunchKernelGGL(convs_pair_finish_kernel, dim3((unsigned)ceil_div((int64_t)p.Mtot * (a->Ntot / 4), 256)), dim3(256), 0, s, p, q);
+  }
   return check_launch("dfl_conv2d_pair");
 }
 
+
+// K-sliced pairs: y1 = ReLU(sum of the first product's slices + bias), y2 = sum of the second product's slices + bias3 + BN(y1) -- the pair
+// epilogue of convs_kernel on the sums (a.partial: [2][splits][M][Ntot] fp32).  One thread: 4 consecutive channels of a pixel.
+__global__ void __launch_bounds__(256) convs_pair_finish_kernel(const ConvP p, const ConvPair q) {
+  const dfl_conv_args& a = p.a;
+  const int nq = a.Ntot >> 2;
+  const int idx = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  if (idx >= p.Mtot * nq) return;
+  const int pix = idx / nq, c = (idx - pix * nq) * 4;
+  const int64_t slice = (int64_t)p.Mtot * a.Ntot;
+  const float* p1 = a.partial + (int64_t)pix * a.Ntot + c;
+  const float* p2 = p1 + (int64_t)p.splits * slice;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f), o = v;
+  for (int s = 0; s < p.splits; ++s) {
+    const float4 t1 = *reinterpret_cast<const float4*>(p1 + (int64_t)s * slice), t2 = *reinterpret_cast<const float4*>(p2 + (int64_t)s * slice);
+    v.x += t1.x; v.y += t1.y; v.z += t1.z; v.w += t1.w;
+    o.x += t2.x; o.y += t2.y; o.z += t2.z; o.w += t2.w;
+  }
+  if (a.bias != nullptr) { v.x += a.bias[c]; v.y += a.bias[c + 1]; v.z += a.bias[c + 2]; v.w += a.bias[c + 3]; }
+  if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+  su32x2 w;
+  w.x = spack_bf2(v.x, v.y);
+  w.y = spack_bf2(v.z, v.w);
+  *reinterpret_cast<su32x2*>(reinterpret_cast<unsigned short*>(a.y) + ((uint32_t)pix * (uint32_t)a.ldy + (uint32_t)c)) = w;
+  if (q.bias3 != nullptr) { o.x += q.bias3[c]; o.y += q.bias3[c + 1]; o.z += q.bias3[c + 2]; o.w += q.bias3[c + 3]; }
+  o.x += fmaf(sbf_lo(w.x), q.add_scale[c], q.add_shift[c]);
+  o.y += fmaf(sbf_hi(w.x), q.add_scale[c + 1], q.add_shift[c + 1]);
+  o.z += fmaf(sbf_lo(w.y), q.add_scale[c + 2], q.add_shift[c + 2]);
+  o.w += fmaf(sbf_hi(w.y), q.add_scale[c + 3], q.add_shift[c + 3]);
+  su32x2 w2;
+  w2.x = spack_bf2(o.x, o.y);
+  w2.y = spack_bf2(o.z, o.w);
+  *reinterpret_cast<su32x2*>(reinterpret_cast<unsigned short*>(q.y2) + ((uint32_t)pix * (uint32_t)q.ldy2 + (uint32_t)c)) = w2;
+}
 
 // ---- the network's first convolution in the same spirit (1-channel fp32 image, 3x3 window, stride 1: unet.py:211 with in_channels = 1):
 // direct_conv3_rows_kernel walks bands of rows, three per workgroup -- 32 workgroups for one 192x192 image, 13 us.  Here a thread owns

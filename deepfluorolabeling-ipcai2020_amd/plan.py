@@ -783,10 +783,15 @@ class UNetPlan:
                            add_live=cur_live)
                 # inference: the block's last 3x3 convolution and this 1x1 run as ONE launch where the library can (dfl_conv2d_pair:
                 # the latency form of a batch-1 forward -- 11 launches less in its chain of 44)
-                if (self.PAIRS and not self.training and not self.need_grad and len(fwd) >= 2 and isinstance(fwd.structs[-2], ConvArgs)
-                        and self.lib.dfl_conv_pair_ok(C.addressof(fwd.structs[-2]), C.addressof(fwd.structs[-1])) == 1):
+                pk = 0
+                if self.PAIRS and not self.training and not self.need_grad and len(fwd) >= 2 and isinstance(fwd.structs[-2], ConvArgs):
+                    pk = self.lib.dfl_conv_pair_ok(C.addressof(fwd.structs[-2]), C.addressof(fwd.structs[-1]))
+                if pk in (1, 2):
                     b_ = fwd.pop()
                     a_ = fwd.pop()
+                    if pk == 2:        # K-sliced: the partial sums of BOTH products go through a buffer of twice the size
+                        Mp = a_.N * a_.Hout * a_.Wout
+                        a_.partial = self._shared_scratch('pair_partial', 2 * a_.splits * Mp * a_.Ntot).data_ptr()
                     fwd.keep += [a_, b_]
                     fwd.add(nat.ConvPairArgs(a=C.addressof(a_), b=C.addressof(b_)))
             else:

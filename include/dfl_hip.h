@@ -160,7 +160,10 @@ int dfl_conv2d(const dfl_conv_args* a, dfl_stream_t stream);
  * adds its BatchNorm) -- and performed as one kernel when dfl_conv_pair_ok(a, b) says 1: a in latency form without K slices, add
  * or scatter; b a 1x1 / stride-1 convolution over the same pixels and columns with add == a->y, add_scale / add_shift, no ReLU,
  * no statistics, its input bf16 (Cin % 16 == 0) or the 1-channel fp32 image of the network's first block.  Otherwise the two
- * launches run one after the other.  A batch-1 forward has 11 such pairs among its 44 dependent convolutions. */
+ * launches run one after the other.  A batch-1 forward has 11 such pairs among its 44 dependent convolutions.
+ * dfl_conv_pair_ok: 0 = two launches; 1 = one kernel; 2 = a is K-sliced (a->splits > 1): one kernel + ONE finish launch for both
+ * outputs, and a->partial must then hold 2 * splits * M * Ntot floats (the second half takes the 1x1 product's slices) -- with a
+ * buffer of the single-convolution size the caller must not ask for the pair. */
 int dfl_conv2d_pair(const dfl_conv_args* a, const dfl_conv_args* b, dfl_stream_t stream);
 int dfl_conv_pair_ok(const dfl_conv_args* a, const dfl_conv_args* b);
 /* Number of row blocks whose statistics dfl_conv2d will write for these args (= first dim of stat_partials);

@@ -172,7 +172,8 @@ def _conv_args(x_dev, w_dev, y_dev, N, H, W, Cin, Cout, K, pad, ldx=None, ldy=No
     return a
 
 
-@pytest.mark.parametrize('case', [(1, 32, 32, 40, 40), (1, 64, 128, 48, 48), (1, 128, 256, 24, 24), (1, 256, 512, 12, 12), (2, 96, 64, 13, 9), (1, 0, 32, 48, 40)])
+@pytest.mark.parametrize('case', [(1, 32, 32, 40, 40), (1, 64, 128, 48, 48), (1, 128, 256, 24, 24), (1, 256, 512, 12, 12), (2, 96, 64, 13, 9), (1, 0, 32, 48, 40),
+                                  (1, 512, 1024, 6, 6), (1, 1024, 512, 12, 12)])
 def test_pair_is_the_two_launches(case):
     """dfl_conv2d_pair(a, b) -- the last 3x3 convolution of a residual block (ReLU) and the block's 1x1
     convolution with '+ BN(y1)' (unet.py:218-231) -- against dfl_conv2d(a); dfl_conv2d(b): y1 bit for bit (same k-step split), y2 up
@@ -211,10 +212,15 @@ def test_pair_is_the_two_launches(case):
             b = _conv_args(xind, w3p, y2, N, H, W, 1, C_, 1, 0, ldy=2 * C_)
             b.x_bf16, b.w_split = 0, 0
         b.bias, b.add, b.ldadd, b.add_scale, b.add_shift = b3.data_ptr(), y1.data_ptr(), C_, asc.data_ptr(), ash.data_ptr()
+        sp = nat.check(lib.dfl_conv_suggest_splits(C.addressof(a)), 'suggest')
+        part = None
+        if sp > 1:                                           # K slices: a finish launch (for the pair: one for both outputs)
+            part = torch.full((2 * sp * N * H * W * C_,), float('nan'), device=DEV)
+            a.splits, a.partial = sp, part.data_ptr()
         ok = lib.dfl_conv_pair_ok(C.addressof(a), C.addressof(b))
         st = torch.cuda.current_stream().cuda_stream
         if paired:
-            assert ok == 1, 'these two convolutions form a pair'
+            assert ok == (2 if sp > 1 else 1), 'these two convolutions form a pair'
             nat.check(lib.dfl_conv2d_pair(C.addressof(a), C.addressof(b), st), 'pair')
         else:
             nat.check(lib.dfl_conv2d(C.addressof(a), st), 'a')
@@ -279,7 +285,7 @@ def test_inference_forward_with_and_without_the_latency_form():
         lib = nat.lib()
         taken = sum(1 for st in lean if lib.dfl_conv_config(C.addressof(st)) == 16 + 39)
         assert taken >= 42, 'latency form taken by %d of %d convolutions' % (taken, len(lean))
-        assert sum(1 for st in plan.fwd.structs if isinstance(st, nat.ConvPairArgs)) >= 8
+        assert sum(1 for st in plan.fwd.structs if isinstance(st, nat.ConvPairArgs)) >= 11
         seg1, heat1 = seg1.clone(), heat1.clone()
         # the same plan with the hint cleared (K slices re-planned by the library for the patch kernels)
         net2 = dfl_amd.UNet(**bench.PAPER).to(DEV).eval()
