@@ -628,6 +628,7 @@ __global__ void __launch_bounds__(256) conv_finish_kernel(const ConvK p, int TX,
         dst = a.y + (int64_t)m * a.ldy + n;
       }
       if (a.accumulate) v += *dst;
+      if (a.out_scale != nullptr) v = fmaf(v, a.out_scale[co], a.out_shift[co]);     // (latency form with K slices: the consumer's BatchNorm)
       *dst = v;
       const float u = (a.stat_other != nullptr) ? a.stat_other[(int64_t)m * a.ldso + n] : v;
       s1 += v;
@@ -798,6 +799,7 @@ extern "C" int dfl_conv_suggest_splits(const dfl_conv_args* a) {
     int rc = dfl::convp_plan(a, &p, 0);
     return rc != DFL_OK ? rc : p.splits;
   }
+  if (const int zs = dfl::convs32_suggest_splits(a)) return zs;          // latency form (fp32 tensors, convs_f32.hip)
   dfl::ConvK k;
   int rc = dfl::prepare(a, &k);
   if (rc != DFL_OK) return rc;
@@ -838,17 +840,23 @@ extern "C" int dfl_conv_config(const dfl_conv_args* a) {
   dfl::ConvK k;
   int rc = dfl::prepare(a, &k);
   if (rc != DFL_OK) return rc;
-  if (dfl::convs_first_ok(a)) return 16 + dfl::CONVS_TILE;
+  if (dfl::convs_first_ok(a) || dfl::convs32_eligible(a)) return 16 + dfl::CONVS_TILE;
   if (dfl::direct_conv_ok(a)) return dfl::CFG_DIRECT;
   if (const int t = dfl::conv_rows_tile(k)) return t;
   return (int)dfl::pick_cfg(k.Mtot, a->Ntot, k.fast);
 }
 
-extern "C" int dfl_conv_pair_ok(const dfl_conv_args* a, const dfl_conv_args* b) { return dfl::convs_pair_ok(a, b); }
+extern "C" int dfl_conv_pair_ok(const dfl_conv_args* a, const dfl_conv_args* b) {
+  return (a != nullptr && !a->x_bf16) ? dfl::convs32_pair_ok(a, b) : dfl::convs_pair_ok(a, b);
+}
 
 extern "C" int dfl_conv2d_pair(const dfl_conv_args* a, const dfl_conv_args* b, dfl_stream_t stream) {
   DFL_REQUIRE(a != nullptr && b != nullptr, "dfl_conv2d_pair: null arguments");
-  if (dfl::convs_pair_ok(a, b) > 0) return dfl::convs_pair_launch(a, b, static_cast<hipStream_t>(stream));
+  if (!a->x_bf16) {
+    if (dfl::convs32_pair_ok(a, b) > 0) return dfl::convs32_pair_launch(a, b, static_cast<hipStream_t>(stream));
+  } else if (dfl::convs_pair_ok(a, b) > 0) {
+    return dfl::convs_pair_launch(a, b, static_cast<hipStream_t>(stream));
+  }
   const int rc = dfl_conv2d(a, stream);
   return rc != DFL_OK ? rc : dfl_conv2d(b, stream);
 }
@@ -863,6 +871,21 @@ extern "C" int dfl_conv2d(const dfl_conv_args* a, dfl_stream_t stream) {
     return dfl::convp_launch(p, static_cast<hipStream_t>(stream));
   }
   if (a != nullptr && a->x != nullptr && a->w != nullptr && a->y != nullptr && dfl::convs_first_ok(a)) return dfl::convs_first_launch(a, static_cast<hipStream_t>(stream));
+  if (a != nullptr && dfl::convs32_eligible(a)) {                      // latency form for fp32 tensors (convs_f32.hip)
+    int sp = 1;
+    int rc = dfl::convs32_launch(a, static_cast<hipStream_t>(stream), &sp);
+    if (rc != DFL_OK || sp <= 1) return rc;
+    dfl::ConvK k;
+    rc = dfl::prepare(a, &k);
+    if (rc != DFL_OK) return rc;
+    k.splits = sp;
+    int tx = 1;
+    while (tx * 2 <= a->Ntot && tx * 2 <= 256) tx *= 2;
+    const int nb = dfl::finish_rows(k.Mtot, a->Ntot);
+    const int rpb = (int)dfl::ceil_div(k.Mtot, nb);
+    hipLaunchKernelGGL(dfl::conv_finish_kernel, dim3((unsigned)nb, (unsigned)dfl::ceil_div(a->Ntot, tx)), dim3(256), 0, static_cast<hipStream_t>(stream), k, tx, rpb);
+    return dfl::check_launch("dfl_conv2d (latency form, split-K finish)");
+  }
   DFL_REQUIRE(a == nullptr || a->out_scale == nullptr, "dfl_conv2d: out_scale / out_shift are implemented by the latency form only (dfl_conv_config tells)");
   DFL_REQUIRE(a == nullptr || (a->x_mode == 0 && a->x_out == nullptr), "dfl_conv2d: x_mode (fused BatchNorm + ReLU backward operand) and x_out are implemented by the bf16 patch kernels only");
   {

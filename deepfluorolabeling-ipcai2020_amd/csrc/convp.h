@@ -44,6 +44,13 @@ int convs_first_launch(const dfl_conv_args* a, hipStream_t s);
 int convs_pair_ok(const dfl_conv_args* a, const dfl_conv_args* b);     // dfl_conv_pair_ok
 int convs_pair_launch(const dfl_conv_args* a, const dfl_conv_args* b, hipStream_t s);
 
+// ... and for fp32 tensors, math modes 0 (fp32 matrix instructions) and 1 (bf16x3): convs_f32.hip
+bool convs32_eligible(const dfl_conv_args* a);
+int convs32_suggest_splits(const dfl_conv_args* a);                      // 0: not this form
+int convs32_launch(const dfl_conv_args* a, hipStream_t s, int* splits_out);
+int convs32_pair_ok(const dfl_conv_args* a, const dfl_conv_args* b);
+int convs32_pair_launch(const dfl_conv_args* a, const dfl_conv_args* b, hipStream_t s);
+
 struct WgP;
 int wgradp_suggest_splits(const dfl_wgrad_args* a);
 int wgradp_launch(const dfl_wgrad_args* a, hipStream_t s);

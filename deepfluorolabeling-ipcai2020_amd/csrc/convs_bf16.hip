@@ -599,6 +599,7 @@ __global__ void __launch_bounds__(256) convs_pair_finish_kernel(const ConvP p, c
 // direct_conv3_rows_kernel walks bands of rows, three per workgroup -- 32 workgroups for one 192x192 image, 13 us.  Here a thread owns
 // one pixel and 8 channels (a wave: 64 consecutive pixels of one channel group): 9 loads of the image, the 9 x 8 weights from LDS,
 // the multiply-adds in direct_conv3_rows_kernel's order (bit-identical results), one 16-byte store.
+template <bool BF>
 __global__ void __launch_bounds__(256) convs_first_kernel(const dfl_conv_args a, int M) {
   __shared__ __attribute__((aligned(16))) float wl[9 * 64 + 3 * 64];          // [9][Ntot] weights, bias, out_scale, out_shift
   const int ncg = a.Ntot >> 3;                            // channel groups of 8
@@ -643,6 +644,18 @@ __global__ void __launch_bounds__(256) convs_first_kernel(const dfl_conv_args a,
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = fmaxf(acc[j], 0.f);
   }
+  if constexpr (!BF) {                                    // fp32 tensors: nothing is rounded, the output affine is the consumer's fma
+    if (a.out_scale != nullptr) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = fmaf(acc[j], wl[10 * Nt + n0 + j], wl[11 * Nt + n0 + j]);
+    }
+    if (pok) {
+      float* dst = a.y + ((int64_t)pix * a.ldy + n0);
+      *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      *reinterpret_cast<float4*>(dst + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+    return;
+  }
   su32x4 w;
   w.x = spack_bf2(acc[0], acc[1]);
   w.y = spack_bf2(acc[2], acc[3]);
@@ -662,7 +675,7 @@ __global__ void __launch_bounds__(256) convs_first_kernel(const dfl_conv_args a,
 
 bool convs_first_ok(const dfl_conv_args* a) {
   if (!a->latency_form || !convs_switch()) return false;
-  if (a->x_bf16 || !a->y_bf16 || a->Cin != 1 || a->KH != 3 || a->KW != 3 || a->stride != 1) return false;
+  if (a->x_bf16 || a->Cin != 1 || a->KH != 3 || a->KW != 3 || a->stride != 1 || a->w_split != 0 || a->x_split != 0) return false;
   if (a->Ntot % 8 != 0 || a->Ntot > 64 || a->ldy % 8 != 0 || !aligned16(a->y)) return false;
   if (a->add != nullptr || a->accumulate || a->scatter2x2 || a->splits > 1 || a->in_scale != nullptr || a->in_tot != nullptr) return false;
   if (a->stat_partials != nullptr || a->stat_totals != nullptr || a->stat_other != nullptr || a->x_mode != 0) return false;
@@ -674,7 +687,8 @@ bool convs_first_ok(const dfl_conv_args* a) {
 int convs_first_launch(const dfl_conv_args* a, hipStream_t s) {
   const int M = a->N * a->Hout * a->Wout;
   const int waves = (int)ceil_div(M, 64) * (a->Ntot / 8);
-  hipLaunchKernelGGL(convs_first_kernel, dim3((unsigned)ceil_div(waves, 4)), dim3(256), 0, s, *a, M);
+  if (a->y_bf16) hipLaunchKernelGGL(convs_first_kernel<true>, dim3((unsigned)ceil_div(waves, 4)), dim3(256), 0, s, *a, M);
+  else hipLaunchKernelGGL(convs_first_kernel<false>, dim3((unsigned)ceil_div(waves, 4)), dim3(256), 0, s, *a, M);
   return check_launch("dfl_conv2d (first layer, latency form)");
 }
 

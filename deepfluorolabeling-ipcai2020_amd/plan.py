@@ -327,7 +327,7 @@ class UNetPlan:
         a.relu, a.accumulate, a.scatter2x2 = relu, accumulate, scatter
         # inference plans ask for the latency form of the bf16 convolution (include/dfl_hip.h: a hint the library honours for the
         # small problems of a batch-1 forward -- the per-image loops of util.py -- and ignores for everything else)
-        a.latency_form = 1 if (self.bf16 and not self.training and not self.need_grad and os.environ.get('DFL_PLAN_LATENCY_FORM', '1') != '0') else 0
+        a.latency_form = 1 if (not self.training and not self.need_grad and os.environ.get('DFL_PLAN_LATENCY_FORM', '1') != '0') else 0
         self._out_aff_taken = False
         if out_aff is not None:
             # the consumer's eval-mode BatchNorm applied by this (producing) kernel: only the latency form does that
@@ -725,7 +725,7 @@ class UNetPlan:
                 # latency form (dfl_conv_args.out_scale: the consumer's two roundings, bit for bit) -- the consumer then reads its operand
                 # plain instead of converting 8 channels per lane and k-step on its way into the matrix instruction
                 pre_aff = None
-                if (bn and self.OUT_AFF and self.bf16 and not self.training and not self.need_grad and not circ and pad == 1 and d < bd - 1):
+                if (bn and self.OUT_AFF and not self.training and not self.need_grad and not circ and pad == 1 and d < bd - 1):
                     pre_aff = (self._new(Cout), self._new(Cout))
                 part = self._conv(fwd, gin, wp, r, 3, 3, 1, 0 if circ else pad, Cout, bias=b,
                                    in_aff=None if cur_live is not None else cur_aff, in_live=cur_live, relu=1,

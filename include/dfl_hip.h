@@ -139,16 +139,17 @@ typedef struct {
    * NULL: nothing is written. */
   void* x_out;
   int32_t ldxo;
-  /* Latency form (bf16 tensors, round 5): 1 asks for the kernel whose dependency chain is shortest instead of the one with the
-   * highest throughput -- for the small problems of a batch-1 inference forward (the per-image loops of util.py:116-165 and
-   * :318-356: 44 dependent convolutions of 0.01 - 1 GFLOP each).  A hint: honoured for at most 65536 output pixels, Cin / 16 a
-   * power of two, no statistics / live totals / x_mode / x_out; otherwise the patch-resident kernels run.  Same contract, same
-   * roundings (another fp32 summation order); dfl_conv_suggest_splits answers for the form the hint selects. */
+  /* Latency form (round 5; bf16 tensors: csrc/convs_bf16.hip, fp32 tensors in math modes 0 / 1: csrc/convs_f32.hip): 1 asks for the
+   * kernel whose dependency chain is shortest instead of the one with the highest throughput -- for the small problems of a batch-1
+   * inference forward (the per-image loops of util.py:116-165 and :318-356: 44 dependent convolutions of 0.01 - 1.4 GFLOP each).  A
+   * hint: honoured for at most 65536 output pixels and 1.5 GFLOP, Cin / 16 a power of two (<= 1024 channels), no statistics / live
+   * totals / x_mode / x_out; otherwise the throughput kernels run.  Same contract, same roundings (another fp32 summation order);
+   * dfl_conv_suggest_splits and dfl_conv_config (16 + 39) answer for the form the hint selects. */
   int32_t latency_form;
   /* Output affine (latency form only, inference): the stored value becomes bf16(out_scale[n] * bf16(v) + out_shift[n]) with v what
-   * the epilogue would have stored -- the eval-mode BatchNorm between this convolution and the next one (unet.py:214-218) applied by
-   * the PRODUCER with the consumer's two roundings, so that the consumer reads its operand plain (no affine on load; zero padding
-   * after BatchNorm stays zero).  Rejected by every other kernel: ask dfl_conv_config (16 + 39 = latency form) before relying on it. */
+   * the epilogue would have stored (fp32 tensors: fma(v, out_scale[n], out_shift[n]), nothing is rounded) -- the eval-mode BatchNorm
+   * between this convolution and the next one (unet.py:214-218) applied by the PRODUCER with the consumer's two roundings, so that
+   * the consumer reads its operand plain (no affine on load; zero padding after BatchNorm stays zero).  Rejected by every other kernel: ask dfl_conv_config (16 + 39 = latency form) before relying on it. */
   const float* out_scale;
   const float* out_shift;
 } dfl_conv_args;

@@ -62,8 +62,9 @@ def pack(w, kind, flip=0, split=0):
 
 def conv_call(x, wp, Ntot, KH, KW, stride, pad, Hout, Wout, bias=None, in_aff=None, relu=0, add=None, add_aff=None,
               y_init=None, accumulate=0, scatter=0, stats=False, stat_other=None, ldy=None, ldx_pad=0,
-              force_splits=None, w_split=0, x_split=0):
-    """x: NCHW cpu tensor -> runs dfl_conv2d -> returns y as NHWC cpu tensor [N,Hout,Wout,Cout] (+ stats)."""
+              force_splits=None, w_split=0, x_split=0, latency=False, out_aff=None):
+    """x: NCHW cpu tensor -> runs dfl_conv2d -> returns y as NHWC cpu tensor [N,Hout,Wout,Cout] (+ stats).
+    latency: the latency form (dfl_conv_args.latency_form, csrc/convs_f32.hip; tests/test_gpu_latency_form_f32.py)."""
     lib = nat.lib()
     N, Cin, Hin, Win = x.shape
     xh = nhwc(x)
@@ -107,6 +108,13 @@ def conv_call(x, wp, Ntot, KH, KW, stride, pad, Hout, Wout, bias=None, in_aff=No
     a.Hout, a.Wout, a.Ntot, a.ldy = Hout, Wout, Ntot, ldy
     a.relu, a.accumulate, a.scatter2x2 = relu, accumulate, scatter
     a.w_split, a.x_split = w_split, x_split
+    if out_aff is not None:
+        osc, osh = out_aff[0].to(DEV), out_aff[1].to(DEV)
+        keep += [osc, osh]
+        a.out_scale, a.out_shift = osc.data_ptr(), osh.data_ptr()
+    if latency:
+        a.latency_form = 1
+        assert lib.dfl_conv_config(C.addressof(a)) == 16 + 39, 'the latency form was asked for and is eligible here'
     sp = force_splits or nat.check(lib.dfl_conv_suggest_splits(C.addressof(a)))
     if sp > 1:
         Mrows = N * (Hin * Win if scatter else Hout * Wout)
