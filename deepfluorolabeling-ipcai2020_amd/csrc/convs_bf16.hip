@@ -431,11 +431,7 @@ bool convs_eligible(const dfl_conv_args& a, const ConvP& p) {
   return true;
 }
 
-static int convs_waves(int ksplit_shift) {
-  static const int force = [] { const char* e = getenv("DFL_CONVS_WAVES"); return e ? atoi(e) : 0; }();      // (A/B: 8 = always eight waves)
-  if (force == 8) return 8;
-  return ksplit_shift == 3 ? 8 : 4;
-}
+static int convs_waves(int ksplit_shift) { return ksplit_shift == 3 ? 8 : 4; }      // (always eight waves: 0.320 instead of 0.3125 ms per forward)
 
 // Work split: 32 x 32 tiles, `ksplit` waves of a workgroup per tile, `splits` K slices over workgroups.  Aim: about one wave
 // per SIMD-slot pair of the chip (2048 waves) and at least 6 k-steps per wave; cross-workgroup slices only when the eight waves

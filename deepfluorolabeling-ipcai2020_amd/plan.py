@@ -362,8 +362,8 @@ class UNetPlan:
     # (fork after dpre is written; joined before dpre's buffer is rewritten two layers later, before a batched sum
     # reads its slices, and at the end of backward).  Measured: +10 % on an isolated pair for 24x24..96x96 layers, -8 % at
     # 192x192 -- but nothing inside the real backward pass (both kernels just run slower side by side), so it is off by default.
-    OUT_AFF = os.environ.get('DFL_PLAN_OUT_AFF', '1') != '0'  # (0: A/B against the BatchNorm affine on load)
-    PAIRS = os.environ.get('DFL_PLAN_PAIRS', '1') != '0'      # (0: A/B against two launches per residual block end)
+    OUT_AFF = True          # inference: a block's inner BatchNorm applied by the producing kernel (measured: affine on load +3 us per 3x3 layer)
+    PAIRS = True            # inference: a block's last 3x3 convolution and its 1x1 as one launch (measured: -4.5 us per block end)
     SIDE_STREAM = False     # off: inside the whole backward pass the pair runs no faster (r01)
     SIDE_MAX_PIXELS = 16 * 96 * 96
 
