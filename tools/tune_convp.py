@@ -19,6 +19,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ['DFL_TUNE'] = '0'                      # measure against the cost model, not an older table
+os.environ['DFL_PLAN_LATENCY_FORM'] = '0'          # the table is about the patch-resident kernels: inference plans without the latency form
 import dfl_amd  # noqa: E402
 from dfl_amd import _native as nat  # noqa: E402
 import bench  # noqa: E402
