@@ -309,6 +309,25 @@ def fwd_ms_per_img(lib, nat, dev, math_name=''):
     nat.check(lib.dfl_set_math_mode(prev), 'dfl_set_math_mode')
     out['192x192_batch1_parity_modes'] = par
     del net
+    # the 5-net ensemble at the same size (util.py:318-356 on 8x-downsampled images): forwards on a stream per net + the reduction
+    nets = []
+    for i in range(5):
+        torch.manual_seed(10 + i)
+        nets.append(dfl_amd.UNet(**PAPER).to(dev).eval())
+
+    def small():
+        with torch.no_grad():
+            outs = util.forward_nets(nets, x, 14)
+            return util.ensemble_reduce([o[0] for o in outs], [o[1] for o in outs], (184, 184))
+    for _ in range(10):
+        small()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        small()
+    torch.cuda.synchronize()
+    out['192x192_5net_ensemble'] = round((time.perf_counter() - t0) / 50 * 1e3, 4)
+    del nets
     nets = []
     for i in range(5):
         torch.manual_seed(10 + i)

@@ -306,3 +306,27 @@ def test_inference_forward_with_and_without_the_latency_form():
     assert float((heat1 - heat0).abs().max()) <= 3e-2 * max(1.0, float(heat0.abs().max()))
     agree = float((seg1.argmax(1) == seg0.argmax(1)).float().mean())
     assert agree > 0.995, 'label agreement %.4f' % agree
+
+
+def test_ensemble_forwards_on_a_stream_per_net_are_the_serial_ones():
+    """util.forward_nets: the nets of an ensemble on one small image run on a stream each (util.py:326-330 calls them one after the
+    other): the same bits as the serial calls, replay after replay; large inputs stay on the caller's stream."""
+    import bench
+    from dfl_amd import util
+    nets = []
+    for i in range(3):
+        torch.manual_seed(20 + i)
+        nets.append(dfl_amd.UNet(**bench.PAPER).to(DEV).eval())
+    with torch.no_grad():
+        for size in (192, 96):
+            x = torch.randn(1, 1, size, size, device=DEV)
+            serial = [n(x) for n in nets]
+            for rep in range(3):
+                outs = util.forward_nets(nets, x, 14)
+                labels, heats, _ = util.ensemble_reduce([o[0] for o in outs], [o[1] for o in outs], (size - 8, size - 8))
+                torch.cuda.synchronize()
+                for (s0, h0), (s1, h1) in zip(serial, outs):
+                    assert torch.equal(s0, s1) and torch.equal(h0, h1)
+            ref = util.ensemble_reduce([o[0] for o in serial], [o[1] for o in serial], (size - 8, size - 8))
+            assert torch.equal(ref[0], labels) and torch.equal(ref[1], heats)
+        assert util.ENSEMBLE_STREAMS_MAX_PIXELS < 1440 * 1440
