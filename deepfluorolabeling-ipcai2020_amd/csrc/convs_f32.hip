@@ -438,9 +438,8 @@ __global__ void __launch_bounds__(256) convs32_pair_finish_kernel(const ConvS32 
 
 static bool convs32_switch() {
   static const bool on = [] {
-    const char* e = getenv("DFL_CONVS");               // 0: the latency form is never taken (A/B)
-    const char* f = getenv("DFL_CONVS_F32");           // 0: ... for fp32 tensors
-    return (e == nullptr || atoi(e) != 0) && (f == nullptr || atoi(f) != 0);
+    const char* e = getenv("DFL_CONVS");               // 0: the latency form is never taken (A/B against the GEMM kernels)
+    return e == nullptr || atoi(e) != 0;
   }();
   return on;
 }
