@@ -56,7 +56,8 @@ CONVP_TILES = ['4,1,2,1', '4,1,1,1', '2,2,4,1', '2,2,3,1', '2,2,2,1', '1,4,2,1',
                '4,1,3,1', '4,1,4,1', '2,2,6,1', '2,2,2,2', '2,2,3,2', '2,2,4,2', '4,1,2,2', '4,1,3,2', '1,4,2,2', '1,4,3,2',
                '4,1,1,1', '4,1,2,1', '2,2,1,1', '2,2,2,1', '1,4,1,1', '1,4,2,1', '4,1,1,2', '2,2,1,2',   # (22 ...: the streamed 1x1 forms)
                '1,4,3,1,k2', '1,4,2,1,k2', '1,4,4,1,k2', '2,2,3,1,k2', '2,2,2,1,k2', '1,4,2,2,k2', '2,2,2,2,k2', '4,1,3,1,k2', '4,1,2,1,k2',   # (30 ...: two k-groups, 512 threads)
-               'latency form']      # csrc/convp_bf16.hip kTiles: waves M x N, tiles M x N per wave
+               'latency form',      # csrc/convp_bf16.hip kTiles: waves M x N, tiles M x N per wave
+               'q0', 'q1', 'q2']   # (40 ...: the unrolled 3x3 form, csrc/convq_bf16.hip: four waves / two k-groups / two row halves)
 WGRAD_KERNELS = ['wgrad_kernel<2,2,2,2,1>', 'wgrad_kernel<2,2,1,1,1>', 'wgrad_kernel<1,1,1,1,3>',
                  'wgrad_kernel<1,1,1,1,2>', 'wgrad_kernel<1,1,1,1,1>', 'direct_wgrad_kernel', 'wgrad_kernel<2,2,1,1,3>']
 
@@ -78,7 +79,7 @@ def op_profile(plan, lib, nat, stream, detail=None):
         for st, t in zip(prog.structs, ms):
             if isinstance(st, nat.ConvArgs):
                 cfg = lib.dfl_conv_config(C.addressof(st))
-                name = CONV_KERNELS[cfg] if cfg < 16 else 'convp_kernel<%s>' % CONVP_TILES[cfg - 16]
+                name = CONV_KERNELS[cfg] if cfg < 16 else ('convq_kernel<%s>' % CONVP_TILES[cfg - 16][1:] if cfg >= 56 else 'convp_kernel<%s>' % CONVP_TILES[cfg - 16])
                 if st.scatter2x2:
                     M = st.N * st.Hin * st.Win
                 else:
@@ -288,7 +289,26 @@ def fwd_ms_per_img(lib, nat, dev, math_name=''):
         for _ in range(200):                 # (a 0.3 ms forward: the pipeline's fill is 1 % of 50 replays)
             net(x)
         torch.cuda.synchronize()
-    out['192x192_batch1'] = round((time.perf_counter() - t0) / 200 * 1e3, 4)
+    out['192x192_batch1'] = round((time.perf_counter() - t0) / 200 * 1e3, 4)      # pipelined: replays back to back, one sync at the end
+    # ... and as util.py:321,363-366 times an image: the image comes from the host, forward, reduction to labels,
+    # a device synchronisation, the labels go back to the host -- one image at a time, nothing overlaps the next one
+    x_host = torch.randn(1, 1, 192, 192)
+    with torch.no_grad():
+        lat = []
+        for i in range(120):
+            t0 = time.perf_counter()
+            seg, heat = net(x_host.to(dev))
+            labels, heats, _ = util.ensemble_reduce([seg], [heat], (184, 184))
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            labels.cpu()
+            t2 = time.perf_counter()
+            if i >= 20:
+                lat.append((t1 - t0, t2 - t0))
+    lat.sort()
+    out['192x192_batch1_latency'] = {'ms_per_img': round(lat[len(lat) // 2][0] * 1e3, 4), 'ms_per_img_with_labels_on_host': round(sorted(v[1] for v in lat)[len(lat) // 2] * 1e3, 4),
+                                     'what': 'median of 100 images, one at a time: H2D copy of the image, forward (one hipGraph replay), dfl_ensemble_reduce to '
+                                             'labels / heat maps, torch.cuda.synchronize -- the timed region of util.py:321,363-366 -- and with the uint8 labels copied back'}
     # the same forward in the arithmetics that hold north_star's 1e-4 bar (fp32 tensors: fp32 matrix instructions / split-bf16
     # products): the patch-free latency form exists for bf16 tensors only, these replay the fp32-tensor kernels
     prev = lib.dfl_get_math_mode()

@@ -784,7 +784,8 @@ __global__ void __launch_bounds__(256) convp_finish_kernel(const ConvP p, int TX
 
 // ---- host side ------------------------------------------------------------------------------------------------------
 
-struct TileCfg { int WM, WN, TM, TN, GA, KS; };   // GA: A fragments straight from global memory (1x1 windows, see the kernel); KS: k-groups (1 or 2)
+struct TileCfg { int WM, WN, TM, TN, GA, KS, Q; };   // GA: A fragments straight from global memory (1x1 windows, see the kernel); KS: k-groups (1 or 2);
+                                                       // Q: the unrolled 3x3 form of convq_bf16.hip (8 x 12 patch, 128 columns)
 // value reported by dfl_conv_config for these kernels = 16 + index
 static const TileCfg kTiles[] = {{4, 1, 2, 1, 0, 1}, {4, 1, 1, 1, 0, 1}, {2, 2, 4, 1, 0, 1}, {2, 2, 3, 1, 0, 1}, {2, 2, 2, 1, 0, 1}, {1, 4, 2, 1, 0, 1},
                                  {1, 4, 3, 1, 0, 1}, {1, 4, 4, 1, 0, 1}, {1, 4, 6, 1, 0, 1}, {1, 4, 9, 1, 0, 1}, {2, 2, 1, 1, 0, 1}, {1, 4, 1, 1, 0, 1},
@@ -796,9 +797,16 @@ static const TileCfg kTiles[] = {{4, 1, 2, 1, 0, 1}, {4, 1, 1, 1, 0, 1}, {2, 2, 
                                  {4, 1, 1, 2, 1, 1}, {2, 2, 1, 2, 1, 1},
                                  // two k-groups (512 threads, 30 ...): only ever chosen through the measured table
                                  {1, 4, 3, 1, 0, 2}, {1, 4, 2, 1, 0, 2}, {1, 4, 4, 1, 0, 2}, {2, 2, 3, 1, 0, 2}, {2, 2, 2, 1, 0, 2}, {1, 4, 2, 2, 0, 2},
-                                 {2, 2, 2, 2, 0, 2}, {4, 1, 3, 1, 0, 2}, {4, 1, 2, 1, 0, 2}};
+                                 {2, 2, 2, 2, 0, 2}, {4, 1, 3, 1, 0, 2}, {4, 1, 2, 1, 0, 2},
+                                 // (39 = CONVS_TILE: the latency form plans itself, never through this table)
+                                 {0, 0, 0, 0, 0, 0, 0},
+                                 // unrolled 3x3 form (convq_bf16.hip; 40: one k-group, 41: two): chosen through the measured table or, for
+                                 // the layer shapes convq_default() names, by default
+                                 {1, 4, 3, 1, 0, 1, 1}, {1, 4, 3, 1, 0, 2, 1},
+                                 // ... 42: eight waves on a 16 x 12 patch
+                                 {2, 4, 3, 1, 0, 1, 1}};
 constexpr int kNumTiles = (int)(sizeof(kTiles) / sizeof(kTiles[0]));
-static_assert(kNumTiles == CONVS_TILE, "convp.h: CONVS_TILE is the first index behind the tile table");
+static_assert(kNumTiles == CONVS_TILE + 4 && CONVQ_TILE == CONVS_TILE + 1, "convp.h: CONVS_TILE is the index behind the patch-kernel configurations, the unrolled 3x3 forms follow it");
 constexpr size_t kLdsSoft = 64 * 1024, kLdsHard = 150 * 1024;
 
 // Row blocks of convp_finish_kernel = rows of stat_partials the following finalize kernel has to read.  Few (<= FIN_ROWS) and
@@ -820,8 +828,10 @@ int convp_finish_rows(const ConvP& p) { return finish_rows_p(p.Mtot, p.a.Ntot); 
 static bool try_geometry(const dfl_conv_args& a, ConvP* p, const TileCfg& t, int ipp, int ph, int pw, int want_splits,
                          double* cost) {
   const int QP = t.WM * t.TM * 32;
+  if (t.WM == 0) return false;
   if (ipp < 1 || ph < 1 || pw < 1 || (int64_t)ipp * ph * pw > QP) return false;
   if (ipp > 1 && (ph != p->Hg || pw != p->Wg)) return false;
+  if (t.Q && (ipp != 1 || ph != 8 * t.WM || pw != 12 || !convq_shape_ok(a))) return false;
   p->IPP = ipp;
   p->PH = ph;
   p->PW = pw;
@@ -852,8 +862,10 @@ static bool try_geometry(const dfl_conv_args& a, ConvP* p, const TileCfg& t, int
   }
   // resident channels: the largest power-of-two multiple of 16 (<= 128, dividing Cin) whose image fits
   int ck = 128;
-  while (ck > 16 && (a.Cin % ck != 0 || npix * (ck * 2 + 16) > (int64_t)kLdsSoft)) ck >>= 1;
+  while (ck > 16 && (a.Cin % ck != 0 || (!t.Q && npix * (ck * 2 + 16) > (int64_t)kLdsSoft))) ck >>= 1;
   if (a.Cin % ck != 0) return false;
+  const int ck_min = t.Q ? 64 : 16;               // (the unrolled form is instantiated for 64 and 128 resident channels)
+  if (ck < ck_min) return false;
   size_t lds = (size_t)npix * (ck * 2 + 16);
   if (lds > kLdsHard) return false;
   const int bn = t.WN * t.TN * 32;
@@ -864,7 +876,7 @@ static bool try_geometry(const dfl_conv_args& a, ConvP* p, const TileCfg& t, int
   int splits = 1;
   if (want_splits > 1) {
     splits = want_splits;
-    while (nblk % splits != 0 && ck > 16) {
+    while (nblk % splits != 0 && ck > ck_min) {
       ck >>= 1;
       nblk = a.Cin / ck;
     }
@@ -894,6 +906,15 @@ static bool try_geometry(const dfl_conv_args& a, ConvP* p, const TileCfg& t, int
         p->grid = 8 * (int)ceil_div(p->npatch, 8 / pairs);
       }
     }
+  }
+  if (t.Q) {
+    if (p->grid >= 65536 || p->npatch >= 65536) return false;      // (the kernel divides workgroup numbers by multiply-high)
+    if (convq_lds_bytes(ck, t.WM == 2 ? 2 : (t.KS == 2 ? 1 : 0), nblk / splits) > 160 * 1024) return false;
+    auto magic = [](int d) { return (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d); };
+    p->qm_npatch = magic(p->npatch);
+    p->qm_ntiles = magic(ntiles);
+    p->qm_perimg = magic(p->npy * p->npx);
+    p->qm_npx = magic(p->npx);
   }
   p->blk_per_slice = nblk / splits;
   p->pix_stride = ck * 2 + 16;
@@ -927,7 +948,7 @@ static bool try_geometry(const dfl_conv_args& a, ConvP* p, const TileCfg& t, int
   const double per_round = busy > lat + loop ? busy : lat + loop;
   double c = (double)rounds * per_round;
   if (splits > 1) c += (double)p->Mtot * a.Ntot * 4.0 * (splits + 1) / 2000.0 + 6000.0;   // partial sums: bytes / (B per cycle of the chip) + the finish launch
-  *cost = t.KS == 2 ? 1e289 : c;                       // (two k-groups: scored only by measurement, tools/tune_convp.py)
+  *cost = (t.KS == 2 || t.Q) ? 1e289 : c;              // (two k-groups, the unrolled form: scored only by measurement, tools/tune_convp.py)
   return true;
 }
 
@@ -980,16 +1001,20 @@ static void for_each_candidate(const dfl_conv_args& a, const ConvP& base, int fo
     int shapes[24][3];
     int ns = 0;
     const int HW = base.Hg * base.Wg;
+    if (t.Q) {                                       // one patch shape
+      if (!wide) continue;
+      shapes[ns][0] = 1; shapes[ns][1] = 8 * t.WM; shapes[ns][2] = 12; ++ns;
+    } else
     if (HW <= QP) {                                  // whole images
       shapes[ns][0] = QP / HW; shapes[ns][1] = base.Hg; shapes[ns][2] = base.Wg; ++ns;
     }
-    if (base.Wg <= QP) {                             // whole rows
+    if (!t.Q && base.Wg <= QP) {                     // whole rows
       int ph = QP / base.Wg;
       if (ph > base.Hg) ph = base.Hg;
       shapes[ns][0] = 1; shapes[ns][1] = ph; shapes[ns][2] = base.Wg; ++ns;
     }
     static const int kPh[] = {1, 2, 4, 8, 16, 3, 6, 12};        // row pieces (the model looks at the powers of two)
-    for (int k = 0; k < (wide ? 8 : 5) && ns < 22; ++k) {
+    for (int k = 0; k < (wide ? 8 : 5) && ns < 22 && !t.Q; ++k) {
       const int ph = kPh[k];
       int pw = QP / ph;
       if (pw >= base.Wg || ph > base.Hg) continue;
@@ -1254,6 +1279,9 @@ int convp_launch(const ConvP& p, hipStream_t s) {
     case 35: rc = convp_launch_t<1, 4, 2, 2, false, 2>(p, s); break;
     case 36: rc = convp_launch_t<2, 2, 2, 2, false, 2>(p, s); break;
     case 37: rc = convp_launch_t<4, 1, 3, 1, false, 2>(p, s); break;
+    case CONVQ_TILE: rc = convq_launch(p, 0, s); break;
+    case CONVQ_TILE + 1: rc = convq_launch(p, 1, s); break;
+    case CONVQ_TILE + 2: rc = convq_launch(p, 2, s); break;
     default: rc = convp_launch_t<4, 1, 2, 1, false, 2>(p, s); break;
   }
   if (rc != DFL_OK || p.splits <= 1) return rc;

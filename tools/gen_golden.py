@@ -483,7 +483,33 @@ def fixture_trajectory(unet, dice, util):
     print('trajectory losses', losses[0], losses[-1], 'dice', np.mean(d))
 
 
-def fixture_plateau(unet, dice, util, wf=3, out_name='plateau.npz'):
+def _add_reference_runs(path, run_dice, threads):
+    """the per-class bar of the plateau tests is 0.005 + the REFERENCE's own spread, so the fixture has to hold more than
+    two reference runs.  Adds runs with the given thread counts (other summation orders inside the reference's convolutions) to an
+    existing fixture -- `dice_train_runs` / `dice_valid_runs` [run][class] and `run_threads` -- keeping every array already there (the
+    8- and 1-thread runs are rows 0 and 1).  run_dice(threads) -> (train dice per class, held-out dice per class)."""
+    old = dict(np.load(path, allow_pickle=False))
+    tr = [old['dice_train'], old['dice_train_1thread']]
+    va = [old['dice_valid'], old['dice_valid_1thread']]
+    th = [8, 1]
+    if 'run_threads' in old:
+        tr, va, th = list(old['dice_train_runs']), list(old['dice_valid_runs']), [int(t) for t in old['run_threads']]
+    for t in threads:
+        if t in th:
+            continue
+        dtr, dva = run_dice(t)
+        tr.append(dtr)
+        va.append(dva)
+        th.append(t)
+        print('  %s: run with %d threads: train dice %s (mean %.4f), held-out mean %.4f' % (os.path.basename(path), t, np.round(dtr, 4), dtr.mean(), dva.mean()), flush=True)
+    old['dice_train_runs'], old['dice_valid_runs'], old['run_threads'] = np.stack(tr), np.stack(va), np.array(th)
+    np.savez_compressed(path, **old)
+    sp = np.stack(tr).max(0) - np.stack(tr).min(0)
+    print('  %s: %d reference runs (threads %s); per-class spread of the training dice %s' % (os.path.basename(path), len(th), th, np.round(sp, 4)))
+    torch.set_num_threads(8)
+
+
+def fixture_plateau(unet, dice, util, wf=3, out_name='plateau.npz', extend=None):
     """The reference trained to a plateau on the toy-ellipses set (16 training + 8 held-out images, 400 SGD steps wired as
     train.py:405-430, learning rate cut 10x for the last 100): hard Dice per class on both sets (formula of
     compute_actual_dice_on_test.py:63-93) -- the quantity north_star's "+-0.005 of reference" is about.  The reference is
@@ -540,6 +566,9 @@ def fixture_plateau(unet, dice, util, wf=3, out_name='plateau.npz'):
         gt = segs.long()
         return sd0, np.array(losses), hard_dice(labels[:NTR], gt[:NTR]), hard_dice(labels[NTR:], gt[NTR:])
 
+    if extend is not None:
+        _add_reference_runs(os.path.join(OUT, out_name), lambda t: run(t)[2:], extend)
+        return
     sd0, l8, dtr8, dva8 = run(8)
     _, l1, dtr1, dva1 = run(1)
     torch.set_num_threads(8)
@@ -554,7 +583,7 @@ def fixture_plateau(unet, dice, util, wf=3, out_name='plateau.npz'):
         l8[0], l8[-20:].mean(), np.round(dtr8, 4), dtr8.mean(), dtr1.mean(), np.round(dva8, 4), dva8.mean(), dva1.mean()))
     print('  per-class |8 threads - 1 thread|: train', np.round(np.abs(dtr8 - dtr1), 4), 'valid', np.round(np.abs(dva8 - dva1), 4))
 
-def fixture_plateau_paper(unet, dice, util, steps=400, cut=300, threads=(8, 1), out_name='plateau_paper.npz'):
+def fixture_plateau_paper(unet, dice, util, steps=400, cut=300, threads=(8, 1), out_name='plateau_paper.npz', extend=None):
     """The PAPER preset (train_test_code/Readme.md:16: depth 6, 32 initial features, BatchNorm, padding, strided convolutions,
     14 landmarks, SGD 0.1 / 0.9 / nesterov / 1e-4) trained by the reference to a plateau on toy-ellipses images of the paper's
     8x-downsampled size (184 x 184 padded to 192; 16 training + 4 held-out images, batch 4, the step body of train.py:405-430,
@@ -618,6 +647,9 @@ def fixture_plateau_paper(unet, dice, util, steps=400, cut=300, threads=(8, 1), 
         gt = segs.long()
         return np.array(losses), hard_dice(labels[:NTR], gt[:NTR]), hard_dice(labels[NTR:], gt[NTR:])
 
+    if extend is not None:
+        _add_reference_runs(os.path.join(OUT, out_name), lambda t: run(t)[1:], extend)
+        return
     runs = [run(t) for t in threads]
     torch.set_num_threads(8)
     (l8, dtr8, dva8), (l1, dtr1, dva1) = runs[0], runs[-1]
@@ -710,6 +742,11 @@ def main():
     import warm_restarts_lr as wr
     import dataset
     torch.set_num_threads(8)
+    if '--extend-plateau-runs' in sys.argv:          # two more reference runs (4 and 2 threads) per plateau fixture
+        fixture_plateau(unet, dice, util, extend=(4, 2))
+        fixture_plateau(unet, dice, util, wf=4, out_name='plateau_wf4.npz', extend=(4, 2))
+        fixture_plateau_paper(unet, dice, util, extend=(4, 2))
+        return
     if '--only-plateau' in sys.argv:
         fixture_plateau(unet, dice, util)
         fixture_plateau(unet, dice, util, wf=4, out_name='plateau_wf4.npz')     # 16..64 channels: the bf16 storage mode's minimum

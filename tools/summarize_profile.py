@@ -20,12 +20,14 @@ import sys
 
 def short(name):
     """conv_gemm_kernel<2,2,1,1,...> style names as bench.py prints them."""
-    m = re.match(r'(?:void )?(?:dfl::)?(\w+)<([^>]*)>', name)
+    m = re.match(r'(?:void )?(?:dfl::)?(?:\(anonymous namespace\)::)?(\w+)<([^>]*)>', name)
     if not m:
         return re.sub(r'\(.*', '', name).replace('void ', '').replace('dfl::', '')[:80]
     args = [a.strip() for a in m.group(2).split(',')]
     keep = {'conv_gemm_kernel': 4, 'conv_rows_kernel': 4, 'wgrad_kernel': 5, 'convp_kernel': 4, 'wgradp_kernel': 2}.get(m.group(1), len(args))
     tail = ',k2' if (m.group(1) == 'convp_kernel' and len(args) >= 7 and args[6] == '2') else ''     # two k-groups (512 threads)
+    if m.group(1) == 'convq_kernel':          # (anonymous namespace: the demangled name may carry it) -> the mode alone, as bench.py names it
+        return 'convq_kernel<%s>' % args[1]
     return '%s<%s%s>' % (m.group(1), ','.join(args[:keep]), tail)
 
 
