@@ -28,7 +28,7 @@ struct ConvP {
   uint32_t qm_npatch, qm_ntiles, qm_perimg, qm_npx;
 };
 constexpr int CONVS_TILE = 39;  // value of ConvP.tile for the latency form (= number of convp tile configurations)
-constexpr int CONVQ_TILE = 40;  // ... and for the unrolled 3x3 form of convq_bf16.hip: 40 four waves, 41 two k-groups, 42 two row halves of a 16 x 12 patch
+constexpr int CONVQ_TILE = 40;  // ... and for the unrolled 3x3 form of convq_bf16.hip: 40 ... 48 = its nine wave layouts (kQ there)
 
 // Chooses the geometry for these arguments.  force_splits: 0 = free choice, else the K-slice count to plan for.
 int convp_plan(const dfl_conv_args* a, ConvP* p, int force_splits);
@@ -41,7 +41,8 @@ int convp_tune_add(const int32_t* key, const int32_t* g);
 // Unrolled 3x3 form for the deep levels (convq_bf16.hip): 8 x 12 patches, 128 columns, 64 / 128 resident channels
 bool convq_shape_ok(const dfl_conv_args& a);
 int convq_launch(const ConvP& p, int mode, hipStream_t s);
-size_t convq_lds_bytes(int ck, int mode, int blk_per_slice);      // LDS a workgroup asks for (also the offset of its tables)
+size_t convq_lds_bytes(int ck, int mode, int blk_per_slice);      // LDS a workgroup asks for
+bool convq_ck_ok(int mode, int ck);                               // is configuration `mode` instantiated for ck resident channels?
 
 // Latency form for the small problems of a batch-1 inference forward (convs_bf16.hip)
 bool convs_eligible(const dfl_conv_args& a, const ConvP& p);

@@ -537,6 +537,13 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : (TM 
   // columns of a row -- bias, ReLU, + BN(other), accumulate, statistics on 8 values at a time, ONE 16-byte bf16 store (and
   // 16-byte loads of the partner tensors) instead of eight 2-byte accesses per tensor.
   constexpr int BN = WN * TN * 32;
+  // The streamed (global A) form passes no barrier between the fill of add_tab at kernel start and the reads below: a wave that did
+  // not take part in the fill can be through a short k loop (K = 64: four k-steps) before the filling wave has derived the live
+  // scale / shift (16 fp64 loads + a square root per column) -- round 6 found a 1x1 layer's output changing from run to run once the
+  // measured table gave it this form with 16 x 8 patches (docs/experiments/table_bisect.py).  The LDS-image form has its staging barriers.
+  if constexpr (GA) {
+    if (a.add != nullptr && a.add_tot != nullptr) __syncthreads();
+  }
   constexpr int EP = BN + 4;                          // row pitch in floats (+4: rows 4 apart on different banks)
   constexpr int UPR = BN / 8;                         // 8-column units per row
   constexpr int RPS = (NT / UPR) < WM * 32 ? (NT / UPR) : WM * 32;   // rows per step of the workgroup's threads
@@ -803,10 +810,11 @@ static const TileCfg kTiles[] = {{4, 1, 2, 1, 0, 1}, {4, 1, 1, 1, 0, 1}, {2, 2, 
                                  // unrolled 3x3 form (convq_bf16.hip; 40: one k-group, 41: two): chosen through the measured table or, for
                                  // the layer shapes convq_default() names, by default
                                  {1, 4, 3, 1, 0, 1, 1}, {1, 4, 3, 1, 0, 2, 1},
-                                 // ... 42: eight waves on a 16 x 12 patch
-                                 {2, 4, 3, 1, 0, 1, 1}};
+                                 // ... 42: eight waves on a 16 x 12 patch; 43-45: 64 columns; 46-48: 32 columns (WM x 8 patch rows)
+                                 {2, 4, 3, 1, 0, 1, 1}, {2, 2, 3, 1, 0, 1, 1}, {4, 2, 3, 1, 0, 1, 1}, {2, 2, 3, 1, 0, 2, 1},
+                                 {4, 1, 3, 1, 0, 1, 1}, {8, 1, 3, 1, 0, 1, 1}, {4, 1, 3, 1, 0, 2, 1}};
 constexpr int kNumTiles = (int)(sizeof(kTiles) / sizeof(kTiles[0]));
-static_assert(kNumTiles == CONVS_TILE + 4 && CONVQ_TILE == CONVS_TILE + 1, "convp.h: CONVS_TILE is the index behind the patch-kernel configurations, the unrolled 3x3 forms follow it");
+static_assert(kNumTiles == CONVS_TILE + 10 && CONVQ_TILE == CONVS_TILE + 1, "convp.h: CONVS_TILE is the index behind the patch-kernel configurations, the unrolled 3x3 forms follow it");
 constexpr size_t kLdsSoft = 64 * 1024, kLdsHard = 150 * 1024;
 
 // Row blocks of convp_finish_kernel = rows of stat_partials the following finalize kernel has to read.  Few (<= FIN_ROWS) and
@@ -864,7 +872,11 @@ static bool try_geometry(const dfl_conv_args& a, ConvP* p, const TileCfg& t, int
   int ck = 128;
   while (ck > 16 && (a.Cin % ck != 0 || (!t.Q && npix * (ck * 2 + 16) > (int64_t)kLdsSoft))) ck >>= 1;
   if (a.Cin % ck != 0) return false;
-  const int ck_min = t.Q ? 64 : 16;               // (the unrolled form is instantiated for 64 and 128 resident channels)
+  const int qmode = (int)(&t - kTiles) - CONVQ_TILE;                      // (the unrolled form: its wave layout)
+  const int ck_min = t.Q ? 32 : 16;
+  if (t.Q) {                                       // the largest resident block the layout is instantiated for and whose image fits
+    while (ck >= 32 && (a.Cin % ck != 0 || !convq_ck_ok(qmode, ck) || convq_lds_bytes(ck, qmode, a.Cin / ck > 1 ? 2 : 1) > 160 * 1024)) ck >>= 1;
+  }
   if (ck < ck_min) return false;
   size_t lds = (size_t)npix * (ck * 2 + 16);
   if (lds > kLdsHard) return false;
@@ -880,6 +892,7 @@ static bool try_geometry(const dfl_conv_args& a, ConvP* p, const TileCfg& t, int
       ck >>= 1;
       nblk = a.Cin / ck;
     }
+    if (t.Q && !convq_ck_ok(qmode, ck)) return false;
     if (nblk % splits != 0) return false;
     lds = (size_t)npix * (ck * 2 + 16);
   }
@@ -909,7 +922,7 @@ static bool try_geometry(const dfl_conv_args& a, ConvP* p, const TileCfg& t, int
   }
   if (t.Q) {
     if (p->grid >= 65536 || p->npatch >= 65536) return false;      // (the kernel divides workgroup numbers by multiply-high)
-    if (convq_lds_bytes(ck, t.WM == 2 ? 2 : (t.KS == 2 ? 1 : 0), nblk / splits) > 160 * 1024) return false;
+    if (convq_lds_bytes(ck, qmode, nblk / splits) > 160 * 1024) return false;
     auto magic = [](int d) { return (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d); };
     p->qm_npatch = magic(p->npatch);
     p->qm_ntiles = magic(ntiles);
@@ -1279,10 +1292,11 @@ int convp_launch(const ConvP& p, hipStream_t s) {
     case 35: rc = convp_launch_t<1, 4, 2, 2, false, 2>(p, s); break;
     case 36: rc = convp_launch_t<2, 2, 2, 2, false, 2>(p, s); break;
     case 37: rc = convp_launch_t<4, 1, 3, 1, false, 2>(p, s); break;
-    case CONVQ_TILE: rc = convq_launch(p, 0, s); break;
-    case CONVQ_TILE + 1: rc = convq_launch(p, 1, s); break;
-    case CONVQ_TILE + 2: rc = convq_launch(p, 2, s); break;
-    default: rc = convp_launch_t<4, 1, 2, 1, false, 2>(p, s); break;
+    case 38: rc = convp_launch_t<4, 1, 2, 1, false, 2>(p, s); break;
+    default:
+      DFL_REQUIRE(p.tile >= CONVQ_TILE && p.tile < kNumTiles, "dfl_conv2d (bf16): tile configuration %d", p.tile);
+      rc = convq_launch(p, p.tile - CONVQ_TILE, s);
+      break;
   }
   if (rc != DFL_OK || p.splits <= 1) return rc;
   int tx = 1;

@@ -44,22 +44,22 @@ __device__ __forceinline__ void q_unpack(const qu32x4 w, float* f) {
 #ifndef DFL_CONVQ_ABL
 #define DFL_CONVQ_ABL 0
 #endif
-constexpr int QPW = 12, QIW = 14, QBN = 128, QTM = 3;   // patch width, staged width, columns per workgroup, 32-row tiles per wave
-constexpr int QEP = QBN + 4;                 // row pitch (floats) of the epilogue image
+constexpr int QPW = 12, QIW = 14, QTM = 3;   // patch width, staged width, 32-row tiles per wave
 constexpr int q_row_pitch(int ck) {
   int r = QIW * (2 * ck + 16) / 16;
   while (r % 16 != 12) ++r;
   return r * 16;
 }
 
-// MODE 0: four waves, one 8 x 12 patch.  MODE 1: eight waves = two k-groups on one 8 x 12 patch (KS = 2).  MODE 2: eight waves = two
-// row halves of a 16 x 12 patch (layers whose K is short: twice the pixels per workgroup halve the number of workgroup lives, and a
-// life is mostly fill and drain there).
-template <int CK, int MODE, int AFF>
-__global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) convq_kernel(const ConvP p) {
-  constexpr int KS = MODE == 1 ? 2 : 1;
-  constexpr int NT = MODE == 0 ? 256 : 512;
-  constexpr int QPH = MODE == 2 ? 16 : 8, QIH = QPH + 2, QNPIX = QIH * QIW, QM = QPH * QPW;
+// WM x WN x KS waves (4 or 8): WN waves side by side take 32 output columns each (the workgroup's column tile is 32 WN wide), WM
+// waves take 8 patch rows = 96 pixels each (the patch is 8 WM x 12 pixels; layers whose K is short want many pixels per workgroup:
+// a workgroup's life is mostly fill and drain there), KS k-groups split a block's 16-channel chunks.
+template <int CK, int WM, int WN, int KS, int AFF>
+__global__ void __launch_bounds__(64 * WM * WN * KS, 2) convq_kernel(const ConvP p) {
+  constexpr int NT = 64 * WM * WN * KS;
+  static_assert(NT == 256 || NT == 512, "four or eight waves");
+  constexpr int QBN = 32 * WN, QEP = QBN + 4;          // columns per workgroup, row pitch (floats) of the epilogue image
+  constexpr int QPH = 8 * WM, QIH = QPH + 2, QNPIX = QIH * QIW;
   constexpr int S = 2 * CK + 16;             // bytes per staged pixel (odd multiple of 16: consecutive pixels on different banks)
   // Row pitch of the image: with pixel (y, x) at y * RPB + x * S a ds_read_b128 lane group -- 16 lanes = pixels q, q + 1, ... of the
   // row-major patch, which wrap into the next patch row -- touches bank quad (y * RPB / 16 + x) mod 16; RPB / 16 = 12 (mod 16) is the
@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) convq_kernel(const C
   static_assert(RPB >= QIW * S && (RPB / 16) % 16 == 12, "conflict-free row pitch");
   constexpr int IMG = QIH * RPB;             // bytes per image
   constexpr int CKC = CK / 16, CCL = CKC / KS, STEPS = 9 * CCL;   // 16-channel chunks per block / per k-group; k-steps per block and k-group
-  constexpr int GS = (STEPS == 18) ? 3 : 4;  // k-steps per weight-ring group
+  constexpr int GS = (STEPS % 12 == 0) ? 4 : 3;  // k-steps per weight-ring group
   constexpr int NG = STEPS / GS;
   static_assert(CCL >= 1 && STEPS % GS == 0 && NG % 3 == 0 && STEPS % 3 == 0, "ring and fragment slots are static");
   constexpr int UPX = CK / 8;                // 16-byte units per staged pixel
@@ -88,9 +88,9 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) convq_kernel(const C
 #else
 #define QTR(i)
 #endif
-  const int tid = threadIdx.x, lane = tid & 63, wn = (tid >> 6) & 3, li = lane & 31, lh = lane >> 5;
-  const int wg = MODE == 0 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 8);   // wave group: k-group (MODE 1) or row half (MODE 2)
-  const int kg = MODE == 1 ? wg : 0;
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform (scalar registers): the k loop's addresses depend on them
+  const int wn = wave % WN, wm = (wave / WN) % WM, kg = wave / (WN * WM);
 
   // ---- which patch, column tile and K slice (convp_kernel's map: weight-heavy layers keep a (tile, slice) pair on one XCD)
   // (divisions by multiply-high with the host's magic numbers: the grid stays below 65536 workgroups -- six run-time divisions
@@ -215,12 +215,14 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) convq_kernel(const C
 
   // ---- first image: its loads go out first, the tables are derived while they fly
   {
-    Unit un[U];
+    constexpr int UG = AFF == 2 ? 6 : 10;         // units in flight per thread (registers: 4 or 8 per unit); larger images take several rounds
+    constexpr int UG0 = U < UG ? U : UG;
+    Unit un[UG0];
 #pragma unroll
-    for (int j = 0; j < U; ++j) unit_load(j, blk_begin * CK, &un[j]);
+    for (int j = 0; j < UG0; ++j) unit_load(j, blk_begin * CK, &un[j]);
     // the epilogue's per-column constants: fetched here, behind the image loads, instead of in front of the row loop (where the
     // whole workgroup waited 1.4-2 us for them: phase clocks, docs/experiments/convq_trace.py)
-    if (tid < QBN) {
+    if (tid < QBN) {                                 // (QBN <= 128 < NT)
       const int col = n0 + tid;
       const bool ok = col < a.Ntot;
       float b_ = 0.f, sc_ = 1.f, sh_ = 0.f;
@@ -257,7 +259,16 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) convq_kernel(const C
     QTR(1)
     if (AFF != 0) __syncthreads();
 #pragma unroll
-    for (int j = 0; j < U; ++j) unit_store(j, blk_begin * CK, 0, 0u, un[j]);
+    for (int j = 0; j < UG0; ++j) unit_store(j, blk_begin * CK, 0, 0u, un[j]);
+#pragma unroll
+    for (int j0 = UG0; j0 < U; j0 += UG0) {
+#pragma unroll
+      for (int j = 0; j < UG0; ++j)
+        if (j0 + j < U) unit_load(j0 + j, blk_begin * CK, &un[j]);
+#pragma unroll
+      for (int j = 0; j < UG0; ++j)
+        if (j0 + j < U) unit_store(j0 + j, blk_begin * CK, 0, 0u, un[j]);
+    }
   }
 
   // ---- LDS base of each tile row of this lane: pixel (py, px) of the patch at tap (0, 0), this lane's k half, this k-group's chunks
@@ -265,7 +276,7 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) convq_kernel(const C
 #pragma unroll
   for (int i = 0; i < QTM; ++i) {
     const int q = i * 32 + li, py = q / QPW, px = q - py * QPW;
-    a_addr[i] = (uint32_t)((py + (MODE == 2 ? wg * 8 : 0)) * RPB + px * S + lh * 16 + kg * CCL * 32);
+    a_addr[i] = (uint32_t)((py + wm * 8) * RPB + px * S + lh * 16 + kg * CCL * 32);
   }
   f32x16 acc[QTM];
 #pragma unroll
@@ -342,13 +353,13 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) convq_kernel(const C
   QTR(3)
   __syncthreads();                                  // every wave is done with the images
   QTR(8)
+  // EPP passes: the 128-column forms (one workgroup per CU, or two) drop all three tile rows at once; the narrow ones -- HBM-bound
+  // layers that want three workgroups per CU -- go tile row by tile row through an image a third of the size
+  constexpr int EPP = WN == 4 ? 1 : 3;
+  constexpr int TPP = QTM / EPP;                    // tile rows per pass
+  constexpr int RW = 32 * TPP;                      // image rows per wave and pass
+  constexpr int RI = WM * RW;                       // image rows per k-group and pass
   float* ep = reinterpret_cast<float*>(smem);
-#pragma unroll
-  for (int i = 0; i < QTM; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ep[(wg * 96 + i * 32 + mfma32_row(r, lane)) * QEP + wn * 32 + li] = acc[i][r];
-
-  QTR(9)
   constexpr int UPR = QBN / 8;                      // 8-column units per row
   constexpr int RPS = NT / UPR;                     // rows per pass of the workgroup's threads
   const int ucol = (tid % UPR) * 8, urow = tid / UPR;
@@ -369,11 +380,20 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) convq_kernel(const C
     s2[e] = 0.f;
   }
   QTR(10)
+#pragma unroll
+  for (int pass = 0; pass < EPP; ++pass) {
+  if (pass > 0) __syncthreads();                    // the previous pass's rows have been read
+#pragma unroll
+  for (int i = 0; i < TPP; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ep[(kg * RI + wm * RW + i * 32 + mfma32_row(r, lane)) * QEP + wn * 32 + li] = acc[pass * TPP + i][r];
+  QTR(9)
   __syncthreads();
   QTR(4)
 #pragma unroll
-  for (int rl = urow; rl < QM; rl += RPS) {
-    const int py = rl / QPW, px = rl - py * QPW;
+  for (int rl = urow; rl < RI; rl += RPS) {
+    const int rw = rl / RW, q = rw * 96 + pass * RW + (rl - rw * RW);      // image row -> patch row
+    const int py = q / QPW, px = q - py * QPW;
     const int gy = gy0 + py, gx = gx0 + px;
     if (!(cok && gy < p.Hg && gx < p.Wg)) continue;
     const uint32_t m = (uint32_t)((img * p.Hg + gy) * p.Wg + gx);
@@ -384,8 +404,8 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) convq_kernel(const C
       v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
     }
     if constexpr (KS == 2) {
-      const float4 v0 = *reinterpret_cast<const float4*>(ep + (QM + rl) * QEP + ucol);
-      const float4 v1 = *reinterpret_cast<const float4*>(ep + (QM + rl) * QEP + ucol + 4);
+      const float4 v0 = *reinterpret_cast<const float4*>(ep + (RI + rl) * QEP + ucol);
+      const float4 v1 = *reinterpret_cast<const float4*>(ep + (RI + rl) * QEP + ucol + 4);
       v[0] += v0.x; v[1] += v0.y; v[2] += v0.z; v[3] += v0.w; v[4] += v1.x; v[5] += v1.y; v[6] += v1.z; v[7] += v1.w;
     }
     if (sliced) {                                   // K slices: raw fp32 sums, convp_finish_kernel does the rest
@@ -434,8 +454,9 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) convq_kernel(const C
       }
     }
   }
+  }
 #ifdef DFL_CONVQ_TRACE
-  if ((tid == 0 || tid == 256) && a.partial != nullptr && !sliced) {
+  if ((tid == 0 || tid == 256) && a.partial != nullptr && !sliced) {   // (wave 0 and, with eight waves, wave 4)
     long long* sink = reinterpret_cast<long long*>(a.partial) + ((int64_t)(bpatch + p.npatch * btile) * 2 + (tid >> 8)) * 12;
     sink[0] = tr_t[0]; sink[1] = tr_t[1]; sink[2] = tr_t[2]; sink[3] = tr_t[3]; sink[4] = tr_t[4]; sink[5] = __builtin_amdgcn_s_memtime();
     sink[6] = tr_t[6]; sink[7] = __builtin_amdgcn_s_memrealtime();
@@ -464,28 +485,34 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) convq_kernel(const C
   }
 }
 
+struct QCfg { int WM, WN, KS; };
+// tile configuration CONVQ_TILE + index (csrc/convp_bf16.hip kTiles lists the same triples)
+constexpr QCfg kQ[] = {{1, 4, 1}, {1, 4, 2}, {2, 4, 1}, {2, 2, 1}, {4, 2, 1}, {2, 2, 2}, {4, 1, 1}, {8, 1, 1}, {4, 1, 2}};
+constexpr int kNumQ = (int)(sizeof(kQ) / sizeof(kQ[0]));
+
 size_t q_tab_off(int ck, int mode, int blk_per_slice) {
-  const int NT = mode == 0 ? 256 : 512;
-  size_t lds = (size_t)(blk_per_slice > 1 ? 2 : 1) * (mode == 2 ? 18 : 10) * q_row_pitch(ck);
-  const size_t epi = (size_t)(mode == 0 ? 96 : 192) * QEP * sizeof(float);
-  const size_t red = (size_t)(NT / (QBN / 8)) * 2 * QBN * sizeof(float);
+  const QCfg c = kQ[mode];
+  const int NT = 64 * c.WM * c.WN * c.KS, BN = 32 * c.WN, EPP = c.WN == 4 ? 1 : 3;
+  size_t lds = (size_t)(blk_per_slice > 1 ? 2 : 1) * (8 * c.WM + 2) * q_row_pitch(ck);
+  const size_t epi = (size_t)c.KS * c.WM * (96 / EPP) * (BN + 4) * sizeof(float);
+  const size_t red = (size_t)(NT / (BN / 8)) * 2 * BN * sizeof(float);
   if (lds < epi) lds = epi;
   if (lds < red) lds = red;
   return (lds + 15) / 16 * 16;
 }
 
-template <int CK, int MODE>
-int convq_launch_t(const ConvP& p, hipStream_t s) {
-  constexpr int NT = MODE == 0 ? 256 : 512;
+template <int CK, int WM, int WN, int KS>
+int convq_launch_t(const ConvP& p, int mode, hipStream_t s) {
+  constexpr int NT = 64 * WM * WN * KS;
   ConvP pl = p;
-  pl.tab_off = (int)q_tab_off(CK, MODE, p.blk_per_slice);
-  const size_t lds = convq_lds_bytes(CK, MODE, p.blk_per_slice);
+  pl.tab_off = (int)q_tab_off(CK, mode, p.blk_per_slice);
+  const size_t lds = convq_lds_bytes(CK, mode, p.blk_per_slice);
   DFL_REQUIRE(lds <= 160 * 1024, "dfl_conv2d (bf16, unrolled 3x3): %zu bytes of LDS", lds);
   const bool aff = p.a.in_scale != nullptr || p.a.in_tot != nullptr;
   dim3 grid((unsigned)p.grid);
 #define DFL_CQ_LAUNCH(AFF_)                                                                                                   \
   {                                                                                                                             \
-    auto k = convq_kernel<CK, MODE, AFF_>;                                                                                        \
+    auto k = convq_kernel<CK, WM, WN, KS, AFF_>;                                                                                \
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
     (void)attr;                                                                                                                 \
     hipLaunchKernelGGL(k, grid, dim3(NT), lds, s, pl);                                                                          \
@@ -497,22 +524,57 @@ int convq_launch_t(const ConvP& p, hipStream_t s) {
   return check_launch("dfl_conv2d (bf16, unrolled 3x3)");
 }
 
+// A configuration is instantiated for the resident blocks whose image is at most 10 staging units (16 bytes) per thread: beyond
+// that the staging registers spill (and such an image leaves no room for a second one anyway)
+constexpr bool q_inst(int ck, int wm, int wn, int ks) {
+  return ((8 * wm + 2) * QIW * (ck / 8) + 64 * wm * wn * ks - 1) / (64 * wm * wn * ks) <= 10 && ck / 16 >= ks;
+}
+
+template <int WM, int WN, int KS>
+int convq_launch_ck(const ConvP& p, int mode, hipStream_t s) {
+  if (p.CK == 128) {
+    if constexpr (q_inst(128, WM, WN, KS)) return convq_launch_t<128, WM, WN, KS>(p, mode, s);
+  } else if (p.CK == 64) {
+    if constexpr (q_inst(64, WM, WN, KS)) return convq_launch_t<64, WM, WN, KS>(p, mode, s);
+  } else if (p.CK == 32) {
+    if constexpr (q_inst(32, WM, WN, KS)) return convq_launch_t<32, WM, WN, KS>(p, mode, s);
+  }
+  set_error("dfl_conv2d (bf16, unrolled 3x3): no instantiation for %d resident channels in configuration %d", p.CK, mode);
+  return DFL_ERR_INVALID_ARG;
+}
+
 }  // namespace
 
 // The layer shapes this form takes (the caller has validated the argument block as convp_plan_search does)
 bool convq_shape_ok(const dfl_conv_args& a) {
-  return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.scatter2x2 == 0 && a.Cin % 64 == 0 && a.Ntot % 8 == 0 &&
+  return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.scatter2x2 == 0 && a.Cin % 32 == 0 && a.Ntot % 8 == 0 &&
          a.Hout == a.Hin && a.Wout == a.Win && a.out_scale == nullptr;
 }
 
+// Resident channels a configuration is instantiated for (q_inst)
+bool convq_ck_ok(int mode, int ck) {
+  if (mode < 0 || mode >= kNumQ || (ck != 32 && ck != 64 && ck != 128)) return false;
+  const QCfg c = kQ[mode];
+  return q_inst(ck, c.WM, c.WN, c.KS);
+}
+
 size_t convq_lds_bytes(int ck, int mode, int blk_per_slice) {
-  return q_tab_off(ck, mode, blk_per_slice) + (size_t)(3 * QBN + 3 * blk_per_slice * ck) * sizeof(float);
+  return q_tab_off(ck, mode, blk_per_slice) + (size_t)(3 * 32 * kQ[mode].WN + 3 * blk_per_slice * ck) * sizeof(float);
 }
 
 int convq_launch(const ConvP& p, int mode, hipStream_t s) {
-  DFL_REQUIRE((p.CK == 128 || p.CK == 64) && mode >= 0 && mode <= 2, "dfl_conv2d (bf16, unrolled 3x3): resident channel block %d, mode %d", p.CK, mode);
-  if (p.CK == 128) return mode == 0 ? convq_launch_t<128, 0>(p, s) : (mode == 1 ? convq_launch_t<128, 1>(p, s) : convq_launch_t<128, 2>(p, s));
-  return mode == 0 ? convq_launch_t<64, 0>(p, s) : (mode == 1 ? convq_launch_t<64, 1>(p, s) : convq_launch_t<64, 2>(p, s));
+  DFL_REQUIRE(convq_ck_ok(mode, p.CK), "dfl_conv2d (bf16, unrolled 3x3): resident channel block %d, configuration %d", p.CK, mode);
+  switch (mode) {
+    case 0: return convq_launch_ck<1, 4, 1>(p, mode, s);
+    case 1: return convq_launch_ck<1, 4, 2>(p, mode, s);
+    case 2: return convq_launch_ck<2, 4, 1>(p, mode, s);
+    case 3: return convq_launch_ck<2, 2, 1>(p, mode, s);
+    case 4: return convq_launch_ck<4, 2, 1>(p, mode, s);
+    case 5: return convq_launch_ck<2, 2, 2>(p, mode, s);
+    case 6: return convq_launch_ck<4, 1, 1>(p, mode, s);
+    case 7: return convq_launch_ck<8, 1, 1>(p, mode, s);
+    default: return convq_launch_ck<4, 1, 2>(p, mode, s);
+  }
 }
 
 }  // namespace dfl

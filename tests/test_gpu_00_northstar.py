@@ -184,19 +184,18 @@ def test_plateau_dice_matches_reference(mode):
     finally:
         nat.check(lib.dfl_set_math_mode(prev), 'dfl_set_math_mode')
     ref8, ref1 = g['dice_train'], g['dice_train_1thread']
-    lo, hi = min(ref8.mean(), ref1.mean()), max(ref8.mean(), ref1.mean())
-    print('plateau %s: mean Dice %.4f (reference %.4f / %.4f), per class %s' % (mode, float(np.mean(d)), ref8.mean(), ref1.mean(), np.round(d, 4)))
-    assert lo - 0.005 <= float(np.mean(d)) <= hi + 0.005, 'mean hard Dice %.4f vs reference %.4f / %.4f' % (float(np.mean(d)), ref8.mean(), ref1.mean())
-    # per class: +-0.005 around the reference's two runs in the arithmetics that hold the 1e-4 forward bar.  ONE trajectory with bf16
-    # tensors (or bf16 products) is not the arithmetic's answer -- a change in the order of an fp32 sum picks another one (fourteen
-    # builds: single classes 0.9891 ... 0.9979 where the reference's runs give 0.993 ... 0.998) -- so a single
-    # class of a single trajectory gets 0.01 there, as in test_paper_preset_plateau_dice_matches_reference; the MEAN bar above is
-    # north_star's +-0.005 in every mode (round 5: class 1 came out at 0.9957 where the better of the reference's two runs has
-    # 0.9904 -- 0.0003 outside 0.005, on the GOOD side -- after the weight-gradient patch shapes had changed)
-    cbar = 0.01 if mode in ('bf16s', 'bf16') else 0.005
+    runs = g['dice_train_runs']                        # the reference's own runs (8 / 1 / 4 / 2 CPU threads: four summation orders)
+    assert runs.shape[0] >= 4
+    lo, hi = float(runs.mean(1).min()), float(runs.mean(1).max())
+    print('plateau %s: mean Dice %.4f (reference runs %s), per class %s' % (mode, float(np.mean(d)), np.round(runs.mean(1), 4), np.round(d, 4)))
+    assert lo - 0.005 <= float(np.mean(d)) <= hi + 0.005, 'mean hard Dice %.4f vs the reference\'s runs %s' % (float(np.mean(d)), np.round(runs.mean(1), 4))
+    # per class: 0.005 around the band the REFERENCE's own runs span on that class -- the same bar in every arithmetic.
+    # (Round 5 gave the bf16 modes a flat 0.01 after one class of one trajectory had landed 0.0003 outside 0.005 around TWO reference
+    # runs; four runs show what the width of that band is: class 1 of this fixture moves by 0.014 between the reference's own thread
+    # counts, the other classes by 0.001-0.004.)
     for c in range(6):
-        a, b = min(ref8[c], ref1[c]), max(ref8[c], ref1[c])
-        assert a - cbar <= d[c] <= b + cbar, 'class %d: hard Dice %.4f vs reference %.4f / %.4f' % (c + 1, d[c], ref8[c], ref1[c])
+        a, b = float(runs[:, c].min()), float(runs[:, c].max())
+        assert a - 0.005 <= d[c] <= b + 0.005, 'class %d: hard Dice %.4f vs the reference\'s runs %s' % (c + 1, d[c], np.round(runs[:, c], 4))
     # plateau loss (mean of the last 20 steps; the trajectories are chaotic at this level: the reference's own two runs -- 8 / 1
     # CPU threads -- end 0.0016 apart for the wf = 3 fixture and 0.0042 for wf = 4, two builds of this library 0.003): not
     # more than 5e-3 above the worse of the reference's runs, and not implausibly far below the better one
@@ -253,27 +252,28 @@ def test_paper_preset_plateau_dice_matches_reference(mode):
     channels, BatchNorm, zero padding, strided convolutions, 14 landmarks (train_test_code/Readme.md:16) -- at the 8x-downsampled
     size (184 x 184 padded to 192), batch 4, SGD 0.1 / 0.9 / nesterov / 1e-4 with the learning rate cut 10x for the last quarter,
     the step body of train.py:405-430, scored by hard Dice per class (compute_actual_dice_on_test.py:63-93).
-    tests/golden/plateau_paper.npz holds the REFERENCE's own two runs (8 / 1 CPU threads; tools/gen_golden.py
-    fixture_plateau_paper): mean training Dice 0.9949 / 0.9955, classes up to 0.0017 apart.  The HIP path from the same seeded
-    initial weights (their SHA-256 is pinned by test_paper_golden), same data, same 400 steps: mean Dice within +-0.005 of the
-    reference's runs, every class within 0.005 + the reference's own spread -- in the two parity arithmetics and in the bf16
-    STORAGE arithmetic the headline is quoted in (1024-channel / 6 x 6-pixel levels included).
+    tests/golden/plateau_paper.npz holds the REFERENCE's own four runs (8 / 1 / 4 / 2 CPU threads = four summation orders inside its
+    convolutions; tools/gen_golden.py fixture_plateau_paper, --extend-plateau-runs): mean training Dice 0.9937 ... 0.9956, single
+    classes up to 0.0065 apart.  The HIP path from the same seeded initial weights (their SHA-256 is pinned by test_paper_golden),
+    same data, same 400 steps: mean Dice within +-0.005 of the reference's runs, every class within 0.005 of the band the reference's
+    runs span on it -- in the two parity arithmetics and in the bf16 STORAGE arithmetic the headline is quoted in (1024-channel /
+    6 x 6-pixel levels included), the same bar for all three.
 
-    Training is chaotic, and in bf16 storage a change in the ORDER of an fp32 sum is enough to pick another trajectory: fourteen
-    builds / switch settings of this library that differ in nothing else (pixel-slice counts, tile sizes, which kernel adds the
-    head's statistics, which layers hand the weight gradient a materialised operand) end between 0.9934 and 0.9954 mean Dice with
-    single classes between 0.9891 and 0.9979.  One trajectory is therefore not the arithmetic's answer: the
-    bf16 storage mode runs the FOUR trajectories its two Python-level switches give (UNetPlan.DPRE_OUT_BYTES 0 / every layer,
-    UNetPlan.LIVE_HEAD on / off; the default build is one of them) and is held to: EVERY trajectory's mean Dice within +-0.005 of
-    the reference (north_star's bar, unchanged), every class of the AVERAGE over the trajectories within 0.005 + the reference's
-    spread (the bar of the parity modes), and every class of every single trajectory within 0.01."""
+    Training is chaotic, and a change in the ORDER of an fp32 sum is enough to pick another trajectory -- in the reference (the four
+    runs above) as in this library (fourteen builds / switch settings that differ in nothing else ended between 0.9934 and 0.9954
+    mean Dice in bf16 storage).  The bf16 storage mode runs two trajectories (the default build; the operand
+    written by every data gradient + the head's statistics from colstats) and EVERY one is held to the bars above."""
     from dfl_amd import plan as P_
     g = load_golden('plateau_paper')
     ref8, ref1 = g['dice_train'], g['dice_train_1thread']
-    lo, hi = min(ref8.mean(), ref1.mean()), max(ref8.mean(), ref1.mean())
+    refs = g['dice_train_runs']                        # the reference's own runs (8 / 1 / 4 / 2 CPU threads), tools/gen_golden.py --extend-plateau-runs
+    assert refs.shape[0] >= 4
+    lo, hi = float(refs.mean(1).min()), float(refs.mean(1).max())
     l8, l1 = float(g['losses'][-20:].mean()), float(g['losses_1thread'][-20:].mean())
     runs = []
-    settings = [(None, None)] if mode != 'bf16s' else [(0, True), (1 << 40, True), (0, False), (1 << 40, False)]
+    # bf16 storage: two trajectories -- the default build and the one with the operand written by the data gradient at every layer
+    # and the head's statistics from colstats (round 5 ran four; the bar below no longer needs an average over them)
+    settings = [(None, None)] if mode != 'bf16s' else [(None, None), (1 << 40, False)]
     for dpre, live_head in settings:
         prev = (P_.UNetPlan.DPRE_OUT_BYTES, P_.UNetPlan.LIVE_HEAD)
         if dpre is not None:
@@ -282,27 +282,22 @@ def test_paper_preset_plateau_dice_matches_reference(mode):
             d, dv, l_hip = _paper_plateau_run(g, mode)
         finally:
             P_.UNetPlan.DPRE_OUT_BYTES, P_.UNetPlan.LIVE_HEAD = prev
-        print('paper-preset plateau %s%s: mean training Dice %.4f (reference %.4f / %.4f), per class %s; held-out %.4f (reference %.4f / %.4f); '
+        print('paper-preset plateau %s%s: mean training Dice %.4f (reference runs %s), per class %s; held-out %.4f (reference %.4f / %.4f); '
               'loss %.4f (reference %.4f / %.4f)' % (mode, '' if dpre is None else ' [operand written: %s, head sums: %s]' % (bool(dpre), live_head),
-                                                     float(d.mean()), ref8.mean(), ref1.mean(), np.round(d, 4), float(dv.mean()),
+                                                     float(d.mean()), np.round(refs.mean(1), 4), np.round(d, 4), float(dv.mean()),
                                                      g['dice_valid'].mean(), g['dice_valid_1thread'].mean(), l_hip, l8, l1))
-        assert lo - 0.005 <= float(d.mean()) <= hi + 0.005, 'mean hard Dice %.4f vs reference %.4f / %.4f' % (float(d.mean()), ref8.mean(), ref1.mean())
+        assert lo - 0.005 <= float(d.mean()) <= hi + 0.005, 'mean hard Dice %.4f vs the reference\'s runs %s' % (float(d.mean()), np.round(refs.mean(1), 4))
         runs.append((d, l_hip))
-    single = 0.005 if len(runs) == 1 else 0.01
-    davg = np.mean([d for d, _ in runs], axis=0)
-    lavg = float(np.mean([l for _, l in runs]))
+    # per class: EVERY trajectory of EVERY arithmetic within 0.005 of the band the reference's own four runs span on
+    # that class (its spread is 0.001-0.0065 here) -- no wider bar for the bf16 modes, no averaging over trajectories
     for c in range(6):
-        a, b = min(ref8[c], ref1[c]), max(ref8[c], ref1[c])
-        assert a - 0.005 <= davg[c] <= b + 0.005, 'class %d: hard Dice %.4f (average of %d trajectories) vs reference %.4f / %.4f' % (
-            c + 1, davg[c], len(runs), ref8[c], ref1[c])
+        a, b = float(refs[:, c].min()), float(refs[:, c].max())
         for d, _ in runs:
-            assert a - single <= d[c] <= b + single, 'class %d: hard Dice %.4f vs reference %.4f / %.4f' % (c + 1, d[c], ref8[c], ref1[c])
-    # plateau loss (mean of the last 20 steps): not more than 5e-3 above the worse of the reference's runs and not implausibly far
-    # below the better one; a single bf16-storage trajectory gets twice that
-    assert min(l8, l1) - 2e-2 <= lavg <= max(l8, l1) + 5e-3, 'plateau loss %.4f vs reference %.4f / %.4f' % (lavg, l8, l1)
+            assert a - 0.005 <= d[c] <= b + 0.005, 'class %d: hard Dice %.4f vs the reference\'s runs %s' % (c + 1, d[c], np.round(refs[:, c], 4))
+    # plateau loss (mean of the last 20 steps): not more than 5e-3 (bf16 storage: 1e-2) above the worse of the reference's runs and not
+    # implausibly far below the better one
     for _, l in runs:
-        assert min(l8, l1) - 2e-2 <= l <= max(l8, l1) + 2 * single, 'plateau loss %.4f vs reference %.4f / %.4f' % (l, l8, l1)
-
+        assert min(l8, l1) - 2e-2 <= l <= max(l8, l1) + (1e-2 if mode == 'bf16s' else 5e-3), 'plateau loss %.4f vs reference %.4f / %.4f' % (l, l8, l1)
 
 
 @pytest.mark.parametrize('optimizer', ['torch', 'dfl'])

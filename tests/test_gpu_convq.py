@@ -1,5 +1,5 @@
-"""The unrolled 3x3 form of the bf16 convolution (csrc/convq_bf16.hip; tile configurations 40 = four waves, 41 = two k-groups,
-42 = two row halves of a 16 x 12 patch), forced through dfl_conv_force_geometry, under every operand / epilogue form the network
+"""The unrolled 3x3 form of the bf16 convolution (csrc/convq_bf16.hip; tile configurations 40 ... 48 = its nine wave layouts: WM x 8
+patch rows, WN x 32 columns, KS k-groups), forced through dfl_conv_force_geometry, under every operand / epilogue form the network
 gives a deep-level 3x3 layer (reference: train_test_code/unet.py:211-222 and their autograd): plain + statistics on ragged
 images and ragged column counts, BatchNorm affine on load + residual + accumulate + partner statistics through K slices, the
 fused BatchNorm + ReLU backward operand with x_out.  Same bars as tests/test_gpu_bf16.py (fp64 PyTorch on the bf16-rounded
@@ -16,25 +16,26 @@ import test_gpu_bf16 as T
 from test_gpu_bf16 import rb, nhwc, pack16, conv_bf16, brb_reference, _mode4  # noqa: F401
 
 pytestmark = pytest.mark.gpu
-TILES = (40, 41, 42)
+QCFG = {40: (1, 4, 1), 41: (1, 4, 2), 42: (2, 4, 1), 43: (2, 2, 1), 44: (4, 2, 1), 45: (2, 2, 2), 46: (4, 1, 1), 47: (8, 1, 1), 48: (4, 1, 2)}   # csrc/convq_bf16.hip kQ
+TILES = tuple(QCFG)
 
 
 def close_bf16(got, ref, what=''):
     """test_gpu_bf16.close_bf16 (2^-8 of the value + 2e-5 of the largest magnitude) with the allowance long contractions need: the
     fp32 sum of K = 9 * 512 products carries ~1e-5 of sum |x||w|, which at these sizes exceeds the absolute term, so a sum next to a
-    bf16 rounding boundary may land on the other side -- at most 1e-4 of the elements, and then by no more than one bf16 step."""
+    bf16 rounding boundary may land on the other side -- at most 2e-4 of the elements, and then by no more than one bf16 step."""
     ref = ref.double()
     err = (got.double() - ref).abs()
     bound = ref.abs() * 2.0 ** -8 + 2e-5 * float(ref.abs().max())
     bad = err > bound
-    assert float(bad.double().mean()) <= 1e-4, '%s: %d of %d elements off; worst |err| %.3e at value %.3e' % (
+    assert float(bad.double().mean()) <= 2e-4, '%s: %d of %d elements off; worst |err| %.3e at value %.3e' % (
         what, int(bad.sum()), bad.numel(), float(err.max()), float(ref.flatten()[err.argmax()]))
     assert not bool((err > 2 * bound).any()), '%s: an element is off by more than one rounding step (|err| %.3e)' % (what, float(err.max()))
 
 
 class forced:
     def __init__(self, tile, splits):
-        self.g = (C.c_int32 * 5)(tile, 1, 16 if tile == 42 else 8, 12, splits)
+        self.g = (C.c_int32 * 5)(tile, 1, 8 * QCFG[tile][0], 12, splits)
 
     def __enter__(self):
         nat.check(nat.lib().dfl_conv_force_geometry(C.addressof(self.g)), 'force')
@@ -45,20 +46,22 @@ class forced:
 
 def _valid(N, Cin, Cout, H, W, tile, splits):
     """Is (tile, splits) among the layer's candidates?"""
-    return (tile, 1, 16 if tile == 42 else 8, 12, splits) in T._candidates(N, Cin, Cout, H, W, 3, 1, 1)
+    return (tile, 1, 8 * QCFG[tile][0], 12, splits) in T._candidates(N, Cin, Cout, H, W, 3, 1, 1)
 
 
 def test_candidates_list_the_unrolled_form_where_it_applies():
-    assert all(_valid(2, 128, 128, 24, 24, t, 1) for t in TILES)
+    assert all(_valid(2, 128, 128, 24, 24, t, 1) for t in (40, 41, 42, 43, 44, 45))
     assert _valid(2, 256, 128, 24, 24, 41, 2) and _valid(2, 512, 128, 12, 12, 40, 8)
-    assert not any(_valid(2, 32, 128, 24, 24, t, 1) for t in TILES)            # needs 64 resident channels
-    assert not any(_valid(2, 128, 64, 24, 24, t, 1) for t in TILES)            # ... and 128 columns
+    assert all(_valid(2, 32, 32, 24, 24, t, 1) for t in (46, 47)) and not any(_valid(2, 32, 32, 24, 24, t, 1) for t in (40, 41, 42, 43, 44, 45))
+    assert _valid(2, 64, 64, 24, 24, 43, 1) and _valid(2, 64, 64, 24, 24, 44, 1) and not _valid(2, 64, 64, 24, 24, 46, 1)   # (a 64-column layer takes 64-column tiles)
+    assert not any(_valid(2, 16, 32, 24, 24, t, 1) for t in TILES)             # needs 32 resident channels
     assert not any(g[0] >= 39 for g in T._candidates(2, 64, 128, 16, 16, 1, 1, 0))   # 3x3 / stride 1 / pad 1 only
 
 
 @pytest.mark.parametrize('tile', TILES)
 @pytest.mark.parametrize('case', [(2, 64, 128, 17, 11), (1, 128, 256, 24, 24), (2, 256, 192, 20, 30), (3, 128, 136, 6, 6),
-                                  (1, 512, 128, 45, 45), (16, 64, 128, 48, 48)])
+                                  (1, 512, 128, 45, 45), (16, 64, 128, 48, 48),
+                                  (2, 32, 32, 40, 25), (2, 64, 32, 33, 12), (2, 32, 64, 17, 30), (1, 128, 64, 50, 24), (2, 64, 64, 96, 96), (1, 96, 40, 20, 20)])
 def test_convq_plain_and_statistics(case, tile):
     N, Cin, Cout, H, W = case
     g = torch.Generator().manual_seed(sum(case) + tile)
@@ -67,6 +70,8 @@ def test_convq_plain_and_statistics(case, tile):
     b = torch.randn(Cout, generator=g)
     ref = nhwc(F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1)))
     wp = pack16(w, 1)
+    if not _valid(N, Cin, Cout, H, W, tile, 1):
+        pytest.skip('not a configuration of this layer')
     for splits in (1, 2, 4):
         if not _valid(N, Cin, Cout, H, W, tile, splits):
             continue
@@ -79,7 +84,7 @@ def test_convq_plain_and_statistics(case, tile):
 
 
 @pytest.mark.parametrize('tile', TILES)
-@pytest.mark.parametrize('case', [(2, 64, 128, 12, 12), (2, 256, 256, 13, 9), (1, 512, 128, 24, 24)])
+@pytest.mark.parametrize('case', [(2, 64, 128, 12, 12), (2, 256, 256, 13, 9), (1, 512, 128, 24, 24), (2, 32, 32, 30, 14), (2, 128, 64, 20, 20), (1, 64, 32, 40, 13)])
 def test_convq_affine_residual_epilogue(case, tile):
     """BatchNorm affine on load with zero padding AFTER it, '+ BN(other)', accumulate, statistics against a partner tensor (the
     forward block epilogue, unet.py:229-231, and the fused backward sums), one launch and through K slices."""
@@ -93,10 +98,12 @@ def test_convq_affine_residual_epilogue(case, tile):
     asc, ash = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.2
     y0 = rb(torch.randn(N, Cout, H, W, generator=g))
     partner = rb(torch.randn(N, Cout, H, W, generator=g))
-    xa = rb(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    xa = rb((x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)).float())     # fmaf: one rounding, then bf16
     ref = F.conv2d(xa.double(), w.double(), b.double(), padding=1)
     ref = ref + other.double() * asc.double().view(1, -1, 1, 1) + ash.double().view(1, -1, 1, 1) + y0.double()
     wp = pack16(w, 1)
+    if not _valid(N, Cin, Cout, H, W, tile, 1):
+        pytest.skip('not a configuration of this layer')
     ran = 0
     for splits in (1, 2, 4):
         if not _valid(N, Cin, Cout, H, W, tile, splits):
@@ -114,7 +121,7 @@ def test_convq_affine_residual_epilogue(case, tile):
 
 @pytest.mark.parametrize('tile', TILES)
 @pytest.mark.parametrize('with_bn', [True, False])
-@pytest.mark.parametrize('case', [(2, 64, 128, 12, 12), (2, 256, 128, 17, 13), (1, 128, 256, 24, 24)])
+@pytest.mark.parametrize('case', [(2, 64, 128, 12, 12), (2, 256, 128, 17, 13), (1, 128, 256, 24, 24), (2, 32, 32, 30, 14), (2, 32, 64, 20, 20), (1, 64, 32, 40, 13)])
 def test_convq_fused_bn_relu_backward_operand(case, with_bn, tile):
     """dfl_conv_args.x_mode: the data gradient forms [r > 0] * (A dy + B r + C) from (dy, r) while it stages its patches; x_out is
     that operand, every element exactly once, bit for bit (K slices each write their own channels)."""
@@ -127,6 +134,8 @@ def test_convq_fused_bn_relu_backward_operand(case, with_bn, tile):
     w = rb(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)
     ref = F.conv2d(dpre.double(), w.double(), padding=1)
     wp = pack16(w, 1)
+    if not _valid(N, Cin, Cout, H, W, tile, 1):
+        pytest.skip('not a configuration of this layer')
     for splits in (1, 2):
         if not _valid(N, Cin, Cout, H, W, tile, splits):
             continue
@@ -149,6 +158,8 @@ def test_convq_is_bit_repeatable_and_agrees_with_the_patch_kernel():
     wp = pack16(w, 1)
     base = conv_bf16(x, wp, Cout, 3, 3, 1, 1, H, W)
     for tile in TILES:
+        if not _valid(N, Cin, Cout, H, W, tile, 1):
+            continue
         with forced(tile, 1):
             y1 = conv_bf16(x, wp, Cout, 3, 3, 1, 1, H, W, force_splits=1)
             y2 = conv_bf16(x, wp, Cout, 3, 3, 1, 1, H, W, force_splits=1)

@@ -28,6 +28,7 @@ def main():
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--rounds', type=int, default=3)
     ap.add_argument('--eval', action='store_true')
+    ap.add_argument('--narrow', action='store_true', help='only the layers with fewer than 128 columns')
     args = ap.parse_args()
     lib = nat.lib()
     nat.check(lib.dfl_set_math_mode(4), 'mode')
@@ -50,7 +51,7 @@ def main():
     torch.cuda.synchronize()
     ops = []
     for st in structs:
-        if isinstance(st, nat.ConvArgs) and st.x_bf16 and st.KH == 3 and st.stride == 1 and st.Cin % 64 == 0 and st.Ntot >= 128 and not st.scatter2x2:
+        if isinstance(st, nat.ConvArgs) and st.x_bf16 and st.KH == 3 and st.stride == 1 and st.Cin % 32 == 0 and not st.scatter2x2 and (not args.narrow or st.Ntot < 128):
             ops.append(st)
     stream = torch.cuda.current_stream().cuda_stream
     scratch = torch.empty(1 << 27, device=dev)
@@ -102,9 +103,9 @@ def main():
         t_lib = time_geom(st, None)
         row = []
         best = t_lib
-        for tile in (40, 41, 42):
+        for tile, wm in ((40, 1), (41, 1), (42, 2), (43, 2), (44, 4), (45, 2), (46, 4), (47, 8), (48, 4)):
             for sp in (1, 2, 4, 8):
-                t = time_geom(st, (tile, 1, 16 if tile == 42 else 8, 12, sp))
+                t = time_geom(st, (tile, 1, 8 * wm, 12, sp))
                 if t is not None:
                     row.append('%d/s%d %.1f' % (tile, sp, t))
                     best = min(best, t)
