@@ -33,19 +33,29 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0        # same guide: dense bf16 MFMA (the 5 PF ma
 HBM_PEAK_GBS = 8000.0                 # same guide: HBM3E, 8 TB/s
 # product arithmetic of the GEMM kernels (include/dfl_hip.h): name -> (mode, bf16 MFMA products per fp32 product)
 MATH = {'fp32': (0, 0), 'bf16x3': (1, 3), 'bf16x6': (2, 6), 'bf16': (3, 1), 'bf16s': (4, 1)}
-TRAFFIC_FILES = ['r05_traffic.json', 'r04_traffic.json']   # per-kernel HBM bytes from committed rocprofv3 --pmc passes, newest first
+TRAFFIC_FILES = ['r06_traffic.json', 'r05_traffic.json', 'r04_traffic.json']   # per-kernel HBM bytes from committed rocprofv3 --pmc passes, newest first
 
 
-def csrc_sha16():
-    """Hash of the kernel sources: a committed traffic figure is quoted as current only when the kernels it was measured on
-    are the kernels of this tree (the line must not quote stale bytes silently)."""
+KERNEL_SOURCES = {'wgradp_kernel': ['wgradp_bf16.hip'], 'convp_kernel': ['convp_bf16.hip', 'convp.h'], 'convq_kernel': ['convq_bf16.hip', 'convp.h'],
+                  'convp_finish_kernel': ['convp_bf16.hip', 'convp.h'], 'conv_gemm_kernel': ['conv_gemm.hip', 'conv_epilogue.h'],
+                  'conv_rows_kernel': ['conv_rows.hip', 'conv_rows.h', 'conv_epilogue.h'], 'wgrad_kernel': ['wgrad_gemm.hip'],
+                  'reduce_batch_kernel': ['bn_elem.hip'], 'sgd_pack_tiles_kernel': ['bn_elem.hip']}
+
+
+def csrc_sha16(kernel=None):
+    """Hash of the kernel sources: a committed traffic figure is quoted as current only when the kernel it was measured on is the
+    kernel of this tree (the line must not quote stale bytes silently).  Per kernel: the source file(s)
+    of THAT kernel + common.h -- an edit elsewhere in csrc/ does not invalidate its figure; kernel None: all of csrc/."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, 'deepfluorolabeling-ipcai2020_amd', 'csrc')
-    for f in sorted(os.listdir(d)):
-        if f.endswith(('.hip', '.h', '.inc')):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), 'rb').read())
+    files = sorted(f for f in os.listdir(d) if f.endswith(('.hip', '.h', '.inc')))
+    if kernel is not None:
+        base = kernel.split('<')[0]
+        files = sorted(set(KERNEL_SOURCES.get(base, files) + ['common.h'])) if base in KERNEL_SOURCES else files
+    for f in files:
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), 'rb').read())
     return h.hexdigest()[:16]
 
 
@@ -57,7 +67,9 @@ CONVP_TILES = ['4,1,2,1', '4,1,1,1', '2,2,4,1', '2,2,3,1', '2,2,2,1', '1,4,2,1',
                '4,1,1,1', '4,1,2,1', '2,2,1,1', '2,2,2,1', '1,4,1,1', '1,4,2,1', '4,1,1,2', '2,2,1,2',   # (22 ...: the streamed 1x1 forms)
                '1,4,3,1,k2', '1,4,2,1,k2', '1,4,4,1,k2', '2,2,3,1,k2', '2,2,2,1,k2', '1,4,2,2,k2', '2,2,2,2,k2', '4,1,3,1,k2', '4,1,2,1,k2',   # (30 ...: two k-groups, 512 threads)
                'latency form',      # csrc/convp_bf16.hip kTiles: waves M x N, tiles M x N per wave
-               'q0', 'q1', 'q2']   # (40 ...: the unrolled 3x3 form, csrc/convq_bf16.hip: four waves / two k-groups / two row halves)
+               # (40 ...: the unrolled 3x3 form, csrc/convq_bf16.hip: row waves, column waves, k-groups; 49 ...: the same, persistent)
+               'q1,4,1', 'q1,4,2', 'q2,4,1', 'q2,2,1', 'q4,2,1', 'q2,2,2', 'q4,1,1', 'q8,1,1', 'q4,1,2',
+               'q1,4,1,p', 'q1,4,2,p', 'q2,4,1,p', 'q2,2,1,p', 'q4,2,1,p', 'q2,2,2,p', 'q4,1,1,p', 'q8,1,1,p', 'q4,1,2,p']
 WGRAD_KERNELS = ['wgrad_kernel<2,2,2,2,1>', 'wgrad_kernel<2,2,1,1,1>', 'wgrad_kernel<1,1,1,1,3>',
                  'wgrad_kernel<1,1,1,1,2>', 'wgrad_kernel<1,1,1,1,1>', 'direct_wgrad_kernel', 'wgrad_kernel<2,2,1,1,3>']
 
@@ -522,7 +534,7 @@ def main():
                 tj = json.load(open(tfile))
                 rec = tj['kernels'].get(name)
                 if rec:
-                    current = tj.get('csrc_sha16') == csrc_sha16()
+                    current = rec.get('src_sha16', tj.get('csrc_sha16')) == (csrc_sha16(name) if 'src_sha16' in rec else csrc_sha16())
                     roofline['traffic'] = rec['hbm_bytes_per_launch']
                     roofline['hbm_frac_traffic'] = round(rec['hbm_bytes_per_launch'] / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                     roofline['traffic_unit'] = 'HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB, rocprofv3 PMC passes of ' \

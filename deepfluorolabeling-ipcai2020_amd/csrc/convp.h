@@ -26,9 +26,11 @@ struct ConvP {
   int s_mt, s_nt, s_ksplit_shift, s_cpk_shift, s_ksteps, s_kper;
   // unrolled 3x3 form (convq_bf16.hip; tile >= CONVQ_TILE): ceil(2^32 / d) for d = npatch, ntiles, patches per image, npx
   uint32_t qm_npatch, qm_ntiles, qm_perimg, qm_npx;
+  int q_ngroups, pad2;          // persistent form: workgroups per (column tile, K slice); qm_npatch is then the magic of q_ngroups
 };
 constexpr int CONVS_TILE = 39;  // value of ConvP.tile for the latency form (= number of convp tile configurations)
-constexpr int CONVQ_TILE = 40;  // ... and for the unrolled 3x3 form of convq_bf16.hip: 40 ... 48 = its nine wave layouts (kQ there)
+constexpr int CONVQ_TILE = 40;  // ... and for the unrolled 3x3 form of convq_bf16.hip: 40 ... 48 = its nine wave layouts (kQ there), 49 ... 57 = the same, persistent
+constexpr int CONVQ_LAYOUTS = 9;
 
 // Chooses the geometry for these arguments.  force_splits: 0 = free choice, else the K-slice count to plan for.
 int convp_plan(const dfl_conv_args* a, ConvP* p, int force_splits);
@@ -40,8 +42,10 @@ int convp_tune_add(const int32_t* key, const int32_t* g);
 
 // Unrolled 3x3 form for the deep levels (convq_bf16.hip): 8 x 12 patches, 128 columns, 64 / 128 resident channels
 bool convq_shape_ok(const dfl_conv_args& a);
-int convq_launch(const ConvP& p, int mode, hipStream_t s);
-size_t convq_lds_bytes(int ck, int mode, int blk_per_slice);      // LDS a workgroup asks for
+int convq_launch(const ConvP& p, int mode, int pers, hipStream_t s);     // pers: the persistent form (a workgroup walks q_ngroups-strided patches)
+size_t convq_lds_bytes(int ck, int mode, int blk_per_slice, int pers);      // LDS a workgroup asks for
+int convq_threads(int mode);
+bool convq_pers_ok(int mode, int ck, int x_mode);                 // is the persistent form built for this layout / operand?
 bool convq_ck_ok(int mode, int ck);                               // is configuration `mode` instantiated for ck resident channels?
 
 // Latency form for the small problems of a batch-1 inference forward (convs_bf16.hip)

@@ -158,13 +158,26 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : (TM 
   //      resident block, [2][BN] for the epilogue's "+ BN(add)")
   float* in_tab = reinterpret_cast<float*>(smem + p.tab_off);
   float* add_tab = in_tab + 384;                      // (in_tab: [3][128] -- scale, shift, or the three backward coefficients)
-  if (a.add != nullptr && a.add_tot != nullptr) {
+  // The epilogue's per-column constants -- bias, scale and shift of "+ BN(add)" (given, or derived from the live totals) -- go into
+  // the table [3][BN] HERE, at kernel start (round 6).  They used to be fetched from global memory in front of the row loop, where the
+  // whole workgroup then waited one memory round trip for them: 1.4-2 us of every launch by the phase clocks of convq_bf16.hip,
+  // whose epilogue is this one -- exposed wherever a layer has one workgroup per CU.
+  {
     constexpr int BN0 = WN * TN * 32;
+    const bool scat0 = a.scatter2x2 != 0;
     for (int col = tid; col < BN0; col += NT) {
-      float sc_ = 1.f, sh_ = 0.f;
-      if (n0 + col < a.Ntot) bn_live_affine(a.add_tot, a.add_gamma, a.add_beta, a.add_count, a.bn_eps, a.Ntot, n0 + col, &sc_, &sh_);
+      const int n = n0 + col;
+      float sc_ = 1.f, sh_ = 0.f, b_ = 0.f;
+      if (n < a.Ntot) {
+        if (a.bias != nullptr) b_ = a.bias[scat0 ? n % p.Cout : n];
+        if (a.add != nullptr) {
+          if (a.add_scale != nullptr) sc_ = a.add_scale[n], sh_ = a.add_shift[n];
+          else if (a.add_tot != nullptr) bn_live_affine(a.add_tot, a.add_gamma, a.add_beta, a.add_count, a.bn_eps, a.Ntot, n, &sc_, &sh_);
+        }
+      }
       add_tab[col] = sc_;
       add_tab[BN0 + col] = sh_;
+      add_tab[2 * BN0 + col] = b_;
     }
   }
 
@@ -541,9 +554,7 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : (TM 
   // not take part in the fill can be through a short k loop (K = 64: four k-steps) before the filling wave has derived the live
   // scale / shift (16 fp64 loads + a square root per column) -- round 6 found a 1x1 layer's output changing from run to run once the
   // measured table gave it this form with 16 x 8 patches (docs/experiments/table_bisect.py).  The LDS-image form has its staging barriers.
-  if constexpr (GA) {
-    if (a.add != nullptr && a.add_tot != nullptr) __syncthreads();
-  }
+  if constexpr (GA) __syncthreads();
   constexpr int EP = BN + 4;                          // row pitch in floats (+4: rows 4 apart on different banks)
   constexpr int UPR = BN / 8;                         // 8-column units per row
   constexpr int RPS = (NT / UPR) < WM * 32 ? (NT / UPR) : WM * 32;   // rows per step of the workgroup's threads
@@ -563,17 +574,10 @@ __global__ void __launch_bounds__(256 * KS, (TM * TN >= 6 || KS == 2) ? 1 : (TM 
   const int cco = scat ? ncol - cab * p.Cout : ncol;
   float cbias[8], casc[8], cash[8], s1[8], s2[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    cbias[e] = (a.bias != nullptr && cok) ? a.bias[cco + e] : 0.f;
-    casc[e] = 1.f;
-    cash[e] = 0.f;
-    if (addp != nullptr && a.add_scale != nullptr && cok) {
-      casc[e] = a.add_scale[ncol + e];
-      cash[e] = a.add_shift[ncol + e];
-    } else if (addp != nullptr && a.add_tot != nullptr && cok) {      // (filled at kernel start; barriers passed since)
-      casc[e] = add_tab[ucol + e];
-      cash[e] = add_tab[BN + ucol + e];
-    }
+  for (int e = 0; e < 8; ++e) {                       // (from the table filled at kernel start; barriers passed since)
+    casc[e] = add_tab[ucol + e];
+    cash[e] = add_tab[BN + ucol + e];
+    cbias[e] = add_tab[2 * BN + ucol + e];
     s1[e] = 0.f;
     s2[e] = 0.f;
   }
@@ -791,8 +795,8 @@ __global__ void __launch_bounds__(256) convp_finish_kernel(const ConvP p, int TX
 
 // ---- host side ------------------------------------------------------------------------------------------------------
 
-struct TileCfg { int WM, WN, TM, TN, GA, KS, Q; };   // GA: A fragments straight from global memory (1x1 windows, see the kernel); KS: k-groups (1 or 2);
-                                                       // Q: the unrolled 3x3 form of convq_bf16.hip (8 x 12 patch, 128 columns)
+struct TileCfg { int WM, WN, TM, TN, GA, KS, Q, P; };   // GA: A fragments straight from global memory (1x1 windows, see the kernel); KS: k-groups (1 or 2);
+                                                       // Q: the unrolled 3x3 form of convq_bf16.hip (8 WM x 12 patch, 32 WN columns); P: its persistent form
 // value reported by dfl_conv_config for these kernels = 16 + index
 static const TileCfg kTiles[] = {{4, 1, 2, 1, 0, 1}, {4, 1, 1, 1, 0, 1}, {2, 2, 4, 1, 0, 1}, {2, 2, 3, 1, 0, 1}, {2, 2, 2, 1, 0, 1}, {1, 4, 2, 1, 0, 1},
                                  {1, 4, 3, 1, 0, 1}, {1, 4, 4, 1, 0, 1}, {1, 4, 6, 1, 0, 1}, {1, 4, 9, 1, 0, 1}, {2, 2, 1, 1, 0, 1}, {1, 4, 1, 1, 0, 1},
@@ -812,9 +816,12 @@ static const TileCfg kTiles[] = {{4, 1, 2, 1, 0, 1}, {4, 1, 1, 1, 0, 1}, {2, 2, 
                                  {1, 4, 3, 1, 0, 1, 1}, {1, 4, 3, 1, 0, 2, 1},
                                  // ... 42: eight waves on a 16 x 12 patch; 43-45: 64 columns; 46-48: 32 columns (WM x 8 patch rows)
                                  {2, 4, 3, 1, 0, 1, 1}, {2, 2, 3, 1, 0, 1, 1}, {4, 2, 3, 1, 0, 1, 1}, {2, 2, 3, 1, 0, 2, 1},
-                                 {4, 1, 3, 1, 0, 1, 1}, {8, 1, 3, 1, 0, 1, 1}, {4, 1, 3, 1, 0, 2, 1}};
+                                 {4, 1, 3, 1, 0, 1, 1}, {8, 1, 3, 1, 0, 1, 1}, {4, 1, 3, 1, 0, 2, 1},
+                                 // 49-57: the same nine layouts, persistent (a workgroup walks several patches, the next one staged ahead)
+                                 {1, 4, 3, 1, 0, 1, 1, 1}, {1, 4, 3, 1, 0, 2, 1, 1}, {2, 4, 3, 1, 0, 1, 1, 1}, {2, 2, 3, 1, 0, 1, 1, 1}, {4, 2, 3, 1, 0, 1, 1, 1},
+                                 {2, 2, 3, 1, 0, 2, 1, 1}, {4, 1, 3, 1, 0, 1, 1, 1}, {8, 1, 3, 1, 0, 1, 1, 1}, {4, 1, 3, 1, 0, 2, 1, 1}};
 constexpr int kNumTiles = (int)(sizeof(kTiles) / sizeof(kTiles[0]));
-static_assert(kNumTiles == CONVS_TILE + 10 && CONVQ_TILE == CONVS_TILE + 1, "convp.h: CONVS_TILE is the index behind the patch-kernel configurations, the unrolled 3x3 forms follow it");
+static_assert(kNumTiles == CONVS_TILE + 1 + 2 * CONVQ_LAYOUTS && CONVQ_TILE == CONVS_TILE + 1, "convp.h: CONVS_TILE is the index behind the patch-kernel configurations, the unrolled 3x3 forms follow it");
 constexpr size_t kLdsSoft = 64 * 1024, kLdsHard = 150 * 1024;
 
 // Row blocks of convp_finish_kernel = rows of stat_partials the following finalize kernel has to read.  Few (<= FIN_ROWS) and
@@ -872,10 +879,10 @@ static bool try_geometry(const dfl_conv_args& a, ConvP* p, const TileCfg& t, int
   int ck = 128;
   while (ck > 16 && (a.Cin % ck != 0 || (!t.Q && npix * (ck * 2 + 16) > (int64_t)kLdsSoft))) ck >>= 1;
   if (a.Cin % ck != 0) return false;
-  const int qmode = (int)(&t - kTiles) - CONVQ_TILE;                      // (the unrolled form: its wave layout)
+  const int qmode = ((int)(&t - kTiles) - CONVQ_TILE) % CONVQ_LAYOUTS;    // (the unrolled form: its wave layout)
   const int ck_min = t.Q ? 32 : 16;
   if (t.Q) {                                       // the largest resident block the layout is instantiated for and whose image fits
-    while (ck >= 32 && (a.Cin % ck != 0 || !convq_ck_ok(qmode, ck) || convq_lds_bytes(ck, qmode, a.Cin / ck > 1 ? 2 : 1) > 160 * 1024)) ck >>= 1;
+    while (ck >= 32 && (a.Cin % ck != 0 || !convq_ck_ok(qmode, ck) || convq_lds_bytes(ck, qmode, a.Cin / ck > 1 ? 2 : 1, t.P) > 160 * 1024)) ck >>= 1;
   }
   if (ck < ck_min) return false;
   size_t lds = (size_t)npix * (ck * 2 + 16);
@@ -922,9 +929,24 @@ static bool try_geometry(const dfl_conv_args& a, ConvP* p, const TileCfg& t, int
   }
   if (t.Q) {
     if (p->grid >= 65536 || p->npatch >= 65536) return false;      // (the kernel divides workgroup numbers by multiply-high)
-    if (convq_lds_bytes(ck, qmode, nblk / splits) > 160 * 1024) return false;
+    const size_t qlds = convq_lds_bytes(ck, qmode, nblk / splits, t.P);
+    if (qlds > 160 * 1024) return false;
+    if (t.P) {
+      if (!convq_pers_ok(qmode, ck, a.x_mode)) return false;
+      // persistent: as many workgroups per (column tile, K slice) as the CUs hold at once, patches dealt out evenly; pointless
+      // (and refused) when that leaves one patch per workgroup
+      int occ = convq_threads(qmode) == 512 ? 1 : 2;
+      if ((size_t)occ * qlds > 160 * 1024) occ = 1;
+      int g0 = 256 * occ / (ntiles * splits);
+      if (g0 < 1) g0 = 1;
+      if (g0 >= p->npatch) return false;
+      const int per = (int)ceil_div(p->npatch, g0);
+      p->q_ngroups = (int)ceil_div(p->npatch, per);
+      p->xcd_mode = 0;
+      p->grid = p->q_ngroups * ntiles * splits;
+    }
     auto magic = [](int d) { return (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d); };
-    p->qm_npatch = magic(p->npatch);
+    p->qm_npatch = magic(t.P ? p->q_ngroups : p->npatch);
     p->qm_ntiles = magic(ntiles);
     p->qm_perimg = magic(p->npy * p->npx);
     p->qm_npx = magic(p->npx);
@@ -1225,7 +1247,7 @@ static int convp_launch_t(const ConvP& p, hipStream_t s) {
   if (lds < red) lds = red;
   ConvP pl = p;                                       // the "live" BatchNorm tables sit behind everything else in LDS
   pl.tab_off = (int)((lds + 15) / 16 * 16);
-  if (p.a.in_tot != nullptr || p.a.add_tot != nullptr) lds = (size_t)pl.tab_off + (384 + 2 * BN_) * sizeof(float);
+  lds = (size_t)pl.tab_off + (384 + 3 * BN_) * sizeof(float);
   const ConvP& p_ = pl;
   if constexpr (GA) {
     static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(convp_kernel<WM, WN, TM, TN, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsHard);
@@ -1295,7 +1317,7 @@ int convp_launch(const ConvP& p, hipStream_t s) {
     case 38: rc = convp_launch_t<4, 1, 2, 1, false, 2>(p, s); break;
     default:
       DFL_REQUIRE(p.tile >= CONVQ_TILE && p.tile < kNumTiles, "dfl_conv2d (bf16): tile configuration %d", p.tile);
-      rc = convq_launch(p, p.tile - CONVQ_TILE, s);
+      rc = convq_launch(p, (p.tile - CONVQ_TILE) % CONVQ_LAYOUTS, (p.tile - CONVQ_TILE) / CONVQ_LAYOUTS, s);
       break;
   }
   if (rc != DFL_OK || p.splits <= 1) return rc;

@@ -41,20 +41,33 @@ __device__ __forceinline__ void q_unpack(const qu32x4 w, float* f) {
   f[4] = q_lo(w.z); f[5] = q_hi(w.z); f[6] = q_lo(w.w); f[7] = q_hi(w.w);
 }
 
-#ifndef DFL_CONVQ_ABL
-#define DFL_CONVQ_ABL 0
-#endif
 constexpr int QPW = 12, QIW = 14, QTM = 3;   // patch width, staged width, 32-row tiles per wave
 constexpr int q_row_pitch(int ck) {
   int r = QIW * (2 * ck + 16) / 16;
   while (r % 16 != 12) ++r;
   return r * 16;
 }
+// Distance of the two image buffers.  One patch per workgroup: the image (the epilogue starts at 0 and may run over both).  Persistent
+// forms: a buffer also has to hold the epilogue's pass image and the statistics scratch, because the other one holds the next patch.
+constexpr int q_buf_bytes(int ck, int wm, int wn, int ks, int pers) {
+  const int img = (8 * wm + 2) * q_row_pitch(ck);
+  if (pers == 0) return img;
+  const int nt = 64 * wm * wn * ks, bn = 32 * wn;
+  const int epi = ks * wm * 32 * (bn + 4) * 4, red = (nt / (bn / 8)) * 2 * bn * 4;
+  int b = img > epi ? img : epi;
+  b = b > red ? b : red;
+  return (b + 15) / 16 * 16;
+}
 
 // WM x WN x KS waves (4 or 8): WN waves side by side take 32 output columns each (the workgroup's column tile is 32 WN wide), WM
 // waves take 8 patch rows = 96 pixels each (the patch is 8 WM x 12 pixels; layers whose K is short want many pixels per workgroup:
 // a workgroup's life is mostly fill and drain there), KS k-groups split a block's 16-channel chunks.
-template <int CK, int WM, int WN, int KS, int AFF>
+// PERS: 0 = one patch per workgroup.  1, 2 = PERSISTENT: a workgroup walks patches pidx, pidx + q_ngroups, ... of its (column tile, K
+// slice); the next patch's first image is staged while the current patch computes -- 1: chunk by chunk between the k-steps of the
+// current patch's last block; 2 (patches of ONE channel block: K is short, the k loop shorter than a memory round trip): its loads are
+// requested before the PREVIOUS patch's epilogue and fly through that epilogue and the whole k loop of the current patch, so a CU
+// has a patch's worth of requests in flight all the time -- and the epilogue runs in the image the k loop has just finished with.
+template <int CK, int WM, int WN, int KS, int AFF, int PERS>
 __global__ void __launch_bounds__(64 * WM * WN * KS, 2) convq_kernel(const ConvP p) {
   constexpr int NT = 64 * WM * WN * KS;
   static_assert(NT == 256 || NT == 512, "four or eight waves");
@@ -63,11 +76,9 @@ __global__ void __launch_bounds__(64 * WM * WN * KS, 2) convq_kernel(const ConvP
   constexpr int S = 2 * CK + 16;             // bytes per staged pixel (odd multiple of 16: consecutive pixels on different banks)
   // Row pitch of the image: with pixel (y, x) at y * RPB + x * S a ds_read_b128 lane group -- 16 lanes = pixels q, q + 1, ... of the
   // row-major patch, which wrap into the next patch row -- touches bank quad (y * RPB / 16 + x) mod 16; RPB / 16 = 12 (mod 16) is the
-  // residue for which the four hardware lane groups of all three tile rows hit 16 different quads (searched exhaustively;
-  // QIW * S = 14 pixels had every group two-way conflicted: the k loop of two k-groups asks the LDS for half its peak)
+  // residue for which the four hardware lane groups of all three tile rows hit 16 different quads (searched exhaustively)
   constexpr int RPB = q_row_pitch(CK);
   static_assert(RPB >= QIW * S && (RPB / 16) % 16 == 12, "conflict-free row pitch");
-  constexpr int IMG = QIH * RPB;             // bytes per image
   constexpr int CKC = CK / 16, CCL = CKC / KS, STEPS = 9 * CCL;   // 16-channel chunks per block / per k-group; k-steps per block and k-group
   constexpr int GS = (STEPS % 12 == 0) ? 4 : 3;  // k-steps per weight-ring group
   constexpr int NG = STEPS / GS;
@@ -78,30 +89,37 @@ __global__ void __launch_bounds__(64 * WM * WN * KS, 2) convq_kernel(const ConvP
   constexpr int CHU = (U + 2) / 3;           // units per staging chunk (at most three chunks per block)
   constexpr int NCH = (U + CHU - 1) / CHU;
   static_assert(NT % UPX == 0, "a thread keeps its channel group");
+  // epilogue: EPP passes over the wave's three tile rows.  One pass where the image may spread over all of the workgroup's LDS
+  // (128-column forms, one patch per workgroup); three where it must stay small (narrow forms: three workgroups per CU) or inside
+  // ONE image buffer (persistent forms: the other buffer already holds the next patch)
+  constexpr int EPP = (WN == 4 && PERS == 0) ? 1 : 3;
+  constexpr int TPP = QTM / EPP;                    // tile rows per pass
+  constexpr int RW = 32 * TPP;                      // image rows per wave and pass
+  constexpr int RI = WM * RW;                       // image rows per k-group and pass
+  constexpr int UPR = QBN / 8;                      // 8-column units per row
+  constexpr int RPS = NT / UPR;                     // rows per step of the workgroup's threads
+  constexpr int BUF = q_buf_bytes(CK, WM, WN, KS, PERS);    // distance of the two images
+  constexpr int ROWS_UNROLL = PERS == 2 ? 1 : 8;            // (PERS 2 holds a whole image in registers across the epilogue's row loop)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const dfl_conv_args& a = p.a;
-#ifdef DFL_CONVQ_TRACE   // diagnosis build (docs/experiments/convq_trace.py): shader-clock stamps of wave 0 at the phase boundaries
-  long long tr_t[12];
-  tr_t[0] = __builtin_amdgcn_s_memtime();
-  tr_t[6] = __builtin_amdgcn_s_memrealtime();
-#define QTR(i) tr_t[i] = __builtin_amdgcn_s_memtime();
-#else
-#define QTR(i)
-#endif
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform (scalar registers): the k loop's addresses depend on them
   const int wn = wave % WN, wm = (wave / WN) % WM, kg = wave / (WN * WM);
 
-  // ---- which patch, column tile and K slice (convp_kernel's map: weight-heavy layers keep a (tile, slice) pair on one XCD)
-  // (divisions by multiply-high with the host's magic numbers: the grid stays below 65536 workgroups -- six run-time divisions
-  // stood in front of the first load otherwise)
+  // ---- which patch(es), column tile and K slice.  One patch per workgroup: convp_kernel's map (weight-heavy layers keep a (tile,
+  // slice) pair on one XCD).  Divisions by multiply-high with the host's magic numbers (the grid stays below 65536 workgroups).
   auto qdiv = [](int q, uint32_t m, int d) { return d == 1 ? q : (int)__umulhi((uint32_t)q, m); };
-  int bpatch, btile, bslice;
+  int pidx, btile, bslice;
   {
     const int b = blockIdx.x;
-    if (p.xcd_mode == 0) {
+    if (PERS != 0) {
+      const int r = qdiv(b, p.qm_npatch, p.q_ngroups);            // (qm_npatch: magic of q_ngroups here)
+      pidx = b - r * p.q_ngroups;
+      bslice = qdiv(r, p.qm_ntiles, p.ntiles);
+      btile = r - bslice * p.ntiles;
+    } else if (p.xcd_mode == 0) {
       const int r = qdiv(b, p.qm_npatch, p.npatch);
-      bpatch = b - r * p.npatch;
+      pidx = b - r * p.npatch;
       bslice = qdiv(r, p.qm_ntiles, p.ntiles);
       btile = r - bslice * p.ntiles;
     } else {
@@ -110,21 +128,25 @@ __global__ void __launch_bounds__(64 * WM * WN * KS, 2) convq_kernel(const ConvP
       if (p.xcd_mode == 1) {
         const int rq = qdiv(r, p.qm_npatch, p.npatch);
         s = x + 8 * rq;
-        bpatch = r - rq * p.npatch;
+        pidx = r - rq * p.npatch;
       } else {
         const int pairs = p.ntiles * p.splits;
         s = x % pairs;
-        bpatch = x / pairs + (8 / pairs) * r;
+        pidx = x / pairs + (8 / pairs) * r;
       }
-      if (s >= p.ntiles * p.splits || bpatch >= p.npatch) return;
+      if (s >= p.ntiles * p.splits || pidx >= p.npatch) return;
       bslice = qdiv(s, p.qm_ntiles, p.ntiles);
       btile = s - bslice * p.ntiles;
     }
   }
+  const int pstride = PERS != 0 ? p.q_ngroups : 0x40000000;
   const int per_img = p.npy * p.npx;
-  const int img = qdiv(bpatch, p.qm_perimg, per_img), pr = bpatch - img * per_img;
-  const int ppy = qdiv(pr, p.qm_npx, p.npx), ppx = pr - ppy * p.npx;
-  const int gy0 = ppy * QPH, gx0 = ppx * QPW;
+  struct Pos { int gy0, gx0, img; };
+  auto pos_of = [&](int pi) {
+    const int img = qdiv(pi, p.qm_perimg, per_img), pr = pi - img * per_img;
+    const int ppy = qdiv(pr, p.qm_npx, p.npx), ppx = pr - ppy * p.npx;
+    return Pos{ppy * QPH, ppx * QPW, img};
+  };
   const int n0 = btile * QBN;
   const int blk_begin = bslice * p.blk_per_slice;
   const int blk_end = min(blk_begin + p.blk_per_slice, p.nblk);
@@ -161,27 +183,26 @@ __global__ void __launch_bounds__(64 * WM * WN * KS, 2) convq_kernel(const ConvP
   // ---- staging: unit j of this thread = 16 bytes (8 channels, group cg) of staged pixel tid / UPX + j * (NT / UPX)
   const int cg = tid & (UPX - 1);
   const int pix0 = tid / UPX;
-  const uint32_t pimg = (uint32_t)img * (uint32_t)a.Hin;
   float* col_tab = reinterpret_cast<float*>(smem + p.tab_off);   // [3][QBN]: bias, scale and shift of "+ BN(add)" of the workgroup's columns
   float* in_tab = col_tab + 3 * QBN;                              // [3][CKS]: scale, shift (AFF 1) / A, B, C (AFF 2) of the slice's channels
   struct Unit { qu32x4 v, v2; };
   auto unit_pix = [&](int j) { return pix0 + j * (NT / UPX); };
-  auto unit_load = [&](int j, int c0, Unit* un) __attribute__((always_inline)) {
+  auto unit_load = [&](int j, const Pos& ps, int c0, bool live, Unit* un) __attribute__((always_inline)) {
     const int pix = unit_pix(j);
     const int iy = pix / QIW, ix = pix - iy * QIW;
-    const int gy = gy0 - 1 + iy, gx = gx0 - 1 + ix;
-    const bool ok = pix < QNPIX && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
-    const uint32_t pixel = (pimg + (uint32_t)gy) * (uint32_t)a.Win + (uint32_t)gx;
+    const int gy = ps.gy0 - 1 + iy, gx = ps.gx0 - 1 + ix;
+    const bool ok = live && pix < QNPIX && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
+    const uint32_t pixel = ((uint32_t)ps.img * (uint32_t)a.Hin + (uint32_t)gy) * (uint32_t)a.Win + (uint32_t)gx;
     const uint32_t cb = (uint32_t)((c0 + cg * 8) * 2);
     un->v = __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? pixel * (uint32_t)a.ldx * 2u + cb : QOOB, 0, 0);
     if constexpr (AFF == 2) un->v2 = __builtin_amdgcn_raw_buffer_load_b128(rsR, ok ? pixel * (uint32_t)a.ldx2 * 2u + cb : QOOB, 0, 0);
   };
   // (the decode is repeated here instead of carried in registers: a dozen integer instructions per unit against 6-10 live registers)
-  auto unit_store = [&](int j, int c0, int crel, uint32_t buf, const Unit& un) __attribute__((always_inline)) {
+  auto unit_store = [&](int j, const Pos& ps, int c0, int crel, uint32_t buf, const Unit& un) __attribute__((always_inline)) {
     const int pix = unit_pix(j);
     if (pix >= QNPIX) return;
     const int iy = pix / QIW, ix = pix - iy * QIW;
-    const int gy = gy0 - 1 + iy, gx = gx0 - 1 + ix;
+    const int gy = ps.gy0 - 1 + iy, gx = ps.gx0 - 1 + ix;
     const bool ok = (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
     qu32x4 w = un.v;
     if constexpr (AFF == 1) {                      // zero padding applies AFTER the BatchNorm affine: outside pixels stay 0
@@ -206,7 +227,7 @@ __global__ void __launch_bounds__(64 * WM * WN * KS, 2) convq_kernel(const ConvP
       w.w = q_pack(brb(q_lo(w.w), q_lo(r.w), A1.z, B1.z, C1.z), brb(q_hi(w.w), q_hi(r.w), A1.w, B1.w, C1.w));
       if (store_on) {                              // x_out: the interior of the patch, this slice's channels
         const bool own = ok && (unsigned)(iy - 1) < (unsigned)QPH && (unsigned)(ix - 1) < (unsigned)QPW;
-        const uint32_t pixel = (pimg + (uint32_t)gy) * (uint32_t)a.Win + (uint32_t)gx;
+        const uint32_t pixel = ((uint32_t)ps.img * (uint32_t)a.Hin + (uint32_t)gy) * (uint32_t)a.Win + (uint32_t)gx;
         __builtin_amdgcn_raw_buffer_store_b128(w, rsO, own ? pixel * (uint32_t)a.ldxo * 2u + (uint32_t)((c0 + cg * 8) * 2) : QOOB, 0, 0);
       }
     }
@@ -214,14 +235,15 @@ __global__ void __launch_bounds__(64 * WM * WN * KS, 2) convq_kernel(const ConvP
   };
 
   // ---- first image: its loads go out first, the tables are derived while they fly
+  Pos pos = pos_of(pidx);
   {
     constexpr int UG = AFF == 2 ? 6 : 10;         // units in flight per thread (registers: 4 or 8 per unit); larger images take several rounds
     constexpr int UG0 = U < UG ? U : UG;
     Unit un[UG0];
 #pragma unroll
-    for (int j = 0; j < UG0; ++j) unit_load(j, blk_begin * CK, &un[j]);
+    for (int j = 0; j < UG0; ++j) unit_load(j, pos, blk_begin * CK, true, &un[j]);
     // the epilogue's per-column constants: fetched here, behind the image loads, instead of in front of the row loop (where the
-    // whole workgroup waited 1.4-2 us for them: phase clocks, docs/experiments/convq_trace.py)
+    // whole workgroup waited 1.4-2 us for them: phase clocks of round 6)
     if (tid < QBN) {                                 // (QBN <= 128 < NT)
       const int col = n0 + tid;
       const bool ok = col < a.Ntot;
@@ -256,19 +278,26 @@ __global__ void __launch_bounds__(64 * WM * WN * KS, 2) convq_kernel(const ConvP
         in_tab[2 * CKS + c] = Cc;
       }
     }
-    QTR(1)
     if (AFF != 0) __syncthreads();
 #pragma unroll
-    for (int j = 0; j < UG0; ++j) unit_store(j, blk_begin * CK, 0, 0u, un[j]);
+    for (int j = 0; j < UG0; ++j) unit_store(j, pos, blk_begin * CK, 0, 0u, un[j]);
 #pragma unroll
     for (int j0 = UG0; j0 < U; j0 += UG0) {
 #pragma unroll
       for (int j = 0; j < UG0; ++j)
-        if (j0 + j < U) unit_load(j0 + j, blk_begin * CK, &un[j]);
+        if (j0 + j < U) unit_load(j0 + j, pos, blk_begin * CK, true, &un[j]);
 #pragma unroll
       for (int j = 0; j < UG0; ++j)
-        if (j0 + j < U) unit_store(j0 + j, blk_begin * CK, 0, 0u, un[j]);
+        if (j0 + j < U) unit_store(j0 + j, pos, blk_begin * CK, 0, 0u, un[j]);
     }
+  }
+  // PERS 2: the registers the next patch waits in (requested one patch ahead: here for the second patch)
+  Unit deep[PERS == 2 ? U : 1];
+  if constexpr (PERS == 2) {
+    const bool live = pidx + pstride < p.npatch;
+    const Pos pn = pos_of(live ? pidx + pstride : pidx);
+#pragma unroll
+    for (int j = 0; j < U; ++j) unit_load(j, pn, blk_begin * CK, live, &deep[j]);
   }
 
   // ---- LDS base of each tile row of this lane: pixel (py, px) of the patch at tap (0, 0), this lane's k half, this k-group's chunks
@@ -279,10 +308,6 @@ __global__ void __launch_bounds__(64 * WM * WN * KS, 2) convq_kernel(const ConvP
     a_addr[i] = (uint32_t)((py + wm * 8) * RPB + px * S + lh * 16 + kg * CCL * 32);
   }
   f32x16 acc[QTM];
-#pragma unroll
-  for (int i = 0; i < QTM; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   bf16x8_t afr[3][QTM];
   auto fetch_a = [&](const int s) __attribute__((always_inline)) {
     const int t = s / CCL, c = s % CCL;
@@ -290,78 +315,7 @@ __global__ void __launch_bounds__(64 * WM * WN * KS, 2) convq_kernel(const ConvP
 #pragma unroll
     for (int i = 0; i < QTM; ++i) afr[s % 3][i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const qu32x4*>(smem + a_addr[i] + off));
   };
-  __syncthreads();
-  QTR(2)
-  fetch_a(0);
-  fetch_a(1);
-
-  uint32_t cur = 0u;                                // byte offset of the image the k-steps read
-  for (int blk = blk_begin; blk < blk_end; ++blk) {
-    const bool has_next = blk + 1 < blk_end;
-    const uint32_t wb = wbase(blk), wbn = wbase(blk + 1);
-    const uint32_t nxt = IMG - cur;
-    const int c0n = (blk + 1) * CK, creln = (blk + 1 - blk_begin) * CK;
-    Unit un[CHU];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-#pragma unroll
-      for (int c = 0; c < CCL; ++c) {
-        const int s = t * CCL + c;
-#if DFL_CONVQ_ABL != 1                    // (ablation builds, timing only: 1 = no weight loads in the loop, 2 = no fragment reads)
-        if (s % GS == 0) {
-          const int g = s / GS + 2;
-          if (g < NG) load_group(g, wb, true);
-          else load_group(g - NG, wbn, has_next);
-        }
-#endif
-#if DFL_CONVQ_ABL != 2
-        if (s + 2 < STEPS) fetch_a(s + 2);
-#endif
-        const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, breg[(s / GS) % 3][s % GS]);
-#pragma unroll
-        for (int i = 0; i < QTM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[s % 3][i], bf, acc[i], 0, 0, 0);
-        // keep the software pipeline as written: left alone the scheduler sinks every fragment read to just in front of its matrix
-        // instruction (one register set, lgkmcnt(0) before each instruction)
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // the next block's image, chunk by chunk between the taps: chunk ch is requested behind tap 2 ch and written behind tap 2 ch + 2
-      if ((t & 1) == 0 && has_next) {
-        const int ch = t / 2;
-        if (ch >= 1 && ch - 1 < NCH) {
-#pragma unroll
-          for (int e = 0; e < CHU; ++e)
-            if ((ch - 1) * CHU + e < U) unit_store((ch - 1) * CHU + e, c0n, creln, nxt, un[e]);
-        }
-        if (ch < NCH) {
-#pragma unroll
-          for (int e = 0; e < CHU; ++e)
-            if (ch * CHU + e < U) unit_load(ch * CHU + e, c0n, &un[e]);
-        }
-      }
-    }
-    if (has_next) {
-      __syncthreads();                              // the next image is complete, this one is no longer read
-#pragma unroll
-      for (int i = 0; i < QTM; ++i) a_addr[i] += nxt - cur;     // (flips between the two images)
-      cur = nxt;
-      fetch_a(0);
-      fetch_a(1);
-    }
-  }
-
-  // ==================================================================== epilogue: both k-groups' tiles -> LDS, all threads run the rows
-  QTR(3)
-  __syncthreads();                                  // every wave is done with the images
-  QTR(8)
-  // EPP passes: the 128-column forms (one workgroup per CU, or two) drop all three tile rows at once; the narrow ones -- HBM-bound
-  // layers that want three workgroups per CU -- go tile row by tile row through an image a third of the size
-  constexpr int EPP = WN == 4 ? 1 : 3;
-  constexpr int TPP = QTM / EPP;                    // tile rows per pass
-  constexpr int RW = 32 * TPP;                      // image rows per wave and pass
-  constexpr int RI = WM * RW;                       // image rows per k-group and pass
-  float* ep = reinterpret_cast<float*>(smem);
-  constexpr int UPR = QBN / 8;                      // 8-column units per row
-  constexpr int RPS = NT / UPR;                     // rows per pass of the workgroup's threads
+  // epilogue constants of this thread
   const int ucol = (tid % UPR) * 8, urow = tid / UPR;
   const int ecol = n0 + ucol;
   const bool cok = ecol < a.Ntot;                   // (Ntot % 8 == 0: a unit is inside or outside as a whole)
@@ -370,118 +324,198 @@ __global__ void __launch_bounds__(64 * WM * WN * KS, 2) convq_kernel(const ConvP
   const unsigned short* addp = reinterpret_cast<const unsigned short*>(a.add);
   const unsigned short* sop = reinterpret_cast<const unsigned short*>(a.stat_other);
   unsigned short* yp = reinterpret_cast<unsigned short*>(a.y);
-  float cbias[8], casc[8], cash[8], s1[8], s2[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    cbias[e] = col_tab[ucol + e];
-    casc[e] = col_tab[QBN + ucol + e];
-    cash[e] = col_tab[2 * QBN + ucol + e];
-    s1[e] = 0.f;
-    s2[e] = 0.f;
-  }
-  QTR(10)
-#pragma unroll
-  for (int pass = 0; pass < EPP; ++pass) {
-  if (pass > 0) __syncthreads();                    // the previous pass's rows have been read
-#pragma unroll
-  for (int i = 0; i < TPP; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ep[(kg * RI + wm * RW + i * 32 + mfma32_row(r, lane)) * QEP + wn * 32 + li] = acc[pass * TPP + i][r];
-  QTR(9)
   __syncthreads();
-  QTR(4)
+
+  uint32_t cur = 0u;                                // byte offset of the image the k-steps read
+  for (;;) {
+    const int pnext = pidx + pstride;
+    const bool next_ok = PERS != 0 && pnext < p.npatch;
+    const Pos posn = pos_of(next_ok ? pnext : pidx);
 #pragma unroll
-  for (int rl = urow; rl < RI; rl += RPS) {
-    const int rw = rl / RW, q = rw * 96 + pass * RW + (rl - rw * RW);      // image row -> patch row
-    const int py = q / QPW, px = q - py * QPW;
-    const int gy = gy0 + py, gx = gx0 + px;
-    if (!(cok && gy < p.Hg && gx < p.Wg)) continue;
-    const uint32_t m = (uint32_t)((img * p.Hg + gy) * p.Wg + gx);
-    float v[8];
-    {
-      const float4 v0 = *reinterpret_cast<const float4*>(ep + rl * QEP + ucol);
-      const float4 v1 = *reinterpret_cast<const float4*>(ep + rl * QEP + ucol + 4);
-      v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+    for (int i = 0; i < QTM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    fetch_a(0);
+    fetch_a(1);
+    for (int blk = blk_begin; blk < blk_end; ++blk) {
+      const bool last = PERS == 2 ? true : blk + 1 == blk_end;        // (PERS 2: patches of one block, known at compile time)
+      const bool ring_next = !last || next_ok;                        // the ring's last two groups: the next block's / next patch's first ones
+      const bool has_next = PERS == 2 ? false : (!last || (PERS == 1 && next_ok));   // an image is staged between this block's k-steps
+      const uint32_t wb = wbase(blk), wbn = wbase(last ? blk_begin : blk + 1);
+      const uint32_t nxt = BUF - cur;
+      const Pos& psn = last ? posn : pos;
+      const int c0n = last ? blk_begin * CK : (blk + 1) * CK, creln = last ? 0 : (blk + 1 - blk_begin) * CK;
+      Unit un[CHU];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int c = 0; c < CCL; ++c) {
+          const int s = t * CCL + c;
+          if (s % GS == 0) {
+            const int g = s / GS + 2;
+            if (g < NG) load_group(g, wb, true);
+            else load_group(g - NG, wbn, ring_next);
+          }
+          if (s + 2 < STEPS) fetch_a(s + 2);
+          const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, breg[(s / GS) % 3][s % GS]);
+#pragma unroll
+          for (int i = 0; i < QTM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[s % 3][i], bf, acc[i], 0, 0, 0);
+          // keep the software pipeline as written: left alone the scheduler sinks every fragment read to just in front of its matrix
+          // instruction (one register set, lgkmcnt(0) before each instruction)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // the next image, chunk by chunk between the taps: chunk ch is requested behind tap 2 ch and written behind tap 2 ch + 2
+        if ((t & 1) == 0 && has_next) {
+          const int ch = t / 2;
+          if (ch >= 1 && ch - 1 < NCH) {
+#pragma unroll
+            for (int e = 0; e < CHU; ++e)
+              if ((ch - 1) * CHU + e < U) unit_store((ch - 1) * CHU + e, psn, c0n, creln, nxt, un[e]);
+          }
+          if (ch < NCH) {
+#pragma unroll
+            for (int e = 0; e < CHU; ++e)
+              if (ch * CHU + e < U) unit_load(ch * CHU + e, psn, c0n, true, &un[e]);
+          }
+        }
+      }
+      if (!last) {
+        __syncthreads();                            // the next image is complete, this one is no longer read
+#pragma unroll
+        for (int i = 0; i < QTM; ++i) a_addr[i] += nxt - cur;     // (flips between the two images)
+        cur = nxt;
+        fetch_a(0);
+        fetch_a(1);
+      }
     }
-    if constexpr (KS == 2) {
-      const float4 v0 = *reinterpret_cast<const float4*>(ep + (RI + rl) * QEP + ucol);
-      const float4 v1 = *reinterpret_cast<const float4*>(ep + (RI + rl) * QEP + ucol + 4);
-      v[0] += v0.x; v[1] += v0.y; v[2] += v0.z; v[3] += v0.w; v[4] += v1.x; v[5] += v1.y; v[6] += v1.z; v[7] += v1.w;
+    if constexpr (PERS == 2) {                      // the next patch's image: its loads have been flying since before the last epilogue
+      if (next_ok) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) unit_store(j, posn, blk_begin * CK, 0, BUF - cur, deep[j]);
+      }
+      const bool live = pnext + pstride < p.npatch;               // ... and the one after it goes out now
+      const Pos pn2 = pos_of(live ? pnext + pstride : pidx);
+#pragma unroll
+      for (int j = 0; j < U; ++j) unit_load(j, pn2, blk_begin * CK, live, &deep[j]);
     }
-    if (sliced) {                                   // K slices: raw fp32 sums, convp_finish_kernel does the rest
-      float* part = a.partial + ((int64_t)bslice * p.Mtot + m) * a.Ntot + ecol;
-      *reinterpret_cast<float4*>(part) = make_float4(v[0], v[1], v[2], v[3]);
-      *reinterpret_cast<float4*>(part + 4) = make_float4(v[4], v[5], v[6], v[7]);
-      continue;
-    }
+
+    // ================================================================== epilogue: the k-groups' tiles -> LDS, all threads run the rows
+    __syncthreads();                                // every wave is done with this patch's image (and has written its share of the next)
+    float* ep = reinterpret_cast<float*>(smem + (PERS != 0 ? cur : 0u));
+    float s1[8], s2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      v[e] += cbias[e];
-      if (a.relu) v[e] = fmaxf(v[e], 0.f);
+      s1[e] = 0.f;
+      s2[e] = 0.f;
     }
-    if (addp != nullptr) {
-      float o[8];
-      q_unpack(*reinterpret_cast<const qu32x4*>(addp + (m * (uint32_t)a.ldadd + (uint32_t)ecol)), o);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += fmaf(o[e], casc[e], cash[e]);
-    }
-    const uint32_t yo = m * (uint32_t)a.ldy + (uint32_t)ecol;
-    if (a.accumulate) {
-      float o[8];
-      q_unpack(*reinterpret_cast<const qu32x4*>(yp + yo), o);
+    for (int pass = 0; pass < EPP; ++pass) {
+      if (pass > 0) __syncthreads();                // the previous pass's rows have been read
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += o[e];
-    }
-    qu32x4 w;
-    w.x = q_pack(v[0], v[1]);
-    w.y = q_pack(v[2], v[3]);
-    w.z = q_pack(v[4], v[5]);
-    w.w = q_pack(v[6], v[7]);
-    *reinterpret_cast<qu32x4*>(yp + yo) = w;
-    if (do_stats) {
-      float vr[8], u[8];
-      q_unpack(w, vr);                              // statistics of the values as stored
-      if (sop != nullptr) {
-        q_unpack(*reinterpret_cast<const qu32x4*>(sop + (m * (uint32_t)a.ldso + (uint32_t)ecol)), u);
-      } else {
+      for (int i = 0; i < TPP; ++i)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) u[e] = vr[e];
+        for (int r = 0; r < 16; ++r) ep[(kg * RI + wm * RW + i * 32 + mfma32_row(r, lane)) * QEP + wn * 32 + li] = acc[pass * TPP + i][r];
+      __syncthreads();
+#pragma unroll ROWS_UNROLL
+      for (int rl = urow; rl < RI; rl += RPS) {
+        const int rw = rl / RW, q = rw * 96 + pass * RW + (rl - rw * RW);      // image row -> patch row
+        const int py = q / QPW, px = q - py * QPW;
+        const int gy = pos.gy0 + py, gx = pos.gx0 + px;
+        if (!(cok && gy < p.Hg && gx < p.Wg)) continue;
+        const uint32_t m = (uint32_t)((pos.img * p.Hg + gy) * p.Wg + gx);
+        float v[8];
+        {
+          const float4 v0 = *reinterpret_cast<const float4*>(ep + rl * QEP + ucol);
+          const float4 v1 = *reinterpret_cast<const float4*>(ep + rl * QEP + ucol + 4);
+          v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+        }
+        if constexpr (KS == 2) {
+          const float4 v0 = *reinterpret_cast<const float4*>(ep + (RI + rl) * QEP + ucol);
+          const float4 v1 = *reinterpret_cast<const float4*>(ep + (RI + rl) * QEP + ucol + 4);
+          v[0] += v0.x; v[1] += v0.y; v[2] += v0.z; v[3] += v0.w; v[4] += v1.x; v[5] += v1.y; v[6] += v1.z; v[7] += v1.w;
+        }
+        if (sliced) {                               // K slices: raw fp32 sums, convp_finish_kernel does the rest
+          float* part = a.partial + ((int64_t)bslice * p.Mtot + m) * a.Ntot + ecol;
+          *reinterpret_cast<float4*>(part) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(part + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          continue;
+        }
+        {                                           // (the per-column constants come from the LDS table row by row: 24 registers less to hold)
+          const float4 b0 = *reinterpret_cast<const float4*>(col_tab + ucol), b1 = *reinterpret_cast<const float4*>(col_tab + ucol + 4);
+          const float cb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            v[e] += cb[e];
+            if (a.relu) v[e] = fmaxf(v[e], 0.f);
+          }
+        }
+        if (addp != nullptr) {
+          float o[8];
+          q_unpack(*reinterpret_cast<const qu32x4*>(addp + (m * (uint32_t)a.ldadd + (uint32_t)ecol)), o);
+          const float4 c0 = *reinterpret_cast<const float4*>(col_tab + QBN + ucol), c1 = *reinterpret_cast<const float4*>(col_tab + QBN + ucol + 4);
+          const float4 h0 = *reinterpret_cast<const float4*>(col_tab + 2 * QBN + ucol), h1 = *reinterpret_cast<const float4*>(col_tab + 2 * QBN + ucol + 4);
+          const float sc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += fmaf(o[e], sc[e], sh[e]);
+        }
+        const uint32_t yo = m * (uint32_t)a.ldy + (uint32_t)ecol;
+        if (a.accumulate) {
+          float o[8];
+          q_unpack(*reinterpret_cast<const qu32x4*>(yp + yo), o);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += o[e];
+        }
+        qu32x4 w;
+        w.x = q_pack(v[0], v[1]);
+        w.y = q_pack(v[2], v[3]);
+        w.z = q_pack(v[4], v[5]);
+        w.w = q_pack(v[6], v[7]);
+        *reinterpret_cast<qu32x4*>(yp + yo) = w;
+        if (do_stats) {
+          float vr[8], u[8];
+          q_unpack(w, vr);                          // statistics of the values as stored
+          if (sop != nullptr) {
+            q_unpack(*reinterpret_cast<const qu32x4*>(sop + (m * (uint32_t)a.ldso + (uint32_t)ecol)), u);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) u[e] = vr[e];
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            s1[e] += vr[e];
+            s2[e] = fmaf(vr[e], u[e], s2[e]);
+          }
+        }
       }
+    }
+    if (do_stats) {
+      // per-column sums of this patch -> one row of stat_partials (rows = patches) or the layer's live totals; fixed order
+      __syncthreads();
+      float* red = ep;                              // [RPS][2][QBN]
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        s1[e] += vr[e];
-        s2[e] = fmaf(vr[e], u[e], s2[e]);
+        red[(urow * 2 + 0) * QBN + ucol + e] = s1[e];
+        red[(urow * 2 + 1) * QBN + ucol + e] = s2[e];
+      }
+      __syncthreads();
+      for (int idx = tid; idx < 2 * QBN; idx += NT) {
+        const int which = idx / QBN, col = idx - which * QBN;
+        const int n = n0 + col;
+        if (n < a.Ntot) {
+          float sum = 0.f;
+          for (int w = 0; w < RPS; ++w) sum += red[(w * 2 + which) * QBN + col];
+          if (a.stat_totals != nullptr) bn_live_add(a.stat_totals, pidx, which, a.Ntot, n, sum);
+          else a.stat_partials[((int64_t)pidx * 2 + which) * a.Ntot + n] = sum;
+        }
       }
     }
-  }
-  }
-#ifdef DFL_CONVQ_TRACE
-  if ((tid == 0 || tid == 256) && a.partial != nullptr && !sliced) {   // (wave 0 and, with eight waves, wave 4)
-    long long* sink = reinterpret_cast<long long*>(a.partial) + ((int64_t)(bpatch + p.npatch * btile) * 2 + (tid >> 8)) * 12;
-    sink[0] = tr_t[0]; sink[1] = tr_t[1]; sink[2] = tr_t[2]; sink[3] = tr_t[3]; sink[4] = tr_t[4]; sink[5] = __builtin_amdgcn_s_memtime();
-    sink[6] = tr_t[6]; sink[7] = __builtin_amdgcn_s_memrealtime();
-    sink[8] = tr_t[8]; sink[9] = tr_t[9]; sink[10] = tr_t[10];
-  }
-#endif
-  if (!do_stats) return;
-  // per-column sums of the workgroup -> one row of stat_partials (rows = patches) or the layer's live totals; fixed order
-  __syncthreads();
-  float* red = reinterpret_cast<float*>(smem);      // [RPS][2][QBN]
+    if (!next_ok) break;
+    __syncthreads();                                // the epilogue's image region goes back to the staging of the patch after the next
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    red[(urow * 2 + 0) * QBN + ucol + e] = s1[e];
-    red[(urow * 2 + 1) * QBN + ucol + e] = s2[e];
-  }
-  __syncthreads();
-  for (int idx = tid; idx < 2 * QBN; idx += NT) {
-    const int which = idx / QBN, col = idx - which * QBN;
-    const int n = n0 + col;
-    if (n < a.Ntot) {
-      float sum = 0.f;
-      for (int w = 0; w < RPS; ++w) sum += red[(w * 2 + which) * QBN + col];
-      if (a.stat_totals != nullptr) bn_live_add(a.stat_totals, bpatch, which, a.Ntot, n, sum);
-      else a.stat_partials[((int64_t)bpatch * 2 + which) * a.Ntot + n] = sum;
-    }
+    for (int i = 0; i < QTM; ++i) a_addr[i] += (BUF - cur) - cur;
+    cur = BUF - cur;
+    pidx = pnext;
+    pos = posn;
   }
 }
 
@@ -490,8 +524,9 @@ struct QCfg { int WM, WN, KS; };
 constexpr QCfg kQ[] = {{1, 4, 1}, {1, 4, 2}, {2, 4, 1}, {2, 2, 1}, {4, 2, 1}, {2, 2, 2}, {4, 1, 1}, {8, 1, 1}, {4, 1, 2}};
 constexpr int kNumQ = (int)(sizeof(kQ) / sizeof(kQ[0]));
 
-size_t q_tab_off(int ck, int mode, int blk_per_slice) {
+size_t q_tab_off(int ck, int mode, int blk_per_slice, int pers) {
   const QCfg c = kQ[mode];
+  if (pers != 0) return 2 * (size_t)q_buf_bytes(ck, c.WM, c.WN, c.KS, 1);
   const int NT = 64 * c.WM * c.WN * c.KS, BN = 32 * c.WN, EPP = c.WN == 4 ? 1 : 3;
   size_t lds = (size_t)(blk_per_slice > 1 ? 2 : 1) * (8 * c.WM + 2) * q_row_pitch(ck);
   const size_t epi = (size_t)c.KS * c.WM * (96 / EPP) * (BN + 4) * sizeof(float);
@@ -501,24 +536,29 @@ size_t q_tab_off(int ck, int mode, int blk_per_slice) {
   return (lds + 15) / 16 * 16;
 }
 
-template <int CK, int WM, int WN, int KS>
+// Persistent forms that would spill are not built: four waves staging 128-channel images of the two-tensor operand (x_mode)
+constexpr bool q_pers_ok(int ck, int nt, int x_mode, int pers) { return pers == 0 || !(ck == 128 && nt == 256 && x_mode != 0); }
+
+template <int CK, int WM, int WN, int KS, int PERS>
 int convq_launch_t(const ConvP& p, int mode, hipStream_t s) {
   constexpr int NT = 64 * WM * WN * KS;
   ConvP pl = p;
-  pl.tab_off = (int)q_tab_off(CK, mode, p.blk_per_slice);
-  const size_t lds = convq_lds_bytes(CK, mode, p.blk_per_slice);
+  pl.tab_off = (int)q_tab_off(CK, mode, p.blk_per_slice, PERS);
+  const size_t lds = convq_lds_bytes(CK, mode, p.blk_per_slice, PERS);
   DFL_REQUIRE(lds <= 160 * 1024, "dfl_conv2d (bf16, unrolled 3x3): %zu bytes of LDS", lds);
   const bool aff = p.a.in_scale != nullptr || p.a.in_tot != nullptr;
   dim3 grid((unsigned)p.grid);
 #define DFL_CQ_LAUNCH(AFF_)                                                                                                   \
   {                                                                                                                             \
-    auto k = convq_kernel<CK, WM, WN, KS, AFF_>;                                                                                \
+    auto k = convq_kernel<CK, WM, WN, KS, AFF_, PERS>;                                                                          \
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
     (void)attr;                                                                                                                 \
     hipLaunchKernelGGL(k, grid, dim3(NT), lds, s, pl);                                                                          \
   }
-  if (p.a.x_mode != 0) DFL_CQ_LAUNCH(2)
-  else if (aff) DFL_CQ_LAUNCH(1)
+  if (p.a.x_mode != 0) {
+    if constexpr (q_pers_ok(CK, NT, 1, PERS) && PERS != 2) DFL_CQ_LAUNCH(2)
+    else DFL_REQUIRE(false, "dfl_conv2d (bf16, unrolled 3x3): the persistent form of this layout does not take the two-tensor operand");
+  } else if (aff) DFL_CQ_LAUNCH(1)
   else DFL_CQ_LAUNCH(0)
 #undef DFL_CQ_LAUNCH
   return check_launch("dfl_conv2d (bf16, unrolled 3x3)");
@@ -530,14 +570,26 @@ constexpr bool q_inst(int ck, int wm, int wn, int ks) {
   return ((8 * wm + 2) * QIW * (ck / 8) + 64 * wm * wn * ks - 1) / (64 * wm * wn * ks) <= 10 && ck / 16 >= ks;
 }
 
+template <int CK, int WM, int WN, int KS>
+int convq_launch_p(const ConvP& p, int mode, int pers, hipStream_t s) {
+  if (pers == 0) return convq_launch_t<CK, WM, WN, KS, 0>(p, mode, s);
+  // persistent: patches of one channel block keep the next patch's loads in flight across the epilogue, longer ones stage it in their last block
+  // (128 resident channels are 72 k-steps: long enough for the chunked staging, and the whole image in registers would spill)
+  // ... as would the two-tensor operand's)
+  if constexpr (CK <= 64) {
+    if (p.blk_per_slice == 1 && p.a.x_mode == 0) return convq_launch_t<CK, WM, WN, KS, 2>(p, mode, s);
+  }
+  return convq_launch_t<CK, WM, WN, KS, 1>(p, mode, s);
+}
+
 template <int WM, int WN, int KS>
-int convq_launch_ck(const ConvP& p, int mode, hipStream_t s) {
+int convq_launch_ck(const ConvP& p, int mode, int pers, hipStream_t s) {
   if (p.CK == 128) {
-    if constexpr (q_inst(128, WM, WN, KS)) return convq_launch_t<128, WM, WN, KS>(p, mode, s);
+    if constexpr (q_inst(128, WM, WN, KS)) return convq_launch_p<128, WM, WN, KS>(p, mode, pers, s);
   } else if (p.CK == 64) {
-    if constexpr (q_inst(64, WM, WN, KS)) return convq_launch_t<64, WM, WN, KS>(p, mode, s);
+    if constexpr (q_inst(64, WM, WN, KS)) return convq_launch_p<64, WM, WN, KS>(p, mode, pers, s);
   } else if (p.CK == 32) {
-    if constexpr (q_inst(32, WM, WN, KS)) return convq_launch_t<32, WM, WN, KS>(p, mode, s);
+    if constexpr (q_inst(32, WM, WN, KS)) return convq_launch_p<32, WM, WN, KS>(p, mode, pers, s);
   }
   set_error("dfl_conv2d (bf16, unrolled 3x3): no instantiation for %d resident channels in configuration %d", p.CK, mode);
   return DFL_ERR_INVALID_ARG;
@@ -558,22 +610,26 @@ bool convq_ck_ok(int mode, int ck) {
   return q_inst(ck, c.WM, c.WN, c.KS);
 }
 
-size_t convq_lds_bytes(int ck, int mode, int blk_per_slice) {
-  return q_tab_off(ck, mode, blk_per_slice) + (size_t)(3 * 32 * kQ[mode].WN + 3 * blk_per_slice * ck) * sizeof(float);
+size_t convq_lds_bytes(int ck, int mode, int blk_per_slice, int pers) {
+  return q_tab_off(ck, mode, blk_per_slice, pers) + (size_t)(3 * 32 * kQ[mode].WN + 3 * blk_per_slice * ck) * sizeof(float);
 }
 
-int convq_launch(const ConvP& p, int mode, hipStream_t s) {
+bool convq_pers_ok(int mode, int ck, int x_mode) { return q_pers_ok(ck, convq_threads(mode), x_mode, 1); }
+
+int convq_threads(int mode) { return 64 * kQ[mode].WM * kQ[mode].WN * kQ[mode].KS; }
+
+int convq_launch(const ConvP& p, int mode, int pers, hipStream_t s) {
   DFL_REQUIRE(convq_ck_ok(mode, p.CK), "dfl_conv2d (bf16, unrolled 3x3): resident channel block %d, configuration %d", p.CK, mode);
   switch (mode) {
-    case 0: return convq_launch_ck<1, 4, 1>(p, mode, s);
-    case 1: return convq_launch_ck<1, 4, 2>(p, mode, s);
-    case 2: return convq_launch_ck<2, 4, 1>(p, mode, s);
-    case 3: return convq_launch_ck<2, 2, 1>(p, mode, s);
-    case 4: return convq_launch_ck<4, 2, 1>(p, mode, s);
-    case 5: return convq_launch_ck<2, 2, 2>(p, mode, s);
-    case 6: return convq_launch_ck<4, 1, 1>(p, mode, s);
-    case 7: return convq_launch_ck<8, 1, 1>(p, mode, s);
-    default: return convq_launch_ck<4, 1, 2>(p, mode, s);
+    case 0: return convq_launch_ck<1, 4, 1>(p, mode, pers, s);
+    case 1: return convq_launch_ck<1, 4, 2>(p, mode, pers, s);
+    case 2: return convq_launch_ck<2, 4, 1>(p, mode, pers, s);
+    case 3: return convq_launch_ck<2, 2, 1>(p, mode, pers, s);
+    case 4: return convq_launch_ck<4, 2, 1>(p, mode, pers, s);
+    case 5: return convq_launch_ck<2, 2, 2>(p, mode, pers, s);
+    case 6: return convq_launch_ck<4, 1, 1>(p, mode, pers, s);
+    case 7: return convq_launch_ck<8, 1, 1>(p, mode, pers, s);
+    default: return convq_launch_ck<4, 1, 2>(p, mode, pers, s);
   }
 }
 

@@ -713,9 +713,12 @@ class UNetPlan:
                         and (d < bd - 1 or (do_res and (patch_in(xin) or one_ch(xin)))))
                 # (round 5) fp32 tensors: the GEMM kernels take part as well -- producer: any of them (statistics tail, K-slice finish
                 # kernel); consumers: the fast gather of the next 3x3 (its scale / shift table in LDS) and the residual 1x1's "+ BN(r)"
-                gemm_in = lambda t: (not t.bf16) and t.C % 16 == 0
+                # (the consumer's table form needs the FAST gather, which needs tensors below 2 GiB -- a larger activation keeps
+                # the finalize launch and the generic kernel instead of failing in dfl_conv2d)
+                small = lambda t: t.N * t.H * t.W * t.ld * 4 < (1 << 31) - 4096
+                gemm_in = lambda t: (not t.bf16) and t.C % 16 == 0 and small(t)
                 if (self.LIVE_BN and bn and self.training and not self.bf16 and not circ and gemm_in(gin) and Cout % 16 == 0
-                        and (d < bd - 1 or do_res)):
+                        and gin.N * gin.H * gin.W * 2 * Cout * 4 < (1 << 31) - 4096 and (d < bd - 1 or do_res)):
                     live = True
                 tot = self._bn_totals(Cout) if live else None
                 live_bwd = (self.LIVE_BN and bn and self.training and self.bf16 and self.FUSE_BRB and self.FUSE_BWD_STATS and not circ

@@ -155,10 +155,13 @@ def _ptr_table(ptrs, dev):
     """Device table of tensor addresses.  A pageable host -> device copy blocks the host until everything queued before it is done --
     one host / GPU round trip per image of the ensemble loop (round 5: 1.78 -> 1.65 ms per 192x192 five-net image); the tables go up
     through pinned memory without blocking, and since the allocator hands the same few blocks round and round the tables are kept."""
-    key = (dev.index, tuple(ptrs))
+    # (keyed by the stream too -- ADVICE r05: the copy is ordered on the stream that was current when the table was made, a consumer
+    # on another stream could read it before it has landed; evicted tables are kept alive until the device is idle at the next wrap)
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, tuple(ptrs))
     t = _PTR_TABLES.get(key)
     if t is None:
         if len(_PTR_TABLES) >= 256:
+            torch.cuda.synchronize(dev)             # kernels queued on other streams may still read the tables about to go
             _PTR_TABLES.clear()
         t = torch.tensor(list(ptrs), dtype=torch.int64).pin_memory().to(dev, non_blocking=True)
         _PTR_TABLES[key] = t

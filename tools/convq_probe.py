@@ -103,7 +103,8 @@ def main():
         t_lib = time_geom(st, None)
         row = []
         best = t_lib
-        for tile, wm in ((40, 1), (41, 1), (42, 2), (43, 2), (44, 4), (45, 2), (46, 4), (47, 8), (48, 4)):
+        lay = ((40, 1), (41, 1), (42, 2), (43, 2), (44, 4), (45, 2), (46, 4), (47, 8), (48, 4))
+        for tile, wm in lay + tuple((t + 9, w) for t, w in lay):
             for sp in (1, 2, 4, 8):
                 t = time_geom(st, (tile, 1, 8 * wm, 12, sp))
                 if t is not None:

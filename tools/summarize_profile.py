@@ -26,8 +26,8 @@ def short(name):
     args = [a.strip() for a in m.group(2).split(',')]
     keep = {'conv_gemm_kernel': 4, 'conv_rows_kernel': 4, 'wgrad_kernel': 5, 'convp_kernel': 4, 'wgradp_kernel': 2}.get(m.group(1), len(args))
     tail = ',k2' if (m.group(1) == 'convp_kernel' and len(args) >= 7 and args[6] == '2') else ''     # two k-groups (512 threads)
-    if m.group(1) == 'convq_kernel':          # (anonymous namespace: the demangled name may carry it) -> the mode alone, as bench.py names it
-        return 'convq_kernel<%s>' % args[1]
+    if m.group(1) == 'convq_kernel':          # (anonymous namespace: the demangled name may carry it) -> the wave layout (+ ',p' persistent), as bench.py names it
+        return 'convq_kernel<%s%s>' % (','.join(args[1:4]), ',p' if len(args) > 5 and args[5] != '0' else '')     # <CK, WM, WN, KS, AFF, PERS>
     return '%s<%s%s>' % (m.group(1), ','.join(args[:keep]), tail)
 
 
@@ -67,7 +67,9 @@ def main():
             traffic[k] = {'fetch_kb_raw': round(fe, 1), 'write_kb_raw': round(wr, 1),
                           'hbm_bytes_per_launch': round((2 * fe + wr) * 1024)}
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    import bench as _bench                                 # (the hash bench.py compares with)
+    import bench as _bench                                 # (the hashes bench.py compares with: per kernel, its own source files)
+    for k, rec in traffic.items():
+        rec['src_sha16'] = _bench.csrc_sha16(k)
     json.dump({'note': 'bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024, averaged over the launches of each kernel in '
                        'bench.py --steps 6 --warmup 2; see tools/summarize_profile.py', 'round': tag.split('_')[0],
                'csrc_sha16': _bench.csrc_sha16(), 'kernels': traffic},

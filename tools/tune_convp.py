@@ -68,6 +68,8 @@ def main():
                 nat.check(lib.dfl_conv_force_geometry(C.addressof(g)), 'force')
                 a.splits = geom[4]
             try:
+                if lib.dfl_conv_config(C.addressof(a)) < 0:      # (a candidate of the group's first op may not exist for another operand form)
+                    return None
                 M = a.N * (a.Hin * a.Win if a.scatter2x2 else a.Hout * a.Wout)
                 if a.splits > 1:
                     if a.splits * M * a.Ntot > scratch.numel():
