@@ -191,25 +191,7 @@ __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const
   // BatchNorm affine of the gathered tensor (applied when a unit is written to LDS): this thread's 8 channels, kept in LDS
   // behind the offset table -- 16 registers that the 3x3 kernel does not have
   float* aff = reinterpret_cast<float*>(smem + p.tab_off + p.P16 * 4);      // [2][CGT]
-  if constexpr (AFF) {
-    for (int c = tid; c < p.CGT; c += NT) {
-      aff[c] = (cg0 + c < a.Cg) ? a.in_scale[cg0 + c] : 1.f;
-      aff[p.CGT + c] = (cg0 + c < a.Cg) ? a.in_shift[cg0 + c] : 0.f;
-    }
-  }
   float* dco = aff + 2 * p.CGT;                                             // [3][CMT]: A, B, C of this tile's d channels
-  if constexpr (DBRB) {
-    for (int c = tid; c < p.CMT; c += NT) {
-      const bool live = a.coef != nullptr && cm0 + c < a.Cm;
-      float A = live ? a.coef[cm0 + c] : 1.f, B = live ? a.coef[a.Cm + cm0 + c] : 0.f, Cc = live ? a.coef[2 * a.Cm + cm0 + c] : 0.f;
-      if (a.coef_tot != nullptr && cm0 + c < a.Cm)      // live statistics (include/dfl_hip.h): derived here
-        bn_live_coef(a.coef_tot, a.bn_gamma, a.bn_mean, a.bn_invstd, a.bn_count, a.Cm, cm0 + c, &A, &B, &Cc);
-      dco[c] = A;
-      dco[p.CMT + c] = B;
-      dco[2 * p.CMT + c] = Cc;
-    }
-  }
-  if constexpr (AFF || DBRB) __syncthreads();             // the first commit() reads these tables
   // issue: the loads of one patch, unit by unit -- issue_setup fixes the patch, issue_d(u) / issue_g(u) request one 16-byte unit each
   int is_nleft = 0, is_oy0 = 0, is_ox0 = 0, is_ybase = 0, is_xbase = 0;
   uint32_t is_dbase = 0, is_dbase2 = 0, is_gbase = 0;
@@ -317,6 +299,26 @@ __global__ void __launch_bounds__(256 * KH, KH == 2 ? 4 : 3) wgradp_kernel(const
 #define WT0(name)
 #endif
   issue(pbegin, pbegin < pend);
+  // (round 6: the first patch's loads go out BEFORE the tables are derived -- with live statistics a column's coefficients are 16 fp64
+  // loads and a square root: a memory round trip that used to stand in front of the first request of every launch)
+  if constexpr (AFF) {
+    for (int c = tid; c < p.CGT; c += NT) {
+      aff[c] = (cg0 + c < a.Cg) ? a.in_scale[cg0 + c] : 1.f;
+      aff[p.CGT + c] = (cg0 + c < a.Cg) ? a.in_shift[cg0 + c] : 0.f;
+    }
+  }
+  if constexpr (DBRB) {
+    for (int c = tid; c < p.CMT; c += NT) {
+      const bool live = a.coef != nullptr && cm0 + c < a.Cm;
+      float A = live ? a.coef[cm0 + c] : 1.f, B = live ? a.coef[a.Cm + cm0 + c] : 0.f, Cc = live ? a.coef[2 * a.Cm + cm0 + c] : 0.f;
+      if (a.coef_tot != nullptr && cm0 + c < a.Cm)      // live statistics (include/dfl_hip.h): derived here
+        bn_live_coef(a.coef_tot, a.bn_gamma, a.bn_mean, a.bn_invstd, a.bn_count, a.Cm, cm0 + c, &A, &B, &Cc);
+      dco[c] = A;
+      dco[p.CMT + c] = B;
+      dco[2 * p.CMT + c] = Cc;
+    }
+  }
+  if constexpr (AFF || DBRB) __syncthreads();             // the first commit() reads these tables
   for (int patch = pbegin; patch < pend; ++patch) {
     WT0(tb0)
     if (patch != pbegin) __syncthreads();               // every wave is done reading the previous images

@@ -1,7 +1,6 @@
 """The paper preset's training step against the fp64 oracle at the batch sizes BASELINE names (shared by
-test_gpu_00a_paper_batch16.py and test_gpu_00b_paper_batch5.py; split out of test_gpu_00_northstar.py in round 6 so that pytest-xdist
--- pytest.ini: file-parallel -- runs the two oracle passes side by side; the fp64 oracle of one batch size is computed once per file
-and shared by its arithmetic modes through tests/noise_floor.py's cache)."""
+test_gpu_00a_paper_batch16.py and test_gpu_00b_paper_batch5.py, split out of test_gpu_00_northstar.py in round 6: one oracle pass per
+file; the fp64 oracle of one batch size is computed once and shared by its arithmetic modes through tests/noise_floor.py's cache)."""
 import os
 
 import torch

@@ -1,7 +1,7 @@
 """North-star parity tests -- collected FIRST (file name) so that a time limit or an unrelated failure further down cannot
 hide them: the paper presets against the reference's own fixtures and the fp64 oracle, BASELINE configs[1]'s
 batch-16 step in every arithmetic mode bench.py quotes (fp32, bf16x3 and the bf16 STORAGE mode it times; files
-test_gpu_00a_paper_batch16.py / test_gpu_00b_paper_batch5.py: the suite runs file-parallel, pytest.ini), the 30-step
+test_gpu_00a_paper_batch16.py / test_gpu_00b_paper_batch5.py), the 30-step
 trajectory against the reference's run, the ensemble loop and the validation loops against the reference's outputs, and
 hard Dice at a training plateau within +-0.005 of the reference (north_star's bar).  pytest -m gpu.
 

@@ -119,11 +119,9 @@ def test_candidates_list_the_unrolled_form_where_it_applies():
 
 
 @pytest.mark.parametrize('tile', TILES)
-@pytest.mark.parametrize('case', [(2, 64, 128, 17, 11), (1, 128, 256, 24, 24), (2, 256, 192, 20, 30), (3, 128, 136, 6, 6),
-                                  (1, 512, 128, 45, 45), (16, 64, 128, 48, 48),
-                                  (2, 32, 32, 40, 25), (2, 64, 32, 33, 12), (2, 32, 64, 17, 30), (1, 128, 64, 50, 24), (2, 64, 64, 96, 96), (1, 96, 40, 20, 20),
+@pytest.mark.parametrize('case', [(2, 64, 128, 17, 11), (2, 256, 192, 20, 30), (3, 128, 136, 6, 6), (2, 32, 32, 40, 25), (2, 64, 32, 33, 12), (1, 128, 64, 50, 24),
                                   # enough patches for the persistent forms: odd counts per workgroup, one and several channel blocks, K slices
-                                  (9, 32, 32, 190, 180), (5, 64, 64, 200, 170), (3, 128, 128, 250, 260), (2, 256, 128, 330, 300), (7, 64, 32, 150, 200)])
+                                  (9, 32, 32, 190, 180), (3, 64, 64, 200, 170), (2, 128, 128, 200, 210), (1, 256, 128, 250, 300)])
 def test_convq_plain_and_statistics(case, tile):
     N, Cin, Cout, H, W = case
     if not _valid(N, Cin, Cout, H, W, tile, 1):
@@ -141,8 +139,8 @@ def test_convq_plain_and_statistics(case, tile):
 
 
 @pytest.mark.parametrize('tile', TILES)
-@pytest.mark.parametrize('case', [(2, 64, 128, 12, 12), (2, 256, 256, 13, 9), (1, 512, 128, 24, 24), (2, 32, 32, 30, 14), (2, 128, 64, 20, 20), (1, 64, 32, 40, 13),
-                                  (9, 32, 32, 190, 180), (4, 64, 64, 200, 170), (3, 128, 128, 250, 260), (2, 256, 128, 330, 300)])
+@pytest.mark.parametrize('case', [(2, 256, 256, 13, 9), (1, 512, 128, 24, 24), (2, 32, 32, 30, 14), (2, 128, 64, 20, 20),
+                                  (9, 32, 32, 190, 180), (2, 128, 128, 200, 210)])
 def test_convq_affine_residual_epilogue(case, tile):
     """BatchNorm affine on load with zero padding AFTER it, '+ BN(other)', accumulate, statistics against a partner tensor (the
     forward block epilogue, unet.py:229-231, and the fused backward sums), one launch and through K slices."""
@@ -166,9 +164,8 @@ def test_convq_affine_residual_epilogue(case, tile):
 
 
 @pytest.mark.parametrize('tile', TILES)
-@pytest.mark.parametrize('with_bn', [True, False])
-@pytest.mark.parametrize('case', [(2, 64, 128, 12, 12), (2, 256, 128, 17, 13), (1, 128, 256, 24, 24), (2, 32, 32, 30, 14), (2, 32, 64, 20, 20), (1, 64, 32, 40, 13),
-                                  (9, 32, 32, 190, 180), (4, 64, 64, 200, 170), (2, 256, 128, 330, 300)])
+@pytest.mark.parametrize('with_bn', [True])
+@pytest.mark.parametrize('case', [(2, 256, 128, 17, 13), (2, 32, 64, 20, 20), (1, 64, 32, 40, 13), (3, 64, 64, 200, 170), (1, 256, 128, 250, 300)])
 def test_convq_fused_bn_relu_backward_operand(case, with_bn, tile):
     """dfl_conv_args.x_mode: the data gradient forms [r > 0] * (A dy + B r + C) from (dy, r) while it stages its patches; x_out is
     that operand, every element exactly once, bit for bit (K slices each write their own channels)."""

@@ -1,6 +1,5 @@
 """BASELINE configs[3] and configs[4] at their full image sizes, against the oracle run on the GPU box's host cores
-(configs[4]: tests/test_gpu_fullsize_ensemble.py, a file of its own so that the file-parallel suite -- pytest.ini -- runs the two
-oracle passes side by side)
+(configs[4]: tests/test_gpu_fullsize_ensemble.py, against the oracle's committed outputs)
 (the oracle is pinned to the reference by tests/test_oracle_golden.py; a 768x768 training step is ~2 TFLOP and a
 1440x1440 forward ~1 TFLOP on the CPU -- seconds).  The oracle comparison of configs[3] runs at batch 2 (kernels, tile
 configurations, 32-bit offsets and split decisions depend on the image size); configs[3] AT ITS BATCH 8 is checked through
