@@ -36,7 +36,7 @@ MATH = {'fp32': (0, 0), 'bf16x3': (1, 3), 'bf16x6': (2, 6), 'bf16': (3, 1), 'bf1
 TRAFFIC_FILES = ['r06_traffic.json', 'r05_traffic.json', 'r04_traffic.json']   # per-kernel HBM bytes from committed rocprofv3 --pmc passes, newest first
 
 
-KERNEL_SOURCES = {'wgradp_kernel': ['wgradp_bf16.hip'], 'convp_kernel': ['convp_bf16.hip', 'convp.h'], 'convq_kernel': ['convq_bf16.hip', 'convp.h'],
+KERNEL_SOURCES = {'wgradp_kernel': ['wgradp_bf16.hip'], 'convp_kernel': ['convp_bf16.hip', 'convp.h'], 'convq_kernel': ['convq_bf16.hip', 'convp.h'], 'convn_kernel': ['convn_bf16.hip', 'convp.h'],
                   'convp_finish_kernel': ['convp_bf16.hip', 'convp.h'], 'conv_gemm_kernel': ['conv_gemm.hip', 'conv_epilogue.h'],
                   'conv_rows_kernel': ['conv_rows.hip', 'conv_rows.h', 'conv_epilogue.h'], 'wgrad_kernel': ['wgrad_gemm.hip'],
                   'reduce_batch_kernel': ['bn_elem.hip'], 'sgd_pack_tiles_kernel': ['bn_elem.hip']}
@@ -69,7 +69,9 @@ CONVP_TILES = ['4,1,2,1', '4,1,1,1', '2,2,4,1', '2,2,3,1', '2,2,2,1', '1,4,2,1',
                'latency form',      # csrc/convp_bf16.hip kTiles: waves M x N, tiles M x N per wave
                # (40 ...: the unrolled 3x3 form, csrc/convq_bf16.hip: row waves, column waves, k-groups; 49 ...: the same, persistent)
                'q1,4,1', 'q1,4,2', 'q2,4,1', 'q2,2,1', 'q4,2,1', 'q2,2,2', 'q4,1,1', 'q8,1,1', 'q4,1,2',
-               'q1,4,1,p', 'q1,4,2,p', 'q2,4,1,p', 'q2,2,1,p', 'q4,2,1,p', 'q2,2,2,p', 'q4,1,1,p', 'q8,1,1,p', 'q4,1,2,p']
+               'q1,4,1,p', 'q1,4,2,p', 'q2,4,1,p', 'q2,2,1,p', 'q4,2,1,p', 'q2,2,2,p', 'q4,1,1,p', 'q8,1,1,p', 'q4,1,2,p',
+               # (58 ...: the narrow 3x3 form, csrc/convn_bf16.hip: waves side by side, rows per wave; named convn_kernel<column tiles, ...>)
+               'n2,4', 'n2,6', 'n1,4', 'n1,6', 'n2,3', 'n1,3']
 WGRAD_KERNELS = ['wgrad_kernel<2,2,2,2,1>', 'wgrad_kernel<2,2,1,1,1>', 'wgrad_kernel<1,1,1,1,3>',
                  'wgrad_kernel<1,1,1,1,2>', 'wgrad_kernel<1,1,1,1,1>', 'direct_wgrad_kernel', 'wgrad_kernel<2,2,1,1,3>']
 
@@ -91,7 +93,8 @@ def op_profile(plan, lib, nat, stream, detail=None):
         for st, t in zip(prog.structs, ms):
             if isinstance(st, nat.ConvArgs):
                 cfg = lib.dfl_conv_config(C.addressof(st))
-                name = CONV_KERNELS[cfg] if cfg < 16 else ('convq_kernel<%s>' % CONVP_TILES[cfg - 16][1:] if cfg >= 56 else 'convp_kernel<%s>' % CONVP_TILES[cfg - 16])
+                name = CONV_KERNELS[cfg] if cfg < 16 else ('convn_kernel<%d,%s>' % (st.Ntot // 32, CONVP_TILES[cfg - 16][1:]) if cfg >= 74 else
+                                                           'convq_kernel<%s>' % CONVP_TILES[cfg - 16][1:] if cfg >= 56 else 'convp_kernel<%s>' % CONVP_TILES[cfg - 16])
                 if st.scatter2x2:
                     M = st.N * st.Hin * st.Win
                 else:

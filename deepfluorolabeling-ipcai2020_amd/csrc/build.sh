@@ -4,7 +4,7 @@ set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 out="$here/../lib"
 mkdir -p "$out"
-srcs=(api.hip conv_gemm.hip conv_rows.hip convp_bf16.hip convq_bf16.hip convs_bf16.hip convs_f32.hip wgradp_bf16.hip wgrad_gemm.hip direct_small.hip bn_elem.hip head.hip loss.hip prep.hip upsample.hip)
+srcs=(api.hip conv_gemm.hip conv_rows.hip convp_bf16.hip convq_bf16.hip convn_bf16.hip convs_bf16.hip convs_f32.hip wgradp_bf16.hip wgrad_gemm.hip direct_small.hip bn_elem.hip head.hip loss.hip prep.hip upsample.hip)
 objs=()
 pids=()
 for s in "${srcs[@]}"; do
@@ -15,7 +15,7 @@ for s in "${srcs[@]}"; do
     # register pressure (same instructions, same results; measured 4.47 -> 4.45 ms per step), and so are the streaming kernels of
     # bn_elem.hip (the batched sums issue their loads earlier: 0.23 -> 0.21 ms per step)
     extra=""
-    case "$s" in convp_bf16.hip|convq_bf16.hip|convs_bf16.hip|convs_f32.hip|wgradp_bf16.hip|bn_elem.hip) extra="-mllvm -amdgpu-sched-strategy=max-ilp";; esac
+    case "$s" in convp_bf16.hip|convq_bf16.hip|convn_bf16.hip|convs_bf16.hip|convs_f32.hip|wgradp_bf16.hip|bn_elem.hip) extra="-mllvm -amdgpu-sched-strategy=max-ilp";; esac
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $extra "$@" -c "$here/$s" -o "$o" &
     pids+=($!)
   fi

@@ -795,8 +795,9 @@ __global__ void __launch_bounds__(256) convp_finish_kernel(const ConvP p, int TX
 
 // ---- host side ------------------------------------------------------------------------------------------------------
 
-struct TileCfg { int WM, WN, TM, TN, GA, KS, Q, P; };   // GA: A fragments straight from global memory (1x1 windows, see the kernel); KS: k-groups (1 or 2);
-                                                       // Q: the unrolled 3x3 form of convq_bf16.hip (8 WM x 12 patch, 32 WN columns); P: its persistent form
+struct TileCfg { int WM, WN, TM, TN, GA, KS, Q, P, NL; };   // GA: A fragments straight from global memory (1x1 windows, see the kernel); KS: k-groups (1 or 2);
+                                                       // Q: the unrolled 3x3 form of convq_bf16.hip (8 WM x 12 patch, 32 WN columns); P: its persistent form;
+                                                       // NL: layout + 1 of the narrow 3x3 form of convn_bf16.hip
 // value reported by dfl_conv_config for these kernels = 16 + index
 static const TileCfg kTiles[] = {{4, 1, 2, 1, 0, 1}, {4, 1, 1, 1, 0, 1}, {2, 2, 4, 1, 0, 1}, {2, 2, 3, 1, 0, 1}, {2, 2, 2, 1, 0, 1}, {1, 4, 2, 1, 0, 1},
                                  {1, 4, 3, 1, 0, 1}, {1, 4, 4, 1, 0, 1}, {1, 4, 6, 1, 0, 1}, {1, 4, 9, 1, 0, 1}, {2, 2, 1, 1, 0, 1}, {1, 4, 1, 1, 0, 1},
@@ -819,9 +820,12 @@ static const TileCfg kTiles[] = {{4, 1, 2, 1, 0, 1}, {4, 1, 1, 1, 0, 1}, {2, 2, 
                                  {4, 1, 3, 1, 0, 1, 1}, {8, 1, 3, 1, 0, 1, 1}, {4, 1, 3, 1, 0, 2, 1},
                                  // 49-57: the same nine layouts, persistent (a workgroup walks several patches, the next one staged ahead)
                                  {1, 4, 3, 1, 0, 1, 1, 1}, {1, 4, 3, 1, 0, 2, 1, 1}, {2, 4, 3, 1, 0, 1, 1, 1}, {2, 2, 3, 1, 0, 1, 1, 1}, {4, 2, 3, 1, 0, 1, 1, 1},
-                                 {2, 2, 3, 1, 0, 2, 1, 1}, {4, 1, 3, 1, 0, 1, 1, 1}, {8, 1, 3, 1, 0, 1, 1, 1}, {4, 1, 3, 1, 0, 2, 1, 1}};
+                                 {2, 2, 3, 1, 0, 2, 1, 1}, {4, 1, 3, 1, 0, 1, 1, 1}, {8, 1, 3, 1, 0, 1, 1, 1}, {4, 1, 3, 1, 0, 2, 1, 1},
+                                 // 58-63: the narrow 3x3 form (convn_bf16.hip: 32 / 64 output columns, its six layouts); table only
+                                 {4, 1, 1, 1, 0, 1, 0, 0, 1}, {4, 1, 1, 1, 0, 1, 0, 0, 2}, {4, 1, 1, 1, 0, 1, 0, 0, 3}, {4, 1, 1, 1, 0, 1, 0, 0, 4},
+                                 {4, 1, 1, 1, 0, 1, 0, 0, 5}, {4, 1, 1, 1, 0, 1, 0, 0, 6}};
 constexpr int kNumTiles = (int)(sizeof(kTiles) / sizeof(kTiles[0]));
-static_assert(kNumTiles == CONVS_TILE + 1 + 2 * CONVQ_LAYOUTS && CONVQ_TILE == CONVS_TILE + 1, "convp.h: CONVS_TILE is the index behind the patch-kernel configurations, the unrolled 3x3 forms follow it");
+static_assert(kNumTiles == CONVN_TILE + CONVN_LAYOUTS && CONVN_TILE == CONVQ_TILE + 2 * CONVQ_LAYOUTS && CONVQ_TILE == CONVS_TILE + 1, "convp.h: CONVS_TILE is the index behind the patch-kernel configurations, the unrolled 3x3 forms follow it");
 constexpr size_t kLdsSoft = 64 * 1024, kLdsHard = 150 * 1024;
 
 // Row blocks of convp_finish_kernel = rows of stat_partials the following finalize kernel has to read.  Few (<= FIN_ROWS) and
@@ -844,6 +848,43 @@ static bool try_geometry(const dfl_conv_args& a, ConvP* p, const TileCfg& t, int
                          double* cost) {
   const int QP = t.WM * t.TM * 32;
   if (t.WM == 0) return false;
+  if (t.NL) {
+    // narrow 3x3 form: the layout fixes the patch, all input channels pass through one image in blocks of 32, no K slices, one
+    // column tile; workgroups are dealt to the XCDs in runs of q_ngroups patches.  Scored only by measurement.
+    int nph, npw;
+    convn_patch(t.NL - 1, &nph, &npw);
+    if (ipp != 1 || ph != nph || pw != npw || want_splits > 1 || !convn_shape_ok(a) || !convn_layout_ok(t.NL - 1, a.Ntot, a.Cin)) return false;
+    p->IPP = 1;
+    p->PH = ph;
+    p->PW = pw;
+    p->mPP = (uint32_t)(((1ull << 32) + (uint64_t)(ph * pw) - 1) / (uint64_t)(ph * pw));
+    p->mPW = (uint32_t)(((1ull << 32) + (uint64_t)pw - 1) / (uint64_t)pw);
+    p->npy = (int)ceil_div(p->Hg, ph);
+    p->npx = (int)ceil_div(p->Wg, pw);
+    p->npatch = a.N * p->npy * p->npx;
+    if (p->npatch >= 65536) return false;              // (the kernel divides patch numbers by multiply-high)
+    p->IH = ph + 2;
+    p->IW = pw + 2;
+    p->CK = 32;
+    p->nblk = a.Cin / 32;
+    p->splits = 1;
+    p->blk_per_slice = p->nblk;
+    p->ntiles = 1;
+    p->pix_stride = 80;
+    p->upp_shift = 2;
+    p->lds_bytes = p->IH * p->IW * 80;
+    p->xcd_mode = 0;
+    p->q_ngroups = (int)ceil_div(p->npatch, 8);
+    p->grid = 8 * p->q_ngroups;
+    auto magic = [](int d) { return (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d); };
+    p->qm_npatch = magic(p->npatch);
+    p->qm_ntiles = magic(1);
+    p->qm_perimg = magic(p->npy * p->npx);
+    p->qm_npx = magic(p->npx);
+    if (convn_lds_bytes(t.NL - 1, a.Cin, a.Ntot) > 160 * 1024) return false;
+    *cost = 1e289;
+    return true;
+  }
   if (ipp < 1 || ph < 1 || pw < 1 || (int64_t)ipp * ph * pw > QP) return false;
   if (ipp > 1 && (ph != p->Hg || pw != p->Wg)) return false;
   if (t.Q && (ipp != 1 || ph != 8 * t.WM || pw != 12 || !convq_shape_ok(a))) return false;
@@ -1024,7 +1065,9 @@ static void for_each_candidate(const dfl_conv_args& a, const ConvP& base, int fo
     if ((tile_off >> ti) & 1u) continue;
     const TileCfg& t = kTiles[ti];
     const int bn = t.WN * t.TN * 32;
-    if (wide) {
+    if (t.NL) {
+      // (takes all the layer's columns itself)
+    } else if (wide) {
       if (bn > n32 || (bn < 64 && n32 >= 64) || (t.TN > 1 && bn > a.Ntot)) continue;
     } else {
       if (t.TN != 1 || t.GA || t.KS != 1) continue;   // the model was fitted on the one-column-tile, one-k-group configurations
@@ -1036,20 +1079,26 @@ static void for_each_candidate(const dfl_conv_args& a, const ConvP& base, int fo
     int shapes[24][3];
     int ns = 0;
     const int HW = base.Hg * base.Wg;
+    if (t.NL) {                                      // the layout's patch
+      if (!wide || !convn_shape_ok(a)) continue;
+      int nph, npw;
+      convn_patch(t.NL - 1, &nph, &npw);
+      shapes[ns][0] = 1; shapes[ns][1] = nph; shapes[ns][2] = npw; ++ns;
+    } else
     if (t.Q) {                                       // one patch shape
       if (!wide) continue;
       shapes[ns][0] = 1; shapes[ns][1] = 8 * t.WM; shapes[ns][2] = 12; ++ns;
     } else
-    if (HW <= QP) {                                  // whole images
+    if (!t.NL && HW <= QP) {                         // whole images
       shapes[ns][0] = QP / HW; shapes[ns][1] = base.Hg; shapes[ns][2] = base.Wg; ++ns;
     }
-    if (!t.Q && base.Wg <= QP) {                     // whole rows
+    if (!t.Q && !t.NL && base.Wg <= QP) {            // whole rows
       int ph = QP / base.Wg;
       if (ph > base.Hg) ph = base.Hg;
       shapes[ns][0] = 1; shapes[ns][1] = ph; shapes[ns][2] = base.Wg; ++ns;
     }
     static const int kPh[] = {1, 2, 4, 8, 16, 3, 6, 12};        // row pieces (the model looks at the powers of two)
-    for (int k = 0; k < (wide ? 8 : 5) && ns < 22 && !t.Q; ++k) {
+    for (int k = 0; k < (wide ? 8 : 5) && ns < 22 && !t.Q && !t.NL; ++k) {
       const int ph = kPh[k];
       int pw = QP / ph;
       if (pw >= base.Wg || ph > base.Hg) continue;
@@ -1317,7 +1366,8 @@ int convp_launch(const ConvP& p, hipStream_t s) {
     case 38: rc = convp_launch_t<4, 1, 2, 1, false, 2>(p, s); break;
     default:
       DFL_REQUIRE(p.tile >= CONVQ_TILE && p.tile < kNumTiles, "dfl_conv2d (bf16): tile configuration %d", p.tile);
-      rc = convq_launch(p, (p.tile - CONVQ_TILE) % CONVQ_LAYOUTS, (p.tile - CONVQ_TILE) / CONVQ_LAYOUTS, s);
+      if (p.tile >= CONVN_TILE) rc = convn_launch(p, p.tile - CONVN_TILE, s);
+      else rc = convq_launch(p, (p.tile - CONVQ_TILE) % CONVQ_LAYOUTS, (p.tile - CONVQ_TILE) / CONVQ_LAYOUTS, s);
       break;
   }
   if (rc != DFL_OK || p.splits <= 1) return rc;

@@ -29,6 +29,7 @@ def main():
     ap.add_argument('--rounds', type=int, default=3)
     ap.add_argument('--eval', action='store_true')
     ap.add_argument('--narrow', action='store_true', help='only the layers with fewer than 128 columns')
+    ap.add_argument('--convn', action='store_true', help='time the narrow 3x3 form (tiles 58 ... 63, csrc/convn_bf16.hip) instead of the unrolled one')
     args = ap.parse_args()
     lib = nat.lib()
     nat.check(lib.dfl_set_math_mode(4), 'mode')
@@ -104,7 +105,13 @@ def main():
         row = []
         best = t_lib
         lay = ((40, 1), (41, 1), (42, 2), (43, 2), (44, 4), (45, 2), (46, 4), (47, 8), (48, 4))
-        for tile, wm in lay + tuple((t + 9, w) for t, w in lay):
+        if args.convn:
+            for tile, (ph, pw) in {58: (8, 64), 59: (12, 64), 60: (16, 32), 61: (24, 32), 62: (6, 64), 63: (12, 32)}.items():
+                t = time_geom(st, (tile, 1, ph, pw, 1))
+                if t is not None:
+                    row.append('%d %.1f' % (tile, t))
+                    best = min(best, t)
+        for tile, wm in (() if args.convn else lay + tuple((t + 9, w) for t, w in lay)):
             for sp in (1, 2, 4, 8):
                 t = time_geom(st, (tile, 1, 8 * wm, 12, sp))
                 if t is not None:

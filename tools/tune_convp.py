@@ -35,23 +35,36 @@ def main():
     ap.add_argument('--size', type=int, default=192)
     ap.add_argument('--reps', type=int, default=10)
     ap.add_argument('--rounds', type=int, default=2)
-    ap.add_argument('--eval', action='store_true', help='also tune the inference program (eval-mode forward)')
+    ap.add_argument('--eval', action='store_true', help='tune the inference program (eval-mode forward) instead of the training step')
     ap.add_argument('--out', default=os.path.join(ROOT, 'deepfluorolabeling-ipcai2020_amd', 'tune', 'gfx950_convp.txt'))
     ap.add_argument('--append', action='store_true', help='keep the entries already in --out (other shapes)')
+    ap.add_argument('--narrow', action='store_true', help='only the 3x3 layers with 32 / 64 output columns (the shapes csrc/convn_bf16.hip takes); use with --append')
     args = ap.parse_args()
     lib = nat.lib()
     nat.check(lib.dfl_set_math_mode(4), 'mode')
     dev = torch.device('cuda:0')
     torch.manual_seed(1)
-    net = dfl_amd.UNet(**bench.PAPER).to(dev).train()
+    net = dfl_amd.UNet(**bench.PAPER).to(dev)
     x = torch.randn(args.batch, 1, args.size, args.size, device=dev)
-    seg, heat = net(x)
-    (seg.float().mean() + heat.float().mean()).backward()
-    torch.cuda.synchronize()
-    plan = [p for ps in net._plans.values() for p in ps if p.need_grad][0]
+    if args.eval:                                               # the inference program only (its operand forms differ from the training step's)
+        net.eval()
+        with torch.no_grad():
+            net(x)
+        torch.cuda.synchronize()
+        plan = [p for ps in net._plans.values() for p in ps][0]
+        structs = list(plan.fwd.structs)
+    else:
+        net.train()
+        seg, heat = net(x)
+        (seg.float().mean() + heat.float().mean()).backward()
+        torch.cuda.synchronize()
+        plan = [p for ps in net._plans.values() for p in ps if p.need_grad][0]
+        structs = list(plan.fwd.structs) + list(plan.bwd.structs)
     ops = OrderedDict()
-    for st in list(plan.fwd.structs) + list(plan.bwd.structs):
+    for st in structs:
         if isinstance(st, nat.ConvArgs) and st.x_bf16 and lib.dfl_conv_config(C.addressof(st)) >= 16:
+            if args.narrow and not (st.KH == 3 and st.stride == 1 and st.Ntot in (32, 64) and st.Cin % 32 == 0 and not st.scatter2x2):
+                continue
             ops.setdefault(key_of(st), []).append(st)
     stream = torch.cuda.current_stream().cuda_stream
     scratch = torch.empty(1 << 28, device=dev)                    # 1 GiB: K-slice partial sums
@@ -68,8 +81,14 @@ def main():
                 nat.check(lib.dfl_conv_force_geometry(C.addressof(g)), 'force')
                 a.splits = geom[4]
             try:
-                if lib.dfl_conv_config(C.addressof(a)) < 0:      # (a candidate of the group's first op may not exist for another operand form)
-                    return None
+                if lib.dfl_conv_config(C.addressof(a)) < 0:      # a candidate of the group's first op may not exist for another operand form:
+                    if geom is None:                             # the library then plans that op by the cost model, and so does this measurement
+                        return None
+                    lib.dfl_conv_force_geometry(None)
+                    a.splits = 0
+                    a.splits = nat.check(lib.dfl_conv_suggest_splits(C.addressof(a)), 'suggest')
+                    if lib.dfl_conv_config(C.addressof(a)) < 0:
+                        return None
                 M = a.N * (a.Hin * a.Win if a.scatter2x2 else a.Hout * a.Wout)
                 if a.splits > 1:
                     if a.splits * M * a.Ntot > scratch.numel():
