@@ -63,6 +63,17 @@ def test_candidates_list_the_narrow_form_where_it_applies():
     assert not any(g[0] >= 58 for g in T._candidates(2, 64, 64, 16, 16, 1, 1, 0))   # 3x3 / stride 1 / pad 1 only
 
 
+def test_the_two_tensor_operand_of_a_wide_layer_stays_with_the_patch_kernel():
+    """convn_shape_ok: 64 columns x several channel blocks x dfl_conv_args.x_mode is not a case of this form -- forcing it fails loudly,
+    the unforced call runs (convp)."""
+    case = (1, 64, 64, 20, 20)
+    dy, r, coef, dpre, w, ref, wp = _brb_problem(case, True)
+    with forced(62):
+        with pytest.raises(nat.DflError):
+            conv_bf16(dy, wp, 64, 3, 3, 1, 1, 20, 20, brb=(r, coef), force_splits=1)
+    close_bf16(conv_bf16(dy, wp, 64, 3, 3, 1, 1, 20, 20, brb=(r, coef)), ref, 'x_mode 64 -> 64, library choice')
+
+
 def _plain_problem(case):
     N, Cin, Cout, H, W = case
     g = torch.Generator().manual_seed(sum(case))
@@ -136,10 +147,11 @@ def _brb_problem(case, with_bn):
 
 @pytest.mark.parametrize('tile', TILES)
 @pytest.mark.parametrize('with_bn', [True, False])
-@pytest.mark.parametrize('case', [(2, 32, 64, 20, 20), (1, 64, 32, 40, 13), (3, 64, 64, 100, 70), (2, 32, 32, 192, 192)])
+@pytest.mark.parametrize('case', [(2, 32, 64, 20, 20), (1, 64, 32, 40, 13), (3, 64, 32, 100, 70), (2, 128, 32, 30, 45), (2, 32, 32, 192, 192)])
 def test_convn_fused_bn_relu_backward_operand(case, with_bn, tile):
     """dfl_conv_args.x_mode: the data gradient forms [r > 0] * (A dy + B r + C) from (dy, r) while it stages its patches; x_out is
-    that operand, every element exactly once, bit for bit."""
+    that operand, every element exactly once, bit for bit.  (Not taken by this form, csrc/convn_bf16.hip convn_shape_ok: the two-tensor
+    operand of a 64-column layer with several channel blocks.)"""
     N, Cin, Cout, H, W = case
     if not _valid(N, Cin, Cout, H, W, tile):
         pytest.skip('not a configuration of this layer')

@@ -262,11 +262,11 @@ def test_latency_form_is_a_hint():
     assert lib.dfl_conv_config(C.addressof(a)) == 16 + 39
     part = torch.zeros(4096, 2, 64, device=DEV)
     a.stat_partials = part.data_ptr()
-    assert lib.dfl_conv_config(C.addressof(a)) < 16 + 39          # statistics: the patch kernels
+    assert 16 <= lib.dfl_conv_config(C.addressof(a)) != 16 + 39   # statistics: the patch kernels (any of their tile configurations)
     a.stat_partials = None
     a.Hin = a.Win = a.Hout = a.Wout = 96
     a.N = 16
-    assert lib.dfl_conv_config(C.addressof(a)) < 16 + 39          # 10.9 GFLOP: a throughput problem
+    assert 16 <= lib.dfl_conv_config(C.addressof(a)) != 16 + 39   # 10.9 GFLOP: a throughput problem
 
 
 def test_inference_forward_with_and_without_the_latency_form():
