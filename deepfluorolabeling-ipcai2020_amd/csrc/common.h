@@ -20,6 +20,27 @@ inline int check_launch(const char* what) {
   return DFL_OK;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE setting of a kernel: asked for once per (kernel instantiation, device) and
+// its return code checked.  `done` = the instantiation's bit mask of devices served (a function-local static at the launch site).
+inline bool lds_opt_in(const void* fn, int bytes, unsigned long long* done, const char* what) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (__atomic_load_n(done, __ATOMIC_ACQUIRE) & bit) return true;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    set_error("%s: %d bytes of dynamic LDS refused on device %d: %s", what, bytes, dev, hipGetErrorString(e));
+    return false;
+  }
+  __atomic_fetch_or(done, bit, __ATOMIC_RELEASE);
+  return true;
+}
+#define DFL_LDS_OPT_IN(kernel, bytes, what)                                                                       \
+  {                                                                                                               \
+    static unsigned long long lds_done_ = 0;                                                                      \
+    if (!::dfl::lds_opt_in(reinterpret_cast<const void*>(kernel), (int)(bytes), &lds_done_, what)) return DFL_ERR_LAUNCH; \
+  }
+
 #define DFL_REQUIRE(cond, ...)              \
   do {                                      \
     if (!(cond)) {                          \

@@ -487,8 +487,7 @@ int convn_launch_t(const ConvP& p, int layout, hipStream_t s) {
 #define DFL_CN_LAUNCH(AFF_)                                                                                                   \
   {                                                                                                                             \
     auto k = convn_kernel<32, NCT, WX, R, AFF_, MB>;                                                                            \
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    (void)attr;                                                                                                                 \
+    DFL_LDS_OPT_IN(k, 160 * 1024, "dfl_conv2d (bf16, narrow 3x3)") \
     hipLaunchKernelGGL(k, grid, dim3(256), lds, s, pl);                                                                         \
   }
   if (p.a.x_mode != 0) DFL_CN_LAUNCH(2)

@@ -1299,23 +1299,20 @@ static int convp_launch_t(const ConvP& p, hipStream_t s) {
   lds = (size_t)pl.tab_off + (384 + 3 * BN_) * sizeof(float);
   const ConvP& p_ = pl;
   if constexpr (GA) {
-    static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(convp_kernel<WM, WN, TM, TN, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsHard);
-    (void)attr0;
-    hipLaunchKernelGGL((convp_kernel<WM, WN, TM, TN, 0, true>), grid, dim3(256), lds, s, p_);
+    auto k = convp_kernel<WM, WN, TM, TN, 0, true>;
+    DFL_LDS_OPT_IN(k, (int)kLdsHard, "dfl_conv2d (bf16)")
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, p_);
   } else if (p.a.x_mode != 0) {
     auto k = convp_kernel<WM, WN, TM, TN, 2, false, KS>;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsHard);
-    (void)attr;
+    DFL_LDS_OPT_IN(k, (int)kLdsHard, "dfl_conv2d (bf16)")
     hipLaunchKernelGGL(k, grid, dim3(NT_), lds, s, p_);
   } else if (aff) {
     auto k = convp_kernel<WM, WN, TM, TN, 1, false, KS>;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsHard);
-    (void)attr;                                      // (once per instantiation, not per launch)
+    DFL_LDS_OPT_IN(k, (int)kLdsHard, "dfl_conv2d (bf16)")
     hipLaunchKernelGGL(k, grid, dim3(NT_), lds, s, p_);
   } else {
     auto k = convp_kernel<WM, WN, TM, TN, 0, false, KS>;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsHard);
-    (void)attr;
+    DFL_LDS_OPT_IN(k, (int)kLdsHard, "dfl_conv2d (bf16)")
     hipLaunchKernelGGL(k, grid, dim3(NT_), lds, s, p_);
   }
   return check_launch("dfl_conv2d (bf16)");

@@ -551,8 +551,7 @@ int convq_launch_t(const ConvP& p, int mode, hipStream_t s) {
 #define DFL_CQ_LAUNCH(AFF_)                                                                                                   \
   {                                                                                                                             \
     auto k = convq_kernel<CK, WM, WN, KS, AFF_, PERS>;                                                                          \
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    (void)attr;                                                                                                                 \
+    DFL_LDS_OPT_IN(k, 160 * 1024, "dfl_conv2d (bf16, unrolled 3x3)") \
     hipLaunchKernelGGL(k, grid, dim3(NT), lds, s, pl);                                                                          \
   }
   if (p.a.x_mode != 0) {

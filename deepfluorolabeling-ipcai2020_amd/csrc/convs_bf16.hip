@@ -542,8 +542,7 @@ int convs_pair_launch(const dfl_conv_args* a, const dfl_conv_args* b, hipStream_
   const size_t lds = (size_t)(W * 2 * 16 * 64 + W * SCONST_PER_WAVE + 2 * a->Cin) * 4;
   if (W == 8) {
     auto k = convs_kernel<false, true, 8>;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    (void)attr;
+    DFL_LDS_OPT_IN(k, 96 * 1024, "dfl_conv2d (bf16, latency form)")
     hipLaunchKernelGGL(k, grid, dim3(512), lds, s, p, q);
   } else {
     hipLaunchKernelGGL((convs_kernel<false, true, 4>), grid, dim3(256), lds, s, p, q);

@@ -526,15 +526,14 @@ int convs32_suggest_splits(const dfl_conv_args* a) {
 }
 
 template <int MATH, bool PAIR>
-static void convs32_launch_t(const ConvS32& p, hipStream_t s) {
+static int convs32_launch_t(const ConvS32& p, hipStream_t s) {
   dim3 grid((unsigned)p.grid, (unsigned)p.splits);
   const size_t lds = (size_t)(p.waves * (PAIR ? 2 : 1) * 16 * 64 + p.waves * FCONST_PER_WAVE + 2 * p.a.Cin) * 4;
   const bool aff = p.a.in_scale != nullptr;
 #define DFL_CS32(AFF_, W_)                                                                                                         \
   {                                                                                                                                \
     auto k = convs32_kernel<MATH, AFF_, PAIR, W_>;                                                                                 \
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
-    (void)attr;                                                                                                                    \
+    DFL_LDS_OPT_IN(k, 96 * 1024, "dfl_conv2d (fp32, latency form)") \
     hipLaunchKernelGGL(k, grid, dim3(64 * W_), lds, s, p);                                                                         \
   }
   if (p.waves == 8) {
@@ -543,6 +542,7 @@ static void convs32_launch_t(const ConvS32& p, hipStream_t s) {
     if (aff) DFL_CS32(true, 4) else DFL_CS32(false, 4)
   }
 #undef DFL_CS32
+  return DFL_OK;
 }
 
 // The convolution itself; *splits_out = K slices the caller has to finish (conv_finish_kernel of conv_gemm.hip)
@@ -551,8 +551,8 @@ int convs32_launch(const dfl_conv_args* a, hipStream_t s, int* splits_out) {
   const bool ok = convs32_plan(a, &p, a->splits > 1 ? a->splits : 1);
   DFL_REQUIRE(ok, "dfl_conv2d (fp32 tensors, latency form): not eligible");
   DFL_REQUIRE(p.splits <= 1 || a->partial != nullptr, "dfl_conv2d: splits > 1 needs the partial buffer");
-  if (p.math == 0) convs32_launch_t<0, false>(p, s);
-  else convs32_launch_t<1, false>(p, s);
+  const int rc = p.math == 0 ? convs32_launch_t<0, false>(p, s) : convs32_launch_t<1, false>(p, s);
+  if (rc != DFL_OK) return rc;
   *splits_out = p.splits;
   return check_launch("dfl_conv2d (fp32 tensors, latency form)");
 }
@@ -600,8 +600,8 @@ int convs32_pair_launch(const dfl_conv_args* a, const dfl_conv_args* b, hipStrea
     p.x3_bytes = (uint32_t)((((int64_t)b->N * b->Hin * b->Win - 1) * b->ldx + b->Cin) * 4);
     p.w3_bytes = (uint32_t)((int64_t)(b->Cin / 4) * b->Ntot * 16);
   }
-  if (p.math == 0) convs32_launch_t<0, true>(p, s);
-  else convs32_launch_t<1, true>(p, s);
+  const int rc = p.math == 0 ? convs32_launch_t<0, true>(p, s) : convs32_launch_t<1, true>(p, s);
+  if (rc != DFL_OK) return rc;
   if (p.splits > 1) {
     const int rc = check_launch("dfl_conv2d_pair (fp32 tensors)");
     if (rc != DFL_OK) return rc;

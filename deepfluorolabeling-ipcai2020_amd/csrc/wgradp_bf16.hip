@@ -669,8 +669,7 @@ static int wgp_launch_t(const WgP& p_in, hipStream_t s) {
 #define DFL_WGP_LAUNCH(AFF_, DBRB_, BIAS_)                                                                                       \
   {                                                                                                                              \
     auto k = wgradp_kernel<KH, KW, AFF_, DBRB_, BIAS_>;                                                                          \
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
-    (void)attr;                                          /* (once per instantiation, not per launch) */                         \
+    DFL_LDS_OPT_IN(k, 150 * 1024, "dfl_conv2d_wgrad (bf16)") \
     hipLaunchKernelGGL(k, grid, dim3(256 * KH), lds, s, p);                                                                      \
   }
   const bool aff = p.a.in_scale != nullptr;
