@@ -71,7 +71,7 @@ CONVP_TILES = ['4,1,2,1', '4,1,1,1', '2,2,4,1', '2,2,3,1', '2,2,2,1', '1,4,2,1',
                'q1,4,1', 'q1,4,2', 'q2,4,1', 'q2,2,1', 'q4,2,1', 'q2,2,2', 'q4,1,1', 'q8,1,1', 'q4,1,2',
                'q1,4,1,p', 'q1,4,2,p', 'q2,4,1,p', 'q2,2,1,p', 'q4,2,1,p', 'q2,2,2,p', 'q4,1,1,p', 'q8,1,1,p', 'q4,1,2,p',
                # (58 ...: the narrow 3x3 form, csrc/convn_bf16.hip: waves side by side, rows per wave; named convn_kernel<column tiles, ...>)
-               'n2,4', 'n2,6', 'n1,4', 'n1,6', 'n2,3', 'n1,3']
+               'n2,4', 'n2,6', 'n1,4', 'n1,6', 'n2,3', 'n1,3', 'n2,3,p', 'n1,3,p']      # (64, 65: persistent)
 WGRAD_KERNELS = ['wgrad_kernel<2,2,2,2,1>', 'wgrad_kernel<2,2,1,1,1>', 'wgrad_kernel<1,1,1,1,3>',
                  'wgrad_kernel<1,1,1,1,2>', 'wgrad_kernel<1,1,1,1,1>', 'direct_wgrad_kernel', 'wgrad_kernel<2,2,1,1,3>']
 

@@ -58,8 +58,15 @@ constexpr int n_occ(int nct, int r, bool mb) { return (!mb || !DFL_CONVN_WL) && 
 // where the next block's units would have to sit beside 128 accumulator registers)
 constexpr bool n_inst(int nct, int r, bool mb) { return !(nct == 2 && (r > 4 || (mb && DFL_CONVN_WL != 0 && r >= 4))); }
 
-template <int CK, int NCT, int WX, int R, int AFF, bool MB>
-__global__ void __launch_bounds__(256, n_occ(NCT, R, MB)) convn_kernel(const ConvP p) {
+// PERS (layers of ONE channel block and 32 columns; rows per wave <= 3): the workgroup is PERSISTENT -- it walks patches pr, pr + q_stride,
+// ... of its XCD's run.  The layer's 18 KB of weights sit in LDS, so the k loop waits on LDS only and the NEXT patch's units, requested
+// before the loop, are in flight through it (vector memory returns in order: behind a register ring they would be waited for at the
+// first weight fragment); they are written into the image once every wave is through the current patch's fragments, and the epilogue
+// of the current patch runs behind that.  The statistics stay in registers over all patches of the workgroup and cross lanes and waves
+// once, at the end (rows of stat_partials: the workgroup's first patch carries its sum, its other patches zeros).
+template <int CK, int NCT, int WX, int R, int AFF, bool MB, bool PERS>
+__global__ void __launch_bounds__(256, PERS ? 2 : n_occ(NCT, R, MB)) convn_kernel(const ConvP p) {
+  static_assert(!PERS || (!MB && NCT == 1 && R <= 3), "the persistent form: one channel block, 32 columns, three rows per wave");
   constexpr int NT = 256, WY = 4 / WX, PW = 32 * WX, PH = R * WY, IW = PW + 2, IH = PH + 2;
   constexpr int S = 2 * CK + 16;               // bytes per staged pixel: an odd multiple of 16, so the 32 pixels of a fragment read hit 16 bank quads twice
   constexpr int RPB = IW * S;                  // row pitch of the image
@@ -83,13 +90,22 @@ __global__ void __launch_bounds__(256, n_occ(NCT, R, MB)) convn_kernel(const Con
   const int wx = wave % WX, wy = wave / WX;
 
   // ---- patch of this workgroup (an XCD = workgroups b = x mod 8 works through one eighth of the patches, in order)
-  const int pidx = ((int)blockIdx.x & 7) * p.q_ngroups + ((int)blockIdx.x >> 3);
-  if (pidx >= p.npatch || ((int)blockIdx.x >> 3) >= p.q_ngroups) return;
+  const int xcd_run = ((int)blockIdx.x & 7) * p.q_ngroups;
+  int prun = (int)blockIdx.x >> 3;                  // patch of the XCD's run (PERS: advances by q_stride)
+  if (xcd_run + prun >= p.npatch || prun >= p.q_ngroups) return;
   auto qdiv = [](int q, uint32_t m, int d) { return d == 1 ? q : (int)__umulhi((uint32_t)q, m); };
   const int per_img = p.npy * p.npx;
-  const int img = qdiv(pidx, p.qm_perimg, per_img), prem = pidx - img * per_img;
-  const int ppy = qdiv(prem, p.qm_npx, p.npx), ppx = prem - ppy * p.npx;
-  const int gy0 = ppy * PH, gx0 = ppx * PW;
+  // the patch being STAGED (PERS: one ahead of the patch the epilogue writes, o_* below)
+  int pidx, img, gy0, gx0;
+  auto patch_pos = [&](int pi) {
+    pidx = pi;
+    img = qdiv(pi, p.qm_perimg, per_img);
+    const int prem = pi - img * per_img;
+    const int ppy = qdiv(prem, p.qm_npx, p.npx), ppx = prem - ppy * p.npx;
+    gy0 = ppy * PH;
+    gx0 = ppx * PW;
+  };
+  patch_pos(xcd_run + prun);
   const int nblk = MB ? p.nblk : 1;                 // (MB false: the layer has 32 input channels)
 
   __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)p.x_bytes, 0x00020000);
@@ -110,7 +126,7 @@ __global__ void __launch_bounds__(256, n_occ(NCT, R, MB)) convn_kernel(const Con
   // MB (several channel blocks): a block's weights -- 9 CKC pieces of NCT KB, piece (tap, chunk) -- pass through LDS beside the
   // image instead: the k loop then waits on LDS only, and the NEXT block's image and weights, requested before the loop, are in
   // flight through it (vector memory returns in order: a wait for a weight fragment would be a wait for the image).
-  constexpr bool WL = MB && DFL_CONVN_WL != 0;
+  constexpr bool WL = (MB && DFL_CONVN_WL != 0) || PERS;
   constexpr int WRS = WL ? 2 : RING;
   nu32x4 wreg[WRS][3 * NCT];
   auto load_w = [&](const int gi, const uint32_t wb, const bool live) __attribute__((always_inline)) {
@@ -160,16 +176,21 @@ __global__ void __launch_bounds__(256, n_occ(NCT, R, MB)) convn_kernel(const Con
   const int px = (tid & (UR - 1)) / UPX;
   const int prow0 = __builtin_amdgcn_readfirstlane(tid / UR);          // (a wave stays inside one row: UR >= 64)
   static_assert(UR >= 64, "wave-uniform image rows");
-  const bool col_ok = gx0 + px < a.Win;
-  const uint32_t x_voff = col_ok ? (uint32_t)((gx0 + px) * a.ldx * 2 + cg * 16) : NOOB;
-  const uint32_t x2_voff = col_ok ? (uint32_t)((gx0 + px) * a.ldx2 * 2 + cg * 16) : NOOB;
-  const uint32_t xo_voff = col_ok ? (uint32_t)((gx0 + px) * a.ldxo * 2 + cg * 16) : NOOB;
   const uint32_t lds_i = (uint32_t)((px + 1) * S + cg * 16);
   const int hrow = tid / (2 * UPX), hside = (tid / UPX) & 1;
-  const int hgx = hside ? gx0 + PW : gx0 - 1, hgy = gy0 - 1 + hrow;
-  const bool h_ok = tid < NUH && (unsigned)hgx < (unsigned)a.Win && (unsigned)hgy < (unsigned)a.Hin;
-  const uint32_t hpix = ((uint32_t)img * (uint32_t)a.Hin + (uint32_t)hgy) * (uint32_t)a.Win + (uint32_t)hgx;
   const uint32_t lds_h = (uint32_t)(hrow * RPB + (hside ? (PW + 1) * S : 0) + cg * 16);
+  bool col_ok, h_ok;
+  uint32_t x_voff, x2_voff, xo_voff, hpix;
+  auto patch_lanes = [&]() {                        // this thread's offsets in the patch being staged
+    col_ok = gx0 + px < a.Win;
+    x_voff = col_ok ? (uint32_t)((gx0 + px) * a.ldx * 2 + cg * 16) : NOOB;
+    x2_voff = col_ok ? (uint32_t)((gx0 + px) * a.ldx2 * 2 + cg * 16) : NOOB;
+    xo_voff = col_ok ? (uint32_t)((gx0 + px) * a.ldxo * 2 + cg * 16) : NOOB;
+    const int hgx = hside ? gx0 + PW : gx0 - 1, hgy = gy0 - 1 + hrow;
+    h_ok = tid < NUH && (unsigned)hgx < (unsigned)a.Win && (unsigned)hgy < (unsigned)a.Hin;
+    hpix = ((uint32_t)img * (uint32_t)a.Hin + (uint32_t)hgy) * (uint32_t)a.Win + (uint32_t)hgx;
+  };
+  patch_lanes();
 
   float* in_tab = reinterpret_cast<float*>(smem + p.tab_off);        // [3][Cin]: scale, shift (AFF 1) / A, B, C (AFF 2)
   float* col_tab = in_tab + 3 * a.Cin;                               // [NB]: bias
@@ -215,7 +236,8 @@ __global__ void __launch_bounds__(256, n_occ(NCT, R, MB)) convn_kernel(const Con
   constexpr int UPR_ = AFF == 2 ? 8 : 4;                            // registers per unit
   constexpr int UGM = AFF == 2 ? 5 : DFL_CONVN_UGM;
   constexpr int UG = (UI + (UI + UGM - 1) / UGM - 1) / ((UI + UGM - 1) / UGM);
-  constexpr int P_AVAIL = (256 - (16 * R * NCT + 8 * (R + 2) + 24 * NCT + (WPRE ? 4 * WU : 0) + 44 + (AFF == 2 ? 24 : AFF == 1 ? 16 : 0))) / UPR_ - 1;   // (- 1: the halo unit)
+  constexpr int P_AVAIL = PERS ? (256 - (16 * R + 8 * (R + 2) + 24 + 44 + 32)) / UPR_ - 1      // (the statistics' 32 registers; weights and tables are read again)
+                               : (256 - (16 * R * NCT + 8 * (R + 2) + 24 * NCT + (WPRE ? 4 * WU : 0) + 44 + (AFF == 2 ? 24 : AFF == 1 ? 16 : 0))) / UPR_ - 1;   // (- 1: the halo unit)
   constexpr int UGP = !WL ? 0 : (P_AVAIL >= UI ? UI : (P_AVAIL > 0 ? P_AVAIL : 0));
   constexpr int UGX = UG > UGP ? UG : UGP;
   Unit ui[UGX], uh;
@@ -304,6 +326,15 @@ __global__ void __launch_bounds__(256, n_occ(NCT, R, MB)) convn_kernel(const Con
     for (int r = 0; r < R; ++r)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[ct][r][e] = 0.f;
+  float s1[NCT][16], s2[NCT][16];                   // statistics of this lane's 16 channels (PERS: over all patches of the workgroup)
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      s1[ct][e] = 0.f;
+      s2[ct][e] = 0.f;
+    }
+  const int first_pidx = pidx;
   bf16x8_t fr[2][R + 2];
   auto fetch_f = [&](const int gi) __attribute__((always_inline)) {
     const int c = gi / 3, dx = gi % 3;
@@ -311,10 +342,28 @@ __global__ void __launch_bounds__(256, n_occ(NCT, R, MB)) convn_kernel(const Con
     for (int rr = 0; rr < R + 2; ++rr)
       fr[gi % 2][rr] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const nu32x4*>(smem + f_addr + (uint32_t)(rr * RPB + dx * S + c * 32)));
   };
+  for (;;) {                                        // (PERS: the patches of this workgroup; else one pass)
+  const int o_pidx = pidx, o_img = img, o_gy0 = gy0, o_gx0 = gx0;     // the patch whose image is in LDS: the one the epilogue writes
+  bool has_next = false;
+  if constexpr (PERS) {
+    prun += p.q_stride;
+    has_next = prun < p.q_ngroups && xcd_run + prun < p.npatch;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[0][r][e] = 0.f;
+  }
   for (int blk = 0; blk < nblk; ++blk) {
     __syncthreads();                                // the image is complete
     const bool more = blk + 1 < nblk;
-    if constexpr (WL) {
+    if constexpr (PERS) {
+      if (has_next) {                               // the next patch: in flight through this patch's k loop
+        patch_pos(xcd_run + prun);
+        patch_lanes();
+        if constexpr (UGP > 0) stage_load(0, 0, UGP);
+      }
+      load_w(0, 0u, true);
+    } else if constexpr (WL) {
       if (more) {                                   // the next block: in flight through this block's k loop
         if constexpr (WPRE) wstage_load(blk + 1);
         if constexpr (UGP > 0) stage_load((blk + 1) * CK, 0, UGP);
@@ -353,25 +402,26 @@ __global__ void __launch_bounds__(256, n_occ(NCT, R, MB)) convn_kernel(const Con
       stage_rest((blk + 1) * CK, UGP > 0 ? UGP : UG);
     }
   }
+  if constexpr (PERS) {
+    __syncthreads();                                // every wave is through this patch's fragments
+    if (has_next) {
+      if constexpr (UGP == 0) stage_load(0, 0, UG);
+      load_tab(0);
+      stage_store(0, 0, UGP > 0 ? UGP : UG);
+      stage_rest(0, UGP > 0 ? UGP : UG);
+    }
+  }
 
   // ================================================================== epilogue on the registers
   // acc[ct][r][e]: pixel (gy0 + wy R + r, gx0 + wx 32 + li), channel ct 32 + (e / 4) 8 + lh 4 + e % 4
   const bool do_stats = a.stat_partials != nullptr || a.stat_totals != nullptr;
-  const int ogx = gx0 + wx * 32 + li;
+  const int ogx = o_gx0 + wx * 32 + li;
   const bool ocol_ok = ogx < p.Wg;
   const uint32_t y_voff = ocol_ok ? (uint32_t)(ogx * a.ldy * 2 + lh * 16) : NOOB;
   const uint32_t so_voff = (uint32_t)(ogx * a.ldso * 2 + lh * 8);
   const unsigned short* sop = reinterpret_cast<const unsigned short*>(a.stat_other);
   const float relu_floor = a.relu ? 0.f : -__builtin_inff();
-  const bool ragged = gx0 + PW > p.Wg;              // (workgroup-uniform)
-  float s1[NCT][16], s2[NCT][16];
-#pragma unroll
-  for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      s1[ct][e] = 0.f;
-      s2[ct][e] = 0.f;
-    }
+  const bool ragged = o_gx0 + PW > p.Wg;            // (workgroup-uniform)
 #pragma unroll
   for (int ct = 0; ct < NCT; ++ct) {
     float bias[16];
@@ -382,9 +432,9 @@ __global__ void __launch_bounds__(256, n_occ(NCT, R, MB)) convn_kernel(const Con
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int gy = gy0 + wy * R + r;
+      const int gy = o_gy0 + wy * R + r;
       if (gy >= p.Hg) continue;                     // (wave-uniform)
-      const uint32_t rowpix = ((uint32_t)img * (uint32_t)p.Hg + (uint32_t)gy) * (uint32_t)p.Wg;
+      const uint32_t rowpix = ((uint32_t)o_img * (uint32_t)p.Hg + (uint32_t)gy) * (uint32_t)p.Wg;
       uint32_t pk[8];                               // pk[g4 * 2 + h]: channels g4 8 + lh 4 + 2 h, + 1
 #pragma unroll
       for (int d = 0; d < 8; ++d) {
@@ -430,9 +480,16 @@ __global__ void __launch_bounds__(256, n_occ(NCT, R, MB)) convn_kernel(const Con
       }
     }
   }
+  if constexpr (PERS) {
+    if (has_next) {                                 // (a later patch of this workgroup: its row of stat_partials carries nothing)
+      if (a.stat_partials != nullptr && a.stat_totals == nullptr && o_pidx != first_pidx && tid < 2 * NB) a.stat_partials[(int64_t)o_pidx * 2 * a.Ntot + tid] = 0.f;
+      continue;
+    }
+    if (a.stat_partials != nullptr && a.stat_totals == nullptr && o_pidx != first_pidx && tid < 2 * NB) a.stat_partials[(int64_t)o_pidx * 2 * a.Ntot + tid] = 0.f;
+  }
   if (do_stats) {
-    // per-column sums of this patch: lanes and waves through LDS in a fixed order -> one row of stat_partials (rows = patches) or
-    // the layer's live totals
+    // per-column sums of this patch (PERS: of the workgroup's patches): lanes and waves through LDS in a fixed order -> one row of
+    // stat_partials (rows = patches) or the layer's live totals
     float* red = reinterpret_cast<float*>(smem);   // [wave][ct][e][lane]
 #pragma unroll
     for (int which = 0; which < 2; ++which) {
@@ -462,31 +519,33 @@ __global__ void __launch_bounds__(256, n_occ(NCT, R, MB)) convn_kernel(const Con
       if (n < a.Ntot) {
         const float4 t = *reinterpret_cast<const float4*>(red2 + idx * 4);
         const float sum = ((t.x + t.y) + t.z) + t.w;
-        if (a.stat_totals != nullptr) bn_live_add(a.stat_totals, pidx, which, a.Ntot, n, sum);
-        else a.stat_partials[((int64_t)pidx * 2 + which) * a.Ntot + n] = sum;
+        if (a.stat_totals != nullptr) bn_live_add(a.stat_totals, first_pidx, which, a.Ntot, n, sum);
+        else a.stat_partials[((int64_t)first_pidx * 2 + which) * a.Ntot + n] = sum;
       }
     }
+  }
+  break;
   }
 }
 
 // LDS: the image, (several channel blocks) a block's weights, the tables
-size_t n_tab_off(int layout, int cin, int ntot) {
+size_t n_tab_off(int layout, int cin, int ntot, int pers) {
   const NCfg c = kN[layout];
   const size_t img = (size_t)(c.R * (4 / c.WX) + 2) * (32 * c.WX + 2) * (2 * 32 + 16);
-  return (img + 15) / 16 * 16 + (cin > 32 && DFL_CONVN_WL != 0 ? (size_t)18 * 1024 * (ntot / 32) : 0);
+  return (img + 15) / 16 * 16 + ((cin > 32 && DFL_CONVN_WL != 0) || pers != 0 ? (size_t)18 * 1024 * (ntot / 32) : 0);
 }
 
-template <int NCT, int WX, int R, bool MB>
+template <int NCT, int WX, int R, bool MB, bool PERS>
 int convn_launch_t(const ConvP& p, int layout, hipStream_t s) {
   ConvP pl = p;
-  pl.tab_off = (int)n_tab_off(layout, p.a.Cin, p.a.Ntot);
-  const size_t lds = convn_lds_bytes(layout, p.a.Cin, p.a.Ntot);
+  pl.tab_off = (int)n_tab_off(layout, p.a.Cin, p.a.Ntot, PERS ? 1 : 0);
+  const size_t lds = convn_lds_bytes(layout, p.a.Cin, p.a.Ntot, PERS ? 1 : 0);
   DFL_REQUIRE(lds <= 160 * 1024, "dfl_conv2d (bf16, narrow 3x3): %zu bytes of LDS", lds);
   const bool aff = p.a.in_scale != nullptr || p.a.in_tot != nullptr;
   dim3 grid((unsigned)p.grid);
 #define DFL_CN_LAUNCH(AFF_)                                                                                                   \
   {                                                                                                                             \
-    auto k = convn_kernel<32, NCT, WX, R, AFF_, MB>;                                                                            \
+    auto k = convn_kernel<32, NCT, WX, R, AFF_, MB, PERS>;                                                                      \
     DFL_LDS_OPT_IN(k, 160 * 1024, "dfl_conv2d (bf16, narrow 3x3)") \
     hipLaunchKernelGGL(k, grid, dim3(256), lds, s, pl);                                                                         \
   }
@@ -498,12 +557,19 @@ int convn_launch_t(const ConvP& p, int layout, hipStream_t s) {
 }
 
 template <int WX, int R>
-int convn_launch_n(const ConvP& p, int layout, hipStream_t s) {
-  if (p.a.Ntot == 32) return p.nblk > 1 ? convn_launch_t<1, WX, R, true>(p, layout, s) : convn_launch_t<1, WX, R, false>(p, layout, s);
+int convn_launch_n(const ConvP& p, int layout, int pers, hipStream_t s) {
+  if (pers != 0) {
+    if constexpr (R <= 3) {
+      if (p.a.Ntot == 32 && p.nblk == 1) return convn_launch_t<1, WX, R, false, true>(p, layout, s);
+    }
+    set_error("dfl_conv2d (bf16, narrow 3x3): the persistent form of layout %d takes 32 -> 32 layers", layout);
+    return DFL_ERR_INVALID_ARG;
+  }
+  if (p.a.Ntot == 32) return p.nblk > 1 ? convn_launch_t<1, WX, R, true, false>(p, layout, s) : convn_launch_t<1, WX, R, false, false>(p, layout, s);
   if (p.nblk > 1) {
-    if constexpr (n_inst(2, R, true)) return convn_launch_t<2, WX, R, true>(p, layout, s);
+    if constexpr (n_inst(2, R, true)) return convn_launch_t<2, WX, R, true, false>(p, layout, s);
   } else {
-    if constexpr (n_inst(2, R, false)) return convn_launch_t<2, WX, R, false>(p, layout, s);
+    if constexpr (n_inst(2, R, false)) return convn_launch_t<2, WX, R, false, false>(p, layout, s);
   }
   set_error("dfl_conv2d (bf16, narrow 3x3): layout %d is not built for 64 columns and %d input channels", layout, p.a.Cin);
   return DFL_ERR_INVALID_ARG;
@@ -527,22 +593,24 @@ void convn_patch(int layout, int* ph, int* pw) {
   *pw = 32 * kN[layout].WX;
 }
 
-size_t convn_lds_bytes(int layout, int cin, int ntot) {
-  size_t img = n_tab_off(layout, cin, ntot);
+bool convn_pers_ok(int layout, const dfl_conv_args& a) { return layout >= 0 && layout < CONVN_LAYOUTS && kN[layout].R <= 3 && a.Cin == 32 && a.Ntot == 32; }
+
+size_t convn_lds_bytes(int layout, int cin, int ntot, int pers) {
+  size_t img = n_tab_off(layout, cin, ntot, pers);
   const size_t red = (size_t)4 * (ntot / 32) * 16 * 64 * sizeof(float);      // the statistics' pass through LDS
   if (img < red) img = red;
   return img + (size_t)(3 * cin + ntot + 2 * ntot * 4) * sizeof(float);
 }
 
-int convn_launch(const ConvP& p, int layout, hipStream_t s) {
+int convn_launch(const ConvP& p, int layout, int pers, hipStream_t s) {
   DFL_REQUIRE(layout >= 0 && layout < CONVN_LAYOUTS && p.CK == 32 && p.splits == 1, "dfl_conv2d (bf16, narrow 3x3): layout %d, %d resident channels, %d K slices", layout, p.CK, p.splits);
   switch (layout) {
-    case 0: return convn_launch_n<2, 4>(p, layout, s);
-    case 1: return convn_launch_n<2, 6>(p, layout, s);
-    case 2: return convn_launch_n<1, 4>(p, layout, s);
-    case 3: return convn_launch_n<1, 6>(p, layout, s);
-    case 4: return convn_launch_n<2, 3>(p, layout, s);
-    default: return convn_launch_n<1, 3>(p, layout, s);
+    case 0: return convn_launch_n<2, 4>(p, layout, pers, s);
+    case 1: return convn_launch_n<2, 6>(p, layout, pers, s);
+    case 2: return convn_launch_n<1, 4>(p, layout, pers, s);
+    case 3: return convn_launch_n<1, 6>(p, layout, pers, s);
+    case 4: return convn_launch_n<2, 3>(p, layout, pers, s);
+    default: return convn_launch_n<1, 3>(p, layout, pers, s);
   }
 }
 

@@ -27,13 +27,15 @@ struct ConvP {
   // unrolled 3x3 form (convq_bf16.hip; tile >= CONVQ_TILE): ceil(2^32 / d) for d = npatch, ntiles, patches per image, npx
   // (narrow form, convn_bf16.hip, tile >= CONVN_TILE: qm_perimg, qm_npx; q_ngroups = patches per XCD)
   uint32_t qm_npatch, qm_ntiles, qm_perimg, qm_npx;
-  int q_ngroups, pad2;          // persistent form: workgroups per (column tile, K slice); qm_npatch is then the magic of q_ngroups
+  int q_ngroups, q_stride;      // persistent form: workgroups per (column tile, K slice); qm_npatch is then the magic of q_ngroups
+                                // (narrow form: patches per XCD; its persistent form: workgroups per XCD = the stride of a workgroup's patches)
 };
 constexpr int CONVS_TILE = 39;  // value of ConvP.tile for the latency form (= number of convp tile configurations)
 constexpr int CONVQ_TILE = 40;  // ... and for the unrolled 3x3 form of convq_bf16.hip: 40 ... 48 = its nine wave layouts (kQ there), 49 ... 57 = the same, persistent
 constexpr int CONVQ_LAYOUTS = 9;
 constexpr int CONVN_TILE = 58;  // ... and for the narrow 3x3 form of convn_bf16.hip (32 / 64 output columns): 58 ... 63 = its six layouts (kN there)
 constexpr int CONVN_LAYOUTS = 6;
+constexpr int CONVN_PERS_TILE = 64;  // 64, 65: the persistent form of its layouts 4 and 5 (three rows per wave), 32 -> 32 layers
 
 // Chooses the geometry for these arguments.  force_splits: 0 = free choice, else the K-slice count to plan for.
 int convp_plan(const dfl_conv_args* a, ConvP* p, int force_splits);
@@ -55,8 +57,9 @@ bool convq_ck_ok(int mode, int ck);                               // is configur
 bool convn_shape_ok(const dfl_conv_args& a);
 bool convn_layout_ok(int layout, int ntot, int cin);              // is the layout built for this column count / one or several channel blocks?
 void convn_patch(int layout, int* ph, int* pw);                   // the layout's patch (rows, pixels per row)
-size_t convn_lds_bytes(int layout, int cin, int ntot);
-int convn_launch(const ConvP& p, int layout, hipStream_t s);
+size_t convn_lds_bytes(int layout, int cin, int ntot, int pers);
+bool convn_pers_ok(int layout, const dfl_conv_args& a);            // is the persistent form built for this layout / layer?
+int convn_launch(const ConvP& p, int layout, int pers, hipStream_t s);
 
 // Latency form for the small problems of a batch-1 inference forward (convs_bf16.hip)
 bool convs_eligible(const dfl_conv_args& a, const ConvP& p);

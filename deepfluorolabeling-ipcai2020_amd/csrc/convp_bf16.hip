@@ -823,9 +823,11 @@ static const TileCfg kTiles[] = {{4, 1, 2, 1, 0, 1}, {4, 1, 1, 1, 0, 1}, {2, 2, 
                                  {2, 2, 3, 1, 0, 2, 1, 1}, {4, 1, 3, 1, 0, 1, 1, 1}, {8, 1, 3, 1, 0, 1, 1, 1}, {4, 1, 3, 1, 0, 2, 1, 1},
                                  // 58-63: the narrow 3x3 form (convn_bf16.hip: 32 / 64 output columns, its six layouts); table only
                                  {4, 1, 1, 1, 0, 1, 0, 0, 1}, {4, 1, 1, 1, 0, 1, 0, 0, 2}, {4, 1, 1, 1, 0, 1, 0, 0, 3}, {4, 1, 1, 1, 0, 1, 0, 0, 4},
-                                 {4, 1, 1, 1, 0, 1, 0, 0, 5}, {4, 1, 1, 1, 0, 1, 0, 0, 6}};
+                                 {4, 1, 1, 1, 0, 1, 0, 0, 5}, {4, 1, 1, 1, 0, 1, 0, 0, 6},
+                                 // 64, 65: its persistent form (layouts 4 and 5; 32 -> 32 layers)
+                                 {4, 1, 1, 1, 0, 1, 0, 1, 5}, {4, 1, 1, 1, 0, 1, 0, 1, 6}};
 constexpr int kNumTiles = (int)(sizeof(kTiles) / sizeof(kTiles[0]));
-static_assert(kNumTiles == CONVN_TILE + CONVN_LAYOUTS && CONVN_TILE == CONVQ_TILE + 2 * CONVQ_LAYOUTS && CONVQ_TILE == CONVS_TILE + 1, "convp.h: CONVS_TILE is the index behind the patch-kernel configurations, the unrolled 3x3 forms follow it");
+static_assert(kNumTiles == CONVN_PERS_TILE + 2 && CONVN_PERS_TILE == CONVN_TILE + CONVN_LAYOUTS && CONVN_TILE == CONVQ_TILE + 2 * CONVQ_LAYOUTS && CONVQ_TILE == CONVS_TILE + 1, "convp.h: CONVS_TILE is the index behind the patch-kernel configurations, the unrolled 3x3 forms follow it");
 constexpr size_t kLdsSoft = 64 * 1024, kLdsHard = 150 * 1024;
 
 // Row blocks of convp_finish_kernel = rows of stat_partials the following finalize kernel has to read.  Few (<= FIN_ROWS) and
@@ -875,13 +877,19 @@ static bool try_geometry(const dfl_conv_args& a, ConvP* p, const TileCfg& t, int
     p->lds_bytes = p->IH * p->IW * 80;
     p->xcd_mode = 0;
     p->q_ngroups = (int)ceil_div(p->npatch, 8);
+    p->q_stride = p->q_ngroups;
     p->grid = 8 * p->q_ngroups;
+    if (t.P) {                                         // persistent: two workgroups per CU (64 per XCD), each walks several patches of its XCD's run
+      if (!convn_pers_ok(t.NL - 1, a) || p->q_ngroups <= 64) return false;
+      p->q_stride = 64;
+      p->grid = 8 * 64;
+    }
     auto magic = [](int d) { return (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d); };
     p->qm_npatch = magic(p->npatch);
     p->qm_ntiles = magic(1);
     p->qm_perimg = magic(p->npy * p->npx);
     p->qm_npx = magic(p->npx);
-    if (convn_lds_bytes(t.NL - 1, a.Cin, a.Ntot) > 160 * 1024) return false;
+    if (convn_lds_bytes(t.NL - 1, a.Cin, a.Ntot, t.P) > 160 * 1024) return false;
     *cost = 1e289;
     return true;
   }
@@ -1363,7 +1371,8 @@ int convp_launch(const ConvP& p, hipStream_t s) {
     case 38: rc = convp_launch_t<4, 1, 2, 1, false, 2>(p, s); break;
     default:
       DFL_REQUIRE(p.tile >= CONVQ_TILE && p.tile < kNumTiles, "dfl_conv2d (bf16): tile configuration %d", p.tile);
-      if (p.tile >= CONVN_TILE) rc = convn_launch(p, p.tile - CONVN_TILE, s);
+      if (p.tile >= CONVN_PERS_TILE) rc = convn_launch(p, p.tile - CONVN_PERS_TILE + 4, 1, s);
+      else if (p.tile >= CONVN_TILE) rc = convn_launch(p, p.tile - CONVN_TILE, 0, s);
       else rc = convq_launch(p, (p.tile - CONVQ_TILE) % CONVQ_LAYOUTS, (p.tile - CONVQ_TILE) / CONVQ_LAYOUTS, s);
       break;
   }

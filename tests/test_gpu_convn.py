@@ -18,7 +18,8 @@ from test_gpu_bf16 import rb, nhwc, pack16, conv_bf16, brb_reference, _mode4  # 
 from test_gpu_convq import close_bf16
 
 pytestmark = pytest.mark.gpu
-NPATCH = {58: (8, 64), 59: (12, 64), 60: (16, 32), 61: (24, 32), 62: (6, 64), 63: (12, 32)}    # csrc/convn_bf16.hip kN: rows x pixels
+NPATCH = {58: (8, 64), 59: (12, 64), 60: (16, 32), 61: (24, 32), 62: (6, 64), 63: (12, 32),    # csrc/convn_bf16.hip kN: rows x pixels
+          64: (6, 64), 65: (12, 32)}                                                          # ... and the persistent form of the last two (32 -> 32 layers with more than 512 patches)
 TILES = tuple(NPATCH)
 
 
@@ -55,7 +56,8 @@ def _memo(key, make):
 
 
 def test_candidates_list_the_narrow_form_where_it_applies():
-    assert all(_valid(2, 32, 32, 40, 25, t) for t in TILES)
+    assert all(_valid(2, 32, 32, 40, 25, t) for t in TILES[:6]) and not _valid(2, 32, 32, 40, 25, 64)     # (persistent: only when a workgroup gets several patches)
+    assert _valid(9, 32, 32, 190, 180, 64) and _valid(9, 32, 32, 190, 180, 65) and not _valid(9, 64, 32, 190, 180, 64) and not _valid(9, 32, 64, 190, 180, 65)
     assert all(_valid(2, 32, 64, 40, 25, t) for t in (58, 60, 62, 63)) and not _valid(2, 32, 64, 40, 25, 59) and not _valid(2, 32, 64, 40, 25, 61)
     assert all(_valid(2, 64, 64, 40, 25, t) for t in (58, 60, 62, 63)) and not _valid(2, 64, 64, 40, 25, 59) and not _valid(2, 64, 64, 40, 25, 61)   # (64 columns: at most four rows per wave)
     assert not any(_valid(2, 64, 128, 24, 24, t) for t in TILES)               # 32 or 64 output columns
@@ -147,7 +149,7 @@ def _brb_problem(case, with_bn):
 
 @pytest.mark.parametrize('tile', TILES)
 @pytest.mark.parametrize('with_bn', [True, False])
-@pytest.mark.parametrize('case', [(2, 32, 64, 20, 20), (1, 64, 32, 40, 13), (3, 64, 32, 100, 70), (2, 128, 32, 30, 45), (2, 32, 32, 192, 192)])
+@pytest.mark.parametrize('case', [(2, 32, 64, 20, 20), (1, 64, 32, 40, 13), (3, 64, 32, 100, 70), (2, 128, 32, 30, 45), (2, 32, 32, 192, 192), (9, 32, 32, 190, 180)])
 def test_convn_fused_bn_relu_backward_operand(case, with_bn, tile):
     """dfl_conv_args.x_mode: the data gradient forms [r > 0] * (A dy + B r + C) from (dy, r) while it stages its patches; x_out is
     that operand, every element exactly once, bit for bit.  (Not taken by this form, csrc/convn_bf16.hip convn_shape_ok: the two-tensor
@@ -188,3 +190,21 @@ def test_convn_is_bit_repeatable_and_agrees_with_the_patch_kernel():
         assert float((d > 0).double().mean()) < 2e-2                             # sums on the other side of a rounding boundary
         ran += 1
     assert ran == 6
+
+
+def test_convn_persistent_form_is_bit_repeatable_and_fills_every_statistics_row():
+    """The persistent form (tiles 64, 65): two launches give the same bits; its statistics rows (one per patch: the workgroup's first patch
+    carries the sum, its other patches zeros) add up to the sums of the stored values even when the buffer held garbage before."""
+    N, Cin, Cout, H, W = 9, 32, 32, 190, 180
+    g = torch.Generator().manual_seed(13)
+    x = rb(torch.randn(N, Cin, H, W, generator=g))
+    w = rb(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)
+    wp = pack16(w, 1)
+    for tile in (64, 65):
+        assert _valid(N, Cin, Cout, H, W, tile)
+        with forced(tile):
+            y1, s1 = conv_bf16(x, wp, Cout, 3, 3, 1, 1, H, W, force_splits=1, stats=True)
+            y2, s2 = conv_bf16(x, wp, Cout, 3, 3, 1, 1, H, W, force_splits=1, stats=True, stats_fill=float('nan'))
+        assert torch.equal(y1, y2) and torch.equal(s1, s2)
+        yd = y1.double().reshape(-1, Cout)
+        np.testing.assert_allclose(s1[0].numpy(), yd.sum(0).numpy(), rtol=2e-5, atol=2e-5 * float(yd.abs().sum(0).max()))

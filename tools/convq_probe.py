@@ -106,7 +106,7 @@ def main():
         best = t_lib
         lay = ((40, 1), (41, 1), (42, 2), (43, 2), (44, 4), (45, 2), (46, 4), (47, 8), (48, 4))
         if args.convn:
-            for tile, (ph, pw) in {58: (8, 64), 59: (12, 64), 60: (16, 32), 61: (24, 32), 62: (6, 64), 63: (12, 32)}.items():
+            for tile, (ph, pw) in {58: (8, 64), 59: (12, 64), 60: (16, 32), 61: (24, 32), 62: (6, 64), 63: (12, 32), 64: (6, 64), 65: (12, 32)}.items():
                 t = time_geom(st, (tile, 1, ph, pw, 1))
                 if t is not None:
                     row.append('%d %.1f' % (tile, t))

@@ -28,8 +28,8 @@ def short(name):
     tail = ',k2' if (m.group(1) == 'convp_kernel' and len(args) >= 7 and args[6] == '2') else ''     # two k-groups (512 threads)
     if m.group(1) == 'convq_kernel':          # (anonymous namespace: the demangled name may carry it) -> the wave layout (+ ',p' persistent), as bench.py names it
         return 'convq_kernel<%s%s>' % (','.join(args[1:4]), ',p' if len(args) > 5 and args[5] != '0' else '')     # <CK, WM, WN, KS, AFF, PERS>
-    if m.group(1) == 'convn_kernel':          # <CK, NCT, WX, R, AFF, MB> -> column tiles, waves side by side, rows per wave
-        return 'convn_kernel<%s>' % ','.join(args[1:4])
+    if m.group(1) == 'convn_kernel':          # <CK, NCT, WX, R, AFF, MB, PERS> -> column tiles, waves side by side, rows per wave
+        return 'convn_kernel<%s%s>' % (','.join(args[1:4]), ',p' if len(args) > 6 and args[6] in ('true', '1') else '')
     return '%s<%s%s>' % (m.group(1), ','.join(args[:keep]), tail)
 
 
