@@ -14,6 +14,21 @@ def _oracle_threads():
     torch.set_num_threads(max(torch.get_num_threads(), min(64, os.cpu_count() or 32)))
 
 
+def _describe_stored_activations(net):
+    """Diagnosis of the event described in paper_gradient: what the plan's stored ReLU outputs look like right now, and again behind a
+    device synchronisation."""
+    import torch
+    plan = NF.train_plan(net)
+    for again in (False, True):
+        if again:
+            torch.cuda.synchronize()
+        for k, a in plan.relu_out.items():
+            t = plan.act_nchw(a)
+            print('stored activations%s: %-28s %s ld %d  > 0: %.4f  == 0: %.4f  finite: %.4f  min %.3e max %.3e  ptr %#x' % (
+                ' (after synchronize)' if again else '', k, tuple(t.shape), a.ld, float((t > 0).float().mean()), float((t == 0).float().mean()),
+                float(torch.isfinite(t).float().mean()), float(t.min()), float(t.max()), a.ptr), flush=True)
+
+
 def paper_gradient(mode, batch):
     """BASELINE configs[1] itself (batch 16): the paper preset with both heads at batch 16 (the step bench.py times), in the two parity
     modes and in the bf16 STORAGE mode the headline is quoted in.  fp32 / bf16x3: forward inside 1e-4, labels bit-exact
@@ -35,6 +50,7 @@ def paper_gradient(mode, batch):
                 import warnings
                 warnings.warn('batch %d bf16s: %d of %d ReLU decisions read back different from the oracle after a pass with a correct '
                               'forward output; repeating the pass once' % (batch, res['info']['relu_flips'], res['info']['relu_total']))
+                _describe_stored_activations(net)
                 net = hip_net(pr)
                 out, seg, loss = hip_step(pr, net)
                 res = dict(gc.whole_error(net, seg), eps_eff=NF.conv_rel_error(mode), worst=float('nan'))
