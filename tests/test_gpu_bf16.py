@@ -90,7 +90,7 @@ def test_pack_bf16_chunk_layout():
 
 def conv_bf16(x, wp, Ntot, KH, KW, stride, pad, Hout, Wout, bias=None, in_aff=None, relu=0, add=None, add_aff=None,
               y_init=None, accumulate=0, scatter=0, stats=False, stat_other=None, ldy=None, ldx_pad=0, force_splits=None, brb=None, x_out=False,
-              latency=False, stats_fill=0.0):
+              latency=False, stats_fill=0.0, live_totals=False):
     """x: NCHW fp32 cpu tensor (bf16-representable) -> dfl_conv2d with bf16 tensors -> y NHWC fp32 cpu tensor (+ stats).
     x_out (with brb): also returns the operand tensor the kernel wrote (dfl_conv_args.x_out; NHWC with 8 channels of padding)."""
     lib = nat.lib()
@@ -156,7 +156,11 @@ def conv_bf16(x, wp, Ntot, KH, KW, stride, pad, Hout, Wout, bias=None, in_aff=No
     if stats:
         gm = nat.check(lib.dfl_conv_grid_m(C.addressof(a)), 'grid_m')
         part = torch.full((4 * gm, 2, Cout), stats_fill, device=DEV) if scatter else torch.full((gm, 2, Ntot), stats_fill, device=DEV)   # (every row is written by the kernel)
-        a.stat_partials = part.data_ptr()
+        if live_totals:                                  # dfl_conv_args.stat_totals: [DFL_BN_R = 8][2][Ntot] doubles the workgroups add their sums to (fp64 atomics)
+            part = torch.zeros(8, 2, Ntot, device=DEV, dtype=torch.float64)
+            a.stat_totals = part.data_ptr()
+        else:
+            a.stat_partials = part.data_ptr()
         if stat_other is not None:
             so = nhwc(stat_other).to(DEV).to(BF).contiguous()
             keep.append(so)

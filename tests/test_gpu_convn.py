@@ -192,6 +192,24 @@ def test_convn_is_bit_repeatable_and_agrees_with_the_patch_kernel():
     assert ran == 6
 
 
+@pytest.mark.parametrize('tile', TILES)
+def test_convn_live_totals(tile):
+    """dfl_conv_args.stat_totals -- the form the bf16 storage training step uses: workgroups add their column sums to [8][2][Ntot] doubles
+    with fp64 atomics -- against the sums of the stored values, with a partner tensor, on a layer large enough for the persistent tiles."""
+    case = (9, 32, 32, 190, 180)
+    N, Cin, Cout, H, W = case
+    if not _valid(N, Cin, Cout, H, W, tile):
+        pytest.skip('not a configuration of this layer')
+    x, w, b, sc, sh, partner, ref, wp = _memo(('aff',) + case, lambda: _affine_problem(case))
+    with forced(tile):
+        y, st = conv_bf16(x, wp, Cout, 3, 3, 1, 1, H, W, bias=b, in_aff=(sc, sh), stats=True, stat_other=partner, force_splits=1, live_totals=True)
+    close_bf16(y, ref, '%s tile %d' % (case, tile))
+    yd = y.double().reshape(-1, Cout)
+    pd = nhwc(partner).double().reshape(-1, Cout)
+    np.testing.assert_allclose(st[0].numpy(), yd.sum(0).numpy(), rtol=2e-5, atol=2e-5 * float(yd.abs().sum(0).max()))
+    np.testing.assert_allclose(st[1].numpy(), (yd * pd).sum(0).numpy(), rtol=2e-5, atol=2e-5 * float((yd * pd).abs().sum(0).max()))
+
+
 def test_convn_persistent_form_is_bit_repeatable_and_fills_every_statistics_row():
     """The persistent form (tiles 64, 65): two launches give the same bits; its statistics rows (one per patch: the workgroup's first patch
     carries the sum, its other patches zeros) add up to the sums of the stored values even when the buffer held garbage before."""
