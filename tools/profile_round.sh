@@ -45,4 +45,6 @@ cp "$(find "$out/trace" -name '*kernel_stats.csv' | head -1)" "$out/${tag}_rocpr
 find "$out" -name '*kernel_trace.csv' -delete 2>/dev/null || true
 find "$out" -name '*counter_collection.csv' -delete 2>/dev/null || true
 find "$out" -name '*.db' -delete 2>/dev/null || true
+# 6. HBM counters of the other BASELINE shapes (separate passes again)
+bash tools/profile_other_pmc.sh "$tag" > "$out/other_pmc.log" 2>&1 || true
 du -sh "$out" || true
